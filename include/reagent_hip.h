@@ -1,0 +1,165 @@
+/* reagent_hip.h — C ABI of libreagent_hip.so: the MI355X (gfx950) batch-RL training-step kernels.
+ *
+ * ReAgent (the reference) has no FFI on this path: every op is an eager torch call made from
+ * Python.  This header therefore DEFINES the boundary; each entry point names the reference
+ * code it replaces (paths relative to the ReAgent tree) so a maintainer can bind it from the
+ * reference side with ctypes.
+ *
+ * Conventions
+ *  - plain device pointers + sizes, no torch types; all matrices row-major, leading dimensions in
+ *    ELEMENTS; every pointer is device memory unless the comment says host.
+ *  - caller owns all memory (PyTorch caching allocator); nothing is allocated or freed here.
+ *  - work is enqueued on `stream` only; no entry point synchronises.
+ *  - return 0 on success, negative RG_E* for argument errors detected on the host before any
+ *    launch, positive = hipError_t of a failed launch.  Never throws, never exits.
+ *  - `precision`: RG_PREC_F32 = fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32, parity mode);
+ *    RG_PREC_BF16 = bf16 operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The
+ *    element type of every `void*` activation/weight operand is float resp. bf16 accordingly.
+ */
+#ifndef REAGENT_HIP_H_
+#define REAGENT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rg_stream_t; /* hipStream_t */
+
+enum { RG_OK = 0, RG_EINVAL = -1, RG_EALIGN = -2, RG_EUNSUPPORTED = -3, RG_EWORKSPACE = -4 };
+enum { RG_PREC_F32 = 0, RG_PREC_BF16 = 1 };
+enum { RG_DT_F32 = 0, RG_DT_BF16 = 1 };
+enum {
+  RG_ACT_LINEAR = 0, RG_ACT_RELU = 1, RG_ACT_LEAKY_RELU = 2, RG_ACT_TANH = 3, RG_ACT_SIGMOID = 4,
+  RG_ACT_SOFTPLUS = 5 /* reagent/models/fully_connected_network.py:37-44 ACTIVATION_MAP */
+};
+enum { RG_LOSS_MSE = 0, RG_LOSS_HUBER = 1 }; /* reagent/training/dqn_trainer_base.py:146-155 */
+
+const char* rg_strerror(int code);
+int rg_abi_version(void);
+
+/* ---- FullyConnected layer ops ------------------------------------------------------------ */
+
+/* y = act(x · w^T + bias).  Replaces nn.Linear + activation,
+ * reagent/models/fully_connected_network.py:101-153.
+ * x [batch, in] (ldx), w [out, in] (ldw, nn.Linear layout), bias [out] fp32 or NULL.
+ * Outputs (each nullable): y [batch, out] compute type; y32 [batch, out] fp32 (both use ldy);
+ * yt [out, batch] (ldyt) transposed copy in compute type (input of rg_fc_wgrad / mask of
+ * rg_fc_dgrad). */
+int rg_fc_forward(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                  void* y, float* y32, int64_t ldy, void* yt, int64_t ldyt, int batch,
+                  int out_features, int in_features, int act, int precision, rg_stream_t stream);
+
+/* dx = (dz · w) ⊙ act'(h_below).  Replaces autograd's AddmmBackward (input grad) +
+ * Relu/Tanh/...Backward of the layer below.
+ * dz [batch, out] (lddz); wt = w^T [in, out] (ldwt); ht = saved transposed output of the layer
+ * below [in, batch] (ldht) or NULL when that "layer" is the network input / linear.
+ * Outputs (nullable): dx [batch, in] compute type, dx32 fp32 (lddx), dxt [in, batch] (lddxt). */
+int rg_fc_dgrad(const void* dz, int64_t lddz, const void* wt, int64_t ldwt, const void* ht,
+                int64_t ldht, int act_below, void* dx, float* dx32, int64_t lddx, void* dxt,
+                int64_t lddxt, int batch, int in_features, int out_features, int precision,
+                rg_stream_t stream);
+
+/* dw [out, in] (contiguous fp32) = dz^T · x ; db [out] = column sums of dz (nullable).
+ * Replaces autograd's AddmmBackward (weight + bias grads).  Inputs are the TRANSPOSED
+ * copies: dzt [out, batch] (lddzt), xt [in, batch] (ldxt).  Deterministic: fixed split of
+ * the batch axis, partial slabs in `workspace`, ordered second-stage sum. */
+size_t rg_fc_wgrad_workspace_bytes(int out_features, int in_features, int batch, int precision);
+int rg_fc_wgrad(const void* dzt, int64_t lddzt, const void* xt, int64_t ldxt, float* dw, float* db,
+                void* workspace, size_t workspace_bytes, int out_features, int in_features,
+                int batch, int precision, rg_stream_t stream);
+
+/* src [rows, cols] (ld_src, dtype src_dt) -> dst [rows, cols] (ld_dst) and/or
+ * dst_t [cols, rows] (ld_t), both of dtype dst_dt.  Used to stage fp32 master weights /
+ * network inputs into the compute type and its transposed twin. */
+int rg_transpose_cast(const void* src, int src_dt, int64_t ld_src, int rows, int cols, void* dst,
+                      int64_t ld_dst, void* dst_t, int64_t ld_t, int dst_dt, rg_stream_t stream);
+
+/* ---- replay buffer ------------------------------------------------------------------------ */
+
+/* n-step bookkeeping of ReplayBuffer.sample_transition_batch,
+ * reagent/replay_memory/circular_replay_buffer.py:652-663,676-678,741-747,759-774.
+ * indices [B] int64; terminal [C] uint8; reward [C] fp32; decays [update_horizon] fp32 host-
+ * computed gamma**k (so the product order matches the reference bit for bit).
+ * Outputs: steps [B] int64; next_indices [B] int64; out_terminal [B] uint8; out_reward [B] fp32. */
+int rg_replay_nstep(const int64_t* indices, const uint8_t* terminal, const float* reward,
+                    const float* decays, int64_t capacity, int update_horizon, int batch,
+                    int64_t* steps, int64_t* next_indices, uint8_t* out_terminal,
+                    float* out_reward, rg_stream_t stream);
+
+/* One launch gathers up to RG_MAX_GATHER_COLS dense columns
+ * (`store[key][stack_indices]` of circular_replay_buffer.py:749-757 + sample_to_output :133-141).
+ * For column c: dst_c[b, e, s] = src_c[(idx_c[b] - (stack-1) + s) mod capacity, e]
+ * with e in [0,row_elems_c), elem_bytes_c in {1,2,4,8}; stack==1 degenerates to a row copy. */
+#define RG_MAX_GATHER_COLS 16
+typedef struct {
+  const void* src;        /* [capacity, row_elems] */
+  void* dst;              /* [batch, row_elems, stack] */
+  const int64_t* indices; /* [batch] */
+  int32_t row_elems;
+  int32_t elem_bytes;
+} rg_gather_col;
+int rg_replay_gather(const rg_gather_col* cols /*host*/, int ncols, int64_t capacity, int stack,
+                     int batch, rg_stream_t stream);
+
+/* ---- dense feature normalization ---------------------------------------------------------- */
+
+/* Preprocessor.forward, reagent/preprocessing/preprocessor.py:115-170 (+ _preprocess_* :197-525).
+ * One descriptor per OUTPUT column (ENUM features expand to several).  x [B, n_in] fp32 (ldx),
+ * presence [B, n_in] uint8 (ldp).  out [B, n_out] fp32 (ldo).
+ * p0..p3 per op:  CONTINUOUS mean,stddev | BOXCOX shift,lambda,mean,stddev | ENUM value |
+ * QUANTILE q_offset,q_count (into `quantiles`),-,- | CONTINUOUS_ACTION min_serving,scaling,min_training */
+enum {
+  RG_NORM_BINARY = 0, RG_NORM_PROBABILITY = 1, RG_NORM_CONTINUOUS = 2, RG_NORM_BOXCOX = 3,
+  RG_NORM_ENUM = 4, RG_NORM_QUANTILE = 5, RG_NORM_CONTINUOUS_ACTION = 6,
+  RG_NORM_DISCRETE_ACTION = 7, RG_NORM_DO_NOT_PREPROCESS = 8, RG_NORM_CLIP_LOG = 9
+};
+typedef struct {
+  int32_t op;
+  int32_t in_col;
+  float p0, p1, p2, p3;
+} rg_norm_col;
+int rg_normalize_dense(const float* x, int64_t ldx, const uint8_t* presence, int64_t ldp,
+                       const rg_norm_col* cols /*device*/, int n_out, const float* quantiles,
+                       float* out, int64_t ldo, int batch, rg_stream_t stream);
+
+/* ---- loss heads --------------------------------------------------------------------------- */
+
+/* DQN TD head: get_max_q_values_with_target (reagent/training/dqn_trainer_base.py:33-77) +
+ * compute_td_loss tail (reagent/training/dqn_trainer.py:201-238) + d loss / d q.
+ * q, qn_online, qn_target [B, A] fp32 (ld = A); action, next_mask [B, A] fp32
+ * (next_mask = possible_next_actions_mask when maxq_learning, next_action when SARSA);
+ * reward (already boosted), not_terminal, discount [B] fp32.
+ * Outputs: dq [B, A] fp32 = d(mean loss)/d q; loss_partials [rg_dqn_head_partials(B)] fp32 whose
+ * ordered sum / B is the loss (rg_reduce_sum finishes it); next_q [B], next_idx [B] int64 and
+ * q_sel [B] (nullable) for logging/tests. */
+int rg_dqn_head_partials(int batch);
+int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
+                const float* next_mask, const float* reward, const float* not_terminal,
+                const float* discount, int batch, int num_actions, int double_q, int loss_type,
+                float* dq, float* loss_partials, float* next_q, int64_t* next_idx, float* q_sel,
+                rg_stream_t stream);
+
+/* out[0] = scale * sum_i in[i], summed in index order by one workgroup (deterministic). */
+int rg_reduce_sum(const float* in, int n, float scale, float* out, rg_stream_t stream);
+
+/* ---- optimizer ---------------------------------------------------------------------------- */
+
+/* torch.optim.Adam single-tensor step (torch/optim/adam.py _single_tensor_adam, the arithmetic
+ * behind reagent/optimizer/uninferrable_optimizers.py:23-33) over one flat fp32 slab.
+ * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) are computed by the
+ * caller in double like the reference does.  grad_scale multiplies g first (1/world for DP). */
+int rg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                 double bias_correction1, double bias_correction2_sqrt, float grad_scale,
+                 rg_stream_t stream);
+
+/* SoftUpdate.step, reagent/optimizer/soft_update.py:60-70: tgt = tau*src + (1-tau)*tgt */
+int rg_soft_update(float* target, const float* source, int64_t n, float tau, rg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REAGENT_HIP_H_ */

@@ -1,0 +1,468 @@
+// rg_gemm.h — the one GEMM core behind every FullyConnected layer op (forward, dgrad, wgrad).
+//
+// All three are expressed as the same "NT" product   C[M,N] = A[M,K] · B[N,K]^T   with BOTH
+// operands contiguous along the reduction axis, which is the friendly layout for CDNA4 MFMA
+// fragments (each lane supplies 8 consecutive-k bf16 / one f32 per operand):
+//   forward : Y   = X   · W^T        A = X   [batch, in]    B = W    [out, in]   (nn.Linear layout)
+//   dgrad   : dX  = dZ  · (W^T)^T    A = dZ  [batch, out]   B = W^T  [in, out]
+//   wgrad   : dW  = dZ^T· (X^T)^T    A = dZ^T[out, batch]   B = X^T  [in, batch]   (split over batch)
+// The transposed activation copies that wgrad needs are written by the producing kernel's
+// epilogue (MFMA accumulators hold 4 consecutive rows of one column per lane, so the transposed
+// store is the natural vector store), not by a separate transpose pass.
+//
+// Reference semantics replaced: torch.nn.Linear + activation inside
+// reagent/models/fully_connected_network.py:101-153 and its autograd backward.
+//
+// Two arithmetic modes:
+//   PrecF32  — v_mfma_f32_32x32x2_f32, exact fp32 products/accumulate (parity mode)
+//   PrecBF16 — v_mfma_f32_32x32x16_bf16, bf16 operands, fp32 accumulate (throughput mode)
+//
+// Workgroup = 256 threads = 4 waves.  LDS single-buffered with register prefetch of the next
+// K-slab (global loads in flight during the MFMA block), 2 barriers per slab, 37 KB (bf16) /
+// 17 KB (f32) of LDS so 3-4 workgroups fit a CU.
+#pragma once
+#include <rg_platform.h>  // resolved via -I (product: csrc/, CPU test harness: tests/emu/)
+
+namespace rg {
+
+enum { ACT_LINEAR = 0, ACT_RELU = 1, ACT_LEAKY_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_SOFTPLUS = 5 };
+
+__device__ __forceinline__ float act_apply(float z, int act) {
+  switch (act) {
+    case ACT_RELU: return z > 0.f ? z : 0.f;
+    case ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
+    case ACT_TANH: return tanhf(z);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-z));
+    case ACT_SOFTPLUS: return z > 20.f ? z : log1pf(expf(z));
+    default: return z;
+  }
+}
+// d act(z) / dz expressed through the activation OUTPUT h = act(z) (all six are invertible enough)
+__device__ __forceinline__ float act_grad_from_output(float h, int act) {
+  switch (act) {
+    case ACT_RELU: return h > 0.f ? 1.f : 0.f;
+    case ACT_LEAKY_RELU: return h > 0.f ? 1.f : 0.01f;
+    case ACT_TANH: return 1.f - h * h;
+    case ACT_SIGMOID: return h * (1.f - h);
+    case ACT_SOFTPLUS: return 1.f - expf(-h);
+    default: return 1.f;
+  }
+}
+
+template <typename T> __device__ __forceinline__ T cvt_out(float v);
+template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return f32_to_bf16(v); }
+__device__ __forceinline__ float cvt_in(float v) { return v; }
+__device__ __forceinline__ float cvt_in(bf16_t v) { return bf16_to_f32(v); }
+
+// ---------------------------------------------------------------------------------------------
+// tile configurations
+template <int BM_, int BN_, int WM_, int WN_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  static constexpr int THREADS = WM * WN * 64;
+};
+typedef TileCfg<128, 128, 2, 2> TileWide;   // 4 waves, each 64x64 (2x2 MFMA tiles)
+typedef TileCfg<256, 32, 4, 1> TileNarrow;  // 4 waves, each 64x32; for N <= 32 outputs
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  long lda, ldb;
+  int M, N, K;
+  int k_per_split;  // multiple of BK; == K rounded up when unsplit
+  int splits;
+  int bias_rows_only;  // unused placeholder for ABI stability
+};
+
+// XCD-aware decode of the linear workgroup id: workgroups that share an operand panel (same
+// `outer`) are placed on the same XCD (hardware dispatches id b to XCD b % 8) so the panel is
+// fetched from HBM once and re-read from that XCD's L2.
+__device__ __forceinline__ void decode_wg(int L, int n_outer, int n_inner, int& outer, int& inner) {
+  if ((n_outer & 7) == 0) {
+    const int xcd = L & 7, w = L >> 3;
+    outer = xcd + 8 * (w / n_inner);
+    inner = w % n_inner;
+  } else {
+    outer = L / n_inner;
+    inner = L % n_inner;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// precision policies: staging registers, LDS image, fragment reads + MFMA issue
+struct PrecBF16 {
+  typedef bf16_t T;
+  static constexpr int BK = 64;     // K-slab per iteration
+  static constexpr int VEC = 8;     // elements per 16-byte chunk
+  static constexpr int PITCH = 72;  // LDS row pitch in elements (144 B: conflict-free ds_read_b128)
+  typedef u16x8 Chunk;
+  template <int ROWS> static constexpr int lds_elems() { return ROWS * PITCH; }
+
+  template <int ROWS, int THREADS>
+  struct Stage {
+    static constexpr int NCH = ROWS * (BK / VEC);
+    static constexpr int PER = (NCH + THREADS - 1) / THREADS;
+    Chunk r[PER];
+  };
+
+  template <int ROWS, int THREADS>
+  static __device__ __forceinline__ void load_global(Stage<ROWS, THREADS>& s, const T* src, long ld,
+                                                     int row0, int nrows, int k0, int k_end,
+                                                     bool vec_ok, int tid) {
+    typedef Stage<ROWS, THREADS> S;
+#pragma unroll
+    for (int i = 0; i < S::PER; ++i) {
+      const int c = tid + i * THREADS;
+      Chunk v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < S::NCH) {
+        const int row = c >> 3, kc = c & 7;
+        const int grow = row0 + row, gk = k0 + kc * 8;
+        if (grow < nrows && gk < k_end) {
+          const T* p = src + (long)grow * ld + gk;
+          if (vec_ok && gk + 8 <= k_end) {
+            v = *(const Chunk*)p;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (gk + e < k_end) v[e] = p[e];
+          }
+        }
+      }
+      s.r[i] = v;
+    }
+  }
+  template <int ROWS, int THREADS>
+  static __device__ __forceinline__ void store_lds(const Stage<ROWS, THREADS>& s, T* lds, int tid) {
+    typedef Stage<ROWS, THREADS> S;
+#pragma unroll
+    for (int i = 0; i < S::PER; ++i) {
+      const int c = tid + i * THREADS;
+      if (c < S::NCH) {
+        const int row = c >> 3, kc = c & 7;
+        *(Chunk*)&lds[row * PITCH + kc * 8] = s.r[i];
+      }
+    }
+  }
+  // one K-slab of MFMA work for this wave. a_row0/b_row0: first LDS row of the wave's sub-tile.
+  template <class C, int BIAS_MODE>
+  static __device__ __forceinline__ void compute(const T* As, const T* Bs, int a_row0, int b_row0,
+                                                 int lane, f32x16 (&acc)[C::TM][C::TN],
+                                                 f32x16 (&accb)[(C::TM > C::TN ? C::TM : C::TN)],
+                                                 bool do_bias) {
+    constexpr int TM = C::TM, TN = C::TN;
+    const Chunk ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const int lr = lane & 31, lk = (lane >> 5) * 8;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      Chunk af[TM], bf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        af[tm] = *(const Chunk*)&As[(a_row0 + tm * 32 + lr) * PITCH + kk * 16 + lk];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        bf[tn] = *(const Chunk*)&Bs[(b_row0 + tn * 32 + lr) * PITCH + kk * 16 + lk];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
+      if (BIAS_MODE == 1 && do_bias) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) accb[tm] = mfma_32x32x16_bf16(af[tm], ones, accb[tm]);
+      }
+      if (BIAS_MODE == 2 && do_bias) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) accb[tn] = mfma_32x32x16_bf16(ones, bf[tn], accb[tn]);
+      }
+    }
+  }
+};
+
+struct PrecF32 {
+  typedef float T;
+  static constexpr int BK = 16;
+  static constexpr int VEC = 4;
+  typedef f32x4 Chunk;
+  // LDS image is k-major [BK][ROWS + 4]: a fragment read is 32 consecutive floats per half-wave
+  template <int ROWS> static constexpr int lds_elems() { return BK * (ROWS + 4); }
+
+  template <int ROWS, int THREADS>
+  struct Stage {
+    static constexpr int NCH = ROWS * (BK / VEC);
+    static constexpr int PER = (NCH + THREADS - 1) / THREADS;
+    Chunk r[PER];
+  };
+
+  template <int ROWS, int THREADS>
+  static __device__ __forceinline__ void load_global(Stage<ROWS, THREADS>& s, const T* src, long ld,
+                                                     int row0, int nrows, int k0, int k_end,
+                                                     bool vec_ok, int tid) {
+    typedef Stage<ROWS, THREADS> S;
+#pragma unroll
+    for (int i = 0; i < S::PER; ++i) {
+      const int c = tid + i * THREADS;
+      Chunk v = {0.f, 0.f, 0.f, 0.f};
+      if (c < S::NCH) {
+        const int row = c >> 2, kc = c & 3;
+        const int grow = row0 + row, gk = k0 + kc * 4;
+        if (grow < nrows && gk < k_end) {
+          const T* p = src + (long)grow * ld + gk;
+          if (vec_ok && gk + 4 <= k_end) {
+            v = *(const Chunk*)p;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gk + e < k_end) v[e] = p[e];
+          }
+        }
+      }
+      s.r[i] = v;
+    }
+  }
+  template <int ROWS, int THREADS>
+  static __device__ __forceinline__ void store_lds(const Stage<ROWS, THREADS>& s, T* lds, int tid) {
+    typedef Stage<ROWS, THREADS> S;
+#pragma unroll
+    for (int i = 0; i < S::PER; ++i) {
+      const int c = tid + i * THREADS;
+      if (c < S::NCH) {
+        const int row = c >> 2, kc = c & 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(kc * 4 + e) * (ROWS + 4) + row] = s.r[i][e];
+      }
+    }
+  }
+  template <class C, int BIAS_MODE>
+  static __device__ __forceinline__ void compute(const T* As, const T* Bs, int a_row0, int b_row0,
+                                                 int lane, f32x16 (&acc)[C::TM][C::TN],
+                                                 f32x16 (&accb)[(C::TM > C::TN ? C::TM : C::TN)],
+                                                 bool do_bias) {
+    constexpr int TM = C::TM, TN = C::TN, AROWS = C::BM, BROWS = C::BN;
+    const int lr = lane & 31, lk = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) af[tm] = As[(ks * 2 + lk) * (AROWS + 4) + a_row0 + tm * 32 + lr];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bf[tn] = Bs[(ks * 2 + lk) * (BROWS + 4) + b_row0 + tn * 32 + lr];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x2_f32(af[tm], bf[tn], acc[tm][tn]);
+      if (BIAS_MODE == 1 && do_bias) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) accb[tm] = mfma_32x32x2_f32(af[tm], 1.0f, accb[tm]);
+      }
+      if (BIAS_MODE == 2 && do_bias) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) accb[tn] = mfma_32x32x2_f32(1.0f, bf[tn], accb[tn]);
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// epilogues.  Called with 4 accumulator values = rows row0..row0+3 of column `col`.
+
+template <typename T>
+struct EpiForward {  // y = act(acc + bias); row-major and/or transposed stores
+  const float* bias;
+  T* y;        // row-major [M, ldy] in the compute type (nullable)
+  float* y32;  // row-major fp32 (nullable) — used by the last layer (Q-values / head inputs)
+  long ldy;
+  T* yt;  // transposed [N, ldyt] (nullable) — saved for wgrad + activation-derivative mask
+  long ldyt;
+  int act, M, N;
+  __device__ __forceinline__ void operator()(int row0, int col, const float (&v)[4]) const {
+    if (col >= N || row0 >= M) return;
+    const float b = bias ? bias[col] : 0.f;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] + b, act);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (row0 + e < M) {
+        if (y32) y32[(long)(row0 + e) * ldy + col] = o[e];
+        if (y) y[(long)(row0 + e) * ldy + col] = cvt_out<T>(o[e]);
+      }
+    }
+    if (yt) {
+      T* p = yt + (long)col * ldyt + row0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (row0 + e < M) p[e] = cvt_out<T>(o[e]);
+    }
+  }
+};
+
+template <typename T>
+struct EpiDgrad {  // dz_prev = acc * act'(h_prev); row-major and/or transposed stores
+  const T* ht;     // transposed saved activation of the layer below [N, ldht] (nullable = linear)
+  long ldht;
+  T* dx;
+  float* dx32;
+  long lddx;
+  T* dxt;
+  long lddxt;
+  int act, M, N;
+  __device__ __forceinline__ void operator()(int row0, int col, const float (&v)[4]) const {
+    if (col >= N || row0 >= M) return;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = 1.f;
+      if (ht && row0 + e < M) g = act_grad_from_output(cvt_in(ht[(long)col * ldht + row0 + e]), act);
+      o[e] = v[e] * g;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (row0 + e < M) {
+        if (dx32) dx32[(long)(row0 + e) * lddx + col] = o[e];
+        if (dx) dx[(long)(row0 + e) * lddx + col] = cvt_out<T>(o[e]);
+      }
+    }
+    if (dxt) {
+      T* p = dxt + (long)col * lddxt + row0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (row0 + e < M) p[e] = cvt_out<T>(o[e]);
+    }
+  }
+};
+
+struct EpiWgrad {  // fp32 split partials; optional transposed placement
+  float* p;          // [splits][rows*ld] partial slabs
+  long ld;           // leading dim of the (possibly transposed) destination
+  long slab;         // elements per split slab
+  int transposed;    // 0: p[row][col]   1: p[col][row]
+  int M, N;
+  int split;         // filled in by the kernel
+  __device__ __forceinline__ void operator()(int row0, int col, const float (&v)[4]) const {
+    if (col >= N || row0 >= M) return;
+    float* base = p + (long)split * slab;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (row0 + e < M) {
+        if (transposed) base[(long)col * ld + row0 + e] = v[e];
+        else base[(long)(row0 + e) * ld + col] = v[e];
+      }
+    }
+  }
+};
+
+template <class E> __device__ __forceinline__ void epi_set_split(E&, int) {}
+__device__ __forceinline__ void epi_set_split(EpiWgrad& e, int split) { e.split = split; }
+
+// ---------------------------------------------------------------------------------------------
+// the kernel.  BIAS_MODE 0: none; 1: also emit rowsum(A) (bias grad when A = dZ^T);
+// 2: also emit rowsum(B) (bias grad when B = dZ^T, the transposed narrow variant).
+template <class P, class C, class Epi, int BIAS_MODE>
+__global__ void RG_LAUNCH_BOUNDS(256, 1)
+    gemm_nt_kernel(GemmArgs g, Epi epi, float* bias_partials /*[splits][rows]*/, long bias_slab) {
+  typedef typename P::T T;
+  __shared__ __attribute__((aligned(16))) T As[P::template lds_elems<C::BM>()];
+  __shared__ __attribute__((aligned(16))) T Bs[P::template lds_elems<C::BN>()];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+
+  const int tiles_m = (g.M + C::BM - 1) / C::BM, tiles_n = (g.N + C::BN - 1) / C::BN;
+  int split, tile, tile_m, tile_n;
+  if (g.splits > 1) {
+    decode_wg((int)blockIdx.x, g.splits, tiles_m * tiles_n, split, tile);
+    tile_m = tile / tiles_n;
+    tile_n = tile % tiles_n;
+  } else {
+    split = 0;
+    decode_wg((int)blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
+  }
+  const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+  const int k_begin = split * g.k_per_split;
+  const int k_end = (k_begin + g.k_per_split < g.K) ? k_begin + g.k_per_split : g.K;
+
+  const T* A = (const T*)g.A;
+  const T* B = (const T*)g.B;
+  const bool a_vec = ((g.lda % P::VEC) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const bool b_vec = ((g.ldb % P::VEC) == 0) && ((((uintptr_t)B) & 15) == 0);
+
+  f32x16 acc[C::TM][C::TN];
+  f32x16 accb[(C::TM > C::TN ? C::TM : C::TN)];
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (C::TM > C::TN ? C::TM : C::TN); ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+
+  const bool do_bias = (BIAS_MODE == 1) ? (tile_n == 0 && wn == 0)
+                                        : (BIAS_MODE == 2 ? (tile_m == 0 && wm == 0) : false);
+
+  typename P::template Stage<C::BM, C::THREADS> sa;
+  typename P::template Stage<C::BN, C::THREADS> sb;
+
+  if (k_begin < k_end) {
+    P::template load_global<C::BM, C::THREADS>(sa, A, g.lda, m0, g.M, k_begin, k_end, a_vec, tid);
+    P::template load_global<C::BN, C::THREADS>(sb, B, g.ldb, n0, g.N, k_begin, k_end, b_vec, tid);
+    P::template store_lds<C::BM, C::THREADS>(sa, As, tid);
+    P::template store_lds<C::BN, C::THREADS>(sb, Bs, tid);
+    __syncthreads();
+    for (int k0 = k_begin; k0 < k_end; k0 += P::BK) {
+      const bool more = (k0 + P::BK) < k_end;
+      if (more) {
+        P::template load_global<C::BM, C::THREADS>(sa, A, g.lda, m0, g.M, k0 + P::BK, k_end, a_vec, tid);
+        P::template load_global<C::BN, C::THREADS>(sb, B, g.ldb, n0, g.N, k0 + P::BK, k_end, b_vec, tid);
+      }
+      P::template compute<C, BIAS_MODE>(As, Bs, wm * (C::TM * 32), wn * (C::TN * 32), lane, acc, accb, do_bias);
+      __syncthreads();
+      if (more) {
+        P::template store_lds<C::BM, C::THREADS>(sa, As, tid);
+        P::template store_lds<C::BN, C::THREADS>(sb, Bs, tid);
+        __syncthreads();
+      }
+    }
+  }
+
+  epi_set_split(epi, split);
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+      const int col = n0 + wn * (C::TN * 32) + tn * 32 + lr;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int row0 = m0 + wm * (C::TM * 32) + tm * 32 + 8 * rq + 4 * lh;
+        const float v[4] = {acc[tm][tn][rq * 4 + 0], acc[tm][tn][rq * 4 + 1], acc[tm][tn][rq * 4 + 2],
+                            acc[tm][tn][rq * 4 + 3]};
+        epi(row0, col, v);
+      }
+    }
+
+  if (BIAS_MODE == 1 && do_bias && lr == 0) {  // D[i][0] = sum_k A[i][k]
+    float* bp = bias_partials + (long)split * bias_slab;
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (C::TM * 32) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.M) bp[row] = accb[tm][r];
+      }
+  }
+  if (BIAS_MODE == 2 && do_bias && lh == 0) {  // D[0][j] = sum_k B[k][j]   (reg 0 of lanes 0..31)
+    float* bp = bias_partials + (long)split * bias_slab;
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+      const int col = n0 + wn * (C::TN * 32) + tn * 32 + lr;
+      if (col < g.N) bp[col] = accb[tn][0];
+    }
+  }
+}
+
+}  // namespace rg

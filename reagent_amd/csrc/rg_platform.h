@@ -1,0 +1,55 @@
+// rg_platform.h — gfx950 (CDNA4) device primitives used by every kernel in this library.
+//
+// Everything hardware-specific that the kernels touch goes through the thin `rg::` wrappers
+// declared here: MFMA issue, wave64 cross-lane moves, bf16 conversion and the launch macro.
+// Keeping them in one header means the fragment layouts below are stated exactly once.
+//
+// Fragment layouts (wave64; `l` = lane id), from /opt/skills/guides/cdna_hip_programming.md §3:
+//   mfma_f32_32x32x16_bf16 : A[i][k]  lane l holds i = l&31, k = (l>>5)*8 + e   (e = 0..7)
+//                            B[k][j]  lane l holds j = l&31, k = (l>>5)*8 + e
+//                            D[i][j]  lane l, reg r: j = l&31, i = (r&3) + 8*(r>>2) + 4*(l>>5)
+//   mfma_f32_32x32x2f32    : A[i][k]  lane l holds i = l&31, k = l>>5 (one f32)
+//                            B[k][j]  lane l holds j = l&31, k = l>>5 ; D as above
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rg {
+
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_hw;
+
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a),
+                                                 __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __builtin_bit_cast(float, ((unsigned)v) << 16);
+}
+// round-to-nearest-even; lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+__device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 64); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+}  // namespace rg
+
+#define RG_LAUNCH(kernel, grid, block, stream, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+#define RG_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)

@@ -1,0 +1,142 @@
+// TEST INFRASTRUCTURE ONLY — never shipped, never loaded by the reagent_amd package.
+//
+// A drop-in replacement for reagent_amd/csrc/rg_platform.h that lets the *unmodified* kernel
+// sources be compiled for the x86 host (amdclang++ -x c++) and executed by a tiny SIMT
+// interpreter: every GPU thread of a workgroup is a ucontext fiber, `__syncthreads()` and the
+// wave64 collectives (MFMA, shuffles) are rendezvous points.  It exists so that `pytest -m "not
+// gpu"` can check the kernels' index arithmetic / fragment layouts / epilogues against the oracle in
+// a container that has no GPU.  It models the MFMA fragment layouts documented in the product
+// header; tests/test_gpu_mfma_layout.py checks those same layouts on real hardware.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <stdlib.h>
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  memset(p, v, n);
+  return 0;
+}
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) {
+  memcpy(d, s, n);
+  return 0;
+}
+#define hipMemcpyDeviceToDevice 3
+#define hipMemcpyDefault 4
+
+namespace emu {
+struct ThreadCtx {
+  dim3 tid, bid, bdim, gdim;
+  int linear_tid;
+};
+ThreadCtx& cur();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_threads();
+// wave collective: every live lane of the wave deposits `bytes` bytes; returns pointer to a
+// 64-slot array (slot stride = bytes) holding all lanes' values, valid until the next collective.
+const void* wave_gather(const void* mine, size_t bytes);
+}  // namespace emu
+
+#define threadIdx (::emu::cur().tid)
+#define blockIdx (::emu::cur().bid)
+#define blockDim (::emu::cur().bdim)
+#define gridDim (::emu::cur().gdim)
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __restrict__
+#define __launch_bounds__(...)
+static inline void __syncthreads() { ::emu::sync_threads(); }
+
+namespace rg {
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+static inline float bf16_to_f32(bf16_t v) {
+  uint32_t u = ((uint32_t)v) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline bf16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  uint32_t r = 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)((u + r) >> 16);
+}
+
+static inline int lane_id() { return ::emu::cur().linear_tid & 63; }
+
+template <typename T>
+static inline T gather_from(T v, int src_lane) {
+  const T* all = (const T*)::emu::wave_gather(&v, sizeof(T));
+  return all[src_lane & 63];
+}
+static inline float shfl_xor(float v, int mask) { return gather_from(v, lane_id() ^ mask); }
+static inline int shfl_xor(int v, int mask) { return gather_from(v, lane_id() ^ mask); }
+static inline float shfl_down(float v, int d) {
+  int l = lane_id();
+  return gather_from(v, (l + d < 64) ? l + d : l);
+}
+static inline float shfl_idx(float v, int src) { return gather_from(v, src); }
+static inline int shfl_idx(int v, int src) { return gather_from(v, src); }
+
+static inline f32x16 mfma_32x32x16_bf16(u16x8 a, u16x8 b, f32x16 c) {
+  struct AB {
+    u16x8 a, b;
+  } mine{a, b};
+  const AB* all = (const AB*)::emu::wave_gather(&mine, sizeof(AB));
+  const int l = lane_id();
+  const int j = l & 31;
+  f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 16; ++k) {
+      const float av = bf16_to_f32(all[i + 32 * (k >> 3)].a[k & 7]);
+      const float bv = bf16_to_f32(all[j + 32 * (k >> 3)].b[k & 7]);
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  return d;
+}
+static inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+  struct AB {
+    float a, b;
+  } mine{a, b};
+  const AB* all = (const AB*)::emu::wave_gather(&mine, sizeof(AB));
+  const int l = lane_id();
+  const int j = l & 31;
+  f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 2; ++k) acc = fmaf(all[i + 32 * k].a, all[j + 32 * k].b, acc);
+    d[r] = acc;
+  }
+  return d;
+}
+
+}  // namespace rg
+
+#define RG_LAUNCH(kernel, grid, block, stream, ...) \
+  ::emu::launch(grid, block, [&]() { kernel(__VA_ARGS__); })
+#define RG_LAUNCH_BOUNDS(t, w)
