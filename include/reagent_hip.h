@@ -127,20 +127,23 @@ int rg_normalize_dense(const float* x, int64_t ldx, const uint8_t* presence, int
 
 /* ---- loss heads --------------------------------------------------------------------------- */
 
-/* DQN TD head: get_max_q_values_with_target (reagent/training/dqn_trainer_base.py:33-77) +
- * compute_td_loss tail (reagent/training/dqn_trainer.py:201-238) + d loss / d q.
- * q, qn_online, qn_target [B, A] fp32 (ld = A); action, next_mask [B, A] fp32
+/* DQN TD head: boost_rewards (reagent/training/dqn_trainer_base.py:216-241),
+ * compute_discount_tensor (reagent/training/dqn_trainer.py:166-177),
+ * get_max_q_values_with_target (dqn_trainer_base.py:33-77), compute_td_loss tail
+ * (dqn_trainer.py:201-238) and d loss / d q, fused in one pass over the batch.
+ * q, qn_online, qn_target [B, A] fp32 contiguous; action, next_mask [B, A] fp32
  * (next_mask = possible_next_actions_mask when maxq_learning, next_action when SARSA);
- * reward (already boosted), not_terminal, discount [B] fp32.
+ * reward, not_terminal [B] fp32; reward_boosts [A] fp32 or NULL;
+ * discount = gamma, or gamma ** gamma_exponent[b] when gamma_exponent != NULL (time_diff / step).
  * Outputs: dq [B, A] fp32 = d(mean loss)/d q; loss_partials [rg_dqn_head_partials(B)] fp32 whose
  * ordered sum / B is the loss (rg_reduce_sum finishes it); next_q [B], next_idx [B] int64 and
  * q_sel [B] (nullable) for logging/tests. */
 int rg_dqn_head_partials(int batch);
 int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
-                const float* next_mask, const float* reward, const float* not_terminal,
-                const float* discount, int batch, int num_actions, int double_q, int loss_type,
-                float* dq, float* loss_partials, float* next_q, int64_t* next_idx, float* q_sel,
-                rg_stream_t stream);
+                const float* next_mask, const float* reward, const float* reward_boosts,
+                const float* not_terminal, double gamma, const float* gamma_exponent, int batch,
+                int num_actions, int double_q, int loss_type, float* dq, float* loss_partials,
+                float* next_q, int64_t* next_idx, float* q_sel, rg_stream_t stream);
 
 /* out[0] = scale * sum_i in[i], summed in index order by one workgroup (deterministic). */
 int rg_reduce_sum(const float* in, int n, float scale, float* out, rg_stream_t stream);
@@ -152,12 +155,12 @@ int rg_reduce_sum(const float* in, int n, float scale, float* out, rg_stream_t s
  * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) are computed by the
  * caller in double like the reference does.  grad_scale multiplies g first (1/world for DP). */
 int rg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                 float lr, float beta1, float beta2, float eps, float weight_decay,
-                 double bias_correction1, double bias_correction2_sqrt, float grad_scale,
+                 double lr, double beta1, double beta2, double eps, double weight_decay,
+                 double bias_correction1, double bias_correction2_sqrt, double grad_scale,
                  rg_stream_t stream);
 
 /* SoftUpdate.step, reagent/optimizer/soft_update.py:60-70: tgt = tau*src + (1-tau)*tgt */
-int rg_soft_update(float* target, const float* source, int64_t n, float tau, rg_stream_t stream);
+int rg_soft_update(float* target, const float* source, int64_t n, double tau, rg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,136 @@
+"""ctypes binding of libreagent_hip.so (the C ABI in include/reagent_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this raises.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C reagent_amd/csrc``.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libreagent_hip.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+DT_F32, DT_BF16 = 0, 1
+ACT = {"linear": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5}
+LOSS = {"mse": 0, "huber": 1}
+MAX_GATHER_COLS = 16
+
+c_void_p, c_int, c_i64, c_f, c_d, c_sz = (
+    ctypes.c_void_p,
+    ctypes.c_int,
+    ctypes.c_int64,
+    ctypes.c_float,
+    ctypes.c_double,
+    ctypes.c_size_t,
+)
+
+
+class GatherCol(ctypes.Structure):
+    _fields_ = [
+        ("src", c_void_p),
+        ("dst", c_void_p),
+        ("indices", c_void_p),
+        ("row_elems", ctypes.c_int32),
+        ("elem_bytes", ctypes.c_int32),
+    ]
+
+
+class NormCol(ctypes.Structure):
+    _fields_ = [
+        ("op", ctypes.c_int32),
+        ("in_col", ctypes.c_int32),
+        ("p0", c_f),
+        ("p1", c_f),
+        ("p2", c_f),
+        ("p3", c_f),
+    ]
+
+
+# every symbol include/reagent_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "rg_strerror": (ctypes.c_char_p, [c_int]),
+    "rg_abi_version": (c_int, []),
+    "rg_fc_forward": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
+                               c_void_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rg_fc_dgrad": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p,
+                             c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
+    "rg_fc_wgrad_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "rg_fc_wgrad": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_sz,
+                             c_int, c_int, c_int, c_int, c_void_p]),
+    "rg_transpose_cast": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p,
+                                   c_i64, c_int, c_void_p]),
+    "rg_replay_nstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rg_replay_gather": (c_int, [ctypes.POINTER(GatherCol), c_int, c_i64, c_int, c_int, c_void_p]),
+    "rg_normalize_dense": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_i64, c_int, c_void_p]),
+    "rg_dqn_head_partials": (c_int, [c_int]),
+    "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "rg_reduce_sum": (c_int, [c_void_p, c_int, c_f, c_void_p, c_void_p]),
+    "rg_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d,
+                              c_d, c_d, c_d, c_void_p]),
+    "rg_soft_update": (c_int, [c_void_p, c_void_p, c_i64, c_d, c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class ReagentHipError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH):
+    """dlopen the library and attach prototypes.  Raises if it is missing or lacks a symbol."""
+    if not os.path.exists(path):
+        raise ReagentHipError(
+            f"{path} not found: the HIP extension is not built and there is no CPU fallback. "
+            "Run `make -C reagent_amd/csrc` (or __graft_entry__.build())."
+        )
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ReagentHipError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                _lib = load()
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().rg_strerror(rc).decode()
+        raise ReagentHipError(f"{what or 'reagent_hip call'} failed: {msg} (code {rc})")
+
+
+def stream_ptr() -> int:
+    """Raw hipStream_t of torch's current stream (kernels are enqueued there)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def require_cuda(t: torch.Tensor, name: str = "tensor"):
+    if not t.is_cuda:
+        raise ReagentHipError(
+            f"{name} lives on {t.device}: reagent_amd ops run only on an AMD GPU (no CPU fallback)"
+        )

@@ -1,0 +1,120 @@
+// heads.hip — loss heads that sit between the last FC forward and the first FC backward.
+#include <rg_platform.h>
+#include "../../include/reagent_hip.h"
+
+namespace rg {
+
+constexpr int HEAD_THREADS = 256;
+
+// block-wide sum in a fixed order (wave shuffles, then wave 0 adds the 4 wave sums in order)
+__device__ __forceinline__ float block_sum_256(float v, float* scratch /*[4]*/) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += shfl_xor(v, off);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+  __syncthreads();
+  const float s = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  __syncthreads();
+  return s;
+}
+
+// One thread per transition.  Masked max / arg-max over |A| with first-index tie-break
+// (torch.max semantics), double-Q gather, TD target, MSE / Huber value and d loss / d q.
+// dqn_trainer_base.py:33-77 + dqn_trainer.py:201-238.
+__global__ void dqn_head_kernel(const float* __restrict__ q, const float* __restrict__ qn_online,
+                                const float* __restrict__ qn_target, const float* __restrict__ action,
+                                const float* __restrict__ next_mask, const float* __restrict__ reward,
+                                const float* __restrict__ reward_boosts,
+                                const float* __restrict__ not_terminal, float gamma,
+                                const float* __restrict__ gamma_exponent, int batch, int A, int double_q,
+                                int loss_type, float* __restrict__ dq, float* __restrict__ loss_partials,
+                                float* __restrict__ next_q_out, int64_t* __restrict__ next_idx_out,
+                                float* __restrict__ q_sel_out) {
+  __shared__ float scratch[4];
+  const int b = blockIdx.x * HEAD_THREADS + threadIdx.x;
+  float loss = 0.f;
+  if (b < batch) {
+    const long o = (long)b * A;
+    float best = 0.f, best_t = 0.f;
+    int best_i = 0;
+    for (int a = 0; a < A; ++a) {
+      const float pen = -1e9f * (1.f - next_mask[o + a]);  // ACTION_NOT_POSSIBLE_VAL * (1 - mask)
+      const float qo = qn_online[o + a] + pen;
+      const float qt = qn_target[o + a] + pen;
+      const float key = double_q ? qo : qt;
+      if (a == 0 || key > best) {
+        best = key;
+        best_t = qt;
+        best_i = a;
+      }
+    }
+    const float next_q = best_t;
+    // boost_rewards (dqn_trainer_base.py:216-241) and compute_discount_tensor (dqn_trainer.py:166-177)
+    float rb = 0.f;
+    if (reward_boosts)
+      for (int a = 0; a < A; ++a) rb += action[o + a] * reward_boosts[a];
+    const float rew = reward[b] + rb;
+    const float disc = gamma_exponent ? powf(gamma, gamma_exponent[b]) : gamma;
+    const float target = rew + disc * (next_q * not_terminal[b]);
+    float qs = 0.f;
+    for (int a = 0; a < A; ++a) qs += q[o + a] * action[o + a];
+    const float d = qs - target;
+    float g;
+    if (loss_type == RG_LOSS_HUBER) {  // F.smooth_l1_loss, beta = 1
+      const float ad = fabsf(d);
+      loss = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+      g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+    } else {  // F.mse_loss
+      loss = d * d;
+      g = 2.f * d;
+    }
+    g /= (float)batch;
+    for (int a = 0; a < A; ++a) dq[o + a] = g * action[o + a];
+    if (next_q_out) next_q_out[b] = next_q;
+    if (next_idx_out) next_idx_out[b] = best_i;
+    if (q_sel_out) q_sel_out[b] = qs;
+  }
+  const float s = block_sum_256(loss, scratch);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = s;
+}
+
+__global__ void reduce_sum_kernel(const float* __restrict__ in, int n, float scale,
+                                  float* __restrict__ out) {
+  __shared__ float scratch[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += HEAD_THREADS) acc += in[i];
+  const float s = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+}  // namespace rg
+
+using namespace rg;
+
+extern "C" {
+
+int rg_dqn_head_partials(int batch) { return (batch + HEAD_THREADS - 1) / HEAD_THREADS; }
+
+int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
+                const float* next_mask, const float* reward, const float* reward_boosts,
+                const float* not_terminal, double gamma, const float* gamma_exponent, int batch,
+                int num_actions, int double_q, int loss_type, float* dq, float* loss_partials,
+                float* next_q, int64_t* next_idx, float* q_sel, rg_stream_t stream) {
+  if (!q || !qn_online || !qn_target || !action || !next_mask || !reward || !not_terminal || !dq ||
+      !loss_partials || batch <= 0 || num_actions <= 0)
+    return RG_EINVAL;
+  if (loss_type != RG_LOSS_MSE && loss_type != RG_LOSS_HUBER) return RG_EINVAL;
+  RG_LAUNCH(dqn_head_kernel, dim3(rg_dqn_head_partials(batch)), dim3(HEAD_THREADS),
+            (hipStream_t)stream, q, qn_online, qn_target, action, next_mask, reward, reward_boosts,
+            not_terminal, (float)gamma, gamma_exponent, batch, num_actions, double_q, loss_type, dq,
+            loss_partials, next_q, next_idx, q_sel);
+  return (int)hipGetLastError();
+}
+
+int rg_reduce_sum(const float* in, int n, float scale, float* out, rg_stream_t stream) {
+  if (!in || !out || n < 0) return RG_EINVAL;
+  RG_LAUNCH(reduce_sum_kernel, dim3(1), dim3(HEAD_THREADS), (hipStream_t)stream, in, n, scale, out);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

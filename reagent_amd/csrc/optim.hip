@@ -1,0 +1,88 @@
+// optim.hip — fused Adam and soft target update over flat fp32 parameter slabs (HBM-bound).
+#include <rg_platform.h>
+#include "../../include/reagent_hip.h"
+
+namespace rg {
+
+// torch/optim/adam.py::_single_tensor_adam arithmetic, same operation order:
+//   g      = grad (+ wd * p)
+//   m      = m + (g - m) * (1 - beta1)                      (lerp_)
+//   v      = v * beta2 + ((1 - beta2) * g) * g              (mul_ + addcmul_)
+//   denom  = sqrt(v) / bias_correction2_sqrt + eps
+//   p      = p + (-step_size * m) / denom                   (addcdiv_)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, long n, float w1,
+                            float beta2, float w2, float eps, float wd, float neg_step_size,
+                            float bc2_sqrt, float grad_scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (grad_scale != 1.f) gi *= grad_scale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float mi = m[i], vi = v[i];
+    mi = mi + w1 * (gi - mi);
+    vi = vi * beta2;
+    vi = vi + (w2 * gi) * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi + (neg_step_size * mi) / denom;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+__global__ void soft_update_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n,
+                                   float tau, float one_minus_tau) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    tgt[i] = tau * src[i] + one_minus_tau * tgt[i];
+}
+
+static unsigned grid_for(long n) {
+  long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace rg
+
+using namespace rg;
+
+extern "C" {
+
+int rg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 double lr, double beta1, double beta2, double eps, double weight_decay,
+                 double bias_correction1, double bias_correction2_sqrt, double grad_scale,
+                 rg_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || bias_correction1 == 0.0) return RG_EINVAL;
+  if (n == 0) return RG_OK;
+  const double step_size = lr / bias_correction1;
+  RG_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), (hipStream_t)stream, param, grad, exp_avg,
+            exp_avg_sq, (long)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+            (float)weight_decay, (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale);
+  return (int)hipGetLastError();
+}
+
+int rg_soft_update(float* target, const float* source, int64_t n, double tau, rg_stream_t stream) {
+  if (!target || !source || n < 0 || tau < 0.0 || tau > 1.0) return RG_EINVAL;
+  if (n == 0) return RG_OK;
+  RG_LAUNCH(soft_update_kernel, dim3(grid_for(n)), dim3(256), (hipStream_t)stream, target, source,
+            (long)n, (float)tau, (float)(1.0 - tau));
+  return (int)hipGetLastError();
+}
+
+int rg_abi_version(void) { return 1; }
+
+const char* rg_strerror(int code) {
+  switch (code) {
+    case RG_OK: return "ok";
+    case RG_EINVAL: return "invalid argument";
+    case RG_EALIGN: return "misaligned pointer or leading dimension";
+    case RG_EUNSUPPORTED: return "unsupported dtype/precision";
+    case RG_EWORKSPACE: return "workspace too small";
+    default: return code > 0 ? "HIP runtime error (code is hipError_t)" : "unknown error";
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// replay.hip — device-resident circular replay buffer sampling (HBM-bound byte movers).
+// Replaces the ~17 advanced-indexing ops of ReplayBuffer.sample_transition_batch,
+// reagent/replay_memory/circular_replay_buffer.py:614-706 (+ :741-774).  Bit-exact by
+// construction: rows are copied, never recomputed; the n-step reward uses the reference's
+// operation order (r * gamma^k * mask, summed k = 0..h-1).
+#include <rg_platform.h>
+#include "../../include/reagent_hip.h"
+
+namespace rg {
+
+// steps / next index / terminal / n-step reward for every sampled index
+__global__ void replay_nstep_kernel(const int64_t* __restrict__ indices,
+                                    const uint8_t* __restrict__ terminal,
+                                    const float* __restrict__ reward,
+                                    const float* __restrict__ decays, int64_t capacity, int horizon,
+                                    int batch, int64_t* __restrict__ steps,
+                                    int64_t* __restrict__ next_indices,
+                                    uint8_t* __restrict__ out_terminal,
+                                    float* __restrict__ out_reward) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const int64_t idx = indices[b];
+  // _get_steps (:759-774): first terminal inside the window, the last slot counts as terminal
+  int st = horizon;
+  for (int k = 0; k < horizon; ++k) {
+    if (terminal[(idx + k) % capacity]) {
+      st = k + 1;
+      break;
+    }
+  }
+  if (steps) steps[b] = st;
+  if (next_indices) next_indices[b] = (idx + st) % capacity;
+  if (out_terminal) out_terminal[b] = terminal[(idx + st - 1) % capacity] ? 1 : 0;
+  if (out_reward) {
+    // _reduce_multi_step_reward (:741-747): (reward * decays * masks).sum(dim=1)
+    float acc = 0.f;
+    for (int k = 0; k < horizon; ++k) {
+      const float m = (k < st) ? 1.f : 0.f;
+      acc += (reward[(idx + k) % capacity] * decays[k]) * m;
+    }
+    out_reward[b] = acc;
+  }
+}
+
+struct GatherTable {
+  rg_gather_col c[RG_MAX_GATHER_COLS];
+};
+
+// stack == 1: each sampled row is a contiguous run of row_bytes; copy it with the widest
+// aligned unit (16 B when the row pitch allows, else the element size).  One workgroup moves
+// ROWS_PER_WG rows of one column; consecutive lanes take consecutive 16-B pieces of a row so a
+// 512-B observation row is one fully coalesced half-wave request.
+constexpr int GATHER_ROWS_PER_WG = 64;
+
+__global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch) {
+  const rg_gather_col col = t.c[blockIdx.y];
+  const int row0 = blockIdx.x * GATHER_ROWS_PER_WG;
+  const int nrows = (batch - row0 < GATHER_ROWS_PER_WG) ? batch - row0 : GATHER_ROWS_PER_WG;
+  const long row_bytes = (long)col.row_elems * col.elem_bytes;
+  const char* src = (const char*)col.src;
+  char* dst = (char*)col.dst;
+  const bool vec16 = (row_bytes % 16 == 0) && ((((uintptr_t)src) & 15) == 0) &&
+                     ((((uintptr_t)dst) & 15) == 0);
+  if (vec16) {
+    const int cpr = (int)(row_bytes / 16);
+    const int total = nrows * cpr;
+    for (int it = threadIdx.x; it < total; it += blockDim.x) {
+      const int r = it / cpr, ch = it % cpr;
+      const int64_t idx = col.indices[row0 + r];
+      const uint4 v = *(const uint4*)(src + idx * row_bytes + (long)ch * 16);
+      *(uint4*)(dst + (long)(row0 + r) * row_bytes + (long)ch * 16) = v;
+    }
+  } else {
+    const int eb = col.elem_bytes;
+    const int epr = col.row_elems;
+    const int total = nrows * epr;
+    for (int it = threadIdx.x; it < total; it += blockDim.x) {
+      const int r = it / epr, e = it % epr;
+      const int64_t idx = col.indices[row0 + r];
+      const char* s = src + idx * row_bytes + (long)e * eb;
+      char* d = dst + (long)(row0 + r) * row_bytes + (long)e * eb;
+      if (eb == 8) *(uint64_t*)d = *(const uint64_t*)s;
+      else if (eb == 4) *(uint32_t*)d = *(const uint32_t*)s;
+      else if (eb == 2) *(uint16_t*)d = *(const uint16_t*)s;
+      else *d = *s;
+    }
+  }
+}
+
+// stack > 1 (_get_stack_for_indices :749-757 + DenseMetadata.sample_to_output :133-141):
+// dst[b, e, s] = src[(idx[b] - (stack-1) + s) mod capacity, e]
+__global__ void replay_gather_stack_kernel(GatherTable t, int64_t capacity, int stack, int batch) {
+  const rg_gather_col col = t.c[blockIdx.y];
+  const int eb = col.elem_bytes, epr = col.row_elems;
+  const long per_row = (long)epr * stack;
+  const long total = (long)batch * per_row;
+  const char* src = (const char*)col.src;
+  char* dst = (char*)col.dst;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total;
+       it += (long)gridDim.x * blockDim.x) {
+    const long b = it / per_row;
+    const int rem = (int)(it % per_row);
+    const int e = rem / stack, s = rem % stack;
+    int64_t r = (col.indices[b] - (stack - 1) + s) % capacity;
+    if (r < 0) r += capacity;
+    const char* sp = src + (r * epr + e) * (long)eb;
+    char* dp = dst + it * (long)eb;
+    if (eb == 8) *(uint64_t*)dp = *(const uint64_t*)sp;
+    else if (eb == 4) *(uint32_t*)dp = *(const uint32_t*)sp;
+    else if (eb == 2) *(uint16_t*)dp = *(const uint16_t*)sp;
+    else *dp = *sp;
+  }
+}
+
+}  // namespace rg
+
+using namespace rg;
+
+extern "C" {
+
+int rg_replay_nstep(const int64_t* indices, const uint8_t* terminal, const float* reward,
+                    const float* decays, int64_t capacity, int update_horizon, int batch,
+                    int64_t* steps, int64_t* next_indices, uint8_t* out_terminal, float* out_reward,
+                    rg_stream_t stream) {
+  if (!indices || !terminal || capacity <= 0 || update_horizon <= 0 || batch < 0) return RG_EINVAL;
+  if (out_reward && (!reward || !decays)) return RG_EINVAL;
+  if (batch == 0) return RG_OK;
+  RG_LAUNCH(replay_nstep_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, indices,
+            terminal, reward, decays, capacity, update_horizon, batch, steps, next_indices,
+            out_terminal, out_reward);
+  return (int)hipGetLastError();
+}
+
+int rg_replay_gather(const rg_gather_col* cols, int ncols, int64_t capacity, int stack, int batch,
+                     rg_stream_t stream) {
+  if (!cols || ncols <= 0 || ncols > RG_MAX_GATHER_COLS || capacity <= 0 || stack <= 0 || batch < 0)
+    return RG_EINVAL;
+  if (batch == 0) return RG_OK;
+  GatherTable t;
+  for (int i = 0; i < ncols; ++i) {
+    t.c[i] = cols[i];
+    const int eb = cols[i].elem_bytes;
+    if (!cols[i].src || !cols[i].dst || !cols[i].indices || cols[i].row_elems <= 0) return RG_EINVAL;
+    if (eb != 1 && eb != 2 && eb != 4 && eb != 8) return RG_EINVAL;
+  }
+  for (int i = ncols; i < RG_MAX_GATHER_COLS; ++i) t.c[i] = cols[0];
+  if (stack == 1) {
+    RG_LAUNCH(replay_gather_kernel,
+              dim3((batch + GATHER_ROWS_PER_WG - 1) / GATHER_ROWS_PER_WG, ncols), dim3(256),
+              (hipStream_t)stream, t, capacity, batch);
+  } else {
+    int gx = (batch + 3) / 4;
+    if (gx > 4096) gx = 4096;
+    RG_LAUNCH(replay_gather_stack_kernel, dim3(gx, ncols), dim3(256), (hipStream_t)stream, t,
+              capacity, stack, batch);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

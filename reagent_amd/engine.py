@@ -1,0 +1,239 @@
+"""Host-side execution engine for FullyConnected stacks on the HIP kernels.
+
+``ParamSlab``  : one flat fp32 arena per network; the nn.Parameters become views into it so that
+                 the fused Adam / soft-update kernels and the RCCL all-reduce see ONE buffer while
+                 ``state_dict()`` / ``parameters()`` keep working.
+``FCStack``    : forward / backward of a FullyConnectedNetwork
+                 (reference: reagent/models/fully_connected_network.py:101-163 + autograd) as a
+                 sequence of rg_fc_forward / rg_fc_dgrad / rg_fc_wgrad launches, with the
+                 compute-type weight copies and the activation workspace it needs.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _mat(rows: int, cols: int, dtype, device) -> torch.Tensor:
+    """[rows, cols] view with a row pitch padded to 16 bytes worth of elements (vector loads)."""
+    ld = _round_up(max(cols, 1), 8)
+    return torch.empty(rows, ld, dtype=dtype, device=device)[:, :cols]
+
+
+class ParamSlab:
+    """Flat fp32 storage for a list of parameters (+ an equally shaped gradient slab)."""
+
+    ALIGN = 4  # elements (16 bytes) so every tensor can be an MFMA-GEMM operand directly
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = list(params)
+        assert len(self.params) > 0
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise L.ReagentHipError("parameters must be float32 (fp32 master weights)")
+            self.offsets.append(off)
+            off += _round_up(p.numel(), self.ALIGN)
+        self.total = off
+        self.data = None
+        self.grad = None
+        self.rebind()
+
+    def rebind(self):
+        """(Re)allocate on the parameters' current device and point every parameter into the slab."""
+        dev = self.params[0].device
+        data = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                data[off : off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = data[off : off + p.numel()].view(p.shape)
+        self.data = data
+        self.grad = torch.zeros_like(data)
+
+    def is_bound(self) -> bool:
+        base = self.data.data_ptr()
+        return all(p.data_ptr() == base + 4 * off and p.device == self.data.device
+                   for p, off in zip(self.params, self.offsets))
+
+    def ensure_bound(self):
+        if not self.is_bound():
+            self.rebind()
+
+    def view(self, slab: torch.Tensor, i: int) -> torch.Tensor:
+        p, off = self.params[i], self.offsets[i]
+        return slab[off : off + p.numel()].view(p.shape)
+
+    def grad_views(self) -> List[torch.Tensor]:
+        return [self.view(self.grad, i) for i in range(len(self.params))]
+
+    def attach_grads(self):
+        """Make p.grad alias the gradient slab (what the HIP backward writes)."""
+        for i, p in enumerate(self.params):
+            p.grad = self.view(self.grad, i)
+
+
+def ensure_slab(params) -> ParamSlab:
+    """The ParamSlab that holds exactly ``params`` (created, and the parameters re-homed, if needed)."""
+    params = list(params)
+    slab = getattr(params[0], "_rg_slab", None)
+    if slab is None or len(slab.params) != len(params) or any(a is not b for a, b in zip(slab.params, params)):
+        slab = ParamSlab(params)
+        for p in params:
+            p._rg_slab = slab
+    else:
+        slab.ensure_bound()
+    return slab
+
+
+class FCStack:
+    """Runs one FullyConnectedNetwork on the GPU kernels.
+
+    weights[i]: [out_i, in_i] fp32 Parameter (nn.Linear layout), biases[i]: [out_i], acts[i]: rg
+    activation code of layer i (the last one is the output activation).
+    """
+
+    def __init__(self, weights, biases, acts: List[int], precision: int):
+        assert len(weights) == len(biases) == len(acts)
+        self.weights, self.biases, self.acts = list(weights), list(biases), list(acts)
+        self.precision = precision
+        self.cdtype = ops.compute_dtype(precision)
+        self.dims = [self.weights[0].shape[1]] + [w.shape[0] for w in self.weights]
+        self.L = len(self.weights)
+        self._wc = [None] * self.L   # compute-type weights [out, in]
+        self._wtc = [None] * self.L  # compute-type transposed weights [in, out]
+        self._batch = -1
+        self._ws = {}
+        self._staged_versions = None
+
+    # ---- weights -------------------------------------------------------------------------
+    def stage_weights(self, need_transposed: bool = True, force: bool = False):
+        """fp32 master weights -> compute-type copies (and W^T for dgrad).  Skipped when the
+        parameters have not been modified since the last staging."""
+        versions = tuple((w._version, getattr(w, "_rg_version", 0)) for w in self.weights) + (need_transposed,)
+        if not force and versions == self._staged_versions and all(
+            self._wsrc_ptrs[i] == self.weights[i].data_ptr() for i in range(self.L)
+        ):
+            return
+        dev = self.weights[0].device
+        for i, w in enumerate(self.weights):
+            out_f, in_f = w.shape
+            wd = w.detach()
+            if self.precision == L.PREC_F32:
+                self._wc[i] = wd  # fp32 master weights are the operand
+                dst = None
+            else:
+                if self._wc[i] is None or self._wc[i].device != dev:
+                    self._wc[i] = _mat(out_f, in_f, self.cdtype, dev)
+                dst = self._wc[i]
+            dst_t = None
+            if need_transposed and (i > 0 or self._need_dx):
+                if self._wtc[i] is None or self._wtc[i].device != dev:
+                    self._wtc[i] = _mat(in_f, out_f, self.cdtype, dev)
+                dst_t = self._wtc[i]
+            if dst is not None or dst_t is not None:
+                ops.transpose_cast(wd, dst, dst_t)
+        self._staged_versions = versions
+        self._wsrc_ptrs = [w.data_ptr() for w in self.weights]
+
+    _need_dx = False
+    _wsrc_ptrs = ()
+
+    def set_need_input_grad(self, flag: bool):
+        if flag != self._need_dx:
+            self._need_dx = flag
+            self._staged_versions = None
+
+    # ---- workspace -----------------------------------------------------------------------
+    def _ensure_ws(self, batch: int, device):
+        if self._batch == batch and self._ws.get("device") == device:
+            return
+        ws = {"device": device}
+        hidden = self.dims[1:-1]
+        wmax = max(hidden) if hidden else 1
+        cd = self.cdtype
+        ws["h"] = [_mat(batch, wmax, cd, device) for _ in range(2)] if hidden else []
+        ws["ht"] = [_mat(n, batch, cd, device) for n in hidden]           # saved (transposed) activations
+        dmax = max(self.dims[1:])
+        ws["dz"] = [_mat(batch, dmax, cd, device) for _ in range(2)]
+        ws["dzt"] = [_mat(dmax, batch, cd, device) for _ in range(2)]
+        nbytes = max(
+            ops.fc_wgrad_workspace_bytes(self.dims[i + 1], self.dims[i], batch, self.precision)
+            for i in range(self.L)
+        )
+        ws["wgrad"] = torch.empty(_round_up(nbytes, 16) // 4, dtype=torch.float32, device=device)
+        self._ws = ws
+        self._batch = batch
+
+    def stage_input(self, x32: torch.Tensor, need_transposed: bool):
+        """fp32 [B, in] network input -> (row-major compute-type operand, transposed copy or None)."""
+        B, in_f = x32.shape
+        dev = x32.device
+        xt = _mat(in_f, B, self.cdtype, dev) if need_transposed else None
+        if self.precision == L.PREC_F32 and x32.stride(1) == 1:
+            xc = x32
+            if xt is not None:
+                ops.transpose_cast(x32, None, xt)
+        else:
+            xc = _mat(B, in_f, self.cdtype, dev)
+            ops.transpose_cast(x32, xc, xt)
+        return xc, xt
+
+    # ---- forward -------------------------------------------------------------------------
+    def forward(self, xc: torch.Tensor, out32: torch.Tensor, save: bool = False):
+        """xc: staged input (compute type) [B, in]; out32: fp32 [B, out_last] (written)."""
+        B = xc.shape[0]
+        self._ensure_ws(B, xc.device)
+        ws = self._ws
+        cur = xc
+        for i in range(self.L):
+            last = i == self.L - 1
+            out_f = self.dims[i + 1]
+            if last:
+                ops.fc_forward(cur, self._wc[i], self.biases[i].detach(), self.acts[i], self.precision,
+                               y=None, y32=out32, yt=None)
+            else:
+                y = ws["h"][i % 2][:, :out_f]
+                yt = ws["ht"][i] if save else None
+                ops.fc_forward(cur, self._wc[i], self.biases[i].detach(), self.acts[i], self.precision,
+                               y=y, y32=None, yt=yt)
+                cur = y
+        return out32
+
+    # ---- backward ------------------------------------------------------------------------
+    def backward(self, dout32: torch.Tensor, xt: torch.Tensor, dw: List[torch.Tensor],
+                 db: List[torch.Tensor], dx32: Optional[torch.Tensor] = None):
+        """Gradients of a scalar loss given d loss / d output (fp32 [B, out_last]).
+
+        Requires a preceding ``forward(..., save=True)`` on the same batch.  xt: transposed staged
+        input [in, B].  dw[i] / db[i]: contiguous fp32 destinations (gradient-slab views).
+        dx32 (optional): fp32 [B, in] destination for the gradient w.r.t. the network input.
+        """
+        if self.acts[-1] != L.ACT["linear"]:
+            raise NotImplementedError("training through a non-linear output activation")
+        B = dout32.shape[0]
+        ws = self._ws
+        n_last = self.dims[-1]
+        dz = ws["dz"][0][:, :n_last]
+        dzt = ws["dzt"][0][:n_last]
+        ops.transpose_cast(dout32, dz, dzt)
+        for i in range(self.L - 1, -1, -1):
+            in_f, out_f = self.dims[i], self.dims[i + 1]
+            x_t = xt if i == 0 else ws["ht"][i - 1]
+            ops.fc_wgrad(dzt, x_t, dw[i], db[i], ws["wgrad"], self.precision)
+            if i > 0:
+                nxt = (self.L - i) % 2
+                dz_n = ws["dz"][nxt][:, :in_f]
+                dzt_n = ws["dzt"][nxt][:in_f]
+                ops.fc_dgrad(dz, self._wtc[i], ws["ht"][i - 1], self.acts[i - 1], self.precision,
+                             dx=dz_n, dx32=None, dxt=dzt_n)
+                dz, dzt = dz_n, dzt_n
+            elif dx32 is not None:
+                ops.fc_dgrad(dz, self._wtc[0], None, L.ACT["linear"], self.precision, dx=None,
+                             dx32=dx32, dxt=None)

@@ -1,0 +1,9 @@
+from .base import ModelBase  # noqa: F401
+from .critic import FullyConnectedCritic  # noqa: F401
+from .dqn import FullyConnectedDQN  # noqa: F401
+from .fully_connected_network import (  # noqa: F401
+    FloatFeatureFullyConnected,
+    FullyConnectedNetwork,
+    get_default_precision,
+    set_default_precision,
+)

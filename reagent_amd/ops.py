@@ -1,0 +1,191 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point of reagent_hip.h).
+
+All tensors must be on the GPU; leading dimensions are taken from ``stride(0)``.  Nothing here
+falls back to torch math.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def compute_dtype(precision: int) -> torch.dtype:
+    return F32 if precision == L.PREC_F32 else BF16
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == F32:
+        return L.DT_F32
+    if dtype == BF16:
+        return L.DT_BF16
+    raise L.ReagentHipError(f"unsupported dtype {dtype}")
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor"
+    return t.stride(0)
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None:
+            L.require_cuda(t)
+
+
+def fc_forward(x, w, bias, act: int, precision: int, y=None, y32=None, yt=None):
+    """y = act(x @ w.T + bias); any of y (compute type), y32 (fp32), yt (transposed) may be given."""
+    _chk_dev(x, w, bias, y, y32, yt)
+    batch, in_f = x.shape
+    out_f = w.shape[0]
+    ldy = _ld(y) if y is not None else (_ld(y32) if y32 is not None else out_f)
+    if y is not None and y32 is not None:
+        assert _ld(y) == _ld(y32)
+    L.check(
+        L.lib().rg_fc_forward(L.ptr(x), _ld(x), L.ptr(w), _ld(w), L.ptr(bias), L.ptr(y), L.ptr(y32), ldy,
+                              L.ptr(yt), _ld(yt) if yt is not None else 0, batch, out_f, in_f, act,
+                              precision, L.stream_ptr()),
+        "rg_fc_forward",
+    )
+
+
+def fc_dgrad(dz, wt, ht, act_below: int, precision: int, dx=None, dx32=None, dxt=None):
+    _chk_dev(dz, wt, ht, dx, dx32, dxt)
+    batch, out_f = dz.shape
+    in_f = wt.shape[0]
+    lddx = _ld(dx) if dx is not None else (_ld(dx32) if dx32 is not None else in_f)
+    L.check(
+        L.lib().rg_fc_dgrad(L.ptr(dz), _ld(dz), L.ptr(wt), _ld(wt), L.ptr(ht),
+                            _ld(ht) if ht is not None else 0, act_below, L.ptr(dx), L.ptr(dx32), lddx,
+                            L.ptr(dxt), _ld(dxt) if dxt is not None else 0, batch, in_f, out_f,
+                            precision, L.stream_ptr()),
+        "rg_fc_dgrad",
+    )
+
+
+def fc_wgrad_workspace_bytes(out_f, in_f, batch, precision) -> int:
+    return int(L.lib().rg_fc_wgrad_workspace_bytes(out_f, in_f, batch, precision))
+
+
+def fc_wgrad(dzt, xt, dw, db, workspace, precision: int):
+    """dw[out,in] (contiguous fp32) = dz^T x, db[out] = sum_b dz; inputs are transposed copies."""
+    _chk_dev(dzt, xt, dw, db, workspace)
+    out_f, batch = dzt.shape
+    in_f = xt.shape[0]
+    assert dw.is_contiguous() and dw.dtype == F32
+    L.check(
+        L.lib().rg_fc_wgrad(L.ptr(dzt), _ld(dzt), L.ptr(xt), _ld(xt), L.ptr(dw), L.ptr(db),
+                            L.ptr(workspace), workspace.numel() * workspace.element_size(), out_f, in_f,
+                            batch, precision, L.stream_ptr()),
+        "rg_fc_wgrad",
+    )
+
+
+def transpose_cast(src, dst=None, dst_t=None):
+    _chk_dev(src, dst, dst_t)
+    rows, cols = src.shape
+    out = dst if dst is not None else dst_t
+    L.check(
+        L.lib().rg_transpose_cast(L.ptr(src), dt_code(src.dtype), _ld(src), rows, cols, L.ptr(dst),
+                                  _ld(dst) if dst is not None else 0, L.ptr(dst_t),
+                                  _ld(dst_t) if dst_t is not None else 0, dt_code(out.dtype),
+                                  L.stream_ptr()),
+        "rg_transpose_cast",
+    )
+
+
+def replay_nstep(indices, terminal_u8, reward, decays, capacity, horizon, steps, next_indices,
+                 out_terminal, out_reward):
+    _chk_dev(indices, terminal_u8, reward, decays, steps, next_indices, out_terminal, out_reward)
+    L.check(
+        L.lib().rg_replay_nstep(L.ptr(indices), L.ptr(terminal_u8), L.ptr(reward), L.ptr(decays),
+                                capacity, horizon, indices.numel(), L.ptr(steps), L.ptr(next_indices),
+                                L.ptr(out_terminal), L.ptr(out_reward), L.stream_ptr()),
+        "rg_replay_nstep",
+    )
+
+
+def replay_gather(cols, capacity: int, stack: int, batch: int):
+    """cols: list of (src [C, ...], dst, indices[int64 B]) tensors; one launch per <=16 columns."""
+    for i in range(0, len(cols), L.MAX_GATHER_COLS):
+        chunk = cols[i : i + L.MAX_GATHER_COLS]
+        arr = (L.GatherCol * len(chunk))()
+        for j, (src, dst, idx) in enumerate(chunk):
+            _chk_dev(src, dst, idx)
+            assert src.is_contiguous() and dst.is_contiguous() and idx.dtype == torch.int64
+            row_elems = 1
+            for s in src.shape[1:]:
+                row_elems *= s
+            arr[j].src = src.data_ptr()
+            arr[j].dst = dst.data_ptr()
+            arr[j].indices = idx.data_ptr()
+            arr[j].row_elems = row_elems
+            arr[j].elem_bytes = src.element_size()
+        L.check(L.lib().rg_replay_gather(arr, len(chunk), capacity, stack, batch, L.stream_ptr()),
+                "rg_replay_gather")
+
+
+def normalize_dense(x, presence_u8, cols_dev, n_out, quantiles, out):
+    _chk_dev(x, presence_u8, cols_dev, quantiles, out)
+    L.check(
+        L.lib().rg_normalize_dense(L.ptr(x), _ld(x), L.ptr(presence_u8),
+                                   _ld(presence_u8) if presence_u8 is not None else 0, L.ptr(cols_dev),
+                                   n_out, L.ptr(quantiles), L.ptr(out), _ld(out), x.shape[0],
+                                   L.stream_ptr()),
+        "rg_normalize_dense",
+    )
+
+
+def dqn_head_partials(batch: int) -> int:
+    return int(L.lib().rg_dqn_head_partials(batch))
+
+
+def dqn_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma,
+             gamma_exponent, double_q, loss_type, dq, loss_partials, next_q=None, next_idx=None,
+             q_sel=None):
+    _chk_dev(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal,
+             gamma_exponent, dq, loss_partials, next_q, next_idx, q_sel)
+    batch, A = q.shape
+    for t in (q, qn_online, qn_target, action, next_mask, dq):
+        assert t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A)
+    for t in (reward, not_terminal, gamma_exponent):
+        assert t is None or (t.is_contiguous() and t.dtype == F32 and t.numel() == batch)
+    L.check(
+        L.lib().rg_dqn_head(L.ptr(q), L.ptr(qn_online), L.ptr(qn_target), L.ptr(action),
+                            L.ptr(next_mask), L.ptr(reward), L.ptr(reward_boosts), L.ptr(not_terminal),
+                            float(gamma), L.ptr(gamma_exponent), batch, A, int(double_q), loss_type,
+                            L.ptr(dq), L.ptr(loss_partials), L.ptr(next_q), L.ptr(next_idx),
+                            L.ptr(q_sel), L.stream_ptr()),
+        "rg_dqn_head",
+    )
+
+
+def reduce_sum(inp, n: int, scale: float, out):
+    _chk_dev(inp, out)
+    L.check(L.lib().rg_reduce_sum(L.ptr(inp), n, scale, L.ptr(out), L.stream_ptr()), "rg_reduce_sum")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
+              grad_scale=1.0, offset=0):
+    """Flat fp32 slabs; [offset, offset+n) is updated."""
+    _chk_dev(param, grad, exp_avg, exp_avg_sq)
+    o = offset * 4
+    L.check(
+        L.lib().rg_adam_step(param.data_ptr() + o, grad.data_ptr() + o, exp_avg.data_ptr() + o,
+                             exp_avg_sq.data_ptr() + o, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                             bc2_sqrt, grad_scale, L.stream_ptr()),
+        "rg_adam_step",
+    )
+
+
+def soft_update(target, source, n, tau, t_off=0, s_off=0):
+    _chk_dev(target, source)
+    L.check(
+        L.lib().rg_soft_update(target.data_ptr() + 4 * t_off, source.data_ptr() + 4 * s_off, n, tau,
+                               L.stream_ptr()),
+        "rg_soft_update",
+    )

@@ -1,0 +1,200 @@
+"""Optimizers of the hot path: fused Adam and the SoftUpdate pseudo-optimizer, both as
+``torch.optim.Optimizer`` subclasses so ``configure_optimizers()`` keeps the reference contract
+(reagent/optimizer/union.py:52-64, reagent/optimizer/soft_update.py:9-71)."""
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import _lib as _L
+from .. import ops
+from ..engine import ParamSlab, ensure_slab
+
+
+def _bump(params):
+    for p in params:
+        p._rg_version = getattr(p, "_rg_version", 0) + 1
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam arithmetic (torch/optim/adam.py::_single_tensor_adam) executed by ONE
+    rg_adam_step launch over the network's flat parameter slab.
+
+    The parameters of a group are re-homed into a ``ParamSlab`` on first use; ``state[p]`` exposes
+    ``step`` / ``exp_avg`` / ``exp_avg_sq`` as views of the flat moment slabs, so ``state_dict()``
+    has the layout of ``torch.optim.Adam``.  ``grad_scale`` (e.g. 1/world_size after a summed
+    all-reduce) is folded into the kernel.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 amsgrad=False, maximize=False):
+        if amsgrad or maximize:
+            raise NotImplementedError("amsgrad/maximize are not on the ReAgent hot path")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._slabs = {}
+        self.grad_scale = 1.0
+
+    def slab_for(self, gi: int) -> ParamSlab:
+        group = self.param_groups[gi]
+        slab = ensure_slab(group["params"])
+        if self._slabs.get(gi) is not slab or not hasattr(slab, "exp_avg"):
+            if not hasattr(slab, "exp_avg"):
+                slab.exp_avg = torch.zeros_like(slab.data)
+                slab.exp_avg_sq = torch.zeros_like(slab.data)
+            self._slabs[gi] = slab
+        if slab.exp_avg.device != slab.data.device:
+            slab.exp_avg = slab.exp_avg.to(slab.data.device)
+            slab.exp_avg_sq = slab.exp_avg_sq.to(slab.data.device)
+        return slab
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            slab = self.slab_for(gi)
+            beta1, beta2 = group["betas"]
+            # collect gradients into the flat slab (zero-copy when backward already wrote there)
+            runs: List[Tuple[int, int, int]] = []  # (offset, n, step)
+            gbase = slab.grad.data_ptr()
+            for i, p in enumerate(slab.params):
+                if p.grad is None:
+                    continue
+                off, n = slab.offsets[i], p.numel()
+                if p.grad.data_ptr() != gbase + 4 * off:
+                    slab.view(slab.grad, i).copy_(p.grad)
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = slab.view(slab.exp_avg, i)
+                    st["exp_avg_sq"] = slab.view(slab.exp_avg_sq, i)
+                    st["_step_int"] = 0
+                st["_step_int"] += 1
+                st["step"] += 1
+                step = st["_step_int"]
+                padded = (n + ParamSlab.ALIGN - 1) // ParamSlab.ALIGN * ParamSlab.ALIGN
+                if runs and runs[-1][0] + runs[-1][1] == off and runs[-1][2] == step:
+                    runs[-1] = (runs[-1][0], runs[-1][1] + padded, step)
+                else:
+                    runs.append((off, padded, step))
+            for off, n, step in runs:
+                bc1 = 1.0 - beta1**step
+                bc2_sqrt = math.sqrt(1.0 - beta2**step)
+                ops.adam_step(slab.data, slab.grad, slab.exp_avg, slab.exp_avg_sq, n, group["lr"],
+                              beta1, beta2, group["eps"], group["weight_decay"], bc1, bc2_sqrt,
+                              self.grad_scale, offset=off)
+            _bump(slab.params)
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        # keep p.grad aliased to the gradient slab: the HIP backward overwrites it every step
+        if set_to_none:
+            for group in self.param_groups:
+                for p in group["params"]:
+                    p.grad = None
+        else:
+            super().zero_grad(set_to_none=False)
+
+
+class SoftUpdate(torch.optim.Optimizer):
+    """target = tau * source + (1 - tau) * target  (reagent/optimizer/soft_update.py:9-71)."""
+
+    def __init__(self, target_params, source_params, tau: float = 0.1) -> None:
+        target_params = list(target_params)
+        source_params = list(source_params)
+        if len(target_params) != len(source_params):
+            raise ValueError("target and source must have the same number of parameters")
+        for t_param, s_param in zip(target_params, source_params):
+            if t_param.shape != s_param.shape:
+                raise ValueError("The shape of target parameter doesn't match that of the source")
+        params = target_params + source_params
+        defaults = dict(tau=tau, lr=1.0)
+        super().__init__(params, defaults)
+        for group in self.param_groups:
+            tau = group["tau"]
+            if tau > 1.0 or tau < 0.0:
+                raise ValueError(f"tau should be in [0.0, 1.0]; got {tau}")
+
+    @classmethod
+    def make_optimizer_scheduler(cls, target_params, source_params, tau):
+        su = cls(target_params, source_params, tau)
+        return {"optimizer": su}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            params = group["params"]
+            n = len(params)
+            tau = group["tau"]
+            tgt, src = params[: n // 2], params[n // 2 :]
+            # segments of consecutive pairs whose sources are one whole ParamSlab -> one launch
+            segs = []
+            for t, s in zip(tgt, src):
+                if t is s:
+                    continue
+                ss = getattr(s, "_rg_slab", None)
+                if segs and ss is not None and segs[-1][0] is ss:
+                    segs[-1][1].append(t)
+                    segs[-1][2].append(s)
+                else:
+                    segs.append((ss, [t], [s]))
+            for ss, ts, srcs in segs:
+                whole = ss is not None and len(ss.params) == len(srcs) and all(
+                    a is b for a, b in zip(ss.params, srcs)) and ss.is_bound()
+                if whole:
+                    tslab = ensure_slab(ts)
+                    ops.soft_update(tslab.data, ss.data, ss.total, tau)
+                else:
+                    for t, s in zip(ts, srcs):
+                        _L.require_cuda(t)
+                        _L.check(_L.lib().rg_soft_update(t.data_ptr(), s.data_ptr(), t.numel(), tau,
+                                                         _L.stream_ptr()), "rg_soft_update")
+            _bump(tgt)
+        return loss
+
+
+# ---- config objects (duck-typed stand-ins for reagent.optimizer.Optimizer__Union) -----------
+@dataclass
+class Adam:
+    """reagent/optimizer/uninferrable_optimizers.py:23-33 defaults."""
+
+    lr: float = 0.001
+    betas: Tuple[float, float] = (0.9, 0.999)
+    eps: float = 1e-08
+    weight_decay: float = 0
+    amsgrad: bool = False
+
+    def make_optimizer_scheduler(self, params):
+        return {
+            "optimizer": FusedAdam(params, lr=self.lr, betas=tuple(self.betas), eps=self.eps,
+                                   weight_decay=self.weight_decay, amsgrad=self.amsgrad)
+        }
+
+
+class Optimizer__Union:
+    """``Optimizer__Union(Adam=Adam(lr=...))`` / ``Optimizer__Union.default()`` as in
+    reagent/optimizer/union.py:52-64.  Only Adam is on the hot path."""
+
+    def __init__(self, Adam: Optional["Adam"] = None, **others):
+        if others:
+            raise NotImplementedError(f"only Adam is implemented natively, got {list(others)}")
+        self.Adam = Adam if Adam is not None else globals()["Adam"]()
+
+    @classmethod
+    def default(cls, **kwargs):
+        return cls(Adam=globals()["Adam"](**kwargs))
+
+    @property
+    def value(self):
+        return self.Adam
+
+    def make_optimizer_scheduler(self, params):
+        return self.value.make_optimizer_scheduler(params)

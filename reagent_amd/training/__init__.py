@@ -1,0 +1,2 @@
+from .dqn_trainer import BCQConfig, DQNTrainer  # noqa: F401
+from .reagent_lightning_module import ReAgentLightningModule  # noqa: F401

@@ -1,0 +1,268 @@
+"""DQNTrainer with the constructor / generator / attribute surface of
+reagent/training/dqn_trainer.py:27-379, executing the step on the HIP kernels.
+
+One training step (reference :241-304, algorithmic form of SURVEY.md §8d: 3 forwards + 1 backward):
+    q'_online = q_network(next_state)            rg_fc_forward x L        (no saved activations)
+    q'_target = q_network_target(next_state)     rg_fc_forward x L
+    q         = q_network(state)                 rg_fc_forward x L        (saves transposed acts)
+    loss, dq  = TD head                          rg_dqn_head + rg_reduce_sum
+    grads     = backward                         rg_fc_wgrad / rg_fc_dgrad x L
+    Adam, soft update                            rg_adam_step, rg_soft_update (via the optimizers)
+The CPE-only 4th forward of the reference (:268) is dead when CPE is off and is not executed.
+"""
+import logging
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import _lib as L
+from .. import ops
+from ..core import types as rlt
+from ..core.parameters import EvaluationParameters, RLParameters
+from ..engine import ensure_slab
+from ..optimizer import Optimizer__Union, SoftUpdate
+from .dqn_trainer_base import DQNTrainerBaseLightning
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass(frozen=True)
+class BCQConfig:
+    drop_threshold: float = 0.1
+
+
+class _HipLoss(torch.autograd.Function):
+    """Scalar loss whose backward runs the HIP backward pass and writes ``.grad`` in place."""
+
+    @staticmethod
+    def forward(ctx, owner, loss_buf, *params):
+        ctx.owner = owner
+        return loss_buf.detach().clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.owner._hip_backward(grad_out)
+        return (None, None) + (None,) * len(ctx.owner._hip_params)
+
+
+class DQNTrainer(DQNTrainerBaseLightning):
+    def __init__(
+        self,
+        q_network,
+        q_network_target,
+        reward_network,
+        q_network_cpe=None,
+        q_network_cpe_target=None,
+        metrics_to_score=None,
+        evaluation: Optional[EvaluationParameters] = None,
+        imitator=None,
+        actions: Optional[List[str]] = None,
+        rl: Optional[RLParameters] = None,
+        double_q_learning: bool = True,
+        bcq: Optional[BCQConfig] = None,
+        minibatch_size: int = 1024,
+        minibatches_per_step: int = 1,
+        optimizer: Optional[Optimizer__Union] = None,
+    ) -> None:
+        # @resolve_defaults of the reference: default_factory values materialised here
+        evaluation = evaluation if evaluation is not None else EvaluationParameters()
+        rl = rl if rl is not None else RLParameters()
+        actions = actions if actions is not None else []
+        optimizer = optimizer if optimizer is not None else Optimizer__Union.default()
+        super().__init__(rl, metrics_to_score=metrics_to_score, actions=actions,
+                         evaluation_parameters=evaluation)
+        assert self._actions is not None, "Discrete-action DQN needs action names"
+        self.double_q_learning = double_q_learning
+        self.minibatch_size = minibatch_size
+        self.minibatches_per_step = minibatches_per_step or 1
+
+        self.q_network = q_network
+        self.q_network_target = q_network_target
+        self.q_network_optimizer = optimizer
+        self._reject_cpe(reward_network, q_network_cpe, q_network_cpe_target)
+
+        self.bcq = bcq is not None
+        if self.bcq:
+            raise NotImplementedError("batch-constrained q-learning needs the imitator net (not on the hot path)")
+        self._ws_batch = -1
+        self._dp_group = None
+        self._dp_world = 1
+
+    # ---- optimizers (dqn_trainer.py:119-155) ------------------------------------------------
+    def configure_optimizers(self):
+        optimizers = []
+        target_params = list(self.q_network_target.parameters())
+        source_params = list(self.q_network.parameters())
+        optimizers.append(self.q_network_optimizer.make_optimizer_scheduler(self.q_network.parameters()))
+        optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
+        return optimizers
+
+    # ---- engine -------------------------------------------------------------------------------
+    def _engine(self, batch: int, device):
+        """Slabs, FC stacks and step buffers (re)built lazily for the current batch size/device."""
+        self._hip_params = list(self.q_network.parameters())
+        self._slab = ensure_slab(self._hip_params)
+        self._qs = self.q_network.fc.stack()
+        self._ts = self.q_network_target.fc.stack()
+        if self._ws_batch != batch or self._q.device != device:
+            A = self.num_actions
+            f32 = dict(dtype=torch.float32, device=device)
+            self._q = torch.empty(batch, A, **f32)
+            self._qn_online = torch.empty(batch, A, **f32)
+            self._qn_target = torch.empty(batch, A, **f32)
+            self._dq = torch.empty(batch, A, **f32)
+            self._loss_partials = torch.empty(ops.dqn_head_partials(batch), **f32)
+            self._loss = torch.empty(1, **f32)
+            self._next_q = torch.empty(batch, **f32)
+            self._next_idx = torch.empty(batch, dtype=torch.int64, device=device)
+            self._q_sel = torch.empty(batch, **f32)
+            self._ws_batch = batch
+        # weight/bias gradient destinations = views of the flat gradient slab, in layer order
+        lin = self.q_network.fc.linears()
+        index = {id(p): i for i, p in enumerate(self._hip_params)}
+        self._dw = [self._slab.view(self._slab.grad, index[id(l.weight)]) for l in lin]
+        self._db = [self._slab.view(self._slab.grad, index[id(l.bias)]) for l in lin]
+
+    @staticmethod
+    def _f32c(t: torch.Tensor) -> torch.Tensor:
+        t = t if t.dtype == torch.float32 else t.float()
+        return t if t.is_contiguous() else t.contiguous()
+
+    def _hip_forward(self, b) -> torch.Tensor:
+        state = self._f32c(b.state.float_features)
+        next_state = self._f32c(b.next_state.float_features)
+        L.require_cuda(state, "training_batch.state")
+        B, dev = state.shape[0], state.device
+        self._engine(B, dev)
+        qs, ts = self._qs, self._ts
+        qs.stage_weights(need_transposed=True)
+        ts.stage_weights(need_transposed=False)
+        xs, self._xs_t = qs.stage_input(state, need_transposed=True)
+        xn, _ = qs.stage_input(next_state, need_transposed=False)
+        qs.forward(xn, self._qn_online, save=False)
+        ts.forward(xn, self._qn_target, save=False)
+        qs.forward(xs, self._q, save=True)
+
+        action = self._f32c(b.action)
+        if self.maxq_learning:
+            next_mask = self._f32c(b.possible_next_actions_mask)
+        else:  # SARSA: the taken next action is the only "possible" one (dqn_trainer.py:218-224)
+            next_mask = self._f32c(b.next_action)
+        gamma_exp = None
+        if self.use_seq_num_diff_as_time_diff:
+            assert self.multi_steps is None
+            gamma_exp = self._f32c(b.time_diff).reshape(-1)
+        if self.multi_steps is not None:
+            assert b.step is not None
+            gamma_exp = self._f32c(b.step).reshape(-1)
+        boosts = self.reward_boosts.reshape(-1) if self._has_reward_boost else None
+        ops.dqn_head(self._q, self._qn_online, self._qn_target, action, next_mask,
+                     self._f32c(b.reward).reshape(-1), boosts, self._f32c(b.not_terminal).reshape(-1),
+                     self.gamma, gamma_exp, self.double_q_learning, self._loss_type, self._dq,
+                     self._loss_partials, self._next_q, self._next_idx, self._q_sel)
+        ops.reduce_sum(self._loss_partials, self._loss_partials.numel(), 1.0 / B, self._loss)
+        self.all_action_scores = self._q
+        return self._loss
+
+    def _hip_backward(self, grad_out=None):
+        if grad_out is not None:
+            self._dq.mul_(grad_out)
+        self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
+        if self._dp_group is not None:
+            torch.distributed.all_reduce(self._slab.grad, group=self._dp_group)
+        # publish the gradients: p.grad aliases the slab (accumulate into foreign .grad tensors)
+        base = self._slab.grad.data_ptr()
+        for i, p in enumerate(self._hip_params):
+            gv = self._slab.view(self._slab.grad, i)
+            if p.grad is None or p.grad.data_ptr() == base + 4 * self._slab.offsets[i]:
+                p.grad = gv
+            else:
+                p.grad.add_(gv)
+
+    # ---- data parallel -------------------------------------------------------
+    def enable_data_parallel(self, process_group=None):
+        """All-reduce(sum) the flat fp32 gradient slab over RCCL after every backward; the 1/world
+        factor is folded into the Adam kernel (FusedAdam.grad_scale)."""
+        import torch.distributed as dist
+
+        self._dp_group = process_group if process_group is not None else dist.group.WORLD
+        self._dp_world = dist.get_world_size(self._dp_group)
+        return self
+
+    # ---- reference surface --------------------------------------------------------------------
+    @torch.no_grad()
+    def get_detached_model_outputs(self, state) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """dqn_trainer.py:157-164"""
+        return self.q_network(state), self.q_network_target(state)
+
+    def compute_discount_tensor(self, batch, boosted_rewards: torch.Tensor):
+        """dqn_trainer.py:166-177 — utility entry point; the step evaluates it inside rg_dqn_head."""
+        discount_tensor = torch.full_like(boosted_rewards, self.gamma)
+        if self.use_seq_num_diff_as_time_diff:
+            assert self.multi_steps is None
+            discount_tensor = torch.pow(self.gamma, batch.time_diff.float())
+        if self.multi_steps is not None:
+            assert batch.step is not None
+            discount_tensor = torch.pow(self.gamma, batch.step.float())
+        return discount_tensor
+
+    def compute_td_loss(self, batch, boosted_rewards=None, discount_tensor=None):
+        """dqn_trainer.py:179-239.  Reward boosting and discounting are recomputed inside the fused
+        head from the batch itself; the two extra arguments are accepted for signature parity."""
+        loss_buf = self._hip_forward(batch)
+        return _HipLoss.apply(self, loss_buf, *self._hip_params)
+
+    def train_step_gen(self, training_batch: rlt.DiscreteDqnInput, batch_idx: int):
+        self._check_input(training_batch)
+        td_loss = self.compute_td_loss(training_batch)
+        yield td_loss
+        td_loss = td_loss.detach()
+        self._log_dqn(td_loss, training_batch)
+        yield self.soft_update_result()
+
+    def _log_dqn(self, td_loss, training_batch):
+        """dqn_trainer.py:306-347; evaluated only when a reporter / logger is attached so the
+        default (no-op reporter) step has no logging kernels and no host syncs."""
+        from .reagent_lightning_module import _NoOpReporter
+
+        if isinstance(self._reporter, _NoOpReporter) and not self.logger:
+            return
+        rewards = self.boost_rewards(training_batch.reward, training_batch.action)
+        logged_action_idxs = torch.argmax(training_batch.action, dim=1, keepdim=True)
+        mask = training_batch.possible_actions_mask if self.maxq_learning else training_batch.action
+        model_action_idxs = self.get_max_q_values(self.all_action_scores, mask.float())[1]
+        self.reporter.log(
+            td_loss=td_loss,
+            logged_actions=logged_action_idxs,
+            logged_propensities=training_batch.extras.action_probability,
+            logged_rewards=rewards,
+            logged_values=None,
+            model_values=self.all_action_scores,
+            model_values_on_logged_actions=None,
+            model_action_idxs=model_action_idxs,
+        )
+
+    # ---- fused native step (what bench.py and the native loop drive) --------------------------
+    def native_optimizers(self):
+        if getattr(self, "_native_opts", None) is None:
+            self._native_opts = [o["optimizer"] for o in self.configure_optimizers()]
+        return self._native_opts
+
+    @torch.no_grad()
+    def train_step_native(self, training_batch) -> torch.Tensor:
+        """forward + head + backward + Adam + soft update with no autograd graph, no generator and
+        no host synchronisation.  Returns the device-resident loss scalar (shape [1])."""
+        adam, soft = self.native_optimizers()
+        loss = self._hip_forward(training_batch)
+        for p in self._hip_params:
+            p.grad = None
+        self._hip_backward(None)
+        adam.grad_scale = 1.0 / self._dp_world
+        adam.step()
+        soft.step()
+        self.all_batches_processed += 1
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        raise NotImplementedError("CPE / EvaluationDataPage is outside the hot path (SURVEY.md §3.4)")

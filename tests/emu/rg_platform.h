@@ -18,6 +18,9 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct __attribute__((aligned(16))) uint4 {
+  unsigned x, y, z, w;
+};
 typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
