@@ -104,6 +104,14 @@ typedef struct {
 int rg_replay_gather(const rg_gather_col* cols /*host*/, int ncols, int64_t capacity, int stack,
                      int batch, rg_stream_t stream);
 
+/* DiscreteDqnInputMaker (reagent/gym/preprocessors/trainer_preprocessor.py:72-97,118-158):
+ * action / next_action [B] int64 -> one-hot fp32 [B, A] (next_action rows zeroed where terminal),
+ * not_terminal [B] = 1 - terminal, action_probability [B] = exp(log_prob) (nullable). */
+int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const uint8_t* terminal,
+                      const float* log_prob, int batch, int num_actions, float* action_onehot,
+                      float* next_action_onehot, float* not_terminal, float* action_probability,
+                      rg_stream_t stream);
+
 /* ---- dense feature normalization ---------------------------------------------------------- */
 
 /* Preprocessor.forward, reagent/preprocessing/preprocessor.py:115-170 (+ _preprocess_* :197-525).

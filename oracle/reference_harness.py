@@ -1,0 +1,143 @@
+"""TEST INFRASTRUCTURE (oracle).  Drives the UNMODIFIED reference trainers from /root/reference.
+
+Used only in the build container (where /root/reference exists) to (a) generate the golden
+fixtures committed under tests/golden/ (oracle/make_golden.py) and (b) validate the restated
+oracle (oracle/restated.py).  It emulates the optimizer loop of pytorch-lightning 1.6.0 — a pinned,
+un-vendored dependency of the reference (setup.cfg:32) whose call site is
+reagent/workflow/utils.py:155-165 — as described in SURVEY.md §3.3 / §8(c):
+    for each optimizer i (in configure_optimizers() order):
+        toggle_optimizer(i)  (requires_grad=False on parameters owned only by other optimizers)
+        loss = training_step(batch, batch_idx, i); opt.zero_grad(); loss.backward(); opt.step()
+        untoggle
+No reference test pins these stepping semantics ("parity unpinned" at the Lightning boundary).
+"""
+from typing import List
+
+import torch
+
+from . import stubs
+
+
+def _install():
+    if not stubs.reference_available():
+        raise RuntimeError("reference tree not available (expected in the build container only)")
+    stubs.install()
+
+
+class PLLoop:
+    """pytorch-lightning 1.6 automatic-optimization loop for ONE module, CPU."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+        self.optimizers = [o["optimizer"] for o in trainer.configure_optimizers()]
+        self.batch_idx = 0
+
+        class _Logger:  # SACTrainer calls self.logger.log_metrics unconditionally (:343)
+            def log_metrics(self, *a, **k):
+                pass
+
+        trainer.logger = _Logger()
+
+    def _toggle(self, idx):
+        saved = {}
+        for opt in self.optimizers:
+            for g in opt.param_groups:
+                for p in g["params"]:
+                    if p not in saved:
+                        saved[p] = p.requires_grad
+                        p.requires_grad = False
+        for g in self.optimizers[idx].param_groups:
+            for p in g["params"]:
+                p.requires_grad = saved[p]
+        return saved
+
+    def step(self, batch) -> List[torch.Tensor]:
+        losses = []
+        for i, opt in enumerate(self.optimizers):
+            saved = self._toggle(i)
+            loss = self.trainer.training_step(batch, self.batch_idx, i)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            for p, rg in saved.items():
+                p.requires_grad = rg
+            losses.append(loss.detach().clone())
+        self.batch_idx += 1
+        return losses
+
+
+def make_rl_parameters(**kw):
+    _install()
+    from reagent.core.parameters import RLParameters
+
+    return RLParameters(**kw)
+
+
+def make_adam(lr=1e-3, **kw):
+    _install()
+    from reagent.optimizer.union import Optimizer__Union
+
+    return Optimizer__Union.default(lr=lr, **kw)
+
+
+def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_q=True, seed=0,
+              num_atoms=None):
+    """Reference FullyConnectedDQN (+ target) and DQNTrainer / QRDQNTrainer, CPE off."""
+    _install()
+    from reagent.core.parameters import EvaluationParameters
+    from reagent.models.dqn import FullyConnectedDQN
+
+    torch.manual_seed(seed)
+    q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
+    qt = q.get_target_network()
+    actions = [str(i) for i in range(num_actions)]
+    common = dict(actions=actions, rl=make_rl_parameters(**rl_kwargs), double_q_learning=double_q,
+                  optimizer=make_adam(lr), evaluation=EvaluationParameters(calc_cpe_in_training=False))
+    if num_atoms is None:
+        from reagent.training.dqn_trainer import DQNTrainer
+
+        trainer = DQNTrainer(q, qt, None, **common)
+    else:
+        from reagent.training.qrdqn_trainer import QRDQNTrainer
+
+        trainer = QRDQNTrainer(q, qt, num_atoms=num_atoms, **common)
+    return trainer
+
+
+def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, **trainer_kw):
+    _install()
+    from reagent.models.actor import GaussianFullyConnectedActor
+    from reagent.models.critic import FullyConnectedCritic
+    from reagent.training.sac_trainer import SACTrainer
+
+    torch.manual_seed(seed)
+    actor = GaussianFullyConnectedActor(state_dim, action_dim, sizes, activations)
+    q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
+    q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
+    return SACTrainer(actor, q1, q2, rl=make_rl_parameters(**rl_kwargs), q_network_optimizer=make_adam(lr),
+                      actor_network_optimizer=make_adam(lr), alpha_optimizer=make_adam(lr), **trainer_kw)
+
+
+def dqn_batch_to_reference(b: dict):
+    """dict of tensors (see oracle/synthetic.py) -> reference rlt.DiscreteDqnInput."""
+    _install()
+    import reagent.core.types as rlt
+
+    return rlt.DiscreteDqnInput(
+        state=rlt.FeatureData(b["state"]), next_state=rlt.FeatureData(b["next_state"]),
+        reward=b["reward"], time_diff=b["time_diff"], step=b["step"], not_terminal=b["not_terminal"],
+        action=b["action"], next_action=b["next_action"], possible_actions_mask=b["possible_actions_mask"],
+        possible_next_actions_mask=b["possible_next_actions_mask"],
+        extras=rlt.ExtraData(action_probability=torch.ones_like(b["reward"])),
+    )
+
+
+def policy_batch_to_reference(b: dict):
+    _install()
+    import reagent.core.types as rlt
+
+    return rlt.PolicyNetworkInput(
+        state=rlt.FeatureData(b["state"]), next_state=rlt.FeatureData(b["next_state"]),
+        reward=b["reward"], time_diff=b["time_diff"], step=b["step"], not_terminal=b["not_terminal"],
+        action=rlt.FeatureData(b["action"]), next_action=rlt.FeatureData(b["next_action"]), extras=None,
+    )

@@ -112,6 +112,33 @@ __global__ void replay_gather_stack_kernel(GatherTable t, int64_t capacity, int 
   }
 }
 
+// DiscreteDqnInputMaker.__call__ / one_hot_actions,
+// reagent/gym/preprocessors/trainer_preprocessor.py:72-97,118-158, in one pass:
+//   action      = one_hot(action)                      (fp32)
+//   next_action = one_hot(next_action), zero rows where terminal
+//   not_terminal = 1 - terminal ;  action_probability = exp(log_prob)
+__global__ void make_dqn_input_kernel(const int64_t* __restrict__ action,
+                                      const int64_t* __restrict__ next_action,
+                                      const uint8_t* __restrict__ terminal,
+                                      const float* __restrict__ log_prob, int batch, int A,
+                                      float* __restrict__ action_1h, float* __restrict__ next_action_1h,
+                                      float* __restrict__ not_terminal,
+                                      float* __restrict__ action_probability) {
+  const long total = (long)batch * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long b = i / A;
+    const int a = (int)(i % A);
+    const bool term = terminal[b] != 0;
+    action_1h[i] = (action[b] == a) ? 1.f : 0.f;
+    next_action_1h[i] = (!term && next_action[b] == a) ? 1.f : 0.f;
+    if (a == 0) {
+      not_terminal[b] = 1.0f - (term ? 1.f : 0.f);
+      if (action_probability) action_probability[b] = expf(log_prob[b]);
+    }
+  }
+}
+
 }  // namespace rg
 
 using namespace rg;
@@ -154,6 +181,22 @@ int rg_replay_gather(const rg_gather_col* cols, int ncols, int64_t capacity, int
     RG_LAUNCH(replay_gather_stack_kernel, dim3(gx, ncols), dim3(256), (hipStream_t)stream, t,
               capacity, stack, batch);
   }
+  return (int)hipGetLastError();
+}
+
+int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const uint8_t* terminal,
+                      const float* log_prob, int batch, int num_actions, float* action_onehot,
+                      float* next_action_onehot, float* not_terminal, float* action_probability,
+                      rg_stream_t stream) {
+  if (!action || !next_action || !terminal || !action_onehot || !next_action_onehot || !not_terminal ||
+      batch < 0 || num_actions <= 0 || (action_probability && !log_prob))
+    return RG_EINVAL;
+  if (batch == 0) return RG_OK;
+  long blocks = ((long)batch * num_actions + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  RG_LAUNCH(make_dqn_input_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, action,
+            next_action, terminal, log_prob, batch, num_actions, action_onehot, next_action_onehot,
+            not_terminal, action_probability);
   return (int)hipGetLastError();
 }
 

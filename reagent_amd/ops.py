@@ -129,6 +129,18 @@ def replay_gather(cols, capacity: int, stack: int, batch: int):
                 "rg_replay_gather")
 
 
+def make_dqn_input(action, next_action, terminal, log_prob, num_actions, action_1h, next_action_1h,
+                   not_terminal, action_probability=None):
+    _chk_dev(action, next_action, terminal, log_prob, action_1h, next_action_1h, not_terminal,
+             action_probability)
+    L.check(
+        L.lib().rg_make_dqn_input(L.ptr(action), L.ptr(next_action), L.ptr(terminal), L.ptr(log_prob),
+                                  action.numel(), num_actions, L.ptr(action_1h), L.ptr(next_action_1h),
+                                  L.ptr(not_terminal), L.ptr(action_probability), L.stream_ptr()),
+        "rg_make_dqn_input",
+    )
+
+
 def normalize_dense(x, presence_u8, cols_dev, n_out, quantiles, out):
     _chk_dev(x, presence_u8, cols_dev, quantiles, out)
     L.check(

@@ -1,0 +1,88 @@
+"""Replay-buffer tuple -> trainer input makers with the call surface of
+reagent/gym/preprocessors/trainer_preprocessor.py:100-227, running on the device the batch lives on.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..core import types as rlt
+from ..core.parameters import CONTINUOUS_TRAINING_ACTION_RANGE
+
+
+class DiscreteDqnInputMaker:
+    """trainer_preprocessor.py:100-158; the one-hot / not_terminal / exp(log_prob) work is one
+    rg_make_dqn_input launch."""
+
+    def __init__(self, num_actions: int, trainer_preprocessor=None):
+        self.num_actions = num_actions
+        self.trainer_preprocessor = trainer_preprocessor
+
+    def __call__(self, batch):
+        action, next_action, terminal = batch.action, batch.next_action, batch.terminal
+        assert (len(action.shape) == 2 and action.shape[1] == 1 and next_action.shape == action.shape), (
+            f"Must be action with stack_size = 1, but got shapes {action.shape}, {next_action.shape}"
+        )
+        B, dev, A = action.shape[0], action.device, self.num_actions
+        f32 = dict(dtype=torch.float32, device=dev)
+        a1h, na1h = torch.empty(B, A, **f32), torch.empty(B, A, **f32)
+        not_terminal, prob = torch.empty(B, 1, **f32), torch.empty(B, 1, **f32)
+        term_u8 = terminal.view(torch.uint8) if terminal.dtype == torch.bool else terminal.to(torch.uint8)
+        ops.make_dqn_input(action.reshape(-1).contiguous(), next_action.reshape(-1).contiguous(),
+                           term_u8.reshape(-1).contiguous(), batch.log_prob.reshape(-1).float().contiguous(),
+                           A, a1h, na1h, not_terminal, prob)
+        if self.trainer_preprocessor is not None:
+            state = self.trainer_preprocessor(batch.state)
+            next_state = self.trainer_preprocessor(batch.next_state)
+        else:
+            state = rlt.FeatureData(float_features=batch.state)
+            next_state = rlt.FeatureData(float_features=batch.next_state)
+        try:
+            possible_actions_mask = batch.possible_actions_mask.float()
+        except AttributeError:
+            possible_actions_mask = torch.ones_like(a1h)
+        try:
+            possible_next_actions_mask = batch.next_possible_actions_mask.float()
+        except AttributeError:
+            possible_next_actions_mask = torch.ones_like(na1h)
+        return rlt.DiscreteDqnInput(
+            state=state, action=a1h, next_state=next_state, next_action=na1h,
+            possible_actions_mask=possible_actions_mask,
+            possible_next_actions_mask=possible_next_actions_mask, reward=batch.reward,
+            not_terminal=not_terminal, step=None, time_diff=None,
+            extras=rlt.ExtraData(mdp_id=None, sequence_number=None, action_probability=prob,
+                                 max_num_actions=None, metrics=None),
+        )
+
+
+def rescale_actions(actions, new_min, new_max, prev_min, prev_max):
+    """reagent/training/utils.py:13-29 (range asserts dropped: they force a host sync)."""
+    prev_range = prev_max - prev_min
+    new_range = new_max - new_min
+    return ((actions - prev_min) / prev_range) * new_range + new_min
+
+
+class PolicyNetworkInputMaker:
+    """trainer_preprocessor.py:161-227 (dense path; candidate-doc features are out of scope)."""
+
+    def __init__(self, action_low: np.ndarray, action_high: np.ndarray):
+        self.action_low = torch.tensor(action_low)
+        self.action_high = torch.tensor(action_high)
+        (train_low, train_high) = CONTINUOUS_TRAINING_ACTION_RANGE
+        self.train_low = torch.tensor(train_low)
+        self.train_high = torch.tensor(train_high)
+
+    def __call__(self, batch):
+        dev = batch.action.device
+        lo, hi = self.action_low.to(dev), self.action_high.to(dev)
+        tl, th = self.train_low.to(dev), self.train_high.to(dev)
+        not_terminal = 1.0 - batch.terminal.float()
+        action = rescale_actions(batch.action, new_min=tl, new_max=th, prev_min=lo, prev_max=hi)
+        next_action = rescale_actions(batch.next_action, new_min=tl, new_max=th, prev_min=lo, prev_max=hi)
+        next_action = next_action * not_terminal  # zero rows of terminal transitions (:190-198)
+        return rlt.PolicyNetworkInput(
+            state=rlt.FeatureData(batch.state), next_state=rlt.FeatureData(batch.next_state),
+            action=rlt.FeatureData(action), next_action=rlt.FeatureData(next_action), reward=batch.reward,
+            not_terminal=not_terminal, step=None, time_diff=None,
+            extras=rlt.ExtraData(mdp_id=None, sequence_number=None, action_probability=batch.log_prob.exp(),
+                                 max_num_actions=None, metrics=None),
+        )

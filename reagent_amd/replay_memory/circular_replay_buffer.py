@@ -1,0 +1,324 @@
+"""Device-resident circular replay buffer with the surface of
+reagent/replay_memory/circular_replay_buffer.py:310-890 (dense columns).
+
+The column store lives in HBM (one tensor ``(capacity, *shape)`` per key, dtype inferred from the
+first ``add`` exactly as DenseMetadata.create_from_example :98-106 does); sampling is two kernel
+launches — rg_replay_nstep (steps / next index / terminal / n-step reward) and rg_replay_gather
+(every output column in one launch) — instead of ~17 advanced-indexing ops, and the result is
+bit-identical to the reference's namedtuple (same field names, order, dtypes and (B,1) shapes).
+Validity bookkeeping (add rules :468-522) is host-side integer logic, mirrored to the device lazily.
+
+Outside the dense hot path and rejected explicitly: id-list / id-score-list (sparse) elements,
+``return_as_timeline_format`` and ``return_everything_as_stack``.
+"""
+import collections
+import logging
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import ops
+
+logger = logging.getLogger(__name__)
+
+REQUIRED_KEYS = ["observation", "action", "reward", "terminal"]
+
+_NP2TORCH = {
+    np.dtype("float32"): torch.float32,
+    np.dtype("float64"): torch.float32,
+    np.dtype("int64"): torch.int64,
+    np.dtype("int32"): torch.int32,
+    np.dtype("int16"): torch.int16,
+    np.dtype("int8"): torch.int8,
+    np.dtype("uint8"): torch.uint8,
+    np.dtype("bool"): torch.bool,
+    np.dtype("float16"): torch.float16,
+}
+
+
+class ReplayBuffer:
+    def __init__(
+        self,
+        stack_size: int = 1,
+        replay_capacity: int = 10000,
+        batch_size: int = 1,
+        return_everything_as_stack: bool = False,
+        return_as_timeline_format: bool = False,
+        update_horizon: int = 1,
+        gamma: float = 0.99,
+        device: Optional[torch.device] = None,
+    ) -> None:
+        if replay_capacity < update_horizon + stack_size:
+            raise ValueError("There is not enough capacity to cover update_horizon and stack_size.")
+        if return_as_timeline_format or return_everything_as_stack:
+            raise NotImplementedError(
+                "return_as_timeline_format / return_everything_as_stack are not on the MI355X hot path"
+            )
+        self._initialized_buffer = False
+        self._stack_size = stack_size
+        self._return_everything_as_stack = return_everything_as_stack
+        self._return_as_timeline_format = return_as_timeline_format
+        self._replay_capacity = replay_capacity
+        self._batch_size = batch_size
+        self._update_horizon = update_horizon
+        self._gamma = gamma
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+
+        self.add_count = np.array(0)
+        # `_decays` is computed by torch exactly as the reference does (:373) so that the n-step
+        # reward product is bit-identical
+        self._decays = (self._gamma ** torch.arange(self._update_horizon)).unsqueeze(0)
+        self._decays_dev = None
+        self._valid_host = np.zeros(self._replay_capacity, dtype=bool)
+        self._terminal_host = np.zeros(self._replay_capacity, dtype=bool)
+        self._valid_dirty = True
+        self._valid_indices_dev = None
+        self._num_valid_indices = 0
+        self._num_transitions_in_current_episode = 0
+
+        self._store: Dict[str, torch.Tensor] = {}
+        self._shapes: Dict[str, tuple] = {}
+        self._np_dtypes: Dict[str, np.dtype] = {}
+        self._extra_keys: List[str] = []
+        self._transition_elements: List[str] = []
+        self._batch_type = collections.namedtuple("filler", [])
+        self._zero_transition = {}
+
+    # ---- storage -----------------------------------------------------------------------------
+    def initialize_buffer(self, **kwargs):
+        kwarg_keys = set(kwargs.keys())
+        assert set(REQUIRED_KEYS).issubset(kwarg_keys), f"{kwarg_keys} doesn't contain all of {REQUIRED_KEYS}"
+        # deterministic order (the reference iterates a set, :394; consumers address fields by name)
+        self._extra_keys = sorted(kwarg_keys - set(REQUIRED_KEYS))
+        for k in REQUIRED_KEYS + self._extra_keys:
+            ex = kwargs[k]
+            if isinstance(ex, (dict, torch.Tensor)):
+                raise ValueError(f"Unable to deduce a dense type for {k}: sparse/tensor inputs are not supported")
+            arr = np.array(ex)
+            dtype = np.dtype("float32") if arr.dtype == np.dtype("float64") else arr.dtype
+            if dtype not in _NP2TORCH:
+                raise ValueError(f"Unable to deduce type for {k}: {ex}")
+            self._shapes[k], self._np_dtypes[k] = arr.shape, dtype
+            # `terminal` is only ever consumed through `.to(torch.bool)` (:678, :765): keep it as
+            # one byte per transition whatever integer type the caller passes
+            tdtype = torch.bool if k == "terminal" else _NP2TORCH[dtype]
+            self._store[k] = torch.zeros((self._replay_capacity, *arr.shape), dtype=tdtype,
+                                         device=self.device)
+        self._transition_elements = self.get_transition_elements()
+        self._batch_type = collections.namedtuple("batch_type", self._transition_elements)
+        self._zero_transition = {k: np.zeros(self._shapes[k], dtype=self._np_dtypes[k]) for k in self._store}
+        self._initialized_buffer = True
+
+    @property
+    def size(self) -> int:
+        return self._num_valid_indices
+
+    def set_index_valid_status(self, idx: int, is_valid: bool):
+        old_valid = self._valid_host[idx]
+        if not old_valid and is_valid:
+            self._num_valid_indices += 1
+        elif old_valid and not is_valid:
+            self._num_valid_indices -= 1
+        assert self._num_valid_indices >= 0, f"{self._num_valid_indices} is negative"
+        self._valid_host[idx] = is_valid
+        self._valid_dirty = True
+
+    def get_add_args_signature(self):
+        return list(self._store.keys())
+
+    def _check_args_length(self, **kwargs):
+        if len(kwargs) != len(self._store):
+            raise ValueError(f"Add expects: {self.get_add_args_signature()}; received {kwargs}")
+
+    def _check_add_types(self, **kwargs):
+        self._check_args_length(**kwargs)
+        for k in self._store:
+            v = kwargs[k]
+            assert not isinstance(v, (dict, torch.Tensor)), f"{k}: {type(v)} is dict or torch.Tensor"
+            arr = np.array(v)
+            dtype = np.dtype("float32") if arr.dtype == np.dtype("float64") else arr.dtype
+            assert arr.shape == self._shapes[k] and dtype == self._np_dtypes[k], (
+                f"{k}: Expected {self._shapes[k]} {self._np_dtypes[k]}, got {arr.shape} {dtype}"
+            )
+
+    def add(self, **kwargs):
+        """circular_replay_buffer.py:468-522 (validity rules) — one transition per call."""
+        if not self._initialized_buffer:
+            self.initialize_buffer(**kwargs)
+        self._check_add_types(**kwargs)
+        last_idx = (self.cursor() - 1) % self._replay_capacity
+        if self.is_empty() or self._terminal_host[last_idx]:
+            self._num_transitions_in_current_episode = 0
+            for _ in range(self._stack_size - 1):
+                self._add(**self._zero_transition)
+        cur_idx = self.cursor()
+        self.set_index_valid_status(idx=cur_idx, is_valid=False)
+        if self._num_transitions_in_current_episode >= self._update_horizon:
+            idx = (cur_idx - self._update_horizon) % self._replay_capacity
+            self.set_index_valid_status(idx=idx, is_valid=True)
+        self._add(**kwargs)
+        self._num_transitions_in_current_episode += 1
+        for i in range(self._stack_size - 1):
+            idx = (self.cursor() + i) % self._replay_capacity
+            self.set_index_valid_status(idx=idx, is_valid=False)
+        if kwargs["terminal"]:
+            num_back = min(self._num_transitions_in_current_episode, self._update_horizon)
+            for i in range(0, num_back):
+                idx = (cur_idx - i) % self._replay_capacity
+                self.set_index_valid_status(idx=idx, is_valid=True)
+
+    def _add(self, **kwargs):
+        self._check_args_length(**kwargs)
+        cursor = self.cursor()
+        for k, v in kwargs.items():
+            arr = np.array(v, dtype=self._np_dtypes[k])
+            if k == "terminal":
+                arr = arr.astype(bool)
+            self._store[k][cursor] = torch.from_numpy(arr)
+        self._terminal_host[cursor] = bool(kwargs["terminal"])
+        self.add_count += 1
+
+    def load_columns(self, columns: Dict[str, torch.Tensor], mark_all_valid: bool = False):
+        """Bulk ingestion of an offline dataset: `columns[key]` holds
+        n <= capacity consecutive transitions; equivalent to n `add` calls with stack_size == 1
+        but done as whole-column device copies.  Validity follows the add rules unless
+        mark_all_valid (throughput runs)."""
+        assert self._stack_size == 1 and self.is_empty(), "bulk load needs an empty, unstacked buffer"
+        n = columns["observation"].shape[0]
+        assert n <= self._replay_capacity
+        if not self._initialized_buffer:
+            first = {k: v[0].cpu().numpy() if v.dim() > 1 else v[0].cpu().numpy()[()] for k, v in columns.items()}
+            first["terminal"] = bool(first["terminal"])
+            self.initialize_buffer(**first)
+        for k, v in columns.items():
+            self._store[k][:n].copy_(v.to(self._store[k].dtype))
+        term = columns["terminal"].cpu().numpy().astype(bool)
+        self._terminal_host[:n] = term
+        self.add_count = np.array(n)
+        valid = np.zeros(self._replay_capacity, dtype=bool)
+        if mark_all_valid:
+            valid[:n] = True
+        else:
+            # add rules (:491-522) in closed form for stack_size == 1: every index of a finished
+            # episode is valid; in the still-open last episode index i is valid once i + h exists
+            h = self._update_horizon
+            ends = np.flatnonzero(term)
+            last_end = int(ends[-1]) if len(ends) else -1
+            ar = np.arange(n)
+            valid[:n] = (ar <= last_end) | (ar + h <= n - 1)
+        self._valid_host = valid
+        self._num_valid_indices = int(valid.sum())
+        self._valid_dirty = True
+        ep_start = 0 if not len(np.flatnonzero(term)) else int(np.flatnonzero(term)[-1]) + 1
+        self._num_transitions_in_current_episode = n - ep_start
+
+    def is_empty(self) -> bool:
+        return self.add_count == 0
+
+    def is_full(self) -> bool:
+        return self.add_count >= self._replay_capacity
+
+    def cursor(self) -> int:
+        return int(self.add_count % self._replay_capacity)
+
+    def is_valid_transition(self, index):
+        return self._valid_host[index]
+
+    @property
+    def _is_index_valid(self) -> torch.Tensor:
+        return torch.from_numpy(self._valid_host.copy())
+
+    # ---- sampling ----------------------------------------------------------------------------
+    def _valid_indices(self) -> torch.Tensor:
+        if self._valid_dirty or self._valid_indices_dev is None:
+            self._valid_indices_dev = torch.from_numpy(np.flatnonzero(self._valid_host)).to(self.device)
+            self._valid_dirty = False
+        return self._valid_indices_dev
+
+    def sample_index_batch(self, batch_size: int) -> torch.Tensor:
+        if self._num_valid_indices == 0:
+            raise RuntimeError(f"Cannot sample {batch_size} since there are no valid indices so far.")
+        valid_indices = self._valid_indices()
+        pick = torch.randint(valid_indices.shape[0], (batch_size,), device=self.device)
+        return valid_indices[pick]
+
+    def sample_all_valid_transitions(self):
+        valid_indices = self._valid_indices()
+        return self.sample_transition_batch(batch_size=len(valid_indices), indices=valid_indices)
+
+    def sample_transition_batch(self, batch_size=None, indices=None):
+        """circular_replay_buffer.py:614-706."""
+        if batch_size is None:
+            batch_size = self._batch_size
+        if indices is None:
+            indices = self.sample_index_batch(batch_size)
+        else:
+            assert isinstance(indices, torch.Tensor), (
+                f"Indices {indices} have type {type(indices)} instead of torch.Tensor"
+            )
+            indices = indices.to(device=self.device, dtype=torch.int64)
+        assert len(indices) == batch_size
+        indices = indices.contiguous()
+        B, dev, S = batch_size, self.device, self._stack_size
+        if self._decays_dev is None or self._decays_dev.device != dev:
+            self._decays_dev = self._decays.reshape(-1).to(device=dev, dtype=torch.float32)
+
+        steps = torch.empty(B, dtype=torch.int64, device=dev)
+        next_indices = torch.empty(B, dtype=torch.int64, device=dev)
+        terminal = torch.empty(B, dtype=torch.bool, device=dev)
+        reward = torch.empty(B, dtype=torch.float32, device=dev)
+        reward_col = self._store["reward"]
+        if reward_col.dtype != torch.float32:  # e.g. integer rewards: promoted like `store * decays`
+            reward_col = reward_col.float()
+        ops.replay_nstep(indices, self._store["terminal"], reward_col, self._decays_dev,
+                         self._replay_capacity, self._update_horizon, steps, next_indices, terminal, reward)
+
+        def out_for(key):
+            shape = self._shapes[key]
+            full = (B, *shape, S) if S > 1 else (B, *shape)
+            return torch.empty(full, dtype=self._store[key].dtype, device=dev)
+
+        results, cols = {}, []
+        for name in self._transition_elements:
+            if name == "state":
+                key, idx = "observation", indices
+            elif name == "next_state":
+                key, idx = "observation", next_indices
+            elif name in ("indices", "terminal", "reward", "step"):
+                continue
+            elif name in self._store:
+                key, idx = name, indices
+            elif name.startswith("next_"):
+                key, idx = name[len("next_"):], next_indices
+                assert key in self._store, f"{key} is not in {self._store.keys()}"
+            else:
+                results[name] = None
+                continue
+            dst = out_for(key)
+            cols.append((self._store[key], dst, idx))
+            results[name] = dst
+        ops.replay_gather(cols, self._replay_capacity, S, B)
+        results.update(indices=indices, terminal=terminal, reward=reward, step=steps)
+
+        batch_arrays = []
+        for name in self._transition_elements:
+            batch = results[name]
+            if isinstance(batch, torch.Tensor) and batch.ndim == 1:
+                batch = batch.unsqueeze(1)
+            batch_arrays.append(batch)
+        return self._batch_type(*batch_arrays)
+
+    def get_transition_elements(self):
+        extra_names = []
+        for name in self._extra_keys:
+            for prefix in ["", "next_"]:
+                extra_names.append(f"{prefix}{name}")
+        return ["state", "action", "reward", "next_state", "next_action", "next_reward", "terminal",
+                "indices", "step", *extra_names]
+
+    def save(self, *a, **k):
+        raise NotImplementedError("checkpointing of the replay buffer is a SURVEY.md §8(f) 'next' row")
+
+    load = save

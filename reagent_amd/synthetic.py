@@ -1,0 +1,88 @@
+"""Seeded synthetic transition data of SURVEY.md §8(d): the same CPU generator feeds the oracle,
+the parity tests and bench.py (tensors are created on the CPU from a seeded torch.Generator and
+then moved), so reference and HIP paths see identical inputs."""
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+
+def dqn_batch(batch: int, state_dim: int, num_actions: int, seed: int = 0, p_terminal: float = 0.1,
+              p_impossible: float = 0.0, with_steps: bool = False) -> Dict[str, torch.Tensor]:
+    """Fields of rlt.DiscreteDqnInput as a plain dict of CPU fp32 tensors."""
+    g = torch.Generator().manual_seed(seed)
+    state = torch.randn(batch, state_dim, generator=g)
+    next_state = torch.randn(batch, state_dim, generator=g)
+    reward = torch.rand(batch, 1, generator=g)
+    not_terminal = (torch.rand(batch, 1, generator=g) > p_terminal).float()
+    action = F.one_hot(torch.randint(num_actions, (batch,), generator=g), num_actions).float()
+    next_action = F.one_hot(torch.randint(num_actions, (batch,), generator=g), num_actions).float()
+    pna = torch.ones(batch, num_actions)
+    if p_impossible > 0:
+        pna = (torch.rand(batch, num_actions, generator=g) >= p_impossible).float()
+        keep = torch.randint(num_actions, (batch,), generator=g)
+        pna[torch.arange(batch), keep] = 1.0  # never a non-terminal state without a possible action
+    if with_steps:
+        step = torch.randint(1, 4, (batch, 1), generator=g).float()
+        time_diff = torch.randint(1, 5, (batch, 1), generator=g).float()
+    else:
+        step = torch.ones(batch, 1)
+        time_diff = torch.ones(batch, 1)
+    return dict(state=state, next_state=next_state, reward=reward, not_terminal=not_terminal,
+                action=action, next_action=next_action, possible_actions_mask=torch.ones(batch, num_actions),
+                possible_next_actions_mask=pna, step=step, time_diff=time_diff)
+
+
+def policy_batch(batch: int, state_dim: int, action_dim: int, seed: int = 0,
+                 p_terminal: float = 0.1) -> Dict[str, torch.Tensor]:
+    """Fields of rlt.PolicyNetworkInput (actions already in the training range)."""
+    g = torch.Generator().manual_seed(seed)
+    return dict(
+        state=torch.randn(batch, state_dim, generator=g),
+        next_state=torch.randn(batch, state_dim, generator=g),
+        action=torch.rand(batch, action_dim, generator=g) * 1.8 - 0.9,
+        next_action=torch.rand(batch, action_dim, generator=g) * 1.8 - 0.9,
+        reward=torch.rand(batch, 1, generator=g),
+        not_terminal=(torch.rand(batch, 1, generator=g) > p_terminal).float(),
+        step=torch.ones(batch, 1), time_diff=torch.ones(batch, 1),
+    )
+
+
+def to_dqn_input(d: Dict[str, torch.Tensor], device=None):
+    from .core import types as rlt
+
+    t = (lambda x: x.to(device)) if device is not None else (lambda x: x)
+    return rlt.DiscreteDqnInput(
+        state=rlt.FeatureData(t(d["state"])), next_state=rlt.FeatureData(t(d["next_state"])),
+        reward=t(d["reward"]), time_diff=t(d["time_diff"]), step=t(d["step"]),
+        not_terminal=t(d["not_terminal"]), action=t(d["action"]), next_action=t(d["next_action"]),
+        possible_actions_mask=t(d["possible_actions_mask"]),
+        possible_next_actions_mask=t(d["possible_next_actions_mask"]),
+        extras=rlt.ExtraData(action_probability=t(torch.ones_like(d["reward"]))),
+    )
+
+
+def to_policy_input(d: Dict[str, torch.Tensor], device=None):
+    from .core import types as rlt
+
+    t = (lambda x: x.to(device)) if device is not None else (lambda x: x)
+    return rlt.PolicyNetworkInput(
+        state=rlt.FeatureData(t(d["state"])), next_state=rlt.FeatureData(t(d["next_state"])),
+        reward=t(d["reward"]), time_diff=t(d["time_diff"]), step=t(d["step"]),
+        not_terminal=t(d["not_terminal"]), action=rlt.FeatureData(t(d["action"])),
+        next_action=rlt.FeatureData(t(d["next_action"])), extras=None,
+    )
+
+
+def replay_contents(capacity: int, obs_dim: int, num_actions: int, seed: int = 0,
+                    p_terminal: float = 0.005) -> Dict[str, torch.Tensor]:
+    """Column contents of a full replay buffer in the gym `Transition` schema."""
+    g = torch.Generator().manual_seed(seed)
+    return dict(
+        observation=torch.randn(capacity, obs_dim, generator=g),
+        action=torch.randint(num_actions, (capacity,), generator=g),
+        reward=torch.rand(capacity, generator=g),
+        terminal=torch.rand(capacity, generator=g) < p_terminal,
+        possible_actions_mask=torch.ones(capacity, num_actions),
+        log_prob=torch.zeros(capacity),
+    )

@@ -1,0 +1,43 @@
+import os
+import sys
+from dataclasses import dataclass
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@dataclass
+class Backend:
+    name: str
+    device: str
+
+
+@pytest.fixture(params=[pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    """Where the C ABI executes.
+
+    hip : the product path — libreagent_hip.so on a real MI355X (`-m gpu`).
+    emu : TEST INFRASTRUCTURE — the same kernel sources compiled for the host against the SIMT
+          interpreter in tests/emu, patched in from the test side (tests/emu_backend.py) so the
+          kernels' index arithmetic and all host logic are checked by `-m "not gpu"` without a GPU.
+    """
+    if request.param == "emu":
+        import emu_backend
+
+        emu_backend.install(monkeypatch)
+        return Backend("emu", "cpu")
+    import torch
+
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    import reagent_amd._lib as L
+
+    L.lib()  # fail loudly if the HIP extension is missing
+    return Backend("hip", "cuda")

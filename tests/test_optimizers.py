@@ -1,0 +1,74 @@
+"""FusedAdam (rg_adam_step) against torch.optim.Adam — the arithmetic the reference delegates to
+(reagent/optimizer/uninferrable_optimizers.py:23-33) — and SoftUpdate (rg_soft_update) against the
+formula of reagent/optimizer/soft_update.py:60-70.  Neither is pinned by a reference test
+("parity unpinned"): tolerance = a few fp32 ulps over 5 steps."""
+import pytest
+import torch
+
+from reagent_amd.optimizer import FusedAdam, Optimizer__Union, SoftUpdate
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(backend, wd):
+    g = torch.Generator().manual_seed(0)
+    shapes = [(33, 7), (33,), (5, 33), (5,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g).to(backend.device)) for s in shapes]
+    rs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    fused = FusedAdam(ps, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    ref = torch.optim.Adam(rs, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    for step in range(5):
+        for p, r in zip(ps, rs):
+            gr = torch.randn(*r.shape, generator=g) * (10.0 ** (step - 3))
+            p.grad, r.grad = gr.to(backend.device), gr.clone()
+        fused.step()
+        ref.step()
+        for p, r in zip(ps, rs):
+            assert (p.detach().cpu() - r.detach()).abs().max() <= 2e-7 + 2e-6 * r.detach().abs().max()
+    for p, r in zip(ps, rs):
+        assert int(fused.state[p]["step"]) == 5
+        assert (fused.state[p]["exp_avg"].cpu() - ref.state[r]["exp_avg"]).abs().max() <= 1e-6 * ref.state[r]["exp_avg"].abs().max() + 1e-12
+        assert (fused.state[p]["exp_avg_sq"].cpu() - ref.state[r]["exp_avg_sq"]).abs().max() <= 1e-6 * ref.state[r]["exp_avg_sq"].abs().max() + 1e-12
+    # parameters stay views of ONE flat slab (what the RCCL all-reduce and the kernels see)
+    slab = fused.slab_for(0)
+    assert slab.is_bound() and all(p.is_contiguous() for p in ps)
+    assert "exp_avg" in fused.state_dict()["state"][0]
+
+
+def test_params_without_grad_are_skipped_like_torch(backend):
+    ps = [torch.nn.Parameter(torch.ones(4, 4).to(backend.device)), torch.nn.Parameter(torch.ones(3).to(backend.device))]
+    opt = FusedAdam(ps, lr=0.1)
+    ps[1].grad = torch.ones(3).to(backend.device)
+    opt.step()
+    assert torch.equal(ps[0].detach().cpu(), torch.ones(4, 4))
+    assert (ps[1].detach().cpu() - 0.9).abs().max() < 1e-6
+
+
+def test_soft_update(backend):
+    g = torch.Generator().manual_seed(1)
+    src = [torch.nn.Parameter(torch.randn(9, 4, generator=g).to(backend.device)), torch.nn.Parameter(torch.randn(9, generator=g).to(backend.device))]
+    tgt = [torch.nn.Parameter(torch.randn(9, 4, generator=g).to(backend.device)), torch.nn.Parameter(torch.randn(9, generator=g).to(backend.device))]
+    s0, t0 = [p.detach().cpu().clone() for p in src], [p.detach().cpu().clone() for p in tgt]
+    su = SoftUpdate.make_optimizer_scheduler(tgt, src, tau=0.3)["optimizer"]
+    su.step()
+    for t, a, b in zip(tgt, s0, t0):
+        assert (t.detach().cpu() - (0.3 * a + (1.0 - 0.3) * b)).abs().max() <= 1e-7
+    # slab-resident sources (after an Adam step) take the single-launch path; same numbers
+    adam = FusedAdam(src, lr=0.0)
+    for p in src:
+        p.grad = torch.zeros_like(p)
+    adam.step()
+    t1 = [p.detach().cpu().clone() for p in tgt]
+    su.step()
+    for t, a, b in zip(tgt, s0, t1):
+        assert (t.detach().cpu() - (0.3 * a + (1.0 - 0.3) * b)).abs().max() <= 1e-7
+    with pytest.raises(ValueError, match="tau should be in"):
+        SoftUpdate(tgt, src, tau=1.5)
+    with pytest.raises(ValueError, match="same number of parameters"):
+        SoftUpdate(tgt, src[:1], tau=0.5)
+
+
+def test_optimizer_union_default_is_adam(backend):
+    p = [torch.nn.Parameter(torch.zeros(2, 2).to(backend.device))]
+    o = Optimizer__Union.default().make_optimizer_scheduler(p)
+    assert set(o) == {"optimizer"} and isinstance(o["optimizer"], FusedAdam)
+    assert o["optimizer"].defaults["lr"] == 0.001 and o["optimizer"].defaults["betas"] == (0.9, 0.999)

@@ -1,0 +1,143 @@
+"""reagent_amd.replay_memory.ReplayBuffer: bit-exact against (a) golden outputs of the reference
+ReplayBuffer (tests/golden/replay_*.npz), (b) the reference's own known-answer tests
+(reagent/test/replay_memory/circular_replay_buffer_test.py:60-352, restated here), (c) the numpy
+oracle on a larger seeded case, and size-independent properties (gather == index_select)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden
+from oracle import restated as R
+from reagent_amd.replay_memory import ReplayBuffer
+
+OBS = (4, 3)
+
+
+@pytest.mark.parametrize("name", ["replay_basic", "replay_nstep", "replay_stack"])
+def test_matches_reference_golden_bit_exact(backend, name):
+    g = Golden(name)
+    c = g.cfg
+    rb = ReplayBuffer(stack_size=c["stack_size"], replay_capacity=c["replay_capacity"], batch_size=c["batch"],
+                      update_horizon=c["update_horizon"], gamma=c["gamma"], device=backend.device)
+    keys = ["observation", "action", "reward", "terminal", "possible_actions_mask", "log_prob", "mdp_id"]
+    for i in range(c["n_add"]):
+        tr = {k: g.a(f"add_{k}")[i] for k in keys}
+        tr["terminal"] = bool(tr["terminal"])
+        rb.add(**tr)
+    assert int(rb.add_count) == int(g.a("add_count"))
+    assert rb.size == int(g.a("size"))
+    np.testing.assert_array_equal(rb._is_index_valid.numpy(), g.a("valid_mask"))
+    batch = rb.sample_transition_batch(batch_size=c["batch"], indices=torch.from_numpy(g.a("indices")))
+    fields = [f[len("out_"):] for f in g.z.files if f.startswith("out_")]
+    assert set(fields) == set(batch._fields)
+    assert list(batch._fields[:9]) == ["state", "action", "reward", "next_state", "next_action",
+                                       "next_reward", "terminal", "indices", "step"]  # :776-793
+    for k in fields:
+        got, ref = getattr(batch, k).cpu().numpy(), g.a(f"out_{k}")
+        assert got.shape == ref.shape and got.dtype == ref.dtype, (k, got.shape, got.dtype, ref.shape, ref.dtype)
+        assert got.tobytes() == ref.tobytes(), k  # bit exact (incl. fp32 n-step reward)
+
+
+def test_reference_known_answers_add_and_errors(backend):
+    m = ReplayBuffer(stack_size=4, replay_capacity=5, batch_size=8, device=backend.device)
+    assert m.cursor() == 0
+    m.add(observation=np.zeros(OBS), action=0, reward=0, terminal=0)
+    assert m.cursor() == 4  # STACK_SIZE - 1 padding adds + 1 (test :60-68)
+    m = ReplayBuffer(stack_size=4, replay_capacity=5, batch_size=8, device=backend.device)
+    m.add(observation=np.zeros(OBS), action=0, reward=0, terminal=0, extra1=0, extra2=[0, 0])
+    with pytest.raises(ValueError, match="Add expects"):
+        m.add(observation=np.zeros(OBS), action=0, reward=0, terminal=0)
+    assert m.cursor() == 4
+    for kw in (dict(stack_size=10, replay_capacity=10, update_horizon=1), dict(stack_size=5, replay_capacity=10, update_horizon=10)):
+        with pytest.raises(ValueError, match="There is not enough capacity"):
+            ReplayBuffer(batch_size=8, gamma=1.0, device=backend.device, **kw)
+    ReplayBuffer(stack_size=5, replay_capacity=10, batch_size=8, update_horizon=5, gamma=1.0, device=backend.device)
+
+
+def test_reference_known_answers_nstep_sum(backend):
+    m = ReplayBuffer(stack_size=4, replay_capacity=10, batch_size=8, update_horizon=5, gamma=1.0,
+                     device=backend.device)
+    for i in range(50):
+        m.add(observation=np.full(OBS, i, dtype=np.uint8), action=0, reward=2.0, terminal=0)
+    for _ in range(5):
+        batch = m.sample_transition_batch()
+        assert batch[2][0].item() == 10.0  # test :115-135
+
+
+def test_reference_known_answers_sample_transition_batch(backend):
+    C, num_adds = 10, 50
+    m = ReplayBuffer(stack_size=1, replay_capacity=C, batch_size=2, device=backend.device)
+    for i in range(num_adds):
+        m.add(observation=np.full(OBS, i, np.uint8), action=0, reward=0, terminal=i % 4)
+    assert m.sample_transition_batch()[0].shape[0] == 2
+    assert m.sample_transition_batch(8)[0].shape[0] == 8
+    indices = [1, 2, 3, 5, 8]
+    exp_states = np.array([np.full(OBS, i, dtype=np.uint8) for i in indices])
+    exp_next = (exp_states + 1) % C
+    exp_states += num_adds - C
+    exp_next += num_adds - C
+    exp_term = np.expand_dims(np.array([min((x + num_adds - C) % 4, 1) for x in indices]), 1).astype(bool)
+    b = m.sample_transition_batch(batch_size=len(indices), indices=torch.tensor(indices))
+    np.testing.assert_array_equal(b.state.cpu(), exp_states)
+    np.testing.assert_array_equal(b.action.cpu(), np.zeros((5, 1)))
+    np.testing.assert_array_equal(b.reward.cpu(), np.zeros((5, 1)))
+    np.testing.assert_array_equal(b.next_action.cpu(), np.zeros((5, 1)))
+    np.testing.assert_array_equal(b.next_reward.cpu(), np.zeros((5, 1)))
+    np.testing.assert_array_equal(b.next_state.cpu(), exp_next)
+    np.testing.assert_array_equal(b.terminal.cpu(), exp_term)
+    np.testing.assert_array_equal(b.indices.cpu(), np.expand_dims(np.array(indices), 1))
+
+
+def test_reference_known_answers_multistep_and_validity(backend):
+    # circular_replay_buffer_test.py:271-312: rewards [5,3,15]-style n-step sums and terminals
+    m = ReplayBuffer(stack_size=1, replay_capacity=10, batch_size=2, update_horizon=5, gamma=1.0,
+                     device=backend.device)
+    for i in range(50):
+        m.add(observation=np.full(OBS, i, np.uint8), action=0, reward=1.0, terminal=(i % 8 == 7))
+    # cursor = 0; slots hold i = 40..49, terminal at i = 47 (slot 7)
+    b = m.sample_transition_batch(batch_size=3, indices=torch.tensor([3, 5, 0]))
+    np.testing.assert_array_equal(b.reward.cpu().numpy().ravel(), [5.0, 3.0, 5.0])
+    np.testing.assert_array_equal(b.terminal.cpu().numpy().ravel(), [True, True, False])
+    np.testing.assert_array_equal(b.step.cpu().numpy().ravel(), [5, 3, 5])
+    # validity (:314-352 rule set): last `update_horizon` slots before the cursor are invalid unless terminal-closed
+    m2 = ReplayBuffer(stack_size=1, replay_capacity=10, batch_size=2, update_horizon=3, gamma=1.0,
+                      device=backend.device)
+    o = R.ReplayOracle(stack_size=1, replay_capacity=10, update_horizon=3, gamma=1.0)
+    for i in range(23):
+        tr = dict(observation=np.full((2,), i, np.float32), action=np.int64(0), reward=np.float32(1.0), terminal=(i % 6 == 5))
+        m2.add(**tr)
+        o.add(**tr)
+        np.testing.assert_array_equal(m2._is_index_valid.numpy(), o.valid)
+        assert m2.size == int(o.valid.sum())
+
+
+def test_large_seeded_case_vs_oracle_and_properties(backend):
+    """C2-schema buffer (smaller C), bulk loaded: gather == index_select for every column."""
+    from reagent_amd import synthetic
+
+    C, S, A, B = 4096, 128, 16, 1000
+    cols = synthetic.replay_contents(C, S, A, seed=3, p_terminal=0.01)
+    rb = ReplayBuffer(replay_capacity=C, batch_size=B, device=backend.device)
+    rb.load_columns({k: v.to(backend.device) for k, v in cols.items()}, mark_all_valid=False)
+    o = R.ReplayOracle(replay_capacity=C)
+    for i in range(C):
+        o.add(**{k: v[i].numpy() for k, v in cols.items()})
+    np.testing.assert_array_equal(rb._is_index_valid.numpy(), o.valid)  # closed-form == per-add rules
+    idx = rb.sample_index_batch(B)
+    assert bool(torch.from_numpy(o.valid)[idx.cpu()].all())
+    b = rb.sample_transition_batch(B, indices=idx)
+    ref = o.sample(idx.cpu().numpy(), extra_keys=["possible_actions_mask", "log_prob"])
+    for k, v in ref.items():
+        got = getattr(b, k).cpu().numpy()
+        assert got.dtype == v.dtype and got.tobytes() == v.tobytes(), k
+    assert torch.equal(b.state.cpu(), cols["observation"][idx.cpu()])
+    assert torch.equal(b.next_state.cpu(), cols["observation"][(idx.cpu() + 1) % C])
+
+
+def test_empty_and_unsupported(backend):
+    rb = ReplayBuffer(replay_capacity=10, batch_size=2, device=backend.device)
+    rb.add(observation=np.zeros(3, np.float32), action=0, reward=0.0, terminal=False)
+    with pytest.raises(RuntimeError, match="no valid indices"):
+        rb.sample_index_batch(2)
+    with pytest.raises(NotImplementedError):
+        ReplayBuffer(replay_capacity=10, return_as_timeline_format=True, device=backend.device)
