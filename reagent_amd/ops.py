@@ -1,10 +1,11 @@
 """Thin tensor-level wrappers over the C ABI (one function per entry point of reagent_hip.h).
 
 All tensors must be on the GPU; leading dimensions are taken from ``stride(0)``.  Nothing here
-falls back to torch math.
+falls back to torch math.  ``profile()`` optionally brackets every C-ABI call with HIP events on
+the stream the kernels are enqueued on (bench.py's per-kernel roofline numbers come from that).
 """
-import ctypes
-from typing import Optional
+import contextlib
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -37,6 +38,50 @@ def _chk_dev(*ts):
             L.require_cuda(t)
 
 
+# ---- optional per-call timing -----------------------------------------------------------------
+class CallProfile:
+    """(entry point, meta) -> HIP-event durations in ms, on torch's current stream."""
+
+    def __init__(self):
+        self.records: List[Tuple[str, dict, torch.cuda.Event, torch.cuda.Event]] = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, meta, s, e in self.records:
+            key = (name, tuple(sorted(meta.items())))
+            d = out.setdefault(key, {"name": name, "meta": meta, "calls": 0, "ms": 0.0})
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+        return sorted(out.values(), key=lambda d: -d["ms"])
+
+
+_prof: Optional[CallProfile] = None
+
+
+@contextlib.contextmanager
+def profile():
+    global _prof
+    prev, _prof = _prof, CallProfile()
+    try:
+        yield _prof
+    finally:
+        _prof = prev
+
+
+def _run(name: str, meta: dict, call):
+    if _prof is None:
+        L.check(call(), name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = call()
+    e.record()
+    L.check(rc, name)
+    _prof.records.append((name, meta, s, e))
+
+
+# ---- FullyConnected ---------------------------------------------------------------------------
 def fc_forward(x, w, bias, act: int, precision: int, y=None, y32=None, yt=None):
     """y = act(x @ w.T + bias); any of y (compute type), y32 (fp32), yt (transposed) may be given."""
     _chk_dev(x, w, bias, y, y32, yt)
@@ -45,12 +90,10 @@ def fc_forward(x, w, bias, act: int, precision: int, y=None, y32=None, yt=None):
     ldy = _ld(y) if y is not None else (_ld(y32) if y32 is not None else out_f)
     if y is not None and y32 is not None:
         assert _ld(y) == _ld(y32)
-    L.check(
-        L.lib().rg_fc_forward(L.ptr(x), _ld(x), L.ptr(w), _ld(w), L.ptr(bias), L.ptr(y), L.ptr(y32), ldy,
-                              L.ptr(yt), _ld(yt) if yt is not None else 0, batch, out_f, in_f, act,
-                              precision, L.stream_ptr()),
-        "rg_fc_forward",
-    )
+    _run("rg_fc_forward", dict(M=batch, N=out_f, K=in_f, prec=precision),
+         lambda: L.lib().rg_fc_forward(L.ptr(x), _ld(x), L.ptr(w), _ld(w), L.ptr(bias), L.ptr(y), L.ptr(y32),
+                                       ldy, L.ptr(yt), _ld(yt) if yt is not None else 0, batch, out_f, in_f,
+                                       act, precision, L.stream_ptr()))
 
 
 def fc_dgrad(dz, wt, ht, act_below: int, precision: int, dx=None, dx32=None, dxt=None):
@@ -58,13 +101,11 @@ def fc_dgrad(dz, wt, ht, act_below: int, precision: int, dx=None, dx32=None, dxt
     batch, out_f = dz.shape
     in_f = wt.shape[0]
     lddx = _ld(dx) if dx is not None else (_ld(dx32) if dx32 is not None else in_f)
-    L.check(
-        L.lib().rg_fc_dgrad(L.ptr(dz), _ld(dz), L.ptr(wt), _ld(wt), L.ptr(ht),
-                            _ld(ht) if ht is not None else 0, act_below, L.ptr(dx), L.ptr(dx32), lddx,
-                            L.ptr(dxt), _ld(dxt) if dxt is not None else 0, batch, in_f, out_f,
-                            precision, L.stream_ptr()),
-        "rg_fc_dgrad",
-    )
+    _run("rg_fc_dgrad", dict(M=batch, N=in_f, K=out_f, prec=precision),
+         lambda: L.lib().rg_fc_dgrad(L.ptr(dz), _ld(dz), L.ptr(wt), _ld(wt), L.ptr(ht),
+                                     _ld(ht) if ht is not None else 0, act_below, L.ptr(dx), L.ptr(dx32), lddx,
+                                     L.ptr(dxt), _ld(dxt) if dxt is not None else 0, batch, in_f, out_f,
+                                     precision, L.stream_ptr()))
 
 
 def fc_wgrad_workspace_bytes(out_f, in_f, batch, precision) -> int:
@@ -77,36 +118,32 @@ def fc_wgrad(dzt, xt, dw, db, workspace, precision: int):
     out_f, batch = dzt.shape
     in_f = xt.shape[0]
     assert dw.is_contiguous() and dw.dtype == F32
-    L.check(
-        L.lib().rg_fc_wgrad(L.ptr(dzt), _ld(dzt), L.ptr(xt), _ld(xt), L.ptr(dw), L.ptr(db),
-                            L.ptr(workspace), workspace.numel() * workspace.element_size(), out_f, in_f,
-                            batch, precision, L.stream_ptr()),
-        "rg_fc_wgrad",
-    )
+    _run("rg_fc_wgrad", dict(M=out_f, N=in_f, K=batch, prec=precision),
+         lambda: L.lib().rg_fc_wgrad(L.ptr(dzt), _ld(dzt), L.ptr(xt), _ld(xt), L.ptr(dw), L.ptr(db),
+                                     L.ptr(workspace), workspace.numel() * workspace.element_size(), out_f,
+                                     in_f, batch, precision, L.stream_ptr()))
 
 
 def transpose_cast(src, dst=None, dst_t=None):
     _chk_dev(src, dst, dst_t)
     rows, cols = src.shape
     out = dst if dst is not None else dst_t
-    L.check(
-        L.lib().rg_transpose_cast(L.ptr(src), dt_code(src.dtype), _ld(src), rows, cols, L.ptr(dst),
-                                  _ld(dst) if dst is not None else 0, L.ptr(dst_t),
-                                  _ld(dst_t) if dst_t is not None else 0, dt_code(out.dtype),
-                                  L.stream_ptr()),
-        "rg_transpose_cast",
-    )
+    _run("rg_transpose_cast", dict(rows=rows, cols=cols),
+         lambda: L.lib().rg_transpose_cast(L.ptr(src), dt_code(src.dtype), _ld(src), rows, cols, L.ptr(dst),
+                                           _ld(dst) if dst is not None else 0, L.ptr(dst_t),
+                                           _ld(dst_t) if dst_t is not None else 0, dt_code(out.dtype),
+                                           L.stream_ptr()))
 
 
+# ---- replay -----------------------------------------------------------------------------------
 def replay_nstep(indices, terminal_u8, reward, decays, capacity, horizon, steps, next_indices,
                  out_terminal, out_reward):
     _chk_dev(indices, terminal_u8, reward, decays, steps, next_indices, out_terminal, out_reward)
-    L.check(
-        L.lib().rg_replay_nstep(L.ptr(indices), L.ptr(terminal_u8), L.ptr(reward), L.ptr(decays),
-                                capacity, horizon, indices.numel(), L.ptr(steps), L.ptr(next_indices),
-                                L.ptr(out_terminal), L.ptr(out_reward), L.stream_ptr()),
-        "rg_replay_nstep",
-    )
+    _run("rg_replay_nstep", dict(B=indices.numel()),
+         lambda: L.lib().rg_replay_nstep(L.ptr(indices), L.ptr(terminal_u8), L.ptr(reward), L.ptr(decays),
+                                         capacity, horizon, indices.numel(), L.ptr(steps),
+                                         L.ptr(next_indices), L.ptr(out_terminal), L.ptr(out_reward),
+                                         L.stream_ptr()))
 
 
 def replay_gather(cols, capacity: int, stack: int, batch: int):
@@ -114,6 +151,7 @@ def replay_gather(cols, capacity: int, stack: int, batch: int):
     for i in range(0, len(cols), L.MAX_GATHER_COLS):
         chunk = cols[i : i + L.MAX_GATHER_COLS]
         arr = (L.GatherCol * len(chunk))()
+        nbytes = 0
         for j, (src, dst, idx) in enumerate(chunk):
             _chk_dev(src, dst, idx)
             assert src.is_contiguous() and dst.is_contiguous() and idx.dtype == torch.int64
@@ -125,33 +163,31 @@ def replay_gather(cols, capacity: int, stack: int, batch: int):
             arr[j].indices = idx.data_ptr()
             arr[j].row_elems = row_elems
             arr[j].elem_bytes = src.element_size()
-        L.check(L.lib().rg_replay_gather(arr, len(chunk), capacity, stack, batch, L.stream_ptr()),
-                "rg_replay_gather")
+            nbytes += 2 * row_elems * src.element_size() * stack + 8
+        _run("rg_replay_gather", dict(B=batch, bytes_per_row=nbytes),
+             lambda: L.lib().rg_replay_gather(arr, len(chunk), capacity, stack, batch, L.stream_ptr()))
 
 
 def make_dqn_input(action, next_action, terminal, log_prob, num_actions, action_1h, next_action_1h,
                    not_terminal, action_probability=None):
     _chk_dev(action, next_action, terminal, log_prob, action_1h, next_action_1h, not_terminal,
              action_probability)
-    L.check(
-        L.lib().rg_make_dqn_input(L.ptr(action), L.ptr(next_action), L.ptr(terminal), L.ptr(log_prob),
-                                  action.numel(), num_actions, L.ptr(action_1h), L.ptr(next_action_1h),
-                                  L.ptr(not_terminal), L.ptr(action_probability), L.stream_ptr()),
-        "rg_make_dqn_input",
-    )
+    _run("rg_make_dqn_input", dict(B=action.numel()),
+         lambda: L.lib().rg_make_dqn_input(L.ptr(action), L.ptr(next_action), L.ptr(terminal), L.ptr(log_prob),
+                                           action.numel(), num_actions, L.ptr(action_1h), L.ptr(next_action_1h),
+                                           L.ptr(not_terminal), L.ptr(action_probability), L.stream_ptr()))
 
 
 def normalize_dense(x, presence_u8, cols_dev, n_out, quantiles, out):
     _chk_dev(x, presence_u8, cols_dev, quantiles, out)
-    L.check(
-        L.lib().rg_normalize_dense(L.ptr(x), _ld(x), L.ptr(presence_u8),
-                                   _ld(presence_u8) if presence_u8 is not None else 0, L.ptr(cols_dev),
-                                   n_out, L.ptr(quantiles), L.ptr(out), _ld(out), x.shape[0],
-                                   L.stream_ptr()),
-        "rg_normalize_dense",
-    )
+    _run("rg_normalize_dense", dict(B=x.shape[0], n_out=n_out),
+         lambda: L.lib().rg_normalize_dense(L.ptr(x), _ld(x), L.ptr(presence_u8),
+                                            _ld(presence_u8) if presence_u8 is not None else 0,
+                                            L.ptr(cols_dev), n_out, L.ptr(quantiles), L.ptr(out), _ld(out),
+                                            x.shape[0], L.stream_ptr()))
 
 
+# ---- heads ------------------------------------------------------------------------------------
 def dqn_head_partials(batch: int) -> int:
     return int(L.lib().rg_dqn_head_partials(batch))
 
@@ -166,38 +202,33 @@ def dqn_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, 
         assert t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A)
     for t in (reward, not_terminal, gamma_exponent):
         assert t is None or (t.is_contiguous() and t.dtype == F32 and t.numel() == batch)
-    L.check(
-        L.lib().rg_dqn_head(L.ptr(q), L.ptr(qn_online), L.ptr(qn_target), L.ptr(action),
-                            L.ptr(next_mask), L.ptr(reward), L.ptr(reward_boosts), L.ptr(not_terminal),
-                            float(gamma), L.ptr(gamma_exponent), batch, A, int(double_q), loss_type,
-                            L.ptr(dq), L.ptr(loss_partials), L.ptr(next_q), L.ptr(next_idx),
-                            L.ptr(q_sel), L.stream_ptr()),
-        "rg_dqn_head",
-    )
+    _run("rg_dqn_head", dict(B=batch, A=A),
+         lambda: L.lib().rg_dqn_head(L.ptr(q), L.ptr(qn_online), L.ptr(qn_target), L.ptr(action),
+                                     L.ptr(next_mask), L.ptr(reward), L.ptr(reward_boosts),
+                                     L.ptr(not_terminal), float(gamma), L.ptr(gamma_exponent), batch, A,
+                                     int(double_q), loss_type, L.ptr(dq), L.ptr(loss_partials), L.ptr(next_q),
+                                     L.ptr(next_idx), L.ptr(q_sel), L.stream_ptr()))
 
 
 def reduce_sum(inp, n: int, scale: float, out):
     _chk_dev(inp, out)
-    L.check(L.lib().rg_reduce_sum(L.ptr(inp), n, scale, L.ptr(out), L.stream_ptr()), "rg_reduce_sum")
+    _run("rg_reduce_sum", dict(n=n), lambda: L.lib().rg_reduce_sum(L.ptr(inp), n, scale, L.ptr(out), L.stream_ptr()))
 
 
+# ---- optimizer --------------------------------------------------------------------------------
 def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt,
               grad_scale=1.0, offset=0):
     """Flat fp32 slabs; [offset, offset+n) is updated."""
     _chk_dev(param, grad, exp_avg, exp_avg_sq)
     o = offset * 4
-    L.check(
-        L.lib().rg_adam_step(param.data_ptr() + o, grad.data_ptr() + o, exp_avg.data_ptr() + o,
-                             exp_avg_sq.data_ptr() + o, n, lr, beta1, beta2, eps, weight_decay, bc1,
-                             bc2_sqrt, grad_scale, L.stream_ptr()),
-        "rg_adam_step",
-    )
+    _run("rg_adam_step", dict(n=n),
+         lambda: L.lib().rg_adam_step(param.data_ptr() + o, grad.data_ptr() + o, exp_avg.data_ptr() + o,
+                                      exp_avg_sq.data_ptr() + o, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                                      bc2_sqrt, grad_scale, L.stream_ptr()))
 
 
 def soft_update(target, source, n, tau, t_off=0, s_off=0):
     _chk_dev(target, source)
-    L.check(
-        L.lib().rg_soft_update(target.data_ptr() + 4 * t_off, source.data_ptr() + 4 * s_off, n, tau,
-                               L.stream_ptr()),
-        "rg_soft_update",
-    )
+    _run("rg_soft_update", dict(n=n),
+         lambda: L.lib().rg_soft_update(target.data_ptr() + 4 * t_off, source.data_ptr() + 4 * s_off, n, tau,
+                                        L.stream_ptr()))

@@ -1,0 +1,43 @@
+"""The offline batch-RL step loop on one GPU: what OfflineReplayBufferDataset + pl.Trainer.fit do in
+the reference (reagent/gym/datasets/replay_buffer_dataset.py:153-206), without a
+dataloader, Lightning or host synchronisation:
+
+    indices = sample_index_batch(B)                       (device RNG)
+    batch   = ReplayBuffer.sample_transition_batch         rg_replay_nstep + rg_replay_gather
+    input   = DiscreteDqnInputMaker(batch)                 rg_make_dqn_input
+    state, next_state = Preprocessor(...)                  rg_normalize_dense x2
+    trainer.train_step_native(input)                       FC fwd x3, head, bwd, Adam, soft update
+Everything is enqueued on torch's current stream; the loss stays on the device.
+"""
+from typing import Optional
+
+import torch
+
+from .core import types as rlt
+from .preprocessing import DiscreteDqnInputMaker, Preprocessor
+from .replay_memory import ReplayBuffer
+
+
+class OfflineDqnLoop:
+    def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int,
+                 state_preprocessor: Optional[Preprocessor] = None):
+        self.rb = replay_buffer
+        self.trainer = trainer
+        self.batch_size = batch_size
+        self.pre = state_preprocessor
+        self.maker = DiscreteDqnInputMaker(trainer.num_actions)
+        self._presence = None
+
+    def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.DiscreteDqnInput:
+        tup = self.rb.sample_transition_batch(self.batch_size, indices=indices)
+        inp = self.maker(tup)
+        if self.pre is not None:
+            s, ns = inp.state.float_features, inp.next_state.float_features
+            if self._presence is None or self._presence.shape != s.shape or self._presence.device != s.device:
+                self._presence = torch.ones(s.shape, dtype=torch.uint8, device=s.device)
+            inp.state = rlt.FeatureData(self.pre(s, self._presence))
+            inp.next_state = rlt.FeatureData(self.pre(ns, self._presence))
+        return inp
+
+    def step(self, indices: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.trainer.train_step_native(self.make_batch(indices))
