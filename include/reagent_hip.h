@@ -77,6 +77,49 @@ int rg_fc_wgrad(const void* dzt, int64_t lddzt, const void* xt, int64_t ldxt, fl
 int rg_transpose_cast(const void* src, int src_dt, int64_t ld_src, int rows, int cols, void* dst,
                       int64_t ld_dst, void* dst_t, int64_t ld_t, int dst_dt, rg_stream_t stream);
 
+/* ---- fused FullyConnected stack (bf16 throughput path) ------------------------------------ */
+
+/* Whole-network kernels for stacks whose hidden layers share one width in {256, 512}, input
+ * width <= 512 and output width <= 128 (rg_mlp_fused_supported): a 128-row activation tile stays
+ * in LDS across all layers; weights stream from HBM/L2 in MFMA B-fragment order
+ * (rg_stage_weights_frag); what backward needs is saved in MFMA C-fragment order
+ * (rg_frag_elems(batch, width) bf16 elements per saved matrix), which rg_fc_wgrad_frag
+ * consumes directly as MFMA operands.  Replaces FullyConnectedNetwork.forward
+ * (reagent/models/fully_connected_network.py:157-163) and its autograd backward. */
+#define RG_MLP_MAX_LAYERS 6
+typedef struct {
+  int32_t n_layers;
+  int32_t dims[RG_MLP_MAX_LAYERS + 1];        /* dims[0] = input features, dims[l+1] = out of layer l */
+  int32_t acts[RG_MLP_MAX_LAYERS];            /* RG_ACT_* per layer (last must be linear to train) */
+  const void* wfrag_fwd[RG_MLP_MAX_LAYERS];   /* rg_stage_weights_frag outputs */
+  const void* wfrag_bwd[RG_MLP_MAX_LAYERS];
+  const float* bias[RG_MLP_MAX_LAYERS];
+  void* act_frag[RG_MLP_MAX_LAYERS];          /* [l] = saved INPUT of layer l, C-fragment order */
+  void* dz_frag[RG_MLP_MAX_LAYERS];           /* [l] = d loss / d pre-activation output of layer l */
+} rg_mlp_desc; /* host struct */
+
+int rg_mlp_fused_supported(const rg_mlp_desc* d);
+size_t rg_frag_elems(int rows, int cols);                  /* bf16 elements of a C-fragment matrix */
+size_t rg_wfrag_elems(int out_features, int in_features);  /* bf16 elements of a B-fragment weight */
+/* w [out, in] fp32 (nn.Linear layout) -> wfrag_fwd (rg_wfrag_elems(out,in)) and/or
+ * wfrag_bwd = fragments of w^T (rg_wfrag_elems(in,out)); zero padded. */
+int rg_stage_weights_frag(const float* w, int out_features, int in_features, void* wfrag_fwd,
+                          void* wfrag_bwd, rg_stream_t stream);
+/* out32 [batch, dims[L]] = network(x); x [batch, dims[0]] row-major of dtype x_dtype (RG_DT_*).
+ * save != 0 additionally writes act_frag[0..L-1]. */
+int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64_t ldx, int batch,
+                         float* out32, int64_t ldo, int save, rg_stream_t stream);
+/* Given dout32 = d loss / d out32: writes dz_frag[0..L-1] (needs act_frag[1..L-1] from a saving
+ * forward of the same batch); dx32 (nullable) = d loss / d x, fp32 [batch, dims[0]]. */
+int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch,
+                          float* dx32, int64_t lddx, rg_stream_t stream);
+/* dw [out, in] fp32 = dz^T x, db [out] (nullable) = column sums of dz, from C-fragment operands
+ * dz_frag (batch x out) and x_frag (batch x in).  Deterministic split over the batch. */
+size_t rg_fc_wgrad_frag_workspace_bytes(int out_features, int in_features, int batch);
+int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, int in_features,
+                     int batch, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                     rg_stream_t stream);
+
 /* ---- replay buffer ------------------------------------------------------------------------ */
 
 /* n-step bookkeeping of ReplayBuffer.sample_transition_batch,

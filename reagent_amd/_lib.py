@@ -50,6 +50,22 @@ class NormCol(ctypes.Structure):
     ]
 
 
+MLP_MAX_LAYERS = 6
+
+
+class MlpDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_layers", ctypes.c_int32),
+        ("dims", ctypes.c_int32 * (MLP_MAX_LAYERS + 1)),
+        ("acts", ctypes.c_int32 * MLP_MAX_LAYERS),
+        ("wfrag_fwd", c_void_p * MLP_MAX_LAYERS),
+        ("wfrag_bwd", c_void_p * MLP_MAX_LAYERS),
+        ("bias", c_void_p * MLP_MAX_LAYERS),
+        ("act_frag", c_void_p * MLP_MAX_LAYERS),
+        ("dz_frag", c_void_p * MLP_MAX_LAYERS),
+    ]
+
+
 # every symbol include/reagent_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "rg_strerror": (ctypes.c_char_p, [c_int]),
@@ -63,6 +79,17 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_int, c_void_p]),
     "rg_transpose_cast": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p,
                                    c_i64, c_int, c_void_p]),
+    "rg_mlp_fused_supported": (c_int, [ctypes.POINTER(MlpDesc)]),
+    "rg_frag_elems": (c_sz, [c_int, c_int]),
+    "rg_wfrag_elems": (c_sz, [c_int, c_int]),
+    "rg_stage_weights_frag": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rg_mlp_forward_fused": (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_int, c_i64, c_int, c_void_p, c_i64,
+                                      c_int, c_void_p]),
+    "rg_mlp_backward_fused": (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_i64, c_int, c_void_p, c_i64,
+                                       c_void_p]),
+    "rg_fc_wgrad_frag_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "rg_fc_wgrad_frag": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_sz,
+                                  c_void_p]),
     "rg_replay_nstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_replay_gather": (c_int, [ctypes.POINTER(GatherCol), c_int, c_i64, c_int, c_int, c_void_p]),

@@ -1,0 +1,680 @@
+// mlp_fused.hip — the bf16 throughput path of a FullyConnected stack: whole-network forward and
+// backward kernels that keep a 128-row activation tile resident in LDS across all layers, plus
+// the weight-gradient kernel that consumes activations saved in MFMA-fragment order.
+//
+// Why (measured on MI355X, profiles/r01_run1): one GEMM launch per layer is bound by the HBM
+// round trip of the [batch, 512] activation (67 MB bf16) between layers and by 2-byte epilogue
+// stores, not by MFMA.  Here
+//   * a workgroup (8 waves, 512 threads) owns 128 rows; the activation tile lives in LDS
+//     (128 x (width+8) bf16 = 133 KB of the CU's 160 KB) and is rewritten in place layer by layer;
+//   * each wave owns 32*TN output columns of a hidden layer (all 128 rows): its weight operand is
+//     private, so weights are pre-staged in HBM in B-fragment order and stream L2 -> VGPR as
+//     perfectly coalesced 1 KB wave loads, no LDS and no barrier on the weight path;
+//   * what backward needs is stored straight from the accumulators in "C-fragment order"
+//     (lane = column, 8 rows per lane per half-tile; 1 KB coalesced stores).  Both wgrad operands
+//     (dZ and X) are produced in that order, and because an MFMA reduction may visit the
+//     reduction index in any order as long as A and B agree, wgrad consumes them as MFMA A/B
+//     fragments directly: no transposes anywhere, no 2-byte stores.
+//
+// Replaces: FullyConnectedNetwork.forward (reagent/models/fully_connected_network.py:157-163)
+// and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
+#include "rg_gemm.h"
+#include "../../include/reagent_hip.h"
+
+namespace rg {
+
+constexpr int FB_BM = 128;
+constexpr int FB_THREADS = 512;
+constexpr int FB_MAXL = RG_MLP_MAX_LAYERS;
+
+struct MlpArgs {
+  int n_layers, batch;
+  int dims[FB_MAXL + 1];
+  int acts[FB_MAXL];
+  const bf16_t* wfrag[FB_MAXL];  // forward: B fragments of W_l; backward: B fragments of W_l^T
+  const float* bias[FB_MAXL];
+  bf16_t* act_frag[FB_MAXL + 1];  // [l] = input of layer l in C-fragment order ([0] = network input)
+  bf16_t* dz_frag[FB_MAXL];       // [l] = d loss / d (pre-activation output of layer l)
+  const void* x;                  // forward input [batch, dims[0]] row-major, bf16 or fp32
+  long ldx;
+  int x_is_f32;
+  float* out32;  // forward output [batch, dims[L]] fp32
+  long ldo;
+  const float* dout32;  // backward input [batch, dims[L]] fp32
+  long lddo;
+  float* dx32;  // backward: optional gradient w.r.t. the network input, fp32 [batch, dims[0]]
+  long lddx;
+  int pitch;  // LDS row pitch (elements)
+  int save;   // forward: store act_frag[]
+};
+
+__device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// C-fragment order: element (row, col) lives in block (row/32, col/32), half h, lane, e with
+//   col%32 = lane&31,  row%32 = (r&3) + 8*(r>>2) + 4*(lane>>5),  r = 8*h + e   (MFMA 32x32 D layout)
+__device__ __forceinline__ long frag_offset(int mb, int nt, int NT, int h, int lane) {
+  return ((((long)mb * NT + nt) * 2 + h) * 64 + lane) * 8;
+}
+__device__ __forceinline__ int frag_row(int h, int e, int lg) {
+  const int r = 8 * h + e;
+  return (r & 3) + 8 * (r >> 2) + 4 * lg;
+}
+
+// ---- LDS tile helpers -----------------------------------------------------------------------
+// rows [row_base, row_base+128) x cols [0, ncols_pad) of a row-major global matrix -> bf16 LDS tile
+template <typename T>
+__device__ __forceinline__ void load_tile_to_lds(bf16_t* act, int pitch, const T* src, long ld, int row_base,
+                                                 int nrows, int ncols, int ncols_pad, int tid) {
+  const int cpr = ncols_pad / 8;  // 8-element chunks per row
+  const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (int c = tid; c < FB_BM * cpr; c += FB_THREADS) {
+    const int r = c / cpr, k0 = (c % cpr) * 8;
+    const int grow = row_base + r;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (grow < nrows && k0 < ncols) {
+      const T* p = src + (long)grow * ld + k0;
+      if (sizeof(T) == 2 && vec && k0 + 8 <= ncols) {
+        v = *(const u16x8*)p;
+      } else if (sizeof(T) == 4 && vec && k0 + 8 <= ncols) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = cvt_out<bf16_t>(a[e]);
+          v[4 + e] = cvt_out<bf16_t>(b[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k0 + e < ncols) v[e] = cvt_out<bf16_t>(cvt_in(p[e]));
+      }
+    }
+    *(u16x8*)&act[r * pitch + k0] = v;
+  }
+}
+
+// LDS tile (128 rows x ntiles*32 cols) -> C-fragment order in global memory
+__device__ __forceinline__ void emit_frags_from_lds(const bf16_t* act, int pitch, int ntiles, bf16_t* dst,
+                                                    int mb_base, int wave, int lane) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const int total = 4 * ntiles * 2;
+  for (int f = wave; f < total; f += FB_THREADS / 64) {
+    const int h = f & 1, nt = (f >> 1) % ntiles, mbl = (f >> 1) / ntiles;
+    u16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act[(mbl * 32 + frag_row(h, e, lg)) * pitch + nt * 32 + lr];
+    *(u16x8*)(dst + frag_offset(mb_base + mbl, nt, ntiles, h, lane)) = v;
+  }
+}
+
+// accumulators of one 32x32 tile (already activated / masked) -> bf16 into the LDS tile.
+// Neighbouring lanes hold neighbouring columns: exchange one value per row pair so every lane
+// writes one packed bf16x2 dword instead of two 2-byte stores.
+__device__ __forceinline__ void store_tile_to_lds(bf16_t* act, int pitch, int row0_tile, int col, int lane,
+                                                  const float (&v)[16]) {
+  const int lg = lane >> 5, odd = lane & 1;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const int row0 = row0_tile + 8 * rq + 4 * lg;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float mine_a = v[rq * 4 + 2 * q], mine_b = v[rq * 4 + 2 * q + 1];
+      const float recv = shfl_xor(odd ? mine_a : mine_b, 1);
+      const unsigned word = odd ? pack_bf16x2(recv, mine_b) : pack_bf16x2(mine_a, recv);
+      const int row = row0 + 2 * q + odd;
+      *(unsigned*)&act[row * pitch + (col & ~1)] = word;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_tile_frags(bf16_t* dst, int mb, int nt, int NT, int lane,
+                                                 const float (&v)[16]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[8 * h + e]);
+    *(u16x8*)(dst + frag_offset(mb, nt, NT, h, lane)) = o;
+  }
+}
+
+// ---- main loop of a wide layer: this wave's [128 x 32*TN] slice over K ------------------------
+template <int TN>
+__device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_lane,
+                                              long nt_stride, f32x16 (&acc)[4][TN], int lr, int lg) {
+  const bf16_t* arow[4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) arow[tm] = act + (tm * 32 + lr) * pitch + lg * 8;
+  u16x8 b0[TN], b1[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) b0[tn] = *(const u16x8*)(wf_lane + tn * nt_stride);
+  int kc = 0;
+  for (; kc + 1 < KC; kc += 2) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b1[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + (long)(kc + 1) * 512);
+    {
+      u16x8 af[4];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow[tm] + kc * 16);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], b0[tn], acc[tm][tn]);
+    }
+    if (kc + 2 < KC) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b0[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + (long)(kc + 2) * 512);
+    }
+    {
+      u16x8 af[4];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow[tm] + (kc + 1) * 16);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], b1[tn], acc[tm][tn]);
+    }
+  }
+  if (kc < KC) {
+    u16x8 af[4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow[tm] + kc * 16);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], b0[tn], acc[tm][tn]);
+  }
+}
+
+// one 32x32 output tile (row tile tm, weight n-tile nt) over K; used for narrow / irregular widths
+__device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf, int tm,
+                                             int nt, int lane) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8;
+  const bf16_t* wl = wf + (long)nt * KC * 512 + lane * 8;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int kc = 0; kc < KC; ++kc)
+    acc = mfma_32x32x16_bf16(*(const u16x8*)(arow + kc * 16), *(const u16x8*)(wl + (long)kc * 512), acc);
+  return acc;
+}
+
+template <int TN>
+__global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
+  RG_DYN_LDS(smem);
+  bf16_t* act = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lg = lane >> 5;
+  const int row_base = blockIdx.x * FB_BM;
+  const int pitch = a.pitch;
+  const int k0p = round_up(a.dims[0], 32);
+  if (a.x_is_f32)
+    load_tile_to_lds<float>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
+  else
+    load_tile_to_lds<bf16_t>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
+  __syncthreads();
+  if (a.save && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * 4, wave, lane);
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int K = a.dims[l], N = a.dims[l + 1];
+    const int KC = (K + 15) / 16;
+    if (l < a.n_layers - 1) {  // hidden layer, N == 256 * TN
+      f32x16 acc[4][TN];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+      const long nt_stride = (long)KC * 512;
+      wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg);
+      __syncthreads();  // every wave is done reading the layer input
+      const int NT = N / 32;
+      const bf16_t* dummy = nullptr;
+      (void)dummy;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int nt = wave * TN + tn, col = nt * 32 + lr;
+        const float b = a.bias[l] ? a.bias[l][col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = act_apply(acc[tm][tn][r] + b, a.acts[l]);
+          if (a.save && a.act_frag[l + 1]) store_tile_frags(a.act_frag[l + 1], blockIdx.x * 4 + tm, nt, NT, lane, v);
+          store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
+        }
+      }
+      __syncthreads();
+    } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
+      const int NTo = (N + 31) / 32;
+      for (int t = wave; t < 4 * NTo; t += FB_THREADS / 64) {
+        const int tm = t & 3, nt = t >> 2;
+        const f32x16 acc = tile_kloop(act, pitch, KC, a.wfrag[l], tm, nt, lane);
+        const int col = nt * 32 + lr;
+        if (col < N) {
+          const float b = a.bias[l] ? a.bias[l][col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+            if (row < a.batch) a.out32[(long)row * a.ldo + col] = act_apply(acc[r] + b, a.acts[l]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int TN>
+__global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
+  RG_DYN_LDS(smem);
+  bf16_t* act = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lg = lane >> 5;
+  const int row_base = blockIdx.x * FB_BM;
+  const int pitch = a.pitch;
+  const int L = a.n_layers;
+  const int nop = round_up(a.dims[L], 32);
+  load_tile_to_lds<float>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
+  __syncthreads();
+  emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, lane);
+
+  for (int l = L - 1; l >= 1; --l) {
+    // dH = dZ_l (LDS, width dims[l+1]) . W_l -> [128, dims[l]] ; dZ_{l-1} = dH * act'(H_l)
+    const int K = a.dims[l + 1], N = a.dims[l];
+    const int KC = (K + 15) / 16;
+    f32x16 acc[4][TN];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    const long nt_stride = (long)KC * 512;
+    wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg);
+    __syncthreads();
+    const int NT = N / 32;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int nt = wave * TN + tn, col = nt * 32 + lr;
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) {
+        const int mb = blockIdx.x * 4 + tm;
+        float v[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u16x8 hf = *(const u16x8*)(a.act_frag[l] + frag_offset(mb, nt, NT, h, lane));
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_from_output(bf16_to_f32(hf[e]), a.acts[l - 1]);
+        }
+        store_tile_frags(a.dz_frag[l - 1], mb, nt, NT, lane, v);
+        store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
+      }
+    }
+    __syncthreads();
+  }
+  if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
+    const int K = a.dims[1], N = a.dims[0];
+    const int KC = (K + 15) / 16, NTi = (N + 31) / 32;
+    for (int t = wave; t < 4 * NTi; t += FB_THREADS / 64) {
+      const int tm = t & 3, nt = t >> 2;
+      const f32x16 acc = tile_kloop(act, pitch, KC, a.wfrag[0], tm, nt, lane);
+      const int col = nt * 32 + lr;
+      if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (row < a.batch) a.dx32[(long)row * a.lddx + col] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+// ---- weight gradient from fragment-ordered operands ------------------------------------------
+// dW[n][k] = sum_m dZ[m][n] X[m][k].  A = dz_frag tiles (lane = n), B = x_frag tiles (lane = k):
+// per 32-row block and half, one MFMA per (n-tile, k-tile) pair.  Workgroup tile 256(n) x 256(k),
+// waves 2(n) x 4(k), each 4x2 MFMA tiles; operands staged HBM -> VGPR -> LDS (lane-linear 16 B,
+// conflict-free), two 32-row blocks per stage, double buffered, one barrier per stage.
+constexpr int WG_MB_STAGE = 2;
+constexpr int WG_STAGE_BYTES = WG_MB_STAGE * 32 * 1024;
+
+struct WgradFragArgs {
+  const bf16_t* a_frag;
+  const bf16_t* b_frag;
+  int NTa, NTb;       // tiles per 32-row block in each operand
+  int MB;             // 32-row blocks in total
+  int mb_per_split;   // multiple of WG_MB_STAGE
+  int splits;
+  float* partial;     // [splits][N*K]
+  long slab;
+  int N, K;           // valid extents of dW
+  float* bias_partial;  // [splits][N] or null
+  long bias_slab;
+};
+
+__global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
+  RG_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 2, wk = wave & 3;
+  const int n_groups = (g.NTa + 7) / 8, k_groups = (g.NTb + 7) / 8;
+  int bid = blockIdx.x;
+  const int kg = bid % k_groups; bid /= k_groups;
+  const int ng = bid % n_groups; bid /= n_groups;
+  const int split = bid;
+  const int mb_begin = split * g.mb_per_split;
+  const int mb_end = (mb_begin + g.mb_per_split < g.MB) ? mb_begin + g.mb_per_split : g.MB;
+  const int ta0 = ng * 8, tb0 = kg * 8;
+  const int na = (g.NTa - ta0 < 8) ? g.NTa - ta0 : 8, nb = (g.NTb - tb0 < 8) ? g.NTb - tb0 : 8;
+
+  f32x16 acc[4][2];
+  f32x16 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  const bool do_bias = g.bias_partial && kg == 0 && wk == 0;
+  const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  // staging registers: 4096 16-byte units per stage / 512 threads
+  constexpr int UNITS = WG_MB_STAGE * 2048, PER = UNITS / FB_THREADS;
+  u16x8 regs[PER];
+  auto gload = [&](int mb0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * FB_THREADS;
+      const int mbl = u >> 11, w = u & 2047, isb = w >> 10, off = w & 1023;
+      const int tile = off >> 7, mb = mb0 + mbl;
+      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (mb < mb_end) {
+        if (!isb) {
+          if (tile < na) v = *(const u16x8*)(g.a_frag + ((long)mb * g.NTa + ta0 + tile) * 1024 + (off & 127) * 8);
+        } else {
+          if (tile < nb) v = *(const u16x8*)(g.b_frag + ((long)mb * g.NTb + tb0 + tile) * 1024 + (off & 127) * 8);
+        }
+      }
+      regs[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * WG_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * FB_THREADS;
+      *(u16x8*)(base + (long)u * 16) = regs[i];
+    }
+  };
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * WG_STAGE_BYTES;
+#pragma unroll
+    for (int mbl = 0; mbl < WG_MB_STAGE; ++mbl) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u16x8 af[4], bf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          af[i] = *(const u16x8*)(base + mbl * 32768 + (wn * 4 + i) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bf[j] = *(const u16x8*)(base + mbl * 32768 + 16384 + (wk * 2 + j) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+        if (do_bias) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb[i] = mfma_32x32x16_bf16(af[i], ones, accb[i]);
+        }
+      }
+    }
+  };
+
+  if (mb_begin < mb_end) {
+    gload(mb_begin);
+    lstore(0);
+    if (mb_begin + WG_MB_STAGE < mb_end) gload(mb_begin + WG_MB_STAGE);
+    __syncthreads();
+    int buf = 0;
+    for (int mb = mb_begin; mb < mb_end; mb += WG_MB_STAGE) {
+      compute(buf);
+      const bool has_next = mb + WG_MB_STAGE < mb_end;
+      if (has_next) lstore(buf ^ 1);
+      if (mb + 2 * WG_MB_STAGE < mb_end) gload(mb + 2 * WG_MB_STAGE);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  float* part = g.partial + (long)split * g.slab;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (tb0 + wk * 2 + j) * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (ta0 + wn * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
+      }
+    }
+  if (do_bias && lr == 0) {
+    float* bp = g.bias_partial + (long)split * g.bias_slab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (ta0 + wn * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row < g.N) bp[row] = accb[i][r];
+      }
+  }
+}
+
+__global__ void reduce_splits2_kernel(const float* __restrict__ partials, long slab, int splits,
+                                      float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += partials[(long)k * slab + i];
+  out[i] = s;
+}
+
+// fp32 master weights -> B-fragment order for forward (W) and backward (W^T), zero padded
+__global__ void stage_weights_frag_kernel(const float* __restrict__ w, int N, int K, bf16_t* __restrict__ wf,
+                                          bf16_t* __restrict__ wb) {
+  const int NTf = (N + 31) / 32, KCf = (K + 15) / 16;
+  const int NTb = (K + 31) / 32, KCb = (N + 15) / 16;
+  const long tf = (long)NTf * KCf * 512, tb = (long)NTb * KCb * 512;
+  const long total = tf > tb ? tf : tb;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long blk = i >> 9;
+    if (wf && i < tf) {
+      const int kc = (int)(blk % KCf), nt = (int)(blk / KCf);
+      const int n = nt * 32 + (lane & 31), k = kc * 16 + (lane >> 5) * 8 + e;
+      wf[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
+    }
+    if (wb && i < tb) {
+      const int kc = (int)(blk % KCb), nt = (int)(blk / KCb);
+      const int k = nt * 32 + (lane & 31), n = kc * 16 + (lane >> 5) * 8 + e;  // "weight" = W^T [K][N]
+      wb[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
+    }
+  }
+}
+
+static int fused_supported(const rg_mlp_desc* d) {
+  if (!d || d->n_layers < 2 || d->n_layers > FB_MAXL) return 0;
+  const int H = d->dims[1];
+  if (H != 256 && H != 512) return 0;
+  for (int l = 1; l < d->n_layers; ++l)
+    if (d->dims[l] != H) return 0;
+  if (d->dims[0] < 1 || d->dims[0] > 512) return 0;
+  if (d->dims[d->n_layers] < 1 || d->dims[d->n_layers] > 128) return 0;
+  return H / 256;
+}
+
+static int fused_pitch(const rg_mlp_desc* d) {
+  int m = 0;
+  for (int l = 0; l <= d->n_layers; ++l) {
+    const int w = (d->dims[l] + 31) / 32 * 32;
+    if (w > m) m = w;
+  }
+  return m + 8;
+}
+
+}  // namespace rg
+
+using namespace rg;
+
+extern "C" {
+
+int rg_mlp_fused_supported(const rg_mlp_desc* d) { return fused_supported(d) > 0; }
+
+size_t rg_frag_elems(int rows, int cols) {
+  return (size_t)((rows + 127) / 128 * 128) * (size_t)((cols + 31) / 32 * 32);
+}
+
+size_t rg_wfrag_elems(int out_features, int in_features) {
+  return (size_t)((out_features + 31) / 32) * (size_t)((in_features + 15) / 16) * 512;
+}
+
+int rg_stage_weights_frag(const float* w, int out_features, int in_features, void* wfrag_fwd, void* wfrag_bwd,
+                          rg_stream_t stream) {
+  if (!w || out_features <= 0 || in_features <= 0 || (!wfrag_fwd && !wfrag_bwd)) return RG_EINVAL;
+  const size_t tf = rg_wfrag_elems(out_features, in_features), tb = rg_wfrag_elems(in_features, out_features);
+  const size_t total = tf > tb ? tf : tb;
+  long blocks = (long)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  RG_LAUNCH(stage_weights_frag_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, w, out_features,
+            in_features, (bf16_t*)wfrag_fwd, (bf16_t*)wfrag_bwd);
+  return (int)hipGetLastError();
+}
+
+static int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int backward) {
+  a.n_layers = d->n_layers;
+  a.batch = batch;
+  for (int l = 0; l <= d->n_layers; ++l) a.dims[l] = d->dims[l];
+  for (int l = 0; l < d->n_layers; ++l) {
+    a.acts[l] = d->acts[l];
+    a.wfrag[l] = (const bf16_t*)(backward ? d->wfrag_bwd[l] : d->wfrag_fwd[l]);
+    a.bias[l] = d->bias[l];
+    a.dz_frag[l] = (bf16_t*)d->dz_frag[l];
+    if (!a.wfrag[l] && !(backward && l == 0)) return RG_EINVAL;
+  }
+  for (int l = 0; l <= d->n_layers; ++l) a.act_frag[l] = (bf16_t*)(l < d->n_layers ? d->act_frag[l] : nullptr);
+  a.pitch = fused_pitch(d);
+  a.x = nullptr; a.ldx = 0; a.x_is_f32 = 0; a.out32 = nullptr; a.ldo = 0; a.dout32 = nullptr; a.lddo = 0;
+  a.dx32 = nullptr; a.lddx = 0; a.save = 0;
+  return RG_OK;
+}
+
+int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64_t ldx, int batch, float* out32,
+                         int64_t ldo, int save, rg_stream_t stream) {
+  const int tn = fused_supported(d);
+  if (!tn) return RG_EUNSUPPORTED;
+  if (!x || !out32 || batch <= 0) return RG_EINVAL;
+  MlpArgs a;
+  int rc = fill_args(d, batch, a, 0);
+  if (rc) return rc;
+  if (save)
+    for (int l = 0; l < d->n_layers; ++l)
+      if (!d->act_frag[l]) return RG_EINVAL;
+  a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
+  const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
+  const dim3 grid((batch + FB_BM - 1) / FB_BM), block(FB_THREADS);
+  if (tn == 1) {
+    RG_ALLOW_LDS(mlp_fwd_fused_kernel<1>, lds);
+    RG_LAUNCH_DYN(mlp_fwd_fused_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
+  } else {
+    RG_ALLOW_LDS(mlp_fwd_fused_kernel<2>, lds);
+    RG_LAUNCH_DYN(mlp_fwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
+int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch, float* dx32,
+                          int64_t lddx, rg_stream_t stream) {
+  const int tn = fused_supported(d);
+  if (!tn) return RG_EUNSUPPORTED;
+  if (!dout32 || batch <= 0) return RG_EINVAL;
+  MlpArgs a;
+  int rc = fill_args(d, batch, a, 1);
+  if (rc) return rc;
+  for (int l = 0; l < d->n_layers; ++l) {
+    if (!d->dz_frag[l]) return RG_EINVAL;
+    if (l >= 1 && !d->act_frag[l]) return RG_EINVAL;
+  }
+  if (dx32 && !d->wfrag_bwd[0]) return RG_EINVAL;
+  a.dout32 = dout32; a.lddo = lddo; a.dx32 = dx32; a.lddx = lddx;
+  const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
+  const dim3 grid((batch + FB_BM - 1) / FB_BM), block(FB_THREADS);
+  if (tn == 1) {
+    RG_ALLOW_LDS(mlp_bwd_fused_kernel<1>, lds);
+    RG_LAUNCH_DYN(mlp_bwd_fused_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
+  } else {
+    RG_ALLOW_LDS(mlp_bwd_fused_kernel<2>, lds);
+    RG_LAUNCH_DYN(mlp_bwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
+struct WgradFragPlan {
+  int NTa, NTb, MB, splits, mb_per_split;
+  long slab, bias_slab;
+};
+static WgradFragPlan wgrad_frag_plan(int out_f, int in_f, int batch) {
+  WgradFragPlan p;
+  p.NTa = (out_f + 31) / 32;
+  p.NTb = (in_f + 31) / 32;
+  p.MB = (batch + 127) / 128 * 4;
+  const int tiles = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8);
+  int want = (256 + tiles - 1) / tiles;  // ~one workgroup per CU
+  const int max_splits = (p.MB + WG_MB_STAGE - 1) / WG_MB_STAGE;
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  int per = (p.MB + want - 1) / want;
+  per = (per + WG_MB_STAGE - 1) / WG_MB_STAGE * WG_MB_STAGE;
+  p.mb_per_split = per;
+  p.splits = (p.MB + per - 1) / per;
+  p.slab = (long)out_f * in_f;
+  p.bias_slab = out_f;
+  return p;
+}
+
+size_t rg_fc_wgrad_frag_workspace_bytes(int out_features, int in_features, int batch) {
+  const WgradFragPlan p = wgrad_frag_plan(out_features, in_features, batch > 0 ? batch : 1);
+  return (size_t)p.splits * (p.slab + p.bias_slab) * sizeof(float);
+}
+
+int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, int in_features, int batch,
+                     float* dw, float* db, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
+  if (!dz_frag || !x_frag || !dw || out_features <= 0 || in_features <= 0 || batch <= 0) return RG_EINVAL;
+  const WgradFragPlan p = wgrad_frag_plan(out_features, in_features, batch);
+  if (!workspace || workspace_bytes < (size_t)p.splits * (p.slab + p.bias_slab) * sizeof(float)) return RG_EWORKSPACE;
+  WgradFragArgs g;
+  g.a_frag = (const bf16_t*)dz_frag; g.b_frag = (const bf16_t*)x_frag;
+  g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
+  g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
+  g.bias_partial = db ? g.partial + (long)p.splits * p.slab : nullptr; g.bias_slab = p.bias_slab;
+  const int grid = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
+  const size_t lds = 2 * (size_t)WG_STAGE_BYTES;
+  RG_ALLOW_LDS(wgrad_frag_kernel, lds);
+  RG_LAUNCH_DYN(wgrad_frag_kernel, dim3(grid), dim3(FB_THREADS), lds, (hipStream_t)stream, g);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  const long n = p.slab;
+  RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
+            (const float*)g.partial, p.slab, p.splits, dw, n);
+  if (db)
+    RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((out_features + 255) / 256)), dim3(256), (hipStream_t)stream,
+              (const float*)g.bias_partial, p.bias_slab, p.splits, db, (long)out_features);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -48,8 +48,19 @@ __device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// two floats -> packed bf16x2 (lo in bits 0..15); lowers to one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
 }  // namespace rg
 
 #define RG_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #define RG_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)
+// dynamic LDS (kernels that need more than the 64 KB static limit; gfx950 has 160 KB per CU)
+#define RG_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define RG_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, __VA_ARGS__)
+#define RG_ALLOW_LDS(kernel, bytes) \
+  (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))

@@ -237,3 +237,142 @@ class FCStack:
             elif dx32 is not None:
                 ops.fc_dgrad(dz, self._wtc[0], None, L.ACT["linear"], self.precision, dx=None,
                              dx32=dx32, dxt=None)
+
+
+class FusedMLP:
+    """bf16 throughput engine for stacks the fused kernels support (hidden width 256/512 shared by
+    all hidden layers, input <= 512, output <= 128): rg_mlp_forward_fused / rg_mlp_backward_fused /
+    rg_fc_wgrad_frag.  Same interface as FCStack."""
+
+    def __init__(self, weights, biases, acts: List[int]):
+        self.weights, self.biases, self.acts = list(weights), list(biases), list(acts)
+        self.precision = L.PREC_BF16
+        self.cdtype = torch.bfloat16
+        self.dims = [self.weights[0].shape[1]] + [w.shape[0] for w in self.weights]
+        self.L = len(self.weights)
+        self._wf = [None] * self.L
+        self._wb = [None] * self.L
+        self._need_dx = False
+        self._staged_versions = None
+        self._wsrc_ptrs = ()
+        self._batch = -1
+        self._ws = {}
+        self._desc = L.MlpDesc()
+
+    @staticmethod
+    def supported(weights, acts) -> bool:
+        d = L.MlpDesc()
+        n = len(weights)
+        if n < 2 or n > L.MLP_MAX_LAYERS:
+            return False
+        d.n_layers = n
+        dims = [weights[0].shape[1]] + [w.shape[0] for w in weights]
+        for i, v in enumerate(dims):
+            d.dims[i] = v
+        return bool(L.lib().rg_mlp_fused_supported(d))
+
+    def set_need_input_grad(self, flag: bool):
+        if flag != self._need_dx:
+            self._need_dx = flag
+            self._staged_versions = None
+
+    def stage_weights(self, need_transposed: bool = True, force: bool = False):
+        versions = tuple((w._version, getattr(w, "_rg_version", 0)) for w in self.weights) + (need_transposed,)
+        if not force and versions == self._staged_versions and all(
+            self._wsrc_ptrs[i] == self.weights[i].data_ptr() for i in range(self.L)
+        ):
+            return
+        dev = self.weights[0].device
+        lib = L.lib()
+        for i, w in enumerate(self.weights):
+            out_f, in_f = w.shape
+            if self._wf[i] is None or self._wf[i].device != dev:
+                self._wf[i] = torch.empty(lib.rg_wfrag_elems(out_f, in_f), dtype=torch.bfloat16, device=dev)
+            wb = None
+            if need_transposed and (i > 0 or self._need_dx):
+                if self._wb[i] is None or self._wb[i].device != dev:
+                    self._wb[i] = torch.empty(lib.rg_wfrag_elems(in_f, out_f), dtype=torch.bfloat16, device=dev)
+                wb = self._wb[i]
+            wd = w.detach()
+            assert wd.is_contiguous()
+            L.require_cuda(wd)
+            ops._run("rg_stage_weights_frag", dict(N=out_f, K=in_f),
+                     lambda: lib.rg_stage_weights_frag(wd.data_ptr(), out_f, in_f, self._wf[i].data_ptr(),
+                                                       wb.data_ptr() if wb is not None else None, L.stream_ptr()))
+        self._staged_versions = versions
+        self._wsrc_ptrs = [w.data_ptr() for w in self.weights]
+
+    def _ensure_ws(self, batch: int, device, training: bool):
+        key = (batch, device, training)
+        if self._ws.get("key") == key or (self._ws.get("key") == (batch, device, True) and not training):
+            return
+        lib = L.lib()
+        ws = {"key": key}
+        if training:
+            bf = dict(dtype=torch.bfloat16, device=device)
+            ws["act_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l]), **bf) for l in range(self.L)]
+            ws["dz_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l + 1]), **bf) for l in range(self.L)]
+            nbytes = max(lib.rg_fc_wgrad_frag_workspace_bytes(self.dims[l + 1], self.dims[l], batch)
+                         for l in range(self.L))
+            ws["wgrad"] = torch.empty(_round_up(nbytes, 16) // 4, dtype=torch.float32, device=device)
+        self._ws = ws
+        self._batch = batch
+
+    def _fill_desc(self):
+        d = self._desc
+        d.n_layers = self.L
+        for i, v in enumerate(self.dims):
+            d.dims[i] = v
+        ws = self._ws
+        for l in range(self.L):
+            d.acts[l] = self.acts[l]
+            d.wfrag_fwd[l] = self._wf[l].data_ptr() if self._wf[l] is not None else None
+            d.wfrag_bwd[l] = self._wb[l].data_ptr() if self._wb[l] is not None else None
+            d.bias[l] = self.biases[l].data_ptr()
+            d.act_frag[l] = ws["act_frag"][l].data_ptr() if "act_frag" in ws else None
+            d.dz_frag[l] = ws["dz_frag"][l].data_ptr() if "dz_frag" in ws else None
+        return d
+
+    def stage_input(self, x32: torch.Tensor, need_transposed: bool):
+        return x32, None  # the kernel reads fp32 (or bf16) rows directly and casts in flight
+
+    def forward(self, xc: torch.Tensor, out32: torch.Tensor, save: bool = False):
+        L.require_cuda(xc)
+        B = xc.shape[0]
+        self._ensure_ws(B, xc.device, training=save)
+        d = self._fill_desc()
+        assert xc.stride(1) == 1 and out32.stride(1) == 1
+        ops._run("rg_mlp_forward_fused", dict(B=B, save=int(save), dims=tuple(self.dims)),
+                 lambda: L.lib().rg_mlp_forward_fused(d, xc.data_ptr(), ops.dt_code(xc.dtype), xc.stride(0), B,
+                                                      out32.data_ptr(), out32.stride(0), int(save),
+                                                      L.stream_ptr()))
+        return out32
+
+    def backward(self, dout32: torch.Tensor, xt, dw: List[torch.Tensor], db: List[torch.Tensor],
+                 dx32: Optional[torch.Tensor] = None):
+        if self.acts[-1] != L.ACT["linear"]:
+            raise NotImplementedError("training through a non-linear output activation")
+        B = dout32.shape[0]
+        assert self._ws.get("key") == (B, dout32.device, True), "backward needs a saving forward first"
+        d = self._fill_desc()
+        lib = L.lib()
+        ops._run("rg_mlp_backward_fused", dict(B=B, dims=tuple(self.dims)),
+                 lambda: lib.rg_mlp_backward_fused(d, dout32.data_ptr(), dout32.stride(0), B,
+                                                   dx32.data_ptr() if dx32 is not None else None,
+                                                   dx32.stride(0) if dx32 is not None else 0, L.stream_ptr()))
+        ws = self._ws
+        wsb = ws["wgrad"].numel() * 4
+        for l in range(self.L):
+            out_f, in_f = self.dims[l + 1], self.dims[l]
+            ops._run("rg_fc_wgrad_frag", dict(M=out_f, N=in_f, K=B),
+                     lambda l=l, out_f=out_f, in_f=in_f: lib.rg_fc_wgrad_frag(
+                         ws["dz_frag"][l].data_ptr(), ws["act_frag"][l].data_ptr(), out_f, in_f, B,
+                         dw[l].data_ptr(), db[l].data_ptr() if db[l] is not None else None,
+                         ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
+
+
+def make_stack(weights, biases, acts: List[int], precision: int):
+    """Engine selection: the fused bf16 kernels when the shape allows, else the per-layer GEMMs."""
+    if precision == L.PREC_BF16 and FusedMLP.supported(weights, acts):
+        return FusedMLP(weights, biases, acts)
+    return FCStack(weights, biases, acts, precision)

@@ -16,7 +16,7 @@ import torch.nn.init as init
 
 from .. import _lib as L
 from ..core import types as rlt
-from ..engine import FCStack
+from ..engine import FCStack, make_stack
 from .base import ModelBase
 
 _DEFAULT_PRECISION = L.PREC_F32
@@ -100,17 +100,17 @@ class FullyConnectedNetwork(ModelBase):
             modules.append(nn.Sequential(linear, _Activation(activation)))
         self.dnn = nn.Sequential(*modules)
         self.precision = _DEFAULT_PRECISION
-        self._stack: Optional[FCStack] = None
+        self._stack = None
 
     # ---- engine plumbing ------------------------------------------------------------------
     def linears(self) -> List[_Linear]:
         return [m[0] for m in self.dnn]
 
-    def stack(self) -> FCStack:
+    def stack(self):
         if self._stack is None or self._stack.precision != self.precision:
             lin = self.linears()
-            self._stack = FCStack([l.weight for l in lin], [l.bias for l in lin],
-                                  [L.ACT[a] for a in self.activation_names], self.precision)
+            self._stack = make_stack([l.weight for l in lin], [l.bias for l in lin],
+                                     [L.ACT[a] for a in self.activation_names], self.precision)
         return self._stack
 
     def __deepcopy__(self, memo):

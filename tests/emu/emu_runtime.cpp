@@ -89,7 +89,11 @@ const void* wave_gather(const void* mine, size_t bytes) {
   return w.buf[gen & 1].data();
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+static std::vector<char> g_dyn_lds;
+char* dyn_lds() { return g_dyn_lds.data(); }
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t dyn_lds_bytes) {
+  if (g_dyn_lds.size() < dyn_lds_bytes + 64) g_dyn_lds.resize(dyn_lds_bytes + 64);
   const int n = (int)(block.x * block.y * block.z);
   if (n <= 0 || n > kMaxThreads) {
     fprintf(stderr, "emu: bad block size %d\n", n);

@@ -42,7 +42,8 @@ struct ThreadCtx {
   int linear_tid;
 };
 ThreadCtx& cur();
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t dyn_lds_bytes = 0);
+char* dyn_lds();
 void sync_threads();
 // wave collective: every live lane of the wave deposits `bytes` bytes; returns pointer to a
 // 64-slot array (slot stride = bytes) holding all lanes' values, valid until the next collective.
@@ -86,6 +87,9 @@ static inline bf16_t f32_to_bf16(float f) {
 }
 
 static inline int lane_id() { return ::emu::cur().linear_tid & 63; }
+static inline unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
 
 template <typename T>
 static inline T gather_from(T v, int src_lane) {
@@ -143,3 +147,7 @@ static inline f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
 #define RG_LAUNCH(kernel, grid, block, stream, ...) \
   ::emu::launch(grid, block, [&]() { kernel(__VA_ARGS__); })
 #define RG_LAUNCH_BOUNDS(t, w)
+#define RG_DYN_LDS(name) char* name = ::emu::dyn_lds()
+#define RG_LAUNCH_DYN(kernel, grid, block, lds_bytes, stream, ...) \
+  ::emu::launch(grid, block, [&]() { kernel(__VA_ARGS__); }, lds_bytes)
+#define RG_ALLOW_LDS(kernel, bytes) (void)0

@@ -1,0 +1,117 @@
+"""The fused bf16 FullyConnected-stack kernels (rg_mlp_forward_fused / rg_mlp_backward_fused /
+rg_fc_wgrad_frag / rg_stage_weights_frag) against a float64 statement of the same math with bf16
+rounding applied at the same points (weights, activations and dZ between layers).
+Tolerance: relative Frobenius error < 0.5 % (fp32 accumulation order + rare rounding ties that flip
+a ReLU mask)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import reagent_amd._lib as L
+from reagent_amd.engine import FCStack, FusedMLP, make_stack
+
+ACTS = {"relu": F.relu, "leaky_relu": F.leaky_relu, "tanh": torch.tanh, "linear": lambda x: x}
+
+
+def _net(dims, acts, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    ws = [torch.nn.Parameter((torch.randn(o, i, generator=g) * (1.5 / i ** 0.5)).to(dev)) for i, o in zip(dims, dims[1:])]
+    bs = [torch.nn.Parameter((torch.randn(o, generator=g) * 0.1).to(dev)) for o in dims[1:]]
+    return ws, bs
+
+
+DACT = {"relu": lambda h: (h > 0).double(), "leaky_relu": lambda h: torch.where(h > 0, 1.0, 0.01).double(),
+        "tanh": lambda h: 1 - h * h, "linear": lambda h: torch.ones_like(h)}
+
+
+def _bf(t):
+    return t.float().to(torch.bfloat16).double()
+
+
+def _ref(ws, bs, acts, x, dout):
+    """float64 statement of the kernels' math with bf16 rounding at the same points: weights,
+    activations between layers, dZ between layers (accumulation itself is fp32 on the GPU)."""
+    W = [_bf(w.detach().cpu()) for w in ws]
+    Bv = [b.detach().cpu().double() for b in bs]
+    hs = [_bf(x.cpu())]
+    for l, (w, b, a) in enumerate(zip(W, Bv, acts)):
+        z = ACTS[a](hs[-1] @ w.t() + b)
+        hs.append(z if l == len(W) - 1 else _bf(z))
+    dz = _bf(dout.cpu())
+    dws, dbs = [None] * len(W), [None] * len(W)
+    for l in range(len(W) - 1, -1, -1):
+        dws[l] = dz.t() @ hs[l]
+        dbs[l] = dz.sum(0)
+        dh = dz @ W[l]
+        if l > 0:
+            dz = _bf(dh * DACT[acts[l - 1]](hs[l]))
+    return hs[-1], dws, dbs, dh
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("dims,acts,batch", [
+    ([24, 256, 256, 16], ["relu", "relu", "linear"], 100),
+    ([128, 512, 512, 512, 16], ["relu", "relu", "relu", "linear"], 300),
+    ([130, 256, 256, 70], ["leaky_relu", "tanh", "linear"], 129),
+    ([40, 512, 512, 3], ["tanh", "relu", "linear"], 64),
+])
+def test_fused_forward_backward_wgrad(backend, dims, acts, batch):
+    dev = backend.device
+    ws, bs = _net(dims, acts, 1, dev)
+    codes = [L.ACT[a] for a in acts]
+    assert FusedMLP.supported(ws, codes)
+    st = make_stack(ws, bs, codes, L.PREC_BF16)
+    assert isinstance(st, FusedMLP)
+    st.set_need_input_grad(True)
+    st.stage_weights(need_transposed=True)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(batch, dims[0], generator=g).to(dev)
+    dout = (torch.randn(batch, dims[-1], generator=g) / batch).to(dev)
+    out = torch.zeros(batch, dims[-1], device=dev)
+    xc, xt = st.stage_input(x, True)
+    st.forward(xc, out, save=True)
+    dw = [torch.zeros_like(w) for w in ws]
+    db = [torch.zeros_like(b) for b in bs]
+    dx = torch.zeros(batch, dims[0], device=dev)
+    st.backward(dout, xt, dw, db, dx32=dx)
+    ref_out, ref_dw, ref_db, ref_dx = _ref(ws, bs, acts, x, dout)
+    assert _rel(out, ref_out) < 2e-3, _rel(out, ref_out)
+    for l in range(len(ws)):
+        assert _rel(dw[l], ref_dw[l]) < 5e-3, (l, _rel(dw[l], ref_dw[l]))
+        assert _rel(db[l], ref_db[l]) < 5e-3, (l, _rel(db[l], ref_db[l]))
+    assert _rel(dx, ref_dx) < 5e-3
+    # non-saving forward gives the same outputs (bit for bit: same kernel, same order)
+    out2 = torch.zeros_like(out)
+    st.forward(xc, out2, save=False)
+    assert torch.equal(out2, out)
+    # bf16 input is accepted as well
+    out3 = torch.zeros_like(out)
+    st.forward(x.to(torch.bfloat16), out3, save=False)
+    assert torch.equal(out3, out)
+
+
+def test_fused_matches_per_layer_bf16_engine(backend):
+    """Same math as the per-layer bf16 GEMM path (both round activations to bf16 between layers)."""
+    dev = backend.device
+    dims, acts = [64, 256, 256, 8], ["relu", "relu", "linear"]
+    ws, bs = _net(dims, acts, 5, dev)
+    codes = [L.ACT[a] for a in acts]
+    fused, plain = make_stack(ws, bs, codes, L.PREC_BF16), FCStack(ws, bs, codes, L.PREC_BF16)
+    fused.stage_weights(True)
+    plain.stage_weights(True)
+    x = torch.randn(200, 64, generator=torch.Generator().manual_seed(3)).to(dev)
+    o1, o2 = torch.zeros(200, 8, device=dev), torch.zeros(200, 8, device=dev)
+    fused.forward(fused.stage_input(x, False)[0], o1)
+    plain.forward(plain.stage_input(x, False)[0], o2)
+    assert (o1 - o2).abs().max() <= 2e-3 * max(1.0, o2.abs().max().item())
+
+
+def test_unsupported_shapes_fall_back_to_per_layer(backend):
+    dev = backend.device
+    ws, bs = _net([16, 128, 64, 4], ["relu", "relu", "linear"], 0, dev)
+    assert isinstance(make_stack(ws, bs, [1, 1, 0], L.PREC_BF16), FCStack)
+    ws, bs = _net([16, 256, 256, 4], ["relu", "relu", "linear"], 0, dev)
+    assert isinstance(make_stack(ws, bs, [1, 1, 0], L.PREC_F32), FCStack)
