@@ -140,17 +140,29 @@ def kernel_profile(args, loop, steps, layer_dims):
         for _ in range(steps):
             loop.step()
     rows = prof.summary()
-    fc = [r for r in rows if r["name"] in ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad")]
+    fc_names = ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad", "rg_fc_wgrad_frag", "rg_mlp_forward_fused",
+                "rg_mlp_backward_fused")
+    fc = [r for r in rows if r["name"] in fc_names]
     for r in fc:
         m = r["meta"]
-        r["flop_per_launch"] = 2.0 * m["M"] * m["N"] * m["K"]
+        if r["name"] == "rg_mlp_forward_fused":
+            d = m["dims"]
+            r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d, d[1:]))
+            r["label"] = f"rg_mlp_forward_fused B={m['B']} dims={list(d)} save={m['save']}"
+        elif r["name"] == "rg_mlp_backward_fused":
+            d = m["dims"]
+            r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d[1:], d[2:]))
+            r["label"] = f"rg_mlp_backward_fused B={m['B']} dims={list(d)}"
+        else:
+            r["flop_per_launch"] = 2.0 * m["M"] * m["N"] * m["K"]
+            r["label"] = f"{r['name']} M={m['M']} N={m['N']} K={m['K']}"
     peak = MFMA_PEAK[args.precision]
     out = {}
     if fc:
         dom = fc[0]
         sec = dom["ms"] * 1e-3 / dom["calls"]
         ach = dom["flop_per_launch"] / sec
-        out["roofline"] = {"bound": "mfma", "kernel": f"{dom['name']} M={dom['meta']['M']} N={dom['meta']['N']} K={dom['meta']['K']}",
+        out["roofline"] = {"bound": "mfma", "kernel": dom["label"],
                            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
                            "avg_launch_us": sec * 1e6, "launches_per_step": dom["calls"] / steps, "traffic": None}
         fc_ms = sum(r["ms"] for r in fc) / steps
@@ -165,7 +177,7 @@ def kernel_profile(args, loop, steps, layer_dims):
         out["gather"] = {"bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": bytes_ / sec / HBM_PEAK, "avg_launch_us": sec * 1e6,
                          "algorithmic_bytes_per_transition": g[0]["meta"]["bytes_per_row"]}
-    out["per_call_ms_per_step"] = {f"{r['name']}{tuple(r['meta'].values())}": round(r["ms"] / steps, 4) for r in rows[:16]}
+    out["per_call_ms_per_step"] = {f"{r['name']}{tuple(r['meta'].values())}": round(r["ms"] / steps, 4) for r in rows[:18]}
     return out
 
 

@@ -16,7 +16,7 @@ echo "== pytest -m gpu =="; timeout 1200 python -m pytest tests -m gpu -q -x --n
 echo "== bench bf16 =="; timeout 900 python bench.py --steps 30 --warmup 5 > $OUT/bench_bf16_$TAG.json 2> $OUT/bench_bf16_$TAG.err; echo "rc=$?"; cat $OUT/bench_bf16_$TAG.json; tail -5 $OUT/bench_bf16_$TAG.err
 echo "== bench f32 =="; timeout 900 python bench.py --steps 5 --warmup 2 --precision f32 --no-cpu-baseline > $OUT/bench_f32_$TAG.json 2> $OUT/bench_f32_$TAG.err; echo "rc=$?"; cat $OUT/bench_f32_$TAG.json; tail -5 $OUT/bench_f32_$TAG.err
 echo "== rocprofv3 kernel trace =="
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
 cd /root/repo
 find $OUT/prof_$TAG -name "*stats*" | head; 
 for f in $(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1); do head -25 $f; done

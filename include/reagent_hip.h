@@ -96,6 +96,7 @@ typedef struct {
   const float* bias[RG_MLP_MAX_LAYERS];
   void* act_frag[RG_MLP_MAX_LAYERS];          /* [l] = saved INPUT of layer l, C-fragment order */
   void* dz_frag[RG_MLP_MAX_LAYERS];           /* [l] = d loss / d pre-activation output of layer l */
+  float* db[RG_MLP_MAX_LAYERS];               /* backward output: bias gradients [dims[l+1]] (nullable) */
 } rg_mlp_desc; /* host struct */
 
 int rg_mlp_fused_supported(const rg_mlp_desc* d);
@@ -110,14 +111,18 @@ int rg_stage_weights_frag(const float* w, int out_features, int in_features, voi
 int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64_t ldx, int batch,
                          float* out32, int64_t ldo, int save, rg_stream_t stream);
 /* Given dout32 = d loss / d out32: writes dz_frag[0..L-1] (needs act_frag[1..L-1] from a saving
- * forward of the same batch); dx32 (nullable) = d loss / d x, fp32 [batch, dims[0]]. */
+ * forward of the same batch) and the bias gradients d->db[l] (column sums of dZ_l, reduced
+ * deterministically from per-workgroup partials in `workspace`); dx32 (nullable) = d loss / d x,
+ * fp32 [batch, dims[0]]. */
+size_t rg_mlp_backward_fused_workspace_bytes(const rg_mlp_desc* d, int batch);
 int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch,
-                          float* dx32, int64_t lddx, rg_stream_t stream);
-/* dw [out, in] fp32 = dz^T x, db [out] (nullable) = column sums of dz, from C-fragment operands
- * dz_frag (batch x out) and x_frag (batch x in).  Deterministic split over the batch. */
+                          float* dx32, int64_t lddx, void* workspace, size_t workspace_bytes,
+                          rg_stream_t stream);
+/* dw [out, in] fp32 = dz^T x from C-fragment operands dz_frag (batch x out) and x_frag
+ * (batch x in).  Deterministic split over the batch. */
 size_t rg_fc_wgrad_frag_workspace_bytes(int out_features, int in_features, int batch);
 int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, int in_features,
-                     int batch, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                     int batch, float* dw, void* workspace, size_t workspace_bytes,
                      rg_stream_t stream);
 
 /* ---- replay buffer ------------------------------------------------------------------------ */

@@ -35,6 +35,7 @@ struct MlpArgs {
   const float* bias[FB_MAXL];
   bf16_t* act_frag[FB_MAXL + 1];  // [l] = input of layer l in C-fragment order ([0] = network input)
   bf16_t* dz_frag[FB_MAXL];       // [l] = d loss / d (pre-activation output of layer l)
+  float* db_part[FB_MAXL];        // backward: [n_workgroups][dims[l+1]] bias-gradient partials (nullable)
   const void* x;                  // forward input [batch, dims[0]] row-major, bf16 or fp32
   long ldx;
   int x_is_f32;
@@ -49,6 +50,20 @@ struct MlpArgs {
 };
 
 __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// compile-time activation (a runtime `switch` per element would bloat the unrolled epilogues until
+// the unroller gives up and the accumulator arrays fall into scratch)
+template <int ACT> __device__ __forceinline__ float act_t(float z) { return act_apply(z, ACT); }
+template <int ACT> __device__ __forceinline__ float act_grad_t(float h) { return act_grad_from_output(h, ACT); }
+#define RG_DISPATCH_ACT(act, ...)                                                   \
+  switch (act) {                                                                    \
+    case ACT_RELU: { constexpr int A_ = ACT_RELU; __VA_ARGS__; } break;             \
+    case ACT_LEAKY_RELU: { constexpr int A_ = ACT_LEAKY_RELU; __VA_ARGS__; } break; \
+    case ACT_TANH: { constexpr int A_ = ACT_TANH; __VA_ARGS__; } break;             \
+    case ACT_SIGMOID: { constexpr int A_ = ACT_SIGMOID; __VA_ARGS__; } break;       \
+    case ACT_SOFTPLUS: { constexpr int A_ = ACT_SOFTPLUS; __VA_ARGS__; } break;     \
+    default: { constexpr int A_ = ACT_LINEAR; __VA_ARGS__; } break;                 \
+  }
 
 // C-fragment order: element (row, col) lives in block (row/32, col/32), half h, lane, e with
 //   col%32 = lane&31,  row%32 = (r&3) + 8*(r>>2) + 4*(lane>>5),  r = 8*h + e   (MFMA 32x32 D layout)
@@ -199,6 +214,55 @@ __device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int K
   return acc;
 }
 
+template <int TN, int ACT>
+__device__ __forceinline__ void fwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const float* bias,
+                                                    bf16_t* save_dst, int NT, int mb_base, int wave, int lane) {
+  const int lr = lane & 31;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int nt = wave * TN + tn, col = nt * 32 + lr;
+    const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
+      if (save_dst) store_tile_frags(save_dst, mb_base + tm, nt, NT, lane, v);
+      store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
+    }
+  }
+}
+
+// dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
+template <int TN, int ACT>
+__device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const bf16_t* h_frag,
+                                                    bf16_t* dz_dst, float* db_part, int NT, int mb_base, int wave,
+                                                    int lane) {
+  const int lr = lane & 31;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int nt = wave * TN + tn, col = nt * 32 + lr;
+    float colsum = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      float v[16];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u16x8 hf = *(const u16x8*)(h_frag + frag_offset(mb_base + tm, nt, NT, h, lane));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_t<ACT>(bf16_to_f32(hf[e]));
+          colsum += v[8 * h + e];
+        }
+      }
+      store_tile_frags(dz_dst, mb_base + tm, nt, NT, lane, v);
+      store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
+    }
+    colsum += shfl_xor(colsum, 32);
+    if (db_part && lane < 32) db_part[col] = colsum;
+  }
+}
+
 template <int TN>
 __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
   RG_DYN_LDS(smem);
@@ -229,25 +293,13 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       const long nt_stride = (long)KC * 512;
       wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg);
       __syncthreads();  // every wave is done reading the layer input
-      const int NT = N / 32;
-      const bf16_t* dummy = nullptr;
-      (void)dummy;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int nt = wave * TN + tn, col = nt * 32 + lr;
-        const float b = a.bias[l] ? a.bias[l][col] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-          float v[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = act_apply(acc[tm][tn][r] + b, a.acts[l]);
-          if (a.save && a.act_frag[l + 1]) store_tile_frags(a.act_frag[l + 1], blockIdx.x * 4 + tm, nt, NT, lane, v);
-          store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
-        }
-      }
+      RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.bias[l],
+                                                              (a.save ? a.act_frag[l + 1] : nullptr), N / 32,
+                                                              blockIdx.x * 4, wave, lane)));
       __syncthreads();
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
+      const int out_act = a.acts[l];
       for (int t = wave; t < 4 * NTo; t += FB_THREADS / 64) {
         const int tm = t & 3, nt = t >> 2;
         const f32x16 acc = tile_kloop(act, pitch, KC, a.wfrag[l], tm, nt, lane);
@@ -257,7 +309,7 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-            if (row < a.batch) a.out32[(long)row * a.ldo + col] = act_apply(acc[r] + b, a.acts[l]);
+            if (row < a.batch) a.out32[(long)row * a.ldo + col] = act_apply(acc[r] + b, out_act);
           }
         }
       }
@@ -278,6 +330,11 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
   load_tile_to_lds<float>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
   emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, lane);
+  if (a.db_part[L - 1] && tid < a.dims[L]) {
+    float s = 0.f;
+    for (int r = 0; r < FB_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]);
+    a.db_part[L - 1][(long)blockIdx.x * a.dims[L] + tid] = s;
+  }
 
   for (int l = L - 1; l >= 1; --l) {
     // dH = dZ_l (LDS, width dims[l+1]) . W_l -> [128, dims[l]] ; dZ_{l-1} = dH * act'(H_l)
@@ -293,25 +350,10 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
     const long nt_stride = (long)KC * 512;
     wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg);
     __syncthreads();
-    const int NT = N / 32;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int nt = wave * TN + tn, col = nt * 32 + lr;
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
-        const int mb = blockIdx.x * 4 + tm;
-        float v[16];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const u16x8 hf = *(const u16x8*)(a.act_frag[l] + frag_offset(mb, nt, NT, h, lane));
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_from_output(bf16_to_f32(hf[e]), a.acts[l - 1]);
-        }
-        store_tile_frags(a.dz_frag[l - 1], mb, nt, NT, lane, v);
-        store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
-      }
-    }
+    RG_DISPATCH_ACT(a.acts[l - 1],
+                    (bwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.act_frag[l], a.dz_frag[l - 1],
+                                                 a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr,
+                                                 N / 32, blockIdx.x * 4, wave, lane)));
     __syncthreads();
   }
   if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
@@ -350,8 +392,6 @@ struct WgradFragArgs {
   float* partial;     // [splits][N*K]
   long slab;
   int N, K;           // valid extents of dW
-  float* bias_partial;  // [splits][N] or null
-  long bias_slab;
 };
 
 __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
@@ -370,18 +410,12 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
   const int na = (g.NTa - ta0 < 8) ? g.NTa - ta0 : 8, nb = (g.NTb - tb0 < 8) ? g.NTb - tb0 : 8;
 
   f32x16 acc[4][2];
-  f32x16 accb[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  }
-  const bool do_bias = g.bias_partial && kg == 0 && wk == 0;
-  const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   // staging registers: 4096 16-byte units per stage / 512 threads
   constexpr int UNITS = WG_MB_STAGE * 2048, PER = UNITS / FB_THREADS;
@@ -428,10 +462,6 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
-        if (do_bias) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) accb[i] = mfma_32x32x16_bf16(af[i], ones, accb[i]);
-        }
       }
     }
   };
@@ -464,16 +494,6 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
         if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
       }
     }
-  if (do_bias && lr == 0) {
-    float* bp = g.bias_partial + (long)split * g.bias_slab;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (ta0 + wn * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-        if (row < g.N) bp[row] = accb[i][r];
-      }
-  }
 }
 
 __global__ void reduce_splits2_kernel(const float* __restrict__ partials, long slab, int splits,
@@ -565,6 +585,7 @@ static int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int backward) 
     a.wfrag[l] = (const bf16_t*)(backward ? d->wfrag_bwd[l] : d->wfrag_fwd[l]);
     a.bias[l] = d->bias[l];
     a.dz_frag[l] = (bf16_t*)d->dz_frag[l];
+    a.db_part[l] = nullptr;
     if (!a.wfrag[l] && !(backward && l == 0)) return RG_EINVAL;
   }
   for (int l = 0; l <= d->n_layers; ++l) a.act_frag[l] = (bf16_t*)(l < d->n_layers ? d->act_frag[l] : nullptr);
@@ -598,22 +619,40 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   return (int)hipGetLastError();
 }
 
+size_t rg_mlp_backward_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
+  if (!d || batch <= 0) return 0;
+  size_t cols = 0;
+  for (int l = 0; l < d->n_layers; ++l) cols += (size_t)d->dims[l + 1];
+  return (size_t)((batch + FB_BM - 1) / FB_BM) * cols * sizeof(float);
+}
+
 int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch, float* dx32,
-                          int64_t lddx, rg_stream_t stream) {
+                          int64_t lddx, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
   const int tn = fused_supported(d);
   if (!tn) return RG_EUNSUPPORTED;
   if (!dout32 || batch <= 0) return RG_EINVAL;
   MlpArgs a;
   int rc = fill_args(d, batch, a, 1);
   if (rc) return rc;
+  bool want_db = false;
   for (int l = 0; l < d->n_layers; ++l) {
     if (!d->dz_frag[l]) return RG_EINVAL;
     if (l >= 1 && !d->act_frag[l]) return RG_EINVAL;
+    if (d->db[l]) want_db = true;
   }
   if (dx32 && !d->wfrag_bwd[0]) return RG_EINVAL;
+  const int n_wg = (batch + FB_BM - 1) / FB_BM;
+  if (want_db) {
+    if (!workspace || workspace_bytes < rg_mlp_backward_fused_workspace_bytes(d, batch)) return RG_EWORKSPACE;
+    float* p = (float*)workspace;
+    for (int l = 0; l < d->n_layers; ++l) {
+      a.db_part[l] = d->db[l] ? p : nullptr;
+      p += (size_t)n_wg * d->dims[l + 1];
+    }
+  }
   a.dout32 = dout32; a.lddo = lddo; a.dx32 = dx32; a.lddx = lddx;
   const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
-  const dim3 grid((batch + FB_BM - 1) / FB_BM), block(FB_THREADS);
+  const dim3 grid(n_wg), block(FB_THREADS);
   if (tn == 1) {
     RG_ALLOW_LDS(mlp_bwd_fused_kernel<1>, lds);
     RG_LAUNCH_DYN(mlp_bwd_fused_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
@@ -621,12 +660,20 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
     RG_ALLOW_LDS(mlp_bwd_fused_kernel<2>, lds);
     RG_LAUNCH_DYN(mlp_bwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
   }
+  rc = (int)hipGetLastError();
+  if (rc) return rc;
+  for (int l = 0; l < d->n_layers; ++l) {
+    if (!a.db_part[l]) continue;
+    const int n = d->dims[l + 1];
+    RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
+              (const float*)a.db_part[l], (long)n, n_wg, d->db[l], (long)n);
+  }
   return (int)hipGetLastError();
 }
 
 struct WgradFragPlan {
   int NTa, NTb, MB, splits, mb_per_split;
-  long slab, bias_slab;
+  long slab;
 };
 static WgradFragPlan wgrad_frag_plan(int out_f, int in_f, int batch) {
   WgradFragPlan p;
@@ -643,25 +690,23 @@ static WgradFragPlan wgrad_frag_plan(int out_f, int in_f, int batch) {
   p.mb_per_split = per;
   p.splits = (p.MB + per - 1) / per;
   p.slab = (long)out_f * in_f;
-  p.bias_slab = out_f;
   return p;
 }
 
 size_t rg_fc_wgrad_frag_workspace_bytes(int out_features, int in_features, int batch) {
   const WgradFragPlan p = wgrad_frag_plan(out_features, in_features, batch > 0 ? batch : 1);
-  return (size_t)p.splits * (p.slab + p.bias_slab) * sizeof(float);
+  return (size_t)p.splits * p.slab * sizeof(float);
 }
 
 int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, int in_features, int batch,
-                     float* dw, float* db, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
+                     float* dw, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
   if (!dz_frag || !x_frag || !dw || out_features <= 0 || in_features <= 0 || batch <= 0) return RG_EINVAL;
   const WgradFragPlan p = wgrad_frag_plan(out_features, in_features, batch);
-  if (!workspace || workspace_bytes < (size_t)p.splits * (p.slab + p.bias_slab) * sizeof(float)) return RG_EWORKSPACE;
+  if (!workspace || workspace_bytes < (size_t)p.splits * p.slab * sizeof(float)) return RG_EWORKSPACE;
   WgradFragArgs g;
   g.a_frag = (const bf16_t*)dz_frag; g.b_frag = (const bf16_t*)x_frag;
   g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
-  g.bias_partial = db ? g.partial + (long)p.splits * p.slab : nullptr; g.bias_slab = p.bias_slab;
   const int grid = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
   const size_t lds = 2 * (size_t)WG_STAGE_BYTES;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
@@ -671,9 +716,6 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   const long n = p.slab;
   RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
             (const float*)g.partial, p.slab, p.splits, dw, n);
-  if (db)
-    RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((out_features + 255) / 256)), dim3(256), (hipStream_t)stream,
-              (const float*)g.bias_partial, p.bias_slab, p.splits, db, (long)out_features);
   return (int)hipGetLastError();
 }
 

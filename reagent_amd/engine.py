@@ -315,6 +315,9 @@ class FusedMLP:
             nbytes = max(lib.rg_fc_wgrad_frag_workspace_bytes(self.dims[l + 1], self.dims[l], batch)
                          for l in range(self.L))
             ws["wgrad"] = torch.empty(_round_up(nbytes, 16) // 4, dtype=torch.float32, device=device)
+            self._ws = ws
+            nb = lib.rg_mlp_backward_fused_workspace_bytes(self._fill_desc(), batch)
+            ws["bwd"] = torch.empty(_round_up(nb, 16) // 4, dtype=torch.float32, device=device)
         self._ws = ws
         self._batch = batch
 
@@ -356,19 +359,21 @@ class FusedMLP:
         assert self._ws.get("key") == (B, dout32.device, True), "backward needs a saving forward first"
         d = self._fill_desc()
         lib = L.lib()
+        ws = self._ws
+        for l in range(self.L):
+            d.db[l] = db[l].data_ptr() if db[l] is not None else None
         ops._run("rg_mlp_backward_fused", dict(B=B, dims=tuple(self.dims)),
                  lambda: lib.rg_mlp_backward_fused(d, dout32.data_ptr(), dout32.stride(0), B,
                                                    dx32.data_ptr() if dx32 is not None else None,
-                                                   dx32.stride(0) if dx32 is not None else 0, L.stream_ptr()))
-        ws = self._ws
+                                                   dx32.stride(0) if dx32 is not None else 0,
+                                                   ws["bwd"].data_ptr(), ws["bwd"].numel() * 4, L.stream_ptr()))
         wsb = ws["wgrad"].numel() * 4
         for l in range(self.L):
             out_f, in_f = self.dims[l + 1], self.dims[l]
             ops._run("rg_fc_wgrad_frag", dict(M=out_f, N=in_f, K=B),
                      lambda l=l, out_f=out_f, in_f=in_f: lib.rg_fc_wgrad_frag(
                          ws["dz_frag"][l].data_ptr(), ws["act_frag"][l].data_ptr(), out_f, in_f, B,
-                         dw[l].data_ptr(), db[l].data_ptr() if db[l] is not None else None,
-                         ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
+                         dw[l].data_ptr(), ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
 
 
 def make_stack(weights, biases, acts: List[int], precision: int):
