@@ -1,0 +1,12 @@
+#!/bin/bash
+# quick perf iteration: fused-path GPU tests + bf16 bench only
+cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT; TAG=${1:-it}
+timeout 600 python -m pytest tests/test_fused_mlp.py tests/test_dqn_trainer.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -3
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "rc=$?"
+python - <<PY
+import json
+r=json.load(open("$OUT/bench_$TAG.json"))
+print("value %.3e  ms/step %.3f  fc_frac %.4f  dom %s" % (r["value"], r["ms_per_step"], r.get("fc_roofline",{}).get("frac",0), r.get("roofline",{}).get("kernel")))
+for k,v in r["per_call_ms_per_step"].items(): print("  %-70s %.4f" % (k,v))
+PY
+tail -3 $OUT/bench_$TAG.err

@@ -153,54 +153,117 @@ __device__ __forceinline__ void store_tile_frags(bf16_t* dst, int mb, int nt, in
 }
 
 // ---- main loop of a wide layer: this wave's [128 x 32*TN] slice over K ------------------------
+// `rot` rotates the order in which the K chunks are visited (a sum may be taken in any order):
+// every workgroup streams the SAME weight fragments, and without de-phasing all 256 CUs would
+// hammer one L2 channel at a time.
+// Software pipeline: the weight (B) fragments come from L2 (~0.5-1 us under load) and are
+// prefetched three chunks ahead through a ring of four register sets; the activation (A)
+// fragments come from LDS and are prefetched one chunk ahead.
 template <int TN>
 __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_lane,
-                                              long nt_stride, f32x16 (&acc)[4][TN], int lr, int lg) {
-  const bf16_t* arow[4];
+                                              long nt_stride, f32x16 (&acc)[4][TN], int lr, int lg, int rot) {
+  auto kx = [&](int kc) { const int k = kc + rot; return k >= KC ? k - KC : k; };
+  const bf16_t* arow = act + lr * pitch + lg * 8;
+  const int tm_stride = 32 * pitch;
+  u16x8 a0[4], a1[4], b0[TN], b1[TN], b2[TN], b3[TN];
+  auto loadB = [&](u16x8 (&bf)[TN], int kc) {
+    const long off = (long)kx(kc) * 512;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) arow[tm] = act + (tm * 32 + lr) * pitch + lg * 8;
-  u16x8 b0[TN], b1[TN];
+    for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + off);
+  };
+  auto loadA = [&](u16x8 (&af)[4], int kc) {
+    const int off = kx(kc) * 16;
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) b0[tn] = *(const u16x8*)(wf_lane + tn * nt_stride);
-  int kc = 0;
-  for (; kc + 1 < KC; kc += 2) {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) b1[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + (long)(kc + 1) * 512);
-    {
-      u16x8 af[4];
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow[tm] + kc * 16);
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], b0[tn], acc[tm][tn]);
-    }
-    if (kc + 2 < KC) {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b0[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + (long)(kc + 2) * 512);
-    }
-    {
-      u16x8 af[4];
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow[tm] + (kc + 1) * 16);
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], b1[tn], acc[tm][tn]);
-    }
-  }
-  if (kc < KC) {
-    u16x8 af[4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow[tm] + kc * 16);
+    for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow + tm * tm_stride + off);
+  };
+  auto mma = [&](const u16x8 (&af)[4], const u16x8 (&bf)[TN]) {
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], b0[tn], acc[tm][tn]);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
+  };
+  if ((KC & 3) == 0) {
+    // fast path: no conditionals around the loads in the steady state, so the compiler can keep
+    // exact s_waitcnt vmcnt(N)/lgkmcnt(N) counts (6 weight loads + 4 LDS reads stay in flight)
+    loadB(b0, 0);
+    loadB(b1, 1);
+    loadB(b2, 2);
+    loadA(a0, 0);
+    int kc = 0;
+    for (; kc < KC - 4; kc += 4) {
+      loadB(b3, kc + 3);
+      loadA(a1, kc + 1);
+      sched_fence();
+      mma(a0, b0);
+      sched_fence();
+      loadB(b0, kc + 4);
+      loadA(a0, kc + 2);
+      sched_fence();
+      mma(a1, b1);
+      sched_fence();
+      loadB(b1, kc + 5);
+      loadA(a1, kc + 3);
+      sched_fence();
+      mma(a0, b2);
+      sched_fence();
+      loadB(b2, kc + 6);
+      loadA(a0, kc + 4);
+      sched_fence();
+      mma(a1, b3);
+      sched_fence();
+    }
+    loadB(b3, kc + 3);
+    loadA(a1, kc + 1);
+    sched_fence();
+    mma(a0, b0);
+    sched_fence();
+    loadA(a0, kc + 2);
+    sched_fence();
+    mma(a1, b1);
+    sched_fence();
+    loadA(a1, kc + 3);
+    sched_fence();
+    mma(a0, b2);
+    mma(a1, b3);
+    return;
+  }
+  // generic K: same ring with guarded loads
+  loadB(b0, 0);
+  if (KC > 1) loadB(b1, 1);
+  if (KC > 2) loadB(b2, 2);
+  loadA(a0, 0);
+  for (int kc = 0; kc < KC; kc += 4) {
+    if (kc + 3 < KC) loadB(b3, kc + 3);
+    if (kc + 1 < KC) loadA(a1, kc + 1);
+    sched_fence();
+    mma(a0, b0);
+    sched_fence();
+    if (kc + 1 < KC) {
+      if (kc + 4 < KC) loadB(b0, kc + 4);
+      if (kc + 2 < KC) loadA(a0, kc + 2);
+      sched_fence();
+      mma(a1, b1);
+      sched_fence();
+    }
+    if (kc + 2 < KC) {
+      if (kc + 5 < KC) loadB(b1, kc + 5);
+      if (kc + 3 < KC) loadA(a1, kc + 3);
+      sched_fence();
+      mma(a0, b2);
+      sched_fence();
+    }
+    if (kc + 3 < KC) {
+      if (kc + 6 < KC) loadB(b2, kc + 6);
+      if (kc + 4 < KC) loadA(a0, kc + 4);
+      sched_fence();
+      mma(a1, b3);
+      sched_fence();
+    }
   }
 }
 
-// one 32x32 output tile (row tile tm, weight n-tile nt) over K; used for narrow / irregular widths
+// one 32x32 output tile (row tile tm, weight n-tile nt) over K; used for narrow / irregular widths.
+// Groups of 4 chunks, next group's fragments in flight during the current group's MFMAs.
 __device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf, int tm,
                                              int nt, int lane) {
   const int lr = lane & 31, lg = lane >> 5;
@@ -209,14 +272,40 @@ __device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int K
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int kc = 0; kc < KC; ++kc)
-    acc = mfma_32x32x16_bf16(*(const u16x8*)(arow + kc * 16), *(const u16x8*)(wl + (long)kc * 512), acc);
+  u16x8 a0[4], b0[4], a1[4], b1[4];
+  auto load = [&](u16x8 (&af)[4], u16x8 (&bf)[4], int kc0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kc = kc0 + i < KC ? kc0 + i : KC - 1;  // clamped; the extra products are skipped below
+      bf[i] = *(const u16x8*)(wl + (long)kc * 512);
+      af[i] = *(const u16x8*)(arow + kc * 16);
+    }
+  };
+  auto mma = [&](const u16x8 (&af)[4], const u16x8 (&bf)[4], int kc0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (kc0 + i < KC) acc = mfma_32x32x16_bf16(af[i], bf[i], acc);
+  };
+  load(a0, b0, 0);
+  for (int kc = 0; kc < KC; kc += 8) {
+    if (kc + 4 < KC) load(a1, b1, kc + 4);
+    sched_fence();
+    mma(a0, b0, kc);
+    sched_fence();
+    if (kc + 4 < KC) {
+      if (kc + 8 < KC) load(a0, b0, kc + 8);
+      sched_fence();
+      mma(a1, b1, kc + 4);
+      sched_fence();
+    }
+  }
   return acc;
 }
 
 template <int TN, int ACT>
 __device__ __forceinline__ void fwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const float* bias,
                                                     bf16_t* save_dst, int NT, int mb_base, int wave, int lane) {
+  lane = opaque(lane);
   const int lr = lane & 31;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -238,6 +327,7 @@ template <int TN, int ACT>
 __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const bf16_t* h_frag,
                                                     bf16_t* dz_dst, float* db_part, int NT, int mb_base, int wave,
                                                     int lane) {
+  lane = opaque(lane);
   const int lr = lane & 31;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -291,7 +381,8 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
       const long nt_stride = (long)KC * 512;
-      wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg);
+      wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
+                        (int)((blockIdx.x * 5 + wave * 11) % KC));
       __syncthreads();  // every wave is done reading the layer input
       RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.bias[l],
                                                               (a.save ? a.act_frag[l + 1] : nullptr), N / 32,
@@ -309,7 +400,7 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-            if (row < a.batch) a.out32[(long)row * a.ldo + col] = act_apply(acc[r] + b, out_act);
+            if (row < a.batch) a.out32[(long)row * a.ldo + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
           }
         }
       }
@@ -348,7 +439,8 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
     const long nt_stride = (long)KC * 512;
-    wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg);
+    wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
+                        (int)((blockIdx.x * 5 + wave * 11) % KC));
     __syncthreads();
     RG_DISPATCH_ACT(a.acts[l - 1],
                     (bwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.act_frag[l], a.dz_frag[l - 1],
@@ -494,6 +586,32 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
         if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
       }
     }
+}
+
+// out[c] = sum_s partials[s][c], S x N row-major: 32 columns x 8 row-groups per workgroup, each
+// thread sums rows g, g+8, ... (independent loads in flight), groups combined in fixed order
+__global__ void reduce_cols_kernel(const float* __restrict__ partials, int S, int N, float* __restrict__ out) {
+  __shared__ float red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < N) {
+    int r = g;
+    for (; r + 24 < S; r += 32) {
+      s0 += partials[(long)r * N + c];
+      s1 += partials[(long)(r + 8) * N + c];
+      s2 += partials[(long)(r + 16) * N + c];
+      s3 += partials[(long)(r + 24) * N + c];
+    }
+    for (; r < S; r += 8) s0 += partials[(long)r * N + c];
+  }
+  red[g][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    out[c] = t;
+  }
 }
 
 __global__ void reduce_splits2_kernel(const float* __restrict__ partials, long slab, int splits,
@@ -665,8 +783,8 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   for (int l = 0; l < d->n_layers; ++l) {
     if (!a.db_part[l]) continue;
     const int n = d->dims[l + 1];
-    RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
-              (const float*)a.db_part[l], (long)n, n_wg, d->db[l], (long)n);
+    RG_LAUNCH(reduce_cols_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), (hipStream_t)stream,
+              (const float*)a.db_part[l], n_wg, n, d->db[l]);
   }
   return (int)hipGetLastError();
 }

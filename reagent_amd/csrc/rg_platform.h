@@ -48,6 +48,15 @@ __device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// value the optimiser must treat as unknown here: keeps address arithmetic that depends on it from
+// being hoisted out of an enclosing loop and parked in VGPRs across an MFMA main loop
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+// scheduling fence: nothing is moved across it (pins "issue the loads, then the MFMA block")
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // two floats -> packed bf16x2 (lo in bits 0..15); lowers to one v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);

@@ -87,6 +87,8 @@ static inline bf16_t f32_to_bf16(float f) {
 }
 
 static inline int lane_id() { return ::emu::cur().linear_tid & 63; }
+static inline int opaque(int x) { return x; }
+static inline void sched_fence() {}
 static inline unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
