@@ -201,6 +201,19 @@ int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, 
                 int num_actions, int double_q, int loss_type, float* dq, float* loss_partials,
                 float* next_q, int64_t* next_idx, float* q_sel, rg_stream_t stream);
 
+/* QR-DQN head, reagent/training/qrdqn_trainer.py:108-160 (+ argmax_with_mask :210-214, huber
+ * :217-218, quantiles :70-73).  q / qn_online / qn_target [B, A*N] fp32 = network outputs viewed
+ * (B, A, N); qn_online NULL = select the next action with the target net (double_q off).
+ * next_mask [B, A] = possible_next_actions_mask (maxq != 0) or next_action (SARSA).
+ * Outputs: dq [B, A*N] = d loss / d q; loss_partials [B] whose sum is the loss; all_q [B, A]
+ * (nullable) = mean over atoms of q (the trainer's logged `all_q_values`).  The (N, B, N) pair
+ * tensor of the reference is never materialised.  Limits: N <= 1024, A <= 256. */
+int rg_qr_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
+               const float* next_mask, const float* reward, const float* reward_boosts,
+               const float* not_terminal, double gamma, const float* gamma_exponent,
+               const float* quantiles, int batch, int num_actions, int num_atoms, int maxq, float* dq,
+               float* loss_partials, float* all_q, rg_stream_t stream);
+
 /* out[0] = scale * sum_i in[i], summed in index order by one workgroup (deterministic). */
 int rg_reduce_sum(const float* in, int n, float scale, float* out, rg_stream_t stream);
 

@@ -100,6 +100,8 @@ SIGNATURES = {
                                     c_void_p, c_i64, c_int, c_void_p]),
     "rg_dqn_head_partials": (c_int, [c_int]),
     "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "rg_qr_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                            c_void_p, c_void_p, c_void_p]),
     "rg_reduce_sum": (c_int, [c_void_p, c_int, c_f, c_void_p, c_void_p]),
     "rg_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d,
                               c_d, c_d, c_d, c_void_p]),

@@ -78,6 +78,110 @@ __global__ void dqn_head_kernel(const float* __restrict__ q, const float* __rest
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = s;
 }
 
+// QR-DQN head (reagent/training/qrdqn_trainer.py:108-160): one workgroup per transition.
+//   next atoms : target(next_state)[b, a*, :] with a* = argmax_a mean_atoms(online or target)(+mask)
+//                (maxq) or sum_a target[b,a,:] * next_action[b,a] (SARSA)
+//   target_Q   = r + (gamma * not_done) * next atoms                                  [N]
+//   current    = sum_a q[b,a,:] * action[b,a]                                         [N]
+//   loss       = mean_{i,b,j} huber(T_i - C_j) * |tau_j - 1[T_i - C_j < 0]|   (the (N,B,N) tensor of
+//                the reference is never materialised: the N x N pairs live in registers / LDS)
+//   dq[b,a,j]  = action[b,a] * d loss / d C_j
+constexpr int QR_MAX_ATOMS = 1024;
+constexpr int QR_MAX_ACTIONS = 256;
+
+__global__ void qr_head_kernel(const float* __restrict__ q, const float* __restrict__ qn_online,
+                               const float* __restrict__ qn_target, const float* __restrict__ action,
+                               const float* __restrict__ next_mask, const float* __restrict__ reward,
+                               const float* __restrict__ reward_boosts,
+                               const float* __restrict__ not_terminal, float gamma,
+                               const float* __restrict__ gamma_exponent,
+                               const float* __restrict__ quantiles, int batch, int A, int N, int maxq,
+                               float* __restrict__ dq, float* __restrict__ loss_partials,
+                               float* __restrict__ all_q) {
+  __shared__ float T[QR_MAX_ATOMS];
+  __shared__ float C[QR_MAX_ATOMS];
+  __shared__ float G[QR_MAX_ATOMS];
+  __shared__ float means[QR_MAX_ACTIONS];
+  __shared__ float scratch[4];
+  __shared__ int a_star;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row = (long)b * A * N;
+  const float* act_row = action + (long)b * A;
+  const float* mask_row = next_mask + (long)b * A;
+  // mean over atoms per action (next-state selection values and, for logging, current q)
+  for (int a = wave; a < A; a += HEAD_THREADS / 64) {
+    const float* sel = (qn_online ? qn_online : qn_target) + row + (long)a * N;
+    const float* cur = q + row + (long)a * N;
+    float s = 0.f, c = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      s += sel[j];
+      c += cur[j];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      s += shfl_xor(s, off);
+      c += shfl_xor(c, off);
+    }
+    if (lane == 0) {
+      means[a] = s / (float)N;
+      if (all_q) all_q[(long)b * A + a] = c / (float)N;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && maxq) {
+    int best = 0;
+    float bv = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float v = means[a] + -1e9f * (1.f - mask_row[a]);
+      if (a == 0 || v > bv) {
+        bv = v;
+        best = a;
+      }
+    }
+    a_star = best;
+  }
+  __syncthreads();
+  float rb = 0.f;
+  if (reward_boosts)
+    for (int a = 0; a < A; ++a) rb += act_row[a] * reward_boosts[a];
+  const float rew = reward[b] + rb;
+  const float disc = gamma_exponent ? powf(gamma, gamma_exponent[b]) : gamma;
+  const float dn = disc * not_terminal[b];
+  for (int j = tid; j < N; j += HEAD_THREADS) {
+    float nq;
+    if (maxq) {
+      nq = qn_target[row + (long)a_star * N + j];
+    } else {
+      nq = 0.f;
+      for (int a = 0; a < A; ++a) nq += qn_target[row + (long)a * N + j] * mask_row[a];
+    }
+    T[j] = rew + dn * nq;
+    float c = 0.f;
+    for (int a = 0; a < A; ++a) c += q[row + (long)a * N + j] * act_row[a];
+    C[j] = c;
+  }
+  __syncthreads();
+  const float inv = 1.f / ((float)N * (float)batch * (float)N);
+  float loss = 0.f;
+  for (int j = tid; j < N; j += HEAD_THREADS) {
+    const float cj = C[j], tau = quantiles[j];
+    float l = 0.f, g = 0.f;
+    for (int i = 0; i < N; ++i) {
+      const float td = T[i] - cj;
+      const float ad = fabsf(td);
+      const float w = fabsf(tau - (td < 0.f ? 1.f : 0.f));
+      l += (ad < 1.f ? 0.5f * td * td : ad - 0.5f) * w;
+      g += (ad < 1.f ? td : (td > 0.f ? 1.f : -1.f)) * w;
+    }
+    loss += l;
+    G[j] = -g * inv;
+  }
+  __syncthreads();
+  for (int k = tid; k < A * N; k += HEAD_THREADS) dq[row + k] = act_row[k / N] * G[k % N];
+  const float s = block_sum_256(loss, scratch);
+  if (tid == 0) loss_partials[b] = s * inv;
+}
+
 __global__ void reduce_sum_kernel(const float* __restrict__ in, int n, float scale,
                                   float* __restrict__ out) {
   __shared__ float scratch[4];
@@ -108,6 +212,21 @@ int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, 
             (hipStream_t)stream, q, qn_online, qn_target, action, next_mask, reward, reward_boosts,
             not_terminal, (float)gamma, gamma_exponent, batch, num_actions, double_q, loss_type, dq,
             loss_partials, next_q, next_idx, q_sel);
+  return (int)hipGetLastError();
+}
+
+int rg_qr_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
+               const float* next_mask, const float* reward, const float* reward_boosts,
+               const float* not_terminal, double gamma, const float* gamma_exponent,
+               const float* quantiles, int batch, int num_actions, int num_atoms, int maxq, float* dq,
+               float* loss_partials, float* all_q, rg_stream_t stream) {
+  if (!q || !qn_target || !action || !next_mask || !reward || !not_terminal || !quantiles || !dq ||
+      !loss_partials || batch <= 0 || num_actions <= 0 || num_atoms <= 0)
+    return RG_EINVAL;
+  if (num_atoms > QR_MAX_ATOMS || num_actions > QR_MAX_ACTIONS) return RG_EUNSUPPORTED;
+  RG_LAUNCH(qr_head_kernel, dim3(batch), dim3(HEAD_THREADS), (hipStream_t)stream, q, qn_online, qn_target,
+            action, next_mask, reward, reward_boosts, not_terminal, (float)gamma, gamma_exponent, quantiles,
+            batch, num_actions, num_atoms, maxq, dq, loss_partials, all_q);
   return (int)hipGetLastError();
 }
 

@@ -210,6 +210,20 @@ def dqn_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, 
                                      L.ptr(next_idx), L.ptr(q_sel), L.stream_ptr()))
 
 
+def qr_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma,
+            gamma_exponent, quantiles, num_atoms, maxq, dq, loss_partials, all_q=None):
+    _chk_dev(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma_exponent,
+             quantiles, dq, loss_partials, all_q)
+    batch, A = action.shape
+    for t in (q, qn_online, qn_target, dq):
+        assert t is None or (t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A * num_atoms))
+    _run("rg_qr_head", dict(B=batch, A=A, N=num_atoms),
+         lambda: L.lib().rg_qr_head(L.ptr(q), L.ptr(qn_online), L.ptr(qn_target), L.ptr(action), L.ptr(next_mask),
+                                    L.ptr(reward), L.ptr(reward_boosts), L.ptr(not_terminal), float(gamma),
+                                    L.ptr(gamma_exponent), L.ptr(quantiles), batch, A, num_atoms, int(maxq),
+                                    L.ptr(dq), L.ptr(loss_partials), L.ptr(all_q), L.stream_ptr()))
+
+
 def reduce_sum(inp, n: int, scale: float, out):
     _chk_dev(inp, out)
     _run("rg_reduce_sum", dict(n=n), lambda: L.lib().rg_reduce_sum(L.ptr(inp), n, scale, L.ptr(out), L.stream_ptr()))

@@ -46,7 +46,143 @@ class _HipLoss(torch.autograd.Function):
         return (None, None) + (None,) * len(ctx.owner._hip_params)
 
 
-class DQNTrainer(DQNTrainerBaseLightning):
+class QStepCore(DQNTrainerBaseLightning):
+    """Engine shared by DQNTrainer and QRDQNTrainer: flat parameter slab, FC stacks, the
+    3-forward / head / backward sequence, the autograd bridge and the fused native step.
+    Subclasses provide the head (``_alloc_head`` / ``_run_head``) and ``_out_cols``."""
+
+    _ws_batch = -1
+    _dp_group = None
+    _dp_world = 1
+
+    def _out_cols(self) -> int:
+        return self.num_actions
+
+    # ---- optimizers (dqn_trainer.py:119-155 / qrdqn_trainer.py:81-106) ------------------------
+    def configure_optimizers(self):
+        optimizers = []
+        target_params = list(self.q_network_target.parameters())
+        source_params = list(self.q_network.parameters())
+        optimizers.append(self.q_network_optimizer.make_optimizer_scheduler(self.q_network.parameters()))
+        optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
+        return optimizers
+
+    # ---- engine -------------------------------------------------------------------------------
+    def _engine(self, batch: int, device):
+        """Slabs, FC stacks and step buffers (re)built lazily for the current batch size/device."""
+        self._hip_params = list(self.q_network.parameters())
+        self._slab = ensure_slab(self._hip_params)
+        self._qs = self.q_network.fc.stack()
+        self._ts = self.q_network_target.fc.stack()
+        if self._ws_batch != batch or self._q.device != device:
+            n = self._out_cols()
+            f32 = dict(dtype=torch.float32, device=device)
+            self._q = torch.empty(batch, n, **f32)
+            self._qn_online = torch.empty(batch, n, **f32)
+            self._qn_target = torch.empty(batch, n, **f32)
+            self._dq = torch.empty(batch, n, **f32)
+            self._loss = torch.empty(1, **f32)
+            self._alloc_head(batch, device)
+            self._ws_batch = batch
+        # weight/bias gradient destinations = views of the flat gradient slab, in layer order
+        lin = self.q_network.fc.linears()
+        index = {id(p): i for i, p in enumerate(self._hip_params)}
+        self._dw = [self._slab.view(self._slab.grad, index[id(l.weight)]) for l in lin]
+        self._db = [self._slab.view(self._slab.grad, index[id(l.bias)]) for l in lin]
+
+    @staticmethod
+    def _f32c(t: torch.Tensor) -> torch.Tensor:
+        t = t if t.dtype == torch.float32 else t.float()
+        return t if t.is_contiguous() else t.contiguous()
+
+    def _needs_online_next(self) -> bool:
+        return True
+
+    def _hip_forward(self, b) -> torch.Tensor:
+        state = self._f32c(b.state.float_features)
+        next_state = self._f32c(b.next_state.float_features)
+        L.require_cuda(state, "training_batch.state")
+        B, dev = state.shape[0], state.device
+        self._engine(B, dev)
+        qs, ts = self._qs, self._ts
+        qs.stage_weights(need_transposed=True)
+        ts.stage_weights(need_transposed=False)
+        xs, self._xs_t = qs.stage_input(state, need_transposed=True)
+        xn, _ = qs.stage_input(next_state, need_transposed=False)
+        if self._needs_online_next():
+            qs.forward(xn, self._qn_online, save=False)
+        ts.forward(xn, self._qn_target, save=False)
+        qs.forward(xs, self._q, save=True)
+        gamma_exp = None
+        if self.use_seq_num_diff_as_time_diff:
+            assert self.multi_steps is None
+            gamma_exp = self._f32c(b.time_diff).reshape(-1)
+        if self.multi_steps is not None:
+            assert b.step is not None
+            gamma_exp = self._f32c(b.step).reshape(-1)
+        boosts = self.reward_boosts.reshape(-1).to(dev) if self._has_reward_boost else None
+        if self.maxq_learning:
+            next_mask = self._f32c(b.possible_next_actions_mask)
+        else:  # SARSA: the taken next action is the only "possible" one (dqn_trainer.py:218-224)
+            next_mask = self._f32c(b.next_action)
+        self._run_head(b, B, self._f32c(b.action), next_mask, boosts, gamma_exp)
+        return self._loss
+
+    def _hip_backward(self, grad_out=None):
+        if grad_out is not None:
+            self._dq.mul_(grad_out)
+        self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
+        if self._dp_group is not None:
+            torch.distributed.all_reduce(self._slab.grad, group=self._dp_group)
+        # publish the gradients: p.grad aliases the slab (accumulate into foreign .grad tensors)
+        base = self._slab.grad.data_ptr()
+        for i, p in enumerate(self._hip_params):
+            gv = self._slab.view(self._slab.grad, i)
+            if p.grad is None or p.grad.data_ptr() == base + 4 * self._slab.offsets[i]:
+                p.grad = gv
+            else:
+                p.grad.add_(gv)
+
+    # ---- data parallel (SURVEY.md §8e) -------------------------------------------------------
+    def enable_data_parallel(self, process_group=None):
+        """All-reduce(sum) the flat fp32 gradient slab over RCCL after every backward; the 1/world
+        factor is folded into the Adam kernel (FusedAdam.grad_scale)."""
+        import torch.distributed as dist
+
+        self._dp_group = process_group if process_group is not None else dist.group.WORLD
+        self._dp_world = dist.get_world_size(self._dp_group)
+        return self
+
+    def _hip_loss(self, batch):
+        loss_buf = self._hip_forward(batch)
+        return _HipLoss.apply(self, loss_buf, *self._hip_params)
+
+    # ---- fused native step (what bench.py and the native loop drive) --------------------------
+    def native_optimizers(self):
+        if getattr(self, "_native_opts", None) is None:
+            self._native_opts = [o["optimizer"] for o in self.configure_optimizers()]
+        return self._native_opts
+
+    @torch.no_grad()
+    def train_step_native(self, training_batch) -> torch.Tensor:
+        """forward + head + backward + Adam + soft update with no autograd graph, no generator and
+        no host synchronisation.  Returns the device-resident loss scalar (shape [1])."""
+        adam, soft = self.native_optimizers()
+        loss = self._hip_forward(training_batch)
+        for p in self._hip_params:
+            p.grad = None
+        self._hip_backward(None)
+        adam.grad_scale = 1.0 / self._dp_world
+        adam.step()
+        soft.step()
+        self.all_batches_processed += 1
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        raise NotImplementedError("CPE / EvaluationDataPage is outside the hot path (SURVEY.md §3.4)")
+
+
+class DQNTrainer(QStepCore):
     def __init__(
         self,
         q_network,
@@ -85,110 +221,22 @@ class DQNTrainer(DQNTrainerBaseLightning):
         self.bcq = bcq is not None
         if self.bcq:
             raise NotImplementedError("batch-constrained q-learning needs the imitator net (not on the hot path)")
-        self._ws_batch = -1
-        self._dp_group = None
-        self._dp_world = 1
 
-    # ---- optimizers (dqn_trainer.py:119-155) ------------------------------------------------
-    def configure_optimizers(self):
-        optimizers = []
-        target_params = list(self.q_network_target.parameters())
-        source_params = list(self.q_network.parameters())
-        optimizers.append(self.q_network_optimizer.make_optimizer_scheduler(self.q_network.parameters()))
-        optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
-        return optimizers
+    # ---- head ---------------------------------------------------------------------------------
+    def _alloc_head(self, batch, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        self._loss_partials = torch.empty(ops.dqn_head_partials(batch), **f32)
+        self._next_q = torch.empty(batch, **f32)
+        self._next_idx = torch.empty(batch, dtype=torch.int64, device=device)
+        self._q_sel = torch.empty(batch, **f32)
 
-    # ---- engine -------------------------------------------------------------------------------
-    def _engine(self, batch: int, device):
-        """Slabs, FC stacks and step buffers (re)built lazily for the current batch size/device."""
-        self._hip_params = list(self.q_network.parameters())
-        self._slab = ensure_slab(self._hip_params)
-        self._qs = self.q_network.fc.stack()
-        self._ts = self.q_network_target.fc.stack()
-        if self._ws_batch != batch or self._q.device != device:
-            A = self.num_actions
-            f32 = dict(dtype=torch.float32, device=device)
-            self._q = torch.empty(batch, A, **f32)
-            self._qn_online = torch.empty(batch, A, **f32)
-            self._qn_target = torch.empty(batch, A, **f32)
-            self._dq = torch.empty(batch, A, **f32)
-            self._loss_partials = torch.empty(ops.dqn_head_partials(batch), **f32)
-            self._loss = torch.empty(1, **f32)
-            self._next_q = torch.empty(batch, **f32)
-            self._next_idx = torch.empty(batch, dtype=torch.int64, device=device)
-            self._q_sel = torch.empty(batch, **f32)
-            self._ws_batch = batch
-        # weight/bias gradient destinations = views of the flat gradient slab, in layer order
-        lin = self.q_network.fc.linears()
-        index = {id(p): i for i, p in enumerate(self._hip_params)}
-        self._dw = [self._slab.view(self._slab.grad, index[id(l.weight)]) for l in lin]
-        self._db = [self._slab.view(self._slab.grad, index[id(l.bias)]) for l in lin]
-
-    @staticmethod
-    def _f32c(t: torch.Tensor) -> torch.Tensor:
-        t = t if t.dtype == torch.float32 else t.float()
-        return t if t.is_contiguous() else t.contiguous()
-
-    def _hip_forward(self, b) -> torch.Tensor:
-        state = self._f32c(b.state.float_features)
-        next_state = self._f32c(b.next_state.float_features)
-        L.require_cuda(state, "training_batch.state")
-        B, dev = state.shape[0], state.device
-        self._engine(B, dev)
-        qs, ts = self._qs, self._ts
-        qs.stage_weights(need_transposed=True)
-        ts.stage_weights(need_transposed=False)
-        xs, self._xs_t = qs.stage_input(state, need_transposed=True)
-        xn, _ = qs.stage_input(next_state, need_transposed=False)
-        qs.forward(xn, self._qn_online, save=False)
-        ts.forward(xn, self._qn_target, save=False)
-        qs.forward(xs, self._q, save=True)
-
-        action = self._f32c(b.action)
-        if self.maxq_learning:
-            next_mask = self._f32c(b.possible_next_actions_mask)
-        else:  # SARSA: the taken next action is the only "possible" one (dqn_trainer.py:218-224)
-            next_mask = self._f32c(b.next_action)
-        gamma_exp = None
-        if self.use_seq_num_diff_as_time_diff:
-            assert self.multi_steps is None
-            gamma_exp = self._f32c(b.time_diff).reshape(-1)
-        if self.multi_steps is not None:
-            assert b.step is not None
-            gamma_exp = self._f32c(b.step).reshape(-1)
-        boosts = self.reward_boosts.reshape(-1) if self._has_reward_boost else None
+    def _run_head(self, b, B, action, next_mask, boosts, gamma_exp):
         ops.dqn_head(self._q, self._qn_online, self._qn_target, action, next_mask,
                      self._f32c(b.reward).reshape(-1), boosts, self._f32c(b.not_terminal).reshape(-1),
                      self.gamma, gamma_exp, self.double_q_learning, self._loss_type, self._dq,
                      self._loss_partials, self._next_q, self._next_idx, self._q_sel)
         ops.reduce_sum(self._loss_partials, self._loss_partials.numel(), 1.0 / B, self._loss)
         self.all_action_scores = self._q
-        return self._loss
-
-    def _hip_backward(self, grad_out=None):
-        if grad_out is not None:
-            self._dq.mul_(grad_out)
-        self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
-        if self._dp_group is not None:
-            torch.distributed.all_reduce(self._slab.grad, group=self._dp_group)
-        # publish the gradients: p.grad aliases the slab (accumulate into foreign .grad tensors)
-        base = self._slab.grad.data_ptr()
-        for i, p in enumerate(self._hip_params):
-            gv = self._slab.view(self._slab.grad, i)
-            if p.grad is None or p.grad.data_ptr() == base + 4 * self._slab.offsets[i]:
-                p.grad = gv
-            else:
-                p.grad.add_(gv)
-
-    # ---- data parallel (SURVEY.md §8e) -------------------------------------------------------
-    def enable_data_parallel(self, process_group=None):
-        """All-reduce(sum) the flat fp32 gradient slab over RCCL after every backward; the 1/world
-        factor is folded into the Adam kernel (FusedAdam.grad_scale)."""
-        import torch.distributed as dist
-
-        self._dp_group = process_group if process_group is not None else dist.group.WORLD
-        self._dp_world = dist.get_world_size(self._dp_group)
-        return self
 
     # ---- reference surface --------------------------------------------------------------------
     @torch.no_grad()
@@ -210,8 +258,7 @@ class DQNTrainer(DQNTrainerBaseLightning):
     def compute_td_loss(self, batch, boosted_rewards=None, discount_tensor=None):
         """dqn_trainer.py:179-239.  Reward boosting and discounting are recomputed inside the fused
         head from the batch itself; the two extra arguments are accepted for signature parity."""
-        loss_buf = self._hip_forward(batch)
-        return _HipLoss.apply(self, loss_buf, *self._hip_params)
+        return self._hip_loss(batch)
 
     def train_step_gen(self, training_batch: rlt.DiscreteDqnInput, batch_idx: int):
         self._check_input(training_batch)
@@ -242,27 +289,3 @@ class DQNTrainer(DQNTrainerBaseLightning):
             model_values_on_logged_actions=None,
             model_action_idxs=model_action_idxs,
         )
-
-    # ---- fused native step (what bench.py and the native loop drive) --------------------------
-    def native_optimizers(self):
-        if getattr(self, "_native_opts", None) is None:
-            self._native_opts = [o["optimizer"] for o in self.configure_optimizers()]
-        return self._native_opts
-
-    @torch.no_grad()
-    def train_step_native(self, training_batch) -> torch.Tensor:
-        """forward + head + backward + Adam + soft update with no autograd graph, no generator and
-        no host synchronisation.  Returns the device-resident loss scalar (shape [1])."""
-        adam, soft = self.native_optimizers()
-        loss = self._hip_forward(training_batch)
-        for p in self._hip_params:
-            p.grad = None
-        self._hip_backward(None)
-        adam.grad_scale = 1.0 / self._dp_world
-        adam.step()
-        soft.step()
-        self.all_batches_processed += 1
-        return loss
-
-    def validation_step(self, batch, batch_idx):
-        raise NotImplementedError("CPE / EvaluationDataPage is outside the hot path (SURVEY.md §3.4)")

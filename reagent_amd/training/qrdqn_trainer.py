@@ -1,0 +1,113 @@
+"""QRDQNTrainer with the constructor / generator surface of
+reagent/training/qrdqn_trainer.py:22-227, executed on the HIP kernels.
+
+Step (reference :108-194): target(next_state) and — when double_q_learning — online(next_state)
+forwards, online(state) forward, the quantile-Huber head (rg_qr_head: per-transition N x N pairs in
+LDS/registers, the (N, B, N) tensor of the reference is never built), backward, Adam, soft update.
+The CPE-only 4th forward (:162-164) is dead when CPE is off and is not executed.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..core import types as rlt
+from ..core.parameters import EvaluationParameters, RLParameters
+from ..optimizer import Optimizer__Union
+from .dqn_trainer import QStepCore
+
+
+class QRDQNTrainer(QStepCore):
+    def __init__(
+        self,
+        q_network,
+        q_network_target,
+        metrics_to_score=None,
+        reward_network=None,
+        q_network_cpe=None,
+        q_network_cpe_target=None,
+        actions: Optional[List[str]] = None,
+        rl: Optional[RLParameters] = None,
+        double_q_learning: bool = True,
+        num_atoms: int = 51,
+        minibatch_size: int = 1024,
+        minibatches_per_step: int = 1,
+        optimizer: Optional[Optimizer__Union] = None,
+        cpe_optimizer: Optional[Optimizer__Union] = None,
+        evaluation: Optional[EvaluationParameters] = None,
+    ) -> None:
+        evaluation = evaluation if evaluation is not None else EvaluationParameters()
+        rl = rl if rl is not None else RLParameters()
+        actions = actions if actions is not None else []
+        optimizer = optimizer if optimizer is not None else Optimizer__Union.default()
+        super().__init__(rl_parameters=rl, metrics_to_score=metrics_to_score, actions=actions,
+                         evaluation_parameters=evaluation)
+        self.double_q_learning = double_q_learning
+        self.minibatch_size = minibatch_size
+        self.minibatches_per_step = minibatches_per_step
+        self._actions = actions
+        self.q_network = q_network
+        self.q_network_target = q_network_target
+        self.q_network_optimizer = optimizer
+        self.num_atoms = num_atoms
+        self.register_buffer("quantiles", None)
+        self.quantiles = ((0.5 + torch.arange(self.num_atoms).float()) / float(self.num_atoms)).view(1, -1)
+        self._reject_cpe(reward_network, q_network_cpe, q_network_cpe_target)
+
+    def _out_cols(self) -> int:
+        return self.num_actions * self.num_atoms
+
+    def _needs_online_next(self) -> bool:
+        return bool(self.maxq_learning and self.double_q_learning)
+
+    def _alloc_head(self, batch, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        self._loss_partials = torch.empty(batch, **f32)
+        self._all_q = torch.empty(batch, self.num_actions, **f32)
+
+    def _run_head(self, b, B, action, next_mask, boosts, gamma_exp):
+        if self.quantiles.device != self._q.device:
+            self.quantiles = self.quantiles.to(self._q.device)
+        ops.qr_head(self._q, self._qn_online if self._needs_online_next() else None, self._qn_target, action,
+                    next_mask, self._f32c(b.reward).reshape(-1), boosts, self._f32c(b.not_terminal).reshape(-1),
+                    self.gamma, gamma_exp, self.quantiles.reshape(-1), self.num_atoms, self.maxq_learning,
+                    self._dq, self._loss_partials, self._all_q)
+        ops.reduce_sum(self._loss_partials, B, 1.0, self._loss)
+        self.all_q_values = self._all_q
+
+    def train_step_gen(self, training_batch: rlt.DiscreteDqnInput, batch_idx: int):
+        self._check_input(training_batch)
+        loss = self._hip_loss(training_batch)
+        yield loss
+        self.loss = loss.detach()
+        self._log(training_batch)
+        yield self.soft_update_result()
+
+    def _log(self, training_batch):
+        from .reagent_lightning_module import _NoOpReporter
+
+        if isinstance(self._reporter, _NoOpReporter):
+            return
+        rewards = self.boost_rewards(training_batch.reward, training_batch.action)
+        logged_action_idxs = torch.argmax(training_batch.action, dim=1, keepdim=True)
+        mask = training_batch.possible_actions_mask.float() if self.maxq_learning else training_batch.action
+        model_action_idxs = self.argmax_with_mask(self.all_q_values, mask)
+        self.reporter.log(td_loss=self.loss, logged_actions=logged_action_idxs,
+                          logged_propensities=training_batch.extras.action_probability, logged_rewards=rewards,
+                          logged_values=None, model_values=self.all_q_values,
+                          model_values_on_logged_actions=None, model_action_idxs=model_action_idxs)
+
+    def argmax_with_mask(self, q_values, possible_actions_mask):
+        """qrdqn_trainer.py:210-214"""
+        q_values = q_values.reshape(possible_actions_mask.shape)
+        q_values = q_values + self.ACTION_NOT_POSSIBLE_VAL * (1 - possible_actions_mask)
+        return q_values.argmax(1)
+
+    def huber(self, x):
+        """qrdqn_trainer.py:217-218"""
+        return torch.where(x.abs() < 1, 0.5 * x.pow(2), x.abs() - 0.5)
+
+    @torch.no_grad()
+    def get_detached_model_outputs(self, state) -> Tuple[torch.Tensor, torch.Tensor]:
+        """qrdqn_trainer.py:220-227"""
+        return self.q_network(state).mean(dim=2), self.q_network_target(state).mean(dim=2)
