@@ -214,6 +214,53 @@ int rg_qr_head(const float* q, const float* qn_online, const float* qn_target, c
                const float* quantiles, int batch, int num_actions, int num_atoms, int maxq, float* dq,
                float* loss_partials, float* all_q, rg_stream_t stream);
 
+/* ---- SAC: Gaussian policy head and loss heads ---------------------------------------------- */
+
+/* GaussianFullyConnectedActor.forward, reagent/models/actor.py:215-231 (+ get_log_prob :233-261),
+ * given the FC output loc_scale [B, 2A] (ldls) and the N(0,1) draw `noise` [B, A] the reference
+ * takes from torch.randn_like (:217): action [B, A] (lda) = clamp(tanh(loc + noise*exp(scale_log))),
+ * log_prob [B] (nullable), squashed_mean [B, A] (nullable). */
+int rg_gaussian_head_forward(const float* loc_scale, int64_t ldls, const float* noise, int batch,
+                             int action_dim, float* action, int64_t lda, float* log_prob,
+                             float* squashed_mean, rg_stream_t stream);
+/* get_log_prob(state, squashed_action) for a given action, actor.py:233-261. */
+int rg_gaussian_log_prob(const float* loc_scale, int64_t ldls, const float* action, int64_t lda,
+                         int batch, int action_dim, float* log_prob, rg_stream_t stream);
+/* Backward of rg_gaussian_head_forward: g_action [B, A] (nullable) and g_log_prob [B] (nullable) are
+ * d loss / d action and d loss / d log_prob; d_loc_scale [B, 2A] = d loss / d loc_scale. */
+int rg_gaussian_head_backward(const float* loc_scale, int64_t ldls, const float* noise,
+                              const float* g_action, int64_t ldga, const float* g_log_prob, int batch,
+                              int action_dim, float* d_loc_scale, int64_t lddls, rg_stream_t stream);
+
+/* Critic segment of SACTrainer.train_step_gen, reagent/training/sac_trainer.py:217-248:
+ * y = r + gamma * (min(q1_t, q2_t) - alpha * clamp(log_prob', -2, 2)) * not_done (y = r if gamma == 0);
+ * loss_i = mse(q_i, y), dq_i = d loss_i / d q_i.  All per-transition arrays are [B] fp32; alpha is a
+ * device fp64 scalar; q2* may be NULL (single critic).  *_partials: [rg_sac_partials(B)]. */
+int rg_sac_partials(int batch);
+int rg_sac_critic_head(const float* q1, const float* q2, const float* q1_target, const float* q2_target,
+                       const float* log_prob_next, const float* reward, const float* not_terminal,
+                       double gamma, const double* alpha, int batch, float* target, float* dq1,
+                       float* dq2, float* loss1_partials, float* loss2_partials, rg_stream_t stream);
+/* Actor segment, sac_trainer.py:254-280: loss = mean(alpha*clamp(log_prob,-2,2) - min(q1a, q2a));
+ * outputs d loss / d log_prob, d loss / d q1a, d loss / d q2a, loss partials and partial sums of
+ * (clamp(log_prob) + target_entropy) for the temperature segment (:311-320). */
+int rg_sac_actor_head(const float* log_prob, const float* q1_actor, const float* q2_actor,
+                      const double* alpha, double target_entropy, int batch, float* g_log_prob,
+                      float* dq1_actor, float* dq2_actor, float* loss_partials,
+                      float* entropy_partials, rg_stream_t stream);
+/* grad[0] = d alpha_loss / d log_alpha = -mean(clamp(log_prob) + target_entropy); alpha_loss
+ * (nullable) = -(log_alpha * mean(...)).  fp64 like the reference's log_alpha (:124-126). */
+int rg_sac_alpha_grad(const float* entropy_partials, int batch, const double* log_alpha, double* grad,
+                      double* alpha_loss, rg_stream_t stream);
+/* torch.optim.Adam arithmetic in fp64; exp_param_out (nullable) = exp(param) (alpha = exp(log_alpha)). */
+int rg_adam_step_f64(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n,
+                     double lr, double beta1, double beta2, double eps, double bias_correction1,
+                     double bias_correction2_sqrt, double* exp_param_out, rg_stream_t stream);
+/* out[b, c] = a[b, c] + b[b, c] (b nullable) on strided [batch, cols] views (sums the two critics'
+ * action-input gradients). */
+int rg_add_cols(const float* a, int64_t lda, const float* b, int64_t ldb, int batch, int cols,
+                float* out, int64_t ldo, rg_stream_t stream);
+
 /* out[0] = scale * sum_i in[i], summed in index order by one workgroup (deterministic). */
 int rg_reduce_sum(const float* in, int n, float scale, float* out, rg_stream_t stream);
 

@@ -1,0 +1,322 @@
+// sac.hip — SAC-specific elementwise kernels: the tanh-squashed Gaussian policy head (forward and
+// backward), the critic / actor / temperature loss heads.  All are per-transition VALU work on
+// [B, action_dim] or [B] arrays (HBM-bound, tiny next to the FC stacks).
+#include <rg_platform.h>
+#include "../../include/reagent_hip.h"
+
+namespace rg {
+
+constexpr float LOG_PROB_MIN = -2.f, LOG_PROB_MAX = 2.f;  // reagent/models/actor.py:18-19
+constexpr float ACT_EPS = 1e-6f;                          // actor.py:160 self.eps
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;   // actor.py:159 self.const
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// GaussianFullyConnectedActor.forward (actor.py:215-231) given the FC output loc_scale [B, 2A]:
+//   loc, scale_log = split; scale_log.clamp(-2, 2)
+//   raw = loc + r * exp(scale_log); action = clamp(tanh(raw), +-(1 - eps))
+//   log_prob = get_log_prob(state, action) (actor.py:233-261), which re-derives r' = (atanh(a) - loc)/sigma
+// One thread per (b, d) computes the action and its log-prob term; the A terms of a row are summed
+// by a row-owner thread in index order.
+__global__ void gaussian_head_fwd_kernel(const float* __restrict__ ls, long ldls,
+                                         const float* __restrict__ noise, int batch, int A,
+                                         float* __restrict__ action, long lda,
+                                         float* __restrict__ log_prob, float* __restrict__ squashed_mean) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  float lp = 0.f;
+  for (int d = 0; d < A; ++d) {
+    const float loc = ls[(long)b * ldls + d];
+    const float s = clampf(ls[(long)b * ldls + A + d], LOG_PROB_MIN, LOG_PROB_MAX);
+    const float sigma = expf(s);
+    const float raw = loc + noise[(long)b * A + d] * sigma;
+    const float a = clampf(tanhf(raw), -1.f + ACT_EPS, 1.f - ACT_EPS);
+    action[(long)b * lda + d] = a;
+    if (squashed_mean) squashed_mean[(long)b * A + d] = clampf(tanhf(loc), -1.f + ACT_EPS, 1.f - ACT_EPS);
+    const float r2 = (atanhf(a) - loc) / sigma;
+    const float normal = -(r2 * r2) / 2.f - s - LOG_SQRT_2PI;          // _normal_log_prob :166-181
+    const float squash = logf(1.f - a * a + ACT_EPS);                  // _squash_correction :183-188
+    lp += normal - squash;
+  }
+  if (log_prob) log_prob[b] = lp;
+}
+
+// get_log_prob(state, squashed_action) for a GIVEN action (actor.py:233-261)
+__global__ void gaussian_log_prob_kernel(const float* __restrict__ ls, long ldls,
+                                         const float* __restrict__ action, long lda, int batch, int A,
+                                         float* __restrict__ log_prob) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  float lp = 0.f;
+  for (int d = 0; d < A; ++d) {
+    const float loc = ls[(long)b * ldls + d];
+    const float s = clampf(ls[(long)b * ldls + A + d], LOG_PROB_MIN, LOG_PROB_MAX);
+    const float a = action[(long)b * lda + d];
+    const float r2 = (atanhf(a) - loc) / expf(s);
+    lp += (-(r2 * r2) / 2.f - s - LOG_SQRT_2PI) - logf(1.f - a * a + ACT_EPS);
+  }
+  log_prob[b] = lp;
+}
+
+// backward of the head: given g_a [B, A] = d loss / d action (may be null) and g_lp [B] = d loss /
+// d log_prob, produce d loss / d loc_scale [B, 2A].  Both uses of (loc, scale_log) in the reference
+// (sampling and the second FC evaluation inside get_log_prob) are the same values, so their
+// gradients add.
+__global__ void gaussian_head_bwd_kernel(const float* __restrict__ ls, long ldls,
+                                         const float* __restrict__ noise, const float* __restrict__ g_a,
+                                         long ldga, const float* __restrict__ g_lp, int batch, int A,
+                                         float* __restrict__ d_ls, long lddls) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)batch * A) return;
+  const int b = (int)(i / A), d = (int)(i % A);
+  const float loc = ls[(long)b * ldls + d];
+  const float sl = ls[(long)b * ldls + A + d];
+  const float s = clampf(sl, LOG_PROB_MIN, LOG_PROB_MAX);
+  const float ds_dsl = (sl >= LOG_PROB_MIN && sl <= LOG_PROB_MAX) ? 1.f : 0.f;
+  const float sigma = expf(s);
+  const float r = noise[(long)b * A + d];
+  const float raw = loc + r * sigma;
+  const float t = tanhf(raw);
+  const float a = clampf(t, -1.f + ACT_EPS, 1.f - ACT_EPS);
+  const float da_dt = (t >= -1.f + ACT_EPS && t <= 1.f - ACT_EPS) ? 1.f : 0.f;
+  const float da_draw = da_dt * (1.f - t * t);
+  const float u = atanhf(a);
+  const float r2 = (u - loc) / sigma;
+  // partials of lp_d = -r2^2/2 - s - c - log(1 - a^2 + eps)
+  const float dlp_da = -r2 * (1.f / (1.f - a * a)) / sigma + 2.f * a / (1.f - a * a + ACT_EPS);
+  const float dlp_dloc = r2 / sigma;
+  const float dlp_ds = r2 * r2 - 1.f;
+  const float glp = g_lp ? g_lp[b] : 0.f;
+  const float ga = g_a ? g_a[(long)b * ldga + d] : 0.f;
+  const float tot_a = ga + glp * dlp_da;  // everything that reaches `action`
+  const float d_loc = glp * dlp_dloc + tot_a * da_draw;
+  const float d_s = glp * dlp_ds + tot_a * da_draw * r * sigma;
+  d_ls[(long)b * lddls + d] = d_loc;
+  d_ls[(long)b * lddls + A + d] = d_s * ds_dsl;
+}
+
+constexpr int SAC_THREADS = 256;
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float s = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  __syncthreads();
+  return s;
+}
+
+// critic segment (sac_trainer.py:217-248):
+//   v' = min(q1_t, q2_t) - alpha * clamp(log_prob', -2, 2); y = r + gamma * v' * not_done (r if gamma == 0)
+//   q_i loss = mse(q_i, y);  dq_i = 2 (q_i - y) / B
+__global__ void sac_critic_head_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                       const float* __restrict__ q1t, const float* __restrict__ q2t,
+                                       const float* __restrict__ lp_next, const float* __restrict__ reward,
+                                       const float* __restrict__ not_terminal, float gamma,
+                                       const double* __restrict__ alpha, int batch,
+                                       float* __restrict__ target, float* __restrict__ dq1,
+                                       float* __restrict__ dq2, float* __restrict__ loss1_part,
+                                       float* __restrict__ loss2_part) {
+  __shared__ float scratch[4];
+  const int b = blockIdx.x * SAC_THREADS + threadIdx.x;
+  float l1 = 0.f, l2 = 0.f;
+  if (b < batch) {
+    float v = q1t[b];
+    if (q2t) v = fminf(v, q2t[b]);
+    v = (float)((double)v - alpha[0] * (double)clampf(lp_next[b], LOG_PROB_MIN, LOG_PROB_MAX));
+    const float y = gamma > 0.f ? reward[b] + gamma * v * not_terminal[b] : reward[b];
+    target[b] = y;
+    const float d1 = q1[b] - y;
+    l1 = d1 * d1;
+    dq1[b] = 2.f * d1 / (float)batch;
+    if (q2) {
+      const float d2 = q2[b] - y;
+      l2 = d2 * d2;
+      dq2[b] = 2.f * d2 / (float)batch;
+    }
+  }
+  const float s1 = block_sum(l1, scratch);
+  const float s2 = block_sum(l2, scratch);
+  if (threadIdx.x == 0) {
+    loss1_part[blockIdx.x] = s1;
+    if (loss2_part) loss2_part[blockIdx.x] = s2;
+  }
+}
+
+// actor segment (sac_trainer.py:254-280): loss = mean(alpha * clamp(log_prob, -2, 2) - min(q1a, q2a))
+// -> g_lp [B], dq1a / dq2a [B] (torch.minimum's backward: the smaller input takes the gradient,
+// ties are split), loss partials.  Also the temperature segment's input (:311-320):
+// ent_part = partial sums of (clamp(log_prob) + target_entropy).
+__global__ void sac_actor_head_kernel(const float* __restrict__ lp, const float* __restrict__ q1a,
+                                      const float* __restrict__ q2a, const double* __restrict__ alpha,
+                                      float target_entropy, int batch, float* __restrict__ g_lp,
+                                      float* __restrict__ dq1a, float* __restrict__ dq2a,
+                                      float* __restrict__ loss_part, float* __restrict__ ent_part) {
+  __shared__ float scratch[4];
+  const int b = blockIdx.x * SAC_THREADS + threadIdx.x;
+  float l = 0.f, e = 0.f;
+  if (b < batch) {
+    const float raw = lp[b];
+    const float c = clampf(raw, LOG_PROB_MIN, LOG_PROB_MAX);
+    const float inside = (raw >= LOG_PROB_MIN && raw <= LOG_PROB_MAX) ? 1.f : 0.f;
+    const float a1 = q1a[b];
+    float mq = a1, w1 = 1.f, w2 = 0.f;
+    if (q2a) {
+      const float a2 = q2a[b];
+      mq = fminf(a1, a2);
+      if (a1 == a2) { w1 = 0.5f; w2 = 0.5f; }
+      else if (a2 < a1) { w1 = 0.f; w2 = 1.f; }
+    }
+    const double al = alpha[0];
+    l = (float)(al * (double)c - (double)mq);
+    const float invb = 1.f / (float)batch;
+    g_lp[b] = (float)al * inside * invb;
+    dq1a[b] = -w1 * invb;
+    if (dq2a) dq2a[b] = -w2 * invb;
+    e = c + target_entropy;
+  }
+  const float sl = block_sum(l, scratch);
+  const float se = block_sum(e, scratch);
+  if (threadIdx.x == 0) {
+    loss_part[blockIdx.x] = sl;
+    ent_part[blockIdx.x] = se;
+  }
+}
+
+// temperature segment: alpha_loss = -mean(log_alpha * (clamp(log_prob) + target_entropy)) so
+// d/d log_alpha = -mean(...).  One block: ordered sum of the partials, writes the fp64 gradient and
+// the loss value.
+__global__ void sac_alpha_grad_kernel(const float* __restrict__ ent_part, int nparts, int batch,
+                                      const double* __restrict__ log_alpha, double* __restrict__ grad,
+                                      double* __restrict__ alpha_loss) {
+  __shared__ float scratch[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += SAC_THREADS) acc += ent_part[i];
+  const float s = block_sum(acc, scratch);
+  if (threadIdx.x == 0) {
+    const double m = (double)s / (double)batch;
+    grad[0] = -m;
+    if (alpha_loss) alpha_loss[0] = -(log_alpha[0] * m);
+  }
+}
+
+// torch.optim.Adam single-tensor arithmetic in fp64 (log_alpha is a float64 parameter,
+// sac_trainer.py:124-126) + alpha = exp(log_alpha) for the next step (:322)
+__global__ void adam_f64_kernel(double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m,
+                                double* __restrict__ v, int n, double lr, double beta1, double beta2,
+                                double eps, double bc1, double bc2_sqrt, double* __restrict__ exp_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double gi = g[i];
+  double mi = m[i], vi = v[i];
+  mi = mi + (1.0 - beta1) * (gi - mi);
+  vi = vi * beta2 + ((1.0 - beta2) * gi) * gi;
+  const double denom = sqrt(vi) / bc2_sqrt + eps;
+  const double pi = p[i] + (-(lr / bc1) * mi) / denom;
+  p[i] = pi;
+  m[i] = mi;
+  v[i] = vi;
+  if (exp_out) exp_out[i] = exp(pi);
+}
+
+// generic scalar MSE head (critics): loss = mean((q - y)^2), dq = 2 (q - y) / B
+__global__ void add_cols_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                int batch, int cols, float* __restrict__ out, long ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)batch * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i % cols);
+  out[r * ldo + c] = a[r * lda + c] + (b ? b[r * ldb + c] : 0.f);
+}
+
+}  // namespace rg
+
+using namespace rg;
+
+extern "C" {
+
+int rg_gaussian_head_forward(const float* loc_scale, int64_t ldls, const float* noise, int batch,
+                             int action_dim, float* action, int64_t lda, float* log_prob,
+                             float* squashed_mean, rg_stream_t stream) {
+  if (!loc_scale || !noise || !action || batch <= 0 || action_dim <= 0) return RG_EINVAL;
+  RG_LAUNCH(gaussian_head_fwd_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, loc_scale,
+            (long)ldls, noise, batch, action_dim, action, (long)lda, log_prob, squashed_mean);
+  return (int)hipGetLastError();
+}
+
+int rg_gaussian_log_prob(const float* loc_scale, int64_t ldls, const float* action, int64_t lda, int batch,
+                         int action_dim, float* log_prob, rg_stream_t stream) {
+  if (!loc_scale || !action || !log_prob || batch <= 0 || action_dim <= 0) return RG_EINVAL;
+  RG_LAUNCH(gaussian_log_prob_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, loc_scale,
+            (long)ldls, action, (long)lda, batch, action_dim, log_prob);
+  return (int)hipGetLastError();
+}
+
+int rg_gaussian_head_backward(const float* loc_scale, int64_t ldls, const float* noise, const float* g_action,
+                              int64_t ldga, const float* g_log_prob, int batch, int action_dim,
+                              float* d_loc_scale, int64_t lddls, rg_stream_t stream) {
+  if (!loc_scale || !noise || !d_loc_scale || batch <= 0 || action_dim <= 0) return RG_EINVAL;
+  const long n = (long)batch * action_dim;
+  RG_LAUNCH(gaussian_head_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
+            loc_scale, (long)ldls, noise, g_action, (long)ldga, g_log_prob, batch, action_dim, d_loc_scale,
+            (long)lddls);
+  return (int)hipGetLastError();
+}
+
+int rg_sac_partials(int batch) { return (batch + SAC_THREADS - 1) / SAC_THREADS; }
+
+int rg_sac_critic_head(const float* q1, const float* q2, const float* q1_target, const float* q2_target,
+                       const float* log_prob_next, const float* reward, const float* not_terminal, double gamma,
+                       const double* alpha, int batch, float* target, float* dq1, float* dq2,
+                       float* loss1_partials, float* loss2_partials, rg_stream_t stream) {
+  if (!q1 || !q1_target || !log_prob_next || !reward || !not_terminal || !alpha || !target || !dq1 ||
+      !loss1_partials || batch <= 0)
+    return RG_EINVAL;
+  if (q2 && (!dq2 || !loss2_partials)) return RG_EINVAL;
+  RG_LAUNCH(sac_critic_head_kernel, dim3(rg_sac_partials(batch)), dim3(SAC_THREADS), (hipStream_t)stream, q1,
+            q2, q1_target, q2_target, log_prob_next, reward, not_terminal, (float)gamma, alpha, batch, target,
+            dq1, dq2, loss1_partials, loss2_partials);
+  return (int)hipGetLastError();
+}
+
+int rg_sac_actor_head(const float* log_prob, const float* q1_actor, const float* q2_actor, const double* alpha,
+                      double target_entropy, int batch, float* g_log_prob, float* dq1_actor, float* dq2_actor,
+                      float* loss_partials, float* entropy_partials, rg_stream_t stream) {
+  if (!log_prob || !q1_actor || !alpha || !g_log_prob || !dq1_actor || !loss_partials || !entropy_partials ||
+      batch <= 0)
+    return RG_EINVAL;
+  if (q2_actor && !dq2_actor) return RG_EINVAL;
+  RG_LAUNCH(sac_actor_head_kernel, dim3(rg_sac_partials(batch)), dim3(SAC_THREADS), (hipStream_t)stream,
+            log_prob, q1_actor, q2_actor, alpha, (float)target_entropy, batch, g_log_prob, dq1_actor, dq2_actor,
+            loss_partials, entropy_partials);
+  return (int)hipGetLastError();
+}
+
+int rg_sac_alpha_grad(const float* entropy_partials, int batch, const double* log_alpha, double* grad,
+                      double* alpha_loss, rg_stream_t stream) {
+  if (!entropy_partials || !log_alpha || !grad || batch <= 0) return RG_EINVAL;
+  RG_LAUNCH(sac_alpha_grad_kernel, dim3(1), dim3(SAC_THREADS), (hipStream_t)stream, entropy_partials,
+            rg_sac_partials(batch), batch, log_alpha, grad, alpha_loss);
+  return (int)hipGetLastError();
+}
+
+int rg_adam_step_f64(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                     double beta1, double beta2, double eps, double bias_correction1,
+                     double bias_correction2_sqrt, double* exp_param_out, rg_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || bias_correction1 == 0.0) return RG_EINVAL;
+  RG_LAUNCH(adam_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream, param, grad,
+            exp_avg, exp_avg_sq, (int)n, lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt,
+            exp_param_out);
+  return (int)hipGetLastError();
+}
+
+int rg_add_cols(const float* a, int64_t lda, const float* b, int64_t ldb, int batch, int cols, float* out,
+                int64_t ldo, rg_stream_t stream) {
+  if (!a || !out || batch <= 0 || cols <= 0) return RG_EINVAL;
+  const long n = (long)batch * cols;
+  RG_LAUNCH(add_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream, a, (long)lda, b,
+            (long)ldb, batch, cols, out, (long)ldo);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

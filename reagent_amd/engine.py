@@ -208,8 +208,9 @@ class FCStack:
 
     # ---- backward ------------------------------------------------------------------------
     def backward(self, dout32: torch.Tensor, xt: torch.Tensor, dw: List[torch.Tensor],
-                 db: List[torch.Tensor], dx32: Optional[torch.Tensor] = None):
+                 db: List[torch.Tensor], dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False):
         """Gradients of a scalar loss given d loss / d output (fp32 [B, out_last]).
+        skip_wgrad: only propagate to the input (frozen network, e.g. SAC's critics in the actor step).
 
         Requires a preceding ``forward(..., save=True)`` on the same batch.  xt: transposed staged
         input [in, B].  dw[i] / db[i]: contiguous fp32 destinations (gradient-slab views).
@@ -226,7 +227,8 @@ class FCStack:
         for i in range(self.L - 1, -1, -1):
             in_f, out_f = self.dims[i], self.dims[i + 1]
             x_t = xt if i == 0 else ws["ht"][i - 1]
-            ops.fc_wgrad(dzt, x_t, dw[i], db[i], ws["wgrad"], self.precision)
+            if not skip_wgrad:
+                ops.fc_wgrad(dzt, x_t, dw[i], db[i], ws["wgrad"], self.precision)
             if i > 0:
                 nxt = (self.L - i) % 2
                 dz_n = ws["dz"][nxt][:, :in_f]
@@ -352,7 +354,7 @@ class FusedMLP:
         return out32
 
     def backward(self, dout32: torch.Tensor, xt, dw: List[torch.Tensor], db: List[torch.Tensor],
-                 dx32: Optional[torch.Tensor] = None):
+                 dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False):
         if self.acts[-1] != L.ACT["linear"]:
             raise NotImplementedError("training through a non-linear output activation")
         B = dout32.shape[0]
@@ -361,14 +363,14 @@ class FusedMLP:
         lib = L.lib()
         ws = self._ws
         for l in range(self.L):
-            d.db[l] = db[l].data_ptr() if db[l] is not None else None
+            d.db[l] = db[l].data_ptr() if (db is not None and not skip_wgrad and db[l] is not None) else None
         ops._run("rg_mlp_backward_fused", dict(B=B, dims=tuple(self.dims)),
                  lambda: lib.rg_mlp_backward_fused(d, dout32.data_ptr(), dout32.stride(0), B,
                                                    dx32.data_ptr() if dx32 is not None else None,
                                                    dx32.stride(0) if dx32 is not None else 0,
                                                    ws["bwd"].data_ptr(), ws["bwd"].numel() * 4, L.stream_ptr()))
         wsb = ws["wgrad"].numel() * 4
-        for l in range(self.L):
+        for l in range(self.L if not skip_wgrad else 0):
             out_f, in_f = self.dims[l + 1], self.dims[l]
             ops._run("rg_fc_wgrad_frag", dict(M=out_f, N=in_f, K=B),
                      lambda l=l, out_f=out_f, in_f=in_f: lib.rg_fc_wgrad_frag(

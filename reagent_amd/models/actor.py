@@ -1,0 +1,79 @@
+"""GaussianFullyConnectedActor (reagent/models/actor.py:113-261): FC stack -> (loc, scale_log),
+tanh-squashed reparameterised Gaussian sample and its log-probability.  The FC stack runs on the HIP
+FC kernels, the head on rg_gaussian_head_forward / rg_gaussian_log_prob.  One FC evaluation per call
+(the reference evaluates it twice in forward() — the values are identical)."""
+import math
+from typing import List
+
+import torch
+
+from .. import ops
+from ..core import types as rlt
+from .base import ModelBase
+from .fully_connected_network import FullyConnectedNetwork
+
+LOG_PROB_MIN: float = -2.0
+LOG_PROB_MAX = 2.0
+
+
+class GaussianFullyConnectedActor(ModelBase):
+    def __init__(
+        self,
+        state_dim: int,
+        action_dim: int,
+        sizes: List[int],
+        activations: List[str],
+        scale: float = 0.05,
+        use_batch_norm: bool = False,
+        use_layer_norm: bool = False,
+        use_l2_normalization: bool = False,
+    ) -> None:
+        super().__init__()
+        assert state_dim > 0, "state_dim must be > 0, got {}".format(state_dim)
+        assert action_dim > 0, "action_dim must be > 0, got {}".format(action_dim)
+        if use_l2_normalization or use_layer_norm or use_batch_norm:
+            raise NotImplementedError("l2 / layer / batch normalisation are off on the MI355X hot path")
+        self.state_dim = state_dim
+        self.action_dim = action_dim
+        assert len(sizes) == len(activations), (
+            "The numbers of sizes and activations must match; got {} vs {}".format(len(sizes), len(activations))
+        )
+        self.fc = FullyConnectedNetwork([state_dim] + list(sizes) + [action_dim * 2], list(activations) + ["linear"])
+        self.use_layer_norm = False
+        self.use_l2_normalization = False
+        self.const = math.log(math.sqrt(2 * math.pi))
+        self.eps = 1e-6
+        self.noise_override = None  # tests / parity runs inject the reference's randn draw here
+
+    def input_prototype(self):
+        return rlt.FeatureData(torch.randn(1, self.state_dim))
+
+    def _get_loc_and_scale_log(self, state):
+        loc_scale = self.fc(state.float_features)
+        loc = loc_scale[::, : self.action_dim]
+        scale_log = loc_scale[::, self.action_dim :].clamp(LOG_PROB_MIN, LOG_PROB_MAX)
+        return loc, scale_log
+
+    def _noise(self, batch: int, device) -> torch.Tensor:
+        if self.noise_override is not None:
+            n, self.noise_override = self.noise_override, None
+            return n.to(device=device, dtype=torch.float32).contiguous()
+        return torch.randn(batch, self.action_dim, device=device)
+
+    @torch.no_grad()
+    def forward(self, state):
+        loc_scale = self.fc(state.float_features)
+        B, dev = loc_scale.shape[0], loc_scale.device
+        action = torch.empty(B, self.action_dim, device=dev)
+        log_prob = torch.empty(B, 1, device=dev)
+        squashed_mean = torch.empty(B, self.action_dim, device=dev)
+        ops.gaussian_head_forward(loc_scale, self._noise(B, dev), action, log_prob, squashed_mean)
+        return rlt.ActorOutput(action=action, log_prob=log_prob, squashed_mean=squashed_mean)
+
+    @torch.no_grad()
+    def get_log_prob(self, state, squashed_action: torch.Tensor):
+        loc_scale = self.fc(state.float_features)
+        log_prob = torch.empty(loc_scale.shape[0], 1, device=loc_scale.device)
+        a = squashed_action if squashed_action.stride(-1) == 1 else squashed_action.contiguous()
+        ops.gaussian_log_prob(loc_scale, a.float(), log_prob)
+        return log_prob

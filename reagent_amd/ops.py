@@ -246,3 +246,78 @@ def soft_update(target, source, n, tau, t_off=0, s_off=0):
     _run("rg_soft_update", dict(n=n),
          lambda: L.lib().rg_soft_update(target.data_ptr() + 4 * t_off, source.data_ptr() + 4 * s_off, n, tau,
                                         L.stream_ptr()))
+
+
+# ---- SAC --------------------------------------------------------------------------------------
+def gaussian_head_forward(loc_scale, noise, action, log_prob=None, squashed_mean=None):
+    _chk_dev(loc_scale, noise, action, log_prob, squashed_mean)
+    B, A = noise.shape
+    assert noise.is_contiguous() and loc_scale.shape == (B, 2 * A)
+    _run("rg_gaussian_head_forward", dict(B=B, A=A),
+         lambda: L.lib().rg_gaussian_head_forward(L.ptr(loc_scale), _ld(loc_scale), L.ptr(noise), B, A,
+                                                  L.ptr(action), _ld(action), L.ptr(log_prob),
+                                                  L.ptr(squashed_mean), L.stream_ptr()))
+
+
+def gaussian_log_prob(loc_scale, action, log_prob):
+    _chk_dev(loc_scale, action, log_prob)
+    B, A = action.shape
+    _run("rg_gaussian_log_prob", dict(B=B, A=A),
+         lambda: L.lib().rg_gaussian_log_prob(L.ptr(loc_scale), _ld(loc_scale), L.ptr(action), _ld(action), B, A,
+                                              L.ptr(log_prob), L.stream_ptr()))
+
+
+def gaussian_head_backward(loc_scale, noise, g_action, g_log_prob, d_loc_scale):
+    _chk_dev(loc_scale, noise, g_action, g_log_prob, d_loc_scale)
+    B, A = noise.shape
+    _run("rg_gaussian_head_backward", dict(B=B, A=A),
+         lambda: L.lib().rg_gaussian_head_backward(L.ptr(loc_scale), _ld(loc_scale), L.ptr(noise),
+                                                   L.ptr(g_action), _ld(g_action) if g_action is not None else 0,
+                                                   L.ptr(g_log_prob), B, A, L.ptr(d_loc_scale),
+                                                   _ld(d_loc_scale), L.stream_ptr()))
+
+
+def sac_partials(batch: int) -> int:
+    return int(L.lib().rg_sac_partials(batch))
+
+
+def sac_critic_head(q1, q2, q1t, q2t, lp_next, reward, not_terminal, gamma, alpha, target, dq1, dq2, l1, l2):
+    _chk_dev(q1, q2, q1t, q2t, lp_next, reward, not_terminal, alpha, target, dq1, dq2, l1, l2)
+    B = q1.numel()
+    _run("rg_sac_critic_head", dict(B=B),
+         lambda: L.lib().rg_sac_critic_head(L.ptr(q1), L.ptr(q2), L.ptr(q1t), L.ptr(q2t), L.ptr(lp_next),
+                                            L.ptr(reward), L.ptr(not_terminal), float(gamma), L.ptr(alpha), B,
+                                            L.ptr(target), L.ptr(dq1), L.ptr(dq2), L.ptr(l1), L.ptr(l2),
+                                            L.stream_ptr()))
+
+
+def sac_actor_head(lp, q1a, q2a, alpha, target_entropy, g_lp, dq1a, dq2a, loss_part, ent_part):
+    _chk_dev(lp, q1a, q2a, alpha, g_lp, dq1a, dq2a, loss_part, ent_part)
+    B = lp.numel()
+    _run("rg_sac_actor_head", dict(B=B),
+         lambda: L.lib().rg_sac_actor_head(L.ptr(lp), L.ptr(q1a), L.ptr(q2a), L.ptr(alpha), float(target_entropy),
+                                           B, L.ptr(g_lp), L.ptr(dq1a), L.ptr(dq2a), L.ptr(loss_part),
+                                           L.ptr(ent_part), L.stream_ptr()))
+
+
+def sac_alpha_grad(ent_part, batch, log_alpha, grad, alpha_loss=None):
+    _chk_dev(ent_part, log_alpha, grad, alpha_loss)
+    _run("rg_sac_alpha_grad", dict(B=batch),
+         lambda: L.lib().rg_sac_alpha_grad(L.ptr(ent_part), batch, L.ptr(log_alpha), L.ptr(grad),
+                                           L.ptr(alpha_loss), L.stream_ptr()))
+
+
+def adam_step_f64(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bc1, bc2_sqrt, exp_out=None):
+    _chk_dev(param, grad, exp_avg, exp_avg_sq, exp_out)
+    _run("rg_adam_step_f64", dict(n=param.numel()),
+         lambda: L.lib().rg_adam_step_f64(L.ptr(param), L.ptr(grad), L.ptr(exp_avg), L.ptr(exp_avg_sq),
+                                          param.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, L.ptr(exp_out),
+                                          L.stream_ptr()))
+
+
+def add_cols(a, b, out):
+    _chk_dev(a, b, out)
+    B, C = out.shape
+    _run("rg_add_cols", dict(B=B, C=C),
+         lambda: L.lib().rg_add_cols(L.ptr(a), _ld(a), L.ptr(b), _ld(b) if b is not None else 0, B, C, L.ptr(out),
+                                     _ld(out), L.stream_ptr()))

@@ -1,0 +1,391 @@
+"""SACTrainer with the constructor / generator surface of reagent/training/sac_trainer.py:50-385
+(twin or single critic, no value network, temperature optimizer optional), executed on the HIP
+kernels.
+
+One step, in the reference's segment order (each segment = one optimizer under the
+Lightning-1.6 toggle, so other networks are constants inside it):
+  seg q1/q2 : a' = actor(s'), log_prob' ; y = r + g*(min(q1_t,q2_t)(s',a') - alpha*clamp(log_prob'))*not_done
+              q_i = q_i(s, a); loss_i = mse(q_i, y)                       -> Adam(q1), Adam(q2)
+  seg actor : (a_pi, log_prob) = actor(s); loss = mean(alpha*clamp(log_prob) - min(q1,q2)(s, a_pi)) with the
+              UPDATED critics; the gradient reaches the actor through the critics' action input -> Adam(actor)
+  seg alpha : loss = -mean(log_alpha * (clamp(log_prob) + target_entropy)); alpha = exp(log_alpha)   (fp64)
+  soft update of the target critics.
+Algorithmic FC work: 2 actor forwards + 1 actor backward, 6 critic forwards, 2 full critic backwards,
+2 input-gradient-only critic backwards (the reference additionally re-evaluates the actor FC inside
+get_log_prob: identical values, not repeated here).
+"""
+import copy
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import ops
+from ..core import types as rlt
+from ..core.parameters import RLParameters
+from ..engine import ensure_slab
+from ..optimizer import Optimizer__Union, SoftUpdate
+from .reagent_lightning_module import ReAgentLightningModule
+from .rl_trainer_pytorch import RLTrainerMixin
+
+
+class _SegmentLoss(torch.autograd.Function):
+    """Scalar loss whose backward runs a HIP backward closure (writes ``.grad`` in place)."""
+
+    @staticmethod
+    def forward(ctx, closure, loss_buf, *params):
+        ctx.closure = closure
+        ctx.n = len(params)
+        return loss_buf.detach().clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.closure(grad_out)
+        return (None, None) + (None,) * ctx.n
+
+
+class AdamF64(torch.optim.Optimizer):
+    """torch.optim.Adam arithmetic for the single fp64 temperature parameter (rg_adam_step_f64);
+    also publishes alpha = exp(log_alpha) to the device scalar the loss heads read."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, alpha_out=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.alpha_out = alpha_out
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                t = st["step"]
+                out = self.alpha_out() if callable(self.alpha_out) else self.alpha_out
+                ops.adam_step_f64(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2,
+                                  group["eps"], 1.0 - b1**t, math.sqrt(1.0 - b2**t), out)
+        return None
+
+
+class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
+    def __init__(
+        self,
+        actor_network,
+        q1_network,
+        q2_network=None,
+        value_network=None,
+        rl: Optional[RLParameters] = None,
+        q_network_optimizer: Optional[Optimizer__Union] = None,
+        value_network_optimizer: Optional[Optimizer__Union] = None,
+        actor_network_optimizer: Optional[Optimizer__Union] = None,
+        alpha_optimizer: Optional[Optimizer__Union] = "default",
+        minibatch_size: int = 1024,
+        entropy_temperature: float = 0.01,
+        logged_action_uniform_prior: bool = True,
+        target_entropy: float = -1.0,
+        action_embedding_kld_weight: Optional[float] = None,
+        apply_kld_on_mean: bool = False,
+        action_embedding_mean: Optional[List[float]] = None,
+        action_embedding_variance: Optional[List[float]] = None,
+        crr_config=None,
+        backprop_through_log_prob: bool = True,
+    ) -> None:
+        super().__init__()
+        if value_network is not None or crr_config is not None:
+            raise NotImplementedError("the value-network / CRR variants are not on the MI355X hot path (BASELINE C4)")
+        if action_embedding_kld_weight:
+            raise NotImplementedError("the action-embedding KLD term needs batch statistics (SURVEY.md §8e): not built")
+        if not backprop_through_log_prob:
+            raise NotImplementedError("backprop_through_log_prob=False is a legacy switch, not built")
+        self.rl_parameters = rl if rl is not None else RLParameters()
+        d = Optimizer__Union.default
+        self.q1_network = q1_network
+        self.q2_network = q2_network
+        self.q_network_optimizer = q_network_optimizer if q_network_optimizer is not None else d()
+        self.value_network = None
+        self.value_network_optimizer = value_network_optimizer if value_network_optimizer is not None else d()
+        self.q1_network_target = copy.deepcopy(self.q1_network)
+        self.q2_network_target = copy.deepcopy(self.q2_network)
+        self.actor_network = actor_network
+        self.actor_network_optimizer = actor_network_optimizer if actor_network_optimizer is not None else d()
+        self.entropy_temperature = entropy_temperature
+        self.alpha_optimizer = d() if isinstance(alpha_optimizer, str) else alpha_optimizer
+        if self.alpha_optimizer is not None:
+            self.target_entropy = target_entropy
+            self.log_alpha = torch.nn.Parameter(torch.tensor([np.log(self.entropy_temperature)]))  # fp64 (:124-126)
+        else:
+            self.target_entropy = target_entropy
+        self.logged_action_uniform_prior = logged_action_uniform_prior
+        self.add_kld_to_loss = False
+        self.crr_config = None
+        self.backprop_through_log_prob = backprop_through_log_prob
+        self.minibatch_size = minibatch_size
+        self._ws_batch = -1
+        self._alpha_dev = None
+        self._dp_group, self._dp_world = None, 1
+
+    # ---- optimizers (sac_trainer.py:148-193) ---------------------------------------------------
+    def configure_optimizers(self):
+        optimizers = [self.q_network_optimizer.make_optimizer_scheduler(self.q1_network.parameters())]
+        if self.q2_network:
+            optimizers.append(self.q_network_optimizer.make_optimizer_scheduler(self.q2_network.parameters()))
+        optimizers.append(self.actor_network_optimizer.make_optimizer_scheduler(self.actor_network.parameters()))
+        if self.alpha_optimizer is not None:
+            cfg = self.alpha_optimizer.value
+            optimizers.append({"optimizer": AdamF64([self.log_alpha], lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
+                                                    weight_decay=cfg.weight_decay,
+                                                    alpha_out=lambda: self._alpha(self.log_alpha.device))})
+        target_params = list(self.q1_network_target.parameters())
+        source_params = list(self.q1_network.parameters())
+        if self.q2_network:
+            target_params += list(self.q2_network_target.parameters())
+            source_params += list(self.q2_network.parameters())
+        optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
+        return optimizers
+
+    # ---- engine ----------------------------------------------------------------------------------
+    def _alpha(self, device):
+        if self._alpha_dev is None or self._alpha_dev.device != device:
+            et = self.entropy_temperature
+            val = float(et.item()) if isinstance(et, torch.Tensor) else float(et)
+            self._alpha_dev = torch.tensor([val], dtype=torch.float64, device=device)
+        return self._alpha_dev
+
+    def _net_engine(self, net):
+        params = list(net.parameters())
+        slab = ensure_slab(params)
+        lin = net.fc.linears()
+        index = {id(p): i for i, p in enumerate(params)}
+        dw = [slab.view(slab.grad, index[id(l.weight)]) for l in lin]
+        db = [slab.view(slab.grad, index[id(l.bias)]) for l in lin]
+        return dict(params=params, slab=slab, stack=net.fc.stack(), dw=dw, db=db)
+
+    def _engine(self, B, dev, S, A):
+        self._e = {k: self._net_engine(n) for k, n in dict(actor=self.actor_network, q1=self.q1_network,
+                                                           q2=self.q2_network).items() if n is not None}
+        self._t = {k: n.fc.stack() for k, n in dict(q1=self.q1_network_target, q2=self.q2_network_target).items()
+                   if n is not None}
+        for k in ("q1", "q2"):
+            if k in self._e:
+                self._e[k]["stack"].set_need_input_grad(True)
+        if self._ws_batch != B or self._x.device != dev:
+            f = dict(dtype=torch.float32, device=dev)
+            P = ops.sac_partials(B)
+            self._x, self._xn, self._xa = (torch.empty(B, S + A, **f) for _ in range(3))
+            self._ls, self._lsn, self._dls = (torch.empty(B, 2 * A, **f) for _ in range(3))
+            self._lp, self._lpn = torch.empty(B, **f), torch.empty(B, **f)
+            names = ["q1v", "q2v", "q1t", "q2t", "q1a", "q2a", "dq1", "dq2", "dq1a", "dq2a", "y", "glp"]
+            for n in names:
+                setattr(self, "_" + n, torch.empty(B, 1, **f))
+            self._dx1, self._dx2 = torch.empty(B, S + A, **f), torch.empty(B, S + A, **f)
+            self._ga = torch.empty(B, A, **f)
+            self._parts = {n: torch.empty(P, **f) for n in ("l1", "l2", "la", "ent")}
+            self._losses = {n: torch.empty(1, **f) for n in ("q1", "q2", "actor")}
+            self._alpha_grad = torch.zeros(1, dtype=torch.float64, device=dev)
+            self._alpha_loss = torch.zeros(1, dtype=torch.float64, device=dev)
+            self._ws_batch = B
+
+    @staticmethod
+    def _f32c(t):
+        t = t if t.dtype == torch.float32 else t.float()
+        return t if t.is_contiguous() else t.contiguous()
+
+    def _publish(self, e):
+        slab = e["slab"]
+        if self._dp_group is not None:
+            torch.distributed.all_reduce(slab.grad, group=self._dp_group)
+        base = slab.grad.data_ptr()
+        for i, p in enumerate(e["params"]):
+            gv = slab.view(slab.grad, i)
+            if p.grad is None or p.grad.data_ptr() == base + 4 * slab.offsets[i]:
+                p.grad = gv
+            else:
+                p.grad.add_(gv)
+
+    # ---- segments ----------------------------------------------------------------------------------
+    def _critic_forward(self, b, noise_next):
+        state, action = self._f32c(b.state.float_features), self._f32c(b.action.float_features)
+        next_state = self._f32c(b.next_state.float_features)
+        L.require_cuda(state, "training_batch.state")
+        B, S, A, dev = state.shape[0], state.shape[1], action.shape[1], state.device
+        self._engine(B, dev, S, A)
+        self._S, self._A, self._B = S, A, B
+        e, t = self._e, self._t
+        for k in e:
+            e[k]["stack"].stage_weights(need_transposed=True)
+        for k in t:
+            t[k].stage_weights(need_transposed=False)
+        alpha = self._alpha(dev)
+        act = e["actor"]["stack"]
+        # a' = actor(s'), log_prob'  (actor frozen in this segment)
+        xn_s, _ = act.stage_input(next_state, need_transposed=False)
+        act.forward(xn_s, self._lsn, save=False)
+        self._xn[:, :S].copy_(next_state)
+        a_next = self._xn[:, S:]
+        ops.gaussian_head_forward(self._lsn, noise_next, a_next, self._lpn, None)
+        xn_c, _ = t["q1"].stage_input(self._xn, need_transposed=False)
+        t["q1"].forward(xn_c, self._q1t, save=False)
+        if "q2" in t:
+            t["q2"].forward(xn_c, self._q2t, save=False)
+        # q_i(s, a)
+        self._x[:, :S].copy_(state)
+        self._x[:, S:].copy_(action)
+        q1s = e["q1"]["stack"]
+        x_c, self._x_t = q1s.stage_input(self._x, need_transposed=True)
+        q1s.forward(x_c, self._q1v, save=True)
+        has_q2 = "q2" in e
+        if has_q2:
+            e["q2"]["stack"].forward(x_c, self._q2v, save=True)
+        ops.sac_critic_head(self._q1v, self._q2v if has_q2 else None, self._q1t, self._q2t if has_q2 else None,
+                            self._lpn, self._f32c(b.reward).reshape(-1), self._f32c(b.not_terminal).reshape(-1),
+                            self.gamma, alpha, self._y, self._dq1, self._dq2 if has_q2 else None, self._parts["l1"],
+                            self._parts["l2"] if has_q2 else None)
+        P = self._parts["l1"].numel()
+        ops.reduce_sum(self._parts["l1"], P, 1.0 / B, self._losses["q1"])
+        if has_q2:
+            ops.reduce_sum(self._parts["l2"], P, 1.0 / B, self._losses["q2"])
+
+    def _critic_backward(self, which, grad_out=None):
+        e = self._e[which]
+        dq = self._dq1 if which == "q1" else self._dq2
+        if grad_out is not None:
+            dq = dq * grad_out
+        e["stack"].backward(dq, self._x_t, e["dw"], e["db"])
+        self._publish(e)
+
+    def _actor_forward(self, b, noise_cur):
+        state = self._f32c(b.state.float_features)
+        S, B, dev = self._S, self._B, state.device
+        e = self._e
+        for k in ("q1", "q2"):  # critics were just updated by their Adam steps
+            if k in e:
+                e[k]["stack"].stage_weights(need_transposed=True)
+        act = e["actor"]["stack"]
+        xs_c, self._xs_t = act.stage_input(state, need_transposed=True)
+        act.forward(xs_c, self._ls, save=True)
+        self._xa[:, :S].copy_(state)
+        self._noise_cur = noise_cur
+        ops.gaussian_head_forward(self._ls, noise_cur, self._xa[:, S:], self._lp, None)
+        q1s = e["q1"]["stack"]
+        xa_c, _ = q1s.stage_input(self._xa, need_transposed=False)
+        q1s.forward(xa_c, self._q1a, save=True)
+        has_q2 = "q2" in e
+        if has_q2:
+            e["q2"]["stack"].forward(xa_c, self._q2a, save=True)
+        ops.sac_actor_head(self._lp, self._q1a, self._q2a if has_q2 else None, self._alpha(dev),
+                           self.target_entropy, self._glp, self._dq1a, self._dq2a if has_q2 else None,
+                           self._parts["la"], self._parts["ent"])
+        ops.reduce_sum(self._parts["la"], self._parts["la"].numel(), 1.0 / B, self._losses["actor"])
+
+    def _actor_backward(self, grad_out=None):
+        e, S = self._e, self._S
+        has_q2 = "q2" in e
+        e["q1"]["stack"].backward(self._dq1a, None, None, None, dx32=self._dx1, skip_wgrad=True)
+        if has_q2:
+            e["q2"]["stack"].backward(self._dq2a, None, None, None, dx32=self._dx2, skip_wgrad=True)
+        ops.add_cols(self._dx1[:, S:], self._dx2[:, S:] if has_q2 else None, self._ga)
+        ops.gaussian_head_backward(self._ls, self._noise_cur, self._ga, self._glp.reshape(-1), self._dls)
+        dls = self._dls if grad_out is None else self._dls * grad_out
+        a = e["actor"]
+        a["stack"].backward(dls, self._xs_t, a["dw"], a["db"])
+        self._publish(a)
+
+    def _alpha_backward(self, grad_out=None):
+        ops.sac_alpha_grad(self._parts["ent"], self._B, self.log_alpha.data, self._alpha_grad, self._alpha_loss)
+        g = self._alpha_grad if grad_out is None else self._alpha_grad * grad_out.double()
+        if self.log_alpha.grad is None:
+            self.log_alpha.grad = g.clone()
+        else:
+            self.log_alpha.grad.add_(g)
+
+    def _noise(self, B, A, dev, given):
+        if given is not None:
+            return given.to(device=dev, dtype=torch.float32).contiguous()
+        return torch.randn(B, A, device=dev)
+
+    # ---- reference surface -------------------------------------------------------------------------
+    def set_noise(self, noise_next: torch.Tensor, noise_cur: torch.Tensor):
+        """Inject the two N(0,1) draws of this step (the reference's torch.randn_like calls in
+        actor(next_state) and actor(state), actor.py:217) — parity runs only."""
+        self._injected = (noise_next, noise_cur)
+
+    def train_step_gen(self, training_batch: rlt.PolicyNetworkInput, batch_idx: int):
+        """IMPORTANT: the input action here is assumed to match the range of the output of the actor."""
+        assert hasattr(training_batch, "action") and hasattr(training_batch.action, "float_features")
+        b = training_batch
+        B, A = b.action.float_features.shape
+        dev = b.action.float_features.device
+        inj = getattr(self, "_injected", None) or (None, None)
+        self._injected = None
+        self._critic_forward(b, self._noise(B, A, dev, inj[0]))
+        q1 = self._e["q1"]
+        yield _SegmentLoss.apply(lambda g: self._critic_backward("q1", g), self._losses["q1"], *q1["params"])
+        if self.q2_network:
+            q2 = self._e["q2"]
+            yield _SegmentLoss.apply(lambda g: self._critic_backward("q2", g), self._losses["q2"], *q2["params"])
+        self._actor_forward(b, self._noise(B, A, dev, inj[1]))
+        yield _SegmentLoss.apply(self._actor_backward, self._losses["actor"], *self._e["actor"]["params"])
+        if self.alpha_optimizer is not None:
+            ops.sac_alpha_grad(self._parts["ent"], self._B, self.log_alpha.data, self._alpha_grad, self._alpha_loss)
+            yield _SegmentLoss.apply(self._alpha_backward, self._alpha_loss, self.log_alpha)
+            self.entropy_temperature = self._alpha(dev)  # = exp(log_alpha), written by AdamF64.step (:322)
+        yield self.soft_update_result()
+
+    # ---- fused native step ---------------------------------------------------------------------------
+    def native_optimizers(self):
+        if getattr(self, "_native_opts", None) is None:
+            self._native_opts = [o["optimizer"] for o in self.configure_optimizers()]
+        return self._native_opts
+
+    def enable_data_parallel(self, process_group=None):
+        import torch.distributed as dist
+
+        self._dp_group = process_group if process_group is not None else dist.group.WORLD
+        self._dp_world = dist.get_world_size(self._dp_group)
+        return self
+
+    @torch.no_grad()
+    def train_step_native(self, training_batch, noise_next=None, noise_cur=None):
+        """All five segments with no autograd graph / generator / host sync.  Returns the dict of
+        device-resident loss scalars."""
+        opts = self.native_optimizers()
+        b = training_batch
+        B, A = b.action.float_features.shape
+        dev = b.action.float_features.device
+        gs = 1.0 / self._dp_world
+        it = iter(opts)
+        self._critic_forward(b, self._noise(B, A, dev, noise_next))
+        for k in ("q1", "q2"):
+            if k in self._e:
+                for p in self._e[k]["params"]:
+                    p.grad = None
+                self._critic_backward(k)
+                o = next(it)
+                o.grad_scale = gs
+                o.step()
+        self._actor_forward(b, self._noise(B, A, dev, noise_cur))
+        for p in self._e["actor"]["params"]:
+            p.grad = None
+        self._actor_backward()
+        o = next(it)
+        o.grad_scale = gs
+        o.step()
+        if self.alpha_optimizer is not None:
+            self.log_alpha.grad = None
+            self._alpha_backward()
+            if self._dp_group is not None:
+                torch.distributed.all_reduce(self.log_alpha.grad, group=self._dp_group)
+                self.log_alpha.grad.mul_(gs)
+            next(it).step()
+            self.entropy_temperature = self._alpha(dev)
+        next(it).step()  # soft update
+        self.all_batches_processed += 1
+        return dict(q1_loss=self._losses["q1"], q2_loss=self._losses["q2"], actor_loss=self._losses["actor"],
+                    alpha_loss=self._alpha_loss)
