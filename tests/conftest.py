@@ -41,3 +41,11 @@ def backend(request, monkeypatch):
 
     L.lib()  # fail loudly if the HIP extension is missing
     return Backend("hip", "cuda")
+
+
+@pytest.fixture
+def emu_lib(monkeypatch):
+    """The host-compiled kernel library patched into reagent_amd for this test process (CPU only)."""
+    import emu_backend
+
+    return emu_backend.install(monkeypatch)

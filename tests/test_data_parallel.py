@@ -1,0 +1,96 @@
+"""Data-parallel path: one process per shard, gradient slab all-reduced (sum) after
+backward, 1/world folded into the fused Adam.  world_size = 2 over gloo on the CPU, kernels through
+the host-compiled sources (tests/emu) — checks the HOST logic: two ranks on disjoint half-batches end
+with identical parameters, equal to one process stepping on the concatenated batch (every loss on
+this path is a batch mean)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(kind):
+    import reagent_amd._lib as L
+    from reagent_amd.core.parameters import EvaluationParameters, RLParameters
+    from reagent_amd.models import FullyConnectedCritic, FullyConnectedDQN, GaussianFullyConnectedActor
+    from reagent_amd.optimizer import Optimizer__Union
+    from reagent_amd.training import DQNTrainer, SACTrainer
+
+    torch.manual_seed(0)  # identical initial weights on every rank
+    if kind == "dqn":
+        q = FullyConnectedDQN(12, 4, [32, 16], ["relu", "relu"])
+        return DQNTrainer(q, q.get_target_network(), None, actions=["a", "b", "c", "d"],
+                          rl=RLParameters(gamma=0.9, target_update_rate=0.1, q_network_loss="huber"),
+                          optimizer=Optimizer__Union.default(lr=0.01),
+                          evaluation=EvaluationParameters(calc_cpe_in_training=False))
+    actor = GaussianFullyConnectedActor(6, 2, [16, 16], ["relu", "relu"])
+    q1 = FullyConnectedCritic(6, 2, [16, 16], ["relu", "relu"])
+    q2 = FullyConnectedCritic(6, 2, [16, 16], ["relu", "relu"])
+    return SACTrainer(actor, q1, q2, rl=RLParameters(gamma=0.9, target_update_rate=0.1),
+                      q_network_optimizer=Optimizer__Union.default(lr=0.01),
+                      actor_network_optimizer=Optimizer__Union.default(lr=0.01),
+                      alpha_optimizer=Optimizer__Union.default(lr=0.01))
+
+
+def _batches(kind, B):
+    from reagent_amd import synthetic
+
+    if kind == "dqn":
+        return synthetic.dqn_batch(B, 12, 4, seed=5, p_impossible=0.2)
+    return synthetic.policy_batch(B, 6, 2, seed=5)
+
+
+def _step(kind, tr, d, noise=None):
+    from reagent_amd import synthetic
+
+    if kind == "dqn":
+        tr.train_step_native(synthetic.to_dqn_input(d))
+    else:
+        tr.train_step_native(synthetic.to_policy_input(d), noise[0], noise[1])
+
+
+def _worker(rank, world, port, kind, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_backend
+
+    emu_backend.install()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 64
+    full = _batches(kind, B)
+    half = {k: v[rank * B // 2 : (rank + 1) * B // 2].contiguous() for k, v in full.items()}
+    g = torch.Generator().manual_seed(9)
+    noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
+    my_noise = tuple(n[rank * B // 2 : (rank + 1) * B // 2].contiguous() for n in noise)
+    tr = _build(kind).enable_data_parallel()
+    for _ in range(2):
+        _step(kind, tr, half, my_noise)
+    torch.save([p.detach().clone() for p in tr.parameters()], os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["dqn", "sac"])
+def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib, kind):
+    port = 29500 + (os.getpid() % 2000) + (0 if kind == "dqn" else 1)
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)  # replicas stay bit-identical
+    # single process, whole batch
+    B = 64
+    full = _batches(kind, B)
+    g = torch.Generator().manual_seed(9)
+    noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
+    tr = _build(kind)
+    for _ in range(2):
+        _step(kind, tr, full, noise)
+    for a, p in zip(r0, tr.parameters()):
+        assert (a.double() - p.detach().double()).abs().max() <= 2e-6, kind
