@@ -141,7 +141,7 @@ def kernel_profile(args, loop, steps, layer_dims):
             loop.step()
     rows = prof.summary()
     fc_names = ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad", "rg_fc_wgrad_frag", "rg_mlp_forward_fused",
-                "rg_mlp_backward_fused")
+                "rg_mlp_backward_fused", "rg_mlp_wgrad_fused")
     fc = [r for r in rows if r["name"] in fc_names]
     for r in fc:
         m = r["meta"]
@@ -149,6 +149,10 @@ def kernel_profile(args, loop, steps, layer_dims):
             d = m["dims"]
             r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d, d[1:]))
             r["label"] = f"rg_mlp_forward_fused B={m['B']} dims={list(d)} save={m['save']}"
+        elif r["name"] == "rg_mlp_wgrad_fused":
+            d = m["dims"]
+            r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d, d[1:]))
+            r["label"] = f"rg_mlp_wgrad_fused B={m['B']} dims={list(d)}"
         elif r["name"] == "rg_mlp_backward_fused":
             d = m["dims"]
             r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d[1:], d[2:]))

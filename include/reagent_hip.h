@@ -97,6 +97,8 @@ typedef struct {
   void* act_frag[RG_MLP_MAX_LAYERS];          /* [l] = saved INPUT of layer l, C-fragment order */
   void* dz_frag[RG_MLP_MAX_LAYERS];           /* [l] = d loss / d pre-activation output of layer l */
   float* db[RG_MLP_MAX_LAYERS];               /* backward output: bias gradients [dims[l+1]] (nullable) */
+  const float* w[RG_MLP_MAX_LAYERS];          /* fp32 master weights [dims[l+1], dims[l]] (stage_weights_fused) */
+  float* dw[RG_MLP_MAX_LAYERS];               /* weight gradients, same shape (wgrad_fused) */
 } rg_mlp_desc; /* host struct */
 
 int rg_mlp_fused_supported(const rg_mlp_desc* d);
@@ -124,6 +126,14 @@ size_t rg_fc_wgrad_frag_workspace_bytes(int out_features, int in_features, int b
 int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, int in_features,
                      int batch, float* dw, void* workspace, size_t workspace_bytes,
                      rg_stream_t stream);
+
+/* Whole-stack variants: every layer's weights staged by ONE launch (d->w -> d->wfrag_fwd, and
+ * d->wfrag_bwd when need_bwd), every layer's weight gradient by ONE wgrad launch + ONE reduce
+ * (d->dz_frag, d->act_frag -> d->dw). */
+int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t stream);
+size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch);
+int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t workspace_bytes,
+                       rg_stream_t stream);
 
 /* ---- replay buffer ------------------------------------------------------------------------ */
 

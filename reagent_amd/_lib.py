@@ -64,6 +64,8 @@ class MlpDesc(ctypes.Structure):
         ("act_frag", c_void_p * MLP_MAX_LAYERS),
         ("dz_frag", c_void_p * MLP_MAX_LAYERS),
         ("db", c_void_p * MLP_MAX_LAYERS),
+        ("w", c_void_p * MLP_MAX_LAYERS),
+        ("dw", c_void_p * MLP_MAX_LAYERS),
     ]
 
 
@@ -91,6 +93,9 @@ SIGNATURES = {
                                        c_void_p, c_sz, c_void_p]),
     "rg_fc_wgrad_frag_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "rg_fc_wgrad_frag": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_sz, c_void_p]),
+    "rg_mlp_stage_weights_fused": (c_int, [ctypes.POINTER(MlpDesc), c_int, c_void_p]),
+    "rg_mlp_wgrad_fused_workspace_bytes": (c_sz, [ctypes.POINTER(MlpDesc), c_int]),
+    "rg_mlp_wgrad_fused": (c_int, [ctypes.POINTER(MlpDesc), c_int, c_void_p, c_sz, c_void_p]),
     "rg_replay_nstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_replay_gather": (c_int, [ctypes.POINTER(GatherCol), c_int, c_i64, c_int, c_int, c_void_p]),

@@ -486,16 +486,14 @@ struct WgradFragArgs {
   int N, K;           // valid extents of dW
 };
 
-__global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
-  RG_DYN_LDS(smem);
+__device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lg = lane >> 5;
   const int wn = wave >> 2, wk = wave & 3;
   const int n_groups = (g.NTa + 7) / 8, k_groups = (g.NTb + 7) / 8;
-  int bid = blockIdx.x;
-  const int kg = bid % k_groups; bid /= k_groups;
-  const int ng = bid % n_groups; bid /= n_groups;
-  const int split = bid;
+  const int kg = bid % k_groups;
+  const int ng = (bid / k_groups) % n_groups;
+  const int split = bid / (k_groups * n_groups);
   const int mb_begin = split * g.mb_per_split;
   const int mb_end = (mb_begin + g.mb_per_split < g.MB) ? mb_begin + g.mb_per_split : g.MB;
   const int ta0 = ng * 8, tb0 = kg * 8;
@@ -588,6 +586,76 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
     }
 }
 
+__global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
+  RG_DYN_LDS(smem);
+  wgrad_frag_body(g, (int)blockIdx.x, smem);
+}
+
+// all layers of a stack in ONE launch (workgroups of the small layers fill the CUs the big ones
+// leave idle; 4 launches + 4 reduces become 1 + 1)
+struct WgradGroupArgs {
+  int n;
+  int wg_begin[FB_MAXL + 1];
+  WgradFragArgs layer[FB_MAXL];
+};
+
+__global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_group_kernel(WgradGroupArgs G) {
+  RG_DYN_LDS(smem);
+  const int bid = blockIdx.x;
+  WgradFragArgs g = G.layer[0];
+  int base = 0;
+#pragma unroll
+  for (int i = 1; i < FB_MAXL; ++i)
+    if (i < G.n && bid >= G.wg_begin[i]) {
+      g = G.layer[i];
+      base = G.wg_begin[i];
+    }
+  wgrad_frag_body(g, bid - base, smem);
+}
+
+struct ReduceGroupArgs {
+  int n;
+  long elem_begin[FB_MAXL + 1];
+  const float* partial[FB_MAXL];
+  long slab[FB_MAXL];
+  int splits[FB_MAXL];
+  float* out[FB_MAXL];
+};
+
+__global__ void reduce_group_kernel(ReduceGroupArgs R) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R.elem_begin[R.n]) return;
+  const float* part = R.partial[0];
+  long slab = R.slab[0], base = 0;
+  int splits = R.splits[0];
+  float* out = R.out[0];
+#pragma unroll
+  for (int k = 1; k < FB_MAXL; ++k)
+    if (k < R.n && i >= R.elem_begin[k]) {
+      part = R.partial[k]; slab = R.slab[k]; splits = R.splits[k]; out = R.out[k]; base = R.elem_begin[k];
+    }
+  const long e = i - base;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < splits; k += 4) {
+    s0 += part[(long)k * slab + e];
+    s1 += part[(long)(k + 1) * slab + e];
+    s2 += part[(long)(k + 2) * slab + e];
+    s3 += part[(long)(k + 3) * slab + e];
+  }
+  for (; k < splits; ++k) s0 += part[(long)k * slab + e];
+  out[e] = (s0 + s1) + (s2 + s3);
+}
+
+struct StageGroupArgs {
+  int n;
+  long begin[FB_MAXL + 1];
+  const float* w[FB_MAXL];
+  int N[FB_MAXL], K[FB_MAXL];
+  bf16_t* wf[FB_MAXL];
+  bf16_t* wb[FB_MAXL];
+};
+
 // out[c] = sum_s partials[s][c], S x N row-major: 32 columns x 8 row-groups per workgroup, each
 // thread sums rows g, g+8, ... (independent loads in flight), groups combined in fixed order
 __global__ void reduce_cols_kernel(const float* __restrict__ partials, int S, int N, float* __restrict__ out) {
@@ -624,6 +692,41 @@ __global__ void reduce_splits2_kernel(const float* __restrict__ partials, long s
 }
 
 // fp32 master weights -> B-fragment order for forward (W) and backward (W^T), zero padded
+__device__ __forceinline__ void stage_weight_elem(const float* __restrict__ w, int N, int K, bf16_t* __restrict__ wf,
+                                                  bf16_t* __restrict__ wb, long i) {
+  const int KCf = (K + 15) / 16, NTf = (N + 31) / 32;
+  const int KCb = (N + 15) / 16, NTb = (K + 31) / 32;
+  const long tf = (long)NTf * KCf * 512, tb = (long)NTb * KCb * 512;
+  const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  const long blk = i >> 9;
+  if (wf && i < tf) {
+    const int kc = (int)(blk % KCf), nt = (int)(blk / KCf);
+    const int n = nt * 32 + (lane & 31), k = kc * 16 + (lane >> 5) * 8 + e;
+    wf[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
+  }
+  if (wb && i < tb) {
+    const int kc = (int)(blk % KCb), nt = (int)(blk / KCb);
+    const int k = nt * 32 + (lane & 31), n = kc * 16 + (lane >> 5) * 8 + e;  // "weight" = W^T [K][N]
+    wb[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
+  }
+}
+
+__global__ void stage_group_kernel(StageGroupArgs G) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G.begin[G.n]) return;
+  const float* w = G.w[0];
+  int N = G.N[0], K = G.K[0];
+  bf16_t* wf = G.wf[0];
+  bf16_t* wb = G.wb[0];
+  long base = 0;
+#pragma unroll
+  for (int k = 1; k < FB_MAXL; ++k)
+    if (k < G.n && i >= G.begin[k]) {
+      w = G.w[k]; N = G.N[k]; K = G.K[k]; wf = G.wf[k]; wb = G.wb[k]; base = G.begin[k];
+    }
+  stage_weight_elem(w, N, K, wf, wb, i - base);
+}
+
 __global__ void stage_weights_frag_kernel(const float* __restrict__ w, int N, int K, bf16_t* __restrict__ wf,
                                           bf16_t* __restrict__ wb) {
   const int NTf = (N + 31) / 32, KCf = (K + 15) / 16;
@@ -631,18 +734,7 @@ __global__ void stage_weights_frag_kernel(const float* __restrict__ w, int N, in
   const long tf = (long)NTf * KCf * 512, tb = (long)NTb * KCb * 512;
   const long total = tf > tb ? tf : tb;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    const long blk = i >> 9;
-    if (wf && i < tf) {
-      const int kc = (int)(blk % KCf), nt = (int)(blk / KCf);
-      const int n = nt * 32 + (lane & 31), k = kc * 16 + (lane >> 5) * 8 + e;
-      wf[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
-    }
-    if (wb && i < tb) {
-      const int kc = (int)(blk % KCb), nt = (int)(blk / KCb);
-      const int k = nt * 32 + (lane & 31), n = kc * 16 + (lane >> 5) * 8 + e;  // "weight" = W^T [K][N]
-      wb[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
-    }
+    stage_weight_elem(w, N, K, wf, wb, i);
   }
 }
 
@@ -834,6 +926,99 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   const long n = p.slab;
   RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
             (const float*)g.partial, p.slab, p.splits, dw, n);
+  return (int)hipGetLastError();
+}
+
+/* all layers' weights of a stack -> fragment order in one launch */
+int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t stream) {
+  if (!d || d->n_layers < 1 || d->n_layers > FB_MAXL) return RG_EINVAL;
+  StageGroupArgs G;
+  G.n = d->n_layers;
+  long off = 0;
+  for (int l = 0; l < FB_MAXL; ++l) {
+    G.begin[l] = off;
+    if (l < d->n_layers) {
+      if (!d->w[l] || !d->wfrag_fwd[l]) return RG_EINVAL;
+      const int N = d->dims[l + 1], K = d->dims[l];
+      G.w[l] = d->w[l]; G.N[l] = N; G.K[l] = K;
+      G.wf[l] = (bf16_t*)d->wfrag_fwd[l];
+      G.wb[l] = need_bwd ? (bf16_t*)d->wfrag_bwd[l] : nullptr;
+      const size_t tf = rg_wfrag_elems(N, K), tb = G.wb[l] ? rg_wfrag_elems(K, N) : 0;
+      off += (long)(tf > tb ? tf : tb);
+    } else {
+      G.w[l] = nullptr; G.N[l] = G.K[l] = 0; G.wf[l] = G.wb[l] = nullptr;
+    }
+  }
+  G.begin[FB_MAXL] = off;
+  for (int l = d->n_layers; l <= FB_MAXL; ++l) G.begin[l] = off;
+  RG_LAUNCH(stage_group_kernel, dim3((unsigned)((off + 255) / 256)), dim3(256), (hipStream_t)stream, G);
+  return (int)hipGetLastError();
+}
+
+static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target_wgs) {
+  WgradFragPlan p = wgrad_frag_plan(out_f, in_f, batch);
+  const int tiles = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8);
+  int want = (target_wgs + tiles - 1) / tiles;
+  const int max_splits = (p.MB + WG_MB_STAGE - 1) / WG_MB_STAGE;
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  int per = (p.MB + want - 1) / want;
+  per = (per + WG_MB_STAGE - 1) / WG_MB_STAGE * WG_MB_STAGE;
+  p.mb_per_split = per;
+  p.splits = (p.MB + per - 1) / per;
+  return p;
+}
+
+size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
+  if (!d || batch <= 0) return 0;
+  size_t total = 0;
+  for (int l = 0; l < d->n_layers; ++l) {
+    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, 128);
+    total += (size_t)p.splits * p.slab;
+  }
+  return total * sizeof(float);
+}
+
+/* dw[l] = dz_frag[l]^T act_frag[l] for every layer, one wgrad launch + one reduce launch */
+int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t workspace_bytes,
+                       rg_stream_t stream) {
+  if (!d || batch <= 0 || d->n_layers < 1 || d->n_layers > FB_MAXL) return RG_EINVAL;
+  if (!workspace || workspace_bytes < rg_mlp_wgrad_fused_workspace_bytes(d, batch)) return RG_EWORKSPACE;
+  WgradGroupArgs G;
+  ReduceGroupArgs R;
+  G.n = R.n = d->n_layers;
+  float* part = (float*)workspace;
+  int wg = 0;
+  long el = 0;
+  for (int l = 0; l < FB_MAXL; ++l) {
+    G.wg_begin[l] = wg;
+    R.elem_begin[l] = el;
+    if (l < d->n_layers) {
+      if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
+      const int out_f = d->dims[l + 1], in_f = d->dims[l];
+      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, 128);
+      WgradFragArgs& g = G.layer[l];
+      g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
+      g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
+      g.partial = part; g.slab = p.slab; g.N = out_f; g.K = in_f;
+      R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
+      part += (size_t)p.splits * p.slab;
+      wg += ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
+      el += p.slab;
+    } else {
+      G.layer[l] = G.layer[0];
+      R.partial[l] = nullptr; R.slab[l] = 0; R.splits[l] = 0; R.out[l] = nullptr;
+    }
+  }
+  G.wg_begin[FB_MAXL] = wg;
+  R.elem_begin[FB_MAXL] = el;
+  for (int l = d->n_layers; l <= FB_MAXL; ++l) { G.wg_begin[l] = wg; R.elem_begin[l] = el; }
+  const size_t lds = 2 * (size_t)WG_STAGE_BYTES;
+  RG_ALLOW_LDS(wgrad_group_kernel, lds);
+  RG_LAUNCH_DYN(wgrad_group_kernel, dim3(wg), dim3(FB_THREADS), lds, (hipStream_t)stream, G);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  RG_LAUNCH(reduce_group_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), (hipStream_t)stream, R);
   return (int)hipGetLastError();
 }
 

@@ -286,21 +286,25 @@ class FusedMLP:
             return
         dev = self.weights[0].device
         lib = L.lib()
+        d = self._desc
+        d.n_layers = self.L
+        for i, v in enumerate(self.dims):
+            d.dims[i] = v
+        need_bwd = bool(need_transposed)
         for i, w in enumerate(self.weights):
             out_f, in_f = w.shape
             if self._wf[i] is None or self._wf[i].device != dev:
                 self._wf[i] = torch.empty(lib.rg_wfrag_elems(out_f, in_f), dtype=torch.bfloat16, device=dev)
-            wb = None
-            if need_transposed and (i > 0 or self._need_dx):
-                if self._wb[i] is None or self._wb[i].device != dev:
-                    self._wb[i] = torch.empty(lib.rg_wfrag_elems(in_f, out_f), dtype=torch.bfloat16, device=dev)
-                wb = self._wb[i]
+            if need_bwd and (self._wb[i] is None or self._wb[i].device != dev):
+                self._wb[i] = torch.empty(lib.rg_wfrag_elems(in_f, out_f), dtype=torch.bfloat16, device=dev)
             wd = w.detach()
             assert wd.is_contiguous()
             L.require_cuda(wd)
-            ops._run("rg_stage_weights_frag", dict(N=out_f, K=in_f),
-                     lambda: lib.rg_stage_weights_frag(wd.data_ptr(), out_f, in_f, self._wf[i].data_ptr(),
-                                                       wb.data_ptr() if wb is not None else None, L.stream_ptr()))
+            d.w[i] = wd.data_ptr()
+            d.wfrag_fwd[i] = self._wf[i].data_ptr()
+            d.wfrag_bwd[i] = self._wb[i].data_ptr() if self._wb[i] is not None else None
+        ops._run("rg_mlp_stage_weights_fused", dict(L=self.L),
+                 lambda: lib.rg_mlp_stage_weights_fused(d, int(need_bwd), L.stream_ptr()))
         self._staged_versions = versions
         self._wsrc_ptrs = [w.data_ptr() for w in self.weights]
 
@@ -314,8 +318,11 @@ class FusedMLP:
             bf = dict(dtype=torch.bfloat16, device=device)
             ws["act_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l]), **bf) for l in range(self.L)]
             ws["dz_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l + 1]), **bf) for l in range(self.L)]
-            nbytes = max(lib.rg_fc_wgrad_frag_workspace_bytes(self.dims[l + 1], self.dims[l], batch)
-                         for l in range(self.L))
+            dd = L.MlpDesc()
+            dd.n_layers = self.L
+            for i, v in enumerate(self.dims):
+                dd.dims[i] = v
+            nbytes = lib.rg_mlp_wgrad_fused_workspace_bytes(dd, batch)
             ws["wgrad"] = torch.empty(_round_up(nbytes, 16) // 4, dtype=torch.float32, device=device)
             self._ws = ws
             nb = lib.rg_mlp_backward_fused_workspace_bytes(self._fill_desc(), batch)
@@ -369,13 +376,12 @@ class FusedMLP:
                                                    dx32.data_ptr() if dx32 is not None else None,
                                                    dx32.stride(0) if dx32 is not None else 0,
                                                    ws["bwd"].data_ptr(), ws["bwd"].numel() * 4, L.stream_ptr()))
-        wsb = ws["wgrad"].numel() * 4
-        for l in range(self.L if not skip_wgrad else 0):
-            out_f, in_f = self.dims[l + 1], self.dims[l]
-            ops._run("rg_fc_wgrad_frag", dict(M=out_f, N=in_f, K=B),
-                     lambda l=l, out_f=out_f, in_f=in_f: lib.rg_fc_wgrad_frag(
-                         ws["dz_frag"][l].data_ptr(), ws["act_frag"][l].data_ptr(), out_f, in_f, B,
-                         dw[l].data_ptr(), ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
+        if not skip_wgrad:
+            for l in range(self.L):
+                d.dw[l] = dw[l].data_ptr()
+            wsb = ws["wgrad"].numel() * 4
+            ops._run("rg_mlp_wgrad_fused", dict(B=B, dims=tuple(self.dims)),
+                     lambda: lib.rg_mlp_wgrad_fused(d, B, ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
 
 
 def make_stack(weights, biases, acts: List[int], precision: int):
