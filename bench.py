@@ -90,7 +90,8 @@ def build(args, device, rank):
     norm = {i: NormalizationParameters(feature_type="CONTINUOUS", mean=mean[i].item(), stddev=std[i].item())
             for i in range(S)}
     pre = Preprocessor(norm, device=device)
-    loop = OfflineDqnLoop(rb, trainer, args.batch, pre)
+    loop = OfflineDqnLoop(rb, trainer, args.batch, pre,
+                          state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32)
     return loop, trainer, init, cols, (mean, std)
 
 

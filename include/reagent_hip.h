@@ -158,6 +158,14 @@ typedef struct {
   const int64_t* indices; /* [batch] */
   int32_t row_elems;
   int32_t elem_bytes;
+  /* optional normalize-on-gather epilogue (fp32 source columns, stack == 1): `norm` points to
+   * row_elems rg_norm_col descriptors on the device (one per element, 1:1 ops — no ENUM), applied
+   * with presence = 1 while the row streams through (Preprocessor.forward fused into the gather);
+   * out_dtype RG_DT_F32 or RG_DT_BF16 selects the element type of dst. */
+  const void* norm;
+  const float* norm_quantiles;
+  int32_t out_dtype;
+  int32_t reserved;
 } rg_gather_col;
 int rg_replay_gather(const rg_gather_col* cols /*host*/, int ncols, int64_t capacity, int stack,
                      int batch, rg_stream_t stream);

@@ -36,6 +36,10 @@ class GatherCol(ctypes.Structure):
         ("indices", c_void_p),
         ("row_elems", ctypes.c_int32),
         ("elem_bytes", ctypes.c_int32),
+        ("norm", c_void_p),
+        ("norm_quantiles", c_void_p),
+        ("out_dtype", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 

@@ -3,8 +3,7 @@
 // reagent/replay_memory/circular_replay_buffer.py:614-706 (+ :741-774).  Bit-exact by
 // construction: rows are copied, never recomputed; the n-step reward uses the reference's
 // operation order (r * gamma^k * mask, summed k = 0..h-1).
-#include <rg_platform.h>
-#include "../../include/reagent_hip.h"
+#include "rg_norm.h"
 
 namespace rg {
 
@@ -61,7 +60,46 @@ __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch)
   char* dst = (char*)col.dst;
   const bool vec16 = (row_bytes % 16 == 0) && ((((uintptr_t)src) & 15) == 0) &&
                      ((((uintptr_t)dst) & 15) == 0);
-  if (vec16) {
+  if (col.norm) {
+    // normalize-on-gather: 4 fp32 features per lane, op-code table applied in registers, optional
+    // bf16 output (the network-ready layout: the normalized fp32 matrix never exists in HBM)
+    const rg_norm_col* nc = (const rg_norm_col*)col.norm;
+    const int epr = col.row_elems;
+    const int cpr = (epr + 3) / 4;
+    const int total = nrows * cpr;
+    const bool v4 = ((epr & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
+    for (int it = threadIdx.x; it < total; it += blockDim.x) {
+      const int r = it / cpr, ch = it % cpr;
+      const int64_t idx = col.indices[row0 + r];
+      const float* sp = (const float*)src + idx * epr + ch * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (v4) {
+        const f32x4 t = *(const f32x4*)sp;
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (ch * 4 + e < epr) v[e] = sp[e];
+      }
+      for (int e = 0; e < 4; ++e)
+        if (ch * 4 + e < epr) v[e] = normalize_value(nc[ch * 4 + e], v[e], 1.f, col.norm_quantiles);
+      if (col.out_dtype == RG_DT_BF16) {
+        bf16_t* dp = (bf16_t*)dst + (long)(row0 + r) * epr + ch * 4;
+        if (v4) {
+          uint2 o;
+          o.x = pack_bf16x2(v[0], v[1]);
+          o.y = pack_bf16x2(v[2], v[3]);
+          *(uint2*)dp = o;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (ch * 4 + e < epr) dp[e] = f32_to_bf16(v[e]);
+        }
+      } else {
+        float* dp = (float*)dst + (long)(row0 + r) * epr + ch * 4;
+        for (int e = 0; e < 4; ++e)
+          if (ch * 4 + e < epr) dp[e] = v[e];
+      }
+    }
+  } else if (vec16) {
     const int cpr = (int)(row_bytes / 16);
     const int total = nrows * cpr;
     for (int it = threadIdx.x; it < total; it += blockDim.x) {
@@ -169,6 +207,8 @@ int rg_replay_gather(const rg_gather_col* cols, int ncols, int64_t capacity, int
     const int eb = cols[i].elem_bytes;
     if (!cols[i].src || !cols[i].dst || !cols[i].indices || cols[i].row_elems <= 0) return RG_EINVAL;
     if (eb != 1 && eb != 2 && eb != 4 && eb != 8) return RG_EINVAL;
+    if (cols[i].norm && (eb != 4 || stack != 1)) return RG_EUNSUPPORTED;
+    if (cols[i].norm && cols[i].out_dtype != RG_DT_F32 && cols[i].out_dtype != RG_DT_BF16) return RG_EINVAL;
   }
   for (int i = ncols; i < RG_MAX_GATHER_COLS; ++i) t.c[i] = cols[0];
   if (stack == 1) {

@@ -176,7 +176,7 @@ class FCStack:
         B, in_f = x32.shape
         dev = x32.device
         xt = _mat(in_f, B, self.cdtype, dev) if need_transposed else None
-        if self.precision == L.PREC_F32 and x32.stride(1) == 1:
+        if self.precision == L.PREC_F32 and x32.stride(1) == 1 and x32.dtype == torch.float32:
             xc = x32
             if xt is not None:
                 ops.transpose_cast(x32, None, xt)

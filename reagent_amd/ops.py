@@ -147,12 +147,15 @@ def replay_nstep(indices, terminal_u8, reward, decays, capacity, horizon, steps,
 
 
 def replay_gather(cols, capacity: int, stack: int, batch: int):
-    """cols: list of (src [C, ...], dst, indices[int64 B]) tensors; one launch per <=16 columns."""
+    """cols: list of (src [C, ...], dst, indices[int64 B][, norm]) tensors; one launch per <=16 columns.
+    norm = (col_table_dev, quantiles_dev): normalize-on-gather epilogue (dst dtype fp32 or bf16)."""
     for i in range(0, len(cols), L.MAX_GATHER_COLS):
         chunk = cols[i : i + L.MAX_GATHER_COLS]
         arr = (L.GatherCol * len(chunk))()
         nbytes = 0
-        for j, (src, dst, idx) in enumerate(chunk):
+        for j, item in enumerate(chunk):
+            src, dst, idx = item[:3]
+            norm = item[3] if len(item) > 3 else None
             _chk_dev(src, dst, idx)
             assert src.is_contiguous() and dst.is_contiguous() and idx.dtype == torch.int64
             row_elems = 1
@@ -163,7 +166,12 @@ def replay_gather(cols, capacity: int, stack: int, batch: int):
             arr[j].indices = idx.data_ptr()
             arr[j].row_elems = row_elems
             arr[j].elem_bytes = src.element_size()
-            nbytes += 2 * row_elems * src.element_size() * stack + 8
+            if norm is not None:
+                assert src.dtype == F32 and stack == 1
+                arr[j].norm = norm[0].data_ptr()
+                arr[j].norm_quantiles = norm[1].data_ptr()
+                arr[j].out_dtype = dt_code(dst.dtype)
+            nbytes += row_elems * (src.element_size() + dst.element_size()) * stack + 8
         _run("rg_replay_gather", dict(B=batch, bytes_per_row=nbytes),
              lambda: L.lib().rg_replay_gather(arr, len(chunk), capacity, stack, batch, L.stream_ptr()))
 

@@ -59,6 +59,8 @@ class Preprocessor(Module):
             else:
                 raise ValueError(f"unknown feature type {t}")
         self.num_output_features = len(cols)
+        # 1:1 table (no ENUM expansion): usable as the normalize-on-gather epilogue of the replay buffer
+        self.elementwise = len(cols) == len(self.sorted_features) and all(c[1] == i for i, c in enumerate(cols))
         table = (L.NormCol * len(cols))()
         for i, c in enumerate(cols):
             table[i].op, table[i].in_col = c[0], c[1]

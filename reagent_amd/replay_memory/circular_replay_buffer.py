@@ -248,8 +248,14 @@ class ReplayBuffer:
         valid_indices = self._valid_indices()
         return self.sample_transition_batch(batch_size=len(valid_indices), indices=valid_indices)
 
-    def sample_transition_batch(self, batch_size=None, indices=None):
-        """circular_replay_buffer.py:614-706."""
+    def sample_transition_batch(self, batch_size=None, indices=None, state_preprocessor=None,
+                                state_dtype=None):
+        """circular_replay_buffer.py:614-706.
+
+        state_preprocessor (optional, extension): a reagent_amd Preprocessor whose table is 1:1
+        (no ENUM expansion) — `state` / `next_state` are then returned already normalized
+        (Preprocessor.forward with all features present fused into the gather), in `state_dtype`
+        (torch.float32 default, or torch.bfloat16 = the network-ready layout of the bf16 path)."""
         if batch_size is None:
             batch_size = self._batch_size
         if indices is None:
@@ -275,10 +281,17 @@ class ReplayBuffer:
         ops.replay_nstep(indices, self._store["terminal"], reward_col, self._decays_dev,
                          self._replay_capacity, self._update_horizon, steps, next_indices, terminal, reward)
 
-        def out_for(key):
+        norm = None
+        if state_preprocessor is not None:
+            assert S == 1 and state_preprocessor.elementwise, "normalize-on-gather needs a 1:1 column table"
+            assert self._store["observation"].dtype == torch.float32
+            norm = (state_preprocessor._col_table, state_preprocessor._quantiles)
+
+        def out_for(key, normalized=False):
             shape = self._shapes[key]
             full = (B, *shape, S) if S > 1 else (B, *shape)
-            return torch.empty(full, dtype=self._store[key].dtype, device=dev)
+            dt = (state_dtype or torch.float32) if normalized else self._store[key].dtype
+            return torch.empty(full, dtype=dt, device=dev)
 
         results, cols = {}, []
         for name in self._transition_elements:
@@ -296,8 +309,9 @@ class ReplayBuffer:
             else:
                 results[name] = None
                 continue
-            dst = out_for(key)
-            cols.append((self._store[key], dst, idx))
+            is_state = norm is not None and name in ("state", "next_state")
+            dst = out_for(key, normalized=is_state)
+            cols.append((self._store[key], dst, idx, norm) if is_state else (self._store[key], dst, idx))
             results[name] = dst
         ops.replay_gather(cols, self._replay_capacity, S, B)
         results.update(indices=indices, terminal=terminal, reward=reward, step=steps)

@@ -20,15 +20,22 @@ from .replay_memory import ReplayBuffer
 
 class OfflineDqnLoop:
     def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int,
-                 state_preprocessor: Optional[Preprocessor] = None):
+                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None):
         self.rb = replay_buffer
         self.trainer = trainer
         self.batch_size = batch_size
         self.pre = state_preprocessor
         self.maker = DiscreteDqnInputMaker(trainer.num_actions)
         self._presence = None
+        self.state_dtype = state_dtype
+        # 1:1 normalization tables ride along with the gather (no separate normalize pass)
+        self.fuse_norm = state_preprocessor is not None and state_preprocessor.elementwise
 
     def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.DiscreteDqnInput:
+        if self.fuse_norm:
+            tup = self.rb.sample_transition_batch(self.batch_size, indices=indices, state_preprocessor=self.pre,
+                                                  state_dtype=self.state_dtype)
+            return self.maker(tup)
         tup = self.rb.sample_transition_batch(self.batch_size, indices=indices)
         inp = self.maker(tup)
         if self.pre is not None:

@@ -98,9 +98,15 @@ class QStepCore(DQNTrainerBaseLightning):
     def _needs_online_next(self) -> bool:
         return True
 
+    @staticmethod
+    def _net_in(t: torch.Tensor) -> torch.Tensor:
+        """network input: fp32, or bf16 (the normalize-on-gather output of the bf16 path)"""
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.float()
+        return t if t.stride(-1) == 1 and t.is_contiguous() else t.contiguous()
+
     def _hip_forward(self, b) -> torch.Tensor:
-        state = self._f32c(b.state.float_features)
-        next_state = self._f32c(b.next_state.float_features)
+        state, next_state = self._net_in(b.state.float_features), self._net_in(b.next_state.float_features)
         L.require_cuda(state, "training_batch.state")
         B, dev = state.shape[0], state.device
         self._engine(B, dev)

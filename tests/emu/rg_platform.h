@@ -21,6 +21,9 @@ struct dim3 {
 struct __attribute__((aligned(16))) uint4 {
   unsigned x, y, z, w;
 };
+struct __attribute__((aligned(8))) uint2 {
+  unsigned x, y;
+};
 typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0

@@ -141,3 +141,45 @@ def test_empty_and_unsupported(backend):
         rb.sample_index_batch(2)
     with pytest.raises(NotImplementedError):
         ReplayBuffer(replay_capacity=10, return_as_timeline_format=True, device=backend.device)
+
+
+def test_normalize_on_gather_equals_gather_then_preprocessor(backend):
+    """Preprocessor.forward fused into the gather: bit-identical to gather -> Preprocessor (fp32),
+    and to that result rounded to bf16 (the bf16 path's network-ready layout)."""
+    from reagent_amd import synthetic
+    from reagent_amd.core.parameters import NormalizationParameters as NP
+    from reagent_amd.preprocessing import Preprocessor
+
+    C, S, A, B = 2048, 24, 4, 333
+    cols = synthetic.replay_contents(C, S, A, seed=8)
+    rb = ReplayBuffer(replay_capacity=C, batch_size=B, device=backend.device)
+    rb.load_columns({k: v.to(backend.device) for k, v in cols.items()}, mark_all_valid=True)
+    g = torch.Generator().manual_seed(1)
+    norm = {}
+    for i in range(S):
+        if i % 3 == 0:
+            norm[i] = NP(feature_type="CONTINUOUS", mean=torch.randn(1, generator=g).item(), stddev=1.3)
+        elif i % 3 == 1:
+            norm[i] = NP(feature_type="QUANTILE", quantiles=[-1.0, 0.0, 0.5, 2.0])
+        else:
+            norm[i] = NP(feature_type="BINARY")
+    pre = Preprocessor(norm, device=backend.device)
+    assert pre.elementwise
+    idx = rb.sample_index_batch(B)
+    plain = rb.sample_transition_batch(B, indices=idx)
+    ones = torch.ones(B, S, dtype=torch.uint8, device=backend.device)
+    # Preprocessor columns are in sorted_features order == replay column order here? build the permutation
+    perm = torch.tensor(pre.sorted_features, device=backend.device)
+    want_s, want_n = pre(plain.state[:, perm], ones), pre(plain.next_state[:, perm], ones)
+    # normalize-on-gather applies descriptor j to column j: give it a table built for identity order
+    pre_id = Preprocessor({k: norm[f] for k, f in enumerate(pre.sorted_features)}, device=backend.device)
+    rb2 = ReplayBuffer(replay_capacity=C, batch_size=B, device=backend.device)
+    cols2 = dict(cols)
+    cols2["observation"] = cols["observation"][:, perm.cpu()]
+    rb2.load_columns({k: v.to(backend.device) for k, v in cols2.items()}, mark_all_valid=True)
+    fused = rb2.sample_transition_batch(B, indices=idx, state_preprocessor=pre_id)
+    assert torch.equal(fused.state, want_s) and torch.equal(fused.next_state, want_n)
+    assert torch.equal(fused.reward, plain.reward) and torch.equal(fused.action, plain.action)
+    fused16 = rb2.sample_transition_batch(B, indices=idx, state_preprocessor=pre_id, state_dtype=torch.bfloat16)
+    assert fused16.state.dtype == torch.bfloat16
+    assert torch.equal(fused16.state.cpu(), want_s.cpu().to(torch.bfloat16))
