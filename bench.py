@@ -215,6 +215,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = loop.step()
+    host_dt = time.perf_counter() - t0  # time the host needed to ENQUEUE the steps (diagnostic)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -242,6 +243,7 @@ def main():
             "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"Discrete DQN state_dim={args.state_dim} |A|={args.actions} "

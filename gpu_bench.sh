@@ -6,7 +6,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench
 python - <<PY
 import json
 r=json.load(open("$OUT/bench_$TAG.json"))
-print("value %.3e  ms/step %.3f  fc_frac %.4f  dom %s" % (r["value"], r["ms_per_step"], r.get("fc_roofline",{}).get("frac",0), r.get("roofline",{}).get("kernel")))
+print("value %.3e  ms/step %.3f host_enqueue %.3f fc_frac %.4f  dom %s" % (r["value"], r["ms_per_step"], r.get("host_enqueue_ms_per_step",0), r.get("fc_roofline",{}).get("frac",0), r.get("roofline",{}).get("kernel")))
 for k,v in r["per_call_ms_per_step"].items(): print("  %-70s %.4f" % (k,v))
 PY
 tail -3 $OUT/bench_$TAG.err

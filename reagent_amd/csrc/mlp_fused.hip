@@ -20,6 +20,7 @@
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
 #include "rg_gemm.h"
 #include "../../include/reagent_hip.h"
+#include <stdlib.h>
 
 namespace rg {
 
@@ -159,20 +160,24 @@ __device__ __forceinline__ void store_tile_frags(bf16_t* dst, int mb, int nt, in
 // Software pipeline: the weight (B) fragments come from L2 (~0.5-1 us under load) and are
 // prefetched three chunks ahead through a ring of four register sets; the activation (A)
 // fragments come from LDS and are prefetched one chunk ahead.
-template <int TN>
+template <int TN, int PROBE = 0>
 __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_lane,
                                               long nt_stride, f32x16 (&acc)[4][TN], int lr, int lg, int rot) {
+  // measured on MI355X (C2 forward): 103.5 us with the rotation, 107 us without — all CUs streaming
+  // the same fragments in the same order do hot-spot the L2 channels
   auto kx = [&](int kc) { const int k = kc + rot; return k >= KC ? k - KC : k; };
   const bf16_t* arow = act + lr * pitch + lg * 8;
   const int tm_stride = 32 * pitch;
   u16x8 a0[4], a1[4], b0[TN], b1[TN], b2[TN], b3[TN];
   auto loadB = [&](u16x8 (&bf)[TN], int kc) {
-    const long off = (long)kx(kc) * 512;
+    if ((PROBE & 4) && kc > 2) return;                       // PROBE: timing experiments only
+    const long off = (PROBE & 1) ? 0 : (long)kx(kc) * 512;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + off);
   };
   auto loadA = [&](u16x8 (&af)[4], int kc) {
-    const int off = kx(kc) * 16;
+    if ((PROBE & 4) && kc > 1) return;
+    const int off = (PROBE & 2) ? 0 : kx(kc) * 16;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow + tm * tm_stride + off);
   };
@@ -353,7 +358,7 @@ __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x
   }
 }
 
-template <int TN>
+template <int TN, int PROBE = 0>
 __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
@@ -381,7 +386,7 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
       const long nt_stride = (long)KC * 512;
-      wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
+      wide_mainloop<TN, PROBE>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
                         (int)((blockIdx.x * 5 + wave * 11) % KC));
       __syncthreads();  // every wave is done reading the layer input
       RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.bias[l],
@@ -491,9 +496,22 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
   const int lr = lane & 31, lg = lane >> 5;
   const int wn = wave >> 2, wk = wave & 3;
   const int n_groups = (g.NTa + 7) / 8, k_groups = (g.NTb + 7) / 8;
-  const int kg = bid % k_groups;
-  const int ng = (bid / k_groups) % n_groups;
-  const int split = bid / (k_groups * n_groups);
+  // workgroups that read the same 32-row blocks (the tiles of one split) go to ONE XCD (hardware
+  // places block b on XCD b % 8), so the second reader of a fragment hits that XCD's L2 instead of
+  // HBM (PMC: 700 MB fetched per launch against 420 MB of unique operands without this)
+  const int tiles = k_groups * n_groups;
+  int tile, split;
+  if ((g.splits & 7) == 0) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    split = (slot / tiles) * 8 + xcd;
+    tile = slot % tiles;
+  } else {
+    tile = bid % tiles;
+    split = bid / tiles;
+  }
+  if (split >= g.splits) return;  // padding workgroups of a grouped launch (uniform for the workgroup)
+  const int kg = tile % k_groups;
+  const int ng = tile / k_groups;
   const int mb_begin = split * g.mb_per_split;
   const int mb_end = (mb_begin + g.mb_per_split < g.MB) ? mb_begin + g.mb_per_split : g.MB;
   const int ta0 = ng * 8, tb0 = kg * 8;
@@ -823,8 +841,24 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
     RG_ALLOW_LDS(mlp_fwd_fused_kernel<1>, lds);
     RG_LAUNCH_DYN(mlp_fwd_fused_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
   } else {
-    RG_ALLOW_LDS(mlp_fwd_fused_kernel<2>, lds);
-    RG_LAUNCH_DYN(mlp_fwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+    const char* pe = getenv("RG_FUSED_PROBE");  // perf-investigation variants (wrong results)
+    const int probe = pe ? atoi(pe) : 0;
+    if (probe == 1) {
+      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 1>), lds);
+      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 1>), grid, block, lds, (hipStream_t)stream, a);
+    } else if (probe == 2) {
+      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 2>), lds);
+      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 2>), grid, block, lds, (hipStream_t)stream, a);
+    } else if (probe == 3) {
+      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 3>), lds);
+      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 3>), grid, block, lds, (hipStream_t)stream, a);
+    } else if (probe == 4) {
+      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 4>), lds);
+      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 4>), grid, block, lds, (hipStream_t)stream, a);
+    } else {
+      RG_ALLOW_LDS(mlp_fwd_fused_kernel<2>, lds);
+      RG_LAUNCH_DYN(mlp_fwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+    }
   }
   return (int)hipGetLastError();
 }
@@ -962,10 +996,12 @@ static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target
   const int max_splits = (p.MB + WG_MB_STAGE - 1) / WG_MB_STAGE;
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
+  if (want >= 8) want = want / 8 * 8;
   int per = (p.MB + want - 1) / want;
   per = (per + WG_MB_STAGE - 1) / WG_MB_STAGE * WG_MB_STAGE;
   p.mb_per_split = per;
   p.splits = (p.MB + per - 1) / per;
+  if (p.splits >= 8) p.splits = (p.splits + 7) / 8 * 8;  // empty tail splits write zeros
   return p;
 }
 
@@ -1004,6 +1040,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
       R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
       part += (size_t)p.splits * p.slab;
       wg += ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
+      wg = (wg + 7) / 8 * 8;  // keep (block id % 8) == (layer-local id % 8) == XCD
       el += p.slab;
     } else {
       G.layer[l] = G.layer[0];
