@@ -96,6 +96,10 @@ typedef struct {
   const float* bias[RG_MLP_MAX_LAYERS];
   void* act_frag[RG_MLP_MAX_LAYERS];          /* [l] = saved INPUT of layer l, C-fragment order */
   void* dz_frag[RG_MLP_MAX_LAYERS];           /* [l] = d loss / d pre-activation output of layer l */
+  void* act_sign[RG_MLP_MAX_LAYERS];          /* optional, [l] (l >= 1) = one bit per element of act_frag[l]
+                                               * (value > 0), rg_sign_bytes(batch, dims[l]) bytes, written by a
+                                               * saving forward; when layer l-1 is ReLU / leaky ReLU the backward
+                                               * reads these 16 B per lane instead of act_frag[l] */
   float* db[RG_MLP_MAX_LAYERS];               /* backward output: bias gradients [dims[l+1]] (nullable) */
   const float* w[RG_MLP_MAX_LAYERS];          /* fp32 master weights [dims[l+1], dims[l]] (stage_weights_fused) */
   float* dw[RG_MLP_MAX_LAYERS];               /* weight gradients, same shape (wgrad_fused) */
@@ -103,6 +107,7 @@ typedef struct {
 
 int rg_mlp_fused_supported(const rg_mlp_desc* d);
 size_t rg_frag_elems(int rows, int cols);                  /* bf16 elements of a C-fragment matrix */
+size_t rg_sign_bytes(int rows, int cols);                  /* bytes of an act_sign plane */
 size_t rg_wfrag_elems(int out_features, int in_features);  /* bf16 elements of a B-fragment weight */
 /* w [out, in] fp32 (nn.Linear layout) -> wfrag_fwd (rg_wfrag_elems(out,in)) and/or
  * wfrag_bwd = fragments of w^T (rg_wfrag_elems(in,out)); zero padded. */

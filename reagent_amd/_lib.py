@@ -67,6 +67,7 @@ class MlpDesc(ctypes.Structure):
         ("bias", c_void_p * MLP_MAX_LAYERS),
         ("act_frag", c_void_p * MLP_MAX_LAYERS),
         ("dz_frag", c_void_p * MLP_MAX_LAYERS),
+        ("act_sign", c_void_p * MLP_MAX_LAYERS),
         ("db", c_void_p * MLP_MAX_LAYERS),
         ("w", c_void_p * MLP_MAX_LAYERS),
         ("dw", c_void_p * MLP_MAX_LAYERS),
@@ -88,6 +89,7 @@ SIGNATURES = {
                                    c_i64, c_int, c_void_p]),
     "rg_mlp_fused_supported": (c_int, [ctypes.POINTER(MlpDesc)]),
     "rg_frag_elems": (c_sz, [c_int, c_int]),
+    "rg_sign_bytes": (c_sz, [c_int, c_int]),
     "rg_wfrag_elems": (c_sz, [c_int, c_int]),
     "rg_stage_weights_frag": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_mlp_forward_fused": (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_int, c_i64, c_int, c_void_p, c_i64,

@@ -20,7 +20,6 @@
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
 #include "rg_gemm.h"
 #include "../../include/reagent_hip.h"
-#include <stdlib.h>
 
 namespace rg {
 
@@ -36,6 +35,7 @@ struct MlpArgs {
   const float* bias[FB_MAXL];
   bf16_t* act_frag[FB_MAXL + 1];  // [l] = input of layer l in C-fragment order ([0] = network input)
   bf16_t* dz_frag[FB_MAXL];       // [l] = d loss / d (pre-activation output of layer l)
+  unsigned* act_sign[FB_MAXL];    // [l] = (act_frag[l] > 0) bits, one per element, private order (nullable)
   float* db_part[FB_MAXL];        // backward: [n_workgroups][dims[l+1]] bias-gradient partials (nullable)
   const void* x;                  // forward input [batch, dims[0]] row-major, bf16 or fp32
   long ldx;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void store_tile_to_lds(bf16_t* act, int pitch, int ro
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const float mine_a = v[rq * 4 + 2 * q], mine_b = v[rq * 4 + 2 * q + 1];
-      const float recv = shfl_xor(odd ? mine_a : mine_b, 1);
+      const float recv = swap_adjacent_lanes(odd ? mine_a : mine_b);
       const unsigned word = odd ? pack_bf16x2(recv, mine_b) : pack_bf16x2(mine_a, recv);
       const int row = row0 + 2 * q + odd;
       *(unsigned*)&act[row * pitch + (col & ~1)] = word;
@@ -153,6 +153,20 @@ __device__ __forceinline__ void store_tile_frags(bf16_t* dst, int mb, int nt, in
   }
 }
 
+// bit r = (v[r] > 0).  NONNEG (ReLU outputs: v is +0 or a positive float, never -0/NaN): the sign
+// bit of (0 - bits(v)) is the answer, shifted in by a funnel shift (v_sub + v_alignbit, 2 VALU per
+// element against 3 for compare/select/or).
+template <bool NONNEG>
+__device__ __forceinline__ unsigned positive_bits(const float (&v)[16]) {
+  unsigned bits = 0u;
+#pragma unroll
+  for (int r = 15; r >= 0; --r) {
+    if (NONNEG) bits = (bits << 1) | ((0u - __builtin_bit_cast(unsigned, v[r])) >> 31);
+    else bits = (bits << 1) | (v[r] > 0.f ? 1u : 0u);
+  }
+  return bits;
+}
+
 // ---- main loop of a wide layer: this wave's [128 x 32*TN] slice over K ------------------------
 // `rot` rotates the order in which the K chunks are visited (a sum may be taken in any order):
 // every workgroup streams the SAME weight fragments, and without de-phasing all 256 CUs would
@@ -160,7 +174,7 @@ __device__ __forceinline__ void store_tile_frags(bf16_t* dst, int mb, int nt, in
 // Software pipeline: the weight (B) fragments come from L2 (~0.5-1 us under load) and are
 // prefetched three chunks ahead through a ring of four register sets; the activation (A)
 // fragments come from LDS and are prefetched one chunk ahead.
-template <int TN, int PROBE = 0>
+template <int TN>
 __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_lane,
                                               long nt_stride, f32x16 (&acc)[4][TN], int lr, int lg, int rot) {
   // measured on MI355X (C2 forward): 103.5 us with the rotation, 107 us without — all CUs streaming
@@ -170,14 +184,12 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
   const int tm_stride = 32 * pitch;
   u16x8 a0[4], a1[4], b0[TN], b1[TN], b2[TN], b3[TN];
   auto loadB = [&](u16x8 (&bf)[TN], int kc) {
-    if ((PROBE & 4) && kc > 2) return;                       // PROBE: timing experiments only
-    const long off = (PROBE & 1) ? 0 : (long)kx(kc) * 512;
+    const long off = (long)kx(kc) * 512;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + off);
   };
   auto loadA = [&](u16x8 (&af)[4], int kc) {
-    if ((PROBE & 4) && kc > 1) return;
-    const int off = (PROBE & 2) ? 0 : kx(kc) * 16;
+    const int off = kx(kc) * 16;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow + tm * tm_stride + off);
   };
@@ -307,31 +319,52 @@ __device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int K
   return acc;
 }
 
+// Sign bits of a wave's [128 x 32*TN] slice: 2*TN dwords per lane, dword = tn*2 + tm/2,
+// bit = (tm&1)*16 + r for accumulator element r of tile (tm, tn).  For ReLU-family activations the
+// derivative depends on nothing else, so backward prefetches these 16 bytes per lane ahead of its
+// main loop instead of waiting on 8 KB of saved activations per wave in the epilogue.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ long sign_offset(int wg, int wave, int lane, int TN) {
+  return (((long)wg * (FB_THREADS / 64) + wave) * 64 + lane) * (2 * TN);
+}
+template <int ACT> constexpr bool act_is_sign_based() { return ACT == ACT_RELU || ACT == ACT_LEAKY_RELU; }
+
 template <int TN, int ACT>
 __device__ __forceinline__ void fwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const float* bias,
-                                                    bf16_t* save_dst, int NT, int mb_base, int wave, int lane) {
+                                                    bf16_t* save_dst, unsigned* sign_dst, int NT, int mb_base,
+                                                    int wave, int lane) {
   lane = opaque(lane);
   const int lr = lane & 31;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int nt = wave * TN + tn, col = nt * 32 + lr;
     const float b = bias ? bias[col] : 0.f;
+    unsigned sg0 = 0u, sg1 = 0u;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
-      if (save_dst) store_tile_frags(save_dst, mb_base + tm, nt, NT, lane, v);
+      if (save_dst) {
+        store_tile_frags(save_dst, mb_base + tm, nt, NT, lane, v);
+        if (act_is_sign_based<ACT>()) {
+          const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
+          if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
+          else sg1 |= bits << ((tm & 1) * 16);
+        }
+      }
       store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
     }
+    if (act_is_sign_based<ACT>() && sign_dst)
+      ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN)))[tn] = u32x2{sg0, sg1};
   }
 }
 
 // dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
-template <int TN, int ACT>
+template <int TN, int ACT, bool USE_SIGN>
 __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const bf16_t* h_frag,
-                                                    bf16_t* dz_dst, float* db_part, int NT, int mb_base, int wave,
-                                                    int lane) {
+                                                    const unsigned (&sg)[2 * TN], bf16_t* dz_dst, float* db_part,
+                                                    int NT, int mb_base, int wave, int lane) {
   lane = opaque(lane);
   const int lr = lane & 31;
 #pragma unroll
@@ -341,13 +374,23 @@ __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
       float v[16];
+      if (USE_SIGN && act_is_sign_based<ACT>()) {
+        const unsigned bits = sg[tn * 2 + (tm >> 1)] >> ((tm & 1) * 16);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const u16x8 hf = *(const u16x8*)(h_frag + frag_offset(mb_base + tm, nt, NT, h, lane));
+        for (int r = 0; r < 16; ++r) {
+          const float g = ((bits >> r) & 1u) ? 1.f : (ACT == ACT_RELU ? 0.f : 0.01f);
+          v[r] = acc[tm][tn][r] * g;
+          colsum += v[r];
+        }
+      } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_t<ACT>(bf16_to_f32(hf[e]));
-          colsum += v[8 * h + e];
+        for (int h = 0; h < 2; ++h) {
+          const u16x8 hf = *(const u16x8*)(h_frag + frag_offset(mb_base + tm, nt, NT, h, lane));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_t<ACT>(bf16_to_f32(hf[e]));
+            colsum += v[8 * h + e];
+          }
         }
       }
       store_tile_frags(dz_dst, mb_base + tm, nt, NT, lane, v);
@@ -358,7 +401,7 @@ __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x
   }
 }
 
-template <int TN, int PROBE = 0>
+template <int TN>
 __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
@@ -386,12 +429,13 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
       const long nt_stride = (long)KC * 512;
-      wide_mainloop<TN, PROBE>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
+      wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
                         (int)((blockIdx.x * 5 + wave * 11) % KC));
       __syncthreads();  // every wave is done reading the layer input
+      unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
       RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.bias[l],
-                                                              (a.save ? a.act_frag[l + 1] : nullptr), N / 32,
-                                                              blockIdx.x * 4, wave, lane)));
+                                                              (a.save ? a.act_frag[l + 1] : nullptr), sign_dst,
+                                                              N / 32, blockIdx.x * 4, wave, lane)));
       __syncthreads();
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
@@ -444,13 +488,34 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
     const long nt_stride = (long)KC * 512;
+    // sign bits of H_l, requested before the main loop so they are in registers at the epilogue
+    unsigned sg[2 * TN];
+    const bool use_sign = a.act_sign[l] != nullptr;
+    if (use_sign) {
+      const u32x2* sp = (const u32x2*)(a.act_sign[l] + sign_offset(blockIdx.x, wave, lane, TN));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const u32x2 t = sp[i];
+        sg[2 * i] = t[0];
+        sg[2 * i + 1] = t[1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2 * TN; ++i) sg[i] = 0u;
+    }
     wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
                         (int)((blockIdx.x * 5 + wave * 11) % KC));
     __syncthreads();
-    RG_DISPATCH_ACT(a.acts[l - 1],
-                    (bwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.act_frag[l], a.dz_frag[l - 1],
-                                                 a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr,
-                                                 N / 32, blockIdx.x * 4, wave, lane)));
+    float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
+    if (use_sign) {
+      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_epilogue<TN, A_, true>(act, pitch, acc, a.act_frag[l], sg,
+                                                                       a.dz_frag[l - 1], dbp, N / 32,
+                                                                       blockIdx.x * 4, wave, lane)));
+    } else {
+      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_epilogue<TN, A_, false>(act, pitch, acc, a.act_frag[l], sg,
+                                                                        a.dz_frag[l - 1], dbp, N / 32,
+                                                                        blockIdx.x * 4, wave, lane)));
+    }
     __syncthreads();
   }
   if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
@@ -788,6 +853,8 @@ size_t rg_frag_elems(int rows, int cols) {
   return (size_t)((rows + 127) / 128 * 128) * (size_t)((cols + 31) / 32 * 32);
 }
 
+size_t rg_sign_bytes(int rows, int cols) { return rg_frag_elems(rows, cols) / 8; }
+
 size_t rg_wfrag_elems(int out_features, int in_features) {
   return (size_t)((out_features + 31) / 32) * (size_t)((in_features + 15) / 16) * 512;
 }
@@ -813,6 +880,9 @@ static int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int backward) 
     a.wfrag[l] = (const bf16_t*)(backward ? d->wfrag_bwd[l] : d->wfrag_fwd[l]);
     a.bias[l] = d->bias[l];
     a.dz_frag[l] = (bf16_t*)d->dz_frag[l];
+    // the sign plane of layer l's input only exists when layer l-1 has a sign-based activation
+    const bool sign_ok = l >= 1 && (d->acts[l - 1] == RG_ACT_RELU || d->acts[l - 1] == RG_ACT_LEAKY_RELU);
+    a.act_sign[l] = sign_ok ? (unsigned*)d->act_sign[l] : nullptr;
     a.db_part[l] = nullptr;
     if (!a.wfrag[l] && !(backward && l == 0)) return RG_EINVAL;
   }
@@ -841,24 +911,8 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
     RG_ALLOW_LDS(mlp_fwd_fused_kernel<1>, lds);
     RG_LAUNCH_DYN(mlp_fwd_fused_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
   } else {
-    const char* pe = getenv("RG_FUSED_PROBE");  // perf-investigation variants (wrong results)
-    const int probe = pe ? atoi(pe) : 0;
-    if (probe == 1) {
-      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 1>), lds);
-      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 1>), grid, block, lds, (hipStream_t)stream, a);
-    } else if (probe == 2) {
-      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 2>), lds);
-      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 2>), grid, block, lds, (hipStream_t)stream, a);
-    } else if (probe == 3) {
-      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 3>), lds);
-      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 3>), grid, block, lds, (hipStream_t)stream, a);
-    } else if (probe == 4) {
-      RG_ALLOW_LDS((mlp_fwd_fused_kernel<2, 4>), lds);
-      RG_LAUNCH_DYN((mlp_fwd_fused_kernel<2, 4>), grid, block, lds, (hipStream_t)stream, a);
-    } else {
-      RG_ALLOW_LDS(mlp_fwd_fused_kernel<2>, lds);
-      RG_LAUNCH_DYN(mlp_fwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
-    }
+    RG_ALLOW_LDS(mlp_fwd_fused_kernel<2>, lds);
+    RG_LAUNCH_DYN(mlp_fwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
   }
   return (int)hipGetLastError();
 }

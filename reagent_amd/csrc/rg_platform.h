@@ -42,6 +42,11 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+// value of lane^1 through DPP quad_perm [1,0,3,2]: a VALU move, no LDS crossbar round trip
+__device__ __forceinline__ float swap_adjacent_lanes(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 64); }

@@ -318,6 +318,8 @@ class FusedMLP:
             bf = dict(dtype=torch.bfloat16, device=device)
             ws["act_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l]), **bf) for l in range(self.L)]
             ws["dz_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l + 1]), **bf) for l in range(self.L)]
+            ws["act_sign"] = [torch.empty(lib.rg_sign_bytes(batch, self.dims[l]), dtype=torch.uint8, device=device)
+                              if l >= 1 else None for l in range(self.L)]
             dd = L.MlpDesc()
             dd.n_layers = self.L
             for i, v in enumerate(self.dims):
@@ -343,6 +345,7 @@ class FusedMLP:
             d.bias[l] = self.biases[l].data_ptr()
             d.act_frag[l] = ws["act_frag"][l].data_ptr() if "act_frag" in ws else None
             d.dz_frag[l] = ws["dz_frag"][l].data_ptr() if "dz_frag" in ws else None
+            d.act_sign[l] = ws["act_sign"][l].data_ptr() if "act_sign" in ws and ws["act_sign"][l] is not None else None
         return d
 
     def stage_input(self, x32: torch.Tensor, need_transposed: bool):

@@ -103,6 +103,7 @@ static inline T gather_from(T v, int src_lane) {
 }
 static inline float shfl_xor(float v, int mask) { return gather_from(v, lane_id() ^ mask); }
 static inline int shfl_xor(int v, int mask) { return gather_from(v, lane_id() ^ mask); }
+static inline float swap_adjacent_lanes(float v) { return gather_from(v, lane_id() ^ 1); }
 static inline float shfl_down(float v, int d) {
   int l = lane_id();
   return gather_from(v, (l + d < 64) ? l + d : l);
