@@ -19,12 +19,23 @@
 // Replaces: FullyConnectedNetwork.forward (reagent/models/fully_connected_network.py:157-163)
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
 #include "rg_gemm.h"
+#include <type_traits>
 #include "../../include/reagent_hip.h"
+
+// phase-timing hook: expands to nothing here; profiles/microbench/fwd_phases.hip defines it to an
+// s_memtime stamp before including this file
+#ifndef RG_STAMP
+#define RG_STAMP(slot)
+#endif
 
 namespace rg {
 
 constexpr int FB_BM = 128;
-constexpr int FB_THREADS = 512;
+constexpr int WG_THREADS = 512;  // weight-gradient kernels
+#ifndef RG_FUSED_WAVES
+#define RG_FUSED_WAVES 8
+#endif
+constexpr int FB_NW = RG_FUSED_WAVES;  // waves per workgroup of the forward / backward kernels (4 or 8)
 constexpr int FB_MAXL = RG_MLP_MAX_LAYERS;
 
 struct MlpArgs {
@@ -52,6 +63,16 @@ struct MlpArgs {
 
 __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// compile-time loop: the body is instantiated once per index, so accumulator arrays indexed by it
+// stay in registers even where `#pragma unroll` gives up ("unrolled size is too large")
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // compile-time activation (a runtime `switch` per element would bloat the unrolled epilogues until
 // the unroller gives up and the accumulator arrays fall into scratch)
 template <int ACT> __device__ __forceinline__ float act_t(float z) { return act_apply(z, ACT); }
@@ -78,12 +99,48 @@ __device__ __forceinline__ int frag_row(int h, int e, int lg) {
 
 // ---- LDS tile helpers -----------------------------------------------------------------------
 // rows [row_base, row_base+128) x cols [0, ncols_pad) of a row-major global matrix -> bf16 LDS tile
-template <typename T>
+template <typename T, int THREADS>
 __device__ __forceinline__ void load_tile_to_lds(bf16_t* act, int pitch, const T* src, long ld, int row_base,
                                                  int nrows, int ncols, int ncols_pad, int tid) {
   const int cpr = ncols_pad / 8;  // 8-element chunks per row
+  const int total = FB_BM * cpr;
   const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
-  for (int c = tid; c < FB_BM * cpr; c += FB_THREADS) {
+  if (vec && ncols == ncols_pad) {
+    // aligned rows: four chunks per thread in flight (all loads issued before the first use; the
+    // addresses of out-of-range chunks are clamped and their result replaced by zeros)
+    constexpr int U = 4;
+    for (int c0 = tid; c0 < total; c0 += THREADS * U) {
+      f32x4 raw[U][sizeof(T) == 4 ? 2 : 1];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cu = c0 + u * THREADS, c = cu < total ? cu : total - 1;
+        const int gr = row_base + c / cpr, grow = gr < nrows ? gr : nrows - 1;
+        const T* p = src + (long)grow * ld + (c % cpr) * 8;
+        raw[u][0] = *(const f32x4*)p;
+        if (sizeof(T) == 4) raw[u][sizeof(T) == 4 ? 1 : 0] = *(const f32x4*)(p + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * THREADS;
+        if (c >= total) break;
+        const int r = c / cpr, k0 = (c % cpr) * 8;
+        u16x8 v;
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = f32_to_bf16(raw[u][0][e]);
+            v[4 + e] = f32_to_bf16(raw[u][sizeof(T) == 4 ? 1 : 0][e]);
+          }
+        } else {
+          v = __builtin_bit_cast(u16x8, raw[u][0]);
+        }
+        if (row_base + r >= nrows) v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        *(u16x8*)&act[r * pitch + k0] = v;
+      }
+    }
+    return;
+  }
+  for (int c = tid; c < total; c += THREADS) {
     const int r = c / cpr, k0 = (c % cpr) * 8;
     const int grow = row_base + r;
     u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -110,10 +167,10 @@ __device__ __forceinline__ void load_tile_to_lds(bf16_t* act, int pitch, const T
 
 // LDS tile (128 rows x ntiles*32 cols) -> C-fragment order in global memory
 __device__ __forceinline__ void emit_frags_from_lds(const bf16_t* act, int pitch, int ntiles, bf16_t* dst,
-                                                    int mb_base, int wave, int lane) {
+                                                    int mb_base, int wave, int n_waves, int lane) {
   const int lr = lane & 31, lg = lane >> 5;
   const int total = 4 * ntiles * 2;
-  for (int f = wave; f < total; f += FB_THREADS / 64) {
+  for (int f = wave; f < total; f += n_waves) {
     const int h = f & 1, nt = (f >> 1) % ntiles, mbl = (f >> 1) / ntiles;
     u16x8 v;
 #pragma unroll
@@ -122,35 +179,38 @@ __device__ __forceinline__ void emit_frags_from_lds(const bf16_t* act, int pitch
   }
 }
 
-// accumulators of one 32x32 tile (already activated / masked) -> bf16 into the LDS tile.
-// Neighbouring lanes hold neighbouring columns: exchange one value per row pair so every lane
-// writes one packed bf16x2 dword instead of two 2-byte stores.
-__device__ __forceinline__ void store_tile_to_lds(bf16_t* act, int pitch, int row0_tile, int col, int lane,
-                                                  const float (&v)[16]) {
+// One 32x32 accumulator tile (values final, fp32) as 8 packed bf16 pairs P[i] = (v[2i], v[2i+1]):
+// rows 2i and 2i+1 of the lane's column.  P[0..3] / P[4..7] ARE the two 16-byte C-fragment records
+// of the tile, so saving for backward costs no further conversion.
+__device__ __forceinline__ void pack_tile(const float (&v)[16], unsigned (&P)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) P[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+}
+
+// Packed tile -> LDS activation tile.  Neighbouring lanes hold neighbouring columns: swap the pair
+// with the neighbour (DPP) and let a byte permute build the dword this lane stores — the even lane
+// writes row 2i (its low half + the neighbour's low half), the odd lane row 2i+1 (high halves).
+// Per value pair: 1 cvt_pk (pack_tile) + 1 DPP move + 1 v_perm + 1 ds_write_b32.
+__device__ __forceinline__ void store_packed_to_lds(bf16_t* act, int pitch, int row0_tile, int col, int lane,
+                                                    const unsigned (&P)[8]) {
   const int lg = lane >> 5, odd = lane & 1;
+  const unsigned sel = odd ? 0x03020706u : 0x05040100u;  // {hi = neighbour's pair, lo = own pair}
+  bf16_t* base = act + (row0_tile + 4 * lg + odd) * pitch + (col & ~1);
 #pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    const int row0 = row0_tile + 8 * rq + 4 * lg;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float mine_a = v[rq * 4 + 2 * q], mine_b = v[rq * 4 + 2 * q + 1];
-      const float recv = swap_adjacent_lanes(odd ? mine_a : mine_b);
-      const unsigned word = odd ? pack_bf16x2(recv, mine_b) : pack_bf16x2(mine_a, recv);
-      const int row = row0 + 2 * q + odd;
-      *(unsigned*)&act[row * pitch + (col & ~1)] = word;
-    }
+  for (int i = 0; i < 8; ++i) {
+    const int r = 2 * i;
+    const unsigned other = swap_adjacent_lanes(P[i]);
+    const unsigned word = perm_bytes(other, P[i], sel);
+    *(unsigned*)(base + ((r & 3) + 8 * (r >> 2)) * pitch) = word;
   }
 }
 
-__device__ __forceinline__ void store_tile_frags(bf16_t* dst, int mb, int nt, int NT, int lane,
-                                                 const float (&v)[16]) {
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ void store_packed_frags(bf16_t* dst, int mb, int nt, int NT, int lane,
+                                                   const unsigned (&P)[8]) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    u16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[8 * h + e]);
-    *(u16x8*)(dst + frag_offset(mb, nt, NT, h, lane)) = o;
-  }
+  for (int h = 0; h < 2; ++h)
+    *(u32x4*)(dst + frag_offset(mb, nt, NT, h, lane)) = u32x4{P[4 * h], P[4 * h + 1], P[4 * h + 2], P[4 * h + 3]};
 }
 
 // bit r = (v[r] > 0).  NONNEG (ReLU outputs: v is +0 or a positive float, never -0/NaN): the sign
@@ -170,23 +230,31 @@ __device__ __forceinline__ unsigned positive_bits(const float (&v)[16]) {
 // ---- main loop of a wide layer: this wave's [128 x 32*TN] slice over K ------------------------
 // `rot` rotates the order in which the K chunks are visited (a sum may be taken in any order):
 // every workgroup streams the SAME weight fragments, and without de-phasing all 256 CUs would
-// hammer one L2 channel at a time.
-// Software pipeline: the weight (B) fragments come from L2 (~0.5-1 us under load) and are
-// prefetched three chunks ahead through a ring of four register sets; the activation (A)
-// fragments come from LDS and are prefetched one chunk ahead.
-template <int TN>
-__device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_lane,
-                                              long nt_stride, f32x16 (&acc)[4][TN], int lr, int lg, int rot) {
-  // measured on MI355X (C2 forward): 103.5 us with the rotation, 107 us without — all CUs streaming
-  // the same fragments in the same order do hot-spot the L2 channels
+// hammer one L2 channel at a time (measured on MI355X, C2 forward: 103.5 us with, 107 us without).
+// Software pipeline: the weight (B) fragments come from L2 — ~2000 cycles under this load, measured
+// with profiles/microbench/fwd_phases — and are prefetched RING-1 chunks ahead through a ring of
+// RING register sets; the activation (A) fragments come from LDS, one chunk ahead.
+// wf_wave, rot and every chunk offset are wave-uniform: the weight address math stays on the
+// scalar unit (SGPR base + lane*16 B), only the LDS reads need a vector add per chunk.
+// The K-rotation of (workgroup, wave) for a layer with KC chunks
+__device__ __forceinline__ int k_rotation(int wg, int wave, int KC) { return (wg * 5 + wave * 11) % KC; }
+
+// (Hoisting the ring fill of a layer ahead of the previous epilogue / the input-tile load was
+// measured with profiles/microbench/fwd_phases: the epilogues got 1.2k cycles slower each and the
+// main loops no faster, so the fill stays at the top of the main loop.)
+template <int TN, int RING>
+__device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave,
+                                              long nt_stride, f32x16 (&acc)[4][TN], int lane, int rot) {
+  static_assert(RING >= 2 && RING % 2 == 0, "the A double buffer alternates with the ring slot parity");
+  const int lr = lane & 31, lg = lane >> 5;
   auto kx = [&](int kc) { const int k = kc + rot; return k >= KC ? k - KC : k; };
   const bf16_t* arow = act + lr * pitch + lg * 8;
   const int tm_stride = 32 * pitch;
-  u16x8 a0[4], a1[4], b0[TN], b1[TN], b2[TN], b3[TN];
+  u16x8 a[2][4], b[RING][TN];
   auto loadB = [&](u16x8 (&bf)[TN], int kc) {
-    const long off = (long)kx(kc) * 512;
+    const bf16_t* chunk = wf_wave + (long)kx(kc) * 512;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(wf_lane + tn * nt_stride + off);
+    for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(chunk + tn * nt_stride + lane * 8);
   };
   auto loadA = [&](u16x8 (&af)[4], int kc) {
     const int off = kx(kc) * 16;
@@ -199,88 +267,57 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
   };
-  if ((KC & 3) == 0) {
-    // fast path: no conditionals around the loads in the steady state, so the compiler can keep
-    // exact s_waitcnt vmcnt(N)/lgkmcnt(N) counts (6 weight loads + 4 LDS reads stay in flight)
-    loadB(b0, 0);
-    loadB(b1, 1);
-    loadB(b2, 2);
-    loadA(a0, 0);
+  if (KC % RING == 0) {
+    // fast path: no conditionals around the loads in the steady state, so the compiler keeps exact
+    // s_waitcnt vmcnt(N)/lgkmcnt(N) counts and (RING-1)*TN weight loads stay in flight
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) loadB(b[s], s);
+    loadA(a[0], 0);
     int kc = 0;
-    for (; kc < KC - 4; kc += 4) {
-      loadB(b3, kc + 3);
-      loadA(a1, kc + 1);
+    for (; kc < KC - RING; kc += RING) {
+#pragma unroll
+      for (int s = 0; s < RING; ++s) {
+        loadB(b[(s + RING - 1) % RING], kc + s + RING - 1);
+        loadA(a[(s + 1) & 1], kc + s + 1);
+        sched_fence();
+        mma(a[s & 1], b[s]);
+        sched_fence();
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {  // last block: only the loads that are still in range
+      if (s == 0) loadB(b[RING - 1], kc + RING - 1);
+      if (s < RING - 1) loadA(a[(s + 1) & 1], kc + s + 1);
       sched_fence();
-      mma(a0, b0);
-      sched_fence();
-      loadB(b0, kc + 4);
-      loadA(a0, kc + 2);
-      sched_fence();
-      mma(a1, b1);
-      sched_fence();
-      loadB(b1, kc + 5);
-      loadA(a1, kc + 3);
-      sched_fence();
-      mma(a0, b2);
-      sched_fence();
-      loadB(b2, kc + 6);
-      loadA(a0, kc + 4);
-      sched_fence();
-      mma(a1, b3);
+      mma(a[s & 1], b[s]);
       sched_fence();
     }
-    loadB(b3, kc + 3);
-    loadA(a1, kc + 1);
-    sched_fence();
-    mma(a0, b0);
-    sched_fence();
-    loadA(a0, kc + 2);
-    sched_fence();
-    mma(a1, b1);
-    sched_fence();
-    loadA(a1, kc + 3);
-    sched_fence();
-    mma(a0, b2);
-    mma(a1, b3);
     return;
   }
   // generic K: same ring with guarded loads
-  loadB(b0, 0);
-  if (KC > 1) loadB(b1, 1);
-  if (KC > 2) loadB(b2, 2);
-  loadA(a0, 0);
-  for (int kc = 0; kc < KC; kc += 4) {
-    if (kc + 3 < KC) loadB(b3, kc + 3);
-    if (kc + 1 < KC) loadA(a1, kc + 1);
-    sched_fence();
-    mma(a0, b0);
-    sched_fence();
-    if (kc + 1 < KC) {
-      if (kc + 4 < KC) loadB(b0, kc + 4);
-      if (kc + 2 < KC) loadA(a0, kc + 2);
-      sched_fence();
-      mma(a1, b1);
-      sched_fence();
-    }
-    if (kc + 2 < KC) {
-      if (kc + 5 < KC) loadB(b1, kc + 5);
-      if (kc + 3 < KC) loadA(a1, kc + 3);
-      sched_fence();
-      mma(a0, b2);
-      sched_fence();
-    }
-    if (kc + 3 < KC) {
-      if (kc + 6 < KC) loadB(b2, kc + 6);
-      if (kc + 4 < KC) loadA(a0, kc + 4);
-      sched_fence();
-      mma(a1, b3);
-      sched_fence();
+#pragma unroll
+  for (int s = 0; s < RING - 1; ++s)
+    if (s < KC) loadB(b[s], s);
+  loadA(a[0], 0);
+  for (int kc = 0; kc < KC; kc += RING) {
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+      if (kc + s < KC) {
+        if (kc + s + RING - 1 < KC) loadB(b[(s + RING - 1) % RING], kc + s + RING - 1);
+        if (kc + s + 1 < KC) loadA(a[(s + 1) & 1], kc + s + 1);
+        sched_fence();
+        mma(a[s & 1], b[s]);
+        sched_fence();
+      }
     }
   }
 }
 
 // one 32x32 output tile (row tile tm, weight n-tile nt) over K; used for narrow / irregular widths.
 // Groups of 4 chunks, next group's fragments in flight during the current group's MFMAs.
+// (Measured alternatives, profiles/microbench/fwd_phases, cycles per wave averaged over the 8 waves:
+// this loop 3.9k; 4 independent accumulators 5.5k; all <= 32 weight chunks requested up front 9.2k —
+// every workgroup reads the same 32 KB, and a burst on that region queues in the L2 channels.)
 __device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf, int tm,
                                              int nt, int lane) {
   const int lr = lane & 31, lg = lane >> 5;
@@ -324,8 +361,9 @@ __device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int K
 // derivative depends on nothing else, so backward prefetches these 16 bytes per lane ahead of its
 // main loop instead of waiting on 8 KB of saved activations per wave in the epilogue.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-__device__ __forceinline__ long sign_offset(int wg, int wave, int lane, int TN) {
-  return (((long)wg * (FB_THREADS / 64) + wave) * 64 + lane) * (2 * TN);
+__device__ __forceinline__ long sign_offset(int wg, int wave, int lane, int TN, int width) {
+  // a workgroup's plane: 128 rows x width bits = 4*width dwords = n_waves * 64 lanes * 2*TN dwords
+  return (long)wg * (4 * width) + ((long)wave * 64 + lane) * (2 * TN);
 }
 template <int ACT> constexpr bool act_is_sign_based() { return ACT == ACT_RELU || ACT == ACT_LEAKY_RELU; }
 
@@ -335,29 +373,31 @@ __device__ __forceinline__ void fwd_hidden_epilogue(bf16_t* act, int pitch, f32x
                                                     int wave, int lane) {
   lane = opaque(lane);
   const int lr = lane & 31;
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
     const int nt = wave * TN + tn, col = nt * 32 + lr;
     const float b = bias ? bias[col] : 0.f;
     unsigned sg0 = 0u, sg1 = 0u;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
+    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
+      unsigned P[8];
+      pack_tile(v, P);
       if (save_dst) {
-        store_tile_frags(save_dst, mb_base + tm, nt, NT, lane, v);
+        store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, P);
         if (act_is_sign_based<ACT>()) {
           const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
           if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
           else sg1 |= bits << ((tm & 1) * 16);
         }
       }
-      store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
-    }
+      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
+    });
     if (act_is_sign_based<ACT>() && sign_dst)
-      ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN)))[tn] = u32x2{sg0, sg1};
-  }
+      ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
+  });
 }
 
 // dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
@@ -367,12 +407,12 @@ __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x
                                                     int NT, int mb_base, int wave, int lane) {
   lane = opaque(lane);
   const int lr = lane & 31;
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
     const int nt = wave * TN + tn, col = nt * 32 + lr;
     float colsum = 0.f;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
+    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
       float v[16];
       if (USE_SIGN && act_is_sign_based<ACT>()) {
         const unsigned bits = sg[tn * 2 + (tm >> 1)] >> ((tm & 1) * 16);
@@ -393,34 +433,53 @@ __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x
           }
         }
       }
-      store_tile_frags(dz_dst, mb_base + tm, nt, NT, lane, v);
-      store_tile_to_lds(act, pitch, tm * 32, col, lane, v);
-    }
+      unsigned P[8];
+      pack_tile(v, P);
+      store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, P);
+      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
+    });
     colsum += shfl_xor(colsum, 32);
     if (db_part && lane < 32) db_part[col] = colsum;
-  }
+  });
 }
 
-template <int TN>
-__global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
+// NW waves per workgroup, each owning 32*TN columns of a hidden layer (hidden width = 32*TN*NW).
+// NW = 4 (one wave per SIMD, up to 512 registers each): 16 accumulator tiles per wave and a weight
+// ring deep enough to cover the L2 latency from a single wave.  NW = 8: two waves per SIMD.
+template <int NW> struct MlpCfg {
+  static constexpr int THREADS = NW * 64;
+#ifdef RG_FUSED_RING
+  static constexpr int RING = RG_FUSED_RING;
+#else
+  static constexpr int RING = NW == 4 ? 8 : 4;
+#endif
+};
+
+// PITCH (LDS row pitch in elements) is a template constant so that every LDS offset of the
+// epilogue stores folds into an instruction immediate instead of a vector add per store.
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
+  constexpr int THREADS = MlpCfg<NW>::THREADS, RING = MlpCfg<NW>::RING;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
   const int row_base = blockIdx.x * FB_BM;
-  const int pitch = a.pitch;
+  constexpr int pitch = PITCH;
   const int k0p = round_up(a.dims[0], 32);
+  RG_STAMP(0);
   if (a.x_is_f32)
-    load_tile_to_lds<float>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
+    load_tile_to_lds<float, THREADS>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   else
-    load_tile_to_lds<bf16_t>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
+    load_tile_to_lds<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   __syncthreads();
-  if (a.save && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * 4, wave, lane);
+  RG_STAMP(1);
+  if (a.save && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * 4, wave, NW, lane);
 
   for (int l = 0; l < a.n_layers; ++l) {
     const int K = a.dims[l], N = a.dims[l + 1];
     const int KC = (K + 15) / 16;
-    if (l < a.n_layers - 1) {  // hidden layer, N == 256 * TN
+    if (l < a.n_layers - 1) {  // hidden layer, N == 32 * TN * NW
       f32x16 acc[4][TN];
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
@@ -429,18 +488,22 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
       const long nt_stride = (long)KC * 512;
-      wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
-                        (int)((blockIdx.x * 5 + wave * 11) % KC));
+      wide_mainloop<TN, RING>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
+                              k_rotation(blockIdx.x, wave, KC));
+      RG_STAMP(2 + 4 * l);
       __syncthreads();  // every wave is done reading the layer input
+      RG_STAMP(3 + 4 * l);
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
       RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.bias[l],
                                                               (a.save ? a.act_frag[l + 1] : nullptr), sign_dst,
                                                               N / 32, blockIdx.x * 4, wave, lane)));
+      RG_STAMP(4 + 4 * l);
       __syncthreads();
+      RG_STAMP(5 + 4 * l);
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
       const int out_act = a.acts[l];
-      for (int t = wave; t < 4 * NTo; t += FB_THREADS / 64) {
+      for (int t = wave; t < 4 * NTo; t += NW) {
         const int tm = t & 3, nt = t >> 2;
         const f32x16 acc = tile_kloop(act, pitch, KC, a.wfrag[l], tm, nt, lane);
         const int col = nt * 32 + lr;
@@ -453,23 +516,25 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_fwd_fused_kernel(MlpArgs a) {
           }
         }
       }
+      RG_STAMP(2 + 4 * l);
     }
   }
 }
 
-template <int TN>
-__global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
+  constexpr int THREADS = MlpCfg<NW>::THREADS, RING = MlpCfg<NW>::RING;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
   const int row_base = blockIdx.x * FB_BM;
-  const int pitch = a.pitch;
+  constexpr int pitch = PITCH;
   const int L = a.n_layers;
   const int nop = round_up(a.dims[L], 32);
-  load_tile_to_lds<float>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
+  load_tile_to_lds<float, THREADS>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, lane);
+  emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, NW, lane);
   if (a.db_part[L - 1] && tid < a.dims[L]) {
     float s = 0.f;
     for (int r = 0; r < FB_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]);
@@ -492,7 +557,7 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
     unsigned sg[2 * TN];
     const bool use_sign = a.act_sign[l] != nullptr;
     if (use_sign) {
-      const u32x2* sp = (const u32x2*)(a.act_sign[l] + sign_offset(blockIdx.x, wave, lane, TN));
+      const u32x2* sp = (const u32x2*)(a.act_sign[l] + sign_offset(blockIdx.x, wave, lane, TN, N));
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const u32x2 t = sp[i];
@@ -503,8 +568,8 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
 #pragma unroll
       for (int i = 0; i < 2 * TN; ++i) sg[i] = 0u;
     }
-    wide_mainloop<TN>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride + lane * 8, nt_stride, acc, lr, lg,
-                        (int)((blockIdx.x * 5 + wave * 11) % KC));
+    wide_mainloop<TN, RING>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
+                            k_rotation(blockIdx.x, wave, KC));
     __syncthreads();
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
     if (use_sign) {
@@ -521,7 +586,7 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) mlp_bwd_fused_kernel(MlpArgs a) {
   if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
     const int K = a.dims[1], N = a.dims[0];
     const int KC = (K + 15) / 16, NTi = (N + 31) / 32;
-    for (int t = wave; t < 4 * NTi; t += FB_THREADS / 64) {
+    for (int t = wave; t < 4 * NTi; t += NW) {
       const int tm = t & 3, nt = t >> 2;
       const f32x16 acc = tile_kloop(act, pitch, KC, a.wfrag[0], tm, nt, lane);
       const int col = nt * 32 + lr;
@@ -557,7 +622,7 @@ struct WgradFragArgs {
 };
 
 __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid, char* smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
   const int wn = wave >> 2, wk = wave & 3;
   const int n_groups = (g.NTa + 7) / 8, k_groups = (g.NTb + 7) / 8;
@@ -591,12 +656,12 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging registers: 4096 16-byte units per stage / 512 threads
-  constexpr int UNITS = WG_MB_STAGE * 2048, PER = UNITS / FB_THREADS;
+  constexpr int UNITS = WG_MB_STAGE * 2048, PER = UNITS / WG_THREADS;
   u16x8 regs[PER];
   auto gload = [&](int mb0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int u = tid + i * FB_THREADS;
+      const int u = tid + i * WG_THREADS;
       const int mbl = u >> 11, w = u & 2047, isb = w >> 10, off = w & 1023;
       const int tile = off >> 7, mb = mb0 + mbl;
       u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -614,7 +679,7 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
     char* base = smem + buf * WG_STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int u = tid + i * FB_THREADS;
+      const int u = tid + i * WG_THREADS;
       *(u16x8*)(base + (long)u * 16) = regs[i];
     }
   };
@@ -832,14 +897,31 @@ static int fused_supported(const rg_mlp_desc* d) {
   return H / 256;
 }
 
+// LDS row pitch: widest layer + 8 elements (row stride = 4 banks mod 64: conflict-free 16-byte reads)
 static int fused_pitch(const rg_mlp_desc* d) {
   int m = 0;
   for (int l = 0; l <= d->n_layers; ++l) {
     const int w = (d->dims[l] + 31) / 32 * 32;
     if (w > m) m = w;
   }
-  return m + 8;
+  return m <= 256 ? 264 : 520;
 }
+
+// the three (hidden width, pitch) instantiations of a fused kernel template
+#define RG_LAUNCH_FUSED(KERNEL, hidden, pitch, grid, lds, stream, args)                                      \
+  do {                                                                                                       \
+    const dim3 block_(FB_NW * 64);                                                                           \
+    if ((hidden) == 256 && (pitch) == 264) {                                                                 \
+      RG_ALLOW_LDS((KERNEL<256 / (32 * FB_NW), FB_NW, 264>), lds);                                           \
+      RG_LAUNCH_DYN((KERNEL<256 / (32 * FB_NW), FB_NW, 264>), grid, block_, lds, (hipStream_t)stream, args); \
+    } else if ((hidden) == 256) {                                                                            \
+      RG_ALLOW_LDS((KERNEL<256 / (32 * FB_NW), FB_NW, 520>), lds);                                           \
+      RG_LAUNCH_DYN((KERNEL<256 / (32 * FB_NW), FB_NW, 520>), grid, block_, lds, (hipStream_t)stream, args); \
+    } else {                                                                                                 \
+      RG_ALLOW_LDS((KERNEL<512 / (32 * FB_NW), FB_NW, 520>), lds);                                           \
+      RG_LAUNCH_DYN((KERNEL<512 / (32 * FB_NW), FB_NW, 520>), grid, block_, lds, (hipStream_t)stream, args); \
+    }                                                                                                        \
+  } while (0)
 
 }  // namespace rg
 
@@ -906,14 +988,8 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
       if (!d->act_frag[l]) return RG_EINVAL;
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
   const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
-  const dim3 grid((batch + FB_BM - 1) / FB_BM), block(FB_THREADS);
-  if (tn == 1) {
-    RG_ALLOW_LDS(mlp_fwd_fused_kernel<1>, lds);
-    RG_LAUNCH_DYN(mlp_fwd_fused_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
-  } else {
-    RG_ALLOW_LDS(mlp_fwd_fused_kernel<2>, lds);
-    RG_LAUNCH_DYN(mlp_fwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
-  }
+  const dim3 grid((batch + FB_BM - 1) / FB_BM);
+  RG_LAUNCH_FUSED(mlp_fwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -950,14 +1026,8 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   }
   a.dout32 = dout32; a.lddo = lddo; a.dx32 = dx32; a.lddx = lddx;
   const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
-  const dim3 grid(n_wg), block(FB_THREADS);
-  if (tn == 1) {
-    RG_ALLOW_LDS(mlp_bwd_fused_kernel<1>, lds);
-    RG_LAUNCH_DYN(mlp_bwd_fused_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
-  } else {
-    RG_ALLOW_LDS(mlp_bwd_fused_kernel<2>, lds);
-    RG_LAUNCH_DYN(mlp_bwd_fused_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
-  }
+  const dim3 grid(n_wg);
+  RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   rc = (int)hipGetLastError();
   if (rc) return rc;
   for (int l = 0; l < d->n_layers; ++l) {
@@ -1008,7 +1078,7 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   const int grid = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
   const size_t lds = 2 * (size_t)WG_STAGE_BYTES;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
-  RG_LAUNCH_DYN(wgrad_frag_kernel, dim3(grid), dim3(FB_THREADS), lds, (hipStream_t)stream, g);
+  RG_LAUNCH_DYN(wgrad_frag_kernel, dim3(grid), dim3(WG_THREADS), lds, (hipStream_t)stream, g);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   const long n = p.slab;
@@ -1106,7 +1176,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   for (int l = d->n_layers; l <= FB_MAXL; ++l) { G.wg_begin[l] = wg; R.elem_begin[l] = el; }
   const size_t lds = 2 * (size_t)WG_STAGE_BYTES;
   RG_ALLOW_LDS(wgrad_group_kernel, lds);
-  RG_LAUNCH_DYN(wgrad_group_kernel, dim3(wg), dim3(FB_THREADS), lds, (hipStream_t)stream, G);
+  RG_LAUNCH_DYN(wgrad_group_kernel, dim3(wg), dim3(WG_THREADS), lds, (hipStream_t)stream, G);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   RG_LAUNCH(reduce_group_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), (hipStream_t)stream, R);

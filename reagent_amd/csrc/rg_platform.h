@@ -43,10 +43,18 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 // value of lane^1 through DPP quad_perm [1,0,3,2]: a VALU move, no LDS crossbar round trip
-__device__ __forceinline__ float swap_adjacent_lanes(float v) {
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, true));
+__device__ __forceinline__ unsigned swap_adjacent_lanes(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true);
 }
+__device__ __forceinline__ float swap_adjacent_lanes(float v) {
+  return __builtin_bit_cast(float, swap_adjacent_lanes(__builtin_bit_cast(unsigned, v)));
+}
+// v_perm_b32: result byte i = byte (sel >> 8i & 7) of the 8-byte value {hi, lo}
+__device__ __forceinline__ unsigned perm_bytes(unsigned hi, unsigned lo, unsigned sel) {
+  return __builtin_amdgcn_perm(hi, lo, sel);
+}
+// a value the program knows to be the same in every lane of the wave -> SGPR (scalar address math)
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 64); }
@@ -63,8 +71,12 @@ __device__ __forceinline__ int opaque(int x) {
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // two floats -> packed bf16x2 (lo in bits 0..15); lowers to one v_cvt_pk_bf16_f32
+// one v_cvt_pk_bf16_f32 (a <2 x float> -> <2 x bfloat> truncation; written with scalar casts and
+// shifts the vectoriser picks its own pairing and repairs it with v_and/v_lshl/v_or_sdwa)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));
 }
 
 }  // namespace rg

@@ -104,6 +104,14 @@ static inline T gather_from(T v, int src_lane) {
 static inline float shfl_xor(float v, int mask) { return gather_from(v, lane_id() ^ mask); }
 static inline int shfl_xor(int v, int mask) { return gather_from(v, lane_id() ^ mask); }
 static inline float swap_adjacent_lanes(float v) { return gather_from(v, lane_id() ^ 1); }
+static inline unsigned swap_adjacent_lanes(unsigned v) { return (unsigned)gather_from((int)v, lane_id() ^ 1); }
+static inline unsigned perm_bytes(unsigned hi, unsigned lo, unsigned sel) {
+  const unsigned long long src = ((unsigned long long)hi << 32) | lo;
+  unsigned out = 0;
+  for (int i = 0; i < 4; ++i) out |= (unsigned)((src >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+  return out;
+}
+static inline int wave_uniform(int x) { return x; }
 static inline float shfl_down(float v, int d) {
   int l = lane_id();
   return gather_from(v, (l + d < 64) ? l + d : l);
