@@ -51,9 +51,9 @@ int main(int argc, char** argv) {
   printf("forward NW=%d RING=%d save=%d: %.2f us/launch (stamps on), err=%d\n", FB_NW, MlpCfg<FB_NW>::RING, save, ms * 1e3 / 20, (int)hipGetLastError());
   std::vector<unsigned long long> h((size_t)n_wg * NWV * NPH);
   hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
-  const char* names[NPH] = {"", "x tile load+barrier", "L0 mainloop(K=128)", "L0 barrier wait", "L0 epilogue", "L0 barrier2",
-                            "L1 mainloop(K=512)", "L1 barrier wait", "L1 epilogue", "L1 barrier2",
-                            "L2 mainloop(K=512)", "L2 barrier wait", "L2 epilogue", "L2 barrier2", "output layer", ""};
+  const char* names[NPH] = {"", "x tile load+barrier", "L0 mainloop(K=128)", "L0 pack", "L0 barrier wait", "L0 LDS store+barrier",
+                            "L1 mainloop(K=512)", "L1 pack", "L1 barrier wait", "L1 LDS store+barrier",
+                            "L2 mainloop(K=512)", "L2 pack", "L2 barrier wait", "L2 LDS store+barrier", "output layer", ""};
   double tot[NPH] = {0}, span = 0;
   for (int g = 0; g < n_wg; ++g)
     for (int w = 0; w < NWV; ++w) {
@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
       const unsigned long long* s = &h[((size_t)g * NWV + w) * NPH];
       ml += (double)(s[6] - s[5]); bw += (double)(s[7] - s[6]); ep += (double)(s[8] - s[7]);
     }
-    printf("  wave %d: mainloop %8.0f  wait %8.0f  epilogue %8.0f\n", w, ml / n_wg, bw / n_wg, ep / n_wg);
+    printf("  wave %d: mainloop %8.0f  pack %8.0f  wait %8.0f\n", w, ml / n_wg, bw / n_wg, ep / n_wg);
   }
   return 0;
 }

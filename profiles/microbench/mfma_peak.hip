@@ -32,8 +32,25 @@ int main() {
   hipEventCreate(&e1);
   const int lds = 133 * 1024;
   hipFuncSetAttribute((const void*)mfma_loop, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  for (int grid : {256, 512, 1024}) {
-    for (int iters : {146, 1168, 4672}) {  // 1168*8... per wave: 146 iters x 8 = one fused forward's MFMAs
+  for (int block : {512, 256}) {
+    for (int iters : {1168}) {
+      const int grid = 512;
+      mfma_loop<<<grid, block, lds>>>(out, iters, 1);
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      const int reps = 20;
+      for (int r = 0; r < reps; ++r) mfma_loop<<<grid, block, lds>>>(out, iters, 1);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      const double us = ms * 1e3 / reps;
+      const double flop = (double)grid * (block / 64) * iters * 8 * 32768.0;
+      printf("block %d (waves/SIMD %d) grid %4d iters %5d : %8.2f us/launch  %7.1f TFLOP/s\n", block, block / 256, grid, iters, us, flop / us * 1e-6);
+    }
+  }
+  for (int grid : {512}) {
+    for (int iters : {1168}) {  // 1168*8... per wave: 146 iters x 8 = one fused forward's MFMAs
       mfma_loop<<<grid, 512, lds>>>(out, iters, 1);
       hipDeviceSynchronize();
       hipEventRecord(e0);

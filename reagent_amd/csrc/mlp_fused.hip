@@ -269,7 +269,12 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
   };
   if (KC % RING == 0) {
     // fast path: no conditionals around the loads in the steady state, so the compiler keeps exact
-    // s_waitcnt vmcnt(N)/lgkmcnt(N) counts and (RING-1)*TN weight loads stay in flight
+    // s_waitcnt vmcnt(N)/lgkmcnt(N) counts and (RING-1)*TN weight loads stay in flight.
+    // Measured alternatives (profiles/microbench/fwd_phases, K=512 main loop, cycles of the early /
+    // late wave of a SIMD): this loop 12.5k / 20.3k; RING=8 13.4k / 21.1k; rotation per block of 4
+    // chunks with all addresses as immediates (a quarter of the scalar instructions) 16.4k / 22.9k;
+    // one wave per SIMD with 16 accumulator tiles 28k.  The loop is bound by how evenly the weight
+    // reads of 256 CUs spread over the L2 channels, not by instruction issue or by load latency.
 #pragma unroll
     for (int s = 0; s < RING - 1; ++s) loadB(b[s], s);
     loadA(a[0], 0);
@@ -367,10 +372,31 @@ __device__ __forceinline__ long sign_offset(int wg, int wave, int lane, int TN, 
 }
 template <int ACT> constexpr bool act_is_sign_based() { return ACT == ACT_RELU || ACT == ACT_LEAKY_RELU; }
 
+// The hidden-layer epilogues run in two phases around the barrier that protects the in-place LDS
+// tile.  PACK (before the barrier; touches no LDS): bias/activation (or the activation-gradient
+// mask), bf16 packing, the global stores of what backward needs.  STORE (after the barrier): the
+// packed pairs go to the LDS tile.  The two waves of a SIMD do not finish a main loop together (the
+// older one wins the MFMA arbitration and is ~8k cycles early, profiles/microbench/fwd_phases), so
+// the early wave's PACK runs under its partner's MFMAs, and the late wave packs with the SIMD's
+// VALU to itself, instead of both competing for the VALU after the barrier.
+template <int TN>
+__device__ __forceinline__ void store_packed_tiles(bf16_t* act, int pitch, const unsigned (&PK)[4][TN][8], int wave,
+                                                   int lane) {
+  const int lr = lane & 31;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    const int col = (wave * TN + tn) * 32 + lr;
+    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      store_packed_to_lds(act, pitch, tm * 32, col, lane, PK[tm][tn]);
+    });
+  });
+}
+
 template <int TN, int ACT>
-__device__ __forceinline__ void fwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const float* bias,
-                                                    bf16_t* save_dst, unsigned* sign_dst, int NT, int mb_base,
-                                                    int wave, int lane) {
+__device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const float* bias, bf16_t* save_dst,
+                                                unsigned* sign_dst, int NT, int mb_base, int wave, int lane,
+                                                unsigned (&PK)[4][TN][8]) {
   lane = opaque(lane);
   const int lr = lane & 31;
   static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
@@ -383,17 +409,15 @@ __device__ __forceinline__ void fwd_hidden_epilogue(bf16_t* act, int pitch, f32x
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
-      unsigned P[8];
-      pack_tile(v, P);
+      pack_tile(v, PK[tm][tn]);
       if (save_dst) {
-        store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, P);
+        store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
         if (act_is_sign_based<ACT>()) {
           const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
           if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
           else sg1 |= bits << ((tm & 1) * 16);
         }
       }
-      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
     });
     if (act_is_sign_based<ACT>() && sign_dst)
       ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
@@ -402,9 +426,9 @@ __device__ __forceinline__ void fwd_hidden_epilogue(bf16_t* act, int pitch, f32x
 
 // dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
 template <int TN, int ACT, bool USE_SIGN>
-__device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x16 (&acc)[4][TN], const bf16_t* h_frag,
-                                                    const unsigned (&sg)[2 * TN], bf16_t* dz_dst, float* db_part,
-                                                    int NT, int mb_base, int wave, int lane) {
+__device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16_t* h_frag,
+                                                const unsigned (&sg)[2 * TN], bf16_t* dz_dst, float* db_part, int NT,
+                                                int mb_base, int wave, int lane, unsigned (&PK)[4][TN][8]) {
   lane = opaque(lane);
   const int lr = lane & 31;
   static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
@@ -433,10 +457,8 @@ __device__ __forceinline__ void bwd_hidden_epilogue(bf16_t* act, int pitch, f32x
           }
         }
       }
-      unsigned P[8];
-      pack_tile(v, P);
-      store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, P);
-      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
+      pack_tile(v, PK[tm][tn]);
+      store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
     });
     colsum += shfl_xor(colsum, 32);
     if (db_part && lane < 32) db_part[col] = colsum;
@@ -491,13 +513,14 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       wide_mainloop<TN, RING>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
                               k_rotation(blockIdx.x, wave, KC));
       RG_STAMP(2 + 4 * l);
-      __syncthreads();  // every wave is done reading the layer input
-      RG_STAMP(3 + 4 * l);
+      unsigned PK[4][TN][8];
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
-      RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_epilogue<TN, A_>(act, pitch, acc, a.bias[l],
-                                                              (a.save ? a.act_frag[l + 1] : nullptr), sign_dst,
-                                                              N / 32, blockIdx.x * 4, wave, lane)));
+      RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack<TN, A_>(acc, a.bias[l], (a.save ? a.act_frag[l + 1] : nullptr),
+                                                          sign_dst, N / 32, blockIdx.x * 4, wave, lane, PK)));
+      RG_STAMP(3 + 4 * l);
+      __syncthreads();  // every wave is done reading the layer input
       RG_STAMP(4 + 4 * l);
+      store_packed_tiles<TN>(act, pitch, PK, wave, lane);
       __syncthreads();
       RG_STAMP(5 + 4 * l);
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
@@ -570,17 +593,17 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
     }
     wide_mainloop<TN, RING>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
                             k_rotation(blockIdx.x, wave, KC));
-    __syncthreads();
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
+    unsigned PK[4][TN][8];
     if (use_sign) {
-      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_epilogue<TN, A_, true>(act, pitch, acc, a.act_frag[l], sg,
-                                                                       a.dz_frag[l - 1], dbp, N / 32,
-                                                                       blockIdx.x * 4, wave, lane)));
+      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, true>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
+                                                                   N / 32, blockIdx.x * 4, wave, lane, PK)));
     } else {
-      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_epilogue<TN, A_, false>(act, pitch, acc, a.act_frag[l], sg,
-                                                                        a.dz_frag[l - 1], dbp, N / 32,
-                                                                        blockIdx.x * 4, wave, lane)));
+      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, false>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
+                                                                    N / 32, blockIdx.x * 4, wave, lane, PK)));
     }
+    __syncthreads();  // every wave is done reading dZ_l
+    store_packed_tiles<TN>(act, pitch, PK, wave, lane);
     __syncthreads();
   }
   if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)

@@ -69,6 +69,12 @@ __device__ __forceinline__ int opaque(int x) {
 }
 // scheduling fence: nothing is moved across it (pins "issue the loads, then the MFMA block")
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// scheduling-group hints (instruction classes of __builtin_amdgcn_sched_group_barrier)
+#define RG_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define RG_SCHED_DS_READ(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define RG_SCHED_VMEM_READ(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+#define RG_SCHED_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+#define RG_SCHED_SALU(n) __builtin_amdgcn_sched_group_barrier(0x004, n, 0)
 
 // two floats -> packed bf16x2 (lo in bits 0..15); lowers to one v_cvt_pk_bf16_f32
 // one v_cvt_pk_bf16_f32 (a <2 x float> -> <2 x bfloat> truncation; written with scalar casts and

@@ -92,6 +92,11 @@ static inline bf16_t f32_to_bf16(float f) {
 static inline int lane_id() { return ::emu::cur().linear_tid & 63; }
 static inline int opaque(int x) { return x; }
 static inline void sched_fence() {}
+#define RG_SCHED_MFMA(n) ((void)0)
+#define RG_SCHED_DS_READ(n) ((void)0)
+#define RG_SCHED_VMEM_READ(n) ((void)0)
+#define RG_SCHED_VALU(n) ((void)0)
+#define RG_SCHED_SALU(n) ((void)0)
 static inline unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
