@@ -27,6 +27,11 @@
 #ifndef RG_STAMP
 #define RG_STAMP(slot)
 #endif
+#ifndef RG_PHASE_INIT  // accumulating variant for loops (profiles/microbench/wgrad_phases.hip)
+#define RG_PHASE_INIT()
+#define RG_PHASE(i)
+#define RG_PHASE_FLUSH()
+#endif
 
 namespace rg {
 
@@ -678,27 +683,30 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging registers: 4096 16-byte units per stage / 512 threads
+  // staging registers: 4096 16-byte units per stage / 512 threads, TWO stages in flight (R0, R1):
+  // the operands come from HBM (~2.5-4.5k cycles under load) and a stage computes in ~1.8k, so a
+  // one-stage lead left every stage waiting on memory (phase timing, profiles/microbench/
+  // wgrad_phases: 16 % in the LDS store's wait + 37 % at the barrier behind the slowest wave).
+  // The loads are unconditional — out-of-range blocks / tiles read a clamped, valid address and the
+  // result is never used (tiles >= na only reach dW rows >= N, which are not stored; stages past the
+  // end are not computed) — so the compiler keeps counted s_waitcnt vmcnt(N) and storing R0 does not
+  // wait for R1's younger loads.
   constexpr int UNITS = WG_MB_STAGE * 2048, PER = UNITS / WG_THREADS;
-  u16x8 regs[PER];
-  auto gload = [&](int mb0) {
+  u16x8 R0[PER], R1[PER];
+  const int mb_last = mb_end - 1;
+  auto gload = [&](u16x8 (&regs)[PER], int mb0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int u = tid + i * WG_THREADS;
       const int mbl = u >> 11, w = u & 2047, isb = w >> 10, off = w & 1023;
-      const int tile = off >> 7, mb = mb0 + mbl;
-      u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (mb < mb_end) {
-        if (!isb) {
-          if (tile < na) v = *(const u16x8*)(g.a_frag + ((long)mb * g.NTa + ta0 + tile) * 1024 + (off & 127) * 8);
-        } else {
-          if (tile < nb) v = *(const u16x8*)(g.b_frag + ((long)mb * g.NTb + tb0 + tile) * 1024 + (off & 127) * 8);
-        }
-      }
-      regs[i] = v;
+      const int tile = off >> 7;
+      const int mb = mb0 + mbl < mb_last ? mb0 + mbl : mb_last;
+      const bf16_t* src = isb ? g.b_frag + ((long)mb * g.NTb + tb0 + (tile < nb ? tile : nb - 1)) * 1024
+                              : g.a_frag + ((long)mb * g.NTa + ta0 + (tile < na ? tile : na - 1)) * 1024;
+      regs[i] = *(const u16x8*)(src + (off & 127) * 8);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const u16x8 (&regs)[PER]) {
     char* base = smem + buf * WG_STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -706,8 +714,13 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
       *(u16x8*)(base + (long)u * 16) = regs[i];
     }
   };
+  // thin layers (dW 16x512, 512x128) fill only part of the 8x8 tile grid: a wave whose tiles are all
+  // padding skips its MFMAs, so those stages stop being MFMA-bound for nothing.  (Guarding single
+  // tiles inside a wave was tried: the accumulators fall into scratch, 5x slower.)
+  const bool wave_has_tiles = wn * 4 < na && wk * 2 < nb;
   auto compute = [&](int buf) {
     const char* base = smem + buf * WG_STAGE_BYTES;
+    if (!wave_has_tiles) return;
 #pragma unroll
     for (int mbl = 0; mbl < WG_MB_STAGE; ++mbl) {
 #pragma unroll
@@ -727,19 +740,37 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
     }
   };
 
+  RG_PHASE_INIT();
   if (mb_begin < mb_end) {
-    gload(mb_begin);
-    lstore(0);
-    if (mb_begin + WG_MB_STAGE < mb_end) gload(mb_begin + WG_MB_STAGE);
+    // stage t covers blocks [mb_begin + t*WG_MB_STAGE, +WG_MB_STAGE); LDS buffer t&1; at the top of an
+    // iteration pair R0 holds stage t+1 and R1 stage t+2
+    const int n_stages = (mb_end - mb_begin + WG_MB_STAGE - 1) / WG_MB_STAGE;
+    auto stage_mb = [&](int t) { return mb_begin + t * WG_MB_STAGE; };
+    gload(R0, stage_mb(0));
+    lstore(0, R0);
+    gload(R0, stage_mb(1));
+    gload(R1, stage_mb(2));
     __syncthreads();
-    int buf = 0;
-    for (int mb = mb_begin; mb < mb_end; mb += WG_MB_STAGE) {
-      compute(buf);
-      const bool has_next = mb + WG_MB_STAGE < mb_end;
-      if (has_next) lstore(buf ^ 1);
-      if (mb + 2 * WG_MB_STAGE < mb_end) gload(mb + 2 * WG_MB_STAGE);
+    RG_PHASE(0);
+    // per iteration: park the next stage in the idle LDS buffer and re-arm its registers FIRST (its
+    // data was requested two stages ago, so this does not wait), then compute: the LDS stores and the
+    // load issue of one wave run under the MFMAs of its SIMD partner, and the barrier only absorbs
+    // the compute skew
+    for (int t = 0; t < n_stages; t += 2) {
+      lstore(1, R0);
+      gload(R0, stage_mb(t + 3));
+      RG_PHASE(2);
+      compute(0);
+      RG_PHASE(1);
       __syncthreads();
-      buf ^= 1;
+      RG_PHASE(3);
+      lstore(0, R1);
+      gload(R1, stage_mb(t + 4));
+      RG_PHASE(2);
+      if (t + 1 < n_stages) compute(1);
+      RG_PHASE(1);
+      __syncthreads();
+      RG_PHASE(3);
     }
   }
 
@@ -755,6 +786,8 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
         if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
       }
     }
+  RG_PHASE(4);
+  RG_PHASE_FLUSH();
 }
 
 __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
