@@ -52,7 +52,9 @@ struct GatherTable {
 constexpr int GATHER_ROWS_PER_WG = 64;
 
 __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch) {
-  const rg_gather_col col = t.c[blockIdx.y];
+  // a reference: the fields are read from the kernel-argument segment with scalar loads (a by-value
+  // copy of a dynamically indexed element became a private array that LLVM promoted to 64 KB of LDS)
+  const rg_gather_col& col = t.c[blockIdx.y];
   const int row0 = blockIdx.x * GATHER_ROWS_PER_WG;
   const int nrows = (batch - row0 < GATHER_ROWS_PER_WG) ? batch - row0 : GATHER_ROWS_PER_WG;
   const long row_bytes = (long)col.row_elems * col.elem_bytes;
@@ -60,7 +62,77 @@ __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch)
   char* dst = (char*)col.dst;
   const bool vec16 = (row_bytes % 16 == 0) && ((((uintptr_t)src) & 15) == 0) &&
                      ((((uintptr_t)dst) & 15) == 0);
-  if (col.norm) {
+  // the workgroup's sampled indices, fetched once and coalesced: without this every 16-byte piece
+  // pays an index load and then a dependent row load (two serial memory latencies per piece)
+  __shared__ int64_t s_idx[GATHER_ROWS_PER_WG];
+  if ((int)threadIdx.x < nrows) s_idx[threadIdx.x] = col.indices[row0 + threadIdx.x];
+  __syncthreads();
+  constexpr int GU = 4;  // pieces per thread in flight (all loads issued before the first store)
+  if (col.norm && ((col.row_elems & 3) == 0) && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)dst) & 7) == 0)) {
+    // normalize-on-gather, aligned rows: 4 fp32 features per lane, op-code table applied in
+    // registers, optional bf16 output (the normalized fp32 matrix never exists in HBM)
+    const rg_norm_col* nc = (const rg_norm_col*)col.norm;
+    const int epr = col.row_elems, cpr = epr / 4;
+    if (blockDim.x % cpr == 0) {
+      // every thread keeps ONE 4-feature slot of the row for the whole workgroup: its four op-code
+      // descriptors are read once (not 96 B of table per 16 B of data) and no per-piece division
+      const int ch = threadIdx.x % cpr, rsub = threadIdx.x / cpr, rstep = blockDim.x / cpr;
+      rg_norm_col d[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = nc[ch * 4 + e];
+      for (int r0 = rsub; r0 < nrows; r0 += rstep * GU) {
+        f32x4 raw[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          const int r = r0 + u * rstep < nrows ? r0 + u * rstep : nrows - 1;
+          raw[u] = *(const f32x4*)((const float*)src + s_idx[r] * epr + ch * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          const int r = r0 + u * rstep;
+          if (r >= nrows) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = normalize_value(d[e], raw[u][e], 1.f, col.norm_quantiles);
+          if (col.out_dtype == RG_DT_BF16) {
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)((bf16_t*)dst + (long)(row0 + r) * epr + ch * 4) = o;
+          } else {
+            *(f32x4*)((float*)dst + (long)(row0 + r) * epr + ch * 4) = f32x4{v[0], v[1], v[2], v[3]};
+          }
+        }
+      }
+      return;
+    }
+    const int total = nrows * cpr;
+    for (int it0 = threadIdx.x; it0 < total; it0 += blockDim.x * GU) {
+      f32x4 raw[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int it = it0 + u * blockDim.x < total ? it0 + u * (int)blockDim.x : total - 1;
+        raw[u] = *(const f32x4*)((const float*)src + s_idx[it / cpr] * epr + (it % cpr) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int it = it0 + u * blockDim.x;
+        if (it >= total) continue;
+        const int r = it / cpr, ch = it % cpr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = normalize_value(nc[ch * 4 + e], raw[u][e], 1.f, col.norm_quantiles);
+        if (col.out_dtype == RG_DT_BF16) {
+          uint2 o;
+          o.x = pack_bf16x2(v[0], v[1]);
+          o.y = pack_bf16x2(v[2], v[3]);
+          *(uint2*)((bf16_t*)dst + (long)(row0 + r) * epr + ch * 4) = o;
+        } else {
+          *(f32x4*)((float*)dst + (long)(row0 + r) * epr + ch * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      }
+    }
+  } else if (col.norm) {
     // normalize-on-gather: 4 fp32 features per lane, op-code table applied in registers, optional
     // bf16 output (the network-ready layout: the normalized fp32 matrix never exists in HBM)
     const rg_norm_col* nc = (const rg_norm_col*)col.norm;
@@ -70,7 +142,7 @@ __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch)
     const bool v4 = ((epr & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
     for (int it = threadIdx.x; it < total; it += blockDim.x) {
       const int r = it / cpr, ch = it % cpr;
-      const int64_t idx = col.indices[row0 + r];
+      const int64_t idx = s_idx[r];
       const float* sp = (const float*)src + idx * epr + ch * 4;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (v4) {
@@ -102,11 +174,19 @@ __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch)
   } else if (vec16) {
     const int cpr = (int)(row_bytes / 16);
     const int total = nrows * cpr;
-    for (int it = threadIdx.x; it < total; it += blockDim.x) {
-      const int r = it / cpr, ch = it % cpr;
-      const int64_t idx = col.indices[row0 + r];
-      const uint4 v = *(const uint4*)(src + idx * row_bytes + (long)ch * 16);
-      *(uint4*)(dst + (long)(row0 + r) * row_bytes + (long)ch * 16) = v;
+    for (int it0 = threadIdx.x; it0 < total; it0 += blockDim.x * GU) {
+      f32x4 raw[GU];  // 16-byte carrier (a native vector: HIP's uint4 struct would not leave memory)
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int it = it0 + u * blockDim.x < total ? it0 + u * (int)blockDim.x : total - 1;
+        raw[u] = *(const f32x4*)(src + s_idx[it / cpr] * row_bytes + (long)(it % cpr) * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int it = it0 + u * blockDim.x;
+        if (it >= total) continue;
+        *(f32x4*)(dst + (long)(row0 + it / cpr) * row_bytes + (long)(it % cpr) * 16) = raw[u];
+      }
     }
   } else {
     const int eb = col.elem_bytes;
@@ -114,7 +194,7 @@ __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch)
     const int total = nrows * epr;
     for (int it = threadIdx.x; it < total; it += blockDim.x) {
       const int r = it / epr, e = it % epr;
-      const int64_t idx = col.indices[row0 + r];
+      const int64_t idx = s_idx[r];
       const char* s = src + idx * row_bytes + (long)e * eb;
       char* d = dst + (long)(row0 + r) * row_bytes + (long)e * eb;
       if (eb == 8) *(uint64_t*)d = *(const uint64_t*)s;

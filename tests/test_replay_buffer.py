@@ -143,14 +143,15 @@ def test_empty_and_unsupported(backend):
         ReplayBuffer(replay_capacity=10, return_as_timeline_format=True, device=backend.device)
 
 
-def test_normalize_on_gather_equals_gather_then_preprocessor(backend):
+@pytest.mark.parametrize("S", [24, 32])  # 4-feature slots per row: 6 (generic loop) / 8 (divides the workgroup: slot-per-thread path)
+def test_normalize_on_gather_equals_gather_then_preprocessor(backend, S):
     """Preprocessor.forward fused into the gather: bit-identical to gather -> Preprocessor (fp32),
     and to that result rounded to bf16 (the bf16 path's network-ready layout)."""
     from reagent_amd import synthetic
     from reagent_amd.core.parameters import NormalizationParameters as NP
     from reagent_amd.preprocessing import Preprocessor
 
-    C, S, A, B = 2048, 24, 4, 333
+    C, A, B = 2048, 4, 333
     cols = synthetic.replay_contents(C, S, A, seed=8)
     rb = ReplayBuffer(replay_capacity=C, batch_size=B, device=backend.device)
     rb.load_columns({k: v.to(backend.device) for k, v in cols.items()}, mark_all_valid=True)
