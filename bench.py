@@ -232,7 +232,8 @@ def main():
         dist.barrier()
     if rank == 0:
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if "roofline" in extra and os.path.exists(traffic_file):
+        # the committed PMC figure belongs to the fused forward (save=0) launch only
+        if "roofline" in extra and os.path.exists(traffic_file) and "forward_fused" in extra["roofline"].get("kernel", ""):
             try:
                 extra["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
             except Exception:

@@ -862,9 +862,10 @@ struct StageGroupArgs {
 
 // out[c] = sum_s partials[s][c], S x N row-major: 32 columns x 8 row-groups per workgroup, each
 // thread sums rows g, g+8, ... (independent loads in flight), groups combined in fixed order
-__global__ void reduce_cols_kernel(const float* __restrict__ partials, int S, int N, float* __restrict__ out) {
+__device__ __forceinline__ void reduce_cols_body(const float* __restrict__ partials, int S, int N,
+                                                 float* __restrict__ out, int block) {
   __shared__ float red[8][33];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  const int c = block * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < N) {
     int r = g;
@@ -884,6 +885,23 @@ __global__ void reduce_cols_kernel(const float* __restrict__ partials, int S, in
     for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
     out[c] = t;
   }
+}
+
+// bias gradients of every layer in one launch (four ~7 us launches were 4 % of a C2 step)
+struct ReduceColsGroupArgs {
+  int n;
+  int block_begin[FB_MAXL + 1];
+  const float* partials[FB_MAXL];
+  float* out[FB_MAXL];
+  int N[FB_MAXL];
+  int S;
+};
+__global__ void reduce_cols_group_kernel(ReduceColsGroupArgs G) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < FB_MAXL; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.block_begin[i]) l = i;
+  reduce_cols_body(G.partials[l], G.S, G.N[l], G.out[l], (int)blockIdx.x - G.block_begin[l]);
 }
 
 __global__ void reduce_splits2_kernel(const float* __restrict__ partials, long slab, int splits,
@@ -1086,12 +1104,22 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   rc = (int)hipGetLastError();
   if (rc) return rc;
+  ReduceColsGroupArgs G;
+  G.n = 0;
+  G.S = n_wg;
+  int blocks = 0;
   for (int l = 0; l < d->n_layers; ++l) {
     if (!a.db_part[l]) continue;
-    const int n = d->dims[l + 1];
-    RG_LAUNCH(reduce_cols_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), (hipStream_t)stream,
-              (const float*)a.db_part[l], n_wg, n, d->db[l]);
+    const int i = G.n++;
+    G.block_begin[i] = blocks;
+    G.partials[i] = a.db_part[l];
+    G.out[i] = d->db[l];
+    G.N[i] = d->dims[l + 1];
+    blocks += (d->dims[l + 1] + 31) / 32;
   }
+  for (int i = G.n; i <= FB_MAXL; ++i) G.block_begin[i] = blocks;
+  for (int i = G.n; i < FB_MAXL; ++i) { G.partials[i] = nullptr; G.out[i] = nullptr; G.N[i] = 0; }
+  if (G.n > 0) RG_LAUNCH(reduce_cols_group_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, G);
   return (int)hipGetLastError();
 }
 

@@ -240,6 +240,9 @@ class ReplayBuffer:
     def sample_index_batch(self, batch_size: int) -> torch.Tensor:
         if self._num_valid_indices == 0:
             raise RuntimeError(f"Cannot sample {batch_size} since there are no valid indices so far.")
+        if self._num_valid_indices == self._replay_capacity:
+            # every slot valid: valid_indices is arange(capacity), so valid_indices[pick] == pick
+            return torch.randint(self._replay_capacity, (batch_size,), device=self.device)
         valid_indices = self._valid_indices()
         pick = torch.randint(valid_indices.shape[0], (batch_size,), device=self.device)
         return valid_indices[pick]
