@@ -175,6 +175,30 @@ typedef struct {
 int rg_replay_gather(const rg_gather_col* cols /*host*/, int ncols, int64_t capacity, int stack,
                      int batch, rg_stream_t stream);
 
+/* ---- sum tree for prioritized replay ------------------------------------------------------ */
+
+/* Device-resident SumTree (reagent/replay_memory/sum_tree.py:30-189) backing
+ * PrioritizedReplayBuffer (reagent/replay_memory/prioritized_replay_buffer.py:30-185).
+ * `tree`: rg_sumtree_nodes(capacity) doubles in heap order (level d at offset 2^d - 1, leaves at
+ * level depth = rg_sumtree_depth(capacity) = ceil(log2(capacity))), zero-initialised by the caller.
+ * Updates of <= 32 pairs (or with claim == NULL) repeat the reference's delta accumulation exactly;
+ * larger batches write the leaves and rebuild node = left + right level by level (identical
+ * whenever the sums are exact in fp64, last-place differences otherwise). */
+int rg_sumtree_depth(int64_t capacity);
+size_t rg_sumtree_nodes(int64_t capacity);
+/* SumTree.set for n (index, value) pairs applied in order (a later pair overrides an earlier one on
+ * the same index), set_priority :146-157.  `claim`: int32 [2^depth] all -1, scratch for n > 32
+ * (returned all -1); nullable -> the in-order single-thread walk is used for any n. */
+int rg_sumtree_set(double* tree, int depth, const int64_t* indices, const double* values, int n,
+                   int* claim, rg_stream_t stream);
+/* SumTree.sample :97-131 for n query values in [0, 1] (each scaled by the root, then the
+ * reference's descent); stratified_sample :133-153 = queries drawn one per segment by the caller. */
+int rg_sumtree_sample(const double* tree, int depth, const double* query01, int n,
+                      int64_t* out_indices, rg_stream_t stream);
+/* leaf values: out32 (float32, get_priority :159-180) and/or out64; either nullable */
+int rg_sumtree_get(const double* tree, int depth, const int64_t* indices, int n, float* out32,
+                   double* out64, rg_stream_t stream);
+
 /* DiscreteDqnInputMaker (reagent/gym/preprocessors/trainer_preprocessor.py:72-97,118-158):
  * action / next_action [B] int64 -> one-hot fp32 [B, A] (next_action rows zeroed where terminal),
  * not_terminal [B] = 1 - terminal, action_probability [B] = exp(log_prob) (nullable). */

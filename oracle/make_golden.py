@@ -253,7 +253,82 @@ def gen_preprocessor():
           dict(x=_np(x), presence=_np(presence), out=_np(out)))
 
 
+def gen_sum_tree():
+    """reference SumTree (sum_tree.py) driven by seeded numpy / `random`: tree contents after a stream
+    of sets, descents for fixed query values, seeded stratified samples."""
+    import random
+
+    rh._install()
+    from reagent.replay_memory.sum_tree import SumTree
+
+    for name, cap, nset, exact in [("sumtree_dyadic_100", 100, 400, True), ("sumtree_real_1000", 1000, 3000, False)]:
+        rng = np.random.RandomState(11)
+        tree = SumTree(cap)
+        idx = rng.randint(cap, size=nset).astype(np.int64)
+        # dyadic priorities: every partial sum is exact in fp64, so any update order gives the same bits
+        val = (rng.randint(0, 64, size=nset) / 8.0) if exact else rng.rand(nset) * 3.0
+        for i, v in zip(idx, val):
+            tree.set(int(i), float(v))
+        q = np.concatenate([rng.rand(257), [0.0, 1.0, 0.5]])
+        samples = np.array([tree.sample(query_value=float(x)) for x in q], dtype=np.int64)
+        random.seed(5)
+        strat = np.array(tree.stratified_sample(64), dtype=np.int64)
+        arrays = dict(set_indices=idx, set_values=val.astype(np.float64), queries=q, samples=samples,
+                      stratified_seed5_b64=strat, leaves=np.array(tree.nodes[-1], dtype=np.float64),
+                      total=np.array(tree.nodes[0][0]), max_recorded=np.array(tree.max_recorded_priority))
+        for d, lvl in enumerate(tree.nodes):
+            arrays[f"level_{d}"] = np.array(lvl, dtype=np.float64)
+        _save(name, dict(capacity=cap, n_set=nset, exact=exact), arrays)
+
+
+def gen_prioritized():
+    """reference PrioritizedReplayBuffer: adds with priorities, set_priority, seeded sample_index_batch
+    (including invalid draws that go through the retry loop), sample_transition_batch."""
+    import random
+
+    rh._install()
+    from reagent.replay_memory.prioritized_replay_buffer import PrioritizedReplayBuffer
+
+    cap, B, obs_dim = 64, 16, 6
+    rb = PrioritizedReplayBuffer(stack_size=1, replay_capacity=cap, batch_size=B, update_horizon=2, gamma=0.9,
+                                 max_sample_attempts=200)
+    rng = np.random.RandomState(3)
+    adds = dict(observation=[], action=[], reward=[], terminal=[], priority=[])
+    for i in range(90):  # wraps the ring
+        tr = dict(observation=rng.randn(obs_dim).astype(np.float32), action=np.int64(rng.randint(4)),
+                  reward=np.float32(rng.rand()), terminal=bool(rng.rand() < 0.15),
+                  priority=np.float32(rng.randint(1, 32) / 4.0))
+        for k, v in tr.items():
+            adds[k].append(v)
+        rb.add(**tr)
+    arrays = {f"add_{k}": np.array(v) for k, v in adds.items()}
+    arrays["valid_mask"] = rb._is_index_valid.numpy()
+    arrays["leaves_after_add"] = np.array(rb.sum_tree.nodes[-1], dtype=np.float64)
+    upd_idx = rng.randint(cap, size=40).astype(np.int32)
+    upd_val = (rng.randint(0, 40, size=40) / 8.0).astype(np.float64)
+    rb.set_priority(upd_idx, upd_val)
+    arrays["upd_indices"], arrays["upd_values"] = upd_idx, upd_val
+    arrays["leaves_after_set"] = np.array(rb.sum_tree.nodes[-1], dtype=np.float64)
+    arrays["get_priority"] = rb.get_priority(np.arange(cap, dtype=np.int32))
+    random.seed(9)
+    idx = rb.sample_index_batch(B)
+    arrays["sample_index_seed9"] = idx.numpy()
+    random.seed(10)
+    batch = rb.sample_transition_batch(batch_size=B)
+    for k in batch._fields:
+        v = getattr(batch, k)
+        if isinstance(v, torch.Tensor):
+            arrays[f"out_{k}"] = v.numpy()
+    _save("prioritized_replay", dict(capacity=cap, batch=B, obs_dim=obs_dim, update_horizon=2, gamma=0.9,
+                                     max_sample_attempts=200), arrays)
+
+
 def main():
+    only = sys.argv[1:]  # e.g. `python -m oracle.make_golden sum_tree prioritized` regenerates only those
+    if only:
+        for n in only:
+            globals()["gen_" + n]()
+        return
     for n, c in DQN_CASES.items():
         gen_dqn(n, c)
     for n, c in QR_CASES.items():
@@ -263,6 +338,8 @@ def main():
     for n, c in REPLAY_CASES.items():
         gen_replay(n, c)
     gen_preprocessor()
+    gen_sum_tree()
+    gen_prioritized()
 
 
 if __name__ == "__main__":

@@ -105,6 +105,11 @@ SIGNATURES = {
     "rg_replay_nstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_replay_gather": (c_int, [ctypes.POINTER(GatherCol), c_int, c_i64, c_int, c_int, c_void_p]),
+    "rg_sumtree_depth": (c_int, [c_i64]),
+    "rg_sumtree_nodes": (c_sz, [c_i64]),
+    "rg_sumtree_set": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rg_sumtree_sample": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "rg_sumtree_get": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_make_dqn_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_normalize_dense": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,

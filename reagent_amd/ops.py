@@ -176,6 +176,32 @@ def replay_gather(cols, capacity: int, stack: int, batch: int):
              lambda: L.lib().rg_replay_gather(arr, len(chunk), capacity, stack, batch, L.stream_ptr()))
 
 
+def sumtree_set(tree, depth: int, indices, values, claim=None):
+    """SumTree.set for every (index, value) pair, in order (sum_tree.py:159-189)."""
+    _chk_dev(tree, indices, values, claim)
+    assert tree.dtype == torch.float64 and values.dtype == torch.float64 and indices.dtype == torch.int64
+    _run("rg_sumtree_set", dict(n=indices.numel()),
+         lambda: L.lib().rg_sumtree_set(L.ptr(tree), depth, L.ptr(indices), L.ptr(values), indices.numel(),
+                                        L.ptr(claim), L.stream_ptr()))
+
+
+def sumtree_sample(tree, depth: int, query01, out_indices):
+    """SumTree.sample for a batch of query values in [0, 1] (sum_tree.py:97-131)."""
+    _chk_dev(tree, query01, out_indices)
+    assert tree.dtype == torch.float64 and query01.dtype == torch.float64 and out_indices.dtype == torch.int64
+    _run("rg_sumtree_sample", dict(n=query01.numel()),
+         lambda: L.lib().rg_sumtree_sample(L.ptr(tree), depth, L.ptr(query01), query01.numel(), L.ptr(out_indices),
+                                           L.stream_ptr()))
+
+
+def sumtree_get(tree, depth: int, indices, out32=None, out64=None):
+    _chk_dev(tree, indices, out32, out64)
+    assert tree.dtype == torch.float64 and indices.dtype == torch.int64
+    _run("rg_sumtree_get", dict(n=indices.numel()),
+         lambda: L.lib().rg_sumtree_get(L.ptr(tree), depth, L.ptr(indices), indices.numel(), L.ptr(out32),
+                                        L.ptr(out64), L.stream_ptr()))
+
+
 def make_dqn_input(action, next_action, terminal, log_prob, num_actions, action_1h, next_action_1h,
                    not_terminal, action_probability=None):
     _chk_dev(action, next_action, terminal, log_prob, action_1h, next_action_1h, not_terminal,
