@@ -211,10 +211,12 @@ def main():
 
     for _ in range(args.warmup):
         loop.step()
+    loop.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = loop.step()
+    loop.flush()  # data parallel: the last step's update joins its all-reduce inside the timed region
     host_dt = time.perf_counter() - t0  # time the host needed to ENQUEUE the steps (diagnostic)
     barrier()
     dt = time.perf_counter() - t0

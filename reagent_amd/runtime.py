@@ -47,4 +47,11 @@ class OfflineDqnLoop:
         return inp
 
     def step(self, indices: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return self.trainer.train_step_native(self.make_batch(indices))
+        # data parallel: the previous step's gradient all-reduce is still in flight here, and the
+        # gather below does not depend on it — the trainer joins it right before Adam
+        batch = self.make_batch(indices)
+        return self.trainer.train_step_native(batch, defer_update=True)
+
+    def flush(self):
+        """apply an update left pending by the last step (call before reading parameters)"""
+        self.trainer.apply_pending_update()

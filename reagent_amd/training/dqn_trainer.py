@@ -134,12 +134,16 @@ class QStepCore(DQNTrainerBaseLightning):
         self._run_head(b, B, self._f32c(b.action), next_mask, boosts, gamma_exp)
         return self._loss
 
-    def _hip_backward(self, grad_out=None):
+    def _hip_backward(self, grad_out=None, async_reduce: bool = False):
         if grad_out is not None:
             self._dq.mul_(grad_out)
         self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
         if self._dp_group is not None:
-            torch.distributed.all_reduce(self._slab.grad, group=self._dp_group)
+            if async_reduce:  # runs on the collective's own stream; joined by apply_pending_update()
+                self._pending_reduce = torch.distributed.all_reduce(self._slab.grad, group=self._dp_group,
+                                                                   async_op=True)
+            else:
+                torch.distributed.all_reduce(self._slab.grad, group=self._dp_group)
         # publish the gradients: p.grad aliases the slab (accumulate into foreign .grad tensors)
         base = self._slab.grad.data_ptr()
         for i, p in enumerate(self._hip_params):
@@ -160,6 +164,7 @@ class QStepCore(DQNTrainerBaseLightning):
         return self
 
     def _hip_loss(self, batch):
+        self.apply_pending_update()  # a deferred native update must land before the next forward
         loss_buf = self._hip_forward(batch)
         return _HipLoss.apply(self, loss_buf, *self._hip_params)
 
@@ -170,19 +175,43 @@ class QStepCore(DQNTrainerBaseLightning):
         return self._native_opts
 
     @torch.no_grad()
-    def train_step_native(self, training_batch) -> torch.Tensor:
+    def train_step_native(self, training_batch, defer_update: bool = False) -> torch.Tensor:
         """forward + head + backward + Adam + soft update with no autograd graph, no generator and
-        no host synchronisation.  Returns the device-resident loss scalar (shape [1])."""
-        adam, soft = self.native_optimizers()
+        no host synchronisation.  Returns the device-resident loss scalar (shape [1]).
+
+        defer_update (data parallel only): the gradient all-reduce is launched asynchronously and
+        Adam + soft update are left pending until `apply_pending_update()` — which the next
+        `train_step_native` calls first.  The step sequence is unchanged (update k always precedes
+        forward k+1); what the caller gains is that whatever it enqueues between two steps (the next
+        batch's replay gather) runs under the all-reduce instead of after it."""
+        self.apply_pending_update()
         loss = self._hip_forward(training_batch)
         for p in self._hip_params:
             p.grad = None
-        self._hip_backward(None)
+        deferred = defer_update and self._dp_group is not None
+        self._hip_backward(None, async_reduce=deferred)
+        self._update_pending = True
+        if not deferred:
+            self.apply_pending_update()
+        return loss
+
+    _update_pending = False
+    _pending_reduce = None
+
+    @torch.no_grad()
+    def apply_pending_update(self):
+        """Adam + soft update of the last backward, after joining its gradient all-reduce."""
+        if not self._update_pending:
+            return
+        if self._pending_reduce is not None:
+            self._pending_reduce.wait()  # the compute stream waits for the collective; the host does not
+            self._pending_reduce = None
+        adam, soft = self.native_optimizers()
         adam.grad_scale = 1.0 / self._dp_world
         adam.step()
         soft.step()
         self.all_batches_processed += 1
-        return loss
+        self._update_pending = False
 
     def validation_step(self, batch, batch_idx):
         raise NotImplementedError("CPE / EvaluationDataPage is outside the hot path (SURVEY.md §3.4)")

@@ -22,7 +22,7 @@ def _build(kind):
     from reagent_amd.training import DQNTrainer, SACTrainer
 
     torch.manual_seed(0)  # identical initial weights on every rank
-    if kind == "dqn":
+    if kind.startswith("dqn"):
         q = FullyConnectedDQN(12, 4, [32, 16], ["relu", "relu"])
         return DQNTrainer(q, q.get_target_network(), None, actions=["a", "b", "c", "d"],
                           rl=RLParameters(gamma=0.9, target_update_rate=0.1, q_network_loss="huber"),
@@ -40,7 +40,7 @@ def _build(kind):
 def _batches(kind, B):
     from reagent_amd import synthetic
 
-    if kind == "dqn":
+    if kind.startswith("dqn"):
         return synthetic.dqn_batch(B, 12, 4, seed=5, p_impossible=0.2)
     return synthetic.policy_batch(B, 6, 2, seed=5)
 
@@ -48,7 +48,9 @@ def _batches(kind, B):
 def _step(kind, tr, d, noise=None):
     from reagent_amd import synthetic
 
-    if kind == "dqn":
+    if kind == "dqn_deferred":  # async all-reduce, Adam joined at the start of the next step
+        tr.train_step_native(synthetic.to_dqn_input(d), defer_update=True)
+    elif kind == "dqn":
         tr.train_step_native(synthetic.to_dqn_input(d))
     else:
         tr.train_step_native(synthetic.to_policy_input(d), noise[0], noise[1])
@@ -72,13 +74,16 @@ def _worker(rank, world, port, kind, out_dir):
     tr = _build(kind).enable_data_parallel()
     for _ in range(2):
         _step(kind, tr, half, my_noise)
+    if kind == "dqn_deferred":
+        assert tr._update_pending  # the last update is still waiting for its all-reduce
+        tr.apply_pending_update()
     torch.save([p.detach().clone() for p in tr.parameters()], os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["dqn", "sac"])
+@pytest.mark.parametrize("kind", ["dqn", "dqn_deferred", "sac"])
 def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib, kind):
-    port = 29500 + (os.getpid() % 2000) + (0 if kind == "dqn" else 1)
+    port = 29500 + (os.getpid() % 2000) + {"dqn": 0, "sac": 1, "dqn_deferred": 2}[kind]
     mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
@@ -92,5 +97,6 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib,
     tr = _build(kind)
     for _ in range(2):
         _step(kind, tr, full, noise)
+    tr.apply_pending_update() if kind == "dqn_deferred" else None
     for a, p in zip(r0, tr.parameters()):
         assert (a.double() - p.detach().double()).abs().max() <= 2e-6, kind
