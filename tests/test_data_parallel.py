@@ -100,3 +100,32 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib,
     tr.apply_pending_update() if kind == "dqn_deferred" else None
     for a, p in zip(r0, tr.parameters()):
         assert (a.double() - p.detach().double()).abs().max() <= 2e-6, kind
+
+
+@pytest.mark.gpu
+def test_rccl_async_reduce_single_rank_group():
+    """The RCCL code path on the real GPU (a 1-rank "nccl" group is all a 1-GPU box allows): the
+    deferred update with an asynchronous all-reduce gives the same parameters as the plain step."""
+    import reagent_amd._lib as L
+    from reagent_amd import synthetic
+
+    L.lib()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        d = {k: v.to(dev) for k, v in synthetic.dqn_batch(256, 12, 4, seed=5, p_impossible=0.2).items()}
+        plain = _build("dqn").to(dev)
+        dp = _build("dqn").to(dev).enable_data_parallel()
+        for _ in range(3):
+            plain.train_step_native(synthetic.to_dqn_input(d))
+            dp.train_step_native(synthetic.to_dqn_input(d), defer_update=True)
+        assert dp._update_pending
+        dp.apply_pending_update()
+        torch.cuda.synchronize()
+        for a, b in zip(plain.parameters(), dp.parameters()):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
