@@ -249,7 +249,8 @@ __device__ __forceinline__ int k_rotation(int wg, int wave, int KC) { return (wg
 // main loops no faster, so the fill stays at the top of the main loop.)
 template <int TN, int RING>
 __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave,
-                                              long nt_stride, f32x16 (&acc)[4][TN], int lane, int rot) {
+                                              long nt_stride, f32x16 (&acc)[4][TN], int lane, int rot,
+                                              int prio_phase = 0) {
   static_assert(RING >= 2 && RING % 2 == 0, "the A double buffer alternates with the ring slot parity");
   const int lr = lane & 31, lg = lane >> 5;
   auto kx = [&](int kc) { const int k = kc + rot; return k >= KC ? k - KC : k; };
@@ -285,6 +286,13 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
     loadA(a[0], 0);
     int kc = 0;
     for (; kc < KC - RING; kc += RING) {
+      // The SIMD arbitrates MFMA issue by priority, then age: left alone, the older wave of a pair
+      // takes ~63 % of the pipe and finishes its loop ~8k cycles before its partner, which then runs
+      // the tail alone at half rate.  The younger wave (prio_phase = 1) therefore runs the first half
+      // of its loop at raised priority and hands the advantage back for the second half, so the two
+      // finish together.
+      if (prio_phase && kc * 2 < KC) RG_SETPRIO(1);
+      else RG_SETPRIO(0);
 #pragma unroll
       for (int s = 0; s < RING; ++s) {
         loadB(b[(s + RING - 1) % RING], kc + s + RING - 1);
@@ -294,6 +302,7 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
         sched_fence();
       }
     }
+    RG_SETPRIO(0);
 #pragma unroll
     for (int s = 0; s < RING; ++s) {  // last block: only the loads that are still in range
       if (s == 0) loadB(b[RING - 1], kc + RING - 1);
@@ -516,7 +525,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
           for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
       const long nt_stride = (long)KC * 512;
       wide_mainloop<TN, RING>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
-                              k_rotation(blockIdx.x, wave, KC));
+                              k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
       RG_STAMP(2 + 4 * l);
       unsigned PK[4][TN][8];
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
@@ -597,7 +606,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
       for (int i = 0; i < 2 * TN; ++i) sg[i] = 0u;
     }
     wide_mainloop<TN, RING>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
-                            k_rotation(blockIdx.x, wave, KC));
+                            k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
     unsigned PK[4][TN][8];
     if (use_sign) {

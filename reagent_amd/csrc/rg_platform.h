@@ -69,6 +69,8 @@ __device__ __forceinline__ int opaque(int x) {
 }
 // scheduling fence: nothing is moved across it (pins "issue the loads, then the MFMA block")
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// wave priority for the SIMD's issue arbitration (0..3)
+#define RG_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // scheduling-group hints (instruction classes of __builtin_amdgcn_sched_group_barrier)
 #define RG_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define RG_SCHED_DS_READ(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)

@@ -92,6 +92,7 @@ static inline bf16_t f32_to_bf16(float f) {
 static inline int lane_id() { return ::emu::cur().linear_tid & 63; }
 static inline int opaque(int x) { return x; }
 static inline void sched_fence() {}
+#define RG_SETPRIO(n) ((void)0)
 #define RG_SCHED_MFMA(n) ((void)0)
 #define RG_SCHED_DS_READ(n) ((void)0)
 #define RG_SCHED_VMEM_READ(n) ((void)0)
