@@ -248,6 +248,24 @@ int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, 
                 int num_actions, int double_q, int loss_type, float* dq, float* loss_partials,
                 float* next_q, int64_t* next_idx, float* q_sel, rg_stream_t stream);
 
+/* CPE heads of the DQN step, _calculate_cpes (reagent/training/dqn_trainer_base.py:338-452) with
+ * masked_softmax (reagent/core/torch_utils.py:62-73): reward-network MSE and CPE q-network loss on the
+ * logged action's column of each of the M metrics, and both output gradients.
+ * reward_est, q_cpe, q_cpe_tgt_next [B, M*A] fp32 = reward_network(state), q_network_cpe(state),
+ * q_network_cpe_target(next_state); next_scores [B, A] = q_network(next_state) (after the q step);
+ * next_mask [B, A] = possible_next_actions_mask (maxq) or next_action (SARSA); action [B, A] one-hot;
+ * reward [B] (unboosted), extra_metrics [B, M-1] or NULL (M == 1); discount as in rg_dqn_head.
+ * Outputs: d_reward_est, d_q_cpe [B, M*A] = d(mean loss)/d output; reward_partials, cpe_partials
+ * [rg_dqn_head_partials(B)] whose ordered sums / (B*M) are the two losses; propensities_out [B, A]
+ * (nullable) = model propensities of the next states. */
+int rg_cpe_head(const float* reward_est, const float* q_cpe, const float* q_cpe_tgt_next,
+                const float* next_scores, const float* next_mask, const float* action,
+                const float* reward, const float* extra_metrics, const float* not_terminal, double gamma,
+                const float* gamma_exponent, double temperature, int batch, int num_actions,
+                int num_metrics, int loss_type, float* d_reward_est, float* d_q_cpe,
+                float* reward_partials, float* cpe_partials, float* propensities_out,
+                rg_stream_t stream);
+
 /* QR-DQN head, reagent/training/qrdqn_trainer.py:108-160 (+ argmax_with_mask :210-214, huber
  * :217-218, quantiles :70-73).  q / qn_online / qn_target [B, A*N] fp32 = network outputs viewed
  * (B, A, N); qn_online NULL = select the next action with the target net (double_q off).

@@ -45,6 +45,16 @@ DQN_CASES = {
                                 rl=dict(gamma=0.95, target_update_rate=0.1, maxq_learning=False,
                                         q_network_loss="mse", multi_steps=3),
                                 lr=0.003, double_q=True, batch=50, steps=2, p_impossible=0.0, with_steps=True),
+    # calc_cpe_in_training: reward network + CPE q-network with one extra metric, masked next actions
+    "dqn_cpe": dict(state_dim=9, num_actions=3, sizes=[32, 24], activations=["relu", "leaky_relu"],
+                    rl=dict(gamma=0.95, target_update_rate=0.1, maxq_learning=True, q_network_loss="huber",
+                            temperature=0.7),
+                    lr=0.002, double_q=True, batch=80, steps=3, p_impossible=0.3, with_steps=False,
+                    cpe_metrics=["clicks"]),
+    "dqn_cpe_sarsa_mse": dict(state_dim=6, num_actions=4, sizes=[16], activations=["tanh"],
+                              rl=dict(gamma=0.9, target_update_rate=0.3, maxq_learning=False, q_network_loss="mse"),
+                              lr=0.005, double_q=False, batch=40, steps=2, p_impossible=0.0, with_steps=False,
+                              cpe_metrics=[]),
     "dqn_timediff": dict(state_dim=7, num_actions=4, sizes=[24], activations=["relu"],
                          rl=dict(gamma=0.9, target_update_rate=0.5, maxq_learning=True,
                                  q_network_loss="huber", use_seq_num_diff_as_time_diff=True),
@@ -52,16 +62,25 @@ DQN_CASES = {
 }
 
 
+CPE_NETS = ("reward_network", "q_network_cpe", "q_network_cpe_target")
+
+
 def gen_dqn(name, c):
+    cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
-                      double_q=c["double_q"], seed=0)
+                      double_q=c["double_q"], seed=0, cpe_metrics=cpe_metrics)
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
+    if cpe_metrics is not None:
+        for net in CPE_NETS:
+            for i, p in enumerate(getattr(tr, net).parameters()):
+                arrays[f"init_{net}_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
     for s in range(c["steps"]):
         b = synthetic.dqn_batch(c["batch"], c["state_dim"], c["num_actions"], seed=100 + s,
-                                p_impossible=c["p_impossible"], with_steps=c["with_steps"])
+                                p_impossible=c["p_impossible"], with_steps=c["with_steps"],
+                                n_extra_metrics=len(cpe_metrics or []))
         for k, v in b.items():
             arrays[f"step{s}_batch_{k}"] = _np(v)
         losses = loop.step(rh.dqn_batch_to_reference(b))
@@ -71,6 +90,11 @@ def gen_dqn(name, c):
             arrays[f"step{s}_param_{i}"] = _np(p)
         for i, p in enumerate(tr.q_network_target.parameters()):
             arrays[f"step{s}_target_{i}"] = _np(p)
+        if cpe_metrics is not None:  # optimizer order: q, reward, cpe, soft update
+            arrays[f"step{s}_reward_loss"], arrays[f"step{s}_cpe_loss"] = _np(losses[1]), _np(losses[2])
+            for net in CPE_NETS:
+                for i, p in enumerate(getattr(tr, net).parameters()):
+                    arrays[f"step{s}_{net}_{i}"] = _np(p)
     adam = loop.optimizers[0]
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"final_exp_avg_{i}"] = _np(adam.state[p]["exp_avg"])

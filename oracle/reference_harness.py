@@ -81,8 +81,11 @@ def make_adam(lr=1e-3, **kw):
 
 
 def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_q=True, seed=0,
-              num_atoms=None):
-    """Reference FullyConnectedDQN (+ target) and DQNTrainer / QRDQNTrainer, CPE off."""
+              num_atoms=None, cpe_metrics=None):
+    """Reference FullyConnectedDQN (+ target) and DQNTrainer / QRDQNTrainer.  cpe_metrics: None = CPE
+    off; a list of extra metric names (may be empty) = calc_cpe_in_training with reward_network,
+    q_network_cpe and its target of output width (len(cpe_metrics) + 1) * num_actions
+    (model_managers/discrete/discrete_dqn.py:84-104)."""
     _install()
     from reagent.core.parameters import EvaluationParameters
     from reagent.models.dqn import FullyConnectedDQN
@@ -91,12 +94,20 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
     q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
     qt = q.get_target_network()
     actions = [str(i) for i in range(num_actions)]
+    cpe = cpe_metrics is not None
     common = dict(actions=actions, rl=make_rl_parameters(**rl_kwargs), double_q_learning=double_q,
-                  optimizer=make_adam(lr), evaluation=EvaluationParameters(calc_cpe_in_training=False))
+                  optimizer=make_adam(lr), evaluation=EvaluationParameters(calc_cpe_in_training=cpe))
     if num_atoms is None:
         from reagent.training.dqn_trainer import DQNTrainer
 
-        trainer = DQNTrainer(q, qt, None, **common)
+        if cpe:
+            n_out = (len(cpe_metrics) + 1) * num_actions
+            reward_net = FullyConnectedDQN(state_dim, n_out, sizes, activations)
+            q_cpe = FullyConnectedDQN(state_dim, n_out, sizes, activations)
+            trainer = DQNTrainer(q, qt, reward_net, q_network_cpe=q_cpe, q_network_cpe_target=q_cpe.get_target_network(),
+                                 metrics_to_score=list(cpe_metrics), **common)
+        else:
+            trainer = DQNTrainer(q, qt, None, **common)
     else:
         from reagent.training.qrdqn_trainer import QRDQNTrainer
 
@@ -128,7 +139,7 @@ def dqn_batch_to_reference(b: dict):
         reward=b["reward"], time_diff=b["time_diff"], step=b["step"], not_terminal=b["not_terminal"],
         action=b["action"], next_action=b["next_action"], possible_actions_mask=b["possible_actions_mask"],
         possible_next_actions_mask=b["possible_next_actions_mask"],
-        extras=rlt.ExtraData(action_probability=torch.ones_like(b["reward"])),
+        extras=rlt.ExtraData(action_probability=torch.ones_like(b["reward"]), metrics=b.get("metrics")),
     )
 
 

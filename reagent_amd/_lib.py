@@ -116,6 +116,8 @@ SIGNATURES = {
                                     c_void_p, c_i64, c_int, c_void_p]),
     "rg_dqn_head_partials": (c_int, [c_int]),
     "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "rg_cpe_head": (c_int, [c_void_p] * 9 + [ctypes.c_double, c_void_p, ctypes.c_double, c_int, c_int, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_qr_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
     "rg_gaussian_head_forward": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p,

@@ -112,6 +112,98 @@ __global__ void dqn_head_kernel(const float* __restrict__ q, const float* __rest
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = s;
 }
 
+// CPE heads of the DQN step (reagent/training/dqn_trainer_base.py:338-452, _calculate_cpes): one
+// thread per transition, M metrics x A actions.
+//   propensities = masked_softmax(all_next_action_scores, next_mask, temperature)
+//                  (core/torch_utils.py:62-73: x/T, -(1-mask)*1e20, -rowmax, exp, *mask, /sum, NaN->0)
+//   reward net   : mse(reward_est[b, i*A + a_b], real[b, i]),                  a_b = argmax(action[b])
+//   CPE q-net    : loss(q_cpe[b, i*A + a_b],
+//                       real[b, i] + discount_b * not_done_b * sum_a tgt_next[b, i*A + a] * prop[a])
+//   real[b, 0] = reward[b] (unboosted), real[b, i >= 1] = extra_metrics[b, i-1]
+// Writes both gradients w.r.t. the network outputs (zero except the logged action's column of
+// every metric) and per-workgroup loss partials (means are over B*M elements).
+__global__ void cpe_head_kernel(const float* __restrict__ reward_est, const float* __restrict__ q_cpe,
+                                const float* __restrict__ q_cpe_tgt_next, const float* __restrict__ next_scores,
+                                const float* __restrict__ next_mask, const float* __restrict__ action,
+                                const float* __restrict__ reward, const float* __restrict__ extra_metrics,
+                                const float* __restrict__ not_terminal, float gamma,
+                                const float* __restrict__ gamma_exponent, float temperature, int batch, int A,
+                                int M, int loss_type, float* __restrict__ d_reward_est, float* __restrict__ d_q_cpe,
+                                float* __restrict__ reward_partials, float* __restrict__ cpe_partials,
+                                float* __restrict__ propensities_out) {
+  __shared__ float scratch[4];
+  const int b = blockIdx.x * HEAD_THREADS + threadIdx.x;
+  float loss_r = 0.f, loss_c = 0.f;
+  if (b < batch) {
+    const long o = (long)b * A, om = (long)b * M * A;
+    // logged action = first maximal entry of the action row (torch.argmax)
+    int a_log = 0;
+    float a_best = action[o];
+    for (int a = 1; a < A; ++a)
+      if (action[o + a] > a_best) {
+        a_best = action[o + a];
+        a_log = a;
+      }
+    // masked softmax, pass 1: row max of x/T - (1-mask)*1e20 ; pass 2: sum of exp * mask
+    float mx = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float v = next_scores[o + a] / temperature - ((1.0f - next_mask[o + a]) * 1e20f);
+      if (a == 0 || v > mx) mx = v;
+    }
+    float den = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float v = next_scores[o + a] / temperature - ((1.0f - next_mask[o + a]) * 1e20f);
+      den += expf(v - mx) * next_mask[o + a];
+    }
+    if (propensities_out)
+      for (int a = 0; a < A; ++a) {
+        const float v = next_scores[o + a] / temperature - ((1.0f - next_mask[o + a]) * 1e20f);
+        const float p = expf(v - mx) * next_mask[o + a] / den;
+        propensities_out[o + a] = p != p ? 0.f : p;
+      }
+    const float disc = gamma_exponent ? powf(gamma, gamma_exponent[b]) : gamma;
+    const float nd = not_terminal[b];
+    const float inv = 1.f / ((float)batch * (float)M);
+    for (int i = 0; i < M; ++i) {
+      const float real = i == 0 ? reward[b] : extra_metrics[(long)b * (M - 1) + (i - 1)];
+      for (int a = 0; a < A; ++a) {
+        d_reward_est[om + (long)i * A + a] = 0.f;
+        d_q_cpe[om + (long)i * A + a] = 0.f;
+      }
+      const long at = om + (long)i * A + a_log;
+      const float dr = reward_est[at] - real;  // F.mse_loss
+      loss_r += dr * dr;
+      d_reward_est[at] = 2.f * dr * inv;
+      float nextq = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float v = next_scores[o + a] / temperature - ((1.0f - next_mask[o + a]) * 1e20f);
+        float p = expf(v - mx) * next_mask[o + a] / den;
+        p = p != p ? 0.f : p;
+        nextq += q_cpe_tgt_next[om + (long)i * A + a] * p;
+      }
+      nextq *= nd;
+      const float target = real + disc * nextq;
+      const float d = q_cpe[at] - target;
+      float g;
+      if (loss_type == RG_LOSS_HUBER) {
+        const float ad = fabsf(d);
+        loss_c += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+        g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+      } else {
+        loss_c += d * d;
+        g = 2.f * d;
+      }
+      d_q_cpe[at] = g * inv;
+    }
+  }
+  const float sr = block_sum_256(loss_r, scratch);
+  const float sc = block_sum_256(loss_c, scratch);
+  if (threadIdx.x == 0) {
+    reward_partials[blockIdx.x] = sr;
+    cpe_partials[blockIdx.x] = sc;
+  }
+}
+
 // QR-DQN head (reagent/training/qrdqn_trainer.py:108-160): one workgroup per transition.
 //   next atoms : target(next_state)[b, a*, :] with a* = argmax_a mean_atoms(online or target)(+mask)
 //                (maxq) or sum_a target[b,a,:] * next_action[b,a] (SARSA)
@@ -246,6 +338,23 @@ int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, 
             (hipStream_t)stream, q, qn_online, qn_target, action, next_mask, reward, reward_boosts,
             not_terminal, (float)gamma, gamma_exponent, batch, num_actions, double_q, loss_type, dq,
             loss_partials, next_q, next_idx, q_sel);
+  return (int)hipGetLastError();
+}
+
+int rg_cpe_head(const float* reward_est, const float* q_cpe, const float* q_cpe_tgt_next, const float* next_scores,
+                const float* next_mask, const float* action, const float* reward, const float* extra_metrics,
+                const float* not_terminal, double gamma, const float* gamma_exponent, double temperature, int batch,
+                int num_actions, int num_metrics, int loss_type, float* d_reward_est, float* d_q_cpe,
+                float* reward_partials, float* cpe_partials, float* propensities_out, rg_stream_t stream) {
+  if (!reward_est || !q_cpe || !q_cpe_tgt_next || !next_scores || !next_mask || !action || !reward || !not_terminal ||
+      !d_reward_est || !d_q_cpe || !reward_partials || !cpe_partials || batch <= 0 || num_actions <= 0 ||
+      num_metrics <= 0 || (num_metrics > 1 && !extra_metrics))
+    return RG_EINVAL;
+  if (loss_type != RG_LOSS_MSE && loss_type != RG_LOSS_HUBER) return RG_EINVAL;
+  RG_LAUNCH(cpe_head_kernel, dim3(rg_dqn_head_partials(batch)), dim3(HEAD_THREADS), (hipStream_t)stream, reward_est,
+            q_cpe, q_cpe_tgt_next, next_scores, next_mask, action, reward, extra_metrics, not_terminal, (float)gamma,
+            gamma_exponent, (float)temperature, batch, num_actions, num_metrics, loss_type, d_reward_est, d_q_cpe,
+            reward_partials, cpe_partials, propensities_out);
   return (int)hipGetLastError();
 }
 

@@ -244,6 +244,27 @@ def dqn_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, 
                                      L.ptr(next_idx), L.ptr(q_sel), L.stream_ptr()))
 
 
+def cpe_head(reward_est, q_cpe, q_cpe_tgt_next, next_scores, next_mask, action, reward, extra_metrics,
+             not_terminal, gamma, gamma_exponent, temperature, num_metrics, loss_type, d_reward_est, d_q_cpe,
+             reward_partials, cpe_partials, propensities_out=None):
+    _chk_dev(reward_est, q_cpe, q_cpe_tgt_next, next_scores, next_mask, action, reward, extra_metrics,
+             not_terminal, gamma_exponent, d_reward_est, d_q_cpe, reward_partials, cpe_partials, propensities_out)
+    batch, A = action.shape
+    M = num_metrics
+    for t in (reward_est, q_cpe, q_cpe_tgt_next, d_reward_est, d_q_cpe):
+        assert t.is_contiguous() and t.dtype == F32 and t.shape == (batch, M * A)
+    for t in (next_scores, next_mask, action):
+        assert t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A)
+    assert extra_metrics is None or (extra_metrics.is_contiguous() and extra_metrics.shape == (batch, M - 1))
+    _run("rg_cpe_head", dict(B=batch, A=A, M=M),
+         lambda: L.lib().rg_cpe_head(L.ptr(reward_est), L.ptr(q_cpe), L.ptr(q_cpe_tgt_next), L.ptr(next_scores),
+                                     L.ptr(next_mask), L.ptr(action), L.ptr(reward), L.ptr(extra_metrics),
+                                     L.ptr(not_terminal), float(gamma), L.ptr(gamma_exponent), float(temperature),
+                                     batch, A, M, loss_type, L.ptr(d_reward_est), L.ptr(d_q_cpe),
+                                     L.ptr(reward_partials), L.ptr(cpe_partials), L.ptr(propensities_out),
+                                     L.stream_ptr()))
+
+
 def qr_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma,
             gamma_exponent, quantiles, num_atoms, maxq, dq, loss_partials, all_q=None):
     _chk_dev(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma_exponent,

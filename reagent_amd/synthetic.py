@@ -8,7 +8,8 @@ import torch.nn.functional as F
 
 
 def dqn_batch(batch: int, state_dim: int, num_actions: int, seed: int = 0, p_terminal: float = 0.1,
-              p_impossible: float = 0.0, with_steps: bool = False) -> Dict[str, torch.Tensor]:
+              p_impossible: float = 0.0, with_steps: bool = False,
+              n_extra_metrics: int = 0) -> Dict[str, torch.Tensor]:
     """Fields of rlt.DiscreteDqnInput as a plain dict of CPU fp32 tensors."""
     g = torch.Generator().manual_seed(seed)
     state = torch.randn(batch, state_dim, generator=g)
@@ -28,9 +29,12 @@ def dqn_batch(batch: int, state_dim: int, num_actions: int, seed: int = 0, p_ter
     else:
         step = torch.ones(batch, 1)
         time_diff = torch.ones(batch, 1)
-    return dict(state=state, next_state=next_state, reward=reward, not_terminal=not_terminal,
-                action=action, next_action=next_action, possible_actions_mask=torch.ones(batch, num_actions),
-                possible_next_actions_mask=pna, step=step, time_diff=time_diff)
+    out = dict(state=state, next_state=next_state, reward=reward, not_terminal=not_terminal,
+               action=action, next_action=next_action, possible_actions_mask=torch.ones(batch, num_actions),
+               possible_next_actions_mask=pna, step=step, time_diff=time_diff)
+    if n_extra_metrics:  # extras.metrics of the CPE heads (drawn last: earlier fields keep their values)
+        out["metrics"] = torch.rand(batch, n_extra_metrics, generator=g)
+    return out
 
 
 def policy_batch(batch: int, state_dim: int, action_dim: int, seed: int = 0,
@@ -58,7 +62,8 @@ def to_dqn_input(d: Dict[str, torch.Tensor], device=None):
         not_terminal=t(d["not_terminal"]), action=t(d["action"]), next_action=t(d["next_action"]),
         possible_actions_mask=t(d["possible_actions_mask"]),
         possible_next_actions_mask=t(d["possible_next_actions_mask"]),
-        extras=rlt.ExtraData(action_probability=t(torch.ones_like(d["reward"]))),
+        extras=rlt.ExtraData(action_probability=t(torch.ones_like(d["reward"])),
+                             metrics=t(d["metrics"]) if "metrics" in d else None),
     )
 
 

@@ -46,6 +46,120 @@ class _HipLoss(torch.autograd.Function):
         return (None, None) + (None,) * len(ctx.owner._hip_params)
 
 
+class _SegmentLoss(torch.autograd.Function):
+    """Scalar loss whose backward runs a HIP backward closure (writes ``.grad`` in place)."""
+
+    @staticmethod
+    def forward(ctx, closure, loss_buf, *params):
+        ctx.closure = closure
+        ctx.n = len(params)
+        return loss_buf.detach().clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.closure(grad_out)
+        return (None, None) + (None,) * ctx.n
+
+
+class _CpeEngine:
+    """The CPE part of the DQN step (reagent/training/dqn_trainer_base.py:338-452, `_calculate_cpes`):
+    reward network and CPE q-network on `state`, CPE target network on `next_state`, the 4th forward
+    `q_network(next_state)` with the weights the q step just produced, all losses and output
+    gradients in one rg_cpe_head launch, then the two FC backward passes."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self._ws_batch = -1
+
+    @staticmethod
+    def _net_engine(net):
+        params = list(net.parameters())
+        slab = ensure_slab(params)
+        lin = net.fc.linears()
+        index = {id(p): i for i, p in enumerate(params)}
+        return dict(params=params, slab=slab, stack=net.fc.stack(),
+                    dw=[slab.view(slab.grad, index[id(l.weight)]) for l in lin],
+                    db=[slab.view(slab.grad, index[id(l.bias)]) for l in lin])
+
+    def _engine(self, B, dev):
+        tr = self.tr
+        self.e = dict(reward=self._net_engine(tr.reward_network), cpe=self._net_engine(tr.q_network_cpe))
+        self.t = tr.q_network_cpe_target.fc.stack()
+        if self._ws_batch != B or self.reward_est.device != dev:
+            A, M = tr.num_actions, len(tr.metrics_to_score)
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.reward_est, self.q_cpe, self.q_cpe_tgt, self.d_reward, self.d_cpe = (
+                torch.empty(B, M * A, **f32) for _ in range(5))
+            self.next_scores = torch.empty(B, A, **f32)
+            P = ops.dqn_head_partials(B)
+            self.parts = dict(reward=torch.empty(P, **f32), cpe=torch.empty(P, **f32))
+            self.losses = dict(reward=torch.empty(1, **f32), cpe=torch.empty(1, **f32))
+            self._ws_batch = B
+
+    def forward(self, b, need_propensities: bool = False):
+        tr = self.tr
+        state, next_state = tr._net_in(b.state.float_features), tr._net_in(b.next_state.float_features)
+        B, dev = state.shape[0], state.device
+        self._engine(B, dev)
+        A, M = tr.num_actions, len(tr.metrics_to_score)
+        # all_next_action_scores = q_network(next_state) AFTER the q-network step (dqn_trainer.py:268)
+        qs = tr._qs
+        qs.stage_weights(need_transposed=True)
+        xn, _ = qs.stage_input(next_state, need_transposed=False)
+        qs.forward(xn, self.next_scores, save=False)
+        for k in ("reward", "cpe"):
+            self.e[k]["stack"].stage_weights(need_transposed=True)
+        self.t.stage_weights(need_transposed=False)
+        rs, cs = self.e["reward"]["stack"], self.e["cpe"]["stack"]
+        xs_r, self._xs_t_r = rs.stage_input(state, need_transposed=True)
+        rs.forward(xs_r, self.reward_est, save=True)
+        xs_c, self._xs_t_c = cs.stage_input(state, need_transposed=True)
+        cs.forward(xs_c, self.q_cpe, save=True)
+        xn_t, _ = self.t.stage_input(next_state, need_transposed=False)
+        self.t.forward(xn_t, self.q_cpe_tgt, save=False)
+        extras = getattr(b, "extras", None)
+        metrics = getattr(extras, "metrics", None) if extras is not None else None
+        if M > 1:
+            assert metrics is not None and metrics.shape == (B, M - 1), "extras.metrics must hold the extra CPE metrics"
+            metrics = tr._f32c(metrics)
+        else:
+            metrics = None
+        gamma_exp = None
+        if tr.use_seq_num_diff_as_time_diff:
+            gamma_exp = tr._f32c(b.time_diff).reshape(-1)
+        if tr.multi_steps is not None:
+            gamma_exp = tr._f32c(b.step).reshape(-1)
+        next_mask = tr._f32c(b.possible_next_actions_mask if tr.maxq_learning else b.next_action)
+        self.propensities = torch.empty(B, A, dtype=torch.float32, device=dev) if need_propensities else None
+        ops.cpe_head(self.reward_est, self.q_cpe, self.q_cpe_tgt, self.next_scores, next_mask, tr._f32c(b.action),
+                     tr._f32c(b.reward).reshape(-1), metrics, tr._f32c(b.not_terminal).reshape(-1), tr.gamma,
+                     gamma_exp, tr.rl_temperature, M, tr._loss_type, self.d_reward, self.d_cpe,
+                     self.parts["reward"], self.parts["cpe"], self.propensities)
+        for k in ("reward", "cpe"):
+            ops.reduce_sum(self.parts[k], self.parts[k].numel(), 1.0 / (B * M), self.losses[k])
+
+    def backward(self, which, grad_out=None):
+        e = self.e[which]
+        d = self.d_reward if which == "reward" else self.d_cpe
+        if grad_out is not None:
+            d = d * grad_out
+        e["stack"].backward(d, self._xs_t_r if which == "reward" else self._xs_t_c, e["dw"], e["db"])
+        slab = e["slab"]
+        if self.tr._dp_group is not None:
+            torch.distributed.all_reduce(slab.grad, group=self.tr._dp_group)
+        base = slab.grad.data_ptr()
+        for i, p in enumerate(e["params"]):
+            gv = slab.view(slab.grad, i)
+            if p.grad is None or p.grad.data_ptr() == base + 4 * slab.offsets[i]:
+                p.grad = gv
+            else:
+                p.grad.add_(gv)
+
+    def loss(self, which):
+        e = self.e[which]
+        return _SegmentLoss.apply(lambda g: self.backward(which, g), self.losses[which], *e["params"])
+
+
 class QStepCore(DQNTrainerBaseLightning):
     """Engine shared by DQNTrainer and QRDQNTrainer: flat parameter slab, FC stacks, the
     3-forward / head / backward sequence, the autograd bridge and the fused native step.
@@ -191,6 +305,7 @@ class QStepCore(DQNTrainerBaseLightning):
         deferred = defer_update and self._dp_group is not None
         self._hip_backward(None, async_reduce=deferred)
         self._update_pending = True
+        self._pending_batch = training_batch if getattr(self, "_cpe", None) is not None else None
         if not deferred:
             self.apply_pending_update()
         return loss
@@ -206,9 +321,20 @@ class QStepCore(DQNTrainerBaseLightning):
         if self._pending_reduce is not None:
             self._pending_reduce.wait()  # the compute stream waits for the collective; the host does not
             self._pending_reduce = None
-        adam, soft = self.native_optimizers()
+        opts = self.native_optimizers()
+        adam, soft = opts[0], opts[-1]
         adam.grad_scale = 1.0 / self._dp_world
         adam.step()
+        cpe = getattr(self, "_cpe", None)
+        if cpe is not None:  # reward network and CPE q-network, in the reference's optimizer order
+            cpe.forward(self._pending_batch)
+            for which, opt in (("reward", opts[1]), ("cpe", opts[2])):
+                for p in cpe.e[which]["params"]:
+                    p.grad = None
+                cpe.backward(which)
+                opt.grad_scale = 1.0 / self._dp_world
+                opt.step()
+            self._pending_batch = None
         soft.step()
         self.all_batches_processed += 1
         self._update_pending = False
@@ -251,7 +377,8 @@ class DQNTrainer(QStepCore):
         self.q_network = q_network
         self.q_network_target = q_network_target
         self.q_network_optimizer = optimizer
-        self._reject_cpe(reward_network, q_network_cpe, q_network_cpe_target)
+        self._initialize_cpe(reward_network, q_network_cpe, q_network_cpe_target, optimizer=optimizer)
+        self._cpe = _CpeEngine(self) if self.calc_cpe_in_training else None
 
         self.bcq = bcq is not None
         if self.bcq:
@@ -295,11 +422,42 @@ class DQNTrainer(QStepCore):
         head from the batch itself; the two extra arguments are accepted for signature parity."""
         return self._hip_loss(batch)
 
+    def configure_optimizers(self):
+        """dqn_trainer.py:119-155: [q_network, (reward_network, q_network_cpe,) soft update]"""
+        optimizers = []
+        target_params = list(self.q_network_target.parameters())
+        source_params = list(self.q_network.parameters())
+        optimizers.append(self.q_network_optimizer.make_optimizer_scheduler(self.q_network.parameters()))
+        if self.calc_cpe_in_training:
+            cpe_target_params, cpe_source_params, cpe_optimizers = self._configure_cpe_optimizers()
+            target_params += cpe_target_params
+            source_params += cpe_source_params
+            optimizers += cpe_optimizers
+        optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
+        return optimizers
+
     def train_step_gen(self, training_batch: rlt.DiscreteDqnInput, batch_idx: int):
         self._check_input(training_batch)
         td_loss = self.compute_td_loss(training_batch)
         yield td_loss
         td_loss = td_loss.detach()
+        if self._cpe is not None:
+            # the caller has stepped the q-network by now (Lightning's optimizer loop): the CPE targets
+            # use q_network(next_state) with the NEW weights, dqn_trainer.py:267-281
+            from .reagent_lightning_module import _NoOpReporter
+
+            self._cpe.forward(training_batch)
+            reward_loss = self._cpe.loss("reward")
+            yield reward_loss
+            if not isinstance(self._reporter, _NoOpReporter):  # dqn_trainer_base.py:430-450
+                from ..core.torch_utils import masked_softmax
+
+                mask = training_batch.possible_actions_mask if self.maxq_learning else training_batch.action
+                self.reporter.log(reward_loss=reward_loss.detach(),
+                                  model_propensities=masked_softmax(self.all_action_scores, mask.float(),
+                                                                    self.rl_temperature),
+                                  model_rewards=self._cpe.reward_est[:, : self.num_actions])
+            yield self._cpe.loss("cpe")
         self._log_dqn(td_loss, training_batch)
         yield self.soft_update_result()
 

@@ -1,8 +1,10 @@
 """DQNTrainerMixin / DQNTrainerBaseLightning surface of
 reagent/training/dqn_trainer_base.py:23-241 for the natively executed trainers.
 
-CPE (reward network / q_network_cpe heads, :243-509) is a "next" row of SURVEY.md §8(f) and is
-rejected at construction rather than silently skipped.
+CPE (reward network / q_network_cpe heads, :243-452) is executed by the
+DQN trainer (`_CpeEngine` in dqn_trainer.py); the trainers that do not run it yet reject
+calc_cpe_in_training=True at construction rather than silently skipping it.  The Evaluator /
+EvaluationDataPage side (:454-509) is control plane and stays out.
 """
 from typing import Dict, List, Optional
 
@@ -95,6 +97,34 @@ class DQNTrainerBaseLightning(DQNTrainerMixin, RLTrainerMixin, ReAgentLightningM
         """dqn_trainer_base.py:216-241 — utility entry point; the step fuses it into rg_dqn_head."""
         reward_boosts = torch.sum(actions.float() * self.reward_boosts, dim=1, keepdim=True)
         return rewards + reward_boosts
+
+    def _initialize_cpe(self, reward_network, q_network_cpe, q_network_cpe_target, optimizer) -> None:
+        """dqn_trainer_base.py:243-311 without the Evaluator object (evaluation pages are control plane)."""
+        if not self.calc_cpe_in_training:
+            self.reward_network = None
+            return
+        assert reward_network is not None, "reward_network is required for CPE"
+        self.reward_network = reward_network
+        self.reward_network_optimizer = optimizer
+        assert q_network_cpe is not None and q_network_cpe_target is not None, (
+            "q_network_cpe and q_network_cpe_target are required for CPE"
+        )
+        self.q_network_cpe = q_network_cpe
+        self.q_network_cpe_target = q_network_cpe_target
+        self.q_network_cpe_optimizer = optimizer
+        num_output_nodes = len(self.metrics_to_score) * self.num_actions
+        self.register_buffer("reward_idx_offsets",
+                             torch.arange(0, num_output_nodes, self.num_actions, dtype=torch.long))
+
+    def _configure_cpe_optimizers(self):
+        """dqn_trainer_base.py:313-336"""
+        target_params = list(self.q_network_cpe_target.parameters())
+        source_params = list(self.q_network_cpe.parameters())
+        optimizers = [
+            self.reward_network_optimizer.make_optimizer_scheduler(self.reward_network.parameters()),
+            self.q_network_cpe_optimizer.make_optimizer_scheduler(self.q_network_cpe.parameters()),
+        ]
+        return target_params, source_params, optimizers
 
     def _reject_cpe(self, reward_network, q_network_cpe, q_network_cpe_target):
         if self.calc_cpe_in_training:

@@ -138,3 +138,70 @@ def test_state_dict_layout_matches_reference_names(backend):
     assert "q_network.fc.dnn.0.0.weight" in keys and "q_network_target.fc.dnn.2.0.bias" in keys
     assert len(keys) == 3 + 2 * 6
     assert tr.q_network.fc.dnn[0][0].weight.shape == (128, 4)  # nn.Linear layout
+
+
+# ---- CPE heads (calc_cpe_in_training=True) --------------------------------------
+CPE_NETS = ("reward_network", "q_network_cpe", "q_network_cpe_target")
+
+
+def build_cpe(g: Golden, device):
+    c = g.cfg
+    A = c["num_actions"]
+    n_out = (len(c["cpe_metrics"]) + 1) * A
+
+    def net(out, prefix):
+        m = FullyConnectedDQN(c["state_dim"], out, c["sizes"], c["activations"])
+        with torch.no_grad():
+            for p, init in zip(m.parameters(), g.seq(prefix)):
+                p.copy_(init)
+        return m.to(device)
+
+    q = net(A, "init_param_")
+    reward_net, q_cpe = net(n_out, "init_reward_network_"), net(n_out, "init_q_network_cpe_")
+    q_cpe_t = q_cpe.get_target_network()
+    tr = DQNTrainer(q, q.get_target_network(), reward_net, q_network_cpe=q_cpe, q_network_cpe_target=q_cpe_t,
+                    metrics_to_score=list(c["cpe_metrics"]), actions=[str(i) for i in range(A)],
+                    rl=RLParameters(**c["rl"]), double_q_learning=c["double_q"],
+                    optimizer=Optimizer__Union.default(lr=c["lr"]),
+                    evaluation=EvaluationParameters(calc_cpe_in_training=True)).to(device)
+    return tr
+
+
+def _check_cpe_step(tr, g, s, losses):
+    ref = [g.t(f"step{s}_loss"), g.t(f"step{s}_reward_loss"), g.t(f"step{s}_cpe_loss")]
+    for got, want in zip(losses[:3], ref):
+        assert abs(float(got) - want.item()) <= 1e-4 * abs(want.item()) + 1e-6
+    for i, p in enumerate(tr.q_network.parameters()):
+        assert (p.detach().cpu() - g.t(f"step{s}_param_{i}")).abs().max() <= 2e-5, (s, i)
+    for i, p in enumerate(tr.q_network_target.parameters()):
+        assert (p.detach().cpu() - g.t(f"step{s}_target_{i}")).abs().max() <= 2e-5, (s, i)
+    for net in CPE_NETS:
+        for i, p in enumerate(getattr(tr, net).parameters()):
+            assert (p.detach().cpu() - g.t(f"step{s}_{net}_{i}")).abs().max() <= 2e-5, (s, net, i)
+
+
+@pytest.mark.parametrize("name", ["dqn_cpe", "dqn_cpe_sarsa_mse"])
+def test_dqn_cpe_matches_reference(backend, name):
+    """four losses per step in the reference's optimizer order (q, reward, cpe, soft update); the CPE
+    targets see q_network(next_state) AFTER the q-network step of the same batch"""
+    g = Golden(name)
+    tr = build_cpe(g, backend.device)
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    assert [type(o).__name__ for o in opts] == ["FusedAdam", "FusedAdam", "FusedAdam", "SoftUpdate"]
+    assert tr.reward_idx_offsets.tolist() == list(range(0, (len(g.cfg["cpe_metrics"]) + 1) * g.cfg["num_actions"],
+                                                        g.cfg["num_actions"]))
+    for s in range(g.cfg["steps"]):
+        batch = synthetic.to_dqn_input(g.batch(s), backend.device)
+        losses = lightning_like_step(tr, opts, batch)
+        assert len(losses) == 4
+        _check_cpe_step(tr, g, s, [l.item() for l in losses])
+
+
+@pytest.mark.parametrize("name", ["dqn_cpe"])
+def test_dqn_cpe_native_step(backend, name):
+    g = Golden(name)
+    tr = build_cpe(g, backend.device)
+    for s in range(g.cfg["steps"]):
+        batch = synthetic.to_dqn_input(g.batch(s), backend.device)
+        loss = tr.train_step_native(batch)
+        _check_cpe_step(tr, g, s, [loss.item(), tr._cpe.losses["reward"].item(), tr._cpe.losses["cpe"].item()])
