@@ -12,7 +12,10 @@ Outside the dense hot path and rejected explicitly: id-list / id-score-list (spa
 ``return_as_timeline_format`` and ``return_everything_as_stack``.
 """
 import collections
+import gzip
 import logging
+import os
+import pickle
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -36,6 +39,12 @@ _NP2TORCH = {
     np.dtype("bool"): torch.bool,
     np.dtype("float16"): torch.float16,
 }
+
+
+STORE_FILENAME_PREFIX = "$store$_"  # circular_replay_buffer.py:302
+_RG_FILENAME_PREFIX = "$rg$_"
+CHECKPOINT_DURATION = 4  # :305
+_NOT_CHECKPOINTED = ("device",)  # where the columns live is a property of the loading process
 
 
 class ReplayBuffer:
@@ -335,7 +344,92 @@ class ReplayBuffer:
         return ["state", "action", "reward", "next_state", "next_action", "next_reward", "terminal",
                 "indices", "step", *extra_names]
 
-    def save(self, *a, **k):
-        raise NotImplementedError("checkpointing of the replay buffer is a SURVEY.md §8(f) 'next' row")
+    # ---- checkpointing (circular_replay_buffer.py:795-890; same files, same names) ------------
+    def _generate_filename(self, checkpoint_dir, name, suffix):
+        return os.path.join(checkpoint_dir, "{}_ckpt.{}.gz".format(name, suffix))
 
-    load = save
+    def _return_checkpointable_elements(self):
+        """:798-811 — every public attribute plus one `$store$_<key>` entry per storage column."""
+        elements = {}
+        for member_name, member in self.__dict__.items():
+            if member_name == "_store":
+                for array_name, array in self._store.items():
+                    elements[STORE_FILENAME_PREFIX + array_name] = array
+            elif not member_name.startswith("_") and member_name not in _NOT_CHECKPOINTED:
+                elements[member_name] = member
+        return elements
+
+    # private bookkeeping the reference does not checkpoint (a buffer restored by it forgets which
+    # indices are valid); written as extra `$rg$_*` files the reference ignores
+    _EXTRA_STATE = ("_valid_host", "_terminal_host", "_num_transitions_in_current_episode")
+
+    def save(self, checkpoint_dir, iteration_number):
+        """:813-861.  One gzip file per element: storage columns and numpy attributes with
+        np.save(allow_pickle=False), anything else pickled; the checkpoint CHECKPOINT_DURATION
+        iterations back is deleted.  Device columns are copied to the host for writing."""
+        if not os.path.exists(checkpoint_dir):
+            return
+        elements = self._return_checkpointable_elements()
+        for name in self._EXTRA_STATE:
+            elements[_RG_FILENAME_PREFIX + name] = np.asarray(getattr(self, name))
+        for attr, value in elements.items():
+            with open(self._generate_filename(checkpoint_dir, attr, iteration_number), "wb") as f:
+                with gzip.GzipFile(fileobj=f, mode="wb") as outfile:
+                    if attr.startswith(STORE_FILENAME_PREFIX):
+                        np.save(outfile, value.cpu().numpy(), allow_pickle=False)
+                    elif isinstance(value, np.ndarray):
+                        np.save(outfile, value, allow_pickle=False)
+                    else:
+                        pickle.dump(value, outfile)
+            stale = iteration_number - CHECKPOINT_DURATION
+            if stale >= 0:
+                try:
+                    os.remove(self._generate_filename(checkpoint_dir, attr, stale))
+                except FileNotFoundError:
+                    pass
+
+    def load(self, checkpoint_dir, suffix):
+        """:863-890.  Nothing is loaded unless every expected file exists (FileNotFoundError).  A
+        checkpoint written by the reference has no `$rg$_*` files: validity is then rebuilt from the
+        `terminal` column with the add rules (possible while the ring has not wrapped, stack_size 1)."""
+        elements = self._return_checkpointable_elements()
+        for attr in elements:
+            filename = self._generate_filename(checkpoint_dir, attr, suffix)
+            if not os.path.exists(filename):
+                raise FileNotFoundError(None, None, "Missing file: {}".format(filename))
+        for attr, current in elements.items():
+            with open(self._generate_filename(checkpoint_dir, attr, suffix), "rb") as f:
+                with gzip.GzipFile(fileobj=f) as infile:
+                    if attr.startswith(STORE_FILENAME_PREFIX):
+                        key = attr[len(STORE_FILENAME_PREFIX):]
+                        arr = torch.from_numpy(np.load(infile, allow_pickle=False))
+                        self._store[key] = arr.to(device=self.device, dtype=self._store[key].dtype)
+                    elif isinstance(current, np.ndarray):
+                        self.__dict__[attr] = np.load(infile, allow_pickle=False)
+                    else:
+                        self.__dict__[attr] = pickle.load(infile)
+        n = int(min(int(self.add_count), self._replay_capacity))
+        extras = {name: self._generate_filename(checkpoint_dir, _RG_FILENAME_PREFIX + name, suffix)
+                  for name in self._EXTRA_STATE}
+        if all(os.path.exists(f) for f in extras.values()):
+            for name, filename in extras.items():
+                with open(filename, "rb") as f, gzip.GzipFile(fileobj=f) as infile:
+                    value = np.load(infile, allow_pickle=False)
+                setattr(self, name, int(value) if value.ndim == 0 else value.astype(bool))
+        else:
+            if int(self.add_count) > self._replay_capacity or self._stack_size != 1:
+                raise ValueError("checkpoint without validity state ($rg$_* files): it can only be rebuilt "
+                                 "for an unwrapped, unstacked buffer")
+            term = self._store["terminal"][:n].cpu().numpy().astype(bool)
+            self._terminal_host = np.zeros(self._replay_capacity, dtype=bool)
+            self._terminal_host[:n] = term
+            ends = np.flatnonzero(term)
+            last_end = int(ends[-1]) if len(ends) else -1
+            ar = np.arange(n)
+            valid = np.zeros(self._replay_capacity, dtype=bool)
+            valid[:n] = (ar <= last_end) | (ar + self._update_horizon <= n - 1)
+            self._valid_host = valid
+            self._num_transitions_in_current_episode = n - (last_end + 1)
+        self._num_valid_indices = int(self._valid_host.sum())
+        self._valid_dirty = True
+        self._valid_indices_dev = None

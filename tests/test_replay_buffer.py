@@ -184,3 +184,106 @@ def test_normalize_on_gather_equals_gather_then_preprocessor(backend, S):
     fused16 = rb2.sample_transition_batch(B, indices=idx, state_preprocessor=pre_id, state_dtype=torch.bfloat16)
     assert fused16.state.dtype == torch.bfloat16
     assert torch.equal(fused16.state.cpu(), want_s.cpu().to(torch.bfloat16))
+
+
+# ---- checkpointing in the reference's file layout (circular_replay_buffer.py:795-890) -------------
+def _filled(backend, n=37, cap=50, horizon=2):
+    rb = ReplayBuffer(stack_size=1, replay_capacity=cap, batch_size=8, update_horizon=horizon, gamma=0.9,
+                      device=backend.device)
+    rng = np.random.RandomState(4)
+    for i in range(n):
+        rb.add(observation=rng.randn(*OBS).astype(np.float32), action=np.int64(rng.randint(3)),
+               reward=np.float32(rng.rand()), terminal=bool(rng.rand() < 0.2), mdp_id=np.int64(i // 5))
+    return rb
+
+
+def test_save_load_round_trip_and_reference_layout(backend, tmp_path):
+    import gzip
+
+    rb = _filled(backend)
+    rb.save(str(tmp_path), 7)
+    # the reference's file set: one gzip'd np.save per storage column ("$store$_<key>") and per public
+    # numpy attribute (add_count), named "<attr>_ckpt.<iteration>.gz"
+    for key in rb._store:
+        f = tmp_path / f"$store$_{key}_ckpt.7.gz"
+        assert f.exists()
+        with gzip.GzipFile(str(f)) as g:
+            arr = np.load(g, allow_pickle=False)
+        np.testing.assert_array_equal(arr, rb._store[key].cpu().numpy())
+    with gzip.GzipFile(str(tmp_path / "add_count_ckpt.7.gz")) as g:
+        assert int(np.load(g, allow_pickle=False)) == 37
+    fresh = _filled(backend, n=3)  # same schema, different contents
+    fresh.load(str(tmp_path), 7)
+    assert int(fresh.add_count) == 37 and fresh.size == rb.size and fresh.cursor() == rb.cursor()
+    np.testing.assert_array_equal(fresh._valid_host, rb._valid_host)
+    idx = torch.from_numpy(np.flatnonzero(rb._valid_host)[:8].astype(np.int64))
+    a, b = rb.sample_transition_batch(8, indices=idx), fresh.sample_transition_batch(8, indices=idx)
+    for k in a._fields:
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    # adding continues identically after the restore
+    for m in (rb, fresh):
+        m.add(observation=np.ones(OBS, dtype=np.float32), action=np.int64(1), reward=np.float32(0.5), terminal=True,
+              mdp_id=np.int64(99))
+    np.testing.assert_array_equal(fresh._valid_host, rb._valid_host)
+
+
+def test_save_garbage_collects_and_load_is_all_or_nothing(backend, tmp_path):
+    rb = _filled(backend)
+    rb.save(str(tmp_path), 1)
+    assert (tmp_path / "add_count_ckpt.1.gz").exists()
+    rb.save(str(tmp_path), 5)  # CHECKPOINT_DURATION = 4 iterations back is deleted
+    assert (tmp_path / "add_count_ckpt.5.gz").exists() and not (tmp_path / "add_count_ckpt.1.gz").exists()
+    rb.save(str(tmp_path / "does_not_exist"), 5)  # silently nothing, like the reference (:823-824)
+    fresh = _filled(backend, n=3)
+    with pytest.raises(FileNotFoundError):
+        fresh.load("/does/not/exist", "3")
+    (tmp_path / "$store$_reward_ckpt.5.gz").unlink()
+    with pytest.raises(FileNotFoundError, match="reward"):
+        fresh.load(str(tmp_path), 5)
+    assert int(fresh.add_count) == 3  # nothing was loaded
+
+
+def test_load_checkpoint_written_by_the_reference_layout_only(backend, tmp_path):
+    """a checkpoint holding only the reference's files (no $rg$_* validity state): validity is rebuilt
+    from the terminal column"""
+    rb = _filled(backend)
+    rb.save(str(tmp_path), 2)
+    for f in tmp_path.glob("$rg$_*"):
+        f.unlink()
+    fresh = _filled(backend, n=3)
+    fresh.load(str(tmp_path), 2)
+    np.testing.assert_array_equal(fresh._valid_host, rb._valid_host)
+    assert fresh.size == rb.size
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/reagent"), reason="needs the reference checkout")
+def test_checkpoints_interchange_with_the_reference_class(emu_lib, tmp_path):
+    """files written by the reference ReplayBuffer load here and vice versa (build container only)"""
+    from oracle import reference_harness as rh
+
+    rh._install()
+    from reagent.replay_memory.circular_replay_buffer import ReplayBuffer as RefBuffer
+
+    def fill(rb, n):
+        rng = np.random.RandomState(4)
+        for i in range(n):
+            rb.add(observation=rng.randn(*OBS).astype(np.float32), action=np.int64(rng.randint(3)),
+                   reward=np.float32(rng.rand()), terminal=bool(rng.rand() < 0.2), mdp_id=np.int64(i // 5))
+        return rb
+
+    kw = dict(stack_size=1, replay_capacity=50, batch_size=8, update_horizon=2, gamma=0.9)
+    ref, mine = fill(RefBuffer(**kw), 37), fill(ReplayBuffer(device="cpu", **kw), 37)
+    d_ref, d_mine = tmp_path / "ref", tmp_path / "mine"
+    d_ref.mkdir(), d_mine.mkdir()
+    ref.save(str(d_ref), 3)
+    mine.save(str(d_mine), 3)
+    assert {f.name for f in d_ref.iterdir()} <= {f.name for f in d_mine.iterdir()}  # same names (+ $rg$_ extras)
+    loaded = fill(ReplayBuffer(device="cpu", **kw), 2)
+    loaded.load(str(d_ref), 3)  # reference -> here
+    assert int(loaded.add_count) == 37
+    np.testing.assert_array_equal(loaded._valid_host, ref._is_index_valid.numpy())
+    ref2 = fill(RefBuffer(**kw), 2)
+    ref2.load(str(d_mine), 3)  # here -> reference
+    assert int(ref2.add_count) == 37
+    for k in ref._store:  # rows never written are uninitialised memory in the reference
+        np.testing.assert_array_equal(ref2._store[k].numpy()[:37], ref._store[k].numpy()[:37])
