@@ -32,6 +32,8 @@ def _save(name, cfg, arrays):
     print("wrote", name, sum(a.nbytes for a in arrays.values()) // 1024, "KiB")
 
 
+CPE_NETS = ("reward_network", "q_network_cpe", "q_network_cpe_target")
+
 DQN_CASES = {
     # mirrors reagent/gym/tests/configs/cartpole/discrete_dqn_cartpole_online.yaml (BASELINE C1 shape)
     "dqn_c1": dict(state_dim=4, num_actions=2, sizes=[128, 64], activations=["leaky_relu", "leaky_relu"],
@@ -60,9 +62,6 @@ DQN_CASES = {
                                  q_network_loss="huber", use_seq_num_diff_as_time_diff=True),
                          lr=0.002, double_q=True, batch=33, steps=2, p_impossible=0.2, with_steps=True),
 }
-
-
-CPE_NETS = ("reward_network", "q_network_cpe", "q_network_cpe_target")
 
 
 def gen_dqn(name, c):
@@ -106,6 +105,10 @@ QR_CASES = {
     "qrdqn_double": dict(state_dim=8, num_actions=3, num_atoms=11, sizes=[32, 32], activations=["relu", "relu"],
                          rl=dict(gamma=0.99, target_update_rate=0.1, maxq_learning=True), lr=0.005,
                          double_q=True, batch=48, steps=2, p_impossible=0.25),
+    "qrdqn_cpe": dict(state_dim=7, num_actions=3, num_atoms=9, sizes=[24, 16], activations=["relu", "relu"],
+                      rl=dict(gamma=0.95, target_update_rate=0.2, maxq_learning=True, q_network_loss="mse",
+                              temperature=0.5),
+                      lr=0.003, double_q=True, batch=56, steps=2, p_impossible=0.2, cpe_metrics=["m1", "m2"]),
     "qrdqn_single_sarsa": dict(state_dim=5, num_actions=4, num_atoms=7, sizes=[24], activations=["leaky_relu"],
                                rl=dict(gamma=0.9, target_update_rate=0.3, maxq_learning=False), lr=0.002,
                                double_q=False, batch=40, steps=2, p_impossible=0.0),
@@ -113,19 +116,29 @@ QR_CASES = {
 
 
 def gen_qr(name, c):
+    cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
-                      double_q=c["double_q"], seed=0, num_atoms=c["num_atoms"])
+                      double_q=c["double_q"], seed=0, num_atoms=c["num_atoms"], cpe_metrics=cpe_metrics)
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
+    if cpe_metrics is not None:
+        for net in CPE_NETS:
+            for i, p in enumerate(getattr(tr, net).parameters()):
+                arrays[f"init_{net}_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
     for s in range(c["steps"]):
         b = synthetic.dqn_batch(c["batch"], c["state_dim"], c["num_actions"], seed=200 + s,
-                                p_impossible=c["p_impossible"])
+                                p_impossible=c["p_impossible"], n_extra_metrics=len(cpe_metrics or []))
         for k, v in b.items():
             arrays[f"step{s}_batch_{k}"] = _np(v)
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
+        if cpe_metrics is not None:
+            arrays[f"step{s}_reward_loss"], arrays[f"step{s}_cpe_loss"] = _np(losses[1]), _np(losses[2])
+            for net in CPE_NETS:
+                for i, p in enumerate(getattr(tr, net).parameters()):
+                    arrays[f"step{s}_{net}_{i}"] = _np(p)
         for i, p in enumerate(tr.q_network.parameters()):
             arrays[f"step{s}_param_{i}"] = _np(p)
         for i, p in enumerate(tr.q_network_target.parameters()):

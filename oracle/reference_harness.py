@@ -111,7 +111,15 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
     else:
         from reagent.training.qrdqn_trainer import QRDQNTrainer
 
-        trainer = QRDQNTrainer(q, qt, num_atoms=num_atoms, **common)
+        if cpe:  # the CPE networks are plain (non-distributional) FC nets, discrete_qrdqn.py:84-103
+            n_out = (len(cpe_metrics) + 1) * num_actions
+            reward_net = FullyConnectedDQN(state_dim, n_out, sizes, activations)
+            q_cpe = FullyConnectedDQN(state_dim, n_out, sizes, activations)
+            trainer = QRDQNTrainer(q, qt, metrics_to_score=list(cpe_metrics), reward_network=reward_net,
+                                   q_network_cpe=q_cpe, q_network_cpe_target=q_cpe.get_target_network(),
+                                   num_atoms=num_atoms, cpe_optimizer=make_adam(lr), **common)
+        else:
+            trainer = QRDQNTrainer(q, qt, num_atoms=num_atoms, **common)
     return trainer
 
 

@@ -106,7 +106,7 @@ class _CpeEngine:
         qs = tr._qs
         qs.stage_weights(need_transposed=True)
         xn, _ = qs.stage_input(next_state, need_transposed=False)
-        qs.forward(xn, self.next_scores, save=False)
+        tr._cpe_next_scores(xn, self.next_scores)
         for k in ("reward", "cpe"):
             self.e[k]["stack"].stage_weights(need_transposed=True)
         self.t.stage_weights(need_transposed=False)
@@ -174,12 +174,49 @@ class QStepCore(DQNTrainerBaseLightning):
 
     # ---- optimizers (dqn_trainer.py:119-155 / qrdqn_trainer.py:81-106) ------------------------
     def configure_optimizers(self):
+        """[q_network, (reward_network, q_network_cpe,) soft update of the target(s)]"""
         optimizers = []
         target_params = list(self.q_network_target.parameters())
         source_params = list(self.q_network.parameters())
         optimizers.append(self.q_network_optimizer.make_optimizer_scheduler(self.q_network.parameters()))
+        if self.calc_cpe_in_training:
+            cpe_target_params, cpe_source_params, cpe_optimizers = self._configure_cpe_optimizers()
+            target_params += cpe_target_params
+            source_params += cpe_source_params
+            optimizers += cpe_optimizers
         optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
         return optimizers
+
+    # ---- CPE (dqn_trainer_base.py:338-452) ----------------------------------------------------
+    _cpe = None
+
+    def _cpe_next_scores(self, xn, out):
+        """all_next_action_scores = q_network(next_state) with the just-updated weights -> out [B, A]"""
+        self._qs.forward(xn, out, save=False)
+
+    def _cpe_scores_for_logging(self):
+        return self.all_action_scores
+
+    def _cpe_segment(self, training_batch):
+        """the two CPE losses of train_step_gen, yielded after the q-network loss: by then the caller
+        (Lightning's optimizer loop) has stepped the q-network, and the CPE targets use
+        q_network(next_state) with the NEW weights (dqn_trainer.py:267-281, qrdqn_trainer.py:161-177)"""
+        if self._cpe is None:
+            return
+        from .reagent_lightning_module import _NoOpReporter
+
+        self._cpe.forward(training_batch)
+        reward_loss = self._cpe.loss("reward")
+        yield reward_loss
+        if not isinstance(self._reporter, _NoOpReporter):  # dqn_trainer_base.py:430-450
+            from ..core.torch_utils import masked_softmax
+
+            mask = training_batch.possible_actions_mask if self.maxq_learning else training_batch.action
+            self.reporter.log(reward_loss=reward_loss.detach(),
+                              model_propensities=masked_softmax(self._cpe_scores_for_logging(), mask.float(),
+                                                                self.rl_temperature),
+                              model_rewards=self._cpe.reward_est[:, : self.num_actions])
+        yield self._cpe.loss("cpe")
 
     # ---- engine -------------------------------------------------------------------------------
     def _engine(self, batch: int, device):
@@ -422,42 +459,12 @@ class DQNTrainer(QStepCore):
         head from the batch itself; the two extra arguments are accepted for signature parity."""
         return self._hip_loss(batch)
 
-    def configure_optimizers(self):
-        """dqn_trainer.py:119-155: [q_network, (reward_network, q_network_cpe,) soft update]"""
-        optimizers = []
-        target_params = list(self.q_network_target.parameters())
-        source_params = list(self.q_network.parameters())
-        optimizers.append(self.q_network_optimizer.make_optimizer_scheduler(self.q_network.parameters()))
-        if self.calc_cpe_in_training:
-            cpe_target_params, cpe_source_params, cpe_optimizers = self._configure_cpe_optimizers()
-            target_params += cpe_target_params
-            source_params += cpe_source_params
-            optimizers += cpe_optimizers
-        optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
-        return optimizers
-
     def train_step_gen(self, training_batch: rlt.DiscreteDqnInput, batch_idx: int):
         self._check_input(training_batch)
         td_loss = self.compute_td_loss(training_batch)
         yield td_loss
         td_loss = td_loss.detach()
-        if self._cpe is not None:
-            # the caller has stepped the q-network by now (Lightning's optimizer loop): the CPE targets
-            # use q_network(next_state) with the NEW weights, dqn_trainer.py:267-281
-            from .reagent_lightning_module import _NoOpReporter
-
-            self._cpe.forward(training_batch)
-            reward_loss = self._cpe.loss("reward")
-            yield reward_loss
-            if not isinstance(self._reporter, _NoOpReporter):  # dqn_trainer_base.py:430-450
-                from ..core.torch_utils import masked_softmax
-
-                mask = training_batch.possible_actions_mask if self.maxq_learning else training_batch.action
-                self.reporter.log(reward_loss=reward_loss.detach(),
-                                  model_propensities=masked_softmax(self.all_action_scores, mask.float(),
-                                                                    self.rl_temperature),
-                                  model_rewards=self._cpe.reward_est[:, : self.num_actions])
-            yield self._cpe.loss("cpe")
+        yield from self._cpe_segment(training_batch)
         self._log_dqn(td_loss, training_batch)
         yield self.soft_update_result()
 

@@ -4,7 +4,7 @@ reagent/training/qrdqn_trainer.py:22-227, executed on the HIP kernels.
 Step (reference :108-194): target(next_state) and — when double_q_learning — online(next_state)
 forwards, online(state) forward, the quantile-Huber head (rg_qr_head: per-transition N x N pairs in
 LDS/registers, the (N, B, N) tensor of the reference is never built), backward, Adam, soft update.
-The CPE-only 4th forward (:162-164) is dead when CPE is off and is not executed.
+The 4th forward (:162-164) feeds only the CPE heads and runs only with calc_cpe_in_training.
 """
 from typing import List, Optional, Tuple
 
@@ -52,7 +52,12 @@ class QRDQNTrainer(QStepCore):
         self.num_atoms = num_atoms
         self.register_buffer("quantiles", None)
         self.quantiles = ((0.5 + torch.arange(self.num_atoms).float()) / float(self.num_atoms)).view(1, -1)
-        self._reject_cpe(reward_network, q_network_cpe, q_network_cpe_target)
+        self._initialize_cpe(reward_network, q_network_cpe, q_network_cpe_target,
+                             optimizer=cpe_optimizer if cpe_optimizer is not None else Optimizer__Union.default())
+        if self.calc_cpe_in_training:
+            from .dqn_trainer import _CpeEngine
+
+            self._cpe = _CpeEngine(self)
 
     def _out_cols(self) -> int:
         return self.num_actions * self.num_atoms
@@ -75,11 +80,21 @@ class QRDQNTrainer(QStepCore):
         ops.reduce_sum(self._loss_partials, B, 1.0, self._loss)
         self.all_q_values = self._all_q
 
+    def _cpe_next_scores(self, xn, out):
+        """qrdqn_trainer.py:162-164: q_network(next_state).mean(dim=2) with the just-updated weights"""
+        B = out.shape[0]
+        self._qs.forward(xn, self._qn_online, save=False)  # the buffer is free once the head has run
+        torch.mean(self._qn_online.view(B, self.num_actions, self.num_atoms), dim=2, out=out)
+
+    def _cpe_scores_for_logging(self):
+        return self.all_q_values
+
     def train_step_gen(self, training_batch: rlt.DiscreteDqnInput, batch_idx: int):
         self._check_input(training_batch)
         loss = self._hip_loss(training_batch)
         yield loss
         self.loss = loss.detach()
+        yield from self._cpe_segment(training_batch)
         self._log(training_batch)
         yield self.soft_update_result()
 

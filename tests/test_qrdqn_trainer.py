@@ -64,3 +64,40 @@ def test_qrdqn_native_step_and_bf16(backend):
     lc = tr_c.train_step_native(batch)
     ref = g.t("step0_loss").item()
     assert abs(lc.item() - ref) <= 3e-2 * abs(ref) + 1e-3
+
+
+def test_qrdqn_cpe_matches_reference(backend):
+    """calc_cpe_in_training for QR-DQN: the CPE targets use q_network(next_state).mean(atoms) after the
+    q-network step (qrdqn_trainer.py:161-177); two extra metrics"""
+    from test_dqn_trainer import CPE_NETS
+
+    g = Golden("qrdqn_cpe")
+    c = g.cfg
+    A, n_out = c["num_actions"], (len(c["cpe_metrics"]) + 1) * c["num_actions"]
+
+    def net(out, prefix, num_atoms=None):
+        m = FullyConnectedDQN(c["state_dim"], out, c["sizes"], c["activations"], num_atoms=num_atoms)
+        with torch.no_grad():
+            for p, init in zip(m.parameters(), g.seq(prefix)):
+                p.copy_(init)
+        return m.to(backend.device)
+
+    q = net(A, "init_param_", c["num_atoms"])
+    reward_net, q_cpe = net(n_out, "init_reward_network_"), net(n_out, "init_q_network_cpe_")
+    tr = QRDQNTrainer(q, q.get_target_network(), metrics_to_score=list(c["cpe_metrics"]), reward_network=reward_net,
+                      q_network_cpe=q_cpe, q_network_cpe_target=q_cpe.get_target_network(),
+                      actions=[str(i) for i in range(A)], rl=RLParameters(**c["rl"]),
+                      double_q_learning=c["double_q"], num_atoms=c["num_atoms"],
+                      optimizer=Optimizer__Union.default(lr=c["lr"]), cpe_optimizer=Optimizer__Union.default(lr=c["lr"]),
+                      evaluation=EvaluationParameters(calc_cpe_in_training=True)).to(backend.device)
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    assert len(opts) == 4
+    for s in range(c["steps"]):
+        batch = synthetic.to_dqn_input(g.batch(s), backend.device)
+        losses = lightning_like_step(tr, opts, batch)
+        for got, key in zip(losses[:3], ["loss", "reward_loss", "cpe_loss"]):
+            want = g.t(f"step{s}_{key}").item()
+            assert abs(got.item() - want) <= 1e-4 * abs(want) + 1e-6, (key, got.item(), want)
+        for netname in CPE_NETS:
+            for i, p in enumerate(getattr(tr, netname).parameters()):
+                assert (p.detach().cpu() - g.t(f"step{s}_{netname}_{i}")).abs().max() <= 2e-5, (s, netname, i)
