@@ -77,6 +77,12 @@ int rg_fc_wgrad(const void* dzt, int64_t lddzt, const void* xt, int64_t ldxt, fl
 int rg_transpose_cast(const void* src, int src_dt, int64_t ld_src, int rows, int cols, void* dst,
                       int64_t ld_dst, void* dst_t, int64_t ld_t, int dst_dt, rg_stream_t stream);
 
+/* dz = dy * act'(z) written through the activation output y = act(z), fp32 [rows, cols]: turns the
+ * gradient w.r.t. a non-linear OUTPUT layer (FullyConnectedActor's tanh head,
+ * reagent/models/actor.py:71-75) into the pre-activation gradient the backward entry points take. */
+int rg_act_backward(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int act, float* dz,
+                    int64_t ld_dz, int rows, int cols, rg_stream_t stream);
+
 /* ---- fused FullyConnected stack (bf16 throughput path) ------------------------------------ */
 
 /* Whole-network kernels for stacks whose hidden layers share one width in {256, 512}, input
@@ -90,7 +96,7 @@ int rg_transpose_cast(const void* src, int src_dt, int64_t ld_src, int rows, int
 typedef struct {
   int32_t n_layers;
   int32_t dims[RG_MLP_MAX_LAYERS + 1];        /* dims[0] = input features, dims[l+1] = out of layer l */
-  int32_t acts[RG_MLP_MAX_LAYERS];            /* RG_ACT_* per layer (last must be linear to train) */
+  int32_t acts[RG_MLP_MAX_LAYERS];            /* RG_ACT_* per layer; backward takes d loss / d PRE-activation of the last layer (rg_act_backward) */
   const void* wfrag_fwd[RG_MLP_MAX_LAYERS];   /* rg_stage_weights_frag outputs */
   const void* wfrag_bwd[RG_MLP_MAX_LAYERS];
   const float* bias[RG_MLP_MAX_LAYERS];
@@ -317,6 +323,13 @@ int rg_sac_actor_head(const float* log_prob, const float* q1_actor, const float*
  * (nullable) = -(log_alpha * mean(...)).  fp64 like the reference's log_alpha (:124-126). */
 int rg_sac_alpha_grad(const float* entropy_partials, int batch, const double* log_alpha, double* grad,
                       double* alpha_loss, rg_stream_t stream);
+/* TD3 target-policy smoothing, reagent/training/td3_trainer.py:141-146:
+ * out[b, :A] (row pitch ld_out) = clamp(next_actor[b] + clamp(noise[b] * noise_variance, +-noise_clip), lo, hi);
+ * noise [B, A] contiguous ~ N(0, 1). */
+int rg_td3_target_action(const float* next_actor, int64_t ld_a, const float* noise, double noise_variance,
+                         double noise_clip, double lo, double hi, float* out, int64_t ld_out, int batch,
+                         int action_dim, rg_stream_t stream);
+
 /* torch.optim.Adam arithmetic in fp64; exp_param_out (nullable) = exp(param) (alpha = exp(log_alpha)). */
 int rg_adam_step_f64(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n,
                      double lr, double beta1, double beta2, double eps, double bias_correction1,

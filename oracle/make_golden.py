@@ -191,6 +191,42 @@ REPLAY_CASES = {
 }
 
 
+TD3_CASES = {
+    "td3_twin": dict(state_dim=7, action_dim=3, sizes=[32, 24], activations=["relu", "relu"],
+                     rl=dict(gamma=0.98, target_update_rate=0.1), lr=0.004, batch=48, steps=4,
+                     noise_variance=0.3, noise_clip=0.4, delayed_policy_update=2),
+}
+
+
+def gen_td3(name, c):
+    tr = rh.build_td3(c["state_dim"], c["action_dim"], c["sizes"], c["activations"], c["rl"], c["lr"], seed=0,
+                      noise_variance=c["noise_variance"], noise_clip=c["noise_clip"],
+                      delayed_policy_update=c["delayed_policy_update"])
+    arrays = {}
+    for n, m in dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network).items():
+        for i, p in enumerate(m.parameters()):
+            arrays[f"init_{n}_{i}"] = _np(p)
+    loop = rh.PLLoop(tr)
+    for s in range(c["steps"]):
+        b = synthetic.policy_batch(c["batch"], c["state_dim"], c["action_dim"], seed=400 + s)
+        for k, v in b.items():
+            arrays[f"step{s}_batch_{k}"] = _np(v)
+        # the only RNG on the path: torch.randn_like(next_actor) (td3_trainer.py:142).  Record the draw.
+        torch.manual_seed(2000 + s)
+        arrays[f"step{s}_noise"] = _np(torch.randn(c["batch"], c["action_dim"]))
+        torch.manual_seed(2000 + s)
+        losses = loop.step(rh.policy_batch_to_reference(b))
+        for j, nm in enumerate(["q1_loss", "q2_loss", "actor_loss"]):
+            if losses[j] is not None:
+                arrays[f"step{s}_{nm}"] = _np(losses[j])
+        nets = dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network, actor_target=tr.actor_network_target,
+                    q1_target=tr.q1_network_target, q2_target=tr.q2_network_target)
+        for n, m in nets.items():
+            for i, p in enumerate(m.parameters()):
+                arrays[f"step{s}_{n}_{i}"] = _np(p)
+    _save(name, c, arrays)
+
+
 def gen_replay(name, c):
     rh._install()
     from reagent.replay_memory.circular_replay_buffer import ReplayBuffer
@@ -374,6 +410,8 @@ def main():
         gen_sac(n, c)
     for n, c in REPLAY_CASES.items():
         gen_replay(n, c)
+    for n, c in TD3_CASES.items():
+        gen_td3(n, c)
     gen_preprocessor()
     gen_sum_tree()
     gen_prioritized()

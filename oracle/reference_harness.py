@@ -37,6 +37,10 @@ class PLLoop:
                 pass
 
         trainer.logger = _Logger()
+        if getattr(trainer, "trainer", None) is None:  # TD3 reads self.trainer.log_every_n_steps (:158)
+            import types
+
+            trainer.trainer = types.SimpleNamespace(log_every_n_steps=50)
 
     def _toggle(self, idx):
         saved = {}
@@ -56,12 +60,13 @@ class PLLoop:
         for i, opt in enumerate(self.optimizers):
             saved = self._toggle(i)
             loss = self.trainer.training_step(batch, self.batch_idx, i)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
+            if loss is not None:  # PL skips the optimizer step when training_step returns None
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
             for p, rg in saved.items():
                 p.requires_grad = rg
-            losses.append(loss.detach().clone())
+            losses.append(loss.detach().clone() if loss is not None else None)
         self.batch_idx += 1
         return losses
 
@@ -135,6 +140,20 @@ def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, 
     q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
     return SACTrainer(actor, q1, q2, rl=make_rl_parameters(**rl_kwargs), q_network_optimizer=make_adam(lr),
                       actor_network_optimizer=make_adam(lr), alpha_optimizer=make_adam(lr), **trainer_kw)
+
+
+def build_td3(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, **trainer_kw):
+    _install()
+    from reagent.models.actor import FullyConnectedActor
+    from reagent.models.critic import FullyConnectedCritic
+    from reagent.training.td3_trainer import TD3Trainer
+
+    torch.manual_seed(seed)
+    actor = FullyConnectedActor(state_dim, action_dim, sizes, activations)
+    q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
+    q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
+    return TD3Trainer(actor, q1, q2, rl=make_rl_parameters(**rl_kwargs), q_network_optimizer=make_adam(lr),
+                      actor_network_optimizer=make_adam(lr), **trainer_kw)
 
 
 def dqn_batch_to_reference(b: dict):

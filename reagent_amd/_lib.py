@@ -85,6 +85,9 @@ SIGNATURES = {
     "rg_fc_wgrad_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "rg_fc_wgrad": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_sz,
                              c_int, c_int, c_int, c_int, c_void_p]),
+    "rg_act_backward": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "rg_td3_target_action": (c_int, [c_void_p, c_i64, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_double, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "rg_transpose_cast": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p,
                                    c_i64, c_int, c_void_p]),
     "rg_mlp_fused_supported": (c_int, [ctypes.POINTER(MlpDesc)]),

@@ -148,6 +148,19 @@ static int fc_wgrad_t(const void* dzt, long lddzt, const void* xt, long ldxt, fl
   return (int)hipGetLastError();
 }
 
+// dz = dy * act'(z) expressed through the activation output y = act(z): lets a stack whose LAST
+// layer is non-linear (e.g. the tanh action head of FullyConnectedActor, reagent/models/actor.py:71-75)
+// be trained by the kernels that assume a linear output layer
+__global__ void act_backward_kernel(const float* __restrict__ dy, long ld_dy, const float* __restrict__ y, long ld_y,
+                                    int act, float* __restrict__ dz, long ld_dz, int rows, int cols) {
+  const long total = (long)rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    dz[r * ld_dz + c] = dy[r * ld_dy + c] * act_grad_from_output(y[r * ld_y + c], act);
+  }
+}
+
 }  // namespace rg
 
 using namespace rg;
@@ -202,6 +215,18 @@ int rg_fc_wgrad(const void* dzt, int64_t lddzt, const void* xt, int64_t ldxt, fl
     return fc_wgrad_t<PrecBF16>(dzt, lddzt, xt, ldxt, dw, db, workspace, workspace_bytes,
                                 out_features, in_features, batch, (hipStream_t)stream);
   return RG_EUNSUPPORTED;
+}
+
+int rg_act_backward(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y, int act, float* dz,
+                    int64_t ld_dz, int rows, int cols, rg_stream_t stream) {
+  if (!dy || !y || !dz || rows < 0 || cols < 0) return RG_EINVAL;
+  if (rows == 0 || cols == 0) return RG_OK;
+  const long total = (long)rows * cols;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  RG_LAUNCH(act_backward_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, dy, (long)ld_dy, y,
+            (long)ld_y, act, dz, (long)ld_dz, rows, cols);
+  return (int)hipGetLastError();
 }
 
 int rg_transpose_cast(const void* src, int src_dt, int64_t ld_src, int rows, int cols, void* dst,

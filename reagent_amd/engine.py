@@ -92,6 +92,17 @@ def ensure_slab(params) -> ParamSlab:
     return slab
 
 
+def _through_output_activation(act: int, dout32: torch.Tensor, out32: Optional[torch.Tensor]) -> torch.Tensor:
+    """d loss / d (pre-activation of the last layer) from d loss / d output"""
+    if act == L.ACT["linear"]:
+        return dout32
+    if out32 is None:
+        raise ValueError("backward through a non-linear output layer needs the forward output (out32=)")
+    dz = torch.empty_like(dout32)
+    ops.act_backward(dout32, out32, act, dz)
+    return dz
+
+
 class FCStack:
     """Runs one FullyConnectedNetwork on the GPU kernels.
 
@@ -208,16 +219,18 @@ class FCStack:
 
     # ---- backward ------------------------------------------------------------------------
     def backward(self, dout32: torch.Tensor, xt: torch.Tensor, dw: List[torch.Tensor],
-                 db: List[torch.Tensor], dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False):
+                 db: List[torch.Tensor], dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False,
+                 out32: Optional[torch.Tensor] = None):
         """Gradients of a scalar loss given d loss / d output (fp32 [B, out_last]).
+        out32: the forward output, needed only when the LAST layer is non-linear (its derivative is
+        applied first with rg_act_backward; the kernels below assume a linear output layer).
         skip_wgrad: only propagate to the input (frozen network, e.g. SAC's critics in the actor step).
 
         Requires a preceding ``forward(..., save=True)`` on the same batch.  xt: transposed staged
         input [in, B].  dw[i] / db[i]: contiguous fp32 destinations (gradient-slab views).
         dx32 (optional): fp32 [B, in] destination for the gradient w.r.t. the network input.
         """
-        if self.acts[-1] != L.ACT["linear"]:
-            raise NotImplementedError("training through a non-linear output activation")
+        dout32 = _through_output_activation(self.acts[-1], dout32, out32)
         B = dout32.shape[0]
         ws = self._ws
         n_last = self.dims[-1]
@@ -364,9 +377,9 @@ class FusedMLP:
         return out32
 
     def backward(self, dout32: torch.Tensor, xt, dw: List[torch.Tensor], db: List[torch.Tensor],
-                 dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False):
-        if self.acts[-1] != L.ACT["linear"]:
-            raise NotImplementedError("training through a non-linear output activation")
+                 dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False,
+                 out32: Optional[torch.Tensor] = None):
+        dout32 = _through_output_activation(self.acts[-1], dout32, out32)
         B = dout32.shape[0]
         assert self._ws.get("key") == (B, dout32.device, True), "backward needs a saving forward first"
         d = self._fill_desc()

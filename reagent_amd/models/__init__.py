@@ -1,4 +1,4 @@
-from .actor import GaussianFullyConnectedActor  # noqa: F401
+from .actor import FullyConnectedActor, GaussianFullyConnectedActor  # noqa: F401
 from .base import ModelBase  # noqa: F401
 from .critic import FullyConnectedCritic  # noqa: F401
 from .dqn import FullyConnectedDQN  # noqa: F401

@@ -77,3 +77,46 @@ class GaussianFullyConnectedActor(ModelBase):
         a = squashed_action if squashed_action.stride(-1) == 1 else squashed_action.contiguous()
         ops.gaussian_log_prob(loc_scale, a.float(), log_prob)
         return log_prob
+
+
+class FullyConnectedActor(ModelBase):
+    """Deterministic actor, reagent/models/actor.py:42-110: FC stack whose last activation is
+    `action_activation` (tanh) -> ActorOutput(action, log_prob = 0); optional Gaussian exploration
+    noise (`exploration_variance`) added and clamped to the training action range (serving path)."""
+
+    def __init__(self, state_dim: int, action_dim: int, sizes: List[int], activations: List[str],
+                 use_batch_norm: bool = False, action_activation: str = "tanh",
+                 exploration_variance: float = None) -> None:
+        super().__init__()
+        assert state_dim > 0, "state_dim must be > 0, got {}".format(state_dim)
+        assert action_dim > 0, "action_dim must be > 0, got {}".format(action_dim)
+        if use_batch_norm:
+            raise NotImplementedError("batch normalisation is off on the MI355X hot path")
+        self.state_dim = state_dim
+        self.action_dim = action_dim
+        assert len(sizes) == len(activations), (
+            "The numbers of sizes and activations must match; got {} vs {}".format(len(sizes), len(activations))
+        )
+        self.action_activation = action_activation
+        self.fc = FullyConnectedNetwork([state_dim] + list(sizes) + [action_dim],
+                                        list(activations) + [self.action_activation])
+        self.exploration_variance = exploration_variance
+        if exploration_variance is not None:
+            assert exploration_variance > 0
+
+    def input_prototype(self):
+        return rlt.FeatureData(torch.randn(1, self.state_dim))
+
+    @torch.no_grad()
+    def forward(self, state) -> rlt.ActorOutput:
+        action = self.fc(state.float_features)
+        batch_size = action.shape[0]
+        assert action.shape == (batch_size, self.action_dim), f"{action.shape} != ({batch_size}, {self.action_dim})"
+        if self.exploration_variance is None:
+            return rlt.ActorOutput(action=action, log_prob=torch.zeros(batch_size, 1, device=action.device))
+        # actor.py:99-110: N(0, variance) noise (`scale` = variance, as the reference has it)
+        dist = torch.distributions.Normal(torch.zeros(self.action_dim), torch.ones(self.action_dim) * self.exploration_variance)
+        noise = dist.sample((batch_size,))
+        log_prob = dist.log_prob(noise).to(action.device).sum(dim=1).view(-1, 1).clamp(LOG_PROB_MIN, LOG_PROB_MAX)
+        action = (action + noise.to(action.device)).clamp(-1.0, 1.0)  # CONTINUOUS_TRAINING_ACTION_RANGE
+        return rlt.ActorOutput(action=action, log_prob=log_prob)

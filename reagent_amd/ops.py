@@ -124,6 +124,27 @@ def fc_wgrad(dzt, xt, dw, db, workspace, precision: int):
                                      in_f, batch, precision, L.stream_ptr()))
 
 
+def act_backward(dy, y, act: int, dz):
+    """dz = dy * act'(z) through the activation output y (all fp32 [rows, cols], unit column stride)"""
+    _chk_dev(dy, y, dz)
+    rows, cols = dy.shape
+    assert dy.dtype == y.dtype == dz.dtype == F32 and dy.stride(1) == y.stride(1) == dz.stride(1) == 1
+    _run("rg_act_backward", dict(rows=rows, cols=cols),
+         lambda: L.lib().rg_act_backward(L.ptr(dy), _ld(dy), L.ptr(y), _ld(y), act, L.ptr(dz), _ld(dz), rows, cols,
+                                         L.stream_ptr()))
+
+
+def td3_target_action(next_actor, noise, noise_variance, noise_clip, lo, hi, out):
+    """out (a [B, A] view, e.g. the action columns of the critic input) = smoothed target action"""
+    _chk_dev(next_actor, noise, out)
+    B, A = next_actor.shape
+    assert noise.is_contiguous() and noise.shape == (B, A) and next_actor.stride(1) == 1 and out.stride(1) == 1
+    _run("rg_td3_target_action", dict(B=B, A=A),
+         lambda: L.lib().rg_td3_target_action(L.ptr(next_actor), _ld(next_actor), L.ptr(noise), float(noise_variance),
+                                              float(noise_clip), float(lo), float(hi), L.ptr(out), _ld(out), B, A,
+                                              L.stream_ptr()))
+
+
 def transpose_cast(src, dst=None, dst_t=None):
     _chk_dev(src, dst, dst_t)
     rows, cols = src.shape

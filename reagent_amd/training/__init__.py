@@ -2,3 +2,4 @@ from .dqn_trainer import BCQConfig, DQNTrainer  # noqa: F401
 from .qrdqn_trainer import QRDQNTrainer  # noqa: F401
 from .reagent_lightning_module import ReAgentLightningModule  # noqa: F401
 from .sac_trainer import SACTrainer  # noqa: F401
+from .td3_trainer import TD3Trainer  # noqa: F401

@@ -1,0 +1,109 @@
+"""TD3Trainer (reagent_amd.training) against golden vectors of the reference
+TD3Trainer (tests/golden/td3_twin.npz: 4 steps with delayed_policy_update = 2, the reference's
+torch.randn_like draw recorded and injected).  The reference has no numeric TD3 test: these vectors,
+produced by the unmodified reference under the Lightning-loop emulation, are the pin.
+Tolerances: losses 1e-4 rel, parameters 2e-5 abs (fp32 mode)."""
+import pytest
+import torch
+
+import reagent_amd._lib as L
+from golden_util import Golden
+from reagent_amd import synthetic
+from reagent_amd.core.parameters import RLParameters
+from reagent_amd.models import FullyConnectedActor, FullyConnectedCritic, set_default_precision
+from reagent_amd.optimizer import Optimizer__Union
+from reagent_amd.training import TD3Trainer
+
+NETS = ("actor", "q1", "q2", "actor_target", "q1_target", "q2_target")
+
+
+def build(g, device, precision=L.PREC_F32):
+    c = g.cfg
+    set_default_precision(precision)
+    try:
+        actor = FullyConnectedActor(c["state_dim"], c["action_dim"], c["sizes"], c["activations"])
+        q1 = FullyConnectedCritic(c["state_dim"], c["action_dim"], c["sizes"], c["activations"])
+        q2 = FullyConnectedCritic(c["state_dim"], c["action_dim"], c["sizes"], c["activations"])
+    finally:
+        set_default_precision(L.PREC_F32)
+    with torch.no_grad():
+        for net, name in ((actor, "actor"), (q1, "q1"), (q2, "q2")):
+            for p, init in zip(net.parameters(), g.seq(f"init_{name}_")):
+                p.copy_(init)
+    adam = lambda: Optimizer__Union.default(lr=c["lr"])  # noqa: E731
+    tr = TD3Trainer(actor.to(device), q1.to(device), q2.to(device), rl=RLParameters(**c["rl"]),
+                    q_network_optimizer=adam(), actor_network_optimizer=adam(), noise_variance=c["noise_variance"],
+                    noise_clip=c["noise_clip"], delayed_policy_update=c["delayed_policy_update"])
+    return tr.to(device)
+
+
+def nets(tr):
+    return dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network, actor_target=tr.actor_network_target,
+                q1_target=tr.q1_network_target, q2_target=tr.q2_network_target)
+
+
+def check(tr, g, s, tol=2e-5):
+    for n, net in nets(tr).items():
+        for i, p in enumerate(net.parameters()):
+            err = (p.detach().cpu() - g.t(f"step{s}_{n}_{i}")).abs().max().item()
+            assert err <= tol, (s, n, i, err)
+
+
+def lightning_like_step(tr, opts, batch, batch_idx):
+    """pl.Trainer.fit per batch: a None loss skips that optimizer's step (reagent_lightning_module.py:108-133)"""
+    losses = []
+    for i, opt in enumerate(opts):
+        loss = tr.training_step(batch, batch_idx, i)
+        if loss is not None:
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        losses.append(None if loss is None else loss.detach())
+    return losses
+
+
+def test_td3_matches_reference_generator_path(backend):
+    g = Golden("td3_twin")
+    tr = build(g, backend.device)
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    assert [type(o).__name__ for o in opts] == ["FusedAdam", "FusedAdam", "FusedAdam", "SoftUpdate"]
+    for s in range(g.cfg["steps"]):
+        batch = synthetic.to_policy_input(g.batch(s), backend.device)
+        tr.set_noise(g.t(f"step{s}_noise"))
+        losses = lightning_like_step(tr, opts, batch, s)
+        assert len(losses) == 4
+        delayed = s % g.cfg["delayed_policy_update"] != 0
+        assert (losses[2] is None) == delayed and (losses[3] is None) == delayed
+        for j, nm in enumerate(["q1_loss", "q2_loss", "actor_loss"]):
+            if losses[j] is None:
+                continue
+            ref = float(g.t(f"step{s}_{nm}"))
+            assert abs(float(losses[j]) - ref) <= 1e-4 * abs(ref) + 2e-6, (s, nm, float(losses[j]), ref)
+        check(tr, g, s)
+    assert any(k.startswith("actor_network_target.fc.dnn.0.0") for k in tr.state_dict())
+
+
+def test_td3_native_step_matches_reference(backend):
+    g = Golden("td3_twin")
+    tr = build(g, backend.device)
+    for s in range(g.cfg["steps"]):
+        batch = synthetic.to_policy_input(g.batch(s), backend.device)
+        out = tr.train_step_native(batch, g.t(f"step{s}_noise"))
+        ref = float(g.t(f"step{s}_q1_loss"))
+        assert abs(out["q1_loss"].item() - ref) <= 1e-4 * abs(ref) + 2e-6
+        assert (out["actor_loss"] is None) == (s % g.cfg["delayed_policy_update"] != 0)
+        check(tr, g, s)
+
+
+def test_actor_model_surface(backend):
+    g = Golden("td3_twin")
+    tr = build(g, backend.device)
+    batch = synthetic.to_policy_input(g.batch(0), backend.device)
+    out = tr.actor_network(batch.state)
+    B, A = g.cfg["batch"], g.cfg["action_dim"]
+    assert out.action.shape == (B, A) and out.log_prob.shape == (B, 1) and float(out.log_prob.abs().max()) == 0.0
+    assert out.action.abs().max() <= 1.0  # tanh head
+    noisy = FullyConnectedActor(g.cfg["state_dim"], A, g.cfg["sizes"], g.cfg["activations"],
+                                exploration_variance=0.3).to(backend.device)
+    o2 = noisy(batch.state)
+    assert o2.action.shape == (B, A) and o2.action.abs().max() <= 1.0 and o2.log_prob.min() >= -2 and o2.log_prob.max() <= 2
