@@ -272,6 +272,18 @@ int rg_cpe_head(const float* reward_est, const float* q_cpe, const float* q_cpe_
                 float* reward_partials, float* cpe_partials, float* propensities_out,
                 rg_stream_t stream);
 
+/* C51 head, reagent/training/c51_trainer.py:98-187 (+ CategoricalDQN.log_dist,
+ * reagent/models/categorical_dqn.py:36-38).  q / qn_online / qn_target [B, A*N] fp32 = logits viewed
+ * (B, A, N); qn_online NULL = select the next action with the target net.  next_mask [B, A] =
+ * possible_next_actions_mask (maxq != 0) or next_action (SARSA); support [N] = linspace(qmin, qmax, N).
+ * Outputs: dq [B, A*N] = d loss / d logits; loss_partials [B] whose sum is the loss; all_q [B, A]
+ * (nullable) = expected values of the current distributions.  Limits: N <= 1024, A <= 256. */
+int rg_c51_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
+                const float* next_mask, const float* reward, const float* reward_boosts,
+                const float* not_terminal, double gamma, const float* gamma_exponent, const float* support,
+                double qmin, double qmax, int batch, int num_actions, int num_atoms, int maxq, float* dq,
+                float* loss_partials, float* all_q, rg_stream_t stream);
+
 /* QR-DQN head, reagent/training/qrdqn_trainer.py:108-160 (+ argmax_with_mask :210-214, huber
  * :217-218, quantiles :70-73).  q / qn_online / qn_target [B, A*N] fp32 = network outputs viewed
  * (B, A, N); qn_online NULL = select the next action with the target net (double_q off).

@@ -191,6 +191,39 @@ REPLAY_CASES = {
 }
 
 
+C51_CASES = {
+    # qmin/qmax tight enough that targets hit both clamps (the l == b == u corner cases of the projection)
+    "c51_double": dict(state_dim=8, num_actions=3, num_atoms=11, qmin=-1.0, qmax=4.0, sizes=[32, 24],
+                       activations=["relu", "relu"], rl=dict(gamma=0.9, target_update_rate=0.1, maxq_learning=True,
+                                                             reward_boost={"1": 0.25}),
+                       lr=0.003, double_q=True, batch=64, steps=2, p_impossible=0.25),
+    "c51_sarsa": dict(state_dim=5, num_actions=4, num_atoms=7, qmin=0.0, qmax=1.5, sizes=[16], activations=["tanh"],
+                      rl=dict(gamma=0.8, target_update_rate=0.3, maxq_learning=False), lr=0.002, double_q=False,
+                      batch=40, steps=2, p_impossible=0.0),
+}
+
+
+def gen_c51(name, c):
+    tr = rh.build_c51(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
+                      c["num_atoms"], c["qmin"], c["qmax"], double_q=c["double_q"], seed=0)
+    arrays = {}
+    for i, p in enumerate(tr.q_network.parameters()):
+        arrays[f"init_param_{i}"] = _np(p)
+    loop = rh.PLLoop(tr)
+    for s in range(c["steps"]):
+        b = synthetic.dqn_batch(c["batch"], c["state_dim"], c["num_actions"], seed=500 + s,
+                                p_impossible=c["p_impossible"])
+        for k, v in b.items():
+            arrays[f"step{s}_batch_{k}"] = _np(v)
+        losses = loop.step(rh.dqn_batch_to_reference(b))
+        arrays[f"step{s}_loss"] = _np(losses[0])
+        for i, p in enumerate(tr.q_network.parameters()):
+            arrays[f"step{s}_param_{i}"] = _np(p)
+        for i, p in enumerate(tr.q_network_target.parameters()):
+            arrays[f"step{s}_target_{i}"] = _np(p)
+    _save(name, c, arrays)
+
+
 TD3_CASES = {
     "td3_twin": dict(state_dim=7, action_dim=3, sizes=[32, 24], activations=["relu", "relu"],
                      rl=dict(gamma=0.98, target_update_rate=0.1), lr=0.004, batch=48, steps=4,
@@ -410,6 +443,8 @@ def main():
         gen_sac(n, c)
     for n, c in REPLAY_CASES.items():
         gen_replay(n, c)
+    for n, c in C51_CASES.items():
+        gen_c51(n, c)
     for n, c in TD3_CASES.items():
         gen_td3(n, c)
     gen_preprocessor()

@@ -156,6 +156,21 @@ def build_td3(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, 
                       actor_network_optimizer=make_adam(lr), **trainer_kw)
 
 
+def build_c51(state_dim, num_actions, sizes, activations, rl_kwargs, lr, num_atoms, qmin, qmax, double_q=True, seed=0):
+    """CategoricalDQN over FullyConnectedDQN(num_atoms) as net_builder/categorical_dqn/categorical.py:36-56"""
+    _install()
+    from reagent.models.categorical_dqn import CategoricalDQN
+    from reagent.models.dqn import FullyConnectedDQN
+    from reagent.training.c51_trainer import C51Trainer
+
+    torch.manual_seed(seed)
+    dist_net = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
+    q = CategoricalDQN(dist_net, qmin=qmin, qmax=qmax, num_atoms=num_atoms)
+    return C51Trainer(q, q.get_target_network(), actions=[str(i) for i in range(num_actions)],
+                      rl=make_rl_parameters(**rl_kwargs), double_q_learning=double_q, num_atoms=num_atoms, qmin=qmin,
+                      qmax=qmax, optimizer=make_adam(lr))
+
+
 def dqn_batch_to_reference(b: dict):
     """dict of tensors (see oracle/synthetic.py) -> reference rlt.DiscreteDqnInput."""
     _install()

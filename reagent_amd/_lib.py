@@ -121,6 +121,8 @@ SIGNATURES = {
     "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rg_cpe_head": (c_int, [c_void_p] * 9 + [ctypes.c_double, c_void_p, ctypes.c_double, c_int, c_int, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rg_c51_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_void_p, c_d, c_d, c_int, c_int, c_int, c_int, c_void_p,
+                            c_void_p, c_void_p, c_void_p]),
     "rg_qr_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
     "rg_gaussian_head_forward": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p,

@@ -308,6 +308,150 @@ __global__ void qr_head_kernel(const float* __restrict__ q, const float* __restr
   if (tid == 0) loss_partials[b] = s * inv;
 }
 
+// C51 head (reagent/training/c51_trainer.py:98-187, models/categorical_dqn.py:36-38): one workgroup
+// per transition; logits viewed (B, A, N).
+//   dist(x)[a, j]  = exp(log_softmax(x[a, :])[j])
+//   next dist      : target dist of a* = argmax_a (sum_j dist_sel[a, j] * support[j] + mask penalty),
+//                    sel = online net (double Q) or target net; SARSA: sum_a target dist[a] * next_action[a]
+//   projection     : tq_j = clamp(r + disc * not_terminal * support_j, qmin, qmax); b_j = (tq_j - qmin) / dz;
+//                    l = floor, u = ceil with the reference's l == b == u fix-ups; m[l] += p_j (u - b),
+//                    m[u] += p_j (b - l)  — the two scatter_adds, applied in j order like torch's on the CPU
+//   loss           = -sum_j m[j] * sum_a action[a] * log_softmax(q[a, :])[j]          (mean over the batch)
+//   dq[a, k]       = action[a] * (softmax(q[a, :])[k] * sum_j m[j] - m[k]) / B
+constexpr int C51_MAX_ATOMS = 1024;
+constexpr int C51_MAX_ACTIONS = 256;
+
+__global__ void c51_head_kernel(const float* __restrict__ q, const float* __restrict__ qn_online,
+                                const float* __restrict__ qn_target, const float* __restrict__ action,
+                                const float* __restrict__ next_mask, const float* __restrict__ reward,
+                                const float* __restrict__ reward_boosts, const float* __restrict__ not_terminal,
+                                float gamma, const float* __restrict__ gamma_exponent,
+                                const float* __restrict__ support, float qmin, float qmax, float scale_support,
+                                int batch, int A, int N, int maxq, float* __restrict__ dq,
+                                float* __restrict__ loss_partials, float* __restrict__ all_q) {
+  __shared__ float P[C51_MAX_ATOMS];   // next distribution
+  __shared__ float Mm[C51_MAX_ATOMS];  // projected target distribution m
+  __shared__ float LD[C51_MAX_ATOMS];  // sum_a action[a] * log_dist(state)[a, :]
+  __shared__ float t_max[C51_MAX_ACTIONS], t_lse[C51_MAX_ACTIONS];  // target net, per action
+  __shared__ float c_max[C51_MAX_ACTIONS], c_lse[C51_MAX_ACTIONS];  // online net on `state`
+  __shared__ float sel_q[C51_MAX_ACTIONS];                          // next-state expected values
+  __shared__ float scratch[4];
+  __shared__ int a_star;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row = (long)b * A * N;
+  const float* act_row = action + (long)b * A;
+  const float* mask_row = next_mask + (long)b * A;
+  // per action: log-softmax statistics (max, log sum exp) of the three logit rows and E[support]
+  auto row_stats = [&](const float* x, float& mx, float& lse) {
+    float m = -3.4e38f;
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, x[j]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, shfl_xor(m, off));
+    float se = 0.f;
+    for (int j = lane; j < N; j += 64) se += expf(x[j] - m);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) se += shfl_xor(se, off);
+    mx = m;
+    lse = logf(se);
+  };
+  auto expectation = [&](const float* x, float mx, float lse) {
+    float e = 0.f;
+    for (int j = lane; j < N; j += 64) e += expf((x[j] - mx) - lse) * support[j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e += shfl_xor(e, off);
+    return e;
+  };
+  for (int a = wave; a < A; a += HEAD_THREADS / 64) {
+    float tm, tl, cm, cl;
+    row_stats(qn_target + row + (long)a * N, tm, tl);
+    row_stats(q + row + (long)a * N, cm, cl);
+    float sq;
+    if (qn_online) {
+      float om, ol;
+      row_stats(qn_online + row + (long)a * N, om, ol);
+      sq = expectation(qn_online + row + (long)a * N, om, ol);
+    } else {
+      sq = expectation(qn_target + row + (long)a * N, tm, tl);
+    }
+    const float cq = all_q ? expectation(q + row + (long)a * N, cm, cl) : 0.f;
+    if (lane == 0) {
+      t_max[a] = tm; t_lse[a] = tl; c_max[a] = cm; c_lse[a] = cl; sel_q[a] = sq;
+      if (all_q) all_q[(long)b * A + a] = cq;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && maxq) {  // argmax_with_mask (:203-211): first maximal index
+    int best = 0;
+    float bv = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float v = sel_q[a] + -1e9f * (1.f - mask_row[a]);
+      if (a == 0 || v > bv) {
+        bv = v;
+        best = a;
+      }
+    }
+    a_star = best;
+  }
+  __syncthreads();
+  for (int j = tid; j < N; j += HEAD_THREADS) {
+    float p = 0.f, ld = 0.f;
+    if (maxq) {
+      const int a = a_star;
+      p = expf((qn_target[row + (long)a * N + j] - t_max[a]) - t_lse[a]);
+    } else {
+      for (int a = 0; a < A; ++a) {
+        const float w = mask_row[a];  // next_action one-hot
+        if (w != 0.f) p += expf((qn_target[row + (long)a * N + j] - t_max[a]) - t_lse[a]) * w;
+      }
+    }
+    for (int a = 0; a < A; ++a) {
+      const float w = act_row[a];
+      if (w != 0.f) ld += ((q[row + (long)a * N + j] - c_max[a]) - c_lse[a]) * w;
+    }
+    P[j] = p;
+    LD[j] = ld;
+    Mm[j] = 0.f;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float rb = 0.f;
+    if (reward_boosts)
+      for (int a = 0; a < A; ++a) rb += act_row[a] * reward_boosts[a];
+    const float rew = reward[b] + rb;
+    const float disc = gamma_exponent ? powf(gamma, gamma_exponent[b]) : gamma;
+    const float dn = disc * not_terminal[b];
+    for (int pass = 0; pass < 2; ++pass) {  // m.scatter_add_(lo, p*(u-b)) then m.scatter_add_(up, p*(b-l))
+      for (int j = 0; j < N; ++j) {
+        float tq = rew + dn * support[j];
+        tq = fminf(fmaxf(tq, qmin), qmax);
+        const float bpos = (tq - qmin) / scale_support;
+        int lo = (int)floorf(bpos), up = (int)ceilf(bpos);
+        if (up > 0 && lo == up) lo -= 1;
+        if (lo < N - 1 && lo == up) up += 1;
+        if (pass == 0) Mm[lo] += P[j] * ((float)up - bpos);
+        else Mm[up] += P[j] * (bpos - (float)lo);
+      }
+    }
+  }
+  __syncthreads();
+  float lsum = 0.f, msum = 0.f;
+  for (int j = tid; j < N; j += HEAD_THREADS) {
+    lsum += Mm[j] * LD[j];
+    msum += Mm[j];
+  }
+  const float tot_l = block_sum_256(lsum, scratch);
+  const float tot_m = block_sum_256(msum, scratch);
+  const float inv_b = 1.f / (float)batch;
+  for (int i = tid; i < A * N; i += HEAD_THREADS) {
+    const int a = i / N, k = i % N;
+    const float w = act_row[a];
+    float g = 0.f;
+    if (w != 0.f) g = w * (expf((q[row + i] - c_max[a]) - c_lse[a]) * tot_m - Mm[k]) * inv_b;
+    dq[row + i] = g;
+  }
+  if (tid == 0) loss_partials[b] = -tot_l * inv_b;
+}
+
 __global__ void reduce_sum_kernel(const float* __restrict__ in, int n, float scale,
                                   float* __restrict__ out) {
   __shared__ float scratch[4];
@@ -370,6 +514,24 @@ int rg_qr_head(const float* q, const float* qn_online, const float* qn_target, c
   RG_LAUNCH(qr_head_kernel, dim3(batch), dim3(HEAD_THREADS), (hipStream_t)stream, q, qn_online, qn_target,
             action, next_mask, reward, reward_boosts, not_terminal, (float)gamma, gamma_exponent, quantiles,
             batch, num_actions, num_atoms, maxq, dq, loss_partials, all_q);
+  return (int)hipGetLastError();
+}
+
+int rg_c51_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
+                const float* next_mask, const float* reward, const float* reward_boosts, const float* not_terminal,
+                double gamma, const float* gamma_exponent, const float* support, double qmin, double qmax,
+                int batch, int num_actions, int num_atoms, int maxq, float* dq, float* loss_partials, float* all_q,
+                rg_stream_t stream) {
+  if (!q || !qn_target || !action || !next_mask || !reward || !not_terminal || !support || !dq || !loss_partials ||
+      batch <= 0 || num_actions <= 0 || num_atoms <= 1)
+    return RG_EINVAL;
+  if (num_atoms > C51_MAX_ATOMS || num_actions > C51_MAX_ACTIONS) return RG_EUNSUPPORTED;
+  // c51_trainer.py:72: scale_support = (qmax - qmin) / (num_atoms - 1.0), a Python float the reference
+  // divides an fp32 tensor by
+  const float scale = (float)((qmax - qmin) / ((double)num_atoms - 1.0));
+  RG_LAUNCH(c51_head_kernel, dim3(batch), dim3(HEAD_THREADS), (hipStream_t)stream, q, qn_online, qn_target, action,
+            next_mask, reward, reward_boosts, not_terminal, (float)gamma, gamma_exponent, support, (float)qmin,
+            (float)qmax, scale, batch, num_actions, num_atoms, maxq, dq, loss_partials, all_q);
   return (int)hipGetLastError();
 }
 

@@ -8,3 +8,4 @@ from .fully_connected_network import (  # noqa: F401
     get_default_precision,
     set_default_precision,
 )
+from .categorical_dqn import CategoricalDQN  # noqa: F401

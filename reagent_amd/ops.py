@@ -286,6 +286,21 @@ def cpe_head(reward_est, q_cpe, q_cpe_tgt_next, next_scores, next_mask, action, 
                                      L.stream_ptr()))
 
 
+def c51_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma,
+             gamma_exponent, support, qmin, qmax, num_atoms, maxq, dq, loss_partials, all_q=None):
+    _chk_dev(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma_exponent,
+             support, dq, loss_partials, all_q)
+    batch, A = action.shape
+    for t in (q, qn_target, dq):
+        assert t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A * num_atoms)
+    _run("rg_c51_head", dict(B=batch, A=A, N=num_atoms),
+         lambda: L.lib().rg_c51_head(L.ptr(q), L.ptr(qn_online), L.ptr(qn_target), L.ptr(action), L.ptr(next_mask),
+                                     L.ptr(reward), L.ptr(reward_boosts), L.ptr(not_terminal), float(gamma),
+                                     L.ptr(gamma_exponent), L.ptr(support), float(qmin), float(qmax), batch, A,
+                                     num_atoms, int(maxq), L.ptr(dq), L.ptr(loss_partials), L.ptr(all_q),
+                                     L.stream_ptr()))
+
+
 def qr_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma,
             gamma_exponent, quantiles, num_atoms, maxq, dq, loss_partials, all_q=None):
     _chk_dev(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma_exponent,
