@@ -146,6 +146,31 @@ size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch);
 int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t workspace_bytes,
                        rg_stream_t stream);
 
+/* Optimizer step fused with weight staging for a fused stack: rg_adam_step on the flat parameter slab
+ * of the online network, rg_soft_update of the equally laid out target slab (target NULL = none), and
+ * the bf16 re-staging of the updated weights into wfrag_fwd / wfrag_bwd (online) and target_wfrag_fwd
+ * — same arithmetic per element as the separate entry points, one launch instead of four.
+ * w_off / b_off: element offsets of layer l's weight [dims[l+1], dims[l]] and bias [dims[l+1]] inside
+ * the slabs.  The fragment buffers must have been staged once (their padding is not rewritten in
+ * wfrag_bwd); any of the three fragment pointers of a layer may be NULL. */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* target;
+  int32_t n_layers;
+  int32_t dims[RG_MLP_MAX_LAYERS + 1];
+  int64_t w_off[RG_MLP_MAX_LAYERS];
+  int64_t b_off[RG_MLP_MAX_LAYERS];
+  void* wfrag_fwd[RG_MLP_MAX_LAYERS];
+  void* wfrag_bwd[RG_MLP_MAX_LAYERS];
+  void* target_wfrag_fwd[RG_MLP_MAX_LAYERS];
+} rg_mlp_update_desc; /* host struct */
+int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, double bias_correction1, double bias_correction2_sqrt,
+                        double grad_scale, double tau, rg_stream_t stream);
+
 /* ---- replay buffer ------------------------------------------------------------------------ */
 
 /* n-step bookkeeping of ReplayBuffer.sample_transition_batch,

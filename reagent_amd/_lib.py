@@ -74,6 +74,19 @@ class MlpDesc(ctypes.Structure):
     ]
 
 
+class MlpUpdateDesc(ctypes.Structure):
+    _fields_ = [
+        ("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("target", c_void_p),
+        ("n_layers", ctypes.c_int32),
+        ("dims", ctypes.c_int32 * (MLP_MAX_LAYERS + 1)),
+        ("w_off", ctypes.c_int64 * MLP_MAX_LAYERS),
+        ("b_off", ctypes.c_int64 * MLP_MAX_LAYERS),
+        ("wfrag_fwd", c_void_p * MLP_MAX_LAYERS),
+        ("wfrag_bwd", c_void_p * MLP_MAX_LAYERS),
+        ("target_wfrag_fwd", c_void_p * MLP_MAX_LAYERS),
+    ]
+
+
 # every symbol include/reagent_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "rg_strerror": (ctypes.c_char_p, [c_int]),
@@ -108,6 +121,7 @@ SIGNATURES = {
     "rg_replay_nstep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_replay_gather": (c_int, [ctypes.POINTER(GatherCol), c_int, c_i64, c_int, c_int, c_void_p]),
+    "rg_mlp_update_fused": (c_int, [ctypes.POINTER(MlpUpdateDesc)] + [ctypes.c_double] * 9 + [c_void_p]),
     "rg_sumtree_depth": (c_int, [c_i64]),
     "rg_sumtree_nodes": (c_sz, [c_i64]),
     "rg_sumtree_set": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -19,6 +19,7 @@
 // Replaces: FullyConnectedNetwork.forward (reagent/models/fully_connected_network.py:157-163)
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
 #include "rg_gemm.h"
+#include "rg_optim.h"
 #include <type_traits>
 #include "../../include/reagent_hip.h"
 
@@ -969,6 +970,70 @@ __global__ void stage_weights_frag_kernel(const float* __restrict__ w, int N, in
   }
 }
 
+// ---- optimizer step fused with weight staging ----------------------------------------------------
+// After the backward pass a DQN step runs Adam on the online network, the soft update of the target
+// network and the bf16 re-staging of both networks' weights: four launches of ~5-8 us each for
+// 600 K parameters (they are launch-bound, not bandwidth-bound).  This kernel walks the flat
+// parameter slab (coalesced on the five fp32 arrays) and does all of it per element: the Adam and
+// soft-update arithmetic of rg_optim.h, then, for weight elements, the bf16 value goes to its three
+// fragment slots (online forward / backward, target forward; 2-byte scattered stores into 1.2 MB).
+struct UpdateArgs {
+  int n;
+  long total;  // slab elements
+  int N[FB_MAXL], K[FB_MAXL];
+  long w_off[FB_MAXL], b_off[FB_MAXL];
+  bf16_t* wf[FB_MAXL];
+  bf16_t* wb[FB_MAXL];
+  bf16_t* twf[FB_MAXL];
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  float* t;
+  AdamCoef c;
+  float tau, one_minus_tau;
+};
+
+__global__ void mlp_update_kernel(UpdateArgs U) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= U.total) return;
+  // which tensor of the slab does element i belong to?  (alignment gaps between tensors: none)
+  int l = -1, is_w = 0;
+  long rel = 0;
+#pragma unroll
+  for (int k = 0; k < FB_MAXL; ++k) {
+    if (k < U.n) {
+      const long wn = (long)U.N[k] * U.K[k];
+      if (i >= U.w_off[k] && i < U.w_off[k] + wn) { l = k; is_w = 1; rel = i - U.w_off[k]; }
+      if (i >= U.b_off[k] && i < U.b_off[k] + U.N[k]) { l = k; is_w = 0; rel = i - U.b_off[k]; }
+    }
+  }
+  if (l < 0) return;
+  float mi = U.m[i], vi = U.v[i];
+  const float pn = adam_element(U.c, U.p[i], U.g[i], mi, vi);
+  U.p[i] = pn;
+  U.m[i] = mi;
+  U.v[i] = vi;
+  float tn = 0.f;
+  if (U.t) {
+    tn = soft_update_element(U.tau, U.one_minus_tau, pn, U.t[i]);
+    U.t[i] = tn;
+  }
+  if (!is_w) return;
+  const int N = U.N[l], K = U.K[l];
+  const int n = (int)(rel / K), k = (int)(rel % K);
+  const int KCf = (K + 15) / 16, KCb = (N + 15) / 16;
+  // B-fragment slot of W[n][k] (forward) and of W^T[k][n] (backward); padding slots were zeroed by
+  // the first staging and are never touched
+  const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+  if (U.wf[l]) U.wf[l][jf] = f32_to_bf16(pn);
+  if (U.twf[l]) U.twf[l][jf] = f32_to_bf16(tn);
+  if (U.wb[l]) {
+    const long jb = ((((long)(k >> 5) * KCb + (n >> 4)) * 64) + ((k & 31) + 32 * ((n & 15) >> 3))) * 8 + (n & 7);
+    U.wb[l][jb] = f32_to_bf16(pn);
+  }
+}
+
 static int fused_supported(const rg_mlp_desc* d) {
   if (!d || d->n_layers < 2 || d->n_layers > FB_MAXL) return 0;
   const int H = d->dims[1];
@@ -1273,6 +1338,38 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   RG_LAUNCH(reduce_group_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), (hipStream_t)stream, R);
+  return (int)hipGetLastError();
+}
+
+int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, double bias_correction1, double bias_correction2_sqrt,
+                        double grad_scale, double tau, rg_stream_t stream) {
+  if (!d || d->n_layers < 1 || d->n_layers > FB_MAXL || !d->param || !d->grad || !d->exp_avg || !d->exp_avg_sq ||
+      bias_correction1 == 0.0 || (d->target && (tau < 0.0 || tau > 1.0)))
+    return RG_EINVAL;
+  UpdateArgs U;
+  U.n = d->n_layers;
+  long total = 0;
+  for (int l = 0; l < FB_MAXL; ++l) {
+    if (l < d->n_layers) {
+      const int K = d->dims[l], N = d->dims[l + 1];
+      U.N[l] = N; U.K[l] = K;
+      U.w_off[l] = d->w_off[l]; U.b_off[l] = d->b_off[l];
+      U.wf[l] = (bf16_t*)d->wfrag_fwd[l]; U.wb[l] = (bf16_t*)d->wfrag_bwd[l]; U.twf[l] = (bf16_t*)d->target_wfrag_fwd[l];
+      const long we = d->w_off[l] + (long)N * K, be = d->b_off[l] + N;
+      total = we > total ? we : total;
+      total = be > total ? be : total;
+    } else {
+      U.N[l] = U.K[l] = 0; U.w_off[l] = U.b_off[l] = 0; U.wf[l] = U.wb[l] = U.twf[l] = nullptr;
+    }
+  }
+  U.total = total;
+  U.p = d->param; U.g = d->grad; U.m = d->exp_avg; U.v = d->exp_avg_sq; U.t = d->target;
+  const double step_size = lr / bias_correction1;
+  U.c = AdamCoef{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                 (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale};
+  U.tau = (float)tau; U.one_minus_tau = (float)(1.0 - tau);
+  RG_LAUNCH(mlp_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (hipStream_t)stream, U);
   return (int)hipGetLastError();
 }
 

@@ -1,41 +1,23 @@
 // optim.hip — fused Adam and soft target update over flat fp32 parameter slabs (HBM-bound).
-#include <rg_platform.h>
+#include "rg_optim.h"
 #include "../../include/reagent_hip.h"
 
 namespace rg {
 
-// torch/optim/adam.py::_single_tensor_adam arithmetic, same operation order:
-//   g      = grad (+ wd * p)
-//   m      = m + (g - m) * (1 - beta1)                      (lerp_)
-//   v      = v * beta2 + ((1 - beta2) * g) * g              (mul_ + addcmul_)
-//   denom  = sqrt(v) / bias_correction2_sqrt + eps
-//   p      = p + (-step_size * m) / denom                   (addcdiv_)
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                            float* __restrict__ m, float* __restrict__ v, long n, float w1,
-                            float beta2, float w2, float eps, float wd, float neg_step_size,
-                            float bc2_sqrt, float grad_scale) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long)gridDim.x * blockDim.x) {
-    float gi = g[i];
-    if (grad_scale != 1.f) gi *= grad_scale;
-    const float pi = p[i];
-    if (wd != 0.f) gi = gi + wd * pi;
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, AdamCoef c) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float mi = m[i], vi = v[i];
-    mi = mi + w1 * (gi - mi);
-    vi = vi * beta2;
-    vi = vi + (w2 * gi) * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi + (neg_step_size * mi) / denom;
+    p[i] = adam_element(c, p[i], g[i], mi, vi);
     m[i] = mi;
     v[i] = vi;
   }
 }
 
-__global__ void soft_update_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n,
-                                   float tau, float one_minus_tau) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long)gridDim.x * blockDim.x)
-    tgt[i] = tau * src[i] + one_minus_tau * tgt[i];
+__global__ void soft_update_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float tau,
+                                   float one_minus_tau) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    tgt[i] = soft_update_element(tau, one_minus_tau, src[i], tgt[i]);
 }
 
 static unsigned grid_for(long n) {
@@ -58,9 +40,10 @@ int rg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
   if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || bias_correction1 == 0.0) return RG_EINVAL;
   if (n == 0) return RG_OK;
   const double step_size = lr / bias_correction1;
-  RG_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), (hipStream_t)stream, param, grad, exp_avg,
-            exp_avg_sq, (long)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-            (float)weight_decay, (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale);
+  const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                      (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale};
+  RG_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n,
+            c);
   return (int)hipGetLastError();
 }
 

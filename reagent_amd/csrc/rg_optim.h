@@ -1,0 +1,42 @@
+// rg_optim.h — the per-element optimizer arithmetic, shared by the stand-alone kernels (optim.hip)
+// and the fused update (mlp_fused.hip) so that both produce the same bits.  Floating-point
+// contraction is switched off inside: whether `a + b * c` becomes an FMA would otherwise depend on
+// the surrounding code, and the two call sites differed in the last place on the MI355X.
+#pragma once
+#include <rg_platform.h>
+
+namespace rg {
+
+// torch/optim/adam.py::_single_tensor_adam, same operation order:
+//   g      = grad * grad_scale (+ wd * p)
+//   m      = m + (g - m) * (1 - beta1)                      (lerp_)
+//   v      = v * beta2 + ((1 - beta2) * g) * g              (mul_ + addcmul_)
+//   denom  = sqrt(v) / bias_correction2_sqrt + eps
+//   p      = p + (-step_size * m) / denom                   (addcdiv_)
+struct AdamCoef {
+  float w1, beta2, w2, eps, wd, neg_step_size, bc2_sqrt, grad_scale;
+};
+
+__device__ __forceinline__ float adam_element(const AdamCoef& c, float pi, float gi, float& mi, float& vi) {
+#pragma clang fp contract(off)
+  if (c.grad_scale != 1.f) gi = gi * c.grad_scale;
+  if (c.wd != 0.f) gi = gi + c.wd * pi;
+  const float dm = gi - mi;
+  mi = mi + c.w1 * dm;
+  vi = vi * c.beta2;
+  const float g2 = (c.w2 * gi) * gi;
+  vi = vi + g2;
+  const float denom = sqrtf(vi) / c.bc2_sqrt + c.eps;
+  const float num = c.neg_step_size * mi;
+  return pi + num / denom;
+}
+
+// reagent/optimizer/soft_update.py:60-70: target = tau * source + (1 - tau) * target
+__device__ __forceinline__ float soft_update_element(float tau, float one_minus_tau, float src, float tgt) {
+#pragma clang fp contract(off)
+  const float a = tau * src;
+  const float b = one_minus_tau * tgt;
+  return a + b;
+}
+
+}  // namespace rg

@@ -349,6 +349,90 @@ class QStepCore(DQNTrainerBaseLightning):
 
     _update_pending = False
     _pending_reduce = None
+    _fused_plan = None
+
+    def _fused_update(self, adam, soft) -> bool:
+        """Adam + soft update + bf16 re-staging of both networks in ONE launch (rg_mlp_update_fused)
+        when the step has the plain shape: both stacks on the fused kernels, one Adam group over the
+        q-network's slab, a soft update pairing exactly the target's parameters with it.  Arithmetic per
+        element is that of the separate launches; returns False (nothing done) otherwise."""
+        import math
+
+        from ..engine import FusedMLP, ensure_slab
+
+        qs, ts = self._qs, self._ts
+        plan = self._fused_plan
+        if plan is None:
+            ok = (isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and len(adam.param_groups) == 1
+                  and len(soft.param_groups) == 1)
+            if ok:
+                sp = soft.param_groups[0]["params"]
+                n = len(sp) // 2
+                tgt, src = sp[:n], sp[n:]
+                ok = (len(src) == len(self._hip_params) and all(a is b for a, b in zip(src, self._hip_params))
+                      and all(a is b for a, b in zip(adam.param_groups[0]["params"], self._hip_params))
+                      and all(t is not s_ for t, s_ in zip(tgt, src)))
+            if ok:
+                tslab = ensure_slab(tgt)
+                ok = tslab.offsets == self._slab.offsets and tslab.total == self._slab.total
+            if not ok:
+                self._fused_plan = plan = False
+            else:
+                index = {id(p): i for i, p in enumerate(self._hip_params)}
+                lin = self.q_network.fc.linears()
+                d = L.MlpUpdateDesc()
+                d.n_layers = len(lin)
+                for i, v in enumerate(qs.dims):
+                    d.dims[i] = v
+                for l, layer in enumerate(lin):
+                    d.w_off[l] = self._slab.offsets[index[id(layer.weight)]]
+                    d.b_off[l] = self._slab.offsets[index[id(layer.bias)]]
+                self._fused_plan = plan = dict(desc=d, tgt=tgt, tslab=tslab)
+        if plan is False:
+            return False
+        for p in self._hip_params:  # needs dense gradients in the slab (what the HIP backward wrote)
+            if p.grad is None:
+                return False
+        if any(w is None for w in qs._wf) or any(w is None for w in qs._wb) or any(w is None for w in ts._wf):
+            return False  # fragments not staged yet (their padding is written by the first staging)
+        slab, tslab, d = adam.slab_for(0), plan["tslab"], plan["desc"]
+        if slab is not self._slab or not tslab.is_bound():
+            return False
+        group = adam.param_groups[0]
+        beta1, beta2 = group["betas"]
+        step = None
+        for i, p in enumerate(slab.params):
+            st = adam.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = slab.view(slab.exp_avg, i)
+                st["exp_avg_sq"] = slab.view(slab.exp_avg_sq, i)
+                st["_step_int"] = 0
+            st["_step_int"] += 1
+            st["step"] += 1
+            step = st["_step_int"] if step is None else step
+            if st["_step_int"] != step:
+                raise RuntimeError("fused update needs every parameter at the same Adam step")
+        d.param, d.grad = slab.data.data_ptr(), slab.grad.data_ptr()
+        d.exp_avg, d.exp_avg_sq = slab.exp_avg.data_ptr(), slab.exp_avg_sq.data_ptr()
+        d.target = tslab.data.data_ptr()
+        for l in range(d.n_layers):
+            d.wfrag_fwd[l], d.wfrag_bwd[l] = qs._wf[l].data_ptr(), qs._wb[l].data_ptr()
+            d.target_wfrag_fwd[l] = ts._wf[l].data_ptr()
+        tau = soft.param_groups[0]["tau"]
+        ops._run("rg_mlp_update_fused", dict(P=slab.total),
+                 lambda: L.lib().rg_mlp_update_fused(d, group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
+                                                     1.0 - beta1**step, math.sqrt(1.0 - beta2**step),
+                                                     1.0 / self._dp_world, tau, L.stream_ptr()))
+        from ..optimizer import _bump
+
+        _bump(slab.params)
+        _bump(plan["tgt"])
+        # both networks' fragments are current for the bumped versions: no separate staging launch
+        for st_, need_t in ((qs, True), (ts, False)):
+            st_._staged_versions = tuple((w._version, getattr(w, "_rg_version", 0)) for w in st_.weights) + (need_t,)
+            st_._wsrc_ptrs = [w.data_ptr() for w in st_.weights]
+        return True
 
     @torch.no_grad()
     def apply_pending_update(self):
@@ -360,9 +444,13 @@ class QStepCore(DQNTrainerBaseLightning):
             self._pending_reduce = None
         opts = self.native_optimizers()
         adam, soft = opts[0], opts[-1]
+        cpe = getattr(self, "_cpe", None)
+        if cpe is None and self._fused_update(adam, soft):
+            self.all_batches_processed += 1
+            self._update_pending = False
+            return
         adam.grad_scale = 1.0 / self._dp_world
         adam.step()
-        cpe = getattr(self, "_cpe", None)
         if cpe is not None:  # reward network and CPE q-network, in the reference's optimizer order
             cpe.forward(self._pending_batch)
             for which, opt in (("reward", opts[1]), ("cpe", opts[2])):

@@ -205,3 +205,44 @@ def test_dqn_cpe_native_step(backend, name):
         batch = synthetic.to_dqn_input(g.batch(s), backend.device)
         loss = tr.train_step_native(batch)
         _check_cpe_step(tr, g, s, [loss.item(), tr._cpe.losses["reward"].item(), tr._cpe.losses["cpe"].item()])
+
+
+def test_fused_update_equals_separate_launches(backend):
+    """rg_mlp_update_fused (Adam + soft update + bf16 re-staging of both networks in one launch, taken by
+    the native step when both stacks are on the fused kernels) leaves the same bits as the four separate
+    launches: parameters, target parameters, Adam moments, and the next step's Q-values (= the staged
+    fragments)."""
+    from reagent_amd.engine import FusedMLP
+
+    def make():
+        set_default_precision(L.PREC_BF16)
+        try:
+            torch.manual_seed(3)
+            q = FullyConnectedDQN(24, 5, [256, 256], ["relu", "relu"]).to(backend.device)
+        finally:
+            set_default_precision(L.PREC_F32)
+        return DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(5)],
+                          rl=RLParameters(gamma=0.9, target_update_rate=0.05, q_network_loss="huber"),
+                          optimizer=Optimizer__Union.default(lr=0.003),
+                          evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(backend.device)
+
+    fused, separate = make(), make()
+    separate._fused_plan = False
+    for s in range(3):
+        batch = synthetic.to_dqn_input(synthetic.dqn_batch(200, 24, 5, seed=40 + s, p_impossible=0.2), backend.device)
+        la, lb = fused.train_step_native(batch), separate.train_step_native(batch)
+        assert torch.equal(la, lb), s
+        assert torch.equal(fused.all_action_scores, separate.all_action_scores), s
+    assert isinstance(fused._qs, FusedMLP) and isinstance(fused._fused_plan, dict)  # the fused path really ran
+    for a, b in zip(fused.q_network.parameters(), separate.q_network.parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(fused.q_network_target.parameters(), separate.q_network_target.parameters()):
+        assert torch.equal(a, b)
+    oa, ob = fused.native_optimizers()[0], separate.native_optimizers()[0]
+    for pa, pb in zip(fused.q_network.parameters(), separate.q_network.parameters()):
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+        assert int(oa.state[pa]["step"]) == int(ob.state[pb]["step"]) == 3
+    x = batch.state
+    assert torch.equal(fused.q_network(x), separate.q_network(x))
+    assert torch.equal(fused.q_network_target(x), separate.q_network_target(x))
