@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
     ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
 
@@ -91,7 +92,8 @@ def build(args, device, rank):
             for i in range(S)}
     pre = Preprocessor(norm, device=device)
     loop = OfflineDqnLoop(rb, trainer, args.batch, pre,
-                          state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32)
+                          state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32,
+                          prefetch=args.prefetch)
     return loop, trainer, init, cols, (mean, std)
 
 

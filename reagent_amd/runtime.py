@@ -8,6 +8,10 @@ dataloader, Lightning or host synchronisation:
     state, next_state = Preprocessor(...)                  rg_normalize_dense x2
     trainer.train_step_native(input)                       FC fwd x3, head, bwd, Adam, soft update
 Everything is enqueued on torch's current stream; the loss stays on the device.
+`prefetch=True` moves the sampling / gather / input-maker launches of batch k+1 to a second HIP stream
+while step k computes.  Measured on one MI355X (same box, C2): 0.642 ms/step with it against 0.615
+without — the fused MLP kernels fill every CU's registers and LDS, so the gather only runs in their
+tails and slows them more than it hides; it is therefore OFF by default and kept as an option.
 """
 from typing import Optional
 
@@ -20,7 +24,7 @@ from .replay_memory import ReplayBuffer
 
 class OfflineDqnLoop:
     def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int,
-                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None):
+                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None, prefetch: bool = False):
         self.rb = replay_buffer
         self.trainer = trainer
         self.batch_size = batch_size
@@ -30,6 +34,9 @@ class OfflineDqnLoop:
         self.state_dtype = state_dtype
         # 1:1 normalization tables ride along with the gather (no separate normalize pass)
         self.fuse_norm = state_preprocessor is not None and state_preprocessor.elementwise
+        self.prefetch = prefetch and torch.device(replay_buffer.device).type == "cuda"
+        self._side = None
+        self._ready = None  # (batch, event) of the prefetched next batch
 
     def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.DiscreteDqnInput:
         if self.fuse_norm:
@@ -46,11 +53,41 @@ class OfflineDqnLoop:
             inp.next_state = rlt.FeatureData(self.pre(ns, self._presence))
         return inp
 
+    @staticmethod
+    def _tensors(obj):
+        if isinstance(obj, torch.Tensor):
+            yield obj
+        elif hasattr(obj, "__dataclass_fields__"):
+            for name in obj.__dataclass_fields__:
+                yield from OfflineDqnLoop._tensors(getattr(obj, name))
+
+    def _launch_prefetch(self):
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)  # once: after whatever filled the replay storage; later launches
+            # depend on nothing the training step writes
+        with torch.cuda.stream(self._side):
+            batch = self.make_batch()
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        for t in self._tensors(batch):  # allocated on the side stream, consumed on the main one
+            t.record_stream(main)
+        return batch, ev
+
     def step(self, indices: Optional[torch.Tensor] = None) -> torch.Tensor:
         # data parallel: the previous step's gradient all-reduce is still in flight here, and the
-        # gather below does not depend on it — the trainer joins it right before Adam
-        batch = self.make_batch(indices)
-        return self.trainer.train_step_native(batch, defer_update=True)
+        # gather does not depend on it — the trainer joins it right before Adam
+        if not self.prefetch or indices is not None:
+            batch = self.make_batch(indices)
+            return self.trainer.train_step_native(batch, defer_update=True)
+        if self._ready is None:
+            self._ready = self._launch_prefetch()
+        batch, ev = self._ready
+        torch.cuda.current_stream().wait_event(ev)
+        loss = self.trainer.train_step_native(batch, defer_update=True)
+        self._ready = self._launch_prefetch()  # batch k+1 travels while step k computes
+        return loss
 
     def flush(self):
         """apply an update left pending by the last step (call before reading parameters)"""
