@@ -644,11 +644,8 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
 // per 32-row block and half, one MFMA per (n-tile, k-tile) pair.  Workgroup tile 256(n) x 256(k),
 // waves 2(n) x 4(k), each 4x2 MFMA tiles; operands staged HBM -> VGPR -> LDS (lane-linear 16 B,
 // conflict-free), two 32-row blocks per stage, double buffered, one barrier per stage.
-constexpr int WG_MB_STAGE = 1;                      // 32-row blocks per stage
+constexpr int WG_MB_STAGE = 2;
 constexpr int WG_STAGE_BYTES = WG_MB_STAGE * 32 * 1024;
-constexpr int WG_DMA_SLOTS = 4;                     // LDS ring (128 KB), three stages in flight
-constexpr int WG_DMA_PER_THREAD = 2048 / 512;       // 16-byte units of a stage per thread
-static_assert(3 * WG_DMA_PER_THREAD - WG_DMA_PER_THREAD == 8, "RG_WAIT_VMCNT(8) in wgrad_frag_body");
 
 struct WgradFragArgs {
   const bf16_t* a_frag;
@@ -696,68 +693,95 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // Operand staging by LDS-DMA (global_load_lds_dwordx4): a ring of WG_DMA_SLOTS stages of one 32-row
-  // block each (A: 8 tiles x 2 KB, B: 8 tiles x 2 KB), three stages in flight.  The LDS image of a
-  // fragment record is lane-linear 16-byte units — exactly what the DMA writes (wave-uniform base +
-  // lane*16) — so nothing passes through VGPRs and there is no ds_write pass.  The kernel is HBM-bound
-  // (414 MB of operands per launch): with register staging its phase profile showed 34 % of a
-  // workgroup's life waiting for operands with two stages in flight (profiles/microbench/wgrad_phases).
-  // Out-of-range blocks / tiles read a clamped valid address; the data is never used (tiles >= na only
-  // reach dW rows >= N, which are not stored; stages past the end are not computed), which keeps the
-  // number of DMAs per stage constant and the vmcnt arithmetic below exact.
+  // staging registers: 4096 16-byte units per stage / 512 threads, TWO stages in flight (R0, R1):
+  // the operands come from HBM (~2.5-4.5k cycles under load) and a stage computes in ~1.8k, so a
+  // one-stage lead left every stage waiting on memory (phase timing, profiles/microbench/
+  // wgrad_phases: 16 % in the LDS store's wait + 37 % at the barrier behind the slowest wave).
+  // The loads are unconditional — out-of-range blocks / tiles read a clamped, valid address and the
+  // result is never used (tiles >= na only reach dW rows >= N, which are not stored; stages past the
+  // end are not computed) — so the compiler keeps counted s_waitcnt vmcnt(N) and storing R0 does not
+  // wait for R1's younger loads.
+  constexpr int UNITS = WG_MB_STAGE * 2048, PER = UNITS / WG_THREADS;
+  u16x8 R0[PER], R1[PER];
   const int mb_last = mb_end - 1;
-  auto issue = [&](int blk, int slot) {
-    const int mb = blk < mb_last ? blk : mb_last;
-    // units 0..1023 of a stage are the A operand, 1024..2047 the B operand: with 512 threads that is a
-    // compile-time property of i, so every wave issues exactly WG_DMA_PER_THREAD DMAs, unconditionally
-    static_for<0, WG_DMA_PER_THREAD>([&](auto i_c) __attribute__((always_inline)) {
-      constexpr int i = decltype(i_c)::value;
-      constexpr bool is_b = i * WG_THREADS >= 1024;
-      const int off = (tid + i * WG_THREADS) & 1023, tile = off >> 7;
-      const bf16_t* src = is_b ? g.b_frag + ((long)mb * g.NTb + tb0 + (tile < nb ? tile : nb - 1)) * 1024
-                               : g.a_frag + ((long)mb * g.NTa + ta0 + (tile < na ? tile : na - 1)) * 1024;
-      global_load_lds_b128(src + (off & 127) * 8, smem + slot * WG_STAGE_BYTES + (wave * 64 + i * WG_THREADS) * 16);
-    });
+  auto gload = [&](u16x8 (&regs)[PER], int mb0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * WG_THREADS;
+      const int mbl = u >> 11, w = u & 2047, isb = w >> 10, off = w & 1023;
+      const int tile = off >> 7;
+      const int mb = mb0 + mbl < mb_last ? mb0 + mbl : mb_last;
+      const bf16_t* src = isb ? g.b_frag + ((long)mb * g.NTb + tb0 + (tile < nb ? tile : nb - 1)) * 1024
+                              : g.a_frag + ((long)mb * g.NTa + ta0 + (tile < na ? tile : na - 1)) * 1024;
+      regs[i] = *(const u16x8*)(src + (off & 127) * 8);
+    }
   };
-  // a wave whose tiles are all padding (thin layers: dW 16x512, 512x128) skips its MFMAs
+  auto lstore = [&](int buf, const u16x8 (&regs)[PER]) {
+    char* base = smem + buf * WG_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * WG_THREADS;
+      *(u16x8*)(base + (long)u * 16) = regs[i];
+    }
+  };
+  // thin layers (dW 16x512, 512x128) fill only part of the 8x8 tile grid: a wave whose tiles are all
+  // padding skips its MFMAs, so those stages stop being MFMA-bound for nothing.  (Guarding single
+  // tiles inside a wave was tried: the accumulators fall into scratch, 5x slower.)
   const bool wave_has_tiles = wn * 4 < na && wk * 2 < nb;
-  auto compute = [&](int slot) {
-    const char* base = smem + slot * WG_STAGE_BYTES;
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * WG_STAGE_BYTES;
     if (!wave_has_tiles) return;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      u16x8 af[4], bf[2];
+    for (int mbl = 0; mbl < WG_MB_STAGE; ++mbl) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const u16x8*)(base + (wn * 4 + i) * 2048 + h * 1024 + lane * 16);
+      for (int h = 0; h < 2; ++h) {
+        u16x8 af[4], bf[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *(const u16x8*)(base + 16384 + (wk * 2 + j) * 2048 + h * 1024 + lane * 16);
+        for (int i = 0; i < 4; ++i)
+          af[i] = *(const u16x8*)(base + mbl * 32768 + (wn * 4 + i) * 2048 + h * 1024 + lane * 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j)
+          bf[j] = *(const u16x8*)(base + mbl * 32768 + 16384 + (wk * 2 + j) * 2048 + h * 1024 + lane * 16);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+      }
     }
   };
 
   RG_PHASE_INIT();
   if (mb_begin < mb_end) {
-    const int n_blk = mb_end - mb_begin;
-    issue(mb_begin + 0, 0);
-    issue(mb_begin + 1, 1);
-    issue(mb_begin + 2, 2);
+    // stage t covers blocks [mb_begin + t*WG_MB_STAGE, +WG_MB_STAGE); LDS buffer t&1; at the top of an
+    // iteration pair R0 holds stage t+1 and R1 stage t+2
+    const int n_stages = (mb_end - mb_begin + WG_MB_STAGE - 1) / WG_MB_STAGE;
+    auto stage_mb = [&](int t) { return mb_begin + t * WG_MB_STAGE; };
+    gload(R0, stage_mb(0));
+    lstore(0, R0);
+    gload(R0, stage_mb(1));
+    gload(R1, stage_mb(2));
+    __syncthreads();
     RG_PHASE(0);
-    for (int t = 0; t < n_blk; ++t) {
-      // three stages (3 * WG_DMA_PER_THREAD DMAs per thread) are outstanding: let the oldest land,
-      // then meet the other waves — past the barrier block t is complete in LDS and every wave has
-      // finished reading block t-1, whose slot the DMA issued below overwrites
-      RG_WAIT_VMCNT(8);
+    // per iteration: park the next stage in the idle LDS buffer and re-arm its registers FIRST (its
+    // data was requested two stages ago, so this does not wait), then compute: the LDS stores and the
+    // load issue of one wave run under the MFMAs of its SIMD partner, and the barrier only absorbs
+    // the compute skew
+    for (int t = 0; t < n_stages; t += 2) {
+      lstore(1, R0);
+      gload(R0, stage_mb(t + 3));
       RG_PHASE(2);
-      raw_barrier();
-      RG_PHASE(3);
-      compute(t & (WG_DMA_SLOTS - 1));
-      issue(mb_begin + t + 3, (t + 3) & (WG_DMA_SLOTS - 1));
+      compute(0);
       RG_PHASE(1);
+      __syncthreads();
+      RG_PHASE(3);
+      lstore(0, R1);
+      gload(R1, stage_mb(t + 4));
+      RG_PHASE(2);
+      if (t + 1 < n_stages) compute(1);
+      RG_PHASE(1);
+      __syncthreads();
+      RG_PHASE(3);
     }
-    RG_WAIT_VMCNT(0);
   }
 
   float* part = g.partial + (long)split * g.slab;
@@ -1210,7 +1234,7 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
   const int grid = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
-  const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
+  const size_t lds = 2 * (size_t)WG_STAGE_BYTES;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
   RG_LAUNCH_DYN(wgrad_frag_kernel, dim3(grid), dim3(WG_THREADS), lds, (hipStream_t)stream, g);
   int rc = (int)hipGetLastError();
@@ -1308,7 +1332,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   G.wg_begin[FB_MAXL] = wg;
   R.elem_begin[FB_MAXL] = el;
   for (int l = d->n_layers; l <= FB_MAXL; ++l) { G.wg_begin[l] = wg; R.elem_begin[l] = el; }
-  const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
+  const size_t lds = 2 * (size_t)WG_STAGE_BYTES;
   RG_ALLOW_LDS(wgrad_group_kernel, lds);
   RG_LAUNCH_DYN(wgrad_group_kernel, dim3(wg), dim3(WG_THREADS), lds, (hipStream_t)stream, G);
   int rc = (int)hipGetLastError();

@@ -18,7 +18,7 @@ __device__ unsigned long long* g_stamps;
       o_[6] = ph_t;                                                                   \
     }                                                                                 \
   } while (0)
-#include "../../reagent_amd/csrc/mlp_fused.hip"
+#include "_head/mlp_fused.hip"
 #include <cstdio>
 #include <vector>
 
@@ -50,7 +50,7 @@ int main() {
   printf("wgrad group + reduce: %.2f us per call (stamps on), err=%d, workspace %.1f MB\n", ms * 1e3 / 20, (int)hipGetLastError(), wsb / 1e6);
   std::vector<unsigned long long> h((size_t)max_wg * 8 * 8);
   hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
-  const char* names[5] = {"prologue (3 stages)", "compute + next issue", "vmcnt wait (HBM)", "barrier", "partial-tile store"};
+  const char* names[5] = {"prologue (first stage)", "compute (LDS+MFMA)", "LDS store (waits HBM)", "issue loads + barrier", "partial-tile store"};
   // workgroup ranges of the four layers: 128 each (see wgrad_group_plan)
   unsigned long long tmin = ~0ull, tmax = 0;
   for (int g = 0; g < 512; ++g) for (int w = 0; w < 8; ++w) { const unsigned long long* s = &h[((size_t)g * 8 + w) * 8]; if (s[5] && s[5] < tmin) tmin = s[5]; if (s[6] > tmax) tmax = s[6]; }

@@ -69,6 +69,29 @@ __device__ __forceinline__ int opaque(int x) {
 }
 // scheduling fence: nothing is moved across it (pins "issue the loads, then the MFMA block")
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// ---- LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS at
+// wave-uniform base + lane*16, no VGPR round trip.  Issued from inline asm so that hipcc neither counts
+// it nor drains it at the next barrier (its own bookkeeping would put s_waitcnt vmcnt(0) there and
+// collapse a multi-stage ring to one stage in flight); the caller pairs it with RG_WAIT_VMCNT(n) and
+// raw_barrier().  `lds_wave_base` must be the same in every lane of the wave.
+__device__ __forceinline__ void global_load_lds_b128(const void* gsrc, const void* lds_wave_base) {
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+// wait until at most n vector-memory operations of this wave (LDS-DMA included) are outstanding
+#define RG_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// s_barrier without the waits __syncthreads() attaches
+__device__ __forceinline__ void raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // wave priority for the SIMD's issue arbitration (0..3)
 #define RG_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // scheduling-group hints (instruction classes of __builtin_amdgcn_sched_group_barrier)

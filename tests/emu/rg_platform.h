@@ -92,6 +92,12 @@ static inline bf16_t f32_to_bf16(float f) {
 static inline int lane_id() { return ::emu::cur().linear_tid & 63; }
 static inline int opaque(int x) { return x; }
 static inline void sched_fence() {}
+// LDS-DMA: the interpreter copies synchronously (lane-linear destination, like the hardware)
+static inline void global_load_lds_b128(const void* gsrc, const void* lds_wave_base) {
+  memcpy((char*)lds_wave_base + lane_id() * 16, gsrc, 16);
+}
+#define RG_WAIT_VMCNT(n) ((void)0)
+static inline void raw_barrier() { __syncthreads(); }
 #define RG_SETPRIO(n) ((void)0)
 #define RG_SCHED_MFMA(n) ((void)0)
 #define RG_SCHED_DS_READ(n) ((void)0)
