@@ -309,6 +309,27 @@ int rg_c51_head(const float* q, const float* qn_online, const float* qn_target, 
                 double qmin, double qmax, int batch, int num_actions, int num_atoms, int maxq, float* dq,
                 float* loss_partials, float* all_q, rg_stream_t stream);
 
+/* Discrete CRR heads, reagent/training/discrete_crr_trainer.py.  All matrices [B, A] fp32 contiguous.
+ * rg_crr_critic_head = compute_target_q_values (:191-206) + compute_td_loss (:208-212) for one or two
+ * critics: target = reward (+ sum_a action * reward_boosts) + gamma * not_terminal * min_k sum_a
+ * Qk_target(s', a) * softmax(next_logits)_a ; loss_k = mean((sum_a Qk(s, a) * action - target)^2).
+ * q2 / q2_next_target / dq2 / partials2 are all NULL for a single critic.  target_out [B] nullable.
+ * partials*: rg_crr_partials(B) floats whose sum / B is the loss.
+ * rg_crr_actor_head = compute_actor_loss (:214-285): q = q1_network(state) AFTER its optimizer step,
+ * logits = actor scores, logged_prob [B] = extras.action_probability (read only if entropy_coeff > 0).
+ * dlogits = d actor_loss / d logits; plain_partials sum / B = actor_loss_without_reg;
+ * entropy_partials sum / B = the entropy term (actor_loss = plain + entropy_coeff * entropy). */
+int rg_crr_partials(int batch);
+int rg_crr_critic_head(const float* q1, const float* q2, const float* q1_next_target, const float* q2_next_target,
+                       const float* next_logits, const float* action, const float* reward,
+                       const float* reward_boosts, const float* not_terminal, double gamma, int batch,
+                       int num_actions, float* target_out, float* dq1, float* dq2, float* partials1,
+                       float* partials2, rg_stream_t stream);
+int rg_crr_actor_head(const float* q, const float* logits, const float* action, const float* logged_prob,
+                      double beta, double max_weight, double entropy_coeff, double clip_limit, int batch,
+                      int num_actions, float* dlogits, float* plain_partials, float* entropy_partials,
+                      rg_stream_t stream);
+
 /* QR-DQN head, reagent/training/qrdqn_trainer.py:108-160 (+ argmax_with_mask :210-214, huber
  * :217-218, quantiles :70-73).  q / qn_online / qn_target [B, A*N] fp32 = network outputs viewed
  * (B, A, N); qn_online NULL = select the next action with the target net (double_q off).

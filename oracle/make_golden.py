@@ -260,6 +260,63 @@ def gen_td3(name, c):
     _save(name, c, arrays)
 
 
+CRR_CASES = {
+    # twin critics, entropy regularisation with logged propensities, CPE heads, reward boosts, masks
+    "crr_twin_entropy_cpe": dict(state_dim=8, num_actions=4, sizes=[32, 24], activations=["relu", "leaky_relu"],
+                                 rl=dict(gamma=0.95, target_update_rate=0.1, maxq_learning=True,
+                                         q_network_loss="huber", temperature=0.8, reward_boost={"2": 0.3}),
+                                 lr=0.003, batch=72, steps=3, p_impossible=0.25, twin=True, cpe_metrics=["m1"],
+                                 trainer=dict(beta=0.7, entropy_coeff=0.05, clip_limit=3.0, max_weight=4.0,
+                                              delayed_policy_update=1, use_target_actor=False)),
+    # single critic, target actor for V(s'), delayed policy update, linear actor head, SARSA masks
+    "crr_single_delayed": dict(state_dim=6, num_actions=3, sizes=[24], activations=["tanh"],
+                               rl=dict(gamma=0.9, target_update_rate=0.25, maxq_learning=False),
+                               lr=0.004, batch=40, steps=4, p_impossible=0.0, twin=False, cpe_metrics=None,
+                               actor_activation="linear",
+                               trainer=dict(beta=1.0, entropy_coeff=0.0, delayed_policy_update=2,
+                                            use_target_actor=True)),
+}
+
+
+def _crr_nets(tr):
+    nets = dict(actor=tr.actor_network, actor_target=tr.actor_network_target, q1=tr.q1_network,
+                q1_target=tr.q1_network_target)
+    if tr.q2_network is not None:
+        nets.update(q2=tr.q2_network, q2_target=tr.q2_network_target)
+    if tr.calc_cpe_in_training:
+        nets.update(reward=tr.reward_network, cpe=tr.q_network_cpe, cpe_target=tr.q_network_cpe_target)
+    return nets
+
+
+def gen_crr(name, c):
+    tr = rh.build_crr(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
+                      twin=c["twin"], cpe_metrics=c["cpe_metrics"], seed=0,
+                      actor_activation=c.get("actor_activation", "tanh"), **c["trainer"])
+    arrays = {}
+    for n, m in _crr_nets(tr).items():
+        if not n.endswith("_target"):
+            for i, p in enumerate(m.parameters()):
+                arrays[f"init_{n}_{i}"] = _np(p)
+    loop = rh.PLLoop(tr)
+    names = ["q1_loss"] + (["q2_loss"] if c["twin"] else []) + ["actor_loss"]
+    names += ["reward_loss", "cpe_loss"] if c["cpe_metrics"] is not None else []
+    for s in range(c["steps"]):
+        b = synthetic.dqn_batch(c["batch"], c["state_dim"], c["num_actions"], seed=600 + s,
+                                p_impossible=c["p_impossible"], n_extra_metrics=len(c["cpe_metrics"] or []),
+                                with_propensity=True)
+        for k, v in b.items():
+            arrays[f"step{s}_batch_{k}"] = _np(v)
+        losses = loop.step(rh.dqn_batch_to_reference(b))
+        assert len(losses) == len(names) + 1
+        for nm, l in zip(names, losses):
+            if l is not None:
+                arrays[f"step{s}_{nm}"] = _np(l)
+        for n, m in _crr_nets(tr).items():
+            for i, p in enumerate(m.parameters()):
+                arrays[f"step{s}_{n}_{i}"] = _np(p)
+    _save(name, c, arrays)
+
+
 def gen_replay(name, c):
     rh._install()
     from reagent.replay_memory.circular_replay_buffer import ReplayBuffer
@@ -433,7 +490,11 @@ def main():
     only = sys.argv[1:]  # e.g. `python -m oracle.make_golden sum_tree prioritized` regenerates only those
     if only:
         for n in only:
-            globals()["gen_" + n]()
+            if n.upper() + "_CASES" in globals():  # e.g. `crr` = every case of CRR_CASES
+                for name, c in globals()[n.upper() + "_CASES"].items():
+                    globals()["gen_" + n](name, c)
+            else:
+                globals()["gen_" + n]()
         return
     for n, c in DQN_CASES.items():
         gen_dqn(n, c)
@@ -447,6 +508,8 @@ def main():
         gen_c51(n, c)
     for n, c in TD3_CASES.items():
         gen_td3(n, c)
+    for n, c in CRR_CASES.items():
+        gen_crr(n, c)
     gen_preprocessor()
     gen_sum_tree()
     gen_prioritized()

@@ -171,6 +171,37 @@ def build_c51(state_dim, num_actions, sizes, activations, rl_kwargs, lr, num_ato
                       qmax=qmax, optimizer=make_adam(lr))
 
 
+def build_crr(state_dim, num_actions, sizes, activations, rl_kwargs, lr, twin=True, cpe_metrics=None, seed=0,
+              actor_activation="tanh", **trainer_kw):
+    """DiscreteCRRTrainer over FullyConnectedActor (net_builder/discrete_actor/fully_connected.py:36-52)
+    and FullyConnectedDQN critics / CPE nets, wired as model_managers/discrete/discrete_crr.py:105-178."""
+    _install()
+    from reagent.core.parameters import EvaluationParameters
+    from reagent.models.actor import FullyConnectedActor
+    from reagent.models.dqn import FullyConnectedDQN
+    from reagent.training.discrete_crr_trainer import DiscreteCRRTrainer
+
+    torch.manual_seed(seed)
+    actor = FullyConnectedActor(state_dim, num_actions, sizes, activations, action_activation=actor_activation)
+    q1 = FullyConnectedDQN(state_dim, num_actions, sizes, activations)
+    q2 = FullyConnectedDQN(state_dim, num_actions, sizes, activations) if twin else None
+    cpe = cpe_metrics is not None
+    reward_net = q_cpe = q_cpe_t = None
+    if cpe:
+        n_out = (len(cpe_metrics) + 1) * num_actions
+        reward_net = FullyConnectedDQN(state_dim, n_out, sizes, activations)
+        q_cpe = FullyConnectedDQN(state_dim, n_out, sizes, activations)
+        q_cpe_t = q_cpe.get_target_network()
+    return DiscreteCRRTrainer(
+        actor_network=actor, actor_network_target=actor.get_target_network(), q1_network=q1,
+        q1_network_target=q1.get_target_network(), reward_network=reward_net, q2_network=q2,
+        q2_network_target=q2.get_target_network() if twin else None, q_network_cpe=q_cpe,
+        q_network_cpe_target=q_cpe_t, metrics_to_score=list(cpe_metrics) if cpe else None,
+        evaluation=EvaluationParameters(calc_cpe_in_training=cpe), rl=make_rl_parameters(**rl_kwargs),
+        q_network_optimizer=make_adam(lr), actor_network_optimizer=make_adam(lr),
+        actions=[str(i) for i in range(num_actions)], **trainer_kw)
+
+
 def dqn_batch_to_reference(b: dict):
     """dict of tensors (see oracle/synthetic.py) -> reference rlt.DiscreteDqnInput."""
     _install()
@@ -181,7 +212,8 @@ def dqn_batch_to_reference(b: dict):
         reward=b["reward"], time_diff=b["time_diff"], step=b["step"], not_terminal=b["not_terminal"],
         action=b["action"], next_action=b["next_action"], possible_actions_mask=b["possible_actions_mask"],
         possible_next_actions_mask=b["possible_next_actions_mask"],
-        extras=rlt.ExtraData(action_probability=torch.ones_like(b["reward"]), metrics=b.get("metrics")),
+        extras=rlt.ExtraData(action_probability=b.get("action_probability", torch.ones_like(b["reward"])),
+                             metrics=b.get("metrics")),
     )
 
 

@@ -137,6 +137,9 @@ SIGNATURES = {
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_c51_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_void_p, c_d, c_d, c_int, c_int, c_int, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
+    "rg_crr_partials": (c_int, [c_int]),
+    "rg_crr_critic_head": (c_int, [c_void_p] * 9 + [c_d, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "rg_crr_actor_head": (c_int, [c_void_p] * 4 + [c_d, c_d, c_d, c_d, c_int, c_int] + [c_void_p] * 3 + [c_void_p]),
     "rg_qr_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
     "rg_gaussian_head_forward": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p,

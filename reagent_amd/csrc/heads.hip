@@ -1,22 +1,11 @@
 // heads.hip — loss heads that sit between the last FC forward and the first FC backward.
 #include <rg_platform.h>
 #include "../../include/reagent_hip.h"
+#include "rg_reduce.h"
 
 namespace rg {
 
 constexpr int HEAD_THREADS = 256;
-
-// block-wide sum in a fixed order (wave shuffles, then wave 0 adds the 4 wave sums in order)
-__device__ __forceinline__ float block_sum_256(float v, float* scratch /*[4]*/) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += shfl_xor(v, off);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
-  __syncthreads();
-  const float s = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-  __syncthreads();
-  return s;
-}
 
 // One thread per transition.  Masked max / arg-max over |A| with first-index tie-break
 // (torch.max semantics), double-Q gather, TD target, MSE / Huber value and d loss / d q.

@@ -301,6 +301,37 @@ def c51_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, 
                                      L.stream_ptr()))
 
 
+def crr_partials(batch: int) -> int:
+    return int(L.lib().rg_crr_partials(batch))
+
+
+def crr_critic_head(q1, q2, q1_next_t, q2_next_t, next_logits, action, reward, reward_boosts, not_terminal, gamma,
+                    target, dq1, dq2, partials1, partials2):
+    _chk_dev(q1, q2, q1_next_t, q2_next_t, next_logits, action, reward, reward_boosts, not_terminal, target, dq1, dq2,
+             partials1, partials2)
+    batch, A = action.shape
+    for t in (q1, q2, q1_next_t, q2_next_t, next_logits, action, dq1, dq2):
+        assert t is None or (t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A))
+    _run("rg_crr_critic_head", dict(B=batch, A=A),
+         lambda: L.lib().rg_crr_critic_head(L.ptr(q1), L.ptr(q2), L.ptr(q1_next_t), L.ptr(q2_next_t),
+                                            L.ptr(next_logits), L.ptr(action), L.ptr(reward), L.ptr(reward_boosts),
+                                            L.ptr(not_terminal), float(gamma), batch, A, L.ptr(target), L.ptr(dq1),
+                                            L.ptr(dq2), L.ptr(partials1), L.ptr(partials2), L.stream_ptr()))
+
+
+def crr_actor_head(q, logits, action, logged_prob, beta, max_weight, entropy_coeff, clip_limit, dlogits,
+                   plain_partials, entropy_partials):
+    _chk_dev(q, logits, action, logged_prob, dlogits, plain_partials, entropy_partials)
+    batch, A = action.shape
+    for t in (q, logits, action, dlogits):
+        assert t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A)
+    _run("rg_crr_actor_head", dict(B=batch, A=A),
+         lambda: L.lib().rg_crr_actor_head(L.ptr(q), L.ptr(logits), L.ptr(action), L.ptr(logged_prob), float(beta),
+                                           float(max_weight), float(entropy_coeff), float(clip_limit), batch, A,
+                                           L.ptr(dlogits), L.ptr(plain_partials), L.ptr(entropy_partials),
+                                           L.stream_ptr()))
+
+
 def qr_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma,
             gamma_exponent, quantiles, num_atoms, maxq, dq, loss_partials, all_q=None):
     _chk_dev(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma_exponent,

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 def dqn_batch(batch: int, state_dim: int, num_actions: int, seed: int = 0, p_terminal: float = 0.1,
               p_impossible: float = 0.0, with_steps: bool = False,
-              n_extra_metrics: int = 0) -> Dict[str, torch.Tensor]:
+              n_extra_metrics: int = 0, with_propensity: bool = False) -> Dict[str, torch.Tensor]:
     """Fields of rlt.DiscreteDqnInput as a plain dict of CPU fp32 tensors."""
     g = torch.Generator().manual_seed(seed)
     state = torch.randn(batch, state_dim, generator=g)
@@ -34,6 +34,8 @@ def dqn_batch(batch: int, state_dim: int, num_actions: int, seed: int = 0, p_ter
                possible_next_actions_mask=pna, step=step, time_diff=time_diff)
     if n_extra_metrics:  # extras.metrics of the CPE heads (drawn last: earlier fields keep their values)
         out["metrics"] = torch.rand(batch, n_extra_metrics, generator=g)
+    if with_propensity:  # extras.action_probability of the logging policy, in (0.05, 1]
+        out["action_probability"] = 0.05 + 0.95 * torch.rand(batch, 1, generator=g)
     return out
 
 
@@ -62,7 +64,8 @@ def to_dqn_input(d: Dict[str, torch.Tensor], device=None):
         not_terminal=t(d["not_terminal"]), action=t(d["action"]), next_action=t(d["next_action"]),
         possible_actions_mask=t(d["possible_actions_mask"]),
         possible_next_actions_mask=t(d["possible_next_actions_mask"]),
-        extras=rlt.ExtraData(action_probability=t(torch.ones_like(d["reward"])),
+        extras=rlt.ExtraData(action_probability=t(d["action_probability"] if "action_probability" in d
+                                                  else torch.ones_like(d["reward"])),
                              metrics=t(d["metrics"]) if "metrics" in d else None),
     )
 

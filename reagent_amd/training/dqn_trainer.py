@@ -102,11 +102,9 @@ class _CpeEngine:
         B, dev = state.shape[0], state.device
         self._engine(B, dev)
         A, M = tr.num_actions, len(tr.metrics_to_score)
-        # all_next_action_scores = q_network(next_state) AFTER the q-network step (dqn_trainer.py:268)
-        qs = tr._qs
-        qs.stage_weights(need_transposed=True)
-        xn, _ = qs.stage_input(next_state, need_transposed=False)
-        tr._cpe_next_scores(xn, self.next_scores)
+        # all_next_action_scores: q_network(next_state) AFTER the q-network step for DQN / QR-DQN
+        # (dqn_trainer.py:268), the target critic's next-state values for CRR
+        tr._cpe_next_action_scores(next_state, self.next_scores)
         for k in ("reward", "cpe"):
             self.e[k]["stack"].stage_weights(need_transposed=True)
         self.t.stage_weights(need_transposed=False)
@@ -124,11 +122,7 @@ class _CpeEngine:
             metrics = tr._f32c(metrics)
         else:
             metrics = None
-        gamma_exp = None
-        if tr.use_seq_num_diff_as_time_diff:
-            gamma_exp = tr._f32c(b.time_diff).reshape(-1)
-        if tr.multi_steps is not None:
-            gamma_exp = tr._f32c(b.step).reshape(-1)
+        gamma_exp = tr._cpe_gamma_exponent(b)
         next_mask = tr._f32c(b.possible_next_actions_mask if tr.maxq_learning else b.next_action)
         self.propensities = torch.empty(B, A, dtype=torch.float32, device=dev) if need_propensities else None
         ops.cpe_head(self.reward_est, self.q_cpe, self.q_cpe_tgt, self.next_scores, next_mask, tr._f32c(b.action),
@@ -189,6 +183,21 @@ class QStepCore(DQNTrainerBaseLightning):
 
     # ---- CPE (dqn_trainer_base.py:338-452) ----------------------------------------------------
     _cpe = None
+
+    def _cpe_gamma_exponent(self, b):
+        """exponent of gamma in the CPE discount tensor (dqn_trainer.py:240-254), None = 1"""
+        gamma_exp = None
+        if self.use_seq_num_diff_as_time_diff:
+            gamma_exp = self._f32c(b.time_diff).reshape(-1)
+        if self.multi_steps is not None:
+            gamma_exp = self._f32c(b.step).reshape(-1)
+        return gamma_exp
+
+    def _cpe_next_action_scores(self, next_state, out):
+        qs = self._qs
+        qs.stage_weights(need_transposed=True)
+        xn, _ = qs.stage_input(next_state, need_transposed=False)
+        self._cpe_next_scores(xn, out)
 
     def _cpe_next_scores(self, xn, out):
         """all_next_action_scores = q_network(next_state) with the just-updated weights -> out [B, A]"""
