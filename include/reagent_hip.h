@@ -259,6 +259,62 @@ int rg_normalize_dense(const float* x, int64_t ldx, const uint8_t* presence, int
                        const rg_norm_col* cols /*device*/, int n_out, const float* quantiles,
                        float* out, int64_t ldo, int batch, rg_stream_t stream);
 
+/* ---- offline table -> training batch ------------------------------------------------------- */
+
+/* The post-timeline dataset (column schema of select_relevant_columns,
+ * reagent/data/oss_data_fetcher.py:293-336) as one device array per column.  rg_table_dqn_batch
+ * replaces the data loader's row fetch plus DiscreteDqnBatchPreprocessor.forward
+ * (reagent/preprocessing/batch_preprocessor.py:35-66) for a batch of row indices, in one launch:
+ * Preprocessor.forward on state / next_state (cols / quantiles as for rg_normalize_dense, n_out
+ * output columns), one-hot action / next_action (next_action == n_actions -> all zeros), not_terminal
+ * = max of possible_next_actions_mask, pass-through columns.  Nullable table columns: presence
+ * (= all present), time_diff / step (= 1), action_probability (= 1), mdp_id / sequence_number (= 0),
+ * possible_actions_mask (= all ones).  Nullable outputs: time_diff, step, action_probability, mdp_id,
+ * sequence_number, possible_actions_mask.  Masks and presence are bytes (0 / 1). */
+typedef struct {
+  const float* state_features;                 /* [n_rows, n_features] */
+  const uint8_t* state_features_presence;      /* [n_rows, n_features] */
+  const float* next_state_features;
+  const uint8_t* next_state_features_presence;
+  const int64_t* action;                       /* [n_rows] index into the action names */
+  const int64_t* next_action;                  /* [n_rows], n_actions = no next action */
+  const float* reward;                         /* [n_rows] */
+  const float* action_probability;
+  const int64_t* time_diff;
+  const int64_t* step;
+  const int64_t* mdp_id;
+  const int64_t* sequence_number;
+  const uint8_t* possible_actions_mask;        /* [n_rows, n_actions] */
+  const uint8_t* possible_next_actions_mask;
+  int64_t n_rows;
+  int32_t n_features;
+  int32_t n_actions;
+} rg_dqn_table; /* host struct */
+typedef struct {
+  void* state;                                 /* [batch, n_out] fp32 or bf16 (state_dtype) */
+  void* next_state;
+  float* action;                               /* [batch, n_actions] one-hot */
+  float* next_action;
+  float* reward;                               /* [batch] */
+  float* time_diff;
+  float* step;
+  float* not_terminal;
+  float* possible_actions_mask;                /* [batch, n_actions] */
+  float* possible_next_actions_mask;
+  float* action_probability;
+  int64_t* mdp_id;
+  int64_t* sequence_number;
+  int32_t state_dtype;                         /* RG_DT_F32 / RG_DT_BF16 */
+  int32_t reserved;
+} rg_dqn_batch_out; /* host struct */
+int rg_table_dqn_batch(const rg_dqn_table* table, const int64_t* indices, int batch, const rg_norm_col* cols,
+                       int n_out, const float* quantiles, const rg_dqn_batch_out* out, rg_stream_t stream);
+/* *bad_flag (device int, zeroed by the caller) becomes 1 if a sampled row holds an action outside
+ * [0, n_actions) or a next_action outside [0, n_actions] (F.one_hot would raise), 2 if an index is
+ * outside [0, n_rows). */
+int rg_table_check_actions(const rg_dqn_table* table, const int64_t* indices, int batch, int* bad_flag,
+                           rg_stream_t stream);
+
 /* ---- loss heads --------------------------------------------------------------------------- */
 
 /* DQN TD head: boost_rewards (reagent/training/dqn_trainer_base.py:216-241),

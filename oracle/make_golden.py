@@ -354,32 +354,8 @@ def gen_replay(name, c):
     _save(name, c, arrays)
 
 
-def gen_preprocessor():
-    rh._install()
-    from reagent.core.parameters import NormalizationParameters as NP
-    from reagent.preprocessing.preprocessor import Preprocessor
-
-    norm = {
-        11: NP(feature_type="BINARY"),
-        3: NP(feature_type="BINARY"),
-        5: NP(feature_type="PROBABILITY"),
-        1: NP(feature_type="CONTINUOUS", mean=0.4, stddev=1.7),
-        9: NP(feature_type="CONTINUOUS", mean=-2.0, stddev=0.3),
-        7: NP(feature_type="BOXCOX", boxcox_lambda=0.6, boxcox_shift=1.5, mean=0.2, stddev=1.1),
-        2: NP(feature_type="ENUM", possible_values=[1, 4, 7]),
-        8: NP(feature_type="ENUM", possible_values=[0, 2]),
-        4: NP(feature_type="QUANTILE", quantiles=[0.0, 0.5, 1.5, 4.0]),
-        12: NP(feature_type="QUANTILE", quantiles=[-1.0, 0.0, 1.0, 2.0, 3.0, 10.0]),
-        6: NP(feature_type="CONTINUOUS_ACTION", min_value=-2.0, max_value=3.0),
-        10: NP(feature_type="DISCRETE_ACTION"),
-        13: NP(feature_type="DO_NOT_PREPROCESS"),
-        14: NP(feature_type="CLIP_LOG"),
-    }
-    pre = Preprocessor(norm, device=torch.device("cpu"))
-    pre.eval()
-    feats = pre.sorted_features
-    B = 257
-    g = torch.Generator().manual_seed(5)
+def _feature_columns(norm, feats, B, g):
+    """raw values that exercise every branch of each feature type"""
     cols = []
     for f in feats:
         t = norm[f].feature_type
@@ -406,14 +382,100 @@ def gen_preprocessor():
         else:
             col = torch.randn(B, generator=g) * 3
         cols.append(col)
+    return cols
+
+
+def _all_types_norm():
+    from reagent.core.parameters import NormalizationParameters as NP
+
+    return {
+        11: NP(feature_type="BINARY"),
+        3: NP(feature_type="BINARY"),
+        5: NP(feature_type="PROBABILITY"),
+        1: NP(feature_type="CONTINUOUS", mean=0.4, stddev=1.7),
+        9: NP(feature_type="CONTINUOUS", mean=-2.0, stddev=0.3),
+        7: NP(feature_type="BOXCOX", boxcox_lambda=0.6, boxcox_shift=1.5, mean=0.2, stddev=1.1),
+        2: NP(feature_type="ENUM", possible_values=[1, 4, 7]),
+        8: NP(feature_type="ENUM", possible_values=[0, 2]),
+        4: NP(feature_type="QUANTILE", quantiles=[0.0, 0.5, 1.5, 4.0]),
+        12: NP(feature_type="QUANTILE", quantiles=[-1.0, 0.0, 1.0, 2.0, 3.0, 10.0]),
+        6: NP(feature_type="CONTINUOUS_ACTION", min_value=-2.0, max_value=3.0),
+        10: NP(feature_type="DISCRETE_ACTION"),
+        13: NP(feature_type="DO_NOT_PREPROCESS"),
+        14: NP(feature_type="CLIP_LOG"),
+    }
+
+
+def _norm_cfg(norm):
+    return {str(k): {a: getattr(v, a) for a in ("feature_type", "boxcox_lambda", "boxcox_shift", "mean", "stddev",
+                                                "possible_values", "quantiles", "min_value", "max_value")}
+            for k, v in norm.items()}
+
+
+def gen_preprocessor():
+    rh._install()
+    from reagent.preprocessing.preprocessor import Preprocessor
+
+    norm = _all_types_norm()
+    pre = Preprocessor(norm, device=torch.device("cpu"))
+    pre.eval()
+    feats = pre.sorted_features
+    B = 257
+    g = torch.Generator().manual_seed(5)
+    cols = _feature_columns(norm, feats, B, g)
     x = torch.stack(cols, dim=1)
     presence = (torch.rand(B, len(feats), generator=g) > 0.1).to(torch.uint8)
     out = pre(x, presence)
-    cfg = {str(k): {a: getattr(v, a) for a in ("feature_type", "boxcox_lambda", "boxcox_shift", "mean", "stddev",
-                                               "possible_values", "quantiles", "min_value", "max_value")}
-           for k, v in norm.items()}
-    _save("preprocessor_all_types", dict(norm=cfg, sorted_features=feats),
+    _save("preprocessor_all_types", dict(norm=_norm_cfg(norm), sorted_features=feats),
           dict(x=_np(x), presence=_np(presence), out=_np(out)))
+
+
+def gen_offline_table():
+    """a post-timeline table (select_relevant_columns schema, oss_data_fetcher.py:293-336), a batch of row
+    indices with repeats, and what the reference's DiscreteDqnBatchPreprocessor.forward returns for the
+    rows its reader would have yielded (batch_preprocessor.py:35-66)"""
+    rh._install()
+    from reagent.preprocessing.batch_preprocessor import DiscreteDqnBatchPreprocessor
+    from reagent.preprocessing.preprocessor import Preprocessor
+
+    norm = _all_types_norm()
+    pre = Preprocessor(norm, device=torch.device("cpu"))
+    pre.eval()
+    feats = pre.sorted_features
+    N, B, A = 301, 160, 5
+    g = torch.Generator().manual_seed(11)
+    table = {}
+    for pfx in ("state", "next_state"):
+        table[f"{pfx}_features"] = torch.stack(_feature_columns(norm, feats, N, g), dim=1)
+        table[f"{pfx}_features_presence"] = torch.rand(N, len(feats), generator=g) > 0.15
+    table["action"] = torch.randint(A, (N,), generator=g)
+    terminal = torch.rand(N, generator=g) < 0.2
+    pnam = (torch.rand(N, A, generator=g) > 0.3).long()
+    pnam[torch.arange(N), torch.randint(A, (N,), generator=g)] = 1
+    pnam[terminal] = 0
+    table["possible_next_actions_mask"] = pnam
+    table["possible_actions_mask"] = (torch.rand(N, A, generator=g) > 0.2).long()
+    nxt = torch.randint(A, (N,), generator=g)
+    nxt[terminal] = A  # "no next action" (discrete_action_preprocessing)
+    table["next_action"] = nxt
+    table["reward"] = torch.randn(N, generator=g)
+    table["action_probability"] = torch.rand(N, generator=g) * 0.9 + 0.1
+    table["time_diff"] = torch.randint(1, 6, (N,), generator=g)
+    table["step"] = torch.randint(1, 4, (N,), generator=g)
+    table["mdp_id"] = torch.randint(0, 1 << 40, (N,), generator=g)
+    table["sequence_number"] = torch.randint(0, 1000, (N,), generator=g)
+    indices = torch.randint(N, (B,), generator=g)
+    bp = DiscreteDqnBatchPreprocessor(A, pre, use_gpu=False)
+    out = bp({k: v[indices] for k, v in table.items()})
+    arrays = {f"table_{k}": _np(v) for k, v in table.items()}
+    arrays["indices"] = _np(indices)
+    for k in ("action", "next_action", "reward", "time_diff", "step", "not_terminal", "possible_actions_mask",
+              "possible_next_actions_mask"):
+        arrays[f"out_{k}"] = _np(getattr(out, k))
+    arrays["out_state"], arrays["out_next_state"] = _np(out.state.float_features), _np(out.next_state.float_features)
+    for k in ("mdp_id", "sequence_number", "action_probability"):
+        arrays[f"out_{k}"] = _np(getattr(out.extras, k))
+    _save("offline_table", dict(norm=_norm_cfg(norm), sorted_features=feats, num_actions=A), arrays)
 
 
 def gen_sum_tree():
@@ -511,6 +573,7 @@ def main():
     for n, c in CRR_CASES.items():
         gen_crr(n, c)
     gen_preprocessor()
+    gen_offline_table()
     gen_sum_tree()
     gen_prioritized()
 

@@ -87,6 +87,26 @@ class MlpUpdateDesc(ctypes.Structure):
     ]
 
 
+TABLE_COLUMNS = ("state_features", "state_features_presence", "next_state_features", "next_state_features_presence",
+                 "action", "next_action", "reward", "action_probability", "time_diff", "step", "mdp_id",
+                 "sequence_number", "possible_actions_mask", "possible_next_actions_mask")
+
+
+class DqnTable(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in TABLE_COLUMNS] + [
+        ("n_rows", ctypes.c_int64), ("n_features", ctypes.c_int32), ("n_actions", ctypes.c_int32)]
+
+
+BATCH_OUT_FIELDS = ("state", "next_state", "action", "next_action", "reward", "time_diff", "step", "not_terminal",
+                    "possible_actions_mask", "possible_next_actions_mask", "action_probability", "mdp_id",
+                    "sequence_number")
+
+
+class DqnBatchOut(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in BATCH_OUT_FIELDS] + [
+        ("state_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 # every symbol include/reagent_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "rg_strerror": (ctypes.c_char_p, [c_int]),
@@ -131,6 +151,9 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_normalize_dense": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,
                                     c_void_p, c_i64, c_int, c_void_p]),
+    "rg_table_dqn_batch": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                    ctypes.POINTER(DqnBatchOut), c_void_p]),
+    "rg_table_check_actions": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_void_p]),
     "rg_dqn_head_partials": (c_int, [c_int]),
     "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rg_cpe_head": (c_int, [c_void_p] * 9 + [ctypes.c_double, c_void_p, ctypes.c_double, c_int, c_int, c_int, c_int,

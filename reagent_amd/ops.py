@@ -5,6 +5,7 @@ falls back to torch math.  ``profile()`` optionally brackets every C-ABI call wi
 the stream the kernels are enqueued on (bench.py's per-kernel roofline numbers come from that).
 """
 import contextlib
+import ctypes
 from typing import List, Optional, Tuple
 
 import torch
@@ -240,6 +241,32 @@ def normalize_dense(x, presence_u8, cols_dev, n_out, quantiles, out):
                                             _ld(presence_u8) if presence_u8 is not None else 0,
                                             L.ptr(cols_dev), n_out, L.ptr(quantiles), L.ptr(out), _ld(out),
                                             x.shape[0], L.stream_ptr()))
+
+
+def table_dqn_batch(table, indices, cols_dev, n_out, quantiles, out: dict):
+    """out: name -> device tensor for every field of rg_dqn_batch_out (a missing name = NULL)"""
+    _chk_dev(indices, cols_dev, quantiles, *out.values())
+    assert indices.dtype == torch.int64 and indices.is_contiguous()
+    o = L.DqnBatchOut()
+    for name in L.BATCH_OUT_FIELDS:
+        t = out.get(name)
+        assert t is None or t.is_contiguous()
+        setattr(o, name, t.data_ptr() if t is not None else None)
+    o.state_dtype = dt_code(out["state"].dtype)
+    assert out["next_state"].dtype == out["state"].dtype
+    B = indices.numel()
+    _run("rg_table_dqn_batch", dict(B=B, n_out=n_out, F=table.num_features, A=table.num_actions),
+         lambda: L.lib().rg_table_dqn_batch(ctypes.byref(table.desc()), L.ptr(indices), B, L.ptr(cols_dev), n_out,
+                                            L.ptr(quantiles), ctypes.byref(o), L.stream_ptr()))
+
+
+def table_check_actions(table, indices) -> int:
+    _chk_dev(indices)
+    flag = torch.zeros(1, dtype=torch.int32, device=indices.device)
+    _run("rg_table_check_actions", dict(B=indices.numel()),
+         lambda: L.lib().rg_table_check_actions(ctypes.byref(table.desc()), L.ptr(indices), indices.numel(),
+                                                L.ptr(flag), L.stream_ptr()))
+    return int(flag.item())
 
 
 # ---- heads ------------------------------------------------------------------------------------
