@@ -114,9 +114,18 @@ class FullyConnectedActor(ModelBase):
         assert action.shape == (batch_size, self.action_dim), f"{action.shape} != ({batch_size}, {self.action_dim})"
         if self.exploration_variance is None:
             return rlt.ActorOutput(action=action, log_prob=torch.zeros(batch_size, 1, device=action.device))
-        # actor.py:99-110: N(0, variance) noise (`scale` = variance, as the reference has it)
+        action, _, log_prob = self.explore(action)
+        return rlt.ActorOutput(action=action, log_prob=log_prob)
+
+    def explore(self, action: torch.Tensor):
+        """actor.py:99-110: add N(0, variance) noise (`scale` = variance, as the reference has it) and clamp
+        to the training action range.  Returns (noisy action, mask of the entries whose clamp passes the
+        gradient, log_prob).  The trainers that evaluate `actor(state).action` inside the step (TD3, CRR)
+        call this on the stack's output so that the noise is part of the step as in the reference."""
+        batch_size = action.shape[0]
         dist = torch.distributions.Normal(torch.zeros(self.action_dim), torch.ones(self.action_dim) * self.exploration_variance)
         noise = dist.sample((batch_size,))
         log_prob = dist.log_prob(noise).to(action.device).sum(dim=1).view(-1, 1).clamp(LOG_PROB_MIN, LOG_PROB_MAX)
-        action = (action + noise.to(action.device)).clamp(-1.0, 1.0)  # CONTINUOUS_TRAINING_ACTION_RANGE
-        return rlt.ActorOutput(action=action, log_prob=log_prob)
+        pre = action + noise.to(action.device)
+        passes = (pre >= -1.0) & (pre <= 1.0)  # CONTINUOUS_TRAINING_ACTION_RANGE
+        return pre.clamp(-1.0, 1.0), passes, log_prob

@@ -132,7 +132,7 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
         if self._ws_batch != B or self._q1v.device != dev:
             f = dict(dtype=torch.float32, device=dev)
             P = ops.crr_partials(B)
-            for n in ("q1v", "q2v", "q1n", "q2n", "next_scores", "dq1", "dq2", "q1_new", "scores", "dscores"):
+            for n in ("q1v", "q2v", "q1n", "q2n", "next_scores", "dq1", "dq2", "q1_new", "raw_scores", "dscores"):
                 setattr(self, "_" + n, torch.empty(B, A, **f))
             self._target = torch.empty(B, **f)
             self._parts = {n: torch.empty(P, **f) for n in ("q1", "q2", "plain", "entropy")}
@@ -173,6 +173,9 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
         next_actor.stage_weights(need_transposed=not self.use_target_actor)
         xa, _ = next_actor.stage_input(next_state, need_transposed=False)
         next_actor.forward(xa, self._next_scores, save=False)
+        next_module = self.actor_network_target if self.use_target_actor else self.actor_network
+        if next_module.exploration_variance is not None:  # `.action` of an exploring actor carries its noise
+            self._next_scores.copy_(next_module.explore(self._next_scores)[0])
         # compute_td_loss for both critics (:208-212)
         q1s = e["q1"]["stack"]
         x1, self._x1_t = q1s.stage_input(state, need_transposed=True)
@@ -212,7 +215,11 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
         act = e["actor"]["stack"]
         act.stage_weights(need_transposed=True)
         xs, self._xs_t = act.stage_input(state, need_transposed=True)
-        act.forward(xs, self._scores, save=with_loss)
+        act.forward(xs, self._raw_scores, save=with_loss)
+        self._scores, self._clamp_passes = self._raw_scores, None
+        if self.actor_network.exploration_variance is not None:
+            noisy, self._clamp_passes, _ = self.actor_network.explore(self._raw_scores)
+            self._scores = noisy.contiguous()
         self.all_action_scores = self._scores
         if not with_loss:
             return
@@ -240,7 +247,9 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
     def _actor_backward(self, grad_out=None):
         a = self._e["actor"]
         d = self._dscores if grad_out is None else self._dscores * grad_out
-        a["stack"].backward(d, self._xs_t, a["dw"], a["db"], out32=self._scores)
+        if self._clamp_passes is not None:  # backward of the exploration clamp
+            d = d * self._clamp_passes
+        a["stack"].backward(d, self._xs_t, a["dw"], a["db"], out32=self._raw_scores)
         self._publish(a)
 
     # ---- CPE hooks (dqn_trainer_base.py:338-452 as called at :354-363) ---------------------------

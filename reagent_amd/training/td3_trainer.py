@@ -145,6 +145,8 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         at = t["actor"]
         xn_s, _ = at.stage_input(next_state, need_transposed=False)
         at.forward(xn_s, self._next_actor, save=False)
+        if self.actor_network_target.exploration_variance is not None:  # `.action` carries the exploration noise
+            self._next_actor.copy_(self.actor_network_target.explore(self._next_actor)[0])
         self._xn[:, :S].copy_(next_state)
         ops.td3_target_action(self._next_actor, noise, self.noise_variance, self.noise_clip_range[1],
                               CONTINUOUS_TRAINING_ACTION_RANGE[0], CONTINUOUS_TRAINING_ACTION_RANGE[1],
@@ -190,7 +192,12 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         xs_c, self._xs_t = act.stage_input(state, need_transposed=True)
         act.forward(xs_c, self._a_out, save=True)
         self._xa[:, :S].copy_(state)
-        self._xa[:, S:].copy_(self._a_out)
+        self._clamp_passes = None
+        if self.actor_network.exploration_variance is not None:
+            noisy, self._clamp_passes, _ = self.actor_network.explore(self._a_out)
+            self._xa[:, S:].copy_(noisy)
+        else:
+            self._xa[:, S:].copy_(self._a_out)
         q1s = e["q1"]["stack"]
         xa_c, _ = q1s.stage_input(self._xa, need_transposed=False)
         q1s.forward(xa_c, self._q1a, save=True)
@@ -201,7 +208,10 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         dq = self._dq1a if grad_out is None else self._dq1a * grad_out
         e["q1"]["stack"].backward(dq, None, None, None, dx32=self._dx1, skip_wgrad=True)
         a = e["actor"]
-        a["stack"].backward(self._dx1[:, S:], self._xs_t, a["dw"], a["db"], out32=self._a_out)
+        da = self._dx1[:, S:]
+        if self._clamp_passes is not None:  # backward of the exploration clamp
+            da = da * self._clamp_passes
+        a["stack"].backward(da, self._xs_t, a["dw"], a["db"], out32=self._a_out)
         self._publish(a)
 
     def _noise(self, B, A, dev, given):

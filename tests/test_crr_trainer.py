@@ -1,7 +1,8 @@
 """DiscreteCRRTrainer (reagent_amd.training) against golden vectors of the reference
 DiscreteCRRTrainer (tests/golden/crr_*.npz, produced by the unmodified reference under the
-Lightning-loop emulation; the reference has no numeric CRR test).  Also the two head kernels against
-the reference's formulas written out in torch with autograd (discrete_crr_trainer.py:191-285).
+Lightning-loop emulation), the two head kernels against the reference's formulas written out in torch
+with autograd (discrete_crr_trainer.py:191-285), and the reference's own structural test
+(reagent/test/training/test_crr.py, which pins counts and order but no numbers) restated at the end.
 Tolerances: losses 1e-4 rel, parameters 2e-5 abs (fp32 mode)."""
 import pytest
 import torch
@@ -193,3 +194,83 @@ def test_crr_rejects_bad_arguments(backend):
         ops.crr_critic_head(t, t, t, None, t, t, v, None, v, 0.9, v, t.clone(), t.clone(), p, p.clone())
     with pytest.raises(Exception):  # entropy term without logged propensities
         ops.crr_actor_head(t, t, t, None, 1.0, 20.0, 0.1, 10.0, t.clone(), p, p.clone())
+
+
+# ---- reagent/test/training/test_crr.py restated (same sizes, same assertions on the result level) ----
+class _RefCrrCase:
+    """setUp of test_crr.py:19-103: batch 3, state 10, 2 actions, two layers of 20, an exploring actor
+    (exploration_variance 1e-10), int64 one-hot actions, CPE nets for the reward metric only"""
+
+    def __init__(self, device):
+        self.B, self.S, self.A = 3, 10, 2
+        sizes, acts = [20, 20], ["relu", "relu"]
+        self.actions = [str(i) for i in range(self.A)]
+        mk = lambda out: FullyConnectedDQN(self.S, out, sizes, acts).to(device)  # noqa: E731
+        self.actor = FullyConnectedActor(self.S, self.A, sizes, acts, exploration_variance=1e-10).to(device)
+        self.q1, self.q2 = mk(self.A), mk(self.A)
+        n_out = 1 * self.A  # get_metrics_to_score(RewardOptions().metric_reward_values) is empty: reward only
+        self.reward_net, self.q_cpe = mk(n_out), mk(n_out)
+        from reagent_amd.core import types as rlt
+
+        g = torch.Generator().manual_seed(0)
+        t = lambda x: x.to(device)  # noqa: E731
+        self.inp = rlt.DiscreteDqnInput(
+            state=rlt.FeatureData(t(torch.rand(self.B, self.S, generator=g))),
+            next_state=rlt.FeatureData(t(torch.rand(self.B, self.S, generator=g))),
+            reward=t(torch.ones(self.B, 1)), time_diff=t(torch.ones(self.B, 1) * 2), step=t(torch.ones(self.B, 1) * 2),
+            not_terminal=t(torch.ones(self.B, 1)), action=t(torch.tensor([[0, 1], [1, 0], [0, 1]])),
+            next_action=t(torch.tensor([[1, 0], [0, 1], [1, 0]])), possible_actions_mask=t(torch.ones(self.B, self.A)),
+            possible_next_actions_mask=t(torch.ones(self.B, self.A)),
+            extras=rlt.ExtraData(action_probability=t(torch.ones(self.B, 1))))
+
+    def trainer(self, no_cpe=False, no_q2=False, **params):
+        return DiscreteCRRTrainer(
+            actor_network=self.actor, actor_network_target=self.actor.get_target_network(), q1_network=self.q1,
+            q1_network_target=self.q1.get_target_network(), q2_network=None if no_q2 else self.q2,
+            q2_network_target=None if no_q2 else self.q2.get_target_network(),
+            reward_network=None if no_cpe else self.reward_net, q_network_cpe=None if no_cpe else self.q_cpe,
+            q_network_cpe_target=None if no_cpe else self.q_cpe.get_target_network(), metrics_to_score=[],
+            evaluation=EvaluationParameters(calc_cpe_in_training=not no_cpe), actions=self.actions, **params)
+
+
+def test_reference_crr_test_init_and_properties(backend):
+    c = _RefCrrCase(backend.device)
+    tr = c.trainer()
+    assert torch.isclose(tr.reward_boosts, torch.zeros(2)).all()  # test_init
+    boosted = c.trainer(rl=RLParameters(reward_boost={i: int(i) + 1 for i in c.actions}))
+    assert torch.isclose(boosted.reward_boosts, torch.tensor([1.0, 2.0])).all()
+    assert tr.q_network is tr.q1_network  # test_q_network_property
+    scores, _ = tr.get_detached_model_outputs(c.inp.state)  # test_get_detached_model_outputs
+    assert scores.shape == (c.B, c.A)
+
+
+def test_reference_crr_test_configure_optimizers(backend):
+    c = _RefCrrCase(backend.device)
+    tr = c.trainer()
+    optimizers = tr.configure_optimizers()
+    assert len(optimizers) == 6
+    order = [tr.q1_network, tr.q2_network, tr.actor_network, tr.reward_network, tr.q_network_cpe, tr.q1_network]
+    for opt, net in zip(optimizers, order):  # the soft update's first group starts with q1's target/source
+        opt_param = opt["optimizer"].param_groups[0]["params"][0]
+        assert torch.isclose(opt_param, list(net.parameters())[0]).all()
+    assert len(c.trainer(no_cpe=True).configure_optimizers()) == 4
+    assert len(c.trainer(no_q2=True).configure_optimizers()) == 5
+
+
+def test_reference_crr_test_train_step_gen(backend):
+    c = _RefCrrCase(backend.device)
+    losses = list(c.trainer().train_step_gen(c.inp, batch_idx=1))
+    assert len(losses) == 6 and all(l.requires_grad for l in losses)  # (grad_fn types cannot hold for fused losses)
+    assert all(torch.isfinite(l).all() for l in losses)
+    assert len(list(c.trainer(no_cpe=True).train_step_gen(c.inp, batch_idx=1))) == 4
+    assert len(list(c.trainer(no_q2=True).train_step_gen(c.inp, batch_idx=1))) == 5
+    assert len(list(c.trainer(use_target_actor=True).train_step_gen(c.inp, batch_idx=1))) == 6
+    delayed = list(c.trainer(delayed_policy_update=2).train_step_gen(c.inp, batch_idx=1))
+    assert len(delayed) == 6 and delayed[2] is None
+    assert len(list(c.trainer(entropy_coeff=1.0).train_step_gen(c.inp, batch_idx=1))) == 6
+    # the losses drive their optimizers: one Lightning-style pass changes every online network
+    tr = c.trainer()
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    before = [p.detach().clone() for p in tr.actor_network.parameters()]
+    lightning_like_step(tr, opts, c.inp, 0)
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, tr.actor_network.parameters()))
