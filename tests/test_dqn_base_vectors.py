@@ -1,0 +1,143 @@
+"""The known-answer vectors of reagent/test/training/test_dqn_base.py applied to the HIP step:
+test_get_max_q_values_with_target (:103-139) and test_boost_rewards (:141-152) against BOTH the
+Python utility entry points and rg_dqn_head (the kernel the training step really runs),
+test__initialize_cpe (+ extra metrics, :154-222), test__configure_cpe_optimizers (:224-239) and
+test__calculate_cpes (:241-331: the two CPE losses equal an independent recomputation)."""
+import pytest
+import torch
+
+import reagent_amd._lib as L
+from reagent_amd import ops
+from reagent_amd.core import types as rlt
+from reagent_amd.core.parameters import EvaluationParameters, RLParameters
+from reagent_amd.core.torch_utils import masked_softmax
+from reagent_amd.models import FullyConnectedDQN
+from reagent_amd.optimizer import Optimizer__Union
+from reagent_amd.training import DQNTrainer
+from reagent_amd.training.dqn_trainer_base import DQNTrainerBaseLightning
+
+
+class MockDQNTrainer(DQNTrainerBaseLightning):
+    """the minimal child of test_dqn_base.py:20-37"""
+
+    def __init__(self, rl_parameters, metrics_to_score=None, actions=None, evaluation_parameters=None,
+                 double_q_learning=True):
+        super().__init__(rl_parameters, metrics_to_score=metrics_to_score, actions=actions,
+                         evaluation_parameters=evaluation_parameters)
+        self.double_q_learning = double_q_learning
+
+
+def mock(cpe=True, actions=("1", "2"), rl=None, metrics=None):
+    return MockDQNTrainer(rl if rl is not None else RLParameters(), metrics_to_score=metrics, actions=list(actions),
+                          evaluation_parameters=EvaluationParameters(calc_cpe_in_training=cpe))
+
+
+def head_next(dev, q_online_next, q_target_next, mask, double_q):
+    """next_q / next_idx as rg_dqn_head computes them inside the step"""
+    B, A = q_online_next.shape
+    f = lambda t: t.float().to(dev).contiguous()  # noqa: E731
+    z = torch.zeros(B, A, device=dev)
+    one_hot = torch.zeros(B, A, device=dev)
+    one_hot[:, 0] = 1
+    dq, parts = torch.empty(B, A, device=dev), torch.empty(ops.dqn_head_partials(B), device=dev)
+    nq, ni = torch.empty(B, device=dev), torch.empty(B, dtype=torch.int64, device=dev)
+    ops.dqn_head(z, f(q_online_next), f(q_target_next), one_hot, f(mask), torch.zeros(B, device=dev), None,
+                 torch.ones(B, device=dev), 0.9, None, double_q, L.LOSS["mse"], dq, parts, nq, ni)
+    return nq.cpu(), ni.cpu()
+
+
+CASES = [  # (double_q, mask, expected index, expected target value)   test_dqn_base.py:108-139
+    (True, [[1, 1]], 1, 1.0),
+    (True, [[1, 0]], 0, 2.0),
+    (False, [[1, 1]], 0, 2.0),
+    (False, [[0, 1]], 1, 1.0),
+]
+
+
+@pytest.mark.parametrize("double_q,mask,idx,val", CASES)
+def test_get_max_q_values_with_target(backend, double_q, mask, idx, val):
+    q_values, q_values_target = torch.tensor([[3.0, 4.0]]), torch.tensor([[2.0, 1.0]])
+    trainer = mock()
+    trainer.double_q_learning = double_q
+    m = torch.tensor(mask)
+    mx, mi = trainer.get_max_q_values_with_target(q_values, q_values_target, m)
+    assert torch.equal(mi, torch.tensor([[idx]])) and torch.equal(mx, torch.tensor([[val]]))
+    nq, ni = head_next(backend.device, q_values, q_values_target, m, double_q)
+    assert ni.tolist() == [idx] and nq.tolist() == [val]
+
+
+def test_boost_rewards(backend):
+    rewards, actions = torch.ones(3, 1), torch.tensor([[0, 1], [1, 0], [0, 1]])
+    trainer = mock(rl=RLParameters(reward_boost={"1": 1.0, "2": 2.0}))
+    assert torch.equal(trainer.boost_rewards(rewards, actions), torch.tensor([[3.0], [2.0], [3.0]]))
+    # the kernel: with gamma = 0 and q(s, a_logged) = 0 the TD error is -(reward + boost)
+    dev = backend.device
+    B, A = 3, 2
+    z = torch.zeros(B, A, device=dev)
+    dq, parts = torch.empty(B, A, device=dev), torch.empty(ops.dqn_head_partials(B), device=dev)
+    ops.dqn_head(z, z, z, actions.float().to(dev), torch.ones(B, A, device=dev), rewards.reshape(-1).to(dev),
+                 trainer.reward_boosts.reshape(-1).to(dev), torch.ones(B, device=dev), 0.0, None, True, L.LOSS["mse"],
+                 dq, parts)
+    # d mse / d q = 2 (q - target) / B on the logged action
+    assert torch.allclose((dq * actions.float().to(dev)).sum(1).cpu() * B / -2, torch.tensor([3.0, 2.0, 3.0]))
+
+
+def nets(n_out, dev):
+    q = FullyConnectedDQN(10, 2, [20, 20], ["relu", "relu"]).to(dev)
+    reward = FullyConnectedDQN(10, n_out, [20, 20], ["relu", "relu"]).to(dev)
+    cpe = FullyConnectedDQN(10, n_out, [20, 20], ["relu", "relu"]).to(dev)
+    return q, reward, cpe
+
+
+def test_initialize_cpe(backend):
+    _, reward, cpe = nets(2, backend.device)
+    opt = Optimizer__Union.default()
+    trainer = mock()
+    trainer._initialize_cpe(reward, cpe, cpe.get_target_network(), opt)
+    assert torch.equal(trainer.reward_idx_offsets, torch.tensor([0]))
+    for attr in ("reward_network", "q_network_cpe", "q_network_cpe_target", "reward_network_optimizer",
+                 "q_network_cpe_optimizer"):
+        assert getattr(trainer, attr) is not None
+    no_cpe = mock(cpe=False)
+    no_cpe._initialize_cpe(reward, cpe, cpe.get_target_network(), opt)
+    assert no_cpe.reward_network is None
+    # extra metrics (:178-222): one block of |A| outputs per metric
+    extra = mock(metrics=["metric_a", "metric_b"])
+    _, reward6, cpe6 = nets(6, backend.device)
+    extra._initialize_cpe(reward6, cpe6, cpe6.get_target_network(), opt)
+    assert torch.equal(extra.reward_idx_offsets, torch.tensor([0, 2, 4]))
+    # :224-239
+    _, _, optimizers = trainer._configure_cpe_optimizers()
+    assert len(optimizers) == 2
+
+
+def test_calculate_cpes(backend):
+    """test_dqn_base.py:241-331 on the natively executed DQN step (discount tensor = gamma ** step here,
+    since the losses come out of the trainer's own generator rather than a direct _calculate_cpes call)"""
+    dev = backend.device
+    torch.manual_seed(0)
+    q, reward_net, cpe = nets(2, dev)
+    cpe_t = cpe.get_target_network()
+    B = 3
+    inp = rlt.DiscreteDqnInput(
+        state=rlt.FeatureData(torch.rand(B, 10).to(dev)), next_state=rlt.FeatureData(torch.rand(B, 10).to(dev)),
+        reward=torch.ones(B, 1, device=dev), time_diff=torch.ones(B, 1, device=dev) * 2,
+        step=torch.ones(B, 1, device=dev) * 2, not_terminal=torch.ones(B, 1, device=dev),
+        action=torch.tensor([[0, 1], [1, 0], [0, 1]], device=dev), next_action=torch.tensor([[1, 0], [0, 1], [1, 0]], device=dev),
+        possible_actions_mask=torch.ones(B, 2, device=dev), possible_next_actions_mask=torch.ones(B, 2, device=dev),
+        extras=rlt.ExtraData())
+    trainer = DQNTrainer(q, q.get_target_network(), reward_net, q_network_cpe=cpe, q_network_cpe_target=cpe_t,
+                         metrics_to_score=[], actions=["1", "2"], rl=RLParameters(),
+                         evaluation=EvaluationParameters(calc_cpe_in_training=True)).to(dev)
+    losses = list(trainer.train_step_gen(inp, 0))  # q loss, reward loss, cpe loss, soft update
+    assert len(losses) == 4
+    idx = torch.tensor([[1], [0], [1]], device=dev)
+    mse_reward_loss = torch.nn.functional.mse_loss(trainer.reward_network(inp.state).gather(1, idx), inp.reward)
+    assert torch.allclose(losses[1].detach(), mse_reward_loss, rtol=1e-5, atol=1e-7)
+    # the generator was drained without optimizer steps: all_next_action_scores = q_network(next_state)
+    props = masked_softmax(trainer.q_network(inp.next_state), inp.possible_next_actions_mask, trainer.rl_temperature)
+    metric_q = trainer.q_network_cpe(inp.state).gather(1, idx)
+    next_q = (trainer.q_network_cpe_target(inp.next_state) * props).sum(1, keepdim=True) * inp.not_terminal
+    target = inp.reward + trainer.gamma * next_q
+    expected = torch.nn.functional.mse_loss(metric_q, target)
+    assert torch.allclose(losses[2].detach(), expected, rtol=1e-5, atol=1e-7), (losses[2], expected)
