@@ -292,6 +292,9 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
       // the tail alone at half rate.  The younger wave (prio_phase = 1) therefore runs the first half
       // of its loop at raised priority and hands the advantage back for the second half, so the two
       // finish together.
+      // (profiles/microbench/fwd_phases, early / late wave of a SIMD, K=512 loop: this hand-off 16.8k /
+      // 19.3k; swapping the priority every ring block 14.7k / 20.3k, every two blocks 15.0k / 20.2k; no
+      // priorities 13.0k / 20.5k — what counts is when the LATER wave gets out.)
       if (prio_phase && kc * 2 < KC) RG_SETPRIO(1);
       else RG_SETPRIO(0);
 #pragma unroll
@@ -408,6 +411,9 @@ __device__ __forceinline__ void store_packed_tiles(bf16_t* act, int pitch, const
   });
 }
 
+// (Starting the accumulators at the bias instead of adding it here was tried: the adds are already
+// packed (v_pk_add_f32, 64 per wave and layer), and accumulators that are not a rematerialisable zero
+// cost the TN = 2 kernel 68 spilled registers.)
 template <int TN, int ACT>
 __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const float* bias, bf16_t* save_dst,
                                                 unsigned* sign_dst, int NT, int mb_base, int wave, int lane,
