@@ -41,6 +41,49 @@ __global__ void table_dqn_batch_kernel(TableArgs a, const int64_t* __restrict__ 
     const float* x = piece == 0 ? t.state_features : t.next_state_features;
     const uint8_t* pres = piece == 0 ? t.state_features_presence : t.next_state_features_presence;
     void* dst = piece == 0 ? o.state : o.next_state;
+    if ((n_out & 3) == 0 && (F & 3) == 0 && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dst) & 15) == 0) &&
+        (!pres || ((((uintptr_t)pres) & 3) == 0))) {
+      // four output columns per lane: where they read four consecutive, 4-aligned input features (every
+      // type but ENUM keeps the 1:1 order) the lane moves 16 B of values + 4 B of presence per request
+      const int cpr = n_out >> 2, total = nrows * cpr;
+      for (int it = threadIdx.x; it < total; it += TABLE_THREADS) {
+        const int r = it / cpr, ch = it - r * cpr;
+        rg_norm_col d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = s_cols[ch * 4 + e];
+        const long base = s_idx[r] * F;
+        float raw[4], p[4];
+        if ((d[0].in_col & 3) == 0 && d[1].in_col == d[0].in_col + 1 && d[2].in_col == d[0].in_col + 2 &&
+            d[3].in_col == d[0].in_col + 3) {
+          const f32x4 t = *(const f32x4*)(x + base + d[0].in_col);
+          const unsigned pb = pres ? *(const unsigned*)(pres + base + d[0].in_col) : 0x01010101u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            raw[e] = t[e];
+            p[e] = (float)((pb >> (8 * e)) & 0xffu);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            raw[e] = x[base + d[e].in_col];
+            p[e] = pres ? (float)pres[base + d[e].in_col] : 1.f;
+          }
+        }
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = normalize_value(d[e], raw[e], p[e], quantiles);
+        const long at = (long)(row0 + r) * n_out + ch * 4;
+        if (o.state_dtype == RG_DT_BF16) {
+          uint2 w;
+          w.x = pack_bf16x2(v[0], v[1]);
+          w.y = pack_bf16x2(v[2], v[3]);
+          *(uint2*)((bf16_t*)dst + at) = w;
+        } else {
+          *(f32x4*)((float*)dst + at) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      }
+      return;
+    }
     const int total = nrows * n_out;
     for (int it = threadIdx.x; it < total; it += TABLE_THREADS) {
       const int r = it / n_out, j = it - r * n_out;

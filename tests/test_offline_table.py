@@ -164,3 +164,47 @@ def test_dqn_trains_from_the_table(backend):
     assert torch.isfinite(la).all() and torch.equal(la.cpu(), lb.cpu())
     for pa, pb in zip(ta.q_network.parameters(), tb.q_network.parameters()):
         assert torch.equal(pa.detach().cpu(), pb.detach().cpu())
+
+
+@pytest.mark.parametrize("layout", ["one_to_one", "enum_in_the_middle"])
+def test_four_wide_path_equals_normalize_dense(backend, layout):
+    """tables whose feature count is a multiple of 4 take the 16-byte path of rg_table_dqn_batch; it must
+    give exactly what rg_normalize_dense (pinned to the reference in test_preprocessing.py) gives for the
+    same rows — both the chunks that stay 1:1 and the ones an ENUM expansion shifts"""
+    from reagent_amd.core.parameters import NormalizationParameters as NP
+
+    dev, N, A, B = backend.device, 200, 3, 96
+    g = torch.Generator().manual_seed(17)
+    if layout == "one_to_one":
+        norm = {i: NP(feature_type="CONTINUOUS", mean=0.1 * i, stddev=1.0 + 0.05 * i) for i in range(32)}
+    else:  # sorted by type: BINARY, PROBABILITY, CONTINUOUS x12, ENUM (5 values), QUANTILE -> 16 in, 20 out
+        norm = {0: NP(feature_type="BINARY"), 1: NP(feature_type="PROBABILITY"),
+                **{i: NP(feature_type="CONTINUOUS", mean=0.0, stddev=2.0) for i in range(2, 14)},
+                14: NP(feature_type="ENUM", possible_values=[0, 1, 2, 3, 4]),
+                15: NP(feature_type="QUANTILE", quantiles=[0.0, 1.0, 2.0, 4.0])}
+    pre = Preprocessor(norm, device=dev)
+    F = len(norm)
+    assert pre.num_output_features % 4 == 0 and F % 4 == 0
+
+    def feats():
+        x = torch.randn(N, F, generator=g)
+        x[:, :2] = torch.rand(N, 2, generator=g)
+        if layout != "one_to_one":
+            x[:, pre.feature_id_to_index[14]] = torch.randint(0, 6, (N,), generator=g).float()
+        return x
+
+    cols = dict(state_features=feats(), next_state_features=feats(),
+                state_features_presence=torch.rand(N, F, generator=g) > 0.2,
+                next_state_features_presence=torch.rand(N, F, generator=g) > 0.2,
+                action=torch.randint(A, (N,), generator=g), next_action=torch.randint(A + 1, (N,), generator=g),
+                reward=torch.randn(N, generator=g),
+                possible_next_actions_mask=(torch.rand(N, A, generator=g) > 0.5).long())
+    table = OfflineTable(cols, A, device=dev)
+    idx = torch.randint(N, (B,), generator=g).to(dev)
+    out = DiscreteDqnBatchPreprocessor(A, pre).from_table(table, idx)
+    for name, got in (("state", out.state.float_features), ("next_state", out.next_state.float_features)):
+        rows = table.columns[f"{name}_features"][idx]
+        ref = pre(rows, table.columns[f"{name}_features_presence"][idx])
+        assert torch.equal(got, ref), name
+    o16 = DiscreteDqnBatchPreprocessor(A, pre, state_dtype=torch.bfloat16).from_table(table, idx)
+    assert torch.equal(o16.state.float_features, out.state.float_features.to(torch.bfloat16))
