@@ -177,13 +177,13 @@ def kernel_profile(args, loop, steps, layer_dims):
         out["fc_roofline"] = {"algorithmic_gflop_per_step": alg / 1e9, "fc_ms_per_step": fc_ms,
                               "achieved": alg / (fc_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                               "frac": alg / (fc_ms * 1e-3) / peak}
-    g = [r for r in rows if r["name"] == "rg_replay_gather"]
+    g = [r for r in rows if r["name"] in ("rg_replay_dqn_batch", "rg_replay_gather")]
     if g:
         sec = g[0]["ms"] * 1e-3 / g[0]["calls"]
         bytes_ = g[0]["meta"]["bytes_per_row"] * B
         out["gather"] = {"bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": bytes_ / sec / HBM_PEAK, "avg_launch_us": sec * 1e6,
-                         "algorithmic_bytes_per_transition": g[0]["meta"]["bytes_per_row"]}
+                         "algorithmic_bytes_per_transition": g[0]["meta"]["bytes_per_row"], "kernel": g[0]["name"]}
     out["per_call_ms_per_step"] = {f"{r['name']}{tuple(r['meta'].values())}": round(r["ms"] / steps, 4) for r in rows[:18]}
     return out
 

@@ -309,6 +309,34 @@ typedef struct {
 } rg_dqn_batch_out; /* host struct */
 int rg_table_dqn_batch(const rg_dqn_table* table, const int64_t* indices, int batch, const rg_norm_col* cols,
                        int n_out, const float* quantiles, const rg_dqn_batch_out* out, rg_stream_t stream);
+/* The replay store as the DQN step reads it (stack_size 1, dense fp32 observations; gym schema of
+ * SURVEY.md §8 a1).  rg_replay_dqn_batch = ReplayBuffer.sample_transition_batch
+ * (reagent/replay_memory/circular_replay_buffer.py:614-706: n-step steps / next index / terminal /
+ * discounted reward, state and next_state rows) + DiscreteDqnInputMaker
+ * (reagent/gym/preprocessors/trainer_preprocessor.py:100-158: one-hots, next_action zeroed on terminal,
+ * not_terminal, exp(log_prob), masks at idx / next idx or ones) in ONE launch, optionally with
+ * Preprocessor.forward on both state matrices (cols = n_features 1:1 descriptors, all present; NULL =
+ * raw fp32 rows).  Bit-identical to rg_replay_nstep + rg_replay_gather + rg_make_dqn_input.
+ * RG_EUNSUPPORTED (n_features % 4, > 512 features, unaligned rows): use those three instead. */
+typedef struct {
+  const float* observation;            /* [capacity, n_features] */
+  const int64_t* action;               /* [capacity] */
+  const float* reward;                 /* [capacity] */
+  const uint8_t* terminal;             /* [capacity] */
+  const float* log_prob;               /* [capacity], nullable (action_probability = 1) */
+  const float* possible_actions_mask;  /* [capacity, n_actions], nullable (all ones) */
+  const int64_t* mdp_id;               /* nullable */
+  const int64_t* sequence_number;      /* nullable */
+  const float* decays;                 /* [update_horizon] gamma**k, as for rg_replay_nstep */
+  int64_t capacity;
+  int32_t n_features;
+  int32_t n_actions;
+  int32_t update_horizon;
+  int32_t reserved;
+} rg_replay_view; /* host struct */
+int rg_replay_dqn_batch(const rg_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
+                        const float* quantiles, const rg_dqn_batch_out* out, rg_stream_t stream);
+
 /* *bad_flag (device int, zeroed by the caller) becomes 1 if a sampled row holds an action outside
  * [0, n_actions) or a next_action outside [0, n_actions] (F.one_hot would raise), 2 if an index is
  * outside [0, n_rows). */

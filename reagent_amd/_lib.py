@@ -107,6 +107,16 @@ class DqnBatchOut(ctypes.Structure):
         ("state_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+REPLAY_VIEW_COLUMNS = ("observation", "action", "reward", "terminal", "log_prob", "possible_actions_mask", "mdp_id",
+                       "sequence_number", "decays")
+
+
+class ReplayView(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in REPLAY_VIEW_COLUMNS] + [
+        ("capacity", ctypes.c_int64), ("n_features", ctypes.c_int32), ("n_actions", ctypes.c_int32),
+        ("update_horizon", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 # every symbol include/reagent_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "rg_strerror": (ctypes.c_char_p, [c_int]),
@@ -153,6 +163,8 @@ SIGNATURES = {
                                     c_void_p, c_i64, c_int, c_void_p]),
     "rg_table_dqn_batch": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_int, c_void_p,
                                     ctypes.POINTER(DqnBatchOut), c_void_p]),
+    "rg_replay_dqn_batch": (c_int, [ctypes.POINTER(ReplayView), c_void_p, c_int, c_void_p, c_void_p,
+                                     ctypes.POINTER(DqnBatchOut), c_void_p]),
     "rg_table_check_actions": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_void_p]),
     "rg_dqn_head_partials": (c_int, [c_int]),
     "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
@@ -185,6 +197,9 @@ SIGNATURES = {
 
 _lib = None
 _lock = threading.Lock()
+
+
+EUNSUPPORTED = -3  # RG_EUNSUPPORTED
 
 
 class ReagentHipError(RuntimeError):

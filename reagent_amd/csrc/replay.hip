@@ -223,6 +223,107 @@ __global__ void make_dqn_input_kernel(const int64_t* __restrict__ action,
   }
 }
 
+
+// ---- sampled indices -> rlt.DiscreteDqnInput in one launch --------------------------------------
+// ReplayBuffer.sample_transition_batch (:614-706, stack_size 1) + DiscreteDqnInputMaker
+// (reagent/gym/preprocessors/trainer_preprocessor.py:100-158) [+ Preprocessor.forward on both state
+// matrices, all features present]: the n-step bookkeeping of replay_nstep_kernel is recomputed by each
+// of the three workgroups that serve a block of 64 transitions (a handful of byte loads), so the
+// next-state rows can be fetched in the launch that finds them, and the one-hot / not_terminal /
+// exp(log_prob) work of make_dqn_input_kernel reads the store directly.  Same arithmetic, operation
+// for operation, as the three kernels it replaces (tests compare them bit for bit).
+struct ReplayBatchArgs {
+  rg_replay_view v;
+  rg_dqn_batch_out o;
+};
+
+__global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __restrict__ indices, int batch,
+                                        const rg_norm_col* __restrict__ cols, const float* __restrict__ quantiles) {
+  __shared__ int64_t s_src[GATHER_ROWS_PER_WG];  // the row this piece reads: idx (state), next idx (next_state)
+  __shared__ int64_t s_nxt[GATHER_ROWS_PER_WG];
+  __shared__ int s_steps[GATHER_ROWS_PER_WG];
+  __shared__ unsigned char s_term[GATHER_ROWS_PER_WG];
+  __shared__ rg_norm_col s_nc[GATHER_MAX_LDS_COLS];
+  const rg_replay_view& v = a.v;
+  const rg_dqn_batch_out& o = a.o;
+  const int row0 = blockIdx.x * GATHER_ROWS_PER_WG;
+  const int nrows = (batch - row0 < GATHER_ROWS_PER_WG) ? batch - row0 : GATHER_ROWS_PER_WG;
+  const int piece = blockIdx.y;  // 0 = state, 1 = next_state, 2 = everything else
+  const int F = v.n_features, A = v.n_actions, H = v.update_horizon;
+  const int64_t C = v.capacity;
+  // (idx + k) % C without the 64-bit division: idx < C and k <= H <= C
+  auto wrap = [&](int64_t t) { return t >= C ? t - C : t; };
+  if ((int)threadIdx.x < nrows) {
+    const int64_t idx = indices[row0 + threadIdx.x];
+    int st = H;  // _get_steps (:759-774); with H == 1 the window is one slot whatever it holds
+    if (H > 1)
+      for (int k = 0; k < H; ++k)
+        if (v.terminal[wrap(idx + k)]) {
+          st = k + 1;
+          break;
+        }
+    const int64_t nidx = wrap(idx + st);
+    s_src[threadIdx.x] = piece == 1 ? nidx : idx;
+    s_nxt[threadIdx.x] = nidx;
+    s_steps[threadIdx.x] = st;
+    if (piece == 2) s_term[threadIdx.x] = v.terminal[wrap(idx + st - 1)] ? 1 : 0;  // the row pieces never read it
+  }
+  if (piece < 2 && cols)
+    for (int j = threadIdx.x; j < F; j += blockDim.x) s_nc[j] = cols[j];
+  __syncthreads();
+  if (piece < 2) {
+    void* dst = piece == 0 ? o.state : o.next_state;
+    const int cpr = F >> 2, total = nrows * cpr;  // F % 4 == 0 (checked by the host)
+    for (int it = threadIdx.x; it < total; it += blockDim.x) {
+      const int r = it / cpr, ch = it - r * cpr;
+      const f32x4 raw = *(const f32x4*)(v.observation + s_src[r] * F + ch * 4);
+      float w[4] = {raw[0], raw[1], raw[2], raw[3]};
+      if (cols) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = normalize_value(s_nc[ch * 4 + e], w[e], 1.f, quantiles);
+      }
+      const long at = (long)(row0 + r) * F + ch * 4;
+      if (o.state_dtype == RG_DT_BF16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(w[0], w[1]);
+        pk.y = pack_bf16x2(w[2], w[3]);
+        *(uint2*)((bf16_t*)dst + at) = pk;
+      } else {
+        *(f32x4*)((float*)dst + at) = f32x4{w[0], w[1], w[2], w[3]};
+      }
+    }
+    return;
+  }
+  if ((int)threadIdx.x < nrows) {
+    const int b = row0 + threadIdx.x, st = s_steps[threadIdx.x];
+    const int64_t idx = s_src[threadIdx.x];
+    // _reduce_multi_step_reward (:741-747): (reward * decays * masks).sum(dim=1), in that order
+    float acc = 0.f;
+    for (int k = 0; k < H; ++k) {
+      const float m = (k < st) ? 1.f : 0.f;
+      acc += (v.reward[wrap(idx + k)] * v.decays[k]) * m;
+    }
+    o.reward[b] = acc;
+    o.not_terminal[b] = 1.0f - (s_term[threadIdx.x] ? 1.f : 0.f);
+    if (o.step) o.step[b] = (float)st;
+    if (o.time_diff) o.time_diff[b] = 1.f;
+    if (o.action_probability) o.action_probability[b] = v.log_prob ? expf(v.log_prob[idx]) : 1.f;
+    if (o.mdp_id) o.mdp_id[b] = v.mdp_id ? v.mdp_id[idx] : 0;
+    if (o.sequence_number) o.sequence_number[b] = v.sequence_number ? v.sequence_number[idx] : 0;
+  }
+  const int total = nrows * A;
+  for (int it = threadIdx.x; it < total; it += blockDim.x) {
+    const int r = it / A, k = it - r * A;
+    const int64_t idx = s_src[r], nidx = s_nxt[r];
+    const long at = (long)(row0 + r) * A + k;
+    o.action[at] = (v.action[idx] == k) ? 1.f : 0.f;
+    o.next_action[at] = (!s_term[r] && v.action[nidx] == k) ? 1.f : 0.f;
+    if (o.possible_actions_mask)
+      o.possible_actions_mask[at] = v.possible_actions_mask ? v.possible_actions_mask[idx * A + k] : 1.f;
+    o.possible_next_actions_mask[at] = v.possible_actions_mask ? v.possible_actions_mask[nidx * A + k] : 1.f;
+  }
+}
+
 }  // namespace rg
 
 using namespace rg;
@@ -267,6 +368,29 @@ int rg_replay_gather(const rg_gather_col* cols, int ncols, int64_t capacity, int
     RG_LAUNCH(replay_gather_stack_kernel, dim3(gx, ncols), dim3(256), (hipStream_t)stream, t,
               capacity, stack, batch);
   }
+  return (int)hipGetLastError();
+}
+
+int rg_replay_dqn_batch(const rg_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
+                        const float* quantiles, const rg_dqn_batch_out* out, rg_stream_t stream) {
+  if (!view || !out || batch < 0) return RG_EINVAL;
+  if (batch == 0) return RG_OK;
+  const rg_replay_view& v = *view;
+  const rg_dqn_batch_out& o = *out;
+  if (!indices || !v.observation || !v.action || !v.reward || !v.terminal || !v.decays || v.capacity <= 0 ||
+      v.n_features <= 0 || v.n_actions <= 0 || v.update_horizon <= 0)
+    return RG_EINVAL;
+  if (!o.state || !o.next_state || !o.action || !o.next_action || !o.reward || !o.not_terminal ||
+      !o.possible_next_actions_mask)
+    return RG_EINVAL;
+  if (o.state_dtype != RG_DT_F32 && o.state_dtype != RG_DT_BF16) return RG_EINVAL;
+  if (!cols && o.state_dtype != RG_DT_F32) return RG_EINVAL;  // a raw copy stays fp32
+  if ((v.n_features & 3) || v.n_features > GATHER_MAX_LDS_COLS || (((uintptr_t)v.observation) & 15) ||
+      (((uintptr_t)o.state) & 15) || (((uintptr_t)o.next_state) & 15))
+    return RG_EUNSUPPORTED;  // callers fall back to rg_replay_nstep + rg_replay_gather + rg_make_dqn_input
+  ReplayBatchArgs a{v, o};
+  RG_LAUNCH(replay_dqn_batch_kernel, dim3((batch + GATHER_ROWS_PER_WG - 1) / GATHER_ROWS_PER_WG, 3), dim3(256),
+            (hipStream_t)stream, a, indices, batch, cols, quantiles);
   return (int)hipGetLastError();
 }
 

@@ -260,6 +260,34 @@ def table_dqn_batch(table, indices, cols_dev, n_out, quantiles, out: dict):
                                             L.ptr(quantiles), ctypes.byref(o), L.stream_ptr()))
 
 
+def replay_dqn_batch(view: "L.ReplayView", indices, cols_dev, quantiles, out: dict) -> bool:
+    """one-launch sample + input maker (+ normalize); False = shape not supported by the fused kernel"""
+    _chk_dev(indices, cols_dev, quantiles, *out.values())
+    assert indices.dtype == torch.int64 and indices.is_contiguous()
+    o = L.DqnBatchOut()
+    for name in L.BATCH_OUT_FIELDS:
+        t = out.get(name)
+        assert t is None or t.is_contiguous()
+        setattr(o, name, t.data_ptr() if t is not None else None)
+    o.state_dtype = dt_code(out["state"].dtype)
+    B = indices.numel()
+    rc = [0]
+
+    def call():
+        rc[0] = L.lib().rg_replay_dqn_batch(ctypes.byref(view), L.ptr(indices), B, L.ptr(cols_dev), L.ptr(quantiles),
+                                            ctypes.byref(o), L.stream_ptr())
+        return 0 if rc[0] == L.EUNSUPPORTED else rc[0]
+
+    F_, A_, H_ = view.n_features, view.n_actions, view.update_horizon
+    es = out["state"].element_size()
+    # algorithmic bytes per transition: rows in (2 F fp32) and out (2 F), n-step window, action / log_prob /
+    # index reads, masks in (if stored) and out, one-hots and scalars out
+    nbytes = (2 * F_ * 4 + 2 * F_ * es + 5 * H_ + 2 * 8 + 4 + 8 + (2 * A_ * 4 if view.possible_actions_mask else 0)
+              + 4 * A_ * 4 + 3 * 4)
+    _run("rg_replay_dqn_batch", dict(B=B, bytes_per_row=nbytes), call)
+    return rc[0] == 0
+
+
 def table_check_actions(table, indices) -> int:
     _chk_dev(indices)
     flag = torch.zeros(1, dtype=torch.int32, device=indices.device)

@@ -336,6 +336,66 @@ class ReplayBuffer:
             batch_arrays.append(batch)
         return self._batch_type(*batch_arrays)
 
+    def sample_dqn_input(self, num_actions: int, batch_size=None, indices=None, state_preprocessor=None,
+                         state_dtype=None):
+        """sample_transition_batch + DiscreteDqnInputMaker (trainer_preprocessor.py:100-158) [+ the state
+        Preprocessor] as ONE launch (rg_replay_dqn_batch): the n-step bookkeeping, both state gathers and
+        the one-hot / not_terminal / exp(log_prob) work, bit-identical to the three-launch path.  Returns
+        None when the store is not of the shape the fused kernel serves (stacked frames, non-fp32 or
+        non-vector observations, an ENUM-expanding preprocessor, ...): callers then use the generic path."""
+        from ..core import types as rlt
+
+        st = self._store
+        obs, act = st.get("observation"), st.get("action")
+        if (self._stack_size != 1 or obs is None or obs.dtype != torch.float32 or obs.dim() != 2 or act is None
+                or act.dtype != torch.int64 or act.dim() != 1 or "log_prob" not in st
+                or st["reward"].dtype != torch.float32):
+            return None
+        if state_preprocessor is not None and not state_preprocessor.elementwise:
+            return None
+        if state_preprocessor is None and state_dtype not in (None, torch.float32):
+            return None
+        mask = st.get("possible_actions_mask")
+        if mask is not None and (mask.dtype != torch.float32 or mask.shape[1:] != (num_actions,)):
+            return None
+        if batch_size is None:
+            batch_size = self._batch_size
+        if indices is None:
+            indices = self.sample_index_batch(batch_size)
+        else:
+            indices = indices.to(device=self.device, dtype=torch.int64)
+        assert len(indices) == batch_size
+        indices = indices.contiguous()
+        B, dev, F, A = batch_size, self.device, obs.shape[1], num_actions
+        if self._decays_dev is None or self._decays_dev.device != dev:
+            self._decays_dev = self._decays.reshape(-1).to(device=dev, dtype=torch.float32)
+        view = L.ReplayView()
+        view.observation, view.action, view.reward = obs.data_ptr(), act.data_ptr(), st["reward"].data_ptr()
+        view.terminal, view.log_prob = st["terminal"].data_ptr(), st["log_prob"].data_ptr()
+        view.possible_actions_mask = mask.data_ptr() if mask is not None else None
+        view.mdp_id, view.sequence_number = None, None
+        view.decays = self._decays_dev.data_ptr()
+        view.capacity, view.n_features, view.n_actions = self._replay_capacity, F, A
+        view.update_horizon = self._update_horizon
+        f32 = dict(dtype=torch.float32, device=dev)
+        sdt = state_dtype or torch.float32
+        out = dict(state=torch.empty(B, F, dtype=sdt, device=dev), next_state=torch.empty(B, F, dtype=sdt, device=dev),
+                   action=torch.empty(B, A, **f32), next_action=torch.empty(B, A, **f32), reward=torch.empty(B, 1, **f32),
+                   not_terminal=torch.empty(B, 1, **f32), possible_actions_mask=torch.empty(B, A, **f32),
+                   possible_next_actions_mask=torch.empty(B, A, **f32), action_probability=torch.empty(B, 1, **f32))
+        pre = state_preprocessor
+        if not ops.replay_dqn_batch(view, indices, pre._col_table if pre is not None else None,
+                                    pre._quantiles if pre is not None else None, out):
+            return None
+        return rlt.DiscreteDqnInput(
+            state=rlt.FeatureData(float_features=out["state"]), action=out["action"],
+            next_state=rlt.FeatureData(float_features=out["next_state"]), next_action=out["next_action"],
+            possible_actions_mask=out["possible_actions_mask"],
+            possible_next_actions_mask=out["possible_next_actions_mask"], reward=out["reward"],
+            not_terminal=out["not_terminal"], step=None, time_diff=None,
+            extras=rlt.ExtraData(mdp_id=None, sequence_number=None, action_probability=out["action_probability"],
+                                 max_num_actions=None, metrics=None))
+
     def get_transition_elements(self):
         extra_names = []
         for name in self._extra_keys:

@@ -3,9 +3,9 @@ the reference (reagent/gym/datasets/replay_buffer_dataset.py:153-206, SURVEY.md 
 dataloader, Lightning or host synchronisation:
 
     indices = sample_index_batch(B)                       (device RNG)
-    batch   = ReplayBuffer.sample_transition_batch         rg_replay_nstep + rg_replay_gather
-    input   = DiscreteDqnInputMaker(batch)                 rg_make_dqn_input
-    state, next_state = Preprocessor(...)                  rg_normalize_dense x2
+    batch   = ReplayBuffer.sample_transition_batch     \
+    input   = DiscreteDqnInputMaker(batch)              }  rg_replay_dqn_batch (one launch; generic stores:
+    state, next_state = Preprocessor(...)              /   rg_replay_nstep + rg_replay_gather + rg_make_dqn_input)
     trainer.train_step_native(input)                       FC fwd x3, head, bwd, Adam, soft update
 Everything is enqueued on torch's current stream; the loss stays on the device.
 `prefetch=True` moves the sampling / gather / input-maker launches of batch k+1 to a second HIP stream
@@ -34,11 +34,19 @@ class OfflineDqnLoop:
         self.state_dtype = state_dtype
         # 1:1 normalization tables ride along with the gather (no separate normalize pass)
         self.fuse_norm = state_preprocessor is not None and state_preprocessor.elementwise
+        self.fused_sampling = True
         self.prefetch = prefetch and torch.device(replay_buffer.device).type == "cuda"
         self._side = None
         self._ready = None  # (batch, event) of the prefetched next batch
 
     def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.DiscreteDqnInput:
+        if self.fused_sampling and (self.fuse_norm or self.pre is None):
+            # one launch: n-step bookkeeping + both state gathers (+ normalization) + input maker
+            inp = self.rb.sample_dqn_input(self.trainer.num_actions, self.batch_size, indices=indices,
+                                           state_preprocessor=self.pre, state_dtype=self.state_dtype)
+            if inp is not None:
+                return inp
+            self.fused_sampling = False  # this store is not of the fused kernel's shape
         if self.fuse_norm:
             tup = self.rb.sample_transition_batch(self.batch_size, indices=indices, state_preprocessor=self.pre,
                                                   state_dtype=self.state_dtype)

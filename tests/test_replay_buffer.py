@@ -340,3 +340,58 @@ def test_pre_timeline_df_equals_the_reference(emu_lib, discrete):
     assert list(a.columns) == list(b.columns) and len(a) == len(b)
     for c in a.columns:
         assert a[c].tolist() == b[c].tolist(), c
+
+
+def _gym_buffer(device, horizon, with_mask, n=90, cap=96, F=8, A=3, seed=12):
+    rb = ReplayBuffer(device=device, stack_size=1, replay_capacity=cap, batch_size=16, update_horizon=horizon, gamma=0.9)
+    rng = np.random.RandomState(seed)
+    for i in range(n):
+        kw = dict(observation=rng.randn(F).astype(np.float32), action=np.int64(rng.randint(A)),
+                  reward=np.float32(rng.rand()), terminal=bool(rng.rand() < 0.2), log_prob=np.float32(-rng.rand()),
+                  mdp_id=np.int64(i // 7), sequence_number=np.int64(i % 7))
+        if with_mask:
+            kw["possible_actions_mask"] = (rng.rand(A) > 0.3).astype(np.float32)
+        rb.add(**kw)
+    return rb
+
+
+@pytest.mark.parametrize("horizon,with_mask,normalize,dtype", [
+    (1, True, False, torch.float32), (3, True, True, torch.float32), (3, False, True, torch.bfloat16),
+    (2, False, False, torch.float32)])
+def test_fused_dqn_input_equals_sample_then_maker(backend, horizon, with_mask, normalize, dtype):
+    """rg_replay_dqn_batch == rg_replay_nstep + rg_replay_gather (+ normalize-on-gather) + rg_make_dqn_input,
+    bit for bit, on every field of the DiscreteDqnInput (n-step windows crossing terminals included)"""
+    from reagent_amd.core.parameters import NormalizationParameters as NP
+    from reagent_amd.preprocessing import DiscreteDqnInputMaker, Preprocessor
+
+    dev, F, A = backend.device, 8, 3
+    rb = _gym_buffer(dev, horizon, with_mask, F=F, A=A)
+    pre = None
+    if normalize:
+        pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=0.1 * i, stddev=1.0 + 0.1 * i) for i in range(F)}, device=dev)
+    idx = rb.sample_index_batch(70)
+    fused = rb.sample_dqn_input(A, 70, indices=idx, state_preprocessor=pre, state_dtype=dtype)
+    assert fused is not None
+    tup = rb.sample_transition_batch(70, indices=idx, state_preprocessor=pre, state_dtype=dtype if pre is not None else None)
+    ref = DiscreteDqnInputMaker(A)(tup)
+    assert fused.state.float_features.dtype == dtype
+    for name in ("action", "next_action", "reward", "not_terminal", "possible_actions_mask", "possible_next_actions_mask"):
+        assert torch.equal(getattr(fused, name), getattr(ref, name)), name
+    assert torch.equal(fused.state.float_features, ref.state.float_features)
+    assert torch.equal(fused.next_state.float_features, ref.next_state.float_features)
+    assert torch.equal(fused.extras.action_probability, ref.extras.action_probability)
+    assert fused.step is None and fused.time_diff is None
+    assert (fused.not_terminal == 0).any() and (fused.not_terminal == 1).any()
+
+
+def test_fused_dqn_input_declines_other_stores(backend):
+    rb = ReplayBuffer(device=backend.device, stack_size=2, replay_capacity=20, batch_size=4)
+    for i in range(10):
+        rb.add(observation=np.zeros(8, np.float32), action=np.int64(0), reward=np.float32(0), terminal=False,
+               log_prob=np.float32(0))
+    assert rb.sample_dqn_input(3, 4) is None  # stacked frames
+    rb = ReplayBuffer(device=backend.device, stack_size=1, replay_capacity=20, batch_size=4)
+    for i in range(10):
+        rb.add(observation=np.zeros(6, np.float32), action=np.int64(0), reward=np.float32(0), terminal=False,
+               log_prob=np.float32(0))
+    assert rb.sample_dqn_input(3, 4) is None  # 6 features: not a multiple of 4
