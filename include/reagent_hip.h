@@ -354,17 +354,14 @@ int rg_table_check_actions(const rg_dqn_table* table, const int64_t* indices, in
  * reward, not_terminal [B] fp32; reward_boosts [A] fp32 or NULL;
  * discount = gamma, or gamma ** gamma_exponent[b] when gamma_exponent != NULL (time_diff / step).
  * Outputs: dq [B, A] fp32 = d(mean loss)/d q; loss_partials [rg_dqn_head_partials(B)] fp32 whose
- * ordered sum / B is the loss; next_q [B], next_idx [B] int64 and q_sel [B] (nullable) for
- * logging/tests.  loss_out (nullable): the workgroup that finishes last writes the loss there — the
- * value rg_reduce_sum(loss_partials, n, 1/B) would give, bit for bit — which saves that launch;
- * ticket: one device uint32, zero before the first launch (the kernel hands it back at zero). */
+ * ordered sum / B is the loss (rg_reduce_sum finishes it); next_q [B], next_idx [B] int64 and
+ * q_sel [B] (nullable) for logging/tests. */
 int rg_dqn_head_partials(int batch);
 int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, const float* action,
                 const float* next_mask, const float* reward, const float* reward_boosts,
                 const float* not_terminal, double gamma, const float* gamma_exponent, int batch,
                 int num_actions, int double_q, int loss_type, float* dq, float* loss_partials,
-                float* next_q, int64_t* next_idx, float* q_sel, float* loss_out, unsigned* ticket,
-                rg_stream_t stream);
+                float* next_q, int64_t* next_idx, float* q_sel, rg_stream_t stream);
 
 /* CPE heads of the DQN step, _calculate_cpes (reagent/training/dqn_trainer_base.py:338-452) with
  * masked_softmax (reagent/core/torch_utils.py:62-73): reward-network MSE and CPE q-network loss on the

@@ -167,7 +167,7 @@ SIGNATURES = {
                                      ctypes.POINTER(DqnBatchOut), c_void_p]),
     "rg_table_check_actions": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_void_p]),
     "rg_dqn_head_partials": (c_int, [c_int]),
-    "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
+    "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rg_cpe_head": (c_int, [c_void_p] * 9 + [ctypes.c_double, c_void_p, ctypes.c_double, c_int, c_int, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_c51_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_void_p, c_d, c_d, c_int, c_int, c_int, c_int, c_void_p,

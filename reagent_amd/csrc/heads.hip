@@ -7,27 +7,6 @@ namespace rg {
 
 constexpr int HEAD_THREADS = 256;
 
-// The workgroup that takes the last ticket sums the per-workgroup partials and writes out[0] =
-// sum * scale — what a separate rg_reduce_sum launch would do, in the same order (strided per-thread
-// sums, then block_sum_256), so the value does not depend on which workgroup comes last.  The ticket
-// is handed back at zero for the next launch.  All threads of the workgroup must call this.
-__device__ __forceinline__ void finish_mean_in_last_block(const float* partials, float scale, float* out,
-                                                          unsigned* ticket, float* scratch /*[4]*/) {
-  __shared__ int s_last;
-  __threadfence();  // this workgroup's partial is visible device-wide before its ticket is
-  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();  // see every other workgroup's partial
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += HEAD_THREADS) acc += __builtin_nontemporal_load(partials + i);
-  const float total = block_sum_256(acc, scratch);
-  if (threadIdx.x == 0) {
-    out[0] = total * scale;
-    *ticket = 0u;
-  }
-}
-
 // One thread per transition.  Masked max / arg-max over |A| with first-index tie-break
 // (torch.max semantics), double-Q gather, TD target, MSE / Huber value and d loss / d q.
 // dqn_trainer_base.py:33-77 + dqn_trainer.py:201-238.
@@ -39,8 +18,7 @@ __global__ void dqn_head_kernel(const float* __restrict__ q, const float* __rest
                                 const float* __restrict__ gamma_exponent, int batch, int A, int double_q,
                                 int loss_type, float* __restrict__ dq, float* __restrict__ loss_partials,
                                 float* __restrict__ next_q_out, int64_t* __restrict__ next_idx_out,
-                                float* __restrict__ q_sel_out, float* __restrict__ loss_out,
-                                unsigned* __restrict__ ticket) {
+                                float* __restrict__ q_sel_out) {
   __shared__ float scratch[4];
   const int b = blockIdx.x * HEAD_THREADS + threadIdx.x;
   float loss = 0.f;
@@ -121,7 +99,6 @@ __global__ void dqn_head_kernel(const float* __restrict__ q, const float* __rest
   }
   const float s = block_sum_256(loss, scratch);
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = s;
-  if (loss_out) finish_mean_in_last_block(loss_partials, 1.f / (float)batch, loss_out, ticket, scratch);
 }
 
 // CPE heads of the DQN step (reagent/training/dqn_trainer_base.py:338-452, _calculate_cpes): one
@@ -485,17 +462,15 @@ int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, 
                 const float* next_mask, const float* reward, const float* reward_boosts,
                 const float* not_terminal, double gamma, const float* gamma_exponent, int batch,
                 int num_actions, int double_q, int loss_type, float* dq, float* loss_partials,
-                float* next_q, int64_t* next_idx, float* q_sel, float* loss_out, unsigned* ticket,
-                rg_stream_t stream) {
+                float* next_q, int64_t* next_idx, float* q_sel, rg_stream_t stream) {
   if (!q || !qn_online || !qn_target || !action || !next_mask || !reward || !not_terminal || !dq ||
       !loss_partials || batch <= 0 || num_actions <= 0)
     return RG_EINVAL;
-  if (loss_out && !ticket) return RG_EINVAL;
   if (loss_type != RG_LOSS_MSE && loss_type != RG_LOSS_HUBER) return RG_EINVAL;
   RG_LAUNCH(dqn_head_kernel, dim3(rg_dqn_head_partials(batch)), dim3(HEAD_THREADS),
             (hipStream_t)stream, q, qn_online, qn_target, action, next_mask, reward, reward_boosts,
             not_terminal, (float)gamma, gamma_exponent, batch, num_actions, double_q, loss_type, dq,
-            loss_partials, next_q, next_idx, q_sel, loss_out, ticket);
+            loss_partials, next_q, next_idx, q_sel);
   return (int)hipGetLastError();
 }
 

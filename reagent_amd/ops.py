@@ -304,12 +304,9 @@ def dqn_head_partials(batch: int) -> int:
 
 def dqn_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal, gamma,
              gamma_exponent, double_q, loss_type, dq, loss_partials, next_q=None, next_idx=None,
-             q_sel=None, loss_out=None, ticket=None):
-    """loss_out + ticket (a zeroed int32[1] owned by the caller): the mean loss is finished inside the
-    launch by the last workgroup instead of a separate reduce_sum"""
+             q_sel=None):
     _chk_dev(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, not_terminal,
-             gamma_exponent, dq, loss_partials, next_q, next_idx, q_sel, loss_out, ticket)
-    assert (loss_out is None) == (ticket is None) and (ticket is None or ticket.dtype == torch.int32)
+             gamma_exponent, dq, loss_partials, next_q, next_idx, q_sel)
     batch, A = q.shape
     for t in (q, qn_online, qn_target, action, next_mask, dq):
         assert t.is_contiguous() and t.dtype == F32 and t.shape == (batch, A)
@@ -320,8 +317,7 @@ def dqn_head(q, qn_online, qn_target, action, next_mask, reward, reward_boosts, 
                                      L.ptr(next_mask), L.ptr(reward), L.ptr(reward_boosts),
                                      L.ptr(not_terminal), float(gamma), L.ptr(gamma_exponent), batch, A,
                                      int(double_q), loss_type, L.ptr(dq), L.ptr(loss_partials), L.ptr(next_q),
-                                     L.ptr(next_idx), L.ptr(q_sel), L.ptr(loss_out), L.ptr(ticket),
-                                     L.stream_ptr()))
+                                     L.ptr(next_idx), L.ptr(q_sel), L.stream_ptr()))
 
 
 def cpe_head(reward_est, q_cpe, q_cpe_tgt_next, next_scores, next_mask, action, reward, extra_metrics,

@@ -525,13 +525,13 @@ class DQNTrainer(QStepCore):
         self._next_q = torch.empty(batch, **f32)
         self._next_idx = torch.empty(batch, dtype=torch.int64, device=device)
         self._q_sel = torch.empty(batch, **f32)
-        self._ticket = torch.zeros(1, dtype=torch.int32, device=device)  # last-workgroup reduction of the loss
 
     def _run_head(self, b, B, action, next_mask, boosts, gamma_exp):
         ops.dqn_head(self._q, self._qn_online, self._qn_target, action, next_mask,
                      self._f32c(b.reward).reshape(-1), boosts, self._f32c(b.not_terminal).reshape(-1),
                      self.gamma, gamma_exp, self.double_q_learning, self._loss_type, self._dq,
-                     self._loss_partials, self._next_q, self._next_idx, self._q_sel, self._loss, self._ticket)
+                     self._loss_partials, self._next_q, self._next_idx, self._q_sel)
+        ops.reduce_sum(self._loss_partials, self._loss_partials.numel(), 1.0 / B, self._loss)
         self.all_action_scores = self._q
 
     # ---- reference surface --------------------------------------------------------------------

@@ -141,26 +141,3 @@ def test_calculate_cpes(backend):
     target = inp.reward + trainer.gamma * next_q
     expected = torch.nn.functional.mse_loss(metric_q, target)
     assert torch.allclose(losses[2].detach(), expected, rtol=1e-5, atol=1e-7), (losses[2], expected)
-
-
-@pytest.mark.parametrize("B", [3, 256, 1000, 5000])
-def test_loss_finished_in_the_head_launch_equals_reduce_sum(backend, B):
-    """rg_dqn_head(loss_out, ticket): the last workgroup writes the mean loss — the bits of a separate
-    rg_reduce_sum over the same partials — and hands the ticket back at zero (second launch identical)"""
-    dev, A = backend.device, 4
-    g = torch.Generator().manual_seed(B)
-    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
-    q, qo, qt = r(B, A), r(B, A), r(B, A)
-    action = torch.nn.functional.one_hot(torch.randint(A, (B,), generator=g), A).float().to(dev)
-    mask = torch.ones(B, A, device=dev)
-    reward, nt = r(B), (torch.rand(B, generator=g) > 0.1).float().to(dev)
-    P = ops.dqn_head_partials(B)
-    dq, parts = torch.empty(B, A, device=dev), torch.empty(P, device=dev)
-    loss, ticket = torch.full((1,), -7.0, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
-    for _ in range(2):
-        loss.fill_(-7.0)
-        ops.dqn_head(q, qo, qt, action, mask, reward, None, nt, 0.9, None, True, L.LOSS["huber"], dq, parts,
-                     loss_out=loss, ticket=ticket)
-        ref = torch.empty(1, device=dev)
-        ops.reduce_sum(parts, P, 1.0 / B, ref)
-        assert torch.equal(loss.cpu(), ref.cpu()) and int(ticket.item()) == 0
