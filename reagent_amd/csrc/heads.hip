@@ -7,6 +7,10 @@ namespace rg {
 
 constexpr int HEAD_THREADS = 256;
 
+// (Finishing the mean loss inside this launch — the workgroup that takes the last ticket sums the
+// partials after a device-scope fence — was measured on MI355X: the kernel went from 13.4 to 44 us.
+// A release fence at agent scope writes the XCD's L2 back, here with the whole dq matrix dirty in it;
+// the separate 6 us rg_reduce_sum launch is the cheaper way to cross the XCDs.)
 // One thread per transition.  Masked max / arg-max over |A| with first-index tie-break
 // (torch.max semantics), double-Q gather, TD target, MSE / Huber value and d loss / d q.
 // dqn_trainer_base.py:33-77 + dqn_trainer.py:201-238.
