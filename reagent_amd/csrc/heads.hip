@@ -105,6 +105,99 @@ __global__ void dqn_head_kernel(const float* __restrict__ q, const float* __rest
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = s;
 }
 
+// The same head with G = A / 4 lanes per transition (A = 4, 8, 16): every lane holds one float4 of each
+// row, so the five [B, A] operands are read with fully coalesced 16-byte requests and the launch has
+// G times the waves in flight (one thread per row leaves a 65 536-row batch at one wave per SIMD,
+// which is latency-bound).  The row reductions run over the G lanes of a row with xor shuffles:
+//   * arg-max: larger key wins, equal keys -> lower index (torch.max's first-index rule);
+//   * sum_a q * action and sum_a action * boost: a one-hot row has one non-zero product, so the order
+//     of the adds cannot change the result.
+// A workgroup still covers 256 transitions (256 * G threads), so loss_partials keeps its length.
+template <int G>
+__global__ void __launch_bounds__(256 * G) dqn_head_lanes_kernel(
+    const float* __restrict__ q, const float* __restrict__ qn_online, const float* __restrict__ qn_target,
+    const float* __restrict__ action, const float* __restrict__ next_mask, const float* __restrict__ reward,
+    const float* __restrict__ reward_boosts, const float* __restrict__ not_terminal, float gamma,
+    const float* __restrict__ gamma_exponent, int batch, int double_q, int loss_type, float* __restrict__ dq,
+    float* __restrict__ loss_partials, float* __restrict__ next_q_out, int64_t* __restrict__ next_idx_out,
+    float* __restrict__ q_sel_out) {
+  constexpr int A = 4 * G, WAVES = 4 * G;
+  __shared__ float scratch[WAVES];
+  const int t = threadIdx.x, sub = t % G;
+  const int b_raw = blockIdx.x * 256 + t / G;
+  // rows past the end recompute the last row and store nothing: every lane takes part in the shuffles
+  const bool live = b_raw < batch;
+  const int b = live ? b_raw : batch - 1;
+  float loss = 0.f;
+  {
+    const long o = (long)b * A + sub * 4;
+    const f32x4 m4 = *(const f32x4*)(next_mask + o);
+    const f32x4 qt4 = *(const f32x4*)(qn_target + o);
+    const f32x4 qo4 = double_q ? *(const f32x4*)(qn_online + o) : qt4;
+    const f32x4 ac4 = *(const f32x4*)(action + o);
+    const f32x4 q4 = *(const f32x4*)(q + o);
+    float best = 0.f, best_t = 0.f, rb = 0.f, qs = 0.f;
+    int best_i = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pen = -1e9f * (1.f - m4[e]);  // ACTION_NOT_POSSIBLE_VAL * (1 - mask)
+      const float qo = qo4[e] + pen, qt = qt4[e] + pen;
+      const float key = double_q ? qo : qt;
+      if (e == 0 || key > best) {
+        best = key;
+        best_t = qt;
+        best_i = sub * 4 + e;
+      }
+      if (reward_boosts) rb += ac4[e] * reward_boosts[sub * 4 + e];
+      qs += q4[e] * ac4[e];
+    }
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+      const float ok = shfl_xor(best, off), ot = shfl_xor(best_t, off);
+      const int oi = shfl_xor(best_i, off);
+      if (ok > best || (ok == best && oi < best_i)) {
+        best = ok;
+        best_t = ot;
+        best_i = oi;
+      }
+      rb += shfl_xor(rb, off);
+      qs += shfl_xor(qs, off);
+    }
+    const float rew = reward[b] + rb;
+    const float disc = gamma_exponent ? powf(gamma, gamma_exponent[b]) : gamma;
+    const float target = rew + disc * (best_t * not_terminal[b]);
+    const float d = qs - target;
+    float g, row_loss;
+    if (loss_type == RG_LOSS_HUBER) {
+      const float ad = fabsf(d);
+      row_loss = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+      g = ad < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+    } else {
+      row_loss = d * d;
+      g = 2.f * d;
+    }
+    g /= (float)batch;
+    if (live) *(f32x4*)(dq + o) = f32x4{g * ac4[0], g * ac4[1], g * ac4[2], g * ac4[3]};
+    if (live && sub == 0) {
+      loss = row_loss;
+      if (next_q_out) next_q_out[b] = best_t;
+      if (next_idx_out) next_idx_out[b] = best_i;
+      if (q_sel_out) q_sel_out[b] = qs;
+    }
+  }
+  // workgroup sum in a fixed order: wave shuffles, then the wave sums added in order
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) loss += shfl_xor(loss, off);
+  if ((t & 63) == 0) scratch[t >> 6] = loss;
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s += scratch[w];
+    loss_partials[blockIdx.x] = s;
+  }
+}
+
 // CPE heads of the DQN step (reagent/training/dqn_trainer_base.py:338-452, _calculate_cpes): one
 // thread per transition, M metrics x A actions.
 //   propensities = masked_softmax(all_next_action_scores, next_mask, temperature)
@@ -471,10 +564,21 @@ int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, 
       !loss_partials || batch <= 0 || num_actions <= 0)
     return RG_EINVAL;
   if (loss_type != RG_LOSS_MSE && loss_type != RG_LOSS_HUBER) return RG_EINVAL;
-  RG_LAUNCH(dqn_head_kernel, dim3(rg_dqn_head_partials(batch)), dim3(HEAD_THREADS),
-            (hipStream_t)stream, q, qn_online, qn_target, action, next_mask, reward, reward_boosts,
-            not_terminal, (float)gamma, gamma_exponent, batch, num_actions, double_q, loss_type, dq,
-            loss_partials, next_q, next_idx, q_sel);
+  const bool aligned = ((((uintptr_t)q | (uintptr_t)qn_target | (uintptr_t)action | (uintptr_t)next_mask |
+                          (uintptr_t)dq | (uintptr_t)(double_q ? qn_online : qn_target)) & 15) == 0);
+  const dim3 grid(rg_dqn_head_partials(batch));
+#define RG_HEAD_LANES(G)                                                                                       \
+  RG_LAUNCH(dqn_head_lanes_kernel<G>, grid, dim3(256 * G), (hipStream_t)stream, q, qn_online, qn_target, action, \
+            next_mask, reward, reward_boosts, not_terminal, (float)gamma, gamma_exponent, batch, double_q,     \
+            loss_type, dq, loss_partials, next_q, next_idx, q_sel)
+  if (aligned && num_actions == 16) RG_HEAD_LANES(4);
+  else if (aligned && num_actions == 8) RG_HEAD_LANES(2);
+  else if (aligned && num_actions == 4) RG_HEAD_LANES(1);
+  else
+    RG_LAUNCH(dqn_head_kernel, grid, dim3(HEAD_THREADS), (hipStream_t)stream, q, qn_online, qn_target, action,
+              next_mask, reward, reward_boosts, not_terminal, (float)gamma, gamma_exponent, batch, num_actions,
+              double_q, loss_type, dq, loss_partials, next_q, next_idx, q_sel);
+#undef RG_HEAD_LANES
   return (int)hipGetLastError();
 }
 

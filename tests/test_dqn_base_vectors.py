@@ -141,3 +141,39 @@ def test_calculate_cpes(backend):
     target = inp.reward + trainer.gamma * next_q
     expected = torch.nn.functional.mse_loss(metric_q, target)
     assert torch.allclose(losses[2].detach(), expected, rtol=1e-5, atol=1e-7), (losses[2], expected)
+
+
+@pytest.mark.parametrize("A,B,double_q,loss", [(4, 37, True, "huber"), (8, 300, False, "mse"), (16, 1000, True, "huber"),
+                                               (16, 64, True, "mse"), (12, 130, True, "huber")])
+def test_head_lane_layouts_against_torch(backend, A, B, double_q, loss):
+    """A = 4 / 8 / 16 run with A/4 lanes per transition, anything else with one thread per row: both
+    against the reference's formulas in torch (dqn_trainer_base.py:33-77, dqn_trainer.py:201-238),
+    ties included (first maximal index wins, also across lanes)"""
+    dev = backend.device
+    g = torch.Generator().manual_seed(A * 1000 + B)
+    qn_o = torch.randint(-3, 4, (B, A), generator=g).float()  # small integers: plenty of ties
+    qn_t, q = torch.randn(B, A, generator=g), torch.randn(B, A, generator=g)
+    mask = (torch.rand(B, A, generator=g) > 0.3).float()
+    mask[torch.arange(B), torch.randint(A, (B,), generator=g)] = 1
+    action = torch.nn.functional.one_hot(torch.randint(A, (B,), generator=g), A).float()
+    reward, nt = torch.randn(B, generator=g), (torch.rand(B, generator=g) > 0.2).float()
+    boosts, gamma = torch.randn(A, generator=g) * 0.1, 0.9
+    pen = -1e9 * (1 - mask)
+    key = (qn_o if double_q else qn_t) + pen
+    idx = key.argmax(1)
+    next_q = (qn_t + pen).gather(1, idx[:, None]).squeeze(1)
+    qr = q.clone().requires_grad_()
+    target = reward + (action * boosts).sum(1) + gamma * next_q * nt
+    qs = (qr * action).sum(1)
+    ref = torch.nn.functional.smooth_l1_loss(qs, target) if loss == "huber" else torch.nn.functional.mse_loss(qs, target)
+    ref.backward()
+    d = lambda t: t.to(dev).contiguous()  # noqa: E731
+    P = ops.dqn_head_partials(B)
+    dq, parts = torch.empty(B, A, device=dev), torch.empty(P, device=dev)
+    nq, ni, qsel = torch.empty(B, device=dev), torch.empty(B, dtype=torch.int64, device=dev), torch.empty(B, device=dev)
+    ops.dqn_head(d(q), d(qn_o), d(qn_t), d(action), d(mask), d(reward), d(boosts), d(nt), gamma, None, double_q,
+                 L.LOSS[loss], dq, parts, nq, ni, qsel)
+    assert torch.equal(ni.cpu(), idx) and torch.equal(nq.cpu(), next_q)
+    assert torch.equal(qsel.cpu(), qs.detach())
+    assert abs(parts.sum().item() / B - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-7
+    assert (dq.cpu() - qr.grad).abs().max() <= 1e-7
