@@ -55,6 +55,7 @@ def _rel(a, b):
 @pytest.mark.parametrize("dims,acts,batch", [
     ([24, 256, 256, 16], ["relu", "relu", "linear"], 100),
     ([128, 512, 512, 512, 16], ["relu", "relu", "relu", "linear"], 300),
+    ([128, 256, 256, 8], ["relu", "relu", "linear"], 700),
     ([130, 256, 256, 70], ["leaky_relu", "tanh", "linear"], 129),
     ([40, 512, 512, 3], ["tanh", "relu", "linear"], 64),
 ])
@@ -91,6 +92,14 @@ def test_fused_forward_backward_wgrad(backend, dims, acts, batch):
     out3 = torch.zeros_like(out)
     st.forward(x.to(torch.bfloat16), out3, save=False)
     assert torch.equal(out3, out)
+    # ... also when saving for backward
+    out4, dw4 = torch.zeros_like(out), [torch.zeros_like(w) for w in ws]
+    db4, dx4 = [torch.zeros_like(b) for b in bs], torch.zeros_like(dx)
+    st.forward(x.to(torch.bfloat16), out4, save=True)
+    st.backward(dout, xt, dw4, db4, dx32=dx4)
+    assert torch.equal(out4, out) and torch.equal(dx4, dx)
+    for l in range(len(ws)):
+        assert torch.equal(dw4[l], dw[l]) and torch.equal(db4[l], db[l]), l
 
 
 def test_fused_matches_per_layer_bf16_engine(backend):
