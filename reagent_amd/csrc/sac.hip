@@ -18,10 +18,77 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 //   log_prob = get_log_prob(state, action) (actor.py:233-261), which re-derives r' = (atanh(a) - loc)/sigma
 // One thread per (b, d) computes the action and its log-prob term; the A terms of a row are summed
 // by a row-owner thread in index order.
+// Element-parallel form: one thread per (b, d) — the transcendental chain (exp, tanh, atanh, log) of
+// the A elements of a row runs on A lanes instead of one after the other on a single lane, which left
+// a 65 536-row batch at one wave per SIMD (C4: 116 us per launch) — the per-element terms go through
+// LDS and the row owner adds them in index order, i.e. the same order as a sequential loop.
+constexpr int GH_THREADS = 256;
+
+__device__ __forceinline__ float gaussian_lp_term(float loc, float s, float a) {
+  const float r2 = (atanhf(a) - loc) / expf(s);
+  const float normal = -(r2 * r2) / 2.f - s - LOG_SQRT_2PI;  // _normal_log_prob :166-181
+  const float squash = logf(1.f - a * a + ACT_EPS);          // _squash_correction :183-188
+  return normal - squash;
+}
+
+// rows_per_wg = GH_THREADS / A rows per workgroup (A <= GH_THREADS); thread t -> (row t / A, d = t % A)
 __global__ void gaussian_head_fwd_kernel(const float* __restrict__ ls, long ldls,
                                          const float* __restrict__ noise, int batch, int A,
                                          float* __restrict__ action, long lda,
                                          float* __restrict__ log_prob, float* __restrict__ squashed_mean) {
+  __shared__ float terms[GH_THREADS];
+  const int rows_per_wg = GH_THREADS / A;
+  const int t = threadIdx.x, rl = t / A, d = t - rl * A;
+  const int b = blockIdx.x * rows_per_wg + rl;
+  const bool live = rl < rows_per_wg && b < batch;
+  if (live) {
+    const float loc = ls[(long)b * ldls + d];
+    const float s = clampf(ls[(long)b * ldls + A + d], LOG_PROB_MIN, LOG_PROB_MAX);
+    const float sigma = expf(s);
+    const float raw = loc + noise[(long)b * A + d] * sigma;
+    const float a = clampf(tanhf(raw), -1.f + ACT_EPS, 1.f - ACT_EPS);
+    action[(long)b * lda + d] = a;
+    if (squashed_mean) squashed_mean[(long)b * A + d] = clampf(tanhf(loc), -1.f + ACT_EPS, 1.f - ACT_EPS);
+    const float r2 = (atanhf(a) - loc) / sigma;
+    const float normal = -(r2 * r2) / 2.f - s - LOG_SQRT_2PI;
+    const float squash = logf(1.f - a * a + ACT_EPS);
+    terms[t] = normal - squash;
+  }
+  __syncthreads();
+  if (live && d == 0 && log_prob) {
+    float lp = 0.f;
+    for (int k = 0; k < A; ++k) lp += terms[t + k];
+    log_prob[b] = lp;
+  }
+}
+
+// get_log_prob(state, squashed_action) for a GIVEN action (actor.py:233-261)
+__global__ void gaussian_log_prob_kernel(const float* __restrict__ ls, long ldls,
+                                         const float* __restrict__ action, long lda, int batch, int A,
+                                         float* __restrict__ log_prob) {
+  __shared__ float terms[GH_THREADS];
+  const int rows_per_wg = GH_THREADS / A;
+  const int t = threadIdx.x, rl = t / A, d = t - rl * A;
+  const int b = blockIdx.x * rows_per_wg + rl;
+  const bool live = rl < rows_per_wg && b < batch;
+  if (live) {
+    const float loc = ls[(long)b * ldls + d];
+    const float s = clampf(ls[(long)b * ldls + A + d], LOG_PROB_MIN, LOG_PROB_MAX);
+    terms[t] = gaussian_lp_term(loc, s, action[(long)b * lda + d]);
+  }
+  __syncthreads();
+  if (live && d == 0) {
+    float lp = 0.f;
+    for (int k = 0; k < A; ++k) lp += terms[t + k];
+    log_prob[b] = lp;
+  }
+}
+
+// one thread per row: action widths beyond a workgroup
+__global__ void gaussian_head_fwd_rows_kernel(const float* __restrict__ ls, long ldls,
+                                              const float* __restrict__ noise, int batch, int A,
+                                              float* __restrict__ action, long lda,
+                                              float* __restrict__ log_prob, float* __restrict__ squashed_mean) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
   float lp = 0.f;
@@ -34,26 +101,21 @@ __global__ void gaussian_head_fwd_kernel(const float* __restrict__ ls, long ldls
     action[(long)b * lda + d] = a;
     if (squashed_mean) squashed_mean[(long)b * A + d] = clampf(tanhf(loc), -1.f + ACT_EPS, 1.f - ACT_EPS);
     const float r2 = (atanhf(a) - loc) / sigma;
-    const float normal = -(r2 * r2) / 2.f - s - LOG_SQRT_2PI;          // _normal_log_prob :166-181
-    const float squash = logf(1.f - a * a + ACT_EPS);                  // _squash_correction :183-188
-    lp += normal - squash;
+    lp += (-(r2 * r2) / 2.f - s - LOG_SQRT_2PI) - logf(1.f - a * a + ACT_EPS);
   }
   if (log_prob) log_prob[b] = lp;
 }
 
-// get_log_prob(state, squashed_action) for a GIVEN action (actor.py:233-261)
-__global__ void gaussian_log_prob_kernel(const float* __restrict__ ls, long ldls,
-                                         const float* __restrict__ action, long lda, int batch, int A,
-                                         float* __restrict__ log_prob) {
+__global__ void gaussian_log_prob_rows_kernel(const float* __restrict__ ls, long ldls,
+                                              const float* __restrict__ action, long lda, int batch, int A,
+                                              float* __restrict__ log_prob) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
   float lp = 0.f;
   for (int d = 0; d < A; ++d) {
     const float loc = ls[(long)b * ldls + d];
     const float s = clampf(ls[(long)b * ldls + A + d], LOG_PROB_MIN, LOG_PROB_MAX);
-    const float a = action[(long)b * lda + d];
-    const float r2 = (atanhf(a) - loc) / expf(s);
-    lp += (-(r2 * r2) / 2.f - s - LOG_SQRT_2PI) - logf(1.f - a * a + ACT_EPS);
+    lp += gaussian_lp_term(loc, s, action[(long)b * lda + d]);
   }
   log_prob[b] = lp;
 }
@@ -256,16 +318,28 @@ int rg_gaussian_head_forward(const float* loc_scale, int64_t ldls, const float* 
                              int action_dim, float* action, int64_t lda, float* log_prob,
                              float* squashed_mean, rg_stream_t stream) {
   if (!loc_scale || !noise || !action || batch <= 0 || action_dim <= 0) return RG_EINVAL;
-  RG_LAUNCH(gaussian_head_fwd_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, loc_scale,
-            (long)ldls, noise, batch, action_dim, action, (long)lda, log_prob, squashed_mean);
+  if (action_dim <= GH_THREADS) {
+    const int rows = GH_THREADS / action_dim;
+    RG_LAUNCH(gaussian_head_fwd_kernel, dim3((batch + rows - 1) / rows), dim3(GH_THREADS), (hipStream_t)stream,
+              loc_scale, (long)ldls, noise, batch, action_dim, action, (long)lda, log_prob, squashed_mean);
+  } else {
+    RG_LAUNCH(gaussian_head_fwd_rows_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, loc_scale,
+              (long)ldls, noise, batch, action_dim, action, (long)lda, log_prob, squashed_mean);
+  }
   return (int)hipGetLastError();
 }
 
 int rg_gaussian_log_prob(const float* loc_scale, int64_t ldls, const float* action, int64_t lda, int batch,
                          int action_dim, float* log_prob, rg_stream_t stream) {
   if (!loc_scale || !action || !log_prob || batch <= 0 || action_dim <= 0) return RG_EINVAL;
-  RG_LAUNCH(gaussian_log_prob_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, loc_scale,
-            (long)ldls, action, (long)lda, batch, action_dim, log_prob);
+  if (action_dim <= GH_THREADS) {
+    const int rows = GH_THREADS / action_dim;
+    RG_LAUNCH(gaussian_log_prob_kernel, dim3((batch + rows - 1) / rows), dim3(GH_THREADS), (hipStream_t)stream,
+              loc_scale, (long)ldls, action, (long)lda, batch, action_dim, log_prob);
+  } else {
+    RG_LAUNCH(gaussian_log_prob_rows_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, loc_scale,
+              (long)ldls, action, (long)lda, batch, action_dim, log_prob);
+  }
   return (int)hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ def _head_ref(ls, noise, A):
     return a, lp
 
 
-@pytest.mark.parametrize("B,A", [(70, 2), (300, 32), (33, 5)])
+@pytest.mark.parametrize("B,A", [(70, 2), (300, 32), (33, 5), (1000, 3), (9, 256), (5, 300)])  # 300 > one workgroup: row-per-thread kernels
 def test_gaussian_head_forward_backward(backend, B, A):
     g = torch.Generator().manual_seed(B)
     ls = torch.randn(B, 2 * A, generator=g) * 1.5
