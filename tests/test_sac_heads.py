@@ -19,7 +19,7 @@ def _head_ref(ls, noise, A):
     return a, lp
 
 
-@pytest.mark.parametrize("B,A", [(70, 2), (300, 32), (33, 5), (1000, 3), (9, 256), (5, 300)])  # 300 > one workgroup: row-per-thread kernels
+@pytest.mark.parametrize("B,A", [(70, 2), (300, 32), (33, 5), (1000, 3), (40, 64), (5, 300)])  # 300 > one workgroup: row-per-thread kernels
 def test_gaussian_head_forward_backward(backend, B, A):
     g = torch.Generator().manual_seed(B)
     ls = torch.randn(B, 2 * A, generator=g) * 1.5
@@ -40,7 +40,8 @@ def test_gaussian_head_forward_backward(backend, B, A):
     # near tanh saturation (|a| -> 1 - 1e-6) fp32 itself is only good to ~1e-2 in log(1 - a^2 + eps):
     # require fp32-class agreement with the fp32 reference there, tight agreement elsewhere
     sat = (a32.abs() > 0.999).any(dim=1)
-    assert (lp.cpu() - lp32)[~sat].abs().max() <= 2e-5 * max(1.0, lp32.abs().max().item())
+    if (~sat).any():  # wide rows: some element saturates in every row
+        assert (lp.cpu() - lp32)[~sat].abs().max() <= 2e-5 * max(1.0, lp32.abs().max().item())
     assert (lp.cpu() - lp32)[sat].abs().max() <= 2e-2 if sat.any() else True
     assert (sm.cpu() - torch.clamp(torch.tanh(ls[:, :A]), -1 + 1e-6, 1 - 1e-6)).abs().max() <= 2e-6
     # log-prob of a given action equals the forward's own log-prob (reagent/test/models/test_actor.py:162-178)
@@ -55,7 +56,7 @@ def test_gaussian_head_forward_backward(backend, B, A):
     err = (d.cpu().double() - ref).abs()
     tol = 2e-4 * (1.0 + ref.abs())
     ok_rows = ~sat
-    assert (err[ok_rows] <= tol[ok_rows]).all(), (err[ok_rows] / tol[ok_rows]).max()
+    assert (err[ok_rows] <= tol[ok_rows]).all(), (err[ok_rows] / tol[ok_rows]).max() if ok_rows.any() else 0
     assert d[0, A].item() == 0.0 and d[1, A + 1].item() == 0.0
 
 
