@@ -53,6 +53,18 @@ static int launch_gemm(const GemmArgs& g, const Epi& epi, float* bias_partials, 
   return (int)hipGetLastError();
 }
 
+// large bf16 shapes: the 256 x 256 DMA kernel (rg_gemm.h); same results bit for bit
+template <class Epi>
+static int launch_gemm_big(const GemmArgs& g, const Epi& epi, hipStream_t stream) {
+  const int tiles = ((g.M + BIG_BM - 1) / BIG_BM) * ((g.N + BIG_BN - 1) / BIG_BN);
+  const size_t lds = (size_t)BIG_SLOTS * BIG_STAGE_BYTES;
+  RG_ALLOW_LDS((gemm_nt_big_kernel<Epi>), lds);
+  RG_LAUNCH_DYN((gemm_nt_big_kernel<Epi>), dim3(tiles), dim3(BIG_THREADS), lds, stream, g, epi);
+  return (int)hipGetLastError();
+}
+template <class P> struct IsBF16 { static constexpr bool value = false; };
+template <> struct IsBF16<PrecBF16> { static constexpr bool value = true; };
+
 template <class P>
 static int fc_forward_t(const void* x, long ldx, const void* w, long ldw, const float* bias, void* y,
                         float* y32, long ldy, void* yt, long ldyt, int batch, int out_f, int in_f,
@@ -67,6 +79,8 @@ static int fc_forward_t(const void* x, long ldx, const void* w, long ldw, const 
   e.bias = bias; e.y = (T*)y; e.y32 = y32; e.ldy = ldy; e.yt = (T*)yt; e.ldyt = ldyt;
   e.act = act; e.M = batch; e.N = out_f;
   if (out_f <= 32) return launch_gemm<P, TileNarrow, EpiForward<T>, 0>(g, e, nullptr, 0, stream);
+  if constexpr (IsBF16<P>::value)
+    if (gemm_big_ok(g)) return launch_gemm_big(g, e, stream);
   return launch_gemm<P, TileWide, EpiForward<T>, 0>(g, e, nullptr, 0, stream);
 }
 
@@ -84,6 +98,8 @@ static int fc_dgrad_t(const void* dz, long lddz, const void* wt, long ldwt, cons
   e.ht = (const T*)ht; e.ldht = ldht; e.dx = (T*)dx; e.dx32 = dx32; e.lddx = lddx;
   e.dxt = (T*)dxt; e.lddxt = lddxt; e.act = act_below; e.M = batch; e.N = in_f;
   if (in_f <= 32) return launch_gemm<P, TileNarrow, EpiDgrad<T>, 0>(g, e, nullptr, 0, stream);
+  if constexpr (IsBF16<P>::value)
+    if (gemm_big_ok(g)) return launch_gemm_big(g, e, stream);
   return launch_gemm<P, TileWide, EpiDgrad<T>, 0>(g, e, nullptr, 0, stream);
 }
 

@@ -69,16 +69,6 @@ struct MlpArgs {
 
 __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// compile-time loop: the body is instantiated once per index, so accumulator arrays indexed by it
-// stay in registers even where `#pragma unroll` gives up ("unrolled size is too large")
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
 // compile-time activation (a runtime `switch` per element would bloat the unrolled epilogues until
 // the unroller gives up and the accumulator arrays fall into scratch)
 template <int ACT> __device__ __forceinline__ float act_t(float z) { return act_apply(z, ACT); }

@@ -22,8 +22,20 @@
 // 17 KB (f32) of LDS so 3-4 workgroups fit a CU.
 #pragma once
 #include <rg_platform.h>  // resolved via -I (product: csrc/, CPU test harness: tests/emu/)
+#include <cstdint>
+#include <type_traits>
 
 namespace rg {
+
+// compile-time loop: the body is instantiated once per index, so accumulator arrays indexed by it
+// stay in registers even where `#pragma unroll` gives up ("unrolled size is too large")
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 enum { ACT_LINEAR = 0, ACT_RELU = 1, ACT_LEAKY_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_SOFTPLUS = 5 };
 
@@ -463,6 +475,122 @@ __global__ void RG_LAUNCH_BOUNDS(256, 1)
       if (col < g.N) bp[col] = accb[tn][0];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The large-shape bf16 kernel: 256 x 256 workgroup tile, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA
+// tiles), K in blocks of 32.  The 128 x 128 kernel above moves 32 KB through LDS per 2.1 MFLOP and has
+// to cross two barriers per K-slab; at 65536 x 3200 x 512 it reaches a tenth of the MFMA peak.  Here:
+//   * operands go HBM/L2 -> LDS by DMA (global_load_lds_dwordx4, no VGPR round trip) through a ring of
+//     four 32 KB stages, three in flight, one s_waitcnt vmcnt(8) + one barrier per K block;
+//   * a DMA instruction fills 1 KB of LDS linearly (lane j -> byte 16 j), so the image is unpadded,
+//     64 B per row; bank conflicts are avoided by WHAT each lane fetches: LDS slot (row, s) holds the
+//     16-byte K chunk s ^ ((row >> 1) & 3), and a fragment read of 8 consecutive rows then covers all
+//     eight 16-byte positions of a 128-byte bank line;
+//   * 6 fragment reads (6 KB) feed 8 MFMAs per wave and K step: 96 B/clk of LDS reads per CU at MFMA
+//     peak, under the 128 B/clk limit (the 64 x 64 wave tile of the small kernel needs 128).
+// Rows past M / N are clamped for the loads and masked by the epilogue; K must be a multiple of 32 and
+// the operands 16-byte aligned with leading dimensions a multiple of 8 (the caller checks).  Every
+// accumulator sees its K chunks of 16 in ascending order, exactly as in gemm_nt_kernel: the two
+// kernels give bit-identical results.
+constexpr int BIG_BM = 256, BIG_BN = 256, BIG_BK = 32, BIG_THREADS = 512;
+constexpr int BIG_STAGE_BYTES = (BIG_BM + BIG_BN) * BIG_BK * 2, BIG_SLOTS = 4, BIG_DMA_PER_THREAD = 4;
+static_assert(BIG_STAGE_BYTES == BIG_DMA_PER_THREAD * BIG_THREADS * 16, "one stage = 4 DMA requests per thread");
+
+template <class Epi>
+__global__ void RG_LAUNCH_BOUNDS(BIG_THREADS, 1) gemm_nt_big_kernel(GemmArgs g, Epi epi) {
+  RG_DYN_LDS(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_m = (g.M + BIG_BM - 1) / BIG_BM, tiles_n = (g.N + BIG_BN - 1) / BIG_BN;
+  int tile_m, tile_n;
+  decode_wg((int)blockIdx.x, tiles_m, tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BIG_BM, n0 = tile_n * BIG_BN;
+  const bf16_t* A = (const bf16_t*)g.A;
+  const bf16_t* B = (const bf16_t*)g.B;
+  const int n_blk = g.K / BIG_BK;
+
+  // this thread's four DMA sources of a stage (requests 0,1: A rows; 2,3: B rows), as row pointers
+  const bf16_t* src[BIG_DMA_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < BIG_DMA_PER_THREAD; ++i) {
+    const int v = (tid + i * BIG_THREADS) & 1023;  // slot index inside the operand's 16 KB image
+    const int row = v >> 2, chunk = (v & 3) ^ ((row >> 1) & 3);
+    if (i < 2) {
+      const int gr = m0 + row < g.M ? m0 + row : g.M - 1;
+      src[i] = A + (long)gr * g.lda + chunk * 8;
+    } else {
+      const int gr = n0 + row < g.N ? n0 + row : g.N - 1;
+      src[i] = B + (long)gr * g.ldb + chunk * 8;
+    }
+  }
+  auto issue = [&](int blk, int slot) {
+    const int kb = (blk < n_blk ? blk : n_blk - 1) * BIG_BK;  // past the end: refetch the last block (keeps vmcnt exact)
+    static_for<0, BIG_DMA_PER_THREAD>([&](auto i_c) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value;
+      global_load_lds_b128(src[i] + kb, smem + slot * BIG_STAGE_BYTES + (wave * 64 + i * BIG_THREADS) * 16);
+    });
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int lr = lane & 31, lg = lane >> 5, sw = (lr >> 1) & 3;
+  auto compute = [&](int slot) {
+    const char* As = smem + slot * BIG_STAGE_BYTES;
+    const char* Bs = As + BIG_BM * BIG_BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < BIG_BK / 16; ++ks) {
+      const int off = ((ks * 2 + lg) ^ sw) * 16;
+      u16x8 af[4], bf[2];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(As + (wm * 128 + tm * 32 + lr) * 64 + off);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) bf[tn] = *(const u16x8*)(Bs + (wn * 64 + tn * 32 + lr) * 64 + off);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
+    }
+  };
+
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  for (int t = 0; t < n_blk; ++t) {
+    RG_WAIT_VMCNT(8);  // 12 requests of this thread in flight; the oldest 4 (block t) have landed
+    raw_barrier();     // ... for every thread; and block t-1 is consumed, so its slot can be refilled
+    issue(t + 3, (t + 3) & 3);
+    compute(t & 3);
+  }
+  RG_WAIT_VMCNT(0);
+
+  // compile-time indices: with an activation switch in the epilogue body `#pragma unroll` gives up
+  // and the accumulators would be indexed at run time, i.e. live in scratch
+  static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+    static_for<0, 2>([&](auto tn_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value, tn = decltype(tn_c)::value;
+      const int col = n0 + wn * 64 + tn * 32 + lr;
+      static_for<0, 4>([&](auto rq_c) __attribute__((always_inline)) {
+        constexpr int rq = decltype(rq_c)::value;
+        const int row0 = m0 + wm * 128 + tm * 32 + 8 * rq + 4 * lg;
+        const float v[4] = {acc[tm][tn][rq * 4 + 0], acc[tm][tn][rq * 4 + 1], acc[tm][tn][rq * 4 + 2],
+                            acc[tm][tn][rq * 4 + 3]};
+        epi(row0, col, v);
+      });
+    });
+  });
+}
+
+// shapes the big kernel takes: enough tiles to fill the chip, K in whole blocks, DMA-able operands
+static inline bool gemm_big_ok(const GemmArgs& g) {
+  return g.M >= 2048 && g.N >= 192 && g.K >= 128 && (g.K % BIG_BK) == 0 && (g.lda % 8) == 0 && (g.ldb % 8) == 0 &&
+         ((((uintptr_t)g.A) | ((uintptr_t)g.B)) & 15) == 0 && g.splits <= 1;
 }
 
 }  // namespace rg

@@ -127,3 +127,46 @@ def test_transpose_cast(backend, src_dt, dst_dt):
     want = src.float().cpu().to(dst_dt)  # torch's RNE cast == v_cvt_pk_bf16_f32
     assert torch.equal(dst.cpu(), want)
     assert torch.equal(dst_t.cpu(), want.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K,act", [(2088, 200, 160, "relu"), (2304, 512, 256, "linear")])
+def test_large_bf16_shapes_take_the_dma_kernel_bit_identically(backend, M, N, K, act):
+    """bf16 forward / dgrad of large shapes run on the 256x256 LDS-DMA kernel (rg_gemm.h); a leading
+    dimension that is not a multiple of 8 elements forces the 128x128 kernel for the same data: the two
+    must agree bit for bit (every accumulator sees its K chunks in the same order) — M and N tails,
+    bias, activation, fp32 + bf16 + transposed outputs included"""
+    dev = backend.device
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(dev)
+    wide = torch.zeros(M, K + 4, dtype=torch.bfloat16)
+    wide[:, :K] = x
+    x_dev, x_odd = x.to(dev).contiguous(), wide.to(dev)[:, :K]  # same values, leading dimension K + 4
+    assert x_odd.stride(0) % 8 != 0
+    w_dev = w.to(dev).contiguous()
+    outs = []
+    for xin in (x_dev, x_odd):
+        y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        y32 = torch.zeros(M, N, device=dev)
+        yt = torch.zeros(N, M, dtype=torch.bfloat16, device=dev)
+        ops.fc_forward(xin, w_dev, bias, L.ACT[act], L.PREC_BF16, y=y, y32=y32, yt=yt)
+        outs.append((y, y32, yt))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = _act((x.double() @ w.double().t() + bias.cpu().double()).numpy(), L.ACT[act])
+    assert np.abs(outs[0][1].cpu().double().numpy() - ref).max() <= 2e-3 * (1 + np.abs(ref).max())
+    # dgrad: dx = dz . wt^T-layout, masked by act'(h) from the transposed activation copy
+    dz = (torch.randn(M, N, generator=g) / N ** 0.5).to(torch.bfloat16)
+    wt = w.t().contiguous()  # [K, N] = W^T, K-contiguous along N
+    dzw = torch.zeros(M, N + 4, dtype=torch.bfloat16)
+    dzw[:, :N] = dz
+    ht = (torch.randn(K, M, generator=g)).to(torch.bfloat16).to(dev)
+    res = []
+    for dzin in (dz.to(dev).contiguous(), dzw.to(dev)[:, :N]):
+        dx = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
+        dx32 = torch.zeros(M, K, device=dev)
+        ops.fc_dgrad(dzin, wt.to(dev), ht, L.ACT["relu"], L.PREC_BF16, dx=dx, dx32=dx32)
+        res.append((dx, dx32))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
