@@ -278,6 +278,58 @@ struct PrecF32 {
 // ---------------------------------------------------------------------------------------------
 // epilogues.  Called with 4 accumulator values = rows row0..row0+3 of column `col`.
 
+// Stores of an accumulator quad (4 consecutive rows of one column per lane; consecutive lanes hold
+// consecutive columns).  The kernels are store-ISSUE bound in their epilogues when every value is its
+// own 2-byte store (65536 x 512 bf16 out + transposed copy: 256 store instructions per lane and tile),
+// so: the transposed copy of a quad is ONE 8-byte store (its 4 rows are contiguous there), and the
+// row-major bf16 copy is paired with the neighbouring lane's column — the even lane stores rows 0 and
+// 2, the odd lane rows 1 and 3, each as one 4-byte (col, col+1) pair.  All lanes of the wave must call
+// these (the pair exchange is a cross-lane move); out-of-range lanes pass live = false.
+template <typename T>
+__device__ __forceinline__ void store_quad_transposed(T* yt, long ldyt, int row0, int col, int M, bool live,
+                                                      const float (&o)[4]) {
+  if (!yt || !live) return;
+  T* p = yt + (long)col * ldyt + row0;
+  if (sizeof(T) == 2 && row0 + 3 < M && ((((uintptr_t)p) & 7) == 0)) {
+    uint2 w;
+    w.x = pack_bf16x2(o[0], o[1]);
+    w.y = pack_bf16x2(o[2], o[3]);
+    *(uint2*)p = w;
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (row0 + e < M) p[e] = cvt_out<T>(o[e]);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_quad_rowmajor(T* y, long ldy, int row0, int col, int M, int N, bool live,
+                                                    const float (&o)[4]) {
+  if (sizeof(T) == 2) {
+    // every lane exchanges (also the ones with nothing to store): packed pairs of rows (0,1) and (2,3)
+    const unsigned mine01 = pack_bf16x2(o[0], o[1]), mine23 = pack_bf16x2(o[2], o[3]);
+    const unsigned other01 = swap_adjacent_lanes(mine01), other23 = swap_adjacent_lanes(mine23);
+    if (!y) return;
+    const int odd = col & 1;  // == lane & 1: tile columns start at multiples of 32
+    const bool pair_ok = (col | 1) < N && ((ldy & 1) == 0) && ((((uintptr_t)y) & 3) == 0);
+    if (pair_ok) {
+      if (!live) return;
+      // even lane: rows 0, 2 = low halves; odd lane: rows 1, 3 = high halves; {hi = odd column, lo = even column}
+      const unsigned sel = odd ? 0x07060302u : 0x05040100u;
+      const unsigned lo01 = odd ? other01 : mine01, hi01 = odd ? mine01 : other01;
+      const unsigned lo23 = odd ? other23 : mine23, hi23 = odd ? mine23 : other23;
+      const int r_a = row0 + odd, r_b = row0 + 2 + odd;
+      if (r_a < M) *(unsigned*)(y + (long)r_a * ldy + (col & ~1)) = perm_bytes(hi01, lo01, sel);
+      if (r_b < M) *(unsigned*)(y + (long)r_b * ldy + (col & ~1)) = perm_bytes(hi23, lo23, sel);
+      return;
+    }
+  }
+  if (!y || !live) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (row0 + e < M) y[(long)(row0 + e) * ldy + col] = cvt_out<T>(o[e]);
+}
+
 template <typename T>
 struct EpiForward {  // y = act(acc + bias); row-major and/or transposed stores
   const float* bias;
@@ -288,24 +340,18 @@ struct EpiForward {  // y = act(acc + bias); row-major and/or transposed stores
   long ldyt;
   int act, M, N;
   __device__ __forceinline__ void operator()(int row0, int col, const float (&v)[4]) const {
-    if (col >= N || row0 >= M) return;
-    const float b = bias ? bias[col] : 0.f;
+    const bool live = col < N && row0 < M;
+    const float b = (bias && live) ? bias[col] : 0.f;
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] + b, act);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (row0 + e < M) {
-        if (y32) y32[(long)(row0 + e) * ldy + col] = o[e];
-        if (y) y[(long)(row0 + e) * ldy + col] = cvt_out<T>(o[e]);
-      }
-    }
-    if (yt) {
-      T* p = yt + (long)col * ldyt + row0;
+    if (y32 && live) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (row0 + e < M) p[e] = cvt_out<T>(o[e]);
+        if (row0 + e < M) y32[(long)(row0 + e) * ldy + col] = o[e];
     }
+    store_quad_rowmajor<T>(y, ldy, row0, col, M, N, live, o);
+    store_quad_transposed<T>(yt, ldyt, row0, col, M, live, o);
   }
 };
 
@@ -320,27 +366,21 @@ struct EpiDgrad {  // dz_prev = acc * act'(h_prev); row-major and/or transposed 
   long lddxt;
   int act, M, N;
   __device__ __forceinline__ void operator()(int row0, int col, const float (&v)[4]) const {
-    if (col >= N || row0 >= M) return;
+    const bool live = col < N && row0 < M;
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float g = 1.f;
-      if (ht && row0 + e < M) g = act_grad_from_output(cvt_in(ht[(long)col * ldht + row0 + e]), act);
+      if (ht && live && row0 + e < M) g = act_grad_from_output(cvt_in(ht[(long)col * ldht + row0 + e]), act);
       o[e] = v[e] * g;
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (row0 + e < M) {
-        if (dx32) dx32[(long)(row0 + e) * lddx + col] = o[e];
-        if (dx) dx[(long)(row0 + e) * lddx + col] = cvt_out<T>(o[e]);
-      }
-    }
-    if (dxt) {
-      T* p = dxt + (long)col * lddxt + row0;
+    if (dx32 && live) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (row0 + e < M) p[e] = cvt_out<T>(o[e]);
+        if (row0 + e < M) dx32[(long)(row0 + e) * lddx + col] = o[e];
     }
+    store_quad_rowmajor<T>(dx, lddx, row0, col, M, N, live, o);
+    store_quad_transposed<T>(dxt, lddxt, row0, col, M, live, o);
   }
 };
 
@@ -587,9 +627,16 @@ __global__ void RG_LAUNCH_BOUNDS(BIG_THREADS, 1) gemm_nt_big_kernel(GemmArgs g, 
   });
 }
 
-// shapes the big kernel takes: enough tiles to fill the chip, K in whole blocks, DMA-able operands
+// Shapes the big kernel takes: enough tiles to fill the chip, K in whole blocks, DMA-able operands —
+// and a LONG reduction.  Measured on MI355X (profiles/microbench/gemm_shapes.py, M = 65536, bf16 out):
+// N=512 K=3200 297 us = 0.72 PFLOP/s, but N=512 K=512 127 us and N=3200 K=512 723 us = 0.27-0.30
+// PFLOP/s: with 16 K blocks per tile the launch is bound by the epilogue's store issue (one workgroup
+// per CU, nothing to overlap it with), and inside the QR-DQN step those two shapes ran SLOWER than on
+// the 128 x 128 kernel (0.18 vs 0.14 ms, 0.98 vs 0.89 ms), whose 3-4 resident workgroups overlap each
+// other's epilogues.  Until the epilogue goes through LDS (16-byte row stores) the kernel is used for
+// K >= 1024 only.
 static inline bool gemm_big_ok(const GemmArgs& g) {
-  return g.M >= 2048 && g.N >= 192 && g.K >= 128 && (g.K % BIG_BK) == 0 && (g.lda % 8) == 0 && (g.ldb % 8) == 0 &&
+  return g.M >= 2048 && g.N >= 192 && g.K >= 1024 && (g.K % BIG_BK) == 0 && (g.lda % 8) == 0 && (g.ldb % 8) == 0 &&
          ((((uintptr_t)g.A) | ((uintptr_t)g.B)) & 15) == 0 && g.splits <= 1;
 }
 

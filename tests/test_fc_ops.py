@@ -129,8 +129,10 @@ def test_transpose_cast(backend, src_dt, dst_dt):
     assert torch.equal(dst_t.cpu(), want.t().contiguous())
 
 
-@pytest.mark.parametrize("M,N,K,act", [(2088, 200, 160, "relu"), (2304, 512, 256, "linear")])
+@pytest.mark.parametrize("M,N,K,act", [(2088, 200, 1024, "relu"), (2304, 1024, 1056, "linear")])
 def test_large_bf16_shapes_take_the_dma_kernel_bit_identically(backend, M, N, K, act):
+    if backend.name == "emu" and N > 256:
+        pytest.skip("the interpreter runs the smaller case only (this one is ~2.5e9 MACs)")
     """bf16 forward / dgrad of large shapes run on the 256x256 LDS-DMA kernel (rg_gemm.h); a leading
     dimension that is not a multiple of 8 elements forces the 128x128 kernel for the same data: the two
     must agree bit for bit (every accumulator sees its K chunks in the same order) — M and N tails,
@@ -156,6 +158,8 @@ def test_large_bf16_shapes_take_the_dma_kernel_bit_identically(backend, M, N, K,
         assert torch.equal(a, b)
     ref = _act((x.double() @ w.double().t() + bias.cpu().double()).numpy(), L.ACT[act])
     assert np.abs(outs[0][1].cpu().double().numpy() - ref).max() <= 2e-3 * (1 + np.abs(ref).max())
+    if backend.name == "emu":
+        return  # forward covers the kernel on the interpreter; dgrad shares everything but the epilogue functor
     # dgrad: dx = dz . wt^T-layout, masked by act'(h) from the transposed activation copy
     dz = (torch.randn(M, N, generator=g) / N ** 0.5).to(torch.bfloat16)
     wt = w.t().contiguous()  # [K, N] = W^T, K-contiguous along N
