@@ -483,19 +483,21 @@ __global__ void RG_LAUNCH_BOUNDS(256, 1)
 
   epi_set_split(epi, split);
   const int lr = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn) {
+  // compile-time indices (see gemm_nt_big_kernel): a `#pragma unroll` that gives up on a heavy epilogue
+  // body leaves the accumulators indexed at run time, i.e. in scratch
+  static_for<0, C::TM>([&](auto tm_c) __attribute__((always_inline)) {
+    static_for<0, C::TN>([&](auto tn_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value, tn = decltype(tn_c)::value;
       const int col = n0 + wn * (C::TN * 32) + tn * 32 + lr;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
+      static_for<0, 4>([&](auto rq_c) __attribute__((always_inline)) {
+        constexpr int rq = decltype(rq_c)::value;
         const int row0 = m0 + wm * (C::TM * 32) + tm * 32 + 8 * rq + 4 * lh;
         const float v[4] = {acc[tm][tn][rq * 4 + 0], acc[tm][tn][rq * 4 + 1], acc[tm][tn][rq * 4 + 2],
                             acc[tm][tn][rq * 4 + 3]};
         epi(row0, col, v);
-      }
-    }
+      });
+    });
+  });
 
   if (BIAS_MODE == 1 && do_bias && lr == 0) {  // D[i][0] = sum_k A[i][k]
     float* bp = bias_partials + (long)split * bias_slab;
