@@ -1010,6 +1010,134 @@ __global__ void mlp_update_kernel(UpdateArgs U) {
   }
 }
 
+// Tiled form of the update for weight matrices whose rows can be read in 32-byte pieces (in_features a
+// multiple of 8, slab offset a multiple of 4): a workgroup owns a 32 (out) x 64 (in) tile, every thread
+// eight consecutive in-features of one row.  Against one element per thread this turns
+//   * the fp32 traffic (p, g, m, v, target) into float4 requests,
+//   * the forward fragments (online and target) into ONE 16-byte store per thread (the 8 values are a
+//     fragment record), and
+//   * the backward fragments (W^T: 8 consecutive OUT-features of one in-feature are a record) into one
+//     16-byte store per thread after a transpose through LDS, instead of 2-byte stores 16 bytes apart.
+// The arithmetic is adam_element / soft_update_element on the same values: bit-identical results.
+constexpr int UT_ROWS = 32, UT_COLS = 64, UT_PITCH = UT_COLS + 2;  // pitch: 33 dwords, conflict-free columns
+
+struct UpdateTileArgs {
+  UpdateArgs u;
+  int tile_begin[FB_MAXL + 1];  // first workgroup of each layer's tiles; [n] = first "rest" workgroup
+  int tiled[FB_MAXL];           // layer's weight handled by tiles
+  long rest_begin[2 * FB_MAXL + 1];  // prefix sums of the element ranges left to the per-element path
+};
+
+__device__ __forceinline__ void update_one(const UpdateArgs& U, long i, float& pn, float& tn) {
+  float mi = U.m[i], vi = U.v[i];
+  pn = adam_element(U.c, U.p[i], U.g[i], mi, vi);
+  U.p[i] = pn;
+  U.m[i] = mi;
+  U.v[i] = vi;
+  tn = 0.f;
+  if (U.t) {
+    tn = soft_update_element(U.tau, U.one_minus_tau, pn, U.t[i]);
+    U.t[i] = tn;
+  }
+}
+
+__global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
+  const UpdateArgs& U = T.u;
+  __shared__ bf16_t tile[UT_ROWS * UT_PITCH];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  if (wg >= T.tile_begin[U.n]) {
+    // everything the tiles do not cover (biases; weights with odd shapes): one element per thread
+    const long j = (long)(wg - T.tile_begin[U.n]) * blockDim.x + tid;
+    int r = -1;
+    for (int q = 0; q < 2 * U.n; ++q)
+      if (j >= T.rest_begin[q] && j < T.rest_begin[q + 1]) r = q;
+    if (r < 0) return;
+    const int l = r >> 1, is_w = r & 1;
+    const long rel = j - T.rest_begin[r];
+    float pn, tn;
+    update_one(U, (is_w ? U.w_off[l] : U.b_off[l]) + rel, pn, tn);
+    if (!is_w) return;
+    const int N = U.N[l], K = U.K[l];
+    const int n = (int)(rel / K), k = (int)(rel % K);
+    const int KCf = (K + 15) / 16, KCb = (N + 15) / 16;
+    const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+    if (U.wf[l]) U.wf[l][jf] = f32_to_bf16(pn);
+    if (U.twf[l]) U.twf[l][jf] = f32_to_bf16(tn);
+    if (U.wb[l]) {
+      const long jb = ((((long)(k >> 5) * KCb + (n >> 4)) * 64) + ((k & 31) + 32 * ((n & 15) >> 3))) * 8 + (n & 7);
+      U.wb[l][jb] = f32_to_bf16(pn);
+    }
+    return;
+  }
+  int l = 0;
+  for (int q = 1; q < U.n; ++q)
+    if (wg >= T.tile_begin[q]) l = q;
+  const int N = U.N[l], K = U.K[l];
+  const int tiles_k = (K + UT_COLS - 1) / UT_COLS;
+  const int tw = wg - T.tile_begin[l];
+  const int n0 = (tw / tiles_k) * UT_ROWS, k0 = (tw % tiles_k) * UT_COLS;
+  const int r = tid >> 3, c = (tid & 7) * 8;  // row of the tile, first of this thread's 8 in-features
+  const int n = n0 + r, k = k0 + c;
+  const bool live = n < N && k < K;  // K % 8 == 0: a piece is entirely inside or outside
+  float pn[8], tn[8];
+  if (live) {
+    const long i = U.w_off[l] + (long)n * K + k;
+    f32x4 P[2], G[2], M[2], V[2], Tg[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      P[h] = *(const f32x4*)(U.p + i + 4 * h);
+      G[h] = *(const f32x4*)(U.g + i + 4 * h);
+      M[h] = *(const f32x4*)(U.m + i + 4 * h);
+      V[h] = *(const f32x4*)(U.v + i + 4 * h);
+      if (U.t) Tg[h] = *(const f32x4*)(U.t + i + 4 * h);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float mi = M[h][e], vi = V[h][e];
+        pn[4 * h + e] = adam_element(U.c, P[h][e], G[h][e], mi, vi);
+        P[h][e] = pn[4 * h + e];
+        M[h][e] = mi;
+        V[h][e] = vi;
+        tn[4 * h + e] = 0.f;
+        if (U.t) {
+          tn[4 * h + e] = soft_update_element(U.tau, U.one_minus_tau, pn[4 * h + e], Tg[h][e]);
+          Tg[h][e] = tn[4 * h + e];
+        }
+      }
+      *(f32x4*)(U.p + i + 4 * h) = P[h];
+      *(f32x4*)(U.m + i + 4 * h) = M[h];
+      *(f32x4*)(U.v + i + 4 * h) = V[h];
+      if (U.t) *(f32x4*)(U.t + i + 4 * h) = Tg[h];
+    }
+    const int KCf = (K + 15) / 16;
+    const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8;
+    if (U.wf[l])
+      *(u32x4*)(U.wf[l] + jf) = u32x4{pack_bf16x2(pn[0], pn[1]), pack_bf16x2(pn[2], pn[3]), pack_bf16x2(pn[4], pn[5]),
+                                      pack_bf16x2(pn[6], pn[7])};
+    if (U.twf[l])
+      *(u32x4*)(U.twf[l] + jf) = u32x4{pack_bf16x2(tn[0], tn[1]), pack_bf16x2(tn[2], tn[3]), pack_bf16x2(tn[4], tn[5]),
+                                       pack_bf16x2(tn[6], tn[7])};
+  }
+  if (!U.wb[l]) return;  // workgroup-uniform
+#pragma unroll
+  for (int e = 0; e < 8; ++e) tile[r * UT_PITCH + c + e] = live ? f32_to_bf16(pn[e]) : (bf16_t)0;
+  __syncthreads();
+  // W^T fragments: thread -> (in-feature kk, group of 8 out-features); a record = 8 consecutive n
+  const int kk = tid & 63, ng = tid >> 6;
+  const int kt = k0 + kk, nt = n0 + ng * 8;
+  if (kt < K && nt < N) {  // N may end inside a record: those slots are padding and stay zero-written
+    unsigned short h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (nt + e < N) ? tile[(ng * 8 + e) * UT_PITCH + kk] : (bf16_t)0;
+    const int KCb = (N + 15) / 16;
+    const long jb = ((((long)(kt >> 5) * KCb + (nt >> 4)) * 64) + ((kt & 31) + 32 * ((nt & 15) >> 3))) * 8;
+    *(u32x4*)(U.wb[l] + jb) = u32x4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+                                    (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+  }
+}
+
 static int fused_supported(const rg_mlp_desc* d) {
   if (!d || d->n_layers < 2 || d->n_layers > FB_MAXL) return 0;
   const int H = d->dims[1];
@@ -1345,7 +1473,43 @@ int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, do
   U.c = AdamCoef{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
                  (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale};
   U.tau = (float)tau; U.one_minus_tau = (float)(1.0 - tau);
-  RG_LAUNCH(mlp_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (hipStream_t)stream, U);
+  // weights with 32-byte-addressable rows go to the tiled kernel, the rest of the slab to its
+  // per-element workgroups (same launch)
+  UpdateTileArgs T;
+  T.u = U;
+  int wgs = 0, any_tiled = 0;
+  long rest = 0;
+  for (int l = 0; l < FB_MAXL; ++l) {
+    T.tile_begin[l] = wgs;
+    T.tiled[l] = 0;
+    if (l < d->n_layers) {
+      const int K = U.K[l], N = U.N[l];
+      const bool ok = (K % 8) == 0 && (U.w_off[l] % 4) == 0 && ((((uintptr_t)U.p | (uintptr_t)U.g | (uintptr_t)U.m |
+                                                                  (uintptr_t)U.v | (uintptr_t)U.t) & 15) == 0) &&
+                      ((((uintptr_t)U.wf[l] | (uintptr_t)U.wb[l] | (uintptr_t)U.twf[l]) & 15) == 0);
+      if (ok) {
+        T.tiled[l] = 1;
+        any_tiled = 1;
+        wgs += ((N + UT_ROWS - 1) / UT_ROWS) * ((K + UT_COLS - 1) / UT_COLS);
+      }
+      T.rest_begin[2 * l] = rest;
+      rest += N;  // bias
+      T.rest_begin[2 * l + 1] = rest;
+      if (!ok) rest += (long)N * K;
+    } else {
+      T.rest_begin[2 * l] = T.rest_begin[2 * l + 1] = rest;
+    }
+  }
+  T.tile_begin[FB_MAXL] = wgs;
+  for (int l = d->n_layers; l <= FB_MAXL; ++l) T.tile_begin[l] = wgs;
+  T.rest_begin[2 * FB_MAXL] = rest;
+  for (int q = 2 * d->n_layers; q <= 2 * FB_MAXL; ++q) T.rest_begin[q] = rest;
+  if (!any_tiled) {
+    RG_LAUNCH(mlp_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (hipStream_t)stream, U);
+    return (int)hipGetLastError();
+  }
+  const int rest_wgs = (int)((rest + 255) / 256);
+  RG_LAUNCH(mlp_update_tiles_kernel, dim3((unsigned)(wgs + rest_wgs)), dim3(256), (hipStream_t)stream, T);
   return (int)hipGetLastError();
 }
 

@@ -207,7 +207,8 @@ def test_dqn_cpe_native_step(backend, name):
         _check_cpe_step(tr, g, s, [loss.item(), tr._cpe.losses["reward"].item(), tr._cpe.losses["cpe"].item()])
 
 
-def test_fused_update_equals_separate_launches(backend):
+@pytest.mark.parametrize("state_dim", [24, 22])  # 22: the first layer's rows are not 32-byte pieces -> per-element path
+def test_fused_update_equals_separate_launches(backend, state_dim):
     """rg_mlp_update_fused (Adam + soft update + bf16 re-staging of both networks in one launch, taken by
     the native step when both stacks are on the fused kernels) leaves the same bits as the four separate
     launches: parameters, target parameters, Adam moments, and the next step's Q-values (= the staged
@@ -218,7 +219,7 @@ def test_fused_update_equals_separate_launches(backend):
         set_default_precision(L.PREC_BF16)
         try:
             torch.manual_seed(3)
-            q = FullyConnectedDQN(24, 5, [256, 256], ["relu", "relu"]).to(backend.device)
+            q = FullyConnectedDQN(state_dim, 5, [256, 256], ["relu", "relu"]).to(backend.device)
         finally:
             set_default_precision(L.PREC_F32)
         return DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(5)],
@@ -229,7 +230,7 @@ def test_fused_update_equals_separate_launches(backend):
     fused, separate = make(), make()
     separate._fused_plan = False
     for s in range(3):
-        batch = synthetic.to_dqn_input(synthetic.dqn_batch(200, 24, 5, seed=40 + s, p_impossible=0.2), backend.device)
+        batch = synthetic.to_dqn_input(synthetic.dqn_batch(200, state_dim, 5, seed=40 + s, p_impossible=0.2), backend.device)
         la, lb = fused.train_step_native(batch), separate.train_step_native(batch)
         assert torch.equal(la, lb), s
         assert torch.equal(fused.all_action_scores, separate.all_action_scores), s
