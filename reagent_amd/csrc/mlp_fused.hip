@@ -1011,15 +1011,15 @@ __global__ void mlp_update_kernel(UpdateArgs U) {
 }
 
 // Tiled form of the update for weight matrices whose rows can be read in 32-byte pieces (in_features a
-// multiple of 8, slab offset a multiple of 4): a workgroup owns a 32 (out) x 64 (in) tile, every thread
-// eight consecutive in-features of one row.  Against one element per thread this turns
+// multiple of 8, slab offset a multiple of 4): a workgroup owns a 32 (out) x 32 (in) tile, every thread
+// four consecutive in-features of one row.  Against one element per thread this turns
 //   * the fp32 traffic (p, g, m, v, target) into float4 requests,
-//   * the forward fragments (online and target) into ONE 16-byte store per thread (the 8 values are a
-//     fragment record), and
+//   * the forward fragments (online and target) into one 8-byte store per thread (half a fragment
+//     record), and
 //   * the backward fragments (W^T: 8 consecutive OUT-features of one in-feature are a record) into one
 //     16-byte store per thread after a transpose through LDS, instead of 2-byte stores 16 bytes apart.
 // The arithmetic is adam_element / soft_update_element on the same values: bit-identical results.
-constexpr int UT_ROWS = 32, UT_COLS = 64, UT_PITCH = UT_COLS + 2;  // pitch: 33 dwords, conflict-free columns
+constexpr int UT_ROWS = 32, UT_COLS = 32, UT_PITCH = UT_COLS + 2;  // pitch: 17 dwords, conflict-free columns
 
 struct UpdateTileArgs {
   UpdateArgs u;
@@ -1076,58 +1076,44 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
   const int tiles_k = (K + UT_COLS - 1) / UT_COLS;
   const int tw = wg - T.tile_begin[l];
   const int n0 = (tw / tiles_k) * UT_ROWS, k0 = (tw % tiles_k) * UT_COLS;
-  const int r = tid >> 3, c = (tid & 7) * 8;  // row of the tile, first of this thread's 8 in-features
+  const int r = tid >> 3, c = (tid & 7) * 4;  // row of the tile, first of this thread's 4 in-features
   const int n = n0 + r, k = k0 + c;
   const bool live = n < N && k < K;  // K % 8 == 0: a piece is entirely inside or outside
-  float pn[8], tn[8];
+  float pn[4], tn[4];
   if (live) {
     const long i = U.w_off[l] + (long)n * K + k;
-    f32x4 P[2], G[2], M[2], V[2], Tg[2];
+    f32x4 P = *(const f32x4*)(U.p + i), G = *(const f32x4*)(U.g + i), M = *(const f32x4*)(U.m + i);
+    f32x4 V = *(const f32x4*)(U.v + i), Tg = U.t ? *(const f32x4*)(U.t + i) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      P[h] = *(const f32x4*)(U.p + i + 4 * h);
-      G[h] = *(const f32x4*)(U.g + i + 4 * h);
-      M[h] = *(const f32x4*)(U.m + i + 4 * h);
-      V[h] = *(const f32x4*)(U.v + i + 4 * h);
-      if (U.t) Tg[h] = *(const f32x4*)(U.t + i + 4 * h);
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float mi = M[h][e], vi = V[h][e];
-        pn[4 * h + e] = adam_element(U.c, P[h][e], G[h][e], mi, vi);
-        P[h][e] = pn[4 * h + e];
-        M[h][e] = mi;
-        V[h][e] = vi;
-        tn[4 * h + e] = 0.f;
-        if (U.t) {
-          tn[4 * h + e] = soft_update_element(U.tau, U.one_minus_tau, pn[4 * h + e], Tg[h][e]);
-          Tg[h][e] = tn[4 * h + e];
-        }
+    for (int e = 0; e < 4; ++e) {
+      float mi = M[e], vi = V[e];
+      pn[e] = adam_element(U.c, P[e], G[e], mi, vi);
+      P[e] = pn[e];
+      M[e] = mi;
+      V[e] = vi;
+      tn[e] = 0.f;
+      if (U.t) {
+        tn[e] = soft_update_element(U.tau, U.one_minus_tau, pn[e], Tg[e]);
+        Tg[e] = tn[e];
       }
-      *(f32x4*)(U.p + i + 4 * h) = P[h];
-      *(f32x4*)(U.m + i + 4 * h) = M[h];
-      *(f32x4*)(U.v + i + 4 * h) = V[h];
-      if (U.t) *(f32x4*)(U.t + i + 4 * h) = Tg[h];
     }
+    *(f32x4*)(U.p + i) = P;
+    *(f32x4*)(U.m + i) = M;
+    *(f32x4*)(U.v + i) = V;
+    if (U.t) *(f32x4*)(U.t + i) = Tg;
     const int KCf = (K + 15) / 16;
-    const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8;
-    if (U.wf[l])
-      *(u32x4*)(U.wf[l] + jf) = u32x4{pack_bf16x2(pn[0], pn[1]), pack_bf16x2(pn[2], pn[3]), pack_bf16x2(pn[4], pn[5]),
-                                      pack_bf16x2(pn[6], pn[7])};
-    if (U.twf[l])
-      *(u32x4*)(U.twf[l] + jf) = u32x4{pack_bf16x2(tn[0], tn[1]), pack_bf16x2(tn[2], tn[3]), pack_bf16x2(tn[4], tn[5]),
-                                       pack_bf16x2(tn[6], tn[7])};
+    const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+    if (U.wf[l]) *(uint2*)(U.wf[l] + jf) = uint2{pack_bf16x2(pn[0], pn[1]), pack_bf16x2(pn[2], pn[3])};
+    if (U.twf[l]) *(uint2*)(U.twf[l] + jf) = uint2{pack_bf16x2(tn[0], tn[1]), pack_bf16x2(tn[2], tn[3])};
   }
   if (!U.wb[l]) return;  // workgroup-uniform
 #pragma unroll
-  for (int e = 0; e < 8; ++e) tile[r * UT_PITCH + c + e] = live ? f32_to_bf16(pn[e]) : (bf16_t)0;
+  for (int e = 0; e < 4; ++e) tile[r * UT_PITCH + c + e] = live ? f32_to_bf16(pn[e]) : (bf16_t)0;
   __syncthreads();
   // W^T fragments: thread -> (in-feature kk, group of 8 out-features); a record = 8 consecutive n
-  const int kk = tid & 63, ng = tid >> 6;
+  const int kk = tid & 31, ng = tid >> 5;
   const int kt = k0 + kk, nt = n0 + ng * 8;
-  if (kt < K && nt < N) {  // N may end inside a record: those slots are padding and stay zero-written
+  if (ng < UT_ROWS / 8 && kt < K && nt < N) {  // N may end inside a record: those slots are padding and stay zero-written
     unsigned short h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = (nt + e < N) ? tile[(ng * 8 + e) * UT_PITCH + kk] : (bf16_t)0;
