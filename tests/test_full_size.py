@@ -143,3 +143,68 @@ def test_training_step_is_deterministic_and_learns_at_full_size():
     l2, p2 = run()
     assert torch.equal(l1, l2) and all(torch.equal(a, b) for a, b in zip(p1, p2))  # no atomics on the value path
     assert l1[-1] < l1[0] and torch.isfinite(l1).all()
+
+
+@pytest.mark.parametrize("horizon", [1, 3])
+def test_one_launch_sampler_equals_three_launches_at_full_size(horizon):
+    """rg_replay_dqn_batch (n-step + both state gathers + normalization + input maker) against
+    rg_replay_nstep + rg_replay_gather + rg_make_dqn_input on 65 536 indices of the 2^20-row store"""
+    from reagent_amd.core.parameters import NormalizationParameters as NP
+    from reagent_amd.preprocessing import DiscreteDqnInputMaker, Preprocessor
+
+    dev = torch.device("cuda")
+    rb, cols = _buffer(dev, horizon=horizon)
+    g = torch.Generator().manual_seed(4)
+    pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=float(torch.randn(1, generator=g)),
+                              stddev=float(0.5 + 1.5 * torch.rand(1, generator=g))) for i in range(S)}, device=dev)
+    idx = torch.randint(C, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    fused = rb.sample_dqn_input(A, B, indices=idx, state_preprocessor=pre, state_dtype=torch.bfloat16)
+    assert fused is not None
+    ref = DiscreteDqnInputMaker(A)(rb.sample_transition_batch(B, indices=idx, state_preprocessor=pre,
+                                                               state_dtype=torch.bfloat16))
+    for name in ("action", "next_action", "reward", "not_terminal", "possible_actions_mask", "possible_next_actions_mask"):
+        assert torch.equal(getattr(fused, name), getattr(ref, name)), name
+    assert torch.equal(fused.state.float_features, ref.state.float_features)
+    assert torch.equal(fused.next_state.float_features, ref.next_state.float_features)
+    assert torch.equal(fused.extras.action_probability, ref.extras.action_probability)
+    # and the state rows are the preprocessor applied to an index_select
+    ones = torch.ones(B, S, dtype=torch.uint8, device=dev)
+    assert torch.equal(fused.state.float_features, pre(cols["observation"][idx], ones).to(torch.bfloat16))
+
+
+def test_offline_table_batch_at_full_size():
+    """rg_table_dqn_batch on a 2^20-row table: normalised rows == Preprocessor(index_select rows, presence),
+    one-hots / not_terminal / pass-through columns from their definitions (batch_preprocessor.py:35-66)"""
+    from reagent_amd.core.parameters import NormalizationParameters as NP
+    from reagent_amd.data import OfflineTable
+    from reagent_amd.preprocessing import DiscreteDqnBatchPreprocessor, Preprocessor
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(6)
+    cols = dict(
+        state_features=torch.randn(C, S, device=dev, generator=g), next_state_features=torch.randn(C, S, device=dev, generator=g),
+        state_features_presence=torch.rand(C, S, device=dev, generator=g) > 0.05,
+        next_state_features_presence=torch.rand(C, S, device=dev, generator=g) > 0.05,
+        action=torch.randint(A, (C,), device=dev, generator=g), next_action=torch.randint(A + 1, (C,), device=dev, generator=g),
+        reward=torch.randn(C, device=dev, generator=g), action_probability=torch.rand(C, device=dev, generator=g),
+        time_diff=torch.randint(1, 5, (C,), device=dev, generator=g), step=torch.randint(1, 4, (C,), device=dev, generator=g),
+        mdp_id=torch.arange(C, device=dev), sequence_number=torch.arange(C, device=dev) % 7,
+        possible_actions_mask=(torch.rand(C, A, device=dev, generator=g) > 0.1).to(torch.uint8),
+        possible_next_actions_mask=(torch.rand(C, A, device=dev, generator=g) > 0.3).to(torch.uint8))
+    table = OfflineTable(cols, A, device=dev)
+    cpu = torch.Generator().manual_seed(7)
+    pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=float(torch.randn(1, generator=cpu)),
+                              stddev=float(0.5 + 1.5 * torch.rand(1, generator=cpu))) for i in range(S)}, device=dev)
+    idx = torch.randint(C, (B,), device=dev, generator=g)
+    out = DiscreteDqnBatchPreprocessor(A, pre).from_table(table, idx)
+    t = table.columns
+    assert torch.equal(out.state.float_features, pre(t["state_features"][idx], t["state_features_presence"][idx]))
+    assert torch.equal(out.next_state.float_features,
+                       pre(t["next_state_features"][idx], t["next_state_features_presence"][idx]))
+    assert torch.equal(out.action, torch.nn.functional.one_hot(t["action"][idx], A).float())
+    assert torch.equal(out.next_action, torch.nn.functional.one_hot(t["next_action"][idx], A + 1)[:, :A].float())
+    assert torch.equal(out.not_terminal, t["possible_next_actions_mask"][idx].max(dim=1)[0].float().unsqueeze(1))
+    assert torch.equal(out.reward, t["reward"][idx].unsqueeze(1))
+    assert torch.equal(out.step, t["step"][idx].float().unsqueeze(1))
+    assert torch.equal(out.extras.mdp_id, t["mdp_id"][idx].unsqueeze(1))
+    assert torch.equal(out.possible_actions_mask, t["possible_actions_mask"][idx].float())
