@@ -478,6 +478,45 @@ def gen_offline_table():
     _save("offline_table", dict(norm=_norm_cfg(norm), sorted_features=feats, num_actions=A), arrays)
 
 
+def gen_policy_batch():
+    """PolicyNetworkBatchPreprocessor.forward of the reference (batch_preprocessor.py:110-166): every
+    feature type on the state side, CONTINUOUS_ACTION features on the action side, missing features"""
+    rh._install()
+    from reagent.core.parameters import NormalizationParameters as NP
+    from reagent.preprocessing.batch_preprocessor import PolicyNetworkBatchPreprocessor
+    from reagent.preprocessing.preprocessor import Preprocessor
+
+    norm = _all_types_norm()
+    act_norm = {i: NP(feature_type="CONTINUOUS_ACTION", min_value=-1.0 - i, max_value=2.0 + 0.5 * i) for i in range(3)}
+    pre, apre = Preprocessor(norm, device=torch.device("cpu")), Preprocessor(act_norm, device=torch.device("cpu"))
+    feats = pre.sorted_features
+    B = 200
+    g = torch.Generator().manual_seed(21)
+    batch = {}
+    for pfx in ("state", "next_state"):
+        batch[f"{pfx}_features"] = torch.stack(_feature_columns(norm, feats, B, g), dim=1)
+        batch[f"{pfx}_features_presence"] = torch.rand(B, len(feats), generator=g) > 0.15
+    for pfx in ("action", "next_action"):
+        batch[pfx] = torch.rand(B, 3, generator=g) * 5 - 2
+        batch[f"{pfx}_presence"] = torch.rand(B, 3, generator=g) > 0.1
+    batch["reward"] = torch.randn(B, generator=g)
+    batch["time_diff"] = torch.randint(1, 6, (B,), generator=g)
+    batch["step"] = torch.randint(1, 4, (B,), generator=g)
+    batch["not_terminal"] = torch.rand(B, generator=g) > 0.2
+    batch["mdp_id"] = torch.randint(0, 1 << 40, (B,), generator=g)
+    batch["sequence_number"] = torch.randint(0, 1000, (B,), generator=g)
+    batch["action_probability"] = torch.rand(B, generator=g) * 0.9 + 0.1
+    out = PolicyNetworkBatchPreprocessor(pre, apre, use_gpu=False)(batch)
+    arrays = {f"in_{k}": _np(v) for k, v in batch.items()}
+    for k in ("state", "next_state", "action", "next_action"):
+        arrays[f"out_{k}"] = _np(getattr(out, k).float_features)
+    for k in ("reward", "time_diff", "step", "not_terminal"):
+        arrays[f"out_{k}"] = _np(getattr(out, k))
+    for k in ("mdp_id", "sequence_number", "action_probability"):
+        arrays[f"out_{k}"] = _np(getattr(out.extras, k))
+    _save("policy_batch", dict(norm=_norm_cfg(norm), action_norm=_norm_cfg(act_norm), sorted_features=feats), arrays)
+
+
 def gen_sum_tree():
     """reference SumTree (sum_tree.py) driven by seeded numpy / `random`: tree contents after a stream
     of sets, descents for fixed query values, seeded stratified samples."""
@@ -574,6 +613,7 @@ def main():
         gen_crr(n, c)
     gen_preprocessor()
     gen_offline_table()
+    gen_policy_batch()
     gen_sum_tree()
     gen_prioritized()
 

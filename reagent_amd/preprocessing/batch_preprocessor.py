@@ -72,3 +72,32 @@ class DiscreteDqnBatchPreprocessor(BatchPreprocessor):
             extras=rlt.ExtraData(mdp_id=out["mdp_id"], sequence_number=out["sequence_number"],
                                  action_probability=out["action_probability"]),
         )
+
+
+class PolicyNetworkBatchPreprocessor(BatchPreprocessor):
+    """batch_preprocessor.py:110-166 (continuous actions: SAC / TD3 on an offline table): the state and
+    action preprocessors (rg_normalize_dense, four launches) over the reader's dict; the scalar columns
+    are handed on as the reference does (`unsqueeze(1)`), moved to the device."""
+
+    def __init__(self, state_preprocessor: Preprocessor, action_preprocessor: Preprocessor, use_gpu: bool = True,
+                 device: Optional[torch.device] = None) -> None:
+        super().__init__()
+        self.state_preprocessor = state_preprocessor
+        self.action_preprocessor = action_preprocessor
+        self.device = torch.device(device) if device is not None else state_preprocessor.device
+
+    @torch.no_grad()
+    def forward(self, batch: Dict[str, torch.Tensor]) -> rlt.PolicyNetworkInput:
+        batch = batch_to_device(batch, self.device)
+        sp, ap = self.state_preprocessor, self.action_preprocessor
+        return rlt.PolicyNetworkInput(
+            state=rlt.FeatureData(sp(batch["state_features"], batch["state_features_presence"])),
+            next_state=rlt.FeatureData(sp(batch["next_state_features"], batch["next_state_features_presence"])),
+            action=rlt.FeatureData(ap(batch["action"], batch["action_presence"])),
+            next_action=rlt.FeatureData(ap(batch["next_action"], batch["next_action_presence"])),
+            reward=batch["reward"].unsqueeze(1), time_diff=batch["time_diff"].unsqueeze(1),
+            step=batch["step"].unsqueeze(1), not_terminal=batch["not_terminal"].unsqueeze(1),
+            extras=rlt.ExtraData(mdp_id=batch["mdp_id"].unsqueeze(1),
+                                 sequence_number=batch["sequence_number"].unsqueeze(1),
+                                 action_probability=batch["action_probability"].unsqueeze(1)),
+        )

@@ -208,3 +208,25 @@ def test_four_wide_path_equals_normalize_dense(backend, layout):
         assert torch.equal(got, ref), name
     o16 = DiscreteDqnBatchPreprocessor(A, pre, state_dtype=torch.bfloat16).from_table(table, idx)
     assert torch.equal(o16.state.float_features, out.state.float_features.to(torch.bfloat16))
+
+
+def test_policy_network_batch_preprocessor_matches_reference(backend):
+    """PolicyNetworkBatchPreprocessor (continuous actions) against the reference class's output
+    (tests/golden/policy_batch.npz): features 1e-5, every other field exact in value and shape"""
+    from reagent_amd.preprocessing import PolicyNetworkBatchPreprocessor
+
+    g = Golden("policy_batch")
+    dev = backend.device
+    pre = Preprocessor({int(k): SimpleNamespace(**v) for k, v in g.cfg["norm"].items()}, device=dev)
+    apre = Preprocessor({int(k): SimpleNamespace(**v) for k, v in g.cfg["action_norm"].items()}, device=dev)
+    batch = {k[len("in_"):]: g.t(k) for k in g.z.files if k.startswith("in_")}
+    out = PolicyNetworkBatchPreprocessor(pre, apre)(batch)
+    for k in ("state", "next_state", "action", "next_action"):
+        got, ref = getattr(out, k).float_features.cpu(), g.t(f"out_{k}")
+        assert got.shape == ref.shape and (got - ref).abs().max() <= 1e-5 + 1e-5 * ref.abs().max(), k
+    for k in ("reward", "time_diff", "step", "not_terminal"):
+        got, ref = getattr(out, k).cpu(), g.t(f"out_{k}")
+        assert got.shape == ref.shape and torch.equal(got.double(), ref.double()), k
+    for k in ("mdp_id", "sequence_number", "action_probability"):
+        got, ref = getattr(out.extras, k).cpu(), g.t(f"out_{k}")
+        assert got.shape == ref.shape and torch.equal(got.double(), ref.double()), k
