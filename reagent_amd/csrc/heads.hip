@@ -418,6 +418,8 @@ __global__ void c51_head_kernel(const float* __restrict__ q, const float* __rest
   __shared__ float P[C51_MAX_ATOMS];   // next distribution
   __shared__ float Mm[C51_MAX_ATOMS];  // projected target distribution m
   __shared__ float LD[C51_MAX_ATOMS];  // sum_a action[a] * log_dist(state)[a, :]
+  __shared__ float W0[C51_MAX_ATOMS], W1[C51_MAX_ATOMS];  // a source atom's contributions to bins lo / up
+  __shared__ short LO[C51_MAX_ATOMS], UP[C51_MAX_ATOMS];
   __shared__ float t_max[C51_MAX_ACTIONS], t_lse[C51_MAX_ACTIONS];  // target net, per action
   __shared__ float c_max[C51_MAX_ACTIONS], c_lse[C51_MAX_ACTIONS];  // online net on `state`
   __shared__ float sel_q[C51_MAX_ACTIONS];                          // next-state expected values
@@ -499,25 +501,39 @@ __global__ void c51_head_kernel(const float* __restrict__ q, const float* __rest
     Mm[j] = 0.f;
   }
   __syncthreads();
-  if (tid == 0) {
+  // The categorical projection (:136-155): m.scatter_add_(lo, p * (u - b)) then m.scatter_add_(up, p * (b - l)).
+  // One thread walking the 2N adds in order was the serial tail of this kernel (C51 step: 1.6 of 5.1 ms
+  // in this head).  Same arithmetic in parallel: every source atom's (lo, up, weights) is computed once,
+  // then target bin k collects its own adds — first the `lo` pass in source order, then the `up` pass —
+  // which is exactly the order in which the sequential scatter_adds reach that bin.
+  {
     float rb = 0.f;
     if (reward_boosts)
       for (int a = 0; a < A; ++a) rb += act_row[a] * reward_boosts[a];
     const float rew = reward[b] + rb;
     const float disc = gamma_exponent ? powf(gamma, gamma_exponent[b]) : gamma;
     const float dn = disc * not_terminal[b];
-    for (int pass = 0; pass < 2; ++pass) {  // m.scatter_add_(lo, p*(u-b)) then m.scatter_add_(up, p*(b-l))
-      for (int j = 0; j < N; ++j) {
-        float tq = rew + dn * support[j];
-        tq = fminf(fmaxf(tq, qmin), qmax);
-        const float bpos = (tq - qmin) / scale_support;
-        int lo = (int)floorf(bpos), up = (int)ceilf(bpos);
-        if (up > 0 && lo == up) lo -= 1;
-        if (lo < N - 1 && lo == up) up += 1;
-        if (pass == 0) Mm[lo] += P[j] * ((float)up - bpos);
-        else Mm[up] += P[j] * (bpos - (float)lo);
-      }
+    for (int j = tid; j < N; j += HEAD_THREADS) {
+      float tq = rew + dn * support[j];
+      tq = fminf(fmaxf(tq, qmin), qmax);
+      const float bpos = (tq - qmin) / scale_support;
+      int lo = (int)floorf(bpos), up = (int)ceilf(bpos);
+      if (up > 0 && lo == up) lo -= 1;
+      if (lo < N - 1 && lo == up) up += 1;
+      LO[j] = lo;
+      UP[j] = up;
+      W0[j] = P[j] * ((float)up - bpos);
+      W1[j] = P[j] * (bpos - (float)lo);
     }
+  }
+  __syncthreads();
+  for (int k = tid; k < N; k += HEAD_THREADS) {
+    float m = 0.f;
+    for (int j = 0; j < N; ++j)
+      if (LO[j] == k) m += W0[j];
+    for (int j = 0; j < N; ++j)
+      if (UP[j] == k) m += W1[j];
+    Mm[k] = m;
   }
   __syncthreads();
   float lsum = 0.f, msum = 0.f;
