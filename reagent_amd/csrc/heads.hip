@@ -449,6 +449,58 @@ __global__ void c51_head_kernel(const float* __restrict__ q, const float* __rest
     for (int off = 32; off >= 1; off >>= 1) e += shfl_xor(e, off);
     return e;
   };
+  auto wave_max = [&](float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, shfl_xor(v, off));
+    return v;
+  };
+  auto wave_sum = [&](float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += shfl_xor(v, off);
+    return v;
+  };
+  if (N <= 64) {
+    // one atom per lane: the three logit rows of an action are loaded once, all of a wave's actions up
+    // front (the generic loop below re-reads each row for max / sum-exp / expectation, one dependent
+    // L2 round trip after the other — with 65 536 short workgroups that latency was the kernel's time).
+    // Same operations in the same order per lane and the same xor-shuffle reductions: same bits.
+    constexpr int PER_WAVE = C51_MAX_ACTIONS / (HEAD_THREADS / 64) > 8 ? 8 : C51_MAX_ACTIONS / (HEAD_THREADS / 64);
+    for (int a0 = wave; a0 < A; a0 += (HEAD_THREADS / 64) * PER_WAVE) {
+      float vt[PER_WAVE], vc[PER_WAVE], vo[PER_WAVE];
+      const bool in = lane < N;
+      const float sup = in ? support[lane] : 0.f;
+#pragma unroll
+      for (int u = 0; u < PER_WAVE; ++u) {
+        const int a = a0 + u * (HEAD_THREADS / 64);
+        vt[u] = vc[u] = vo[u] = 0.f;
+        if (a < A) {  // wave-uniform
+          const long o = row + (long)a * N + (in ? lane : 0);
+          vt[u] = qn_target[o];
+          vc[u] = q[o];
+          if (qn_online) vo[u] = qn_online[o];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PER_WAVE; ++u) {
+        const int a = a0 + u * (HEAD_THREADS / 64);
+        if (a >= A) break;  // wave-uniform
+        const float tm = wave_max(in ? vt[u] : -3.4e38f), tl = logf(wave_sum(in ? expf(vt[u] - tm) : 0.f));
+        const float cm = wave_max(in ? vc[u] : -3.4e38f), cl = logf(wave_sum(in ? expf(vc[u] - cm) : 0.f));
+        float sq;
+        if (qn_online) {
+          const float om = wave_max(in ? vo[u] : -3.4e38f), ol = logf(wave_sum(in ? expf(vo[u] - om) : 0.f));
+          sq = wave_sum(in ? expf((vo[u] - om) - ol) * sup : 0.f);
+        } else {
+          sq = wave_sum(in ? expf((vt[u] - tm) - tl) * sup : 0.f);
+        }
+        const float cq = all_q ? wave_sum(in ? expf((vc[u] - cm) - cl) * sup : 0.f) : 0.f;
+        if (lane == 0) {
+          t_max[a] = tm; t_lse[a] = tl; c_max[a] = cm; c_lse[a] = cl; sel_q[a] = sq;
+          if (all_q) all_q[(long)b * A + a] = cq;
+        }
+      }
+    }
+  } else
   for (int a = wave; a < A; a += HEAD_THREADS / 64) {
     float tm, tl, cm, cl;
     row_stats(qn_target + row + (long)a * N, tm, tl);
