@@ -753,8 +753,8 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
       RG_PHASE(2);
       raw_barrier();
       RG_PHASE(3);
+      issue(mb_begin + t + 3, (t + 3) & (WG_DMA_SLOTS - 1));  // before the MFMAs: the requests leave a block time earlier
       compute(t & (WG_DMA_SLOTS - 1));
-      issue(mb_begin + t + 3, (t + 3) & (WG_DMA_SLOTS - 1));
       RG_PHASE(1);
     }
     RG_WAIT_VMCNT(0);
