@@ -243,6 +243,7 @@ __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __rest
   __shared__ int64_t s_nxt[GATHER_ROWS_PER_WG];
   __shared__ int s_steps[GATHER_ROWS_PER_WG];
   __shared__ unsigned char s_term[GATHER_ROWS_PER_WG];
+  __shared__ int s_act[GATHER_ROWS_PER_WG], s_nact[GATHER_ROWS_PER_WG];
   __shared__ rg_norm_col s_nc[GATHER_MAX_LDS_COLS];
   const rg_replay_view& v = a.v;
   const rg_dqn_batch_out& o = a.o;
@@ -266,7 +267,12 @@ __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __rest
     s_src[threadIdx.x] = piece == 1 ? nidx : idx;
     s_nxt[threadIdx.x] = nidx;
     s_steps[threadIdx.x] = st;
-    if (piece == 2) s_term[threadIdx.x] = v.terminal[wrap(idx + st - 1)] ? 1 : 0;  // the row pieces never read it
+    if (piece == 2) {  // the row pieces never read these
+      s_term[threadIdx.x] = v.terminal[wrap(idx + st - 1)] ? 1 : 0;
+      const int64_t a0 = v.action[idx], a1 = v.action[nidx];  // fetched once per row, not once per (row, action)
+      s_act[threadIdx.x] = (a0 >= 0 && a0 < A) ? (int)a0 : -1;
+      s_nact[threadIdx.x] = (a1 >= 0 && a1 < A) ? (int)a1 : -1;
+    }
   }
   if (piece < 2 && cols)
     for (int j = threadIdx.x; j < F; j += blockDim.x) s_nc[j] = cols[j];
@@ -316,8 +322,8 @@ __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __rest
     const int r = it / A, k = it - r * A;
     const int64_t idx = s_src[r], nidx = s_nxt[r];
     const long at = (long)(row0 + r) * A + k;
-    o.action[at] = (v.action[idx] == k) ? 1.f : 0.f;
-    o.next_action[at] = (!s_term[r] && v.action[nidx] == k) ? 1.f : 0.f;
+    o.action[at] = (s_act[r] == k) ? 1.f : 0.f;
+    o.next_action[at] = (!s_term[r] && s_nact[r] == k) ? 1.f : 0.f;
     if (o.possible_actions_mask)
       o.possible_actions_mask[at] = v.possible_actions_mask ? v.possible_actions_mask[idx * A + k] : 1.f;
     o.possible_next_actions_mask[at] = v.possible_actions_mask ? v.possible_actions_mask[nidx * A + k] : 1.f;

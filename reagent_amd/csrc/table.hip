@@ -30,7 +30,15 @@ __global__ void table_dqn_batch_kernel(TableArgs a, const int64_t* __restrict__ 
   const int row0 = blockIdx.x * TABLE_ROWS_PER_WG;
   const int nrows = (batch - row0 < TABLE_ROWS_PER_WG) ? batch - row0 : TABLE_ROWS_PER_WG;
   const int piece = blockIdx.y;  // 0 = state, 1 = next_state, 2 = everything else
-  if ((int)threadIdx.x < nrows) s_idx[threadIdx.x] = indices[row0 + threadIdx.x];
+  int* s_act = (int*)(smem + TABLE_ROWS_PER_WG * 8 + (size_t)n_out * sizeof(rg_norm_col));  // [2][TABLE_ROWS_PER_WG]
+  if ((int)threadIdx.x < nrows) {
+    const int64_t i = indices[row0 + threadIdx.x];
+    s_idx[threadIdx.x] = i;
+    if (piece == 2) {  // fetched once per row, not once per (row, action)
+      s_act[threadIdx.x] = (int)a.t.action[i];
+      s_act[TABLE_ROWS_PER_WG + threadIdx.x] = (int)a.t.next_action[i];
+    }
+  }
   if (piece < 2)
     for (int j = threadIdx.x; j < n_out; j += TABLE_THREADS) s_cols[j] = cols[j];
   __syncthreads();
@@ -118,8 +126,8 @@ __global__ void table_dqn_batch_kernel(TableArgs a, const int64_t* __restrict__ 
     const int r = it / A, k = it - r * A;
     const int64_t i = s_idx[r];
     const long at = (long)(row0 + r) * A + k;
-    o.action[at] = t.action[i] == k ? 1.f : 0.f;            // F.one_hot(action, A)
-    o.next_action[at] = t.next_action[i] == k ? 1.f : 0.f;  // F.one_hot(next_action, A + 1)[:, :A]
+    o.action[at] = s_act[r] == k ? 1.f : 0.f;                           // F.one_hot(action, A)
+    o.next_action[at] = s_act[TABLE_ROWS_PER_WG + r] == k ? 1.f : 0.f;  // F.one_hot(next_action, A + 1)[:, :A]
     if (o.possible_actions_mask)
       o.possible_actions_mask[at] = t.possible_actions_mask ? (float)t.possible_actions_mask[i * A + k] : 1.f;
     o.possible_next_actions_mask[at] = (float)t.possible_next_actions_mask[i * A + k];
@@ -160,7 +168,7 @@ int rg_table_dqn_batch(const rg_dqn_table* table, const int64_t* indices, int ba
       !o.possible_next_actions_mask)
     return RG_EINVAL;
   if (o.state_dtype != RG_DT_F32 && o.state_dtype != RG_DT_BF16) return RG_EINVAL;
-  const size_t lds = (size_t)TABLE_ROWS_PER_WG * 8 + (size_t)n_out * sizeof(rg_norm_col);
+  const size_t lds = (size_t)TABLE_ROWS_PER_WG * 8 + (size_t)n_out * sizeof(rg_norm_col) + 2 * TABLE_ROWS_PER_WG * sizeof(int);
   if (lds > 64 * 1024) return RG_EUNSUPPORTED;  // > 2700 output features
   TableArgs a{t, o};
   const dim3 grid((batch + TABLE_ROWS_PER_WG - 1) / TABLE_ROWS_PER_WG, 3);
