@@ -42,13 +42,13 @@ __global__ void transpose_cast_kernel(const TS* __restrict__ src, long ld_src, i
   }
 }
 
-template <class P, class C, class Epi, int BIAS>
+template <class P, class C, class Epi, int BIAS, int SWAP = 0>
 static int launch_gemm(const GemmArgs& g, const Epi& epi, float* bias_partials, long bias_slab,
                        hipStream_t stream) {
   const int tiles = ((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN);
   const int grid = tiles * (g.splits > 1 ? g.splits : 1);
   if (grid <= 0) return RG_OK;
-  RG_LAUNCH((gemm_nt_kernel<P, C, Epi, BIAS>), dim3(grid), dim3(256), stream, g, epi, bias_partials,
+  RG_LAUNCH((gemm_nt_kernel<P, C, Epi, BIAS, SWAP>), dim3(grid), dim3(256), stream, g, epi, bias_partials,
             bias_slab);
   return (int)hipGetLastError();
 }
@@ -79,8 +79,12 @@ static int fc_forward_t(const void* x, long ldx, const void* w, long ldw, const 
   e.bias = bias; e.y = (T*)y; e.y32 = y32; e.ldy = ldy; e.yt = (T*)yt; e.ldyt = ldyt;
   e.act = act; e.M = batch; e.N = out_f;
   if (out_f <= 32) return launch_gemm<P, TileNarrow, EpiForward<T>, 0>(g, e, nullptr, 0, stream);
-  if constexpr (IsBF16<P>::value)
+  if constexpr (IsBF16<P>::value) {
     if (gemm_big_ok(g)) return launch_gemm_big(g, e, stream);
+    // no transposed copy wanted (inference, the last layer): swapped accumulators, 16-byte fp32 / 8-byte
+    // bf16 row stores — the epilogue of these launches is bound by store issue, not by bytes
+    if (!yt) return launch_gemm<P, TileWide, EpiForward<T>, 0, 1>(g, e, nullptr, 0, stream);
+  }
   return launch_gemm<P, TileWide, EpiForward<T>, 0>(g, e, nullptr, 0, stream);
 }
 

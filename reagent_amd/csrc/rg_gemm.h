@@ -158,7 +158,10 @@ struct PrecBF16 {
     }
   }
   // one K-slab of MFMA work for this wave. a_row0/b_row0: first LDS row of the wave's sub-tile.
-  template <class C, int BIAS_MODE>
+  // SWAP: the operands trade places in the MFMA, so the accumulator tile is the TRANSPOSE of the
+  // output tile (a lane then holds 4 consecutive COLUMNS of one output row; same products, same k order,
+  // same values) — see the swapped epilogue of gemm_nt_kernel
+  template <class C, int BIAS_MODE, int SWAP = 0>
   static __device__ __forceinline__ void compute(const T* As, const T* Bs, int a_row0, int b_row0,
                                                  int lane, f32x16 (&acc)[C::TM][C::TN],
                                                  f32x16 (&accb)[(C::TM > C::TN ? C::TM : C::TN)],
@@ -178,7 +181,8 @@ struct PrecBF16 {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = SWAP ? mfma_32x32x16_bf16(bf[tn], af[tm], acc[tm][tn]) : mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
       if (BIAS_MODE == 1 && do_bias) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) accb[tm] = mfma_32x32x16_bf16(af[tm], ones, accb[tm]);
@@ -245,11 +249,12 @@ struct PrecF32 {
       }
     }
   }
-  template <class C, int BIAS_MODE>
+  template <class C, int BIAS_MODE, int SWAP = 0>
   static __device__ __forceinline__ void compute(const T* As, const T* Bs, int a_row0, int b_row0,
                                                  int lane, f32x16 (&acc)[C::TM][C::TN],
                                                  f32x16 (&accb)[(C::TM > C::TN ? C::TM : C::TN)],
                                                  bool do_bias) {
+    static_assert(SWAP == 0, "the swapped epilogue is a bf16 path");
     constexpr int TM = C::TM, TN = C::TN, AROWS = C::BM, BROWS = C::BN;
     const int lr = lane & 31, lk = lane >> 5;
 #pragma unroll
@@ -353,6 +358,44 @@ struct EpiForward {  // y = act(acc + bias); row-major and/or transposed stores
     store_quad_rowmajor<T>(y, ldy, row0, col, M, N, live, o);
     store_quad_transposed<T>(yt, ldyt, row0, col, M, live, o);
   }
+  // swapped accumulators: 4 consecutive columns col0..col0+3 of output row `row` — the fp32 copy is ONE
+  // 16-byte store and the bf16 copy one 8-byte store per quad (against 4 and 2 the other way round);
+  // the transposed copy is the expensive one here, so the caller swaps only when there is none
+  __device__ __forceinline__ void cols(int row, int col0, const float (&v)[4]) const {
+    if (row >= M || col0 >= N) return;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] + ((bias && col0 + e < N) ? bias[col0 + e] : 0.f), act);
+    const bool full = col0 + 3 < N;
+    if (y32) {
+      float* p = y32 + (long)row * ldy + col0;
+      if (full && ((((uintptr_t)p) & 15) == 0)) {
+        *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col0 + e < N) p[e] = o[e];
+      }
+    }
+    if (y) {
+      T* p = y + (long)row * ldy + col0;
+      if (sizeof(T) == 2 && full && ((((uintptr_t)p) & 7) == 0)) {
+        uint2 w;
+        w.x = pack_bf16x2(o[0], o[1]);
+        w.y = pack_bf16x2(o[2], o[3]);
+        *(uint2*)p = w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col0 + e < N) p[e] = cvt_out<T>(o[e]);
+      }
+    }
+    if (yt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col0 + e < N) yt[(long)(col0 + e) * ldyt + row] = cvt_out<T>(o[e]);
+    }
+  }
 };
 
 template <typename T>
@@ -410,9 +453,10 @@ __device__ __forceinline__ void epi_set_split(EpiWgrad& e, int split) { e.split 
 // ---------------------------------------------------------------------------------------------
 // the kernel.  BIAS_MODE 0: none; 1: also emit rowsum(A) (bias grad when A = dZ^T);
 // 2: also emit rowsum(B) (bias grad when B = dZ^T, the transposed narrow variant).
-template <class P, class C, class Epi, int BIAS_MODE>
+template <class P, class C, class Epi, int BIAS_MODE, int SWAP = 0>
 __global__ void RG_LAUNCH_BOUNDS(256, 1)
     gemm_nt_kernel(GemmArgs g, Epi epi, float* bias_partials /*[splits][rows]*/, long bias_slab) {
+  static_assert(SWAP == 0 || BIAS_MODE == 0, "bias row sums assume the unswapped accumulators");
   typedef typename P::T T;
   __shared__ __attribute__((aligned(16))) T As[P::template lds_elems<C::BM>()];
   __shared__ __attribute__((aligned(16))) T Bs[P::template lds_elems<C::BN>()];
@@ -471,7 +515,7 @@ __global__ void RG_LAUNCH_BOUNDS(256, 1)
         P::template load_global<C::BM, C::THREADS>(sa, A, g.lda, m0, g.M, k0 + P::BK, k_end, a_vec, tid);
         P::template load_global<C::BN, C::THREADS>(sb, B, g.ldb, n0, g.N, k0 + P::BK, k_end, b_vec, tid);
       }
-      P::template compute<C, BIAS_MODE>(As, Bs, wm * (C::TM * 32), wn * (C::TN * 32), lane, acc, accb, do_bias);
+      P::template compute<C, BIAS_MODE, SWAP>(As, Bs, wm * (C::TM * 32), wn * (C::TN * 32), lane, acc, accb, do_bias);
       __syncthreads();
       if (more) {
         P::template store_lds<C::BM, C::THREADS>(sa, As, tid);
@@ -491,10 +535,13 @@ __global__ void RG_LAUNCH_BOUNDS(256, 1)
       const int col = n0 + wn * (C::TN * 32) + tn * 32 + lr;
       static_for<0, 4>([&](auto rq_c) __attribute__((always_inline)) {
         constexpr int rq = decltype(rq_c)::value;
-        const int row0 = m0 + wm * (C::TM * 32) + tm * 32 + 8 * rq + 4 * lh;
         const float v[4] = {acc[tm][tn][rq * 4 + 0], acc[tm][tn][rq * 4 + 1], acc[tm][tn][rq * 4 + 2],
                             acc[tm][tn][rq * 4 + 3]};
-        epi(row0, col, v);
+        if constexpr (SWAP) {  // transposed accumulator tile: lane = output row, quad = 4 consecutive columns
+          epi.cols(m0 + wm * (C::TM * 32) + tm * 32 + lr, n0 + wn * (C::TN * 32) + tn * 32 + 8 * rq + 4 * lh, v);
+        } else {
+          epi(m0 + wm * (C::TM * 32) + tm * 32 + 8 * rq + 4 * lh, col, v);
+        }
       });
     });
   });

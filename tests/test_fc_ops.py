@@ -174,3 +174,33 @@ def test_large_bf16_shapes_take_the_dma_kernel_bit_identically(backend, M, N, K,
         res.append((dx, dx32))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 150, 100, "relu"), (257, 131, 72, "tanh"), (128, 64, 64, "linear")])
+def test_swapped_accumulator_epilogue_is_bit_identical(backend, M, N, K, act):
+    """a bf16 forward that wants no transposed copy runs with the MFMA operands swapped (lane = output
+    row, 16-byte fp32 / 8-byte bf16 row stores); asking for the transposed copy too selects the other
+    epilogue.  Same products in the same order: y and y32 must agree bit for bit (tails, odd N, bias and
+    activation included)."""
+    dev = backend.device
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+
+    def run(with_yt):
+        ldy = (N + 7) // 8 * 8  # row pitch a multiple of 16 bytes, as the engine allocates it
+        y = torch.zeros(M, ldy, dtype=torch.bfloat16, device=dev)[:, :N]
+        y32 = torch.zeros(M, ldy, device=dev)[:, :N]
+        yt = torch.zeros(N, M, dtype=torch.bfloat16, device=dev) if with_yt else None
+        ops.fc_forward(x, w, bias, L.ACT[act], L.PREC_BF16, y=y, y32=y32, yt=yt)
+        return y, y32
+
+    (ya, y32a), (yb, y32b) = run(False), run(True)
+    assert torch.equal(ya, yb) and torch.equal(y32a, y32b)
+    ref = _act((x.cpu().double() @ w.cpu().double().t() + bias.cpu().double()).numpy(), L.ACT[act])
+    assert np.abs(y32a.cpu().double().numpy() - ref).max() <= 2e-3 * (1 + np.abs(ref).max())
+    # fp32 output alone (the last layer of an inference forward)
+    only32 = torch.zeros(M, N, device=dev)
+    ops.fc_forward(x, w, bias, L.ACT[act], L.PREC_BF16, y32=only32)
+    assert torch.equal(only32, y32a.contiguous())
