@@ -1,5 +1,7 @@
-"""rg_fc_forward (bf16) on the GPU box: large-shape DMA kernel against the 128x128 kernel (forced by a
-leading dimension that is not a multiple of 8), with and without the bf16 / transposed / fp32 outputs:
+"""rg_fc_forward (bf16) on the GPU box for three large shapes, aligned operands (the dispatch picks the
+256x256 DMA kernel for K >= 1024, the 128x128 kernel otherwise, swapped accumulators when no transposed
+copy is asked for) and a leading dimension that is not a multiple of 8 (scalar-load path of the 128x128
+kernel), with the bf16 / bf16 + transposed / fp32 outputs:
 python profiles/microbench/gemm_shapes.py"""
 import sys
 
@@ -35,7 +37,7 @@ for M, N, K in ((65536, 512, 512), (65536, 3200, 512), (65536, 512, 3200)):
     yt = torch.empty(N, M, dtype=torch.bfloat16, device=dev)
     y32 = torch.empty(M, N, device=dev)
     gf = 2.0 * M * N * K / 1e9
-    for name, xin in (("dma 256x256", x), ("128x128", xw[:, :K])):
+    for name, xin in (("aligned", x), ("ld % 8 != 0", xw[:, :K])):  # aligned: 256x256 DMA kernel for K >= 1024, else 128x128
         for outs in (dict(y=y), dict(y=y, yt=yt), dict(y32=y32)):
             us = timed(lambda: ops.fc_forward(xin, w, b, L.ACT["relu"], L.PREC_BF16, **outs))
-            print(f"M={M} N={N} K={K} {name:12s} outputs={'+'.join(outs):8s} {us:8.1f} us  {gf / us * 1e-3:6.3f} PFLOP/s")
+            print(f"M={M} N={N} K={K} {name:12s} outputs={'+'.join(outs):8s} {us:8.1f} us  {gf / us:7.1f} TFLOP/s")

@@ -683,7 +683,9 @@ __global__ void RG_LAUNCH_BOUNDS(BIG_THREADS, 1) gemm_nt_big_kernel(GemmArgs g, 
 // per CU, nothing to overlap it with), and inside the QR-DQN step those two shapes ran SLOWER than on
 // the 128 x 128 kernel (0.18 vs 0.14 ms, 0.98 vs 0.89 ms), whose 3-4 resident workgroups overlap each
 // other's epilogues.  Until the epilogue goes through LDS (16-byte row stores) the kernel is used for
-// K >= 1024 only.
+// K >= 1024 only.  (Its accumulators swapped like gemm_nt_kernel's SWAP mode — 16-byte row stores — were
+// measured too: 203 vs 123 us at N=512 K=512 and 1180 vs 730 us at N=3200 K=512 against the swapped
+// 128 x 128 kernel; with one workgroup per CU a row-scattered epilogue has nothing to hide behind.)
 static inline bool gemm_big_ok(const GemmArgs& g) {
   return g.M >= 2048 && g.N >= 192 && g.K >= 1024 && (g.K % BIG_BK) == 0 && (g.lda % 8) == 0 && (g.ldb % 8) == 0 &&
          ((((uintptr_t)g.A) | ((uintptr_t)g.B)) & 15) == 0 && g.splits <= 1;
