@@ -40,4 +40,4 @@ for M, N, K in ((65536, 512, 512), (65536, 3200, 512), (65536, 512, 3200)):
     for name, xin in (("aligned", x), ("ld % 8 != 0", xw[:, :K])):  # aligned: 256x256 DMA kernel for K >= 1024, else 128x128
         for outs in (dict(y=y), dict(y=y, yt=yt), dict(y32=y32)):
             us = timed(lambda: ops.fc_forward(xin, w, b, L.ACT["relu"], L.PREC_BF16, **outs))
-            print(f"M={M} N={N} K={K} {name:12s} outputs={'+'.join(outs):8s} {us:8.1f} us  {gf / us:7.1f} TFLOP/s")
+            print(f"M={M} N={N} K={K} {name:12s} outputs={'+'.join(outs):8s} {us:8.1f} us  {gf / us * 1e3:7.1f} TFLOP/s")
