@@ -100,3 +100,34 @@ class OfflineDqnLoop:
     def flush(self):
         """apply an update left pending by the last step (call before reading parameters)"""
         self.trainer.apply_pending_update()
+
+
+class OfflineTableLoop:
+    """Epochs over an offline (post-timeline) table resident in HBM: what the reference's petastorm
+    DataLoader + DiscreteDqnBatchPreprocessor + pl.Trainer.fit do for batch RL from a dataset
+    (reagent/data/oss_data_fetcher.py, reagent/preprocessing/batch_preprocessor.py:35-66,
+    reagent/workflow/training.py), with the table as one device array per column:
+
+        for indices in table.epoch(batch_size):             (device permutation, no host sync)
+            batch = batch_preprocessor.from_table(table, indices)     rg_table_dqn_batch (one launch)
+            trainer.train_step_native(batch)                 FC fwd x3, head, bwd, Adam, soft update
+    """
+
+    def __init__(self, table, trainer, batch_preprocessor, batch_size: int, shuffle: bool = True,
+                 generator: Optional[torch.Generator] = None):
+        self.table, self.trainer, self.bp = table, trainer, batch_preprocessor
+        self.batch_size, self.shuffle, self.generator = batch_size, shuffle, generator
+        self.batches_done = 0
+
+    def run_epoch(self) -> Optional[torch.Tensor]:
+        """one pass over the table (the last partial batch is dropped); returns the last loss (device)"""
+        loss = None
+        deferred = hasattr(self.trainer, "apply_pending_update")
+        for indices in self.table.epoch(self.batch_size, shuffle=self.shuffle, generator=self.generator):
+            batch = self.bp.from_table(self.table, indices)
+            loss = self.trainer.train_step_native(batch, defer_update=True) if deferred \
+                else self.trainer.train_step_native(batch)
+            self.batches_done += 1
+        if deferred:
+            self.trainer.apply_pending_update()
+        return loss
