@@ -395,3 +395,41 @@ def test_fused_dqn_input_declines_other_stores(backend):
         rb.add(observation=np.zeros(6, np.float32), action=np.int64(0), reward=np.float32(0), terminal=False,
                log_prob=np.float32(0))
     assert rb.sample_dqn_input(3, 4) is None  # 6 features: not a multiple of 4
+
+
+def test_stack_slaughter(backend):
+    """reagent/test/replay_memory/extra_replay_buffer_test.py:242-256 (test_stack_slaughter): stack_size 7,
+    1..9 trajectories of random length, buffer sized as the reference does; every valid transition's frame
+    stacks (state, action, extra) must equal the restatement :45-57 — zero frames before the trajectory
+    start, never a frame of the previous trajectory.  (The reward comes back as the n-step sum here:
+    return_everything_as_stack, which would stack it too, is outside the hot path.)"""
+    stack = 7
+    rng = np.random.RandomState(0)
+    for n_traj in range(1, 10):
+        lengths = rng.randint(1, 30, size=n_traj).tolist()
+        cap = int(sum(lengths) + (n_traj + 1) * (stack - 1))
+        rb = ReplayBuffer(device=backend.device, stack_size=stack, replay_capacity=cap, batch_size=1)
+        i = 0
+        for traj_len in lengths:
+            for j in range(traj_len):
+                rb.add(observation=(np.ones((3, 3)) * i).astype(np.float32), action=np.int64(i), reward=np.float32(2 * i),
+                       terminal=bool(j == traj_len - 1), extra1=np.float32(3 * i))
+                i += 1
+        got = rb.sample_all_valid_transitions()
+        exp_state, exp_scalar, exp_term, last = [], [], [], []
+        i = 0
+        for traj_len in lengths:
+            start = i
+            for j in range(traj_len):
+                window = range(i - stack + 1, i + 1)
+                exp_state.append(np.stack([np.zeros((3, 3)) if k < start else np.ones((3, 3)) * k for k in window], axis=-1))
+                exp_scalar.append([0 if k < start else k for k in window])
+                exp_term.append(j == traj_len - 1)
+                last.append(i)
+                i += 1
+        frames = np.array(exp_scalar)
+        np.testing.assert_array_equal(got.state.cpu().numpy(), np.stack(exp_state).astype(np.float32))
+        np.testing.assert_array_equal(got.action.cpu().numpy(), frames)
+        np.testing.assert_array_equal(got.extra1.cpu().numpy(), 3.0 * frames.astype(np.float32))
+        np.testing.assert_array_equal(got.terminal.cpu().numpy().reshape(-1), np.array(exp_term))
+        np.testing.assert_array_equal(got.reward.cpu().numpy().reshape(-1), 2.0 * np.array(last, dtype=np.float32))
