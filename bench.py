@@ -230,8 +230,11 @@ def main():
 
     layer_dims = [args.state_dim] + [args.hidden] * args.layers + [args.actions]
     extra = {}
-    if not args.no_kernel_profile and rank == 0:
+    if not args.no_kernel_profile:
+        # every rank runs the instrumented steps (they contain the gradient all-reduce: a pass on rank 0
+        # alone would never return); rank 0 reports
         extra = kernel_profile(args, loop, min(args.steps, 10), layer_dims)
+        loop.flush()
     if dist is not None:
         dist.barrier()
     if rank == 0:
