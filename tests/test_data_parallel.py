@@ -109,6 +109,50 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
+def _loop_worker(rank, world, port, out_dir):
+    """bench.py's data-parallel flow on two ranks: own replay shard per rank, OfflineDqnLoop.step (one-launch
+    sampler, deferred update under the asynchronous all-reduce), flush, barrier, max-reduce of a timing"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_backend
+
+    emu_backend.install()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reagent_amd import synthetic
+    from reagent_amd.core.parameters import NormalizationParameters as NP
+    from reagent_amd.preprocessing import Preprocessor
+    from reagent_amd.replay_memory import ReplayBuffer
+    from reagent_amd.runtime import OfflineDqnLoop
+
+    S, A, C, B = 12, 4, 512, 64
+    tr = _build("dqn").enable_data_parallel()
+    cols = synthetic.replay_contents(C, S, A, seed=100 + rank)  # this rank's shard
+    rb = ReplayBuffer(replay_capacity=C, batch_size=B, device="cpu")
+    rb.load_columns(cols, mark_all_valid=True)
+    pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=0.1 * i, stddev=1.0 + 0.1 * i) for i in range(S)}, device="cpu")
+    loop = OfflineDqnLoop(rb, tr, B, pre)
+    torch.manual_seed(1000 + rank)  # different index draws per rank
+    for _ in range(3):
+        loss = loop.step()
+    loop.flush()
+    dist.barrier()
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == world - 1 and torch.isfinite(loss).all() and loop.fused_sampling
+    torch.save([p.detach().clone() for p in tr.parameters()], os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_offline_loop_two_ranks_stay_in_lockstep(tmp_path, emu_lib):
+    port = 29500 + (os.getpid() % 2000) + 7
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
 @pytest.mark.parametrize("kind", ["dqn", "dqn_deferred", "sac", "td3", "crr"])
 def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib, kind):
     port = 29500 + (os.getpid() % 2000) + {"dqn": 0, "sac": 1, "dqn_deferred": 2, "td3": 3, "crr": 4}[kind]
