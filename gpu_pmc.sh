@@ -1,6 +1,9 @@
 #!/bin/bash
 # PMC passes (separate runs per counter group, kernel-trace only — never combined with sys/hip traces)
 cd /root/repo; OUT=/root/repo/gpurun_out; TAG=${1:-pmc}; mkdir -p $OUT/pmc_$TAG
+# preflight: a node whose first device touch faults (seen once: "Memory access fault by GPU" on tensor.to)
+# would otherwise burn the whole GPU budget in core dumps and timeouts
+timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 export TMPDIR=/tmp
 CMD="python /root/repo/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-profile"
 i=0
