@@ -587,7 +587,42 @@ def gen_prioritized():
                                      max_sample_attempts=200), arrays)
 
 
+def check():
+    """`python -m oracle.make_golden --check`: regenerate every fixture into a scratch directory and compare
+    it, array by array, with the committed file — the committed vectors are what the unmodified reference
+    produces today.  (`prioritized_replay` holds a column of uninitialised reference memory: skipped there.)"""
+    import tempfile
+
+    global OUT
+    committed = OUT
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        sys.argv = sys.argv[:1]
+        main()
+        OUT = committed
+        bad = []
+        for f in sorted(os.listdir(tmp)):
+            new, old = np.load(os.path.join(tmp, f)), np.load(os.path.join(committed, f))
+            if set(new.files) != set(old.files):
+                bad.append((f, "keys differ"))
+                continue
+            for k in new.files:
+                if f.startswith("prioritized_replay") and k.endswith("priority"):
+                    continue
+                if new[k].dtype.kind in "fc":
+                    same = np.array_equal(new[k], old[k], equal_nan=True)
+                else:
+                    same = np.array_equal(new[k], old[k])
+                if not same:
+                    bad.append((f, k))
+        missing = sorted(set(os.listdir(committed)) - set(os.listdir(tmp)))
+        print("checked", len(os.listdir(tmp)), "fixtures;", "all identical" if not bad and not missing else f"DIFFERENT: {bad} missing: {missing}")
+        return not bad and not missing
+
+
 def main():
+    if sys.argv[1:] == ["--check"]:
+        sys.exit(0 if check() else 1)
     only = sys.argv[1:]  # e.g. `python -m oracle.make_golden sum_tree prioritized` regenerates only those
     if only:
         for n in only:

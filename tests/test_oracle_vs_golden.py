@@ -113,3 +113,16 @@ def test_preprocessor_oracle_matches_reference():
     assert R.sort_features(norm) == g.cfg["sorted_features"]
     out = R.preprocess(norm, g.t("x"), g.t("presence"))
     torch.testing.assert_close(out, g.t("out"), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/reagent"), reason="needs the reference checkout")
+def test_committed_goldens_are_what_the_reference_produces():
+    """`python -m oracle.make_golden --check`: every fixture under tests/golden regenerated from the
+    unmodified reference and compared array by array with the committed file (build container only)"""
+    import subprocess
+    import sys
+
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "oracle.make_golden", "--check"], cwd=root, capture_output=True, text=True,
+                         timeout=1500)
+    assert out.returncode == 0 and "all identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
