@@ -363,6 +363,12 @@ int rg_dqn_head(const float* q, const float* qn_online, const float* qn_target, 
                 int num_actions, int double_q, int loss_type, float* dq, float* loss_partials,
                 float* next_q, int64_t* next_idx, float* q_sel, rg_stream_t stream);
 
+/* Batch-constrained q-learning (reagent/training/dqn_trainer.py:209-215 with
+ * get_valid_actions_from_imitator, reagent/training/imitator_training.py:12-25): mask [B, A] (in place)
+ * *= (softmax(imitator_logits)[b, a] / max_a softmax(imitator_logits)[b, :] >= drop_threshold). */
+int rg_bcq_filter(const float* imitator_logits, int batch, int num_actions, double drop_threshold, float* mask,
+                  rg_stream_t stream);
+
 /* CPE heads of the DQN step, _calculate_cpes (reagent/training/dqn_trainer_base.py:338-452) with
  * masked_softmax (reagent/core/torch_utils.py:62-73): reward-network MSE and CPE q-network loss on the
  * logged action's column of each of the M metrics, and both output gradients.

@@ -57,6 +57,11 @@ DQN_CASES = {
                               rl=dict(gamma=0.9, target_update_rate=0.3, maxq_learning=False, q_network_loss="mse"),
                               lr=0.005, double_q=False, batch=40, steps=2, p_impossible=0.0, with_steps=False,
                               cpe_metrics=[]),
+    # batch-constrained q-learning: next actions the imitator finds unlikely are masked out of the max
+    "dqn_bcq": dict(state_dim=9, num_actions=5, sizes=[32, 16], activations=["relu", "relu"],
+                    rl=dict(gamma=0.9, target_update_rate=0.2, maxq_learning=True, q_network_loss="mse"),
+                    lr=0.004, double_q=True, batch=72, steps=3, p_impossible=0.15, with_steps=False,
+                    bcq_threshold=0.6),
     "dqn_timediff": dict(state_dim=7, num_actions=4, sizes=[24], activations=["relu"],
                          rl=dict(gamma=0.9, target_update_rate=0.5, maxq_learning=True,
                                  q_network_loss="huber", use_seq_num_diff_as_time_diff=True),
@@ -67,10 +72,13 @@ DQN_CASES = {
 def gen_dqn(name, c):
     cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
-                      double_q=c["double_q"], seed=0, cpe_metrics=cpe_metrics)
+                      double_q=c["double_q"], seed=0, cpe_metrics=cpe_metrics, bcq_threshold=c.get("bcq_threshold"))
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
+    if c.get("bcq_threshold") is not None:
+        for i, p in enumerate(tr.bcq_imitator.parameters()):
+            arrays[f"imitator_{i}"] = _np(p)
     if cpe_metrics is not None:
         for net in CPE_NETS:
             for i, p in enumerate(getattr(tr, net).parameters()):
@@ -626,7 +634,10 @@ def main():
     only = sys.argv[1:]  # e.g. `python -m oracle.make_golden sum_tree prioritized` regenerates only those
     if only:
         for n in only:
-            if n.upper() + "_CASES" in globals():  # e.g. `crr` = every case of CRR_CASES
+            if ":" in n:  # e.g. `dqn:dqn_bcq` = one case of DQN_CASES
+                kind, name = n.split(":")
+                globals()["gen_" + kind](name, globals()[kind.upper() + "_CASES"][name])
+            elif n.upper() + "_CASES" in globals():  # e.g. `crr` = every case of CRR_CASES
                 for name, c in globals()[n.upper() + "_CASES"].items():
                     globals()["gen_" + n](name, c)
             else:

@@ -86,7 +86,7 @@ def make_adam(lr=1e-3, **kw):
 
 
 def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_q=True, seed=0,
-              num_atoms=None, cpe_metrics=None):
+              num_atoms=None, cpe_metrics=None, bcq_threshold=None):
     """Reference FullyConnectedDQN (+ target) and DQNTrainer / QRDQNTrainer.  cpe_metrics: None = CPE
     off; a list of extra metric names (may be empty) = calc_cpe_in_training with reward_network,
     q_network_cpe and its target of output width (len(cpe_metrics) + 1) * num_actions
@@ -111,6 +111,13 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
             q_cpe = FullyConnectedDQN(state_dim, n_out, sizes, activations)
             trainer = DQNTrainer(q, qt, reward_net, q_network_cpe=q_cpe, q_network_cpe_target=q_cpe.get_target_network(),
                                  metrics_to_score=list(cpe_metrics), **common)
+        elif bcq_threshold is not None:
+            # batch-constrained q-learning: `imitator` is any module mapping state features to action logits
+            # (imitator_training.py:12-25); a two-layer torch net, its weights saved with the fixture
+            from reagent.training.dqn_trainer import BCQConfig
+
+            imitator = torch.nn.Sequential(torch.nn.Linear(state_dim, 16), torch.nn.ReLU(), torch.nn.Linear(16, num_actions))
+            trainer = DQNTrainer(q, qt, None, imitator=imitator, bcq=BCQConfig(drop_threshold=bcq_threshold), **common)
         else:
             trainer = DQNTrainer(q, qt, None, **common)
     else:

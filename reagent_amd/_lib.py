@@ -166,6 +166,7 @@ SIGNATURES = {
     "rg_replay_dqn_batch": (c_int, [ctypes.POINTER(ReplayView), c_void_p, c_int, c_void_p, c_void_p,
                                      ctypes.POINTER(DqnBatchOut), c_void_p]),
     "rg_table_check_actions": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_void_p]),
+    "rg_bcq_filter": (c_int, [c_void_p, c_int, c_int, c_d, c_void_p, c_void_p]),
     "rg_dqn_head_partials": (c_int, [c_int]),
     "rg_dqn_head": (c_int, [c_void_p] * 8 + [c_d, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rg_cpe_head": (c_int, [c_void_p] * 9 + [ctypes.c_double, c_void_p, ctypes.c_double, c_int, c_int, c_int, c_int,

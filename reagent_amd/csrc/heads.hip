@@ -606,6 +606,27 @@ __global__ void c51_head_kernel(const float* __restrict__ q, const float* __rest
   if (tid == 0) loss_partials[b] = -tot_l * inv_b;
 }
 
+// get_valid_actions_from_imitator (reagent/training/imitator_training.py:12-25) applied to a mask:
+//   p = softmax(imitator logits); keep[a] = (p[a] / max_a p) >= drop_threshold; mask[b, a] *= keep[a]
+// (batch-constrained q-learning, dqn_trainer.py:209-215).  One thread per transition, the reference's
+// operation order (exp(x - max) / sum, then the division by the row maximum of the probabilities).
+__global__ void bcq_filter_kernel(const float* __restrict__ logits, int batch, int A, float drop_threshold,
+                                  float* __restrict__ mask) {
+  const int b = blockIdx.x * HEAD_THREADS + threadIdx.x;
+  if (b >= batch) return;
+  const long o = (long)b * A;
+  float mx = logits[o];
+  for (int a = 1; a < A; ++a) mx = fmaxf(mx, logits[o + a]);
+  float den = 0.f;
+  for (int a = 0; a < A; ++a) den += expf(logits[o + a] - mx);
+  float pmax = 0.f;
+  for (int a = 0; a < A; ++a) pmax = fmaxf(pmax, expf(logits[o + a] - mx) / den);
+  for (int a = 0; a < A; ++a) {
+    const float keep = ((expf(logits[o + a] - mx) / den) / pmax >= drop_threshold) ? 1.f : 0.f;
+    mask[o + a] *= keep;
+  }
+}
+
 __global__ void reduce_sum_kernel(const float* __restrict__ in, int n, float scale,
                                   float* __restrict__ out) {
   __shared__ float scratch[4];
@@ -697,6 +718,15 @@ int rg_c51_head(const float* q, const float* qn_online, const float* qn_target, 
   RG_LAUNCH(c51_head_kernel, dim3(batch), dim3(HEAD_THREADS), (hipStream_t)stream, q, qn_online, qn_target, action,
             next_mask, reward, reward_boosts, not_terminal, (float)gamma, gamma_exponent, support, (float)qmin,
             (float)qmax, scale, batch, num_actions, num_atoms, maxq, dq, loss_partials, all_q);
+  return (int)hipGetLastError();
+}
+
+int rg_bcq_filter(const float* imitator_logits, int batch, int num_actions, double drop_threshold, float* mask,
+                  rg_stream_t stream) {
+  if (!imitator_logits || !mask || batch < 0 || num_actions <= 0) return RG_EINVAL;
+  if (batch == 0) return RG_OK;
+  RG_LAUNCH(bcq_filter_kernel, dim3((batch + HEAD_THREADS - 1) / HEAD_THREADS), dim3(HEAD_THREADS),
+            (hipStream_t)stream, imitator_logits, batch, num_actions, (float)drop_threshold, mask);
   return (int)hipGetLastError();
 }
 

@@ -298,6 +298,16 @@ def table_check_actions(table, indices) -> int:
 
 
 # ---- heads ------------------------------------------------------------------------------------
+def bcq_filter(imitator_logits, drop_threshold: float, mask):
+    """mask *= (softmax(logits) / rowmax >= drop_threshold), in place"""
+    _chk_dev(imitator_logits, mask)
+    B, A = mask.shape
+    assert imitator_logits.shape == (B, A) and imitator_logits.dtype == F32 and mask.dtype == F32
+    assert imitator_logits.is_contiguous() and mask.is_contiguous()
+    _run("rg_bcq_filter", dict(B=B, A=A),
+         lambda: L.lib().rg_bcq_filter(L.ptr(imitator_logits), B, A, float(drop_threshold), L.ptr(mask), L.stream_ptr()))
+
+
 def dqn_head_partials(batch: int) -> int:
     return int(L.lib().rg_dqn_head_partials(batch))
 

@@ -255,6 +255,18 @@ class QStepCore(DQNTrainerBaseLightning):
         t = t if t.dtype == torch.float32 else t.float()
         return t if t.is_contiguous() else t.contiguous()
 
+    def _bcq_mask(self, next_mask, next_state):
+        """possible_next_actions_mask * get_valid_actions_from_imitator(imitator, next_state, threshold)
+        (dqn_trainer.py:209-215) on a copy — the batch's own mask is left alone"""
+        st = self.bcq_imitator.stack()
+        st.stage_weights(need_transposed=False)
+        xi, _ = st.stage_input(next_state, need_transposed=False)
+        logits = torch.empty(next_state.shape[0], self.num_actions, dtype=torch.float32, device=next_state.device)
+        st.forward(xi, logits, save=False)
+        mask = next_mask.clone()
+        ops.bcq_filter(logits, self.bcq_drop_threshold, mask)
+        return mask
+
     def _needs_online_next(self) -> bool:
         return True
 
@@ -289,6 +301,8 @@ class QStepCore(DQNTrainerBaseLightning):
         boosts = self.reward_boosts.reshape(-1).to(dev) if self._has_reward_boost else None
         if self.maxq_learning:
             next_mask = self._f32c(b.possible_next_actions_mask)
+            if getattr(self, "bcq", False):
+                next_mask = self._bcq_mask(next_mask, next_state)
         else:  # SARSA: the taken next action is the only "possible" one (dqn_trainer.py:218-224)
             next_mask = self._f32c(b.next_action)
         self._run_head(b, B, self._f32c(b.action), next_mask, boosts, gamma_exp)
@@ -514,9 +528,16 @@ class DQNTrainer(QStepCore):
         self._initialize_cpe(reward_network, q_network_cpe, q_network_cpe_target, optimizer=optimizer)
         self._cpe = _CpeEngine(self) if self.calc_cpe_in_training else None
 
+        # batch-constrained q-learning (:113-117): next actions the behaviour policy (the imitator) finds
+        # unlikely are masked out of the max (:209-215)
         self.bcq = bcq is not None
         if self.bcq:
-            raise NotImplementedError("batch-constrained q-learning needs the imitator net (not on the hot path)")
+            self.bcq_drop_threshold = bcq.drop_threshold
+            if imitator is None or not hasattr(imitator, "stack"):
+                raise NotImplementedError(
+                    "bcq needs `imitator` as a reagent_amd FullyConnectedNetwork (state features -> action logits); "
+                    "scikit-learn imitators (a CPU call per batch) are not served")
+            self.bcq_imitator = imitator
 
     # ---- head ---------------------------------------------------------------------------------
     def _alloc_head(self, batch, device):

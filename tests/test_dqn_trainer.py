@@ -247,3 +247,45 @@ def test_fused_update_equals_separate_launches(backend, state_dim):
     x = batch.state
     assert torch.equal(fused.q_network(x), separate.q_network(x))
     assert torch.equal(fused.q_network_target(x), separate.q_network_target(x))
+
+
+def test_dqn_bcq_matches_reference(backend):
+    """batch-constrained q-learning (dqn_trainer.py:113-117, 209-215; imitator_training.py:12-25): next
+    actions whose imitator probability is below drop_threshold x the row maximum leave the max.
+    Golden run of the reference with a torch imitator (tests/golden/dqn_bcq.npz); here the imitator is a
+    FullyConnectedNetwork with the same weights.  The batch's own mask must stay untouched."""
+    from reagent_amd.models.fully_connected_network import FullyConnectedNetwork
+    from reagent_amd.training import BCQConfig
+
+    g = Golden("dqn_bcq")
+    c = g.cfg
+    q = FullyConnectedDQN(c["state_dim"], c["num_actions"], c["sizes"], c["activations"])
+    imitator = FullyConnectedNetwork([c["state_dim"], 16, c["num_actions"]], ["relu", "linear"])
+    with torch.no_grad():
+        for p, init in zip(q.parameters(), g.seq("init_param_")):
+            p.copy_(init)
+        for p, init in zip(imitator.parameters(), g.seq("imitator_")):
+            p.copy_(init)
+    q, imitator = q.to(backend.device), imitator.to(backend.device)
+    tr = DQNTrainer(q, q.get_target_network(), None, imitator=imitator, bcq=BCQConfig(drop_threshold=c["bcq_threshold"]),
+                    actions=[str(i) for i in range(c["num_actions"])], rl=RLParameters(**c["rl"]),
+                    double_q_learning=c["double_q"], optimizer=Optimizer__Union.default(lr=c["lr"]),
+                    evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(backend.device)
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    for s in range(c["steps"]):
+        batch = synthetic.to_dqn_input(g.batch(s), backend.device)
+        before = batch.possible_next_actions_mask.clone()
+        losses = lightning_like_step(tr, opts, batch)
+        assert torch.equal(batch.possible_next_actions_mask, before)
+        ref_loss = g.t(f"step{s}_loss").item()
+        assert abs(losses[0].item() - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-6
+        for i, p in enumerate(tr.q_network.parameters()):
+            assert (p.detach().cpu() - g.t(f"step{s}_param_{i}")).abs().max() <= 2e-5, (s, i)
+    # the constraint really bites in this fixture: an unconstrained trainer takes a different step
+    free = build(g, backend.device, L.PREC_F32)
+    free_loss = lightning_like_step(free, [o["optimizer"] for o in free.configure_optimizers()],
+                                    synthetic.to_dqn_input(g.batch(0), backend.device))[0].item()
+    assert abs(free_loss - g.t("step0_loss").item()) > 1e-3 * abs(free_loss)
+    with pytest.raises(NotImplementedError):
+        DQNTrainer(q, q.get_target_network(), None, bcq=BCQConfig(), actions=["0", "1", "2", "3", "4"],
+                   evaluation=EvaluationParameters(calc_cpe_in_training=False))  # no imitator given
