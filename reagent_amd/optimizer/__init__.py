@@ -2,7 +2,7 @@
 ``torch.optim.Optimizer`` subclasses so ``configure_optimizers()`` keeps the reference contract
 (reagent/optimizer/union.py:52-64, reagent/optimizer/soft_update.py:9-71)."""
 import math
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
 import torch
@@ -161,22 +161,67 @@ class SoftUpdate(torch.optim.Optimizer):
         return loss
 
 
+# ---- learning-rate schedulers (reagent/optimizer/scheduler.py:16-41, uninferrable_schedulers.py) -----
+class LearningRateSchedulerConfig:
+    """A config whose class name is the torch.optim.lr_scheduler class it builds and whose fields are that
+    class's arguments (scheduler.py:19-38).  FusedAdam and rg_mlp_update_fused read group["lr"] at every
+    step, so the torch schedulers drive the fused optimizer unchanged."""
+
+    def make_from_optimizer(self, optimizer: torch.optim.Optimizer):
+        import inspect
+
+        cls = getattr(torch.optim.lr_scheduler, type(self).__name__)
+        args = {k: getattr(self, k) for k in inspect.signature(cls).parameters if k != "optimizer" and hasattr(self, k)}
+        return cls(optimizer=optimizer, **args)
+
+
+@dataclass
+class StepLR(LearningRateSchedulerConfig):
+    step_size: int
+    gamma: float = 0.1
+    last_epoch: int = -1
+
+
+@dataclass
+class MultiStepLR(LearningRateSchedulerConfig):
+    milestones: List[int]
+    gamma: float = 0.1
+    last_epoch: int = -1
+
+
+@dataclass
+class ExponentialLR(LearningRateSchedulerConfig):
+    gamma: float
+    last_epoch: int = -1
+
+
+@dataclass
+class CosineAnnealingLR(LearningRateSchedulerConfig):
+    T_max: int
+    eta_min: float = 0
+    last_epoch: int = -1
+
+
 # ---- config objects (duck-typed stand-ins for reagent.optimizer.Optimizer__Union) -----------
 @dataclass
 class Adam:
-    """reagent/optimizer/uninferrable_optimizers.py:23-33 defaults."""
+    """reagent/optimizer/uninferrable_optimizers.py:23-33 defaults; `lr_schedulers` as in
+    OptimizerConfig (optimizer.py:61-85: at most one)."""
 
     lr: float = 0.001
     betas: Tuple[float, float] = (0.9, 0.999)
     eps: float = 1e-08
     weight_decay: float = 0
     amsgrad: bool = False
+    lr_schedulers: List[LearningRateSchedulerConfig] = field(default_factory=list)
 
     def make_optimizer_scheduler(self, params):
-        return {
-            "optimizer": FusedAdam(params, lr=self.lr, betas=tuple(self.betas), eps=self.eps,
-                                   weight_decay=self.weight_decay, amsgrad=self.amsgrad)
-        }
+        assert len(self.lr_schedulers) <= 1, "Multiple schedulers for one optimizer is no longer supported"
+        optimizer = FusedAdam(params, lr=self.lr, betas=tuple(self.betas), eps=self.eps,
+                              weight_decay=self.weight_decay, amsgrad=self.amsgrad)
+        if len(self.lr_schedulers) == 0:
+            return {"optimizer": optimizer}
+        return {"optimizer": optimizer, "lr_scheduler": self.lr_schedulers[0].make_from_optimizer(optimizer)}
 
 
 class Optimizer__Union:

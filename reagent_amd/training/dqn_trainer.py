@@ -345,8 +345,16 @@ class QStepCore(DQNTrainerBaseLightning):
     # ---- fused native step (what bench.py and the native loop drive) --------------------------
     def native_optimizers(self):
         if getattr(self, "_native_opts", None) is None:
-            self._native_opts = [o["optimizer"] for o in self.configure_optimizers()]
+            made = self.configure_optimizers()
+            self._native_opts = [o["optimizer"] for o in made]
+            # lr schedulers of the optimizer configs (None where there is none): with Lightning its loop
+            # steps them per epoch; a caller of the native loop does `for s in native_schedulers(): s.step()`
+            self._native_scheds = [o.get("lr_scheduler") for o in made]
         return self._native_opts
+
+    def native_schedulers(self):
+        self.native_optimizers()
+        return [s for s in self._native_scheds if s is not None]
 
     @torch.no_grad()
     def train_step_native(self, training_batch, defer_update: bool = False) -> torch.Tensor:

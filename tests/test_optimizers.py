@@ -72,3 +72,31 @@ def test_optimizer_union_default_is_adam(backend):
     o = Optimizer__Union.default().make_optimizer_scheduler(p)
     assert set(o) == {"optimizer"} and isinstance(o["optimizer"], FusedAdam)
     assert o["optimizer"].defaults["lr"] == 0.001 and o["optimizer"].defaults["betas"] == (0.9, 0.999)
+
+
+def test_lr_scheduler_drives_the_fused_adam(backend):
+    """Optimizer__Union(Adam=Adam(lr_schedulers=[StepLR(...)])) as in reagent/optimizer/optimizer.py:61-85:
+    the torch scheduler object changes group["lr"], which the fused kernel reads at every step — the
+    parameters follow torch.optim.Adam + the same scheduler bit for bit"""
+    from reagent_amd.optimizer import Adam, Optimizer__Union, StepLR
+
+    dev = backend.device
+    torch.manual_seed(0)
+    p_ref = torch.nn.Parameter(torch.randn(300))
+    p_hip = torch.nn.Parameter(p_ref.detach().clone().to(dev))
+    made = Optimizer__Union(Adam=Adam(lr=0.05, lr_schedulers=[StepLR(step_size=2, gamma=0.5)])).make_optimizer_scheduler([p_hip])
+    opt, sched = made["optimizer"], made["lr_scheduler"]
+    ref_opt = torch.optim.Adam([p_ref], lr=0.05)
+    ref_sched = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=2, gamma=0.5)
+    g = torch.Generator().manual_seed(1)
+    for step in range(6):
+        grad = torch.randn(300, generator=g)
+        p_ref.grad, p_hip.grad = grad.clone(), grad.clone().to(dev)
+        ref_opt.step()
+        opt.step()
+        ref_sched.step()
+        sched.step()
+        assert opt.param_groups[0]["lr"] == ref_opt.param_groups[0]["lr"]
+    assert opt.param_groups[0]["lr"] == 0.05 * 0.5 ** 3
+    assert (p_hip.detach().cpu() - p_ref.detach()).abs().max() <= 1e-6
+    assert "lr_scheduler" not in Optimizer__Union.default(lr=0.1).make_optimizer_scheduler([torch.nn.Parameter(torch.zeros(4, device=dev))])
