@@ -219,16 +219,19 @@ int rg_sumtree_depth(int64_t capacity);
 size_t rg_sumtree_nodes(int64_t capacity);
 /* SumTree.set for n (index, value) pairs applied in order (a later pair overrides an earlier one on
  * the same index), set_priority :146-157.  `claim`: int32 [2^depth] all -1, scratch for n > 32
- * (returned all -1); nullable -> the in-order single-thread walk is used for any n. */
-int rg_sumtree_set(double* tree, int depth, const int64_t* indices, const double* values, int n,
-                   int* claim, rg_stream_t stream);
+ * (returned all -1); nullable -> the in-order single-thread walk is used for any n.
+ * Indices outside [0, capacity) are skipped, never dereferenced (the reference raises IndexError; the host
+ * wrapper raises it too whenever the indices are host data). */
+int rg_sumtree_set(double* tree, int depth, int64_t capacity, const int64_t* indices, const double* values,
+                   int n, int* claim, rg_stream_t stream);
 /* SumTree.sample :97-131 for n query values in [0, 1] (each scaled by the root, then the
  * reference's descent); stratified_sample :133-153 = queries drawn one per segment by the caller. */
 int rg_sumtree_sample(const double* tree, int depth, const double* query01, int n,
                       int64_t* out_indices, rg_stream_t stream);
-/* leaf values: out32 (float32, get_priority :159-180) and/or out64; either nullable */
-int rg_sumtree_get(const double* tree, int depth, const int64_t* indices, int n, float* out32,
-                   double* out64, rg_stream_t stream);
+/* leaf values: out32 (float32, get_priority :159-180) and/or out64; either nullable; 0 for an index outside
+ * [0, capacity) */
+int rg_sumtree_get(const double* tree, int depth, int64_t capacity, const int64_t* indices, int n,
+                   float* out32, double* out64, rg_stream_t stream);
 
 /* DiscreteDqnInputMaker (reagent/gym/preprocessors/trainer_preprocessor.py:72-97,118-158):
  * action / next_action [B] int64 -> one-hot fp32 [B, A] (next_action rows zeroed where terminal),
@@ -472,11 +475,12 @@ int rg_sac_actor_head(const float* log_prob, const float* q1_actor, const float*
 int rg_sac_alpha_grad(const float* entropy_partials, int batch, const double* log_alpha, double* grad,
                       double* alpha_loss, rg_stream_t stream);
 /* TD3 target-policy smoothing, reagent/training/td3_trainer.py:141-146:
- * out[b, :A] (row pitch ld_out) = clamp(next_actor[b] + clamp(noise[b] * noise_variance, +-noise_clip), lo, hi);
+ * out[b, :A] (row pitch ld_out) = clamp(next_actor[b] + clamp(noise[b] * noise_variance, noise_clip_lo,
+ * noise_clip_hi), lo, hi)   (the reference's `noise.clamp(*self.noise_clip_range)`);
  * noise [B, A] contiguous ~ N(0, 1). */
 int rg_td3_target_action(const float* next_actor, int64_t ld_a, const float* noise, double noise_variance,
-                         double noise_clip, double lo, double hi, float* out, int64_t ld_out, int batch,
-                         int action_dim, rg_stream_t stream);
+                         double noise_clip_lo, double noise_clip_hi, double lo, double hi, float* out,
+                         int64_t ld_out, int batch, int action_dim, rg_stream_t stream);
 
 /* torch.optim.Adam arithmetic in fp64; exp_param_out (nullable) = exp(param) (alpha = exp(log_alpha)). */
 int rg_adam_step_f64(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n,

@@ -121,3 +121,19 @@ def install():
     tr.__path__ = [os.path.join(REFERENCE_ROOT, "reagent", "training")]
     tr._oracle_stub = True
     sys.modules["reagent.training"] = tr
+
+
+def install_gym():
+    """A bare `gym` module plus bypass packages for reagent.gym / reagent.gym.preprocessors, so that the
+    unmodified input makers (reagent/gym/preprocessors/trainer_preprocessor.py:100-227) import without the
+    gym package (absent here) and without reagent/gym/__init__.py (which imports every environment)."""
+    install()
+    if getattr(sys.modules.get("reagent.gym"), "_oracle_stub", False):
+        return
+    spaces = _mod("gym.spaces", Discrete=type("Discrete", (), {}), Box=type("Box", (), {}))
+    _mod("gym", Env=type("Env", (), {}), spaces=spaces)
+    for name, sub in (("reagent.gym", "gym"), ("reagent.gym.preprocessors", os.path.join("gym", "preprocessors"))):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REFERENCE_ROOT, "reagent", sub)]
+        m._oracle_stub = True
+        sys.modules[name] = m

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libreagent_hip.so")
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5}
 LOSS = {"mse": 0, "huber": 1}
@@ -130,7 +130,7 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_int, c_void_p]),
     "rg_act_backward": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "rg_td3_target_action": (c_int, [c_void_p, c_i64, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                     ctypes.c_double, c_void_p, c_i64, c_int, c_int, c_void_p]),
+                                     ctypes.c_double, ctypes.c_double, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "rg_transpose_cast": (c_int, [c_void_p, c_int, c_i64, c_int, c_int, c_void_p, c_i64, c_void_p,
                                    c_i64, c_int, c_void_p]),
     "rg_mlp_fused_supported": (c_int, [ctypes.POINTER(MlpDesc)]),
@@ -154,9 +154,9 @@ SIGNATURES = {
     "rg_mlp_update_fused": (c_int, [ctypes.POINTER(MlpUpdateDesc)] + [ctypes.c_double] * 9 + [c_void_p]),
     "rg_sumtree_depth": (c_int, [c_i64]),
     "rg_sumtree_nodes": (c_sz, [c_i64]),
-    "rg_sumtree_set": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rg_sumtree_set": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rg_sumtree_sample": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "rg_sumtree_get": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "rg_sumtree_get": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_make_dqn_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_normalize_dense": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,

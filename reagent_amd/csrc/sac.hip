@@ -292,17 +292,17 @@ __global__ void add_cols_kernel(const float* __restrict__ a, long lda, const flo
 }
 
 // TD3 target-policy smoothing (reagent/training/td3_trainer.py:141-146):
-//   a' = clamp(actor_target(s') + clamp(noise * noise_variance, -clip, clip), lo, hi)
+//   a' = clamp(actor_target(s') + clamp(noise * noise_variance, clip_lo, clip_hi), lo, hi)
 // written straight into the action columns of the critics' input matrix
 __global__ void td3_target_action_kernel(const float* __restrict__ next_actor, long ld_a,
-                                         const float* __restrict__ noise, float noise_variance, float clip, float lo,
-                                         float hi, float* __restrict__ out, long ld_out, int batch, int A) {
+                                         const float* __restrict__ noise, float noise_variance, float clip_lo,
+                                         float clip_hi, float lo, float hi, float* __restrict__ out, long ld_out, int batch, int A) {
   const long total = (long)batch * A;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long b = i / A;
     const int a = (int)(i % A);
     float n = noise[i] * noise_variance;
-    n = fminf(fmaxf(n, -clip), clip);
+    n = fminf(fmaxf(n, clip_lo), clip_hi);
     const float v = next_actor[b * ld_a + a] + n;
     out[b * ld_out + a] = fminf(fmaxf(v, lo), hi);
   }
@@ -411,14 +411,14 @@ int rg_add_cols(const float* a, int64_t lda, const float* b, int64_t ldb, int ba
 }
 
 int rg_td3_target_action(const float* next_actor, int64_t ld_a, const float* noise, double noise_variance,
-                         double noise_clip, double lo, double hi, float* out, int64_t ld_out, int batch,
-                         int action_dim, rg_stream_t stream) {
+                         double noise_clip_lo, double noise_clip_hi, double lo, double hi, float* out,
+                         int64_t ld_out, int batch, int action_dim, rg_stream_t stream) {
   if (!next_actor || !noise || !out || batch <= 0 || action_dim <= 0) return RG_EINVAL;
   const long total = (long)batch * action_dim;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   RG_LAUNCH(td3_target_action_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, next_actor, (long)ld_a,
-            noise, (float)noise_variance, (float)noise_clip, (float)lo, (float)hi, out, (long)ld_out, batch,
+            noise, (float)noise_variance, (float)noise_clip_lo, (float)noise_clip_hi, (float)lo, (float)hi, out, (long)ld_out, batch,
             action_dim);
   return (int)hipGetLastError();
 }

@@ -25,10 +25,11 @@ __device__ __forceinline__ const double* level_ptr(const double* tree, int d) { 
 
 // one thread applies the updates in order, with SumTree.set's own arithmetic (sum_tree.py:180-187)
 __global__ void sumtree_set_walk_kernel(double* tree, int depth, const int64_t* __restrict__ indices,
-                                        const double* __restrict__ values, int n) {
+                                        const double* __restrict__ values, int n, long capacity) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   for (int j = 0; j < n; ++j) {
     long node = indices[j];
+    if (node < 0 || node >= capacity) continue;  // the reference raises IndexError; checked on the host when it can be
     const double delta = values[j] - level_ptr(tree, depth)[node];
     for (int d = depth; d >= 0; --d) {
       level_ptr(tree, d)[node] += delta;
@@ -39,20 +40,25 @@ __global__ void sumtree_set_walk_kernel(double* tree, int depth, const int64_t* 
 
 // many updates: (1) the LAST position that names a leaf claims it, (2) the claimant writes the
 // leaf and releases the claim, (3) the levels above are rebuilt bottom-up
-__global__ void sumtree_claim_kernel(const int64_t* __restrict__ indices, int n, int* __restrict__ claim) {
+__device__ __forceinline__ bool leaf_ok(long i, long capacity) { return i >= 0 && i < capacity; }
+
+__global__ void sumtree_claim_kernel(const int64_t* __restrict__ indices, int n, int* __restrict__ claim,
+                                     long capacity) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) atomicMax(&claim[indices[j]], j);
+  if (j < n && leaf_ok(indices[j], capacity)) atomicMax(&claim[indices[j]], j);
 }
 
 __global__ void sumtree_scatter_kernel(double* tree, int depth, const int64_t* __restrict__ indices,
-                                       const double* __restrict__ values, int n, const int* __restrict__ claim) {
+                                       const double* __restrict__ values, int n, const int* __restrict__ claim,
+                                       long capacity) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n && claim[indices[j]] == j) level_ptr(tree, depth)[indices[j]] = values[j];
+  if (j < n && leaf_ok(indices[j], capacity) && claim[indices[j]] == j) level_ptr(tree, depth)[indices[j]] = values[j];
 }
 
-__global__ void sumtree_release_kernel(const int64_t* __restrict__ indices, int n, int* __restrict__ claim) {
+__global__ void sumtree_release_kernel(const int64_t* __restrict__ indices, int n, int* __restrict__ claim,
+                                       long capacity) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) claim[indices[j]] = -1;
+  if (j < n && leaf_ok(indices[j], capacity)) claim[indices[j]] = -1;
 }
 
 // one level: parent = left + right
@@ -93,10 +99,10 @@ __global__ void sumtree_sample_kernel(const double* __restrict__ tree, int depth
 }
 
 __global__ void sumtree_get_kernel(const double* __restrict__ tree, int depth, const int64_t* __restrict__ indices,
-                                   int n, float* __restrict__ out32, double* __restrict__ out64) {
+                                   int n, float* __restrict__ out32, double* __restrict__ out64, long capacity) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const double v = level_ptr(tree, depth)[indices[j]];
+  const double v = leaf_ok(indices[j], capacity) ? level_ptr(tree, depth)[indices[j]] : 0.0;
   if (out32) out32[j] = (float)v;  // get_priority returns float32 (prioritized_replay_buffer.py:176)
   if (out64) out64[j] = v;
 }
@@ -119,19 +125,21 @@ size_t rg_sumtree_nodes(int64_t capacity) {
   return depth < 0 ? 0 : (size_t)((1L << (depth + 1)) - 1);
 }
 
-int rg_sumtree_set(double* tree, int depth, const int64_t* indices, const double* values, int n, int* claim,
-                   rg_stream_t stream) {
+int rg_sumtree_set(double* tree, int depth, int64_t capacity, const int64_t* indices, const double* values, int n,
+                   int* claim, rg_stream_t stream) {
   if (!tree || depth < 0 || depth > 40 || n < 0 || (n > 0 && (!indices || !values))) return RG_EINVAL;
+  if (capacity <= 0 || capacity > (1L << depth)) return RG_EINVAL;
   if (n == 0) return RG_OK;
   hipStream_t s = (hipStream_t)stream;
   if (n <= 32 || !claim) {
-    RG_LAUNCH(sumtree_set_walk_kernel, dim3(1), dim3(64), s, tree, depth, indices, values, n);
+    RG_LAUNCH(sumtree_set_walk_kernel, dim3(1), dim3(64), s, tree, depth, indices, values, n, (long)capacity);
     return (int)hipGetLastError();
   }
   const dim3 grid((n + 255) / 256), block(256);
-  RG_LAUNCH(sumtree_claim_kernel, grid, block, s, indices, n, claim);
-  RG_LAUNCH(sumtree_scatter_kernel, grid, block, s, tree, depth, indices, values, n, (const int*)claim);
-  RG_LAUNCH(sumtree_release_kernel, grid, block, s, indices, n, claim);
+  RG_LAUNCH(sumtree_claim_kernel, grid, block, s, indices, n, claim, (long)capacity);
+  RG_LAUNCH(sumtree_scatter_kernel, grid, block, s, tree, depth, indices, values, n, (const int*)claim,
+            (long)capacity);
+  RG_LAUNCH(sumtree_release_kernel, grid, block, s, indices, n, claim, (long)capacity);
   int d = depth - 1;
   for (; d > 10; --d)
     RG_LAUNCH(sumtree_level_kernel, dim3((unsigned)(((1L << d) + 255) / 256)), dim3(256), s, tree, d);
@@ -148,12 +156,13 @@ int rg_sumtree_sample(const double* tree, int depth, const double* query01, int 
   return (int)hipGetLastError();
 }
 
-int rg_sumtree_get(const double* tree, int depth, const int64_t* indices, int n, float* out32, double* out64,
-                   rg_stream_t stream) {
+int rg_sumtree_get(const double* tree, int depth, int64_t capacity, const int64_t* indices, int n, float* out32,
+                   double* out64, rg_stream_t stream) {
   if (!tree || depth < 0 || n < 0 || (n > 0 && (!indices || (!out32 && !out64)))) return RG_EINVAL;
+  if (capacity <= 0 || capacity > (1L << depth)) return RG_EINVAL;
   if (n == 0) return RG_OK;
   RG_LAUNCH(sumtree_get_kernel, dim3((n + 255) / 256), dim3(256), (hipStream_t)stream, tree, depth, indices, n, out32,
-            out64);
+            out64, (long)capacity);
   return (int)hipGetLastError();
 }
 

@@ -135,14 +135,14 @@ def act_backward(dy, y, act: int, dz):
                                          L.stream_ptr()))
 
 
-def td3_target_action(next_actor, noise, noise_variance, noise_clip, lo, hi, out):
+def td3_target_action(next_actor, noise, noise_variance, noise_clip_range, lo, hi, out):
     """out (a [B, A] view, e.g. the action columns of the critic input) = smoothed target action"""
     _chk_dev(next_actor, noise, out)
     B, A = next_actor.shape
     assert noise.is_contiguous() and noise.shape == (B, A) and next_actor.stride(1) == 1 and out.stride(1) == 1
     _run("rg_td3_target_action", dict(B=B, A=A),
          lambda: L.lib().rg_td3_target_action(L.ptr(next_actor), _ld(next_actor), L.ptr(noise), float(noise_variance),
-                                              float(noise_clip), float(lo), float(hi), L.ptr(out), _ld(out), B, A,
+                                              float(noise_clip_range[0]), float(noise_clip_range[1]), float(lo), float(hi), L.ptr(out), _ld(out), B, A,
                                               L.stream_ptr()))
 
 
@@ -198,12 +198,12 @@ def replay_gather(cols, capacity: int, stack: int, batch: int):
              lambda: L.lib().rg_replay_gather(arr, len(chunk), capacity, stack, batch, L.stream_ptr()))
 
 
-def sumtree_set(tree, depth: int, indices, values, claim=None):
+def sumtree_set(tree, depth: int, capacity: int, indices, values, claim=None):
     """SumTree.set for every (index, value) pair, in order (sum_tree.py:159-189)."""
     _chk_dev(tree, indices, values, claim)
     assert tree.dtype == torch.float64 and values.dtype == torch.float64 and indices.dtype == torch.int64
     _run("rg_sumtree_set", dict(n=indices.numel()),
-         lambda: L.lib().rg_sumtree_set(L.ptr(tree), depth, L.ptr(indices), L.ptr(values), indices.numel(),
+         lambda: L.lib().rg_sumtree_set(L.ptr(tree), depth, capacity, L.ptr(indices), L.ptr(values), indices.numel(),
                                         L.ptr(claim), L.stream_ptr()))
 
 
@@ -216,11 +216,11 @@ def sumtree_sample(tree, depth: int, query01, out_indices):
                                            L.stream_ptr()))
 
 
-def sumtree_get(tree, depth: int, indices, out32=None, out64=None):
+def sumtree_get(tree, depth: int, capacity: int, indices, out32=None, out64=None):
     _chk_dev(tree, indices, out32, out64)
     assert tree.dtype == torch.float64 and indices.dtype == torch.int64
     _run("rg_sumtree_get", dict(n=indices.numel()),
-         lambda: L.lib().rg_sumtree_get(L.ptr(tree), depth, L.ptr(indices), indices.numel(), L.ptr(out32),
+         lambda: L.lib().rg_sumtree_get(L.ptr(tree), depth, capacity, L.ptr(indices), indices.numel(), L.ptr(out32),
                                         L.ptr(out64), L.stream_ptr()))
 
 

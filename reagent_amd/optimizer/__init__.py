@@ -33,21 +33,61 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("amsgrad/maximize are not on the ReAgent hot path")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
-        self._slabs = {}
+        self._moments = {}  # group index -> (slab, exp_avg, exp_avg_sq): THIS optimizer's flat moment buffers
         self.grad_scale = 1.0
 
     def slab_for(self, gi: int) -> ParamSlab:
+        return self.moments_for(gi)[0]
+
+    def moments_for(self, gi: int):
+        """(parameter slab, exp_avg, exp_avg_sq) of group gi.  The moment buffers belong to the optimizer
+        instance (a second FusedAdam over the same network starts from zero moments like a second
+        torch.optim.Adam would); state[p]["exp_avg"/"exp_avg_sq"] are views into them."""
         group = self.param_groups[gi]
         slab = ensure_slab(group["params"])
-        if self._slabs.get(gi) is not slab or not hasattr(slab, "exp_avg"):
-            if not hasattr(slab, "exp_avg"):
-                slab.exp_avg = torch.zeros_like(slab.data)
-                slab.exp_avg_sq = torch.zeros_like(slab.data)
-            self._slabs[gi] = slab
-        if slab.exp_avg.device != slab.data.device:
-            slab.exp_avg = slab.exp_avg.to(slab.data.device)
-            slab.exp_avg_sq = slab.exp_avg_sq.to(slab.data.device)
-        return slab
+        rec = self._moments.get(gi)
+        if rec is None or rec[0] is not slab or rec[1].numel() != slab.total:
+            m, v = torch.zeros_like(slab.data), torch.zeros_like(slab.data)
+            for i, p in enumerate(slab.params):  # moments that already exist (loaded state, re-homed slab)
+                st = self.state.get(p)
+                if st:
+                    slab.view(m, i).copy_(st["exp_avg"])
+                    slab.view(v, i).copy_(st["exp_avg_sq"])
+                    st["exp_avg"], st["exp_avg_sq"] = slab.view(m, i), slab.view(v, i)
+            rec = self._moments[gi] = (slab, m, v)
+        if rec[1].device != slab.data.device:
+            m, v = rec[1].to(slab.data.device), rec[2].to(slab.data.device)
+            rec = self._moments[gi] = (slab, m, v)
+            for i, p in enumerate(slab.params):
+                st = self.state.get(p)
+                if st:
+                    st["exp_avg"], st["exp_avg_sq"] = slab.view(m, i), slab.view(v, i)
+        return rec
+
+    def advance(self, gi: int, i: int) -> int:
+        """count one more step of parameter i of group gi; returns the new step number"""
+        slab, m, v = self.moments_for(gi)
+        p = slab.params[i]
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = slab.view(m, i)
+            st["exp_avg_sq"] = slab.view(v, i)
+        st["step"] += 1
+        return int(st["step"])
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam's state_dict layout (step / exp_avg / exp_avg_sq per parameter): the loaded
+        moments are copied INTO the flat buffers the kernel reads and state[p] re-bound to views of them."""
+        super().load_state_dict(state_dict)
+        self._moments = {}
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st.pop("_step_int", None)
+                    st["step"] = torch.tensor(float(st["step"]))  # own copy: torch hands the saved tensor through
+            self.moments_for(gi)  # adopts the loaded tensors
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -56,7 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
-            slab = self.slab_for(gi)
+            slab, exp_avg, exp_avg_sq = self.moments_for(gi)
             beta1, beta2 = group["betas"]
             # collect gradients into the flat slab (zero-copy when backward already wrote there)
             runs: List[Tuple[int, int, int]] = []  # (offset, n, step)
@@ -67,15 +107,7 @@ class FusedAdam(torch.optim.Optimizer):
                 off, n = slab.offsets[i], p.numel()
                 if p.grad.data_ptr() != gbase + 4 * off:
                     slab.view(slab.grad, i).copy_(p.grad)
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = slab.view(slab.exp_avg, i)
-                    st["exp_avg_sq"] = slab.view(slab.exp_avg_sq, i)
-                    st["_step_int"] = 0
-                st["_step_int"] += 1
-                st["step"] += 1
-                step = st["_step_int"]
+                step = self.advance(gi, i)
                 padded = (n + ParamSlab.ALIGN - 1) // ParamSlab.ALIGN * ParamSlab.ALIGN
                 if runs and runs[-1][0] + runs[-1][1] == off and runs[-1][2] == step:
                     runs[-1] = (runs[-1][0], runs[-1][1] + padded, step)
@@ -84,7 +116,7 @@ class FusedAdam(torch.optim.Optimizer):
             for off, n, step in runs:
                 bc1 = 1.0 - beta1**step
                 bc2_sqrt = math.sqrt(1.0 - beta2**step)
-                ops.adam_step(slab.data, slab.grad, slab.exp_avg, slab.exp_avg_sq, n, group["lr"],
+                ops.adam_step(slab.data, slab.grad, exp_avg, exp_avg_sq, n, group["lr"],
                               beta1, beta2, group["eps"], group["weight_decay"], bc1, bc2_sqrt,
                               self.grad_scale, offset=off)
             _bump(slab.params)

@@ -76,7 +76,17 @@ class SumTree:
                       torch.tensor([float(value)], dtype=torch.float64))
 
     # ---- batched forms -----------------------------------------------------------------------
+    def _check_indices(self, idx: torch.Tensor) -> None:
+        """IndexError for a leaf outside [0, capacity) like the reference's list indexing (which, unlike
+        here, lets negative indices wrap) — on host data only; indices that already live on the device
+        are not synchronised for and the kernels skip out-of-range ones"""
+        if idx.device.type == "cpu" and idx.numel() > 0:
+            lo, hi = int(idx.min()), int(idx.max())
+            if lo < 0 or hi >= self.capacity:
+                raise IndexError(f"sum tree index out of range: [{lo}, {hi}] for capacity {self.capacity}")
+
     def _set_dev(self, indices: torch.Tensor, values: torch.Tensor, sequential: bool = False) -> None:
+        self._check_indices(indices)
         indices = indices.to(device=self.device, dtype=torch.int64).contiguous()
         values = values.to(device=self.device, dtype=torch.float64).contiguous()
         claim = None
@@ -84,7 +94,7 @@ class SumTree:
             if self._claim is None:
                 self._claim = torch.full((1 << self.depth,), -1, dtype=torch.int32, device=self.device)
             claim = self._claim
-        ops.sumtree_set(self._tree, self.depth, indices, values, claim)
+        ops.sumtree_set(self._tree, self.depth, self.capacity, indices, values, claim)
 
     def set_many(self, indices, values, sequential: bool = False) -> None:
         """`for i, v in zip(indices, values): self.set(i, v)` as one update (later pairs win).
@@ -103,13 +113,14 @@ class SumTree:
 
     def get_many(self, indices, dtype=torch.float32) -> torch.Tensor:
         idx = indices if isinstance(indices, torch.Tensor) else torch.as_tensor(np.asarray(indices, dtype=np.int64))
+        self._check_indices(idx)
         idx = idx.to(device=self.device, dtype=torch.int64).contiguous()
         out = torch.empty(idx.numel(), dtype=dtype, device=self.device)
         if dtype == torch.float32:
-            ops.sumtree_get(self._tree, self.depth, idx, out32=out)
+            ops.sumtree_get(self._tree, self.depth, self.capacity, idx, out32=out)
         else:
             assert dtype == torch.float64
-            ops.sumtree_get(self._tree, self.depth, idx, out64=out)
+            ops.sumtree_get(self._tree, self.depth, self.capacity, idx, out64=out)
         return out
 
     def sample_many(self, query_values) -> torch.Tensor:

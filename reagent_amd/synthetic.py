@@ -94,3 +94,29 @@ def replay_contents(capacity: int, obs_dim: int, num_actions: int, seed: int = 0
         possible_actions_mask=torch.ones(capacity, num_actions),
         log_prob=torch.zeros(capacity),
     )
+
+
+def fc_init(dims, activations, seed: int = 0):
+    """Seeded weights for a FullyConnected stack, drawn like the reference's initialiser
+    (reagent/models/fully_connected_network.py:21-23,122-126: W ~ N(0, (gain * sqrt(1/fan_in))^2), b = 0)
+    from an explicit CPU generator.  The BASELINE-shape goldens (oracle/make_golden.py, `baseline_*`) load
+    these into the reference networks and the parity tests load them into the HIP-backed ones, so fixtures
+    of 0.6-2.2 M parameters do not have to carry their initial weights."""
+    import math
+
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i, (fan_in, fan_out) in enumerate(zip(dims, dims[1:])):
+        try:
+            gain = torch.nn.init.calculate_gain(activations[i])
+        except ValueError:
+            gain = 1.0
+        out.append(torch.randn(fan_out, fan_in, generator=g) * (gain * math.sqrt(1.0 / fan_in)))
+        out.append(torch.zeros(fan_out))
+    return out
+
+
+def normalization_table(n_features: int, seed: int = 7):
+    """(mean, stddev) of n CONTINUOUS features: mean ~ N(0,1), stddev ~ U[0.5, 2)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n_features, generator=g), torch.rand(n_features, generator=g) * 1.5 + 0.5

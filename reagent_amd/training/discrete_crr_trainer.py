@@ -19,7 +19,7 @@ from ..core import types as rlt
 from ..core.parameters import EvaluationParameters, RLParameters
 from ..engine import ensure_slab
 from ..optimizer import Optimizer__Union, SoftUpdate
-from .dqn_trainer import _CpeEngine, _SegmentLoss
+from .dqn_trainer import _CpeEngine, _SegmentLoss, dp_reduce, held_gradients, native_step, publish_gradients
 from .dqn_trainer_base import DQNTrainerBaseLightning
 
 
@@ -139,17 +139,11 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
             self._losses = {n: torch.empty(1, **f) for n in ("q1", "q2", "plain", "entropy", "actor")}
             self._ws_batch = B
 
-    def _publish(self, e):
+    def _publish(self, e, held=()):
         slab = e["slab"]
         if self._dp_group is not None:
-            torch.distributed.all_reduce(slab.grad, group=self._dp_group)
-        base = slab.grad.data_ptr()
-        for i, p in enumerate(e["params"]):
-            gv = slab.view(slab.grad, i)
-            if p.grad is None or p.grad.data_ptr() == base + 4 * slab.offsets[i]:
-                p.grad = gv
-            else:
-                p.grad.add_(gv)
+            dp_reduce(self, slab)
+        publish_gradients(slab, e["params"], held)
 
     # ---- segments --------------------------------------------------------------------------------
     def _critic_forward(self, b):
@@ -203,8 +197,9 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
         dq = self._dq1 if which == "q1" else self._dq2
         if grad_out is not None:
             dq = dq * grad_out
+        held = held_gradients(e["slab"], e["params"])
         e["stack"].backward(dq, self._x1_t if which == "q1" else self._x2_t, e["dw"], e["db"])
-        self._publish(e)
+        self._publish(e, held)
 
     def _actor_forward(self, b, with_loss: bool):
         """all_q_values = q1_network(state) with the weights its optimizer just produced (:327), the
@@ -249,8 +244,9 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
         d = self._dscores if grad_out is None else self._dscores * grad_out
         if self._clamp_passes is not None:  # backward of the exploration clamp
             d = d * self._clamp_passes
+        held = held_gradients(a["slab"], a["params"])
         a["stack"].backward(d, self._xs_t, a["dw"], a["db"], out32=self._raw_scores)
-        self._publish(a)
+        self._publish(a, held)
 
     # ---- CPE hooks (dqn_trainer_base.py:338-452 as called at :354-363) ---------------------------
     def _cpe_next_action_scores(self, next_state, out):
@@ -313,6 +309,7 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
         return self
 
     @torch.no_grad()
+    @native_step
     def train_step_native(self, training_batch, batch_idx: Optional[int] = None):
         """the same segments and optimizer order with no autograd graph / generator / host sync"""
         opts = iter(self.native_optimizers())

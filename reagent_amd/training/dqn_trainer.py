@@ -61,6 +61,66 @@ class _SegmentLoss(torch.autograd.Function):
         return (None, None) + (None,) * ctx.n
 
 
+def dp_reduce(tr, slab):
+    """Sum the gradient slab over the data-parallel group (RCCL).  Inside a native step the 1/world factor
+    is folded into the Adam launch (grad_scale); on the generator / Lightning path the optimizers are
+    stepped by the caller, so the sum is turned into the mean here and Adam, weight decay and any gradient
+    clipping see what a single rank would on the concatenated batch."""
+    torch.distributed.all_reduce(slab.grad, group=tr._dp_group)
+    if not getattr(tr, "_native_active", False):
+        slab.grad.mul_(1.0 / tr._dp_world)
+
+
+class _NativeStep:
+    """marks the trainer as inside a native step (see dp_reduce)"""
+
+    def __init__(self, tr):
+        self.tr = tr
+
+    def __enter__(self):
+        self.prev = getattr(self.tr, "_native_active", False)
+        self.tr._native_active = True
+
+    def __exit__(self, *exc):
+        self.tr._native_active = self.prev
+
+
+def held_gradients(slab, params):
+    """A backward without a preceding zero_grad() accumulates in PyTorch, but the HIP backward OVERWRITES
+    the gradient slab.  Returns copies of the gradients still published through p.grad (aliases of the
+    slab) so that `publish_gradients` can add them back; empty when the gradients were cleared
+    (`zero_grad(set_to_none=True)`, every native step)."""
+    base = slab.grad.data_ptr()
+    return [(i, slab.view(slab.grad, i).clone()) for i, p in enumerate(params)
+            if p.grad is not None and p.grad.data_ptr() == base + 4 * slab.offsets[i]]
+
+
+def publish_gradients(slab, params, held=()):
+    """p.grad aliases the slab the backward wrote (gradients held over a missing zero_grad() are added
+    back; foreign .grad tensors are accumulated into)"""
+    for i, g in held:
+        slab.view(slab.grad, i).add_(g)
+    base = slab.grad.data_ptr()
+    for i, p in enumerate(params):
+        gv = slab.view(slab.grad, i)
+        if p.grad is None or p.grad.data_ptr() == base + 4 * slab.offsets[i]:
+            p.grad = gv
+        else:
+            p.grad.add_(gv)
+
+
+def native_step(fn):
+    """decorator for train_step_native of the trainers: the whole call runs as a native step"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with _NativeStep(self):
+            return fn(self, *a, **k)
+
+    return wrapper
+
+
 class _CpeEngine:
     """The CPE part of the DQN step (reagent/training/dqn_trainer_base.py:338-452, `_calculate_cpes`):
     reward network and CPE q-network on `state`, CPE target network on `next_state`, the 4th forward
@@ -137,17 +197,12 @@ class _CpeEngine:
         d = self.d_reward if which == "reward" else self.d_cpe
         if grad_out is not None:
             d = d * grad_out
+        held = held_gradients(e["slab"], e["params"])
         e["stack"].backward(d, self._xs_t_r if which == "reward" else self._xs_t_c, e["dw"], e["db"])
         slab = e["slab"]
         if self.tr._dp_group is not None:
-            torch.distributed.all_reduce(slab.grad, group=self.tr._dp_group)
-        base = slab.grad.data_ptr()
-        for i, p in enumerate(e["params"]):
-            gv = slab.view(slab.grad, i)
-            if p.grad is None or p.grad.data_ptr() == base + 4 * slab.offsets[i]:
-                p.grad = gv
-            else:
-                p.grad.add_(gv)
+            dp_reduce(self.tr, slab)
+        publish_gradients(slab, e["params"], held)
 
     def loss(self, which):
         e = self.e[which]
@@ -311,21 +366,15 @@ class QStepCore(DQNTrainerBaseLightning):
     def _hip_backward(self, grad_out=None, async_reduce: bool = False):
         if grad_out is not None:
             self._dq.mul_(grad_out)
+        held = held_gradients(self._slab, self._hip_params)
         self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
         if self._dp_group is not None:
             if async_reduce:  # runs on the collective's own stream; joined by apply_pending_update()
                 self._pending_reduce = torch.distributed.all_reduce(self._slab.grad, group=self._dp_group,
                                                                    async_op=True)
             else:
-                torch.distributed.all_reduce(self._slab.grad, group=self._dp_group)
-        # publish the gradients: p.grad aliases the slab (accumulate into foreign .grad tensors)
-        base = self._slab.grad.data_ptr()
-        for i, p in enumerate(self._hip_params):
-            gv = self._slab.view(self._slab.grad, i)
-            if p.grad is None or p.grad.data_ptr() == base + 4 * self._slab.offsets[i]:
-                p.grad = gv
-            else:
-                p.grad.add_(gv)
+                dp_reduce(self, self._slab)
+        publish_gradients(self._slab, self._hip_params, held)
 
     # ---- data parallel -------------------------------------------------------
     def enable_data_parallel(self, process_group=None):
@@ -371,7 +420,8 @@ class QStepCore(DQNTrainerBaseLightning):
         for p in self._hip_params:
             p.grad = None
         deferred = defer_update and self._dp_group is not None
-        self._hip_backward(None, async_reduce=deferred)
+        with _NativeStep(self):
+            self._hip_backward(None, async_reduce=deferred)
         self._update_pending = True
         self._pending_batch = training_batch if getattr(self, "_cpe", None) is not None else None
         if not deferred:
@@ -426,26 +476,17 @@ class QStepCore(DQNTrainerBaseLightning):
                 return False
         if any(w is None for w in qs._wf) or any(w is None for w in qs._wb) or any(w is None for w in ts._wf):
             return False  # fragments not staged yet (their padding is written by the first staging)
-        slab, tslab, d = adam.slab_for(0), plan["tslab"], plan["desc"]
+        (slab, exp_avg, exp_avg_sq), tslab, d = adam.moments_for(0), plan["tslab"], plan["desc"]
         if slab is not self._slab or not tslab.is_bound():
             return False
         group = adam.param_groups[0]
         beta1, beta2 = group["betas"]
-        step = None
-        for i, p in enumerate(slab.params):
-            st = adam.state[p]
-            if len(st) == 0:
-                st["step"] = torch.tensor(0.0)
-                st["exp_avg"] = slab.view(slab.exp_avg, i)
-                st["exp_avg_sq"] = slab.view(slab.exp_avg_sq, i)
-                st["_step_int"] = 0
-            st["_step_int"] += 1
-            st["step"] += 1
-            step = st["_step_int"] if step is None else step
-            if st["_step_int"] != step:
-                raise RuntimeError("fused update needs every parameter at the same Adam step")
+        steps = {adam.advance(0, i) for i in range(len(slab.params))}
+        if len(steps) != 1:
+            raise RuntimeError("fused update needs every parameter at the same Adam step")
+        step = steps.pop()
         d.param, d.grad = slab.data.data_ptr(), slab.grad.data_ptr()
-        d.exp_avg, d.exp_avg_sq = slab.exp_avg.data_ptr(), slab.exp_avg_sq.data_ptr()
+        d.exp_avg, d.exp_avg_sq = exp_avg.data_ptr(), exp_avg_sq.data_ptr()
         d.target = tslab.data.data_ptr()
         for l in range(d.n_layers):
             d.wfrag_fwd[l], d.wfrag_bwd[l] = qs._wf[l].data_ptr(), qs._wb[l].data_ptr()
@@ -470,6 +511,10 @@ class QStepCore(DQNTrainerBaseLightning):
         """Adam + soft update of the last backward, after joining its gradient all-reduce."""
         if not self._update_pending:
             return
+        with _NativeStep(self):
+            self._apply_pending_update()
+
+    def _apply_pending_update(self):
         if self._pending_reduce is not None:
             self._pending_reduce.wait()  # the compute stream waits for the collective; the host does not
             self._pending_reduce = None

@@ -27,6 +27,7 @@ from ..core import types as rlt
 from ..core.parameters import RLParameters
 from ..engine import ensure_slab
 from ..optimizer import Optimizer__Union, SoftUpdate
+from .dqn_trainer import dp_reduce, held_gradients, native_step, publish_gradients
 from .reagent_lightning_module import ReAgentLightningModule
 from .rl_trainer_pytorch import RLTrainerMixin
 
@@ -197,17 +198,11 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         t = t if t.dtype == torch.float32 else t.float()
         return t if t.is_contiguous() else t.contiguous()
 
-    def _publish(self, e):
+    def _publish(self, e, held=()):
         slab = e["slab"]
         if self._dp_group is not None:
-            torch.distributed.all_reduce(slab.grad, group=self._dp_group)
-        base = slab.grad.data_ptr()
-        for i, p in enumerate(e["params"]):
-            gv = slab.view(slab.grad, i)
-            if p.grad is None or p.grad.data_ptr() == base + 4 * slab.offsets[i]:
-                p.grad = gv
-            else:
-                p.grad.add_(gv)
+            dp_reduce(self, slab)
+        publish_gradients(slab, e["params"], held)
 
     # ---- segments ----------------------------------------------------------------------------------
     def _critic_forward(self, b, noise_next):
@@ -257,8 +252,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         dq = self._dq1 if which == "q1" else self._dq2
         if grad_out is not None:
             dq = dq * grad_out
+        held = held_gradients(e["slab"], e["params"])
         e["stack"].backward(dq, self._x_t, e["dw"], e["db"])
-        self._publish(e)
+        self._publish(e, held)
 
     def _actor_forward(self, b, noise_cur):
         state = self._f32c(b.state.float_features)
@@ -294,8 +290,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         ops.gaussian_head_backward(self._ls, self._noise_cur, self._ga, self._glp.reshape(-1), self._dls)
         dls = self._dls if grad_out is None else self._dls * grad_out
         a = e["actor"]
+        held = held_gradients(a["slab"], a["params"])
         a["stack"].backward(dls, self._xs_t, a["dw"], a["db"])
-        self._publish(a)
+        self._publish(a, held)
 
     def _alpha_backward(self, grad_out=None):
         ops.sac_alpha_grad(self._parts["ent"], self._B, self.log_alpha.data, self._alpha_grad, self._alpha_loss)
@@ -352,6 +349,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         return self
 
     @torch.no_grad()
+    @native_step
     def train_step_native(self, training_batch, noise_next=None, noise_cur=None):
         """All five segments with no autograd graph / generator / host sync.  Returns the dict of
         device-resident loss scalars."""

@@ -20,6 +20,7 @@ from ..engine import ensure_slab
 from ..optimizer import Optimizer__Union, SoftUpdate
 from .reagent_lightning_module import ReAgentLightningModule
 from .rl_trainer_pytorch import RLTrainerMixin
+from .dqn_trainer import dp_reduce, held_gradients, native_step, publish_gradients
 from .sac_trainer import _SegmentLoss
 
 CONTINUOUS_TRAINING_ACTION_RANGE = (-1.0, 1.0)  # reagent/core/parameters.py:20
@@ -115,17 +116,11 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         t = t if t.dtype == torch.float32 else t.float()
         return t if t.is_contiguous() else t.contiguous()
 
-    def _publish(self, e):
+    def _publish(self, e, held=()):
         slab = e["slab"]
         if self._dp_group is not None:
-            torch.distributed.all_reduce(slab.grad, group=self._dp_group)
-        base = slab.grad.data_ptr()
-        for i, p in enumerate(e["params"]):
-            gv = slab.view(slab.grad, i)
-            if p.grad is None or p.grad.data_ptr() == base + 4 * slab.offsets[i]:
-                p.grad = gv
-            else:
-                p.grad.add_(gv)
+            dp_reduce(self, slab)
+        publish_gradients(slab, e["params"], held)
 
     # ---- segments --------------------------------------------------------------------------------
     def _critic_forward(self, b, noise):
@@ -148,7 +143,7 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         if self.actor_network_target.exploration_variance is not None:  # `.action` carries the exploration noise
             self._next_actor.copy_(self.actor_network_target.explore(self._next_actor)[0])
         self._xn[:, :S].copy_(next_state)
-        ops.td3_target_action(self._next_actor, noise, self.noise_variance, self.noise_clip_range[1],
+        ops.td3_target_action(self._next_actor, noise, self.noise_variance, self.noise_clip_range,
                               CONTINUOUS_TRAINING_ACTION_RANGE[0], CONTINUOUS_TRAINING_ACTION_RANGE[1],
                               self._xn[:, S:])
         xn_c, _ = t["q1"].stage_input(self._xn, need_transposed=False)
@@ -179,8 +174,9 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         dq = self._dq1 if which == "q1" else self._dq2
         if grad_out is not None:
             dq = dq * grad_out
+        held = held_gradients(e["slab"], e["params"])
         e["stack"].backward(dq, self._x_t, e["dw"], e["db"])
-        self._publish(e)
+        self._publish(e, held)
 
     def _actor_forward(self, b):
         state = self._f32c(b.state.float_features)
@@ -211,8 +207,9 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         da = self._dx1[:, S:]
         if self._clamp_passes is not None:  # backward of the exploration clamp
             da = da * self._clamp_passes
+        held = held_gradients(a["slab"], a["params"])
         a["stack"].backward(da, self._xs_t, a["dw"], a["db"], out32=self._a_out)
-        self._publish(a)
+        self._publish(a, held)
 
     def _noise(self, B, A, dev, given):
         if given is not None:
@@ -260,6 +257,7 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         return self
 
     @torch.no_grad()
+    @native_step
     def train_step_native(self, training_batch, noise=None, batch_idx: Optional[int] = None):
         """critic segments, and on every delayed_policy_update-th call the actor segment and the soft
         update, with no autograd graph / generator / host sync"""

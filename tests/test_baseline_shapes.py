@@ -1,0 +1,237 @@
+"""The BENCHMARKED code path against the unmodified reference at BASELINE.json's layer shapes
+(tests/golden/baseline_c{2,3,4}.npz, made by `python -m oracle.make_golden baseline`):
+
+  C2  replay gather -> input maker -> Preprocessor x2 -> DQN step, net 128-512-512-512-16, B=2048 —
+      driven exactly as bench.py drives it (OfflineDqnLoop: rg_replay_dqn_batch -> train_step_native with
+      the deferred rg_mlp_update_fused), in fp32 parity mode, bf16x3 accurate-MFMA mode and bf16 throughput mode
+  C3  QR-DQN N=200 (3200-wide output layer), B=256
+  C4  SAC, actor + twin critics, S=256, A=32, H=3x512, B=1024
+
+Tolerances (BASELINE.json north_star): accurate modes (f32, bf16x3) — Q-values / policy logits within 1e-4,
+loss within 1e-4 rel, post-step weights within 2e-5.  bf16 throughput mode: the measured errors are
+PRINTED (run with -s) and bounded by stated, looser limits.
+Big tensors are compared through the fixture's digest: full biases, every 61st weight, fp64 sums.
+"""
+import numpy as np
+import pytest
+import torch
+
+import reagent_amd._lib as L
+from golden_util import Golden
+from reagent_amd import synthetic
+from reagent_amd.core.parameters import EvaluationParameters, NormalizationParameters, RLParameters
+from reagent_amd.models import (FullyConnectedCritic, FullyConnectedDQN, GaussianFullyConnectedActor,
+                                set_default_precision)
+from reagent_amd.optimizer import Optimizer__Union
+
+W_STRIDE = 61  # oracle/make_golden.py
+
+
+def digest(t):
+    a = t.detach().cpu().numpy().reshape(-1)
+    return torch.from_numpy(a if a.size <= 8192 else a[::W_STRIDE].copy())
+
+
+def digest_err(t, g, key):
+    return (digest(t) - g.t(key)).abs().max().item()
+
+
+def check_regenerated(t, g, key):
+    """inputs / initial weights are regenerated from seeds on both sides: must be the same bits"""
+    assert torch.equal(digest(t), g.t(key)), key
+    a = t.detach().cpu().numpy().reshape(-1).astype(np.float64)
+    assert np.array_equal(np.array([a.sum(), (a * a).sum()]), g.a(key + "_sums")), key
+
+
+def load_init(net, dims, acts, seed, g=None, prefix=None):
+    init = synthetic.fc_init(dims, acts, seed)
+    with torch.no_grad():
+        for p, w in zip(net.parameters(), init):
+            assert p.shape == w.shape
+            p.copy_(w)
+    if g is not None:
+        for i, p in enumerate(net.parameters()):
+            check_regenerated(p, g, f"{prefix}{i}")
+
+
+MODES = {"f32": L.PREC_F32, "bf16x3": L.PREC_BF16X3, "bf16": L.PREC_BF16}
+ACCURATE = ("f32", "bf16x3")
+
+
+def _with_precision(prec, fn):
+    set_default_precision(prec)
+    try:
+        return fn()
+    finally:
+        set_default_precision(L.PREC_F32)
+
+
+# ---- C2: the loop bench.py times -----------------------------------------------------------------
+def build_c2(g, device, mode):
+    from reagent_amd.preprocessing import Preprocessor
+    from reagent_amd.replay_memory import ReplayBuffer
+    from reagent_amd.runtime import OfflineDqnLoop
+    from reagent_amd.training import DQNTrainer
+
+    c = g.cfg
+    S, A, B, C = c["state_dim"], c["num_actions"], c["batch"], c["capacity"]
+    q = _with_precision(MODES[mode], lambda: FullyConnectedDQN(S, A, c["sizes"], c["activations"]))
+    load_init(q, [S] + c["sizes"] + [A], c["activations"] + ["linear"], c["init_seed"], g, "init_param_")
+    q = q.to(device)
+    tr = DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(A)], rl=RLParameters(**c["rl"]),
+                    double_q_learning=c["double_q"], optimizer=Optimizer__Union.default(lr=c["lr"]),
+                    evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(device)
+    cols = synthetic.replay_contents(C, S, A, seed=c["replay_seed"], p_terminal=c["p_terminal"])
+    rb = ReplayBuffer(replay_capacity=C, batch_size=B, device=device)
+    rb.load_columns({k: v.to(device) for k, v in cols.items()})
+    assert np.array_equal(rb._is_index_valid.numpy(), g.a("valid_mask"))  # closed-form validity == 8192 adds
+    mean, std = synthetic.normalization_table(S, c["norm_seed"])
+    pre = Preprocessor({i: NormalizationParameters(feature_type="CONTINUOUS", mean=mean[i].item(), stddev=std[i].item())
+                        for i in range(S)}, device=device)
+    loop = OfflineDqnLoop(rb, tr, B, pre, state_dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+    return loop, tr
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_c2_loop_matches_reference(backend, mode):
+    from reagent_amd.engine import FusedMLP
+
+    if backend.name == "emu" and mode != "bf16":
+        pytest.skip("the SIMT interpreter runs the 2048-row C2 step in the fused bf16 mode only (time)")
+    g = Golden("baseline_c2")
+    loop, tr = build_c2(g, backend.device, mode)
+    steps = g.cfg["steps"] if backend.name == "hip" else 1
+    for s in range(steps):
+        idx = g.t(f"step{s}_indices").to(backend.device)
+        batch = loop.make_batch(idx)
+        # gather + input maker: exact; normalize-on-gather: the reference Preprocessor's fp32 arithmetic
+        for k in ("action", "next_action", "reward", "not_terminal", "possible_next_actions_mask"):
+            assert torch.equal(getattr(batch, k).float().cpu().reshape(g.t(f"step{s}_{k}").shape), g.t(f"step{s}_{k}")), k
+        tol_state = 1e-5 if mode != "bf16" else 4e-2  # bf16 rows: 2^-8 relative of |x| <= 11.5
+        for k in ("state", "next_state"):
+            got = getattr(batch, k).float_features.float().cpu()
+            assert (got[:16] - g.t(f"step{s}_{k}_rows")).abs().max() <= tol_state
+            assert (digest(got) - g.t(f"step{s}_{k}")).abs().max() <= tol_state
+        loss = loop.step(idx)
+        loop.flush()
+        if mode != "f32":
+            assert isinstance(tr._qs, FusedMLP) and isinstance(tr._ts, FusedMLP), "the fused kernels must be the ones running"
+        ref_loss = g.t(f"step{s}_loss").item()
+        dq = (tr.all_action_scores.cpu() - g.t(f"step{s}_q")).abs().max().item()
+        dl = abs(loss.item() - ref_loss) / abs(ref_loss)
+        dw = max(digest_err(p, g, f"step{s}_param_{i}") for i, p in enumerate(tr.q_network.parameters()))
+        dt = max(digest_err(p, g, f"step{s}_target_{i}") for i, p in enumerate(tr.q_network_target.parameters()))
+        print(f"\n[baseline_c2 {mode} {backend.name} step {s}] max|dQ| {dq:.3e}  rel dloss {dl:.3e}  "
+              f"max|dW| {dw:.3e}  max|dW_target| {dt:.3e}")
+        if mode in ACCURATE:
+            assert dq <= 1e-4 and dl <= 1e-4 and dw <= 2e-5 and dt <= 2e-5
+        else:
+            # bf16 inputs, fp32 accumulate: SURVEY.md §7.3 measured 1.9e-2 on this net.  A first Adam step
+            # moves every weight by +-lr whatever the gradient's size, so an element whose tiny gradient
+            # changes sign under bf16 rounding differs by 2*lr; the target moves by tau times that
+            assert dq <= 6e-2 and dl <= 3e-2 and dw <= 2.0 * (s + 1) * g.cfg["lr"] * 1.05 and dt <= 1e-5
+    if backend.name == "hip" and mode in ACCURATE:
+        adam = tr.native_optimizers()[0]
+        for i, p in enumerate(tr.q_network.parameters()):
+            ref_m, ref_v = g.t(f"final_exp_avg_{i}"), g.t(f"final_exp_avg_sq_{i}")
+            assert (digest(adam.state[p]["exp_avg"]) - ref_m).abs().max() <= 1e-6 + 1e-3 * ref_m.abs().max()
+            assert (digest(adam.state[p]["exp_avg_sq"]) - ref_v).abs().max() <= 1e-9 + 1e-3 * ref_v.abs().max()
+
+
+# ---- C3: QR-DQN, N = 200 -------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_c3_qrdqn_matches_reference(mode):
+    from reagent_amd.training import QRDQNTrainer
+
+    assert torch.cuda.is_available()
+    dev = "cuda"
+    g = Golden("baseline_c3")
+    c = g.cfg
+    S, A, N, B = c["state_dim"], c["num_actions"], c["num_atoms"], c["batch"]
+    q = _with_precision(MODES[mode], lambda: FullyConnectedDQN(S, A, c["sizes"], c["activations"], num_atoms=N))
+    load_init(q, [S] + c["sizes"] + [A * N], c["activations"] + ["linear"], c["init_seed"], g, "init_param_")
+    q = q.to(dev)
+    tr = QRDQNTrainer(q, q.get_target_network(), actions=[str(i) for i in range(A)], rl=RLParameters(**c["rl"]),
+                      double_q_learning=c["double_q"], num_atoms=N, optimizer=Optimizer__Union.default(lr=c["lr"]),
+                      evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(dev)
+    for s in range(c["steps"]):
+        b = synthetic.dqn_batch(B, S, A, seed=700 + s, p_impossible=c["p_impossible"])
+        check_regenerated(b["state"], g, f"step{s}_batch_state")
+        batch = synthetic.to_dqn_input(b, dev)
+        z = tr.q_network(batch.state)
+        assert z.shape == (B, A, N)
+        dz = (z[:8].cpu() - g.t(f"step{s}_quantile_rows")).abs().max().item()
+        dq = (z.mean(dim=2).cpu() - g.t(f"step{s}_q_mean")).abs().max().item()
+        loss = tr.train_step_native(batch)
+        ref = g.t(f"step{s}_loss").item()
+        dl = abs(loss.item() - ref) / abs(ref)
+        dw = max(digest_err(p, g, f"step{s}_param_{i}") for i, p in enumerate(tr.q_network.parameters()))
+        dt = max(digest_err(p, g, f"step{s}_target_{i}") for i, p in enumerate(tr.q_network_target.parameters()))
+        print(f"\n[baseline_c3 {mode} step {s}] max|dquantile| {dz:.3e} max|dQmean| {dq:.3e} rel dloss {dl:.3e} "
+              f"max|dW| {dw:.3e} max|dW_target| {dt:.3e}")
+        if mode in ACCURATE:
+            assert dz <= 1e-4 and dq <= 1e-4 and dl <= 1e-4 and dw <= 2e-5 and dt <= 2e-5
+        else:
+            assert dz <= 6e-2 and dl <= 3e-2 and dw <= 2.0 * (s + 1) * c["lr"] * 1.05 and dt <= 1e-5
+
+
+# ---- C4: SAC --------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_c4_sac_matches_reference(mode):
+    from reagent_amd.training import SACTrainer
+
+    assert torch.cuda.is_available()
+    dev = "cuda"
+    g = Golden("baseline_c4")
+    c = g.cfg
+    S, A, B = c["state_dim"], c["action_dim"], c["batch"]
+    acts = c["activations"] + ["linear"]
+
+    def nets():
+        return (GaussianFullyConnectedActor(S, A, c["sizes"], c["activations"]),
+                FullyConnectedCritic(S, A, c["sizes"], c["activations"]),
+                FullyConnectedCritic(S, A, c["sizes"], c["activations"]))
+
+    actor, q1, q2 = _with_precision(MODES[mode], nets)
+    load_init(actor, [S] + c["sizes"] + [2 * A], acts, c["init_seed"], g, "init_actor_")
+    load_init(q1, [S + A] + c["sizes"] + [1], acts, c["init_seed"] + 1, g, "init_q1_")
+    load_init(q2, [S + A] + c["sizes"] + [1], acts, c["init_seed"] + 2, g, "init_q2_")
+    adam = lambda: Optimizer__Union.default(lr=c["lr"])  # noqa: E731
+    tr = SACTrainer(actor.to(dev), q1.to(dev), q2.to(dev), rl=RLParameters(**c["rl"]), q_network_optimizer=adam(),
+                    actor_network_optimizer=adam(), alpha_optimizer=adam()).to(dev)
+    for s in range(c["steps"]):
+        b = synthetic.policy_batch(B, S, A, seed=800 + s)
+        check_regenerated(b["state"], g, f"step{s}_batch_state")
+        batch = synthetic.to_policy_input(b, dev)
+        loc, scale_log = tr.actor_network._get_loc_and_scale_log(batch.state)
+        d_loc = (loc.cpu() - g.t(f"step{s}_loc")).abs().max().item()
+        d_sl = (scale_log.cpu() - g.t(f"step{s}_scale_log")).abs().max().item()
+        d_q1 = (tr.q1_network(batch.state, batch.action).cpu() - g.t(f"step{s}_q1")).abs().max().item()
+        torch.manual_seed(3000 + s)
+        noise_next, noise_cur = torch.randn(B, A), torch.randn(B, A)
+        check_regenerated(noise_next, g, f"step{s}_noise_next")
+        check_regenerated(noise_cur, g, f"step{s}_noise_cur")
+        out = tr.train_step_native(batch, noise_next, noise_cur)
+        dl = {}
+        for nm in ("q1_loss", "q2_loss", "actor_loss", "alpha_loss"):
+            ref = float(g.t(f"step{s}_{nm}"))
+            dl[nm] = abs(float(out[nm]) - ref) / max(abs(ref), 1e-3)
+        dw = {}
+        for n, net in dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network, q1_target=tr.q1_network_target,
+                           q2_target=tr.q2_network_target).items():
+            dw[n] = max(digest_err(p, g, f"step{s}_{n}_{i}") for i, p in enumerate(net.parameters()))
+        d_alpha = abs(tr.log_alpha.item() - g.t(f"step{s}_log_alpha").item())
+        print(f"\n[baseline_c4 {mode} step {s}] max|dloc| {d_loc:.3e} max|dscale_log| {d_sl:.3e} max|dq1| {d_q1:.3e} "
+              f"rel dloss { {k: float('%.2e' % v) for k, v in dl.items()} } max|dW| { {k: float('%.2e' % v) for k, v in dw.items()} } "
+              f"|dlog_alpha| {d_alpha:.2e}")
+        if mode in ACCURATE:
+            assert d_loc <= 1e-4 and d_sl <= 1e-4 and d_q1 <= 1e-4
+            assert all(v <= 2e-4 for v in dl.values()), dl
+            assert all(v <= 2e-5 for v in dw.values()), dw
+            assert d_alpha <= 1e-6
+        else:
+            assert d_loc <= 6e-2 and d_sl <= 6e-2 and d_q1 <= 6e-2
+            assert all(v <= 5e-2 for v in dl.values()), dl
+            assert all(v <= 2.0 * (s + 1) * c["lr"] * 1.05 for v in dw.values()), dw

@@ -74,7 +74,13 @@ def _batches(kind, B):
 def _step(kind, tr, d, noise=None):
     from reagent_amd import synthetic
 
-    if kind == "dqn_deferred":  # async all-reduce, Adam joined at the start of the next step
+    if kind == "dqn_generator":  # the Lightning protocol: the CALLER steps the optimizers (no grad_scale set by us)
+        from test_dqn_trainer import lightning_like_step
+
+        if not hasattr(tr, "_test_opts"):
+            tr._test_opts = [o["optimizer"] for o in tr.configure_optimizers()]
+        lightning_like_step(tr, tr._test_opts, synthetic.to_dqn_input(d))
+    elif kind == "dqn_deferred":  # async all-reduce, Adam joined at the start of the next step
         tr.train_step_native(synthetic.to_dqn_input(d), defer_update=True)
     elif kind in ("dqn", "crr"):
         tr.train_step_native(synthetic.to_dqn_input(d))
@@ -153,9 +159,9 @@ def test_offline_loop_two_ranks_stay_in_lockstep(tmp_path, emu_lib):
         assert torch.equal(a, b) and torch.isfinite(a).all()
 
 
-@pytest.mark.parametrize("kind", ["dqn", "dqn_deferred", "sac", "td3", "crr"])
+@pytest.mark.parametrize("kind", ["dqn", "dqn_deferred", "dqn_generator", "sac", "td3", "crr"])
 def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib, kind):
-    port = 29500 + (os.getpid() % 2000) + {"dqn": 0, "sac": 1, "dqn_deferred": 2, "td3": 3, "crr": 4}[kind]
+    port = 29500 + (os.getpid() % 2000) + {"dqn": 0, "sac": 1, "dqn_deferred": 2, "td3": 3, "crr": 4, "dqn_generator": 5}[kind]
     mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")

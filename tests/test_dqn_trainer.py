@@ -289,3 +289,71 @@ def test_dqn_bcq_matches_reference(backend):
     with pytest.raises(NotImplementedError):
         DQNTrainer(q, q.get_target_network(), None, bcq=BCQConfig(), actions=["0", "1", "2", "3", "4"],
                    evaluation=EvaluationParameters(calc_cpe_in_training=False))  # no imitator given
+
+
+def test_backward_without_zero_grad_accumulates(backend):
+    """PyTorch semantics for a second backward before zero_grad(): the gradients add up (the HIP backward
+    overwrites its slab, so the published gradient is held and added back)"""
+    g = Golden("dqn_huber_masks")
+    tr = build(g, backend.device, L.PREC_F32)
+    b0 = synthetic.to_dqn_input(g.batch(0), backend.device)
+    b1 = synthetic.to_dqn_input(g.batch(1), backend.device)
+    params = list(tr.q_network.parameters())
+
+    def grads_of(batch, clear=True):
+        if clear:
+            for p in params:
+                p.grad = None
+        tr.compute_td_loss(batch).backward()
+        return [p.grad.detach().cpu().clone() for p in params]
+
+    g0, g1 = grads_of(b0), grads_of(b1)
+    grads_of(b0)
+    both = grads_of(b1, clear=False)
+    for a, b, c in zip(g0, g1, both):
+        assert (c - (a + b)).abs().max() <= 1e-6 * max(1.0, (a + b).abs().max().item())
+    tr.q_network.zero_grad(set_to_none=False)  # zeroed in place, still aliases the slab
+    again = grads_of(b0, clear=False)
+    for a, c in zip(g0, again):
+        assert torch.equal(a, c)
+
+
+def test_logged_fields_of_the_dqn_step(backend):
+    """dqn_trainer.py:306-347: what the step hands to reporter.log, pinned against the golden batch
+    (logged actions / propensities / boosted rewards exactly; td_loss, model values and the masked
+    arg-max against the reference run's numbers)"""
+    g = Golden("dqn_huber_masks")
+    tr = build(g, backend.device, L.PREC_F32)
+
+    class Reporter:
+        def __init__(self):
+            self.calls = []
+
+        def log(self, **kw):
+            self.calls.append(kw)
+
+    rep = Reporter()
+    tr.set_reporter(rep)
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    raw = g.batch(0)
+    batch = synthetic.to_dqn_input(raw, backend.device)
+    lightning_like_step(tr, opts, batch)
+    assert len(rep.calls) == 1
+    kw = rep.calls[0]
+    assert set(kw) == {"td_loss", "logged_actions", "logged_propensities", "logged_rewards", "logged_values",
+                       "model_values", "model_values_on_logged_actions", "model_action_idxs"}
+    assert kw["logged_values"] is None and kw["model_values_on_logged_actions"] is None
+    assert torch.equal(kw["logged_actions"].cpu(), raw["action"].argmax(dim=1, keepdim=True))
+    assert torch.equal(kw["logged_propensities"].cpu(), torch.ones_like(raw["reward"]))
+    boosts = torch.zeros(g.cfg["num_actions"])
+    for k, v in g.cfg["rl"]["reward_boost"].items():
+        boosts[int(k)] = v
+    want_r = raw["reward"] + (raw["action"] * boosts).sum(dim=1, keepdim=True)  # dqn_trainer_base.py:216-241
+    assert (kw["logged_rewards"].cpu() - want_r).abs().max() <= 1e-6
+    ref_loss = g.t("step0_loss").item()
+    assert abs(kw["td_loss"].item() - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-6 and not kw["td_loss"].requires_grad
+    q_ref = g.t("step0_q")
+    assert (kw["model_values"].cpu() - q_ref).abs().max() <= 1e-4
+    # get_max_q_values: arg-max over q - 1e9 * (1 - possible_actions_mask) (dqn_trainer_base.py:33-77)
+    want_idx = (q_ref - 1e9 * (1 - raw["possible_actions_mask"])).argmax(dim=1, keepdim=True)
+    assert torch.equal(kw["model_action_idxs"].cpu(), want_idx)

@@ -100,3 +100,76 @@ def test_lr_scheduler_drives_the_fused_adam(backend):
     assert opt.param_groups[0]["lr"] == 0.05 * 0.5 ** 3
     assert (p_hip.detach().cpu() - p_ref.detach()).abs().max() <= 1e-6
     assert "lr_scheduler" not in Optimizer__Union.default(lr=0.1).make_optimizer_scheduler([torch.nn.Parameter(torch.zeros(4, device=dev))])
+
+
+def _grads(shapes, g, scale=1.0):
+    return [torch.randn(*s, generator=g) * scale for s in shapes]
+
+
+def test_checkpoint_resume_continues_like_torch_adam(backend):
+    """3 steps, state_dict() -> a FRESH FusedAdam over fresh parameters -> load_state_dict(), 3 more steps:
+    identical to 6 uninterrupted torch.optim.Adam steps; the state_dict has torch.optim.Adam's layout in
+    both directions (a torch.optim.Adam state_dict loads into FusedAdam)"""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(17, 5), (17,), (3, 17), (3,)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    rs = [torch.nn.Parameter(w.clone()) for w in init]
+    ref = torch.optim.Adam(rs, lr=0.01)
+    ps = [torch.nn.Parameter(w.clone().to(backend.device)) for w in init]
+    fused = FusedAdam(ps, lr=0.01)
+    for step in range(3):
+        gr = _grads(shapes, g)
+        for p, r, x in zip(ps, rs, gr):
+            p.grad, r.grad = x.to(backend.device), x.clone()
+        fused.step()
+        ref.step()
+    sd = fused.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}  # torch.optim.Adam's keys, nothing private
+    # resume A: our own state_dict into a fresh optimizer over fresh parameter objects
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fused2 = FusedAdam(ps2, lr=0.01)
+    fused2.load_state_dict(sd)
+    # resume B: torch.optim.Adam's state_dict into a fresh FusedAdam
+    ps3 = [torch.nn.Parameter(r.detach().clone().to(backend.device)) for r in rs]
+    fused3 = FusedAdam(ps3, lr=0.01)
+    fused3.load_state_dict(ref.state_dict())
+    for step in range(3):
+        gr = _grads(shapes, g)
+        for p2, p3, r, x in zip(ps2, ps3, rs, gr):
+            p2.grad, p3.grad, r.grad = x.to(backend.device), x.to(backend.device), x.clone()
+        fused2.step()
+        fused3.step()
+        ref.step()
+    for p2, p3, r in zip(ps2, ps3, rs):
+        assert (p2.detach().cpu() - r.detach()).abs().max() <= 2e-6, "resumed run diverged from torch.optim.Adam"
+        assert (p3.detach().cpu() - r.detach()).abs().max() <= 2e-6
+        assert int(fused2.state[p2]["step"]) == 6 and int(fused3.state[p3]["step"]) == 6
+        # state[p] stays a view of the flat buffer the kernel updates
+        m = fused2.moments_for(0)[1]
+        assert fused2.state[p2]["exp_avg"].data_ptr() >= m.data_ptr()
+        assert (fused2.state[p2]["exp_avg"].cpu() - ref.state[r]["exp_avg"]).abs().max() <= 1e-6
+
+
+def test_a_second_optimizer_over_the_same_parameters_starts_from_zero_moments(backend):
+    """configure_optimizers() may be called more than once per network: every FusedAdam owns its moments"""
+    g = torch.Generator().manual_seed(4)
+    shapes = [(9, 4), (9,)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    ps = [torch.nn.Parameter(w.clone().to(backend.device)) for w in init]
+    first = FusedAdam(ps, lr=0.01)
+    for _ in range(3):
+        for p, x in zip(ps, _grads(shapes, g)):
+            p.grad = x.to(backend.device)
+        first.step()
+    rs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    ref = torch.optim.Adam(rs, lr=0.01)  # a fresh torch optimizer at the same point
+    second = FusedAdam(ps, lr=0.01)
+    gr = _grads(shapes, g)
+    for p, r, x in zip(ps, rs, gr):
+        p.grad, r.grad = x.to(backend.device), x.clone()
+    second.step()
+    ref.step()
+    for p, r in zip(ps, rs):
+        assert (p.detach().cpu() - r.detach()).abs().max() <= 1e-6
+    assert float(first.state[ps[0]]["exp_avg"].abs().max()) > 0  # and the first one kept its own
+    assert first.moments_for(0)[1].data_ptr() != second.moments_for(0)[1].data_ptr()

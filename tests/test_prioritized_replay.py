@@ -262,3 +262,33 @@ def test_full_size_properties():
     t.set_many(hot, torch.full((B,), 1e6, dtype=torch.float64, device=dev))
     idx2 = t.stratified_sample(B, generator=g)
     assert float(torch.isin(idx2, hot).double().mean()) > 0.99
+
+
+def test_out_of_range_leaves_raise_or_are_skipped(backend, monkeypatch):
+    """the reference indexes python lists (IndexError past the end); here host-side indices raise the same
+    error, and indices that already live on the device are skipped by the kernels, never dereferenced"""
+    from reagent_amd.replay_memory.sum_tree import SumTree
+
+    t = SumTree(100, device=backend.device)
+    t.set_many(np.arange(100), np.ones(100))
+    for bad in ([100], [127], [-1], [5, 1 << 20]):
+        with pytest.raises(IndexError):
+            t.set_many(np.array(bad), np.ones(len(bad)))
+        with pytest.raises(IndexError):
+            t.get_many(np.array(bad))
+    with pytest.raises(IndexError):
+        t.set(100, 1.0)
+    # device-resident indices: no host sync, out-of-range entries ignored (a padding leaf in [100, 128)
+    # must never receive priority, or `sample` could return it)
+    if backend.name == "emu":  # the interpreter's "device" memory is host memory: skip the host-side check
+        monkeypatch.setattr(SumTree, "_check_indices", lambda self, idx: None)
+    idx = torch.tensor([3, 100, 127, -5, 1 << 30, 7], dtype=torch.int64).to(backend.device)
+    t.set_many(idx, torch.full((6,), 4.0, dtype=torch.float64).to(backend.device))
+    leaves = t.nodes[-1]
+    assert leaves[3] == 4.0 and leaves[7] == 4.0 and leaves[100:].sum() == 0.0
+    assert abs(t.nodes[0][0] - (98 + 8.0)) < 1e-12
+    got = t.get_many(idx, dtype=torch.float64).cpu()
+    assert got.tolist() == [4.0, 0.0, 0.0, 0.0, 0.0, 4.0]
+    many = torch.cat([idx, torch.arange(40, dtype=torch.int64).to(backend.device)])  # the parallel (claim) path
+    t.set_many(many, torch.full((46,), 2.0, dtype=torch.float64).to(backend.device))
+    assert t.nodes[-1][100:].sum() == 0.0 and t.nodes[-1][:40].sum() == 80.0

@@ -107,3 +107,18 @@ def test_actor_model_surface(backend):
                                 exploration_variance=0.3).to(backend.device)
     o2 = noisy(batch.state)
     assert o2.action.shape == (B, A) and o2.action.abs().max() <= 1.0 and o2.log_prob.min() >= -2 and o2.log_prob.max() <= 2
+
+
+def test_target_action_noise_uses_both_clip_bounds(backend):
+    """td3_trainer.py:141-146: `noise.clamp(*self.noise_clip_range)` — a range a caller made asymmetric is
+    applied as given"""
+    from reagent_amd import ops
+
+    g_ = torch.Generator().manual_seed(0)
+    B, A = 64, 3
+    mu = (torch.rand(B, A, generator=g_) * 1.6 - 0.8).to(backend.device)
+    noise = torch.randn(B, A, generator=g_).to(backend.device)
+    out = torch.empty(B, A).to(backend.device)
+    ops.td3_target_action(mu, noise, 0.5, (-0.1, 0.3), -0.95, 0.95, out)
+    want = (mu.cpu() + (noise.cpu() * 0.5).clamp(-0.1, 0.3)).clamp(-0.95, 0.95)
+    assert (out.cpu() - want).abs().max() <= 1e-7
