@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — transitions/sec of the DQN hot path (BASELINE.json configs[1]: Discrete DQN,
-state_dim=128, |A|=16, 3x512 MLP, batch=65536, bf16) on N MI355X of one node.
+"""bench.py — transitions/sec of the batch-RL hot path on N MI355X of one node.
+
+Default workload = BASELINE.json configs[1] (`--config c2`): Discrete DQN, state_dim=128, |A|=16, 3x512
+MLP, batch=65536, bf16.  `--config c3` = QR-DQN with 200 quantiles, `--config c4` = SAC (S=256, A=32,
+actor + twin critics, H=3x512), `--config c5` = c2 per rank on 8 ranks (global batch 524288).
 
 One "step" = one pass of the whole hot path over one minibatch, everything already resident in HBM:
-replay index sampling -> gather (rg_replay_*) -> input maker -> dense normalization x2 ->
-3 FC forwards + TD/Huber head + FC backward -> [N>1: RCCL all-reduce of the flat fp32 gradient
-slab] -> fused Adam + soft target update.
+replay index sampling -> gather (rg_replay_*) -> input maker -> dense normalization x2 -> FC forwards
++ loss head + FC backward(s) -> [N>1: RCCL all-reduce of the flat fp32 gradient slab] -> fused Adam +
+soft target update.
 
-N>1 is launched by torch.distributed.run (one rank per GPU); every rank owns a disjoint shard of
-the offline dataset (its own replay buffer), per-rank batch stays 65536 (weak scaling) and the
-only collective is the gradient all-reduce.
+`--gpus N` with N > 1 and no torchrun environment re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` (one rank per
+GPU over RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE and checks WORLD_SIZE == --gpus.
+Every rank owns a disjoint shard of the offline dataset (its own replay buffer), the per-rank batch
+stays 65536 (weak scaling) and the only collective is the gradient all-reduce.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     — dominant FC kernel: algorithmic FLOP of its launches / HIP-event time of those
                  launches (events on the launch stream, measured in a second, instrumented pass of
-                 the same K steps so the timed region itself stays un-instrumented)
-  fc_roofline  — all FC kernels together against BASELINE.md's 5.849 MFLOP/transition
-  cpu_baseline — the CPU oracle (torch-CPU restatement of the reference step, oracle/restated.py)
-                 timed on this box's host cores, rank 0, N == 1 only
+                 the same K steps so the timed region itself stays un-instrumented); `traffic` = HBM
+                 bytes per launch from the PMC pass stamped into profiles/traffic.json for exactly this
+                 kernel source (null when the stamp does not match the source that is running)
+  fc_roofline  — all FC kernels together against the algorithmic FLOP of the step; in
+                 bf16x3 mode `executed_frac` counts the three MFMAs per product that mode issues
+  parity       — one extra step on a 4096-row slice of the same workload (fresh trainer, same initial
+                 weights), outside the timed region, checked against the CPU oracle (oracle/restated.py,
+                 itself pinned to the reference's golden vectors by tests/)
+  cpu_baseline — the CPU oracle timed on this box's host cores, rank 0, N == 1 only
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,140 +41,335 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}  # /opt/skills/guides/MI355X_MICROARCH.md:40-42
+MFMA_PEAK = {"bf16": 2.5e15, "bf16x3": 2.5e15, "f32": 157.3e12}  # /opt/skills/guides/MI355X_MICROARCH.md:40-42
 HBM_PEAK = 8.0e12
+
+CONFIGS = {
+    "c2": dict(algo="dqn", state_dim=128, actions=16, atoms=None,
+               name="Discrete DQN state_dim=128 |A|=16 3x512 MLP (BASELINE.json configs[1]; replay gather + "
+                    "normalize + 3 fwd + TD/Huber + bwd + Adam + soft update)"),
+    "c3": dict(algo="qrdqn", state_dim=128, actions=16, atoms=200,
+               name="QR-DQN 200 quantiles state_dim=128 |A|=16 3x512 MLP, 3200-wide head (BASELINE.json configs[2])"),
+    "c4": dict(algo="sac", state_dim=256, actions=32, atoms=None,
+               name="SAC state_dim=256 action_dim=32, Gaussian actor + twin critics, H=3x512 (BASELINE.json configs[3])"),
+    "c5": dict(algo="dqn", state_dim=128, actions=16, atoms=None,
+               name="Discrete DQN state_dim=128 |A|=16 3x512 MLP, global batch 524288 over 8 ranks "
+                    "(BASELINE.json configs[4])"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default 1; 8 for --config c5)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=65536)
-    ap.add_argument("--state-dim", type=int, default=128)
-    ap.add_argument("--actions", type=int, default=16)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--batch", type=int, default=65536, help="per-rank batch")
+    ap.add_argument("--state-dim", type=int, default=None)
+    ap.add_argument("--actions", type=int, default=None)
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--capacity", type=int, default=1 << 20)
-    ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "bf16x3", "f32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from the host instead of replaying the captured HIP graph")
     ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
-    ap.add_argument("--cpu-steps", type=int, default=4)
-    return ap.parse_args()
+    ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--parity-batch", type=int, default=4096)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher self-test: form the process group (gloo when there is no GPU), report its size, exit")
+    args = ap.parse_args()
+    c = CONFIGS[args.config]
+    if args.gpus is None:
+        args.gpus = 8 if args.config == "c5" else 1
+    args.state_dim = args.state_dim or c["state_dim"]
+    args.actions = args.actions or c["actions"]
+    args.algo, args.atoms = c["algo"], c["atoms"]
+    return args
 
 
-def fc_flops(layer_dims, batch):
-    """Algorithmic FLOP of one DQN step: 3 forwards + wgrad(all) + dgrad(all but first)."""
-    fwd = sum(a * b for a, b in zip(layer_dims, layer_dims[1:]))
-    dgrad = sum(a * b for a, b in zip(layer_dims[1:], layer_dims[2:]))
-    return 2 * batch * (3 * fwd + fwd + dgrad)
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: become N ranks."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
-def build(args, device, rank):
+def layer_dims(args):
+    out = args.actions * (args.atoms or 1)
+    return [args.state_dim] + [args.hidden] * args.layers + [out]
+
+
+def mac(dims):
+    return sum(a * b for a, b in zip(dims, dims[1:]))
+
+
+def fc_flops(args, batch):
+    """Algorithmic FLOP of one step.  DQN / QR-DQN: 3 forwards + wgrad(all layers) +
+    dgrad(all but the first).  SAC: 2 actor fwd + 1 actor bwd + 6 critic fwd + 2 critic full bwd + 2 critic
+    dgrad-only passes (down to the action columns of layer 1)."""
+    if args.algo != "sac":
+        d = layer_dims(args)
+        return 2 * batch * (3 * mac(d) + mac(d) + mac(d[1:]))
+    S, A, H = args.state_dim, args.actions, [args.hidden] * args.layers
+    da, dc = [S] + H + [2 * A], [S + A] + H + [1]
+    actor_fwd, actor_bwd = mac(da), mac(da) + mac(da[1:])
+    critic_fwd, critic_bwd = mac(dc), mac(dc) + mac(dc[1:])
+    critic_dgrad = mac(dc[1:]) + A * H[0]
+    return 2 * batch * (2 * actor_fwd + actor_bwd + 6 * critic_fwd + 2 * critic_bwd + 2 * critic_dgrad)
+
+
+def precision_code(args):
     import reagent_amd._lib as L
+
+    return {"bf16": L.PREC_BF16, "bf16x3": L.PREC_BF16X3, "f32": L.PREC_F32}[args.precision]
+
+
+def build(args, device, rank, batch=None, cols=None):
+    """this rank's trainer + replay shard + loop for the configured workload"""
     from reagent_amd import synthetic
     from reagent_amd.core.parameters import EvaluationParameters, NormalizationParameters, RLParameters
-    from reagent_amd.models import FullyConnectedDQN, set_default_precision
+    from reagent_amd.models import (FullyConnectedCritic, FullyConnectedDQN, GaussianFullyConnectedActor,
+                                    set_default_precision)
     from reagent_amd.optimizer import Optimizer__Union
     from reagent_amd.preprocessing import Preprocessor
     from reagent_amd.replay_memory import ReplayBuffer
-    from reagent_amd.runtime import OfflineDqnLoop
-    from reagent_amd.training import DQNTrainer
+    from reagent_amd.runtime import OfflineDqnLoop, OfflinePolicyLoop
 
-    S, A, H = args.state_dim, args.actions, args.hidden
-    set_default_precision(L.PREC_BF16 if args.precision == "bf16" else L.PREC_F32)
-    torch.manual_seed(0)  # identical initial weights on every rank
-    q = FullyConnectedDQN(S, A, [H] * args.layers, ["relu"] * args.layers)
-    init = [p.detach().clone() for p in q.parameters()]
-    q = q.to(device)
-    trainer = DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(A)],
-                         rl=RLParameters(gamma=0.99, target_update_rate=0.001, maxq_learning=True,
-                                         q_network_loss="huber"),
-                         double_q_learning=True, optimizer=Optimizer__Union.default(lr=1e-3),
-                         evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(device)
+    batch = batch or args.batch
+    S, A, H = args.state_dim, args.actions, [args.hidden] * args.layers
+    acts = ["relu"] * args.layers
+    adam = lambda: Optimizer__Union.default(lr=1e-3)  # noqa: E731
+    import reagent_amd._lib as L
+
+    set_default_precision(precision_code(args))
+    try:
+        if args.algo == "sac":
+            nets = [GaussianFullyConnectedActor(S, A, H, acts), FullyConnectedCritic(S, A, H, acts),
+                    FullyConnectedCritic(S, A, H, acts)]
+            shapes = [[S] + H + [2 * A], [S + A] + H + [1], [S + A] + H + [1]]
+        else:
+            nets = [FullyConnectedDQN(S, A, H, acts, num_atoms=args.atoms)]
+            shapes = [layer_dims(args)]
+    finally:
+        set_default_precision(L.PREC_F32)
+    init = []
+    for k, (net, dims) in enumerate(zip(nets, shapes)):  # identical initial weights on every rank
+        w = synthetic.fc_init(dims, acts + ["linear"], seed=40 + k)
+        with torch.no_grad():
+            for p, x in zip(net.parameters(), w):
+                p.copy_(x)
+        init.append(w)
+        net.to(device)
+    if args.algo == "sac":
+        from reagent_amd.training import SACTrainer
+
+        trainer = SACTrainer(nets[0], nets[1], nets[2], rl=RLParameters(gamma=0.99, target_update_rate=0.001),
+                             q_network_optimizer=adam(), actor_network_optimizer=adam(), alpha_optimizer=adam()).to(device)
+    else:
+        rl = RLParameters(gamma=0.99, target_update_rate=0.001, maxq_learning=True, q_network_loss="huber")
+        common = dict(actions=[str(i) for i in range(A)], rl=rl, double_q_learning=True, optimizer=adam(),
+                      evaluation=EvaluationParameters(calc_cpe_in_training=False))
+        q = nets[0]
+        if args.algo == "qrdqn":
+            from reagent_amd.training import QRDQNTrainer
+
+            trainer = QRDQNTrainer(q, q.get_target_network(), num_atoms=args.atoms, **common).to(device)
+        else:
+            from reagent_amd.training import DQNTrainer
+
+            trainer = DQNTrainer(q, q.get_target_network(), None, **common).to(device)
     # this rank's shard of the offline dataset (different seed per rank), resident in HBM
-    cols = synthetic.replay_contents(args.capacity, S, A, seed=100 + rank)
-    rb = ReplayBuffer(replay_capacity=args.capacity, batch_size=args.batch, device=device)
+    own_cols = cols is None
+    if own_cols:
+        cols = synthetic.replay_contents(args.capacity, S, A, seed=100 + rank)
+        if args.algo == "sac":  # continuous actions already in the training range (SURVEY §8d C4)
+            g = torch.Generator().manual_seed(200 + rank)
+            cols["action"] = torch.rand(args.capacity, A, generator=g) * 1.8 - 0.9
+            del cols["possible_actions_mask"]
+    rb = ReplayBuffer(replay_capacity=args.capacity, batch_size=batch, device=device)
     rb.load_columns({k: v.to(device) for k, v in cols.items()}, mark_all_valid=True)
-    g = torch.Generator().manual_seed(7)
-    mean, std = torch.randn(S, generator=g), torch.rand(S, generator=g) * 1.5 + 0.5
+    mean, std = synthetic.normalization_table(S, 7)
     norm = {i: NormalizationParameters(feature_type="CONTINUOUS", mean=mean[i].item(), stddev=std[i].item())
             for i in range(S)}
     pre = Preprocessor(norm, device=device)
-    loop = OfflineDqnLoop(rb, trainer, args.batch, pre,
-                          state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32,
-                          prefetch=args.prefetch)
+    if args.algo == "sac":
+        import numpy as np
+
+        from reagent_amd.core.parameters import CONTINUOUS_TRAINING_ACTION_RANGE as R
+        from reagent_amd.preprocessing import PolicyNetworkInputMaker
+
+        maker = PolicyNetworkInputMaker(np.full(A, R[0], dtype=np.float32), np.full(A, R[1], dtype=np.float32))
+        loop = OfflinePolicyLoop(rb, trainer, batch, maker, pre)
+    else:
+        loop = OfflineDqnLoop(rb, trainer, batch, pre,
+                              state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32,
+                              prefetch=args.prefetch)
     return loop, trainer, init, cols, (mean, std)
 
 
-def cpu_baseline(args, init, cols, norm):
-    """The reference step restated on torch-CPU (oracle/restated.py), on this box's host cores:
-    numpy/torch gather of the same columns, (x-mean)/std normalization, DQN step.  Bounded sample."""
+def cpu_batch(args, cols, norm, idx):
+    """the reference path's batch on the CPU: gather of the same columns, (x - mean) / std normalization
+    with the Preprocessor's clamp, input maker"""
+    mean, std = norm
+    C, A = args.capacity, args.actions
+    nxt = (idx + 1) % C
+    clamp = lambda x: torch.clamp(x, -11.513, 11.513)  # noqa: E731  (preprocessor.py:156-168; no-op for N(0,1)/0.5 here)
+    term = cols["terminal"][idx]
+    b = dict(state=clamp((cols["observation"][idx] - mean) / std), next_state=clamp((cols["observation"][nxt] - mean) / std),
+             reward=cols["reward"][idx].unsqueeze(1), not_terminal=1.0 - term.float().unsqueeze(1))
+    if args.algo == "sac":
+        # PolicyNetworkInputMaker (trainer_preprocessor.py:175-227): rescale_actions (training/utils.py:13-29) from
+        # the environment range to the training range — here the same interval, the arithmetic still runs
+        lo, hi = -1.0, 1.0  # CONTINUOUS_TRAINING_ACTION_RANGE
+        rescale = lambda a: ((a - lo) / (hi - lo)) * (hi - lo) + lo  # noqa: E731
+        b["action"] = rescale(cols["action"][idx])
+        b["next_action"] = rescale(cols["action"][nxt]) * b["not_terminal"]
+    else:
+        one_hot = torch.nn.functional.one_hot
+        b["action"] = one_hot(cols["action"][idx], A).float()
+        b["next_action"] = one_hot(cols["action"][nxt], A).float() * b["not_terminal"]
+        b["possible_next_actions_mask"] = cols["possible_actions_mask"][nxt]
+        b["possible_actions_mask"] = cols["possible_actions_mask"][idx]
+    return b
+
+
+def make_oracle(args, init):
     from oracle import restated as R
 
-    B, S, A = args.batch, args.state_dim, args.actions
-    mean, std = norm
     acts = ["relu"] * args.layers + ["linear"]
-    o = R.DQNOracle(init, init, acts, gamma=0.99, tau=0.001, loss="huber", lr=1e-3)
+    if args.algo == "dqn":
+        return R.DQNOracle(init[0], init[0], acts, gamma=0.99, tau=0.001, loss="huber", lr=1e-3)
+    if args.algo == "qrdqn":
+        return R.QRDQNOracle(init[0], init[0], acts, num_actions=args.actions, num_atoms=args.atoms, gamma=0.99,
+                             tau=0.001, lr=1e-3)
+    return R.SACOracle(init[0], init[1], init[2], acts, acts, args.actions, gamma=0.99, tau=0.001, lr=1e-3)
+
+
+def cpu_baseline(args, init, cols, norm):
+    """The reference step restated on torch-CPU (oracle/restated.py) on this box's host cores: gather of the
+    same columns by advanced indexing (`cols[idx]` per column — NOT the reference's sample_transition_batch
+    with its nonzero() + 17 index ops, which is slower still), normalization, trainer step.  Bounded sample."""
+    B = args.batch if args.algo != "qrdqn" else min(args.batch, 8192)  # the (N, B, N) tensor: 62 GB hosts (SURVEY §6)
+    steps = args.cpu_steps or (4 if args.algo == "dqn" else 2)
+    o = make_oracle(args, init)
     g = torch.Generator().manual_seed(3)
-    C = args.capacity
 
     def one():
-        idx = torch.randint(C, (B,), generator=g)
-        nxt = (idx + 1) % C
-        state = torch.clamp((cols["observation"][idx] - mean) / std, -11.513, 11.513)
-        next_state = torch.clamp((cols["observation"][nxt] - mean) / std, -11.513, 11.513)
-        term = cols["terminal"][idx]
-        b = dict(state=state, next_state=next_state,
-                 action=torch.nn.functional.one_hot(cols["action"][idx], A).float(),
-                 next_action=torch.nn.functional.one_hot(cols["action"][nxt], A).float(),
-                 reward=cols["reward"][idx].unsqueeze(1), not_terminal=1.0 - term.float().unsqueeze(1),
-                 possible_next_actions_mask=cols["possible_actions_mask"][nxt],
-                 possible_actions_mask=cols["possible_actions_mask"][idx])
-        o.step(b)
+        idx = torch.randint(args.capacity, (B,), generator=g)
+        b = cpu_batch(args, cols, norm, idx)
+        if args.algo == "sac":
+            o.step(b, torch.randn(B, args.actions, generator=g), torch.randn(B, args.actions, generator=g))
+        else:
+            o.step(b)
 
     one()  # warm-up
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    for _ in range(steps):
         one()
     dt = time.perf_counter() - t0
-    return {"value": args.cpu_steps * B / dt, "unit": "transitions/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{args.cpu_steps} steps of the same workload (B={B}, gather+normalize+DQN step, fp32, "
-                      f"torch-CPU restatement of the reference trainer; {dt / args.cpu_steps * 1e3:.0f} ms/step)"}
+    return {"value": steps * B / dt, "unit": "transitions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps at B={B} of the same workload (advanced-index gather of the same columns + "
+                      f"normalize + {args.algo} step, fp32, oracle/restated.py = torch-CPU restatement of the reference "
+                      f"trainer; {dt / steps * 1e3:.0f} ms/step)"}
 
 
-def kernel_profile(args, loop, steps, layer_dims):
+def parity_check(args, device, init, cols, norm):
+    """One step of the SAME workload on a 4096-row slice — fresh trainer with the timed run's initial weights,
+    the same replay shard, the same code path (one-launch sampler, native step, fused update) — against the
+    CPU oracle on the indices the device drew."""
+    B = args.parity_batch
+    loop, trainer, _, _, _ = build(args, device, 0, batch=B, cols=cols)
+    g = torch.Generator().manual_seed(11)
+    idx = torch.randint(args.capacity, (B,), generator=g)
+    o = make_oracle(args, init)
+    b = cpu_batch(args, cols, norm, idx)
+    batch = loop.make_batch(idx.to(device))
+    exact = []
+    for k in ("action", "next_action", "reward", "not_terminal", "possible_next_actions_mask"):
+        if k in b:
+            got = getattr(batch, k)
+            got = got.float_features if hasattr(got, "float_features") else got
+            exact.append(bool(torch.equal(got.float().cpu().reshape(b[k].shape), b[k].float())))
+    d_state = max((getattr(batch, k).float_features.float().cpu() - b[k]).abs().max().item() for k in ("state", "next_state"))
+    out = {"batch": B, "mode": args.precision, "gather_fields_bit_exact": all(exact), "max_abs_dstate": d_state,
+           "oracle": "oracle/restated.py (torch-CPU fp32 restatement, pinned to the reference by tests/golden)"}
+    if args.algo == "sac":
+        nn_, nc = torch.randn(B, args.actions, generator=g), torch.randn(B, args.actions, generator=g)
+        loc, scale_log = trainer.actor_network._get_loc_and_scale_log(batch.state)
+        rl, rs = o.pi.loc_scale_log(o.actor, b["state"])
+        out["max_abs_dlogits"] = max((loc.cpu() - rl.detach()).abs().max().item(), (scale_log.cpu() - rs.detach()).abs().max().item())
+        got = loop.trainer.train_step_native(batch, nn_, nc)
+        ref = o.step(b, nn_, nc)
+        out["rel_dloss"] = max(abs(float(got[k]) - float(ref[k])) / max(abs(float(ref[k])), 1e-3)
+                               for k in ("q1_loss", "q2_loss", "actor_loss"))
+        pairs = list(zip(trainer.actor_network.parameters(), o.actor)) + list(zip(trainer.q1_network.parameters(), o.q1))
+    else:
+        loss = loop.step(idx.to(device))
+        loop.flush()
+        ref = o.step(b)
+        q = trainer.all_action_scores if args.algo == "dqn" else None
+        if q is not None:
+            out["max_abs_dq"] = (q.cpu() - ref["q"]).abs().max().item()
+        out["rel_dloss"] = abs(loss.item() - ref["loss"].item()) / abs(ref["loss"].item())
+        pairs = list(zip(trainer.q_network.parameters(), o.params))
+    out["max_abs_dw"] = max((p.detach().cpu() - r.detach()).abs().max().item() for p, r in pairs)
+    out["tolerance"] = ("Q / logits 1e-4, weights 2e-5 (north_star)" if args.precision != "bf16" else
+                        "bf16 operands: Q ~3e-2, |dW| <= 2*lr after one Adam step (sign flips of tiny gradients)")
+    if args.precision != "bf16":
+        out["ok"] = bool(out.get("max_abs_dq", out.get("max_abs_dlogits", 0.0)) <= 1e-4 and out["max_abs_dw"] <= 2e-5
+                         and out["gather_fields_bit_exact"])
+    else:
+        out["ok"] = bool(out.get("max_abs_dq", out.get("max_abs_dlogits", 0.0)) <= 6e-2 and out["max_abs_dw"] <= 2.1e-3
+                         and out["gather_fields_bit_exact"])
+    return out
+
+
+def source_stamp():
+    """sha256 of the kernel sources the dominant kernels are built from (stamps profiles/traffic.json)"""
+    h = hashlib.sha256()
+    for f in ("mlp_fused.hip", "rg_gemm.h", "fc.hip"):
+        with open(os.path.join(ROOT, "reagent_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_profile(args, step, steps):
     """Instrumented pass: HIP events around every C-ABI launch (on the launch stream)."""
     from reagent_amd import ops
 
     B = args.batch
     with ops.profile() as prof:
         for _ in range(steps):
-            loop.step()
+            step()
     rows = prof.summary()
     fc_names = ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad", "rg_fc_wgrad_frag", "rg_mlp_forward_fused",
                 "rg_mlp_backward_fused", "rg_mlp_wgrad_fused")
     fc = [r for r in rows if r["name"] in fc_names]
     for r in fc:
         m = r["meta"]
-        if r["name"] == "rg_mlp_forward_fused":
+        if r["name"] in ("rg_mlp_forward_fused", "rg_mlp_wgrad_fused"):
             d = m["dims"]
-            r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d, d[1:]))
-            r["label"] = f"rg_mlp_forward_fused B={m['B']} dims={list(d)} save={m['save']}"
-        elif r["name"] == "rg_mlp_wgrad_fused":
-            d = m["dims"]
-            r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d, d[1:]))
-            r["label"] = f"rg_mlp_wgrad_fused B={m['B']} dims={list(d)}"
+            r["flop_per_launch"] = 2.0 * m["B"] * mac(d)
+            r["label"] = f"{r['name']} B={m['B']} dims={list(d)}" + (f" save={m['save']}" if "save" in m else "")
         elif r["name"] == "rg_mlp_backward_fused":
             d = m["dims"]
-            r["flop_per_launch"] = 2.0 * m["B"] * sum(a * b for a, b in zip(d[1:], d[2:]))
+            r["flop_per_launch"] = 2.0 * m["B"] * (mac(d[1:]) + (d[0] * d[1] if m.get("dx") else 0))
             r["label"] = f"rg_mlp_backward_fused B={m['B']} dims={list(d)}"
         else:
             r["flop_per_launch"] = 2.0 * m["M"] * m["N"] * m["K"]
             r["label"] = f"{r['name']} M={m['M']} N={m['N']} K={m['K']}"
     peak = MFMA_PEAK[args.precision]
+    mfma_per_product = 3 if args.precision == "bf16x3" else 1
     out = {}
     if fc:
         dom = fc[0]
@@ -172,11 +378,28 @@ def kernel_profile(args, loop, steps, layer_dims):
         out["roofline"] = {"bound": "mfma", "kernel": dom["label"],
                            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
                            "avg_launch_us": sec * 1e6, "launches_per_step": dom["calls"] / steps, "traffic": None}
+        if mfma_per_product != 1:
+            out["roofline"]["executed_frac"] = mfma_per_product * ach / peak
         fc_ms = sum(r["ms"] for r in fc) / steps
-        alg = fc_flops(layer_dims, B)
+        alg = fc_flops(args, B)
         out["fc_roofline"] = {"algorithmic_gflop_per_step": alg / 1e9, "fc_ms_per_step": fc_ms,
                               "achieved": alg / (fc_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                               "frac": alg / (fc_ms * 1e-3) / peak}
+        if mfma_per_product != 1:
+            out["fc_roofline"]["executed_frac"] = mfma_per_product * out["fc_roofline"]["frac"]
+            out["fc_roofline"]["note"] = "bf16x3: three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                t = json.load(open(traffic_file))
+                if t.get("source_stamp") == source_stamp():
+                    key = dom["label"].split(" ")[0] + (":save=%d" % dom["meta"]["save"] if "save" in dom["meta"] else "")
+                    out["roofline"]["traffic"] = t.get("kernels", {}).get(f"{args.config}:{args.precision}:{key}")
+                    out["roofline"]["traffic_source"] = t.get("from")
+                else:
+                    out["roofline"]["traffic_source"] = "profiles/traffic.json is stamped for other kernel sources: not reported"
+            except Exception:
+                pass
     g = [r for r in rows if r["name"] in ("rg_replay_dqn_batch", "rg_replay_gather")]
     if g:
         sec = g[0]["ms"] * 1e-3 / g[0]["calls"]
@@ -190,10 +413,32 @@ def kernel_profile(args, loop, steps, layer_dims):
 
 def main():
     args = parse()
+    under_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not under_torchrun:
+        relaunch_under_torchrun(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    have_gpu = torch.cuda.is_available()
+    if args.rendezvous_only:  # launcher self-test (CPU boxes use gloo)
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl" if have_gpu else "gloo", rank=rank, world_size=world)
+        t = torch.ones(1, device="cuda" if have_gpu else "cpu")
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "ranks": int(t.item()), "backend": dist.get_backend(), "n_gpus": args.gpus}))
+        dist.destroy_process_group()
+        return
+    if not have_gpu:
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback "
+                         f"(rank {rank} of {world})")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (device_count {torch.cuda.device_count()}, --gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -202,22 +447,38 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # "nccl" IS RCCL on ROCm
+        assert dist.get_world_size() == args.gpus
     loop, trainer, init, cols, norm = build(args, device, rank)
     if world > 1:
         trainer.enable_data_parallel()
+    parity = None
+    if rank == 0 and not args.no_parity:
+        try:
+            parity = parity_check(args, device, init, cols, norm)
+        except Exception as e:  # reported, never fatal to the measurement
+            parity = {"error": repr(e)}
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = loop.step
+    graph_note = None
+    if not args.no_graph and hasattr(loop, "capture"):
+        try:
+            step = loop.capture(warmup=max(2, min(args.warmup, 3)))
+            graph_note = "hip graph replay (index draw, sampler, forwards, head, backward, wgrad, update in one graph)"
+        except Exception as e:
+            graph_note = f"graph capture failed, eager launches: {e!r}"
+            step = loop.step
     for _ in range(args.warmup):
-        loop.step()
+        step()
     loop.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = loop.step()
+        loss = step()
     loop.flush()  # data parallel: the last step's update joins its all-reduce inside the timed region
     host_dt = time.perf_counter() - t0  # time the host needed to ENQUEUE the steps (diagnostic)
     barrier()
@@ -226,41 +487,35 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    if isinstance(loss, dict):
+        loss = loss["q1_loss"]
     loss_val = float(loss.item())
 
-    layer_dims = [args.state_dim] + [args.hidden] * args.layers + [args.actions]
     extra = {}
     if not args.no_kernel_profile:
         # every rank runs the instrumented steps (they contain the gradient all-reduce: a pass on rank 0
-        # alone would never return); rank 0 reports
-        extra = kernel_profile(args, loop, min(args.steps, 10), layer_dims)
+        # alone would never return); rank 0 reports.  Eager launches: events bracket each C-ABI call.
+        extra = kernel_profile(args, loop.step, min(args.steps, 10))
         loop.flush()
     if dist is not None:
         dist.barrier()
     if rank == 0:
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        # the committed PMC figure belongs to the fused forward (save=0) launch only
-        if "roofline" in extra and os.path.exists(traffic_file) and "forward_fused" in extra["roofline"].get("kernel", ""):
-            try:
-                extra["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
         res = {
             "metric": "transitions/sec at batch=65536 state_dim=128; 1/2/4/8 MI355X scaling",
             "value": world * args.batch * args.steps / dt,
             "unit": "transitions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": world if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"Discrete DQN state_dim={args.state_dim} |A|={args.actions} "
-                                   f"{args.layers}x{args.hidden} MLP batch={args.batch}/GPU "
-                                   f"(BASELINE.json configs[1]; replay gather + normalize + 3 fwd + TD/Huber + bwd + Adam + soft update)",
-                       "global_batch": world * args.batch, "replay_capacity_per_gpu": args.capacity,
-                       "parallelism": f"dp{world}", "final_loss": loss_val},
+            "config": {"workload": f"{CONFIGS[args.config]['name']}; batch={args.batch}/GPU, {args.layers}x{args.hidden} hidden",
+                       "name": args.config, "global_batch": world * args.batch, "replay_capacity_per_gpu": args.capacity,
+                       "parallelism": f"dp{world}", "final_loss": loss_val, "launch": graph_note or "eager launches"},
         }
         res.update(extra)
+        if parity is not None:
+            res["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, init, cols, norm)

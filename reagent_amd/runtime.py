@@ -131,3 +131,27 @@ class OfflineTableLoop:
         if deferred:
             self.trainer.apply_pending_update()
         return loss
+
+
+class OfflinePolicyLoop:
+    """The same loop for continuous-action trainers (SAC / TD3, BASELINE C4): uniform index draw ->
+    ReplayBuffer.sample_transition_batch (rg_replay_nstep + rg_replay_gather, state rows normalized on the
+    way when a 1:1 Preprocessor is given) -> PolicyNetworkInputMaker -> trainer.train_step_native, the
+    actor's N(0,1) draws taken from the device RNG."""
+
+    def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int, input_maker,
+                 state_preprocessor: Optional[Preprocessor] = None):
+        self.rb, self.trainer, self.batch_size, self.maker = replay_buffer, trainer, batch_size, input_maker
+        self.pre = state_preprocessor
+        if state_preprocessor is not None and not state_preprocessor.elementwise:
+            raise NotImplementedError("normalize-on-gather needs a 1:1 column table")
+
+    def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.PolicyNetworkInput:
+        tup = self.rb.sample_transition_batch(self.batch_size, indices=indices, state_preprocessor=self.pre)
+        return self.maker(tup)
+
+    def step(self, indices: Optional[torch.Tensor] = None, **noise):
+        return self.trainer.train_step_native(self.make_batch(indices), **noise)
+
+    def flush(self):
+        pass
