@@ -74,7 +74,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from the host instead of replaying the captured HIP graph")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step as a HIP graph at all")
+    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="auto: replay the captured HIP graph or enqueue eagerly, whichever a short calibration finds faster")
     ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--parity-batch", type=int, default=4096)
@@ -467,11 +469,38 @@ def main():
     graph_note = None
     if not args.no_graph and hasattr(loop, "capture"):
         try:
-            step = loop.capture(warmup=max(2, min(args.warmup, 3)))
-            graph_note = "hip graph replay (index draw, sampler, forwards, head, backward, wgrad, update in one graph)"
+            replay = loop.capture(warmup=max(2, min(args.warmup, 3)))
         except Exception as e:
+            replay = None
             graph_note = f"graph capture failed, eager launches: {e!r}"
-            step = loop.step
+        if replay is not None:
+            # Which launch path is faster depends on the workload: a replayed graph costs the host ~0.02 ms per
+            # step but serialises its kernel nodes a little more loosely than back-to-back stream launches, an
+            # eager step costs the host 0.3-1.2 ms.  Calibrate outside the timed region (every rank takes the same
+            # decision: the slowest rank's times count).
+            def timed(fn, n=8):
+                fn()
+                loop.flush()
+                barrier()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                loop.flush()
+                barrier()
+                return (time.perf_counter() - t) / n
+
+            t_graph, t_eager = timed(replay), timed(loop.step)
+            if dist is not None:
+                tt = torch.tensor([t_graph, t_eager], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_graph, t_eager = tt.tolist()
+            use_graph = args.launch == "graph" or (args.launch == "auto" and t_graph <= t_eager)
+            what = ("one HIP graph per step (index draw, sampler, forwards, head, backward, wgrad, update)" if world == 1 else
+                    "three HIP graphs per step (sample | update | forward+backward), the RCCL all-reduce of the gradient "
+                    "slab launched eagerly between them")
+            graph_note = (f"{'graph replay: ' + what if use_graph else 'eager stream launches'}; calibration "
+                          f"{t_graph * 1e3:.3f} ms/step replayed vs {t_eager * 1e3:.3f} ms/step eager")
+            step = replay if use_graph else loop.step
     for _ in range(args.warmup):
         step()
     loop.flush()

@@ -505,6 +505,26 @@ int rg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  double bias_correction1, double bias_correction2_sqrt, double grad_scale,
                  rg_stream_t stream);
 
+/* Graph-safe Adam steps.  A captured HIP graph bakes launch ARGUMENTS in, and bias_correction1/2 change every
+ * step: the `_sched` variants read them (and lr) from a device-resident schedule instead, so one captured
+ * step replays as step t, t+1, ...  Layout of `sched` (doubles, written by the host):
+ *   [0] steps applied so far   [1] lr   [2] n = table entries   [3] reserved
+ *   [4 + 2(t-1)], [5 + 2(t-1)] = 1 - beta1^t, sqrt(1 - beta2^t) for t = 1..n (steps past n use entry n; the
+ *   host extends the table until both have reached 1.0), computed in double as for the scalar entry points.
+ * A launch applies step [0] + 1; rg_sched_tick (one thread: [0] += 1) is enqueued after the last launch of
+ * that step.  Arithmetic per element is that of rg_adam_step / rg_mlp_update_fused / rg_adam_step_f64 with the
+ * same coefficients: identical bits. */
+int rg_adam_step_sched(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                       const double* sched, rg_stream_t stream);
+int rg_mlp_update_fused_sched(const rg_mlp_update_desc* d, double beta1, double beta2, double eps,
+                              double weight_decay, double grad_scale, double tau, const double* sched,
+                              rg_stream_t stream);
+int rg_adam_step_f64_sched(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n,
+                           double beta1, double beta2, double eps, const double* sched,
+                           double* exp_param_out, rg_stream_t stream);
+int rg_sched_tick(double* sched, rg_stream_t stream);
+
 /* SoftUpdate.step, reagent/optimizer/soft_update.py:60-70: tgt = tau*src + (1-tau)*tgt */
 int rg_soft_update(float* target, const float* source, int64_t n, double tau, rg_stream_t stream);
 

@@ -194,6 +194,12 @@ SIGNATURES = {
     "rg_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d,
                               c_d, c_d, c_d, c_void_p]),
     "rg_soft_update": (c_int, [c_void_p, c_void_p, c_i64, c_d, c_void_p]),
+    "rg_adam_step_sched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d, c_void_p,
+                                    c_void_p]),
+    "rg_mlp_update_fused_sched": (c_int, [ctypes.POINTER(MlpUpdateDesc)] + [ctypes.c_double] * 6 + [c_void_p, c_void_p]),
+    "rg_adam_step_f64_sched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_void_p,
+                                        c_void_p, c_void_p]),
+    "rg_sched_tick": (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

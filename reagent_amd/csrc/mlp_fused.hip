@@ -18,463 +18,10 @@
 //
 // Replaces: FullyConnectedNetwork.forward (reagent/models/fully_connected_network.py:157-163)
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
-#include "rg_gemm.h"
-#include "rg_optim.h"
-#include <type_traits>
-#include "../../include/reagent_hip.h"
 
-// phase-timing hook: expands to nothing here; profiles/microbench/fwd_phases.hip defines it to an
-// s_memtime stamp before including this file
-#ifndef RG_STAMP
-#define RG_STAMP(slot)
-#endif
-#ifndef RG_PHASE_INIT  // accumulating variant for loops (profiles/microbench/wgrad_phases.hip)
-#define RG_PHASE_INIT()
-#define RG_PHASE(i)
-#define RG_PHASE_FLUSH()
-#endif
+#include "rg_mlp_frag.h"
 
 namespace rg {
-
-constexpr int FB_BM = 128;
-constexpr int WG_THREADS = 512;  // weight-gradient kernels
-#ifndef RG_FUSED_WAVES
-#define RG_FUSED_WAVES 8
-#endif
-constexpr int FB_NW = RG_FUSED_WAVES;  // waves per workgroup of the forward / backward kernels (4 or 8)
-constexpr int FB_MAXL = RG_MLP_MAX_LAYERS;
-
-struct MlpArgs {
-  int n_layers, batch;
-  int dims[FB_MAXL + 1];
-  int acts[FB_MAXL];
-  const bf16_t* wfrag[FB_MAXL];  // forward: B fragments of W_l; backward: B fragments of W_l^T
-  const float* bias[FB_MAXL];
-  bf16_t* act_frag[FB_MAXL + 1];  // [l] = input of layer l in C-fragment order ([0] = network input)
-  bf16_t* dz_frag[FB_MAXL];       // [l] = d loss / d (pre-activation output of layer l)
-  unsigned* act_sign[FB_MAXL];    // [l] = (act_frag[l] > 0) bits, one per element, private order (nullable)
-  float* db_part[FB_MAXL];        // backward: [n_workgroups][dims[l+1]] bias-gradient partials (nullable)
-  const void* x;                  // forward input [batch, dims[0]] row-major, bf16 or fp32
-  long ldx;
-  int x_is_f32;
-  float* out32;  // forward output [batch, dims[L]] fp32
-  long ldo;
-  const float* dout32;  // backward input [batch, dims[L]] fp32
-  long lddo;
-  float* dx32;  // backward: optional gradient w.r.t. the network input, fp32 [batch, dims[0]]
-  long lddx;
-  int pitch;  // LDS row pitch (elements)
-  int save;   // forward: store act_frag[]
-};
-
-__device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
-
-// compile-time activation (a runtime `switch` per element would bloat the unrolled epilogues until
-// the unroller gives up and the accumulator arrays fall into scratch)
-template <int ACT> __device__ __forceinline__ float act_t(float z) { return act_apply(z, ACT); }
-template <int ACT> __device__ __forceinline__ float act_grad_t(float h) { return act_grad_from_output(h, ACT); }
-#define RG_DISPATCH_ACT(act, ...)                                                   \
-  switch (act) {                                                                    \
-    case ACT_RELU: { constexpr int A_ = ACT_RELU; __VA_ARGS__; } break;             \
-    case ACT_LEAKY_RELU: { constexpr int A_ = ACT_LEAKY_RELU; __VA_ARGS__; } break; \
-    case ACT_TANH: { constexpr int A_ = ACT_TANH; __VA_ARGS__; } break;             \
-    case ACT_SIGMOID: { constexpr int A_ = ACT_SIGMOID; __VA_ARGS__; } break;       \
-    case ACT_SOFTPLUS: { constexpr int A_ = ACT_SOFTPLUS; __VA_ARGS__; } break;     \
-    default: { constexpr int A_ = ACT_LINEAR; __VA_ARGS__; } break;                 \
-  }
-
-// C-fragment order: element (row, col) lives in block (row/32, col/32), half h, lane, e with
-//   col%32 = lane&31,  row%32 = (r&3) + 8*(r>>2) + 4*(lane>>5),  r = 8*h + e   (MFMA 32x32 D layout)
-__device__ __forceinline__ long frag_offset(int mb, int nt, int NT, int h, int lane) {
-  return ((((long)mb * NT + nt) * 2 + h) * 64 + lane) * 8;
-}
-__device__ __forceinline__ int frag_row(int h, int e, int lg) {
-  const int r = 8 * h + e;
-  return (r & 3) + 8 * (r >> 2) + 4 * lg;
-}
-
-// ---- LDS tile helpers -----------------------------------------------------------------------
-// rows [row_base, row_base+128) x cols [0, ncols_pad) of a row-major global matrix -> bf16 LDS tile
-template <typename T, int THREADS>
-__device__ __forceinline__ void load_tile_to_lds(bf16_t* act, int pitch, const T* src, long ld, int row_base,
-                                                 int nrows, int ncols, int ncols_pad, int tid) {
-  const int cpr = ncols_pad / 8;  // 8-element chunks per row
-  const int total = FB_BM * cpr;
-  const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
-  if (vec && ncols == ncols_pad) {
-    // aligned rows: four chunks per thread in flight (all loads issued before the first use; the
-    // addresses of out-of-range chunks are clamped and their result replaced by zeros)
-    constexpr int U = 4;
-    for (int c0 = tid; c0 < total; c0 += THREADS * U) {
-      f32x4 raw[U][sizeof(T) == 4 ? 2 : 1];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int cu = c0 + u * THREADS, c = cu < total ? cu : total - 1;
-        const int gr = row_base + c / cpr, grow = gr < nrows ? gr : nrows - 1;
-        const T* p = src + (long)grow * ld + (c % cpr) * 8;
-        raw[u][0] = *(const f32x4*)p;
-        if (sizeof(T) == 4) raw[u][sizeof(T) == 4 ? 1 : 0] = *(const f32x4*)(p + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int c = c0 + u * THREADS;
-        if (c >= total) break;
-        const int r = c / cpr, k0 = (c % cpr) * 8;
-        u16x8 v;
-        if (sizeof(T) == 4) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = f32_to_bf16(raw[u][0][e]);
-            v[4 + e] = f32_to_bf16(raw[u][sizeof(T) == 4 ? 1 : 0][e]);
-          }
-        } else {
-          v = __builtin_bit_cast(u16x8, raw[u][0]);
-        }
-        if (row_base + r >= nrows) v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        *(u16x8*)&act[r * pitch + k0] = v;
-      }
-    }
-    return;
-  }
-  for (int c = tid; c < total; c += THREADS) {
-    const int r = c / cpr, k0 = (c % cpr) * 8;
-    const int grow = row_base + r;
-    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (grow < nrows && k0 < ncols) {
-      const T* p = src + (long)grow * ld + k0;
-      if (sizeof(T) == 2 && vec && k0 + 8 <= ncols) {
-        v = *(const u16x8*)p;
-      } else if (sizeof(T) == 4 && vec && k0 + 8 <= ncols) {
-        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = cvt_out<bf16_t>(a[e]);
-          v[4 + e] = cvt_out<bf16_t>(b[e]);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (k0 + e < ncols) v[e] = cvt_out<bf16_t>(cvt_in(p[e]));
-      }
-    }
-    *(u16x8*)&act[r * pitch + k0] = v;
-  }
-}
-
-// LDS tile (128 rows x ntiles*32 cols) -> C-fragment order in global memory
-__device__ __forceinline__ void emit_frags_from_lds(const bf16_t* act, int pitch, int ntiles, bf16_t* dst,
-                                                    int mb_base, int wave, int n_waves, int lane) {
-  const int lr = lane & 31, lg = lane >> 5;
-  const int total = 4 * ntiles * 2;
-  for (int f = wave; f < total; f += n_waves) {
-    const int h = f & 1, nt = (f >> 1) % ntiles, mbl = (f >> 1) / ntiles;
-    u16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act[(mbl * 32 + frag_row(h, e, lg)) * pitch + nt * 32 + lr];
-    *(u16x8*)(dst + frag_offset(mb_base + mbl, nt, ntiles, h, lane)) = v;
-  }
-}
-
-// One 32x32 accumulator tile (values final, fp32) as 8 packed bf16 pairs P[i] = (v[2i], v[2i+1]):
-// rows 2i and 2i+1 of the lane's column.  P[0..3] / P[4..7] ARE the two 16-byte C-fragment records
-// of the tile, so saving for backward costs no further conversion.
-__device__ __forceinline__ void pack_tile(const float (&v)[16], unsigned (&P)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) P[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-}
-
-// Packed tile -> LDS activation tile.  Neighbouring lanes hold neighbouring columns: swap the pair
-// with the neighbour (DPP) and let a byte permute build the dword this lane stores — the even lane
-// writes row 2i (its low half + the neighbour's low half), the odd lane row 2i+1 (high halves).
-// Per value pair: 1 cvt_pk (pack_tile) + 1 DPP move + 1 v_perm + 1 ds_write_b32.
-__device__ __forceinline__ void store_packed_to_lds(bf16_t* act, int pitch, int row0_tile, int col, int lane,
-                                                    const unsigned (&P)[8]) {
-  const int lg = lane >> 5, odd = lane & 1;
-  const unsigned sel = odd ? 0x03020706u : 0x05040100u;  // {hi = neighbour's pair, lo = own pair}
-  bf16_t* base = act + (row0_tile + 4 * lg + odd) * pitch + (col & ~1);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = 2 * i;
-    const unsigned other = swap_adjacent_lanes(P[i]);
-    const unsigned word = perm_bytes(other, P[i], sel);
-    *(unsigned*)(base + ((r & 3) + 8 * (r >> 2)) * pitch) = word;
-  }
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-__device__ __forceinline__ void store_packed_frags(bf16_t* dst, int mb, int nt, int NT, int lane,
-                                                   const unsigned (&P)[8]) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-    *(u32x4*)(dst + frag_offset(mb, nt, NT, h, lane)) = u32x4{P[4 * h], P[4 * h + 1], P[4 * h + 2], P[4 * h + 3]};
-}
-
-// bit r = (v[r] > 0).  NONNEG (ReLU outputs: v is +0 or a positive float, never -0/NaN): the sign
-// bit of (0 - bits(v)) is the answer, shifted in by a funnel shift (v_sub + v_alignbit, 2 VALU per
-// element against 3 for compare/select/or).
-template <bool NONNEG>
-__device__ __forceinline__ unsigned positive_bits(const float (&v)[16]) {
-  unsigned bits = 0u;
-#pragma unroll
-  for (int r = 15; r >= 0; --r) {
-    if (NONNEG) bits = (bits << 1) | ((0u - __builtin_bit_cast(unsigned, v[r])) >> 31);
-    else bits = (bits << 1) | (v[r] > 0.f ? 1u : 0u);
-  }
-  return bits;
-}
-
-// ---- main loop of a wide layer: this wave's [128 x 32*TN] slice over K ------------------------
-// `rot` rotates the order in which the K chunks are visited (a sum may be taken in any order):
-// every workgroup streams the SAME weight fragments, and without de-phasing all 256 CUs would
-// hammer one L2 channel at a time (measured on MI355X, C2 forward: 103.5 us with, 107 us without).
-// Software pipeline: the weight (B) fragments come from L2 — ~2000 cycles under this load, measured
-// with profiles/microbench/fwd_phases — and are prefetched RING-1 chunks ahead through a ring of
-// RING register sets; the activation (A) fragments come from LDS, one chunk ahead.
-// wf_wave, rot and every chunk offset are wave-uniform: the weight address math stays on the
-// scalar unit (SGPR base + lane*16 B), only the LDS reads need a vector add per chunk.
-// The K-rotation of (workgroup, wave) for a layer with KC chunks
-__device__ __forceinline__ int k_rotation(int wg, int wave, int KC) { return (wg * 5 + wave * 11) % KC; }
-
-// (Hoisting the ring fill of a layer ahead of the previous epilogue / the input-tile load was
-// measured with profiles/microbench/fwd_phases: the epilogues got 1.2k cycles slower each and the
-// main loops no faster, so the fill stays at the top of the main loop.)
-template <int TN, int RING>
-__device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave,
-                                              long nt_stride, f32x16 (&acc)[4][TN], int lane, int rot,
-                                              int prio_phase = 0) {
-  static_assert(RING >= 2 && RING % 2 == 0, "the A double buffer alternates with the ring slot parity");
-  const int lr = lane & 31, lg = lane >> 5;
-  auto kx = [&](int kc) { const int k = kc + rot; return k >= KC ? k - KC : k; };
-  const bf16_t* arow = act + lr * pitch + lg * 8;
-  const int tm_stride = 32 * pitch;
-  u16x8 a[2][4], b[RING][TN];
-  auto loadB = [&](u16x8 (&bf)[TN], int kc) {
-    const bf16_t* chunk = wf_wave + (long)kx(kc) * 512;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(chunk + tn * nt_stride + lane * 8);
-  };
-  auto loadA = [&](u16x8 (&af)[4], int kc) {
-    const int off = kx(kc) * 16;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow + tm * tm_stride + off);
-  };
-  auto mma = [&](const u16x8 (&af)[4], const u16x8 (&bf)[TN]) {
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
-  };
-  if (KC % RING == 0) {
-    // fast path: no conditionals around the loads in the steady state, so the compiler keeps exact
-    // s_waitcnt vmcnt(N)/lgkmcnt(N) counts and (RING-1)*TN weight loads stay in flight.
-    // Measured alternatives (profiles/microbench/fwd_phases, K=512 main loop, cycles of the early /
-    // late wave of a SIMD): this loop 12.5k / 20.3k; RING=8 13.4k / 21.1k; rotation per block of 4
-    // chunks with all addresses as immediates (a quarter of the scalar instructions) 16.4k / 22.9k;
-    // one wave per SIMD with 16 accumulator tiles 28k.  The loop is bound by how evenly the weight
-    // reads of 256 CUs spread over the L2 channels, not by instruction issue or by load latency.
-#pragma unroll
-    for (int s = 0; s < RING - 1; ++s) loadB(b[s], s);
-    loadA(a[0], 0);
-    int kc = 0;
-    for (; kc < KC - RING; kc += RING) {
-      // The SIMD arbitrates MFMA issue by priority, then age: left alone, the older wave of a pair
-      // takes ~63 % of the pipe and finishes its loop ~8k cycles before its partner, which then runs
-      // the tail alone at half rate.  The younger wave (prio_phase = 1) therefore runs the first half
-      // of its loop at raised priority and hands the advantage back for the second half, so the two
-      // finish together.
-      // (profiles/microbench/fwd_phases, early / late wave of a SIMD, K=512 loop: this hand-off 16.8k /
-      // 19.3k; swapping the priority every ring block 14.7k / 20.3k, every two blocks 15.0k / 20.2k; no
-      // priorities 13.0k / 20.5k — what counts is when the LATER wave gets out.)
-      if (prio_phase && kc * 2 < KC) RG_SETPRIO(1);
-      else RG_SETPRIO(0);
-#pragma unroll
-      for (int s = 0; s < RING; ++s) {
-        loadB(b[(s + RING - 1) % RING], kc + s + RING - 1);
-        loadA(a[(s + 1) & 1], kc + s + 1);
-        sched_fence();
-        mma(a[s & 1], b[s]);
-        sched_fence();
-      }
-    }
-    RG_SETPRIO(0);
-#pragma unroll
-    for (int s = 0; s < RING; ++s) {  // last block: only the loads that are still in range
-      if (s == 0) loadB(b[RING - 1], kc + RING - 1);
-      if (s < RING - 1) loadA(a[(s + 1) & 1], kc + s + 1);
-      sched_fence();
-      mma(a[s & 1], b[s]);
-      sched_fence();
-    }
-    return;
-  }
-  // generic K: same ring with guarded loads
-#pragma unroll
-  for (int s = 0; s < RING - 1; ++s)
-    if (s < KC) loadB(b[s], s);
-  loadA(a[0], 0);
-  for (int kc = 0; kc < KC; kc += RING) {
-#pragma unroll
-    for (int s = 0; s < RING; ++s) {
-      if (kc + s < KC) {
-        if (kc + s + RING - 1 < KC) loadB(b[(s + RING - 1) % RING], kc + s + RING - 1);
-        if (kc + s + 1 < KC) loadA(a[(s + 1) & 1], kc + s + 1);
-        sched_fence();
-        mma(a[s & 1], b[s]);
-        sched_fence();
-      }
-    }
-  }
-}
-
-// one 32x32 output tile (row tile tm, weight n-tile nt) over K; used for narrow / irregular widths.
-// Groups of 4 chunks, next group's fragments in flight during the current group's MFMAs.
-// (Measured alternatives, profiles/microbench/fwd_phases, cycles per wave averaged over the 8 waves:
-// this loop 3.9k; 4 independent accumulators 5.5k; all <= 32 weight chunks requested up front 9.2k —
-// every workgroup reads the same 32 KB, and a burst on that region queues in the L2 channels.)
-__device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf, int tm,
-                                             int nt, int lane) {
-  const int lr = lane & 31, lg = lane >> 5;
-  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8;
-  const bf16_t* wl = wf + (long)nt * KC * 512 + lane * 8;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  u16x8 a0[4], b0[4], a1[4], b1[4];
-  auto load = [&](u16x8 (&af)[4], u16x8 (&bf)[4], int kc0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kc = kc0 + i < KC ? kc0 + i : KC - 1;  // clamped; the extra products are skipped below
-      bf[i] = *(const u16x8*)(wl + (long)kc * 512);
-      af[i] = *(const u16x8*)(arow + kc * 16);
-    }
-  };
-  auto mma = [&](const u16x8 (&af)[4], const u16x8 (&bf)[4], int kc0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (kc0 + i < KC) acc = mfma_32x32x16_bf16(af[i], bf[i], acc);
-  };
-  load(a0, b0, 0);
-  for (int kc = 0; kc < KC; kc += 8) {
-    if (kc + 4 < KC) load(a1, b1, kc + 4);
-    sched_fence();
-    mma(a0, b0, kc);
-    sched_fence();
-    if (kc + 4 < KC) {
-      if (kc + 8 < KC) load(a0, b0, kc + 8);
-      sched_fence();
-      mma(a1, b1, kc + 4);
-      sched_fence();
-    }
-  }
-  return acc;
-}
-
-// Sign bits of a wave's [128 x 32*TN] slice: 2*TN dwords per lane, dword = tn*2 + tm/2,
-// bit = (tm&1)*16 + r for accumulator element r of tile (tm, tn).  For ReLU-family activations the
-// derivative depends on nothing else, so backward prefetches these 16 bytes per lane ahead of its
-// main loop instead of waiting on 8 KB of saved activations per wave in the epilogue.
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-__device__ __forceinline__ long sign_offset(int wg, int wave, int lane, int TN, int width) {
-  // a workgroup's plane: 128 rows x width bits = 4*width dwords = n_waves * 64 lanes * 2*TN dwords
-  return (long)wg * (4 * width) + ((long)wave * 64 + lane) * (2 * TN);
-}
-template <int ACT> constexpr bool act_is_sign_based() { return ACT == ACT_RELU || ACT == ACT_LEAKY_RELU; }
-
-// The hidden-layer epilogues run in two phases around the barrier that protects the in-place LDS
-// tile.  PACK (before the barrier; touches no LDS): bias/activation (or the activation-gradient
-// mask), bf16 packing, the global stores of what backward needs.  STORE (after the barrier): the
-// packed pairs go to the LDS tile.  The two waves of a SIMD do not finish a main loop together (the
-// older one wins the MFMA arbitration and is ~8k cycles early, profiles/microbench/fwd_phases), so
-// the early wave's PACK runs under its partner's MFMAs, and the late wave packs with the SIMD's
-// VALU to itself, instead of both competing for the VALU after the barrier.
-template <int TN>
-__device__ __forceinline__ void store_packed_tiles(bf16_t* act, int pitch, const unsigned (&PK)[4][TN][8], int wave,
-                                                   int lane) {
-  const int lr = lane & 31;
-  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
-    constexpr int tn = decltype(tn_c)::value;
-    const int col = (wave * TN + tn) * 32 + lr;
-    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
-      constexpr int tm = decltype(tm_c)::value;
-      store_packed_to_lds(act, pitch, tm * 32, col, lane, PK[tm][tn]);
-    });
-  });
-}
-
-// (Starting the accumulators at the bias instead of adding it here was tried: the adds are already
-// packed (v_pk_add_f32, 64 per wave and layer), and accumulators that are not a rematerialisable zero
-// cost the TN = 2 kernel 68 spilled registers.)
-template <int TN, int ACT>
-__device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const float* bias, bf16_t* save_dst,
-                                                unsigned* sign_dst, int NT, int mb_base, int wave, int lane,
-                                                unsigned (&PK)[4][TN][8]) {
-  lane = opaque(lane);
-  const int lr = lane & 31;
-  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
-    constexpr int tn = decltype(tn_c)::value;
-    const int nt = wave * TN + tn, col = nt * 32 + lr;
-    const float b = bias ? bias[col] : 0.f;
-    unsigned sg0 = 0u, sg1 = 0u;
-    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
-      constexpr int tm = decltype(tm_c)::value;
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
-      pack_tile(v, PK[tm][tn]);
-      if (save_dst) {
-        store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
-        if (act_is_sign_based<ACT>()) {
-          const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
-          if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
-          else sg1 |= bits << ((tm & 1) * 16);
-        }
-      }
-    });
-    if (act_is_sign_based<ACT>() && sign_dst)
-      ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
-  });
-}
-
-// dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
-template <int TN, int ACT, bool USE_SIGN>
-__device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16_t* h_frag,
-                                                const unsigned (&sg)[2 * TN], bf16_t* dz_dst, float* db_part, int NT,
-                                                int mb_base, int wave, int lane, unsigned (&PK)[4][TN][8]) {
-  lane = opaque(lane);
-  const int lr = lane & 31;
-  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
-    constexpr int tn = decltype(tn_c)::value;
-    const int nt = wave * TN + tn, col = nt * 32 + lr;
-    float colsum = 0.f;
-    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
-      constexpr int tm = decltype(tm_c)::value;
-      float v[16];
-      if (USE_SIGN && act_is_sign_based<ACT>()) {
-        const unsigned bits = sg[tn * 2 + (tm >> 1)] >> ((tm & 1) * 16);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float g = ((bits >> r) & 1u) ? 1.f : (ACT == ACT_RELU ? 0.f : 0.01f);
-          v[r] = acc[tm][tn][r] * g;
-          colsum += v[r];
-        }
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const u16x8 hf = *(const u16x8*)(h_frag + frag_offset(mb_base + tm, nt, NT, h, lane));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_t<ACT>(bf16_to_f32(hf[e]));
-            colsum += v[8 * h + e];
-          }
-        }
-      }
-      pack_tile(v, PK[tm][tn]);
-      store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
-    });
-    colsum += shfl_xor(colsum, 32);
-    if (db_part && lane < 32) db_part[col] = colsum;
-  });
-}
 
 // NW waves per workgroup, each owning 32*TN columns of a hidden layer (hidden width = 32*TN*NW).
 // NW = 4 (one wave per SIMD, up to 512 registers each): 16 accumulator tiles per wave and a weight
@@ -968,6 +515,7 @@ struct UpdateArgs {
   float* t;
   AdamCoef c;
   float tau, one_minus_tau;
+  const double* sched;  // device-resident Adam schedule (rg_optim.h) or null: coefficients as launch arguments
 };
 
 __global__ void mlp_update_kernel(UpdateArgs U) {
@@ -985,8 +533,9 @@ __global__ void mlp_update_kernel(UpdateArgs U) {
     }
   }
   if (l < 0) return;
+  const AdamCoef coef = sched_coef(U.c, U.sched);
   float mi = U.m[i], vi = U.v[i];
-  const float pn = adam_element(U.c, U.p[i], U.g[i], mi, vi);
+  const float pn = adam_element(coef, U.p[i], U.g[i], mi, vi);
   U.p[i] = pn;
   U.m[i] = mi;
   U.v[i] = vi;
@@ -1028,9 +577,9 @@ struct UpdateTileArgs {
   long rest_begin[2 * FB_MAXL + 1];  // prefix sums of the element ranges left to the per-element path
 };
 
-__device__ __forceinline__ void update_one(const UpdateArgs& U, long i, float& pn, float& tn) {
+__device__ __forceinline__ void update_one(const UpdateArgs& U, const AdamCoef& coef, long i, float& pn, float& tn) {
   float mi = U.m[i], vi = U.v[i];
-  pn = adam_element(U.c, U.p[i], U.g[i], mi, vi);
+  pn = adam_element(coef, U.p[i], U.g[i], mi, vi);
   U.p[i] = pn;
   U.m[i] = mi;
   U.v[i] = vi;
@@ -1045,6 +594,7 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
   const UpdateArgs& U = T.u;
   __shared__ bf16_t tile[UT_ROWS * UT_PITCH];
   const int wg = blockIdx.x, tid = threadIdx.x;
+  const AdamCoef coef = sched_coef(U.c, U.sched);
   if (wg >= T.tile_begin[U.n]) {
     // everything the tiles do not cover (biases; weights with odd shapes): one element per thread
     const long j = (long)(wg - T.tile_begin[U.n]) * blockDim.x + tid;
@@ -1055,7 +605,7 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
     const int l = r >> 1, is_w = r & 1;
     const long rel = j - T.rest_begin[r];
     float pn, tn;
-    update_one(U, (is_w ? U.w_off[l] : U.b_off[l]) + rel, pn, tn);
+    update_one(U, coef, (is_w ? U.w_off[l] : U.b_off[l]) + rel, pn, tn);
     if (!is_w) return;
     const int N = U.N[l], K = U.K[l];
     const int n = (int)(rel / K), k = (int)(rel % K);
@@ -1087,7 +637,7 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float mi = M[e], vi = V[e];
-      pn[e] = adam_element(U.c, P[e], G[e], mi, vi);
+      pn[e] = adam_element(coef, P[e], G[e], mi, vi);
       P[e] = pn[e];
       M[e] = mi;
       V[e] = vi;
@@ -1122,27 +672,6 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
     *(u32x4*)(U.wb[l] + jb) = u32x4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
                                     (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
   }
-}
-
-static int fused_supported(const rg_mlp_desc* d) {
-  if (!d || d->n_layers < 2 || d->n_layers > FB_MAXL) return 0;
-  const int H = d->dims[1];
-  if (H != 256 && H != 512) return 0;
-  for (int l = 1; l < d->n_layers; ++l)
-    if (d->dims[l] != H) return 0;
-  if (d->dims[0] < 1 || d->dims[0] > 512) return 0;
-  if (d->dims[d->n_layers] < 1 || d->dims[d->n_layers] > 128) return 0;
-  return H / 256;
-}
-
-// LDS row pitch: widest layer + 8 elements (row stride = 4 banks mod 64: conflict-free 16-byte reads)
-static int fused_pitch(const rg_mlp_desc* d) {
-  int m = 0;
-  for (int l = 0; l <= d->n_layers; ++l) {
-    const int w = (d->dims[l] + 31) / 32 * 32;
-    if (w > m) m = w;
-  }
-  return m <= 256 ? 264 : 520;
 }
 
 // the three (hidden width, pitch) instantiations of a fused kernel template
@@ -1431,9 +960,9 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   return (int)hipGetLastError();
 }
 
-int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
-                        double weight_decay, double bias_correction1, double bias_correction2_sqrt,
-                        double grad_scale, double tau, rg_stream_t stream) {
+static int mlp_update_launch(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, double bias_correction1, double bias_correction2_sqrt,
+                             double grad_scale, double tau, const double* sched, rg_stream_t stream) {
   if (!d || d->n_layers < 1 || d->n_layers > FB_MAXL || !d->param || !d->grad || !d->exp_avg || !d->exp_avg_sq ||
       bias_correction1 == 0.0 || (d->target && (tau < 0.0 || tau > 1.0)))
     return RG_EINVAL;
@@ -1459,6 +988,7 @@ int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, do
   U.c = AdamCoef{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
                  (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale};
   U.tau = (float)tau; U.one_minus_tau = (float)(1.0 - tau);
+  U.sched = sched;
   // weights with 32-byte-addressable rows go to the tiled kernel, the rest of the slab to its
   // per-element workgroups (same launch)
   UpdateTileArgs T;
@@ -1497,6 +1027,20 @@ int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, do
   const int rest_wgs = (int)((rest + 255) / 256);
   RG_LAUNCH(mlp_update_tiles_kernel, dim3((unsigned)(wgs + rest_wgs)), dim3(256), (hipStream_t)stream, T);
   return (int)hipGetLastError();
+}
+
+int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, double bias_correction1, double bias_correction2_sqrt,
+                        double grad_scale, double tau, rg_stream_t stream) {
+  return mlp_update_launch(d, lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, grad_scale,
+                           tau, nullptr, stream);
+}
+
+int rg_mlp_update_fused_sched(const rg_mlp_update_desc* d, double beta1, double beta2, double eps,
+                              double weight_decay, double grad_scale, double tau, const double* sched,
+                              rg_stream_t stream) {
+  if (!sched) return RG_EINVAL;
+  return mlp_update_launch(d, 0.0, beta1, beta2, eps, weight_decay, 1.0, 1.0, grad_scale, tau, sched, stream);
 }
 
 }  // extern "C"

@@ -5,13 +5,18 @@
 namespace rg {
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, AdamCoef c) {
+                            float* __restrict__ v, long n, AdamCoef c0, const double* __restrict__ sched) {
+  const AdamCoef c = sched_coef(c0, sched);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float mi = m[i], vi = v[i];
     p[i] = adam_element(c, p[i], g[i], mi, vi);
     m[i] = mi;
     v[i] = vi;
   }
+}
+
+__global__ void sched_tick_kernel(double* sched) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) sched[0] = sched[0] + 1.0;
 }
 
 __global__ void soft_update_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float tau,
@@ -33,17 +38,38 @@ using namespace rg;
 
 extern "C" {
 
-int rg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                 double lr, double beta1, double beta2, double eps, double weight_decay,
-                 double bias_correction1, double bias_correction2_sqrt, double grad_scale,
-                 rg_stream_t stream) {
+static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                       double beta1, double beta2, double eps, double weight_decay, double bias_correction1,
+                       double bias_correction2_sqrt, double grad_scale, const double* sched, rg_stream_t stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || bias_correction1 == 0.0) return RG_EINVAL;
   if (n == 0) return RG_OK;
   const double step_size = lr / bias_correction1;
   const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay,
                       (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale};
   RG_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)n,
-            c);
+            c, sched);
+  return (int)hipGetLastError();
+}
+
+int rg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 double lr, double beta1, double beta2, double eps, double weight_decay,
+                 double bias_correction1, double bias_correction2_sqrt, double grad_scale,
+                 rg_stream_t stream) {
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
+                     bias_correction2_sqrt, grad_scale, nullptr, stream);
+}
+
+int rg_adam_step_sched(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double beta1,
+                       double beta2, double eps, double weight_decay, double grad_scale, const double* sched,
+                       rg_stream_t stream) {
+  if (!sched) return RG_EINVAL;
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, n, 0.0, beta1, beta2, eps, weight_decay, 1.0, 1.0, grad_scale,
+                     sched, stream);
+}
+
+int rg_sched_tick(double* sched, rg_stream_t stream) {
+  if (!sched) return RG_EINVAL;
+  RG_LAUNCH(sched_tick_kernel, dim3(1), dim3(64), (hipStream_t)stream, sched);
   return (int)hipGetLastError();
 }
 

@@ -31,6 +31,32 @@ __device__ __forceinline__ float adam_element(const AdamCoef& c, float pi, float
   return pi + num / denom;
 }
 
+// Device-resident Adam schedule (graph-safe steps): the two step-dependent coefficients are looked up in HBM
+// instead of arriving as launch arguments, so a captured HIP graph replays the RIGHT step every time.
+//   sched[0] = steps applied so far (the launch applies step sched[0] + 1; rg_sched_tick adds 1 afterwards)
+//   sched[1] = lr      sched[2] = n (table entries)      sched[3] reserved
+//   sched[4 + 2*(t-1)], sched[5 + 2*(t-1)] = 1 - beta1^t, sqrt(1 - beta2^t) for t = 1..n, computed by the host
+//   in double exactly as for the scalar entry points; steps past n use entry n (the host builds the table up to
+//   the step where both have reached their limit 1.0).
+// The divisions below are IEEE double operations, so the coefficients equal the host-computed ones bit for bit.
+__device__ __forceinline__ void sched_lookup(const double* __restrict__ sched, double& lr, double& bc1, double& bc2_sqrt) {
+  long t = (long)sched[0] + 1;
+  const long n = (long)sched[2];
+  if (t > n) t = n;
+  lr = sched[1];
+  bc1 = sched[4 + 2 * (t - 1)];
+  bc2_sqrt = sched[5 + 2 * (t - 1)];
+}
+__device__ __forceinline__ AdamCoef sched_coef(AdamCoef c, const double* __restrict__ sched) {
+  if (sched) {
+    double lr, bc1, bc2s;
+    sched_lookup(sched, lr, bc1, bc2s);
+    c.neg_step_size = (float)(-(lr / bc1));
+    c.bc2_sqrt = (float)bc2s;
+  }
+  return c;
+}
+
 // reagent/optimizer/soft_update.py:60-70: target = tau * source + (1 - tau) * target
 __device__ __forceinline__ float soft_update_element(float tau, float one_minus_tau, float src, float tgt) {
 #pragma clang fp contract(off)

@@ -2,6 +2,7 @@
 // backward), the critic / actor / temperature loss heads.  All are per-transition VALU work on
 // [B, action_dim] or [B] arrays (HBM-bound, tiny next to the FC stacks).
 #include <rg_platform.h>
+#include "rg_optim.h"
 #include "../../include/reagent_hip.h"
 
 namespace rg {
@@ -266,9 +267,11 @@ __global__ void sac_alpha_grad_kernel(const float* __restrict__ ent_part, int np
 // sac_trainer.py:124-126) + alpha = exp(log_alpha) for the next step (:322)
 __global__ void adam_f64_kernel(double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m,
                                 double* __restrict__ v, int n, double lr, double beta1, double beta2,
-                                double eps, double bc1, double bc2_sqrt, double* __restrict__ exp_out) {
+                                double eps, double bc1, double bc2_sqrt, double* __restrict__ exp_out,
+                                const double* __restrict__ sched) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (sched) sched_lookup(sched, lr, bc1, bc2_sqrt);
   const double gi = g[i];
   double mi = m[i], vi = v[i];
   mi = mi + (1.0 - beta1) * (gi - mi);
@@ -397,7 +400,16 @@ int rg_adam_step_f64(double* param, const double* grad, double* exp_avg, double*
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || bias_correction1 == 0.0) return RG_EINVAL;
   RG_LAUNCH(adam_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream, param, grad,
             exp_avg, exp_avg_sq, (int)n, lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt,
-            exp_param_out);
+            exp_param_out, (const double*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int rg_adam_step_f64_sched(double* param, const double* grad, double* exp_avg, double* exp_avg_sq, int64_t n,
+                           double beta1, double beta2, double eps, const double* sched, double* exp_param_out,
+                           rg_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || !sched) return RG_EINVAL;
+  RG_LAUNCH(adam_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream, param, grad,
+            exp_avg, exp_avg_sq, (int)n, 0.0, beta1, beta2, eps, 1.0, 1.0, exp_param_out, sched);
   return (int)hipGetLastError();
 }
 

@@ -428,6 +428,22 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight
                                       bc2_sqrt, grad_scale, L.stream_ptr()))
 
 
+def adam_step_sched(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, sched, grad_scale=1.0,
+                    offset=0):
+    """rg_adam_step with lr and the bias corrections read from the device schedule `sched` (graph-safe)."""
+    _chk_dev(param, grad, exp_avg, exp_avg_sq, sched)
+    o = offset * 4
+    _run("rg_adam_step", dict(n=n),
+         lambda: L.lib().rg_adam_step_sched(param.data_ptr() + o, grad.data_ptr() + o, exp_avg.data_ptr() + o,
+                                            exp_avg_sq.data_ptr() + o, n, beta1, beta2, eps, weight_decay,
+                                            grad_scale, sched.data_ptr(), L.stream_ptr()))
+
+
+def sched_tick(sched):
+    _chk_dev(sched)
+    _run("rg_sched_tick", {}, lambda: L.lib().rg_sched_tick(sched.data_ptr(), L.stream_ptr()))
+
+
 def soft_update(target, source, n, tau, t_off=0, s_off=0):
     _chk_dev(target, source)
     _run("rg_soft_update", dict(n=n),
@@ -500,6 +516,14 @@ def adam_step_f64(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bc1, 
          lambda: L.lib().rg_adam_step_f64(L.ptr(param), L.ptr(grad), L.ptr(exp_avg), L.ptr(exp_avg_sq),
                                           param.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, L.ptr(exp_out),
                                           L.stream_ptr()))
+
+
+def adam_step_f64_sched(param, grad, exp_avg, exp_avg_sq, beta1, beta2, eps, sched, exp_out=None):
+    _chk_dev(param, grad, exp_avg, exp_avg_sq, exp_out, sched)
+    _run("rg_adam_step_f64", dict(n=param.numel()),
+         lambda: L.lib().rg_adam_step_f64_sched(L.ptr(param), L.ptr(grad), L.ptr(exp_avg), L.ptr(exp_avg_sq),
+                                                param.numel(), beta1, beta2, eps, sched.data_ptr(), L.ptr(exp_out),
+                                                L.stream_ptr()))
 
 
 def add_cols(a, b, out):

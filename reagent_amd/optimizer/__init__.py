@@ -17,6 +17,46 @@ def _bump(params):
         p._rg_version = getattr(p, "_rg_version", 0) + 1
 
 
+class AdamSchedule:
+    """Device-resident Adam schedule read by the rg_*_sched entry points (include/reagent_hip.h): the number of
+    steps applied, lr, and the table of (1 - beta1^t, sqrt(1 - beta2^t)) — in double, computed with the same
+    Python expressions the scalar path passes per launch, up to the step where both have reached 1.0.  With it a
+    step captured once in a HIP graph replays as step t, t+1, ... (launch arguments are frozen in a graph; HBM
+    is not).  `pending` counts device steps the host-side `state[p]["step"]` has not been told about yet."""
+
+    MAX_ENTRIES = 1 << 20
+
+    def __init__(self, lr: float, betas, step: int, device):
+        b1, b2 = betas
+        rows = []
+        t = 0
+        while True:
+            t += 1
+            bc1, bc2 = 1.0 - b1**t, math.sqrt(1.0 - b2**t)
+            rows += [bc1, bc2]
+            if bc1 == 1.0 and bc2 == 1.0:
+                break
+            if t >= self.MAX_ENTRIES:
+                raise NotImplementedError(f"betas {betas}: the bias corrections do not reach 1.0 within "
+                                          f"{self.MAX_ENTRIES} steps; use the per-launch scalar path")
+        self.n, self.lr, self.betas = t, float(lr), (b1, b2)
+        self.buf = torch.tensor([float(step), float(lr), float(t), 0.0] + rows, dtype=torch.float64).to(device)
+        self.pending = 0
+
+    def set_lr(self, lr: float):
+        if float(lr) != self.lr:
+            self.lr = float(lr)
+            self.buf[1:2].copy_(torch.tensor([self.lr], dtype=torch.float64))
+
+    def set_step(self, step: int):
+        self.buf[0:1].copy_(torch.tensor([float(step)], dtype=torch.float64))
+        self.pending = 0
+
+
+def capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam arithmetic (torch/optim/adam.py::_single_tensor_adam) executed by ONE
     rg_adam_step launch over the network's flat parameter slab.
@@ -34,7 +74,48 @@ class FusedAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._moments = {}  # group index -> (slab, exp_avg, exp_avg_sq): THIS optimizer's flat moment buffers
+        self._scheds = {}   # group index -> AdamSchedule (graph-safe stepping, enable_device_schedule)
         self.grad_scale = 1.0
+
+    # ---- graph-safe stepping ------------------------------------------------------------------
+    def enable_device_schedule(self):
+        """From now on step() reads lr and the bias corrections from HBM (rg_adam_step_sched) and counts steps on
+        the device: a step captured in a HIP graph stays correct on every replay.  Same bits as the scalar path."""
+        for gi, group in enumerate(self.param_groups):
+            if gi in self._scheds:
+                continue
+            slab, _, _ = self.moments_for(gi)
+            steps = {int(self.state[p]["step"]) if len(self.state.get(p, {})) else 0 for p in slab.params}
+            if len(steps) != 1:
+                raise RuntimeError("a device schedule needs every parameter of the group at the same Adam step")
+            self._scheds[gi] = AdamSchedule(group["lr"], group["betas"], steps.pop(), slab.data.device)
+        return self
+
+    def schedule_for(self, gi: int):
+        return self._scheds.get(gi)
+
+    def note_device_steps(self, n: int):
+        """n more steps were applied on the device without step() being called (graph replays)"""
+        for s in self._scheds.values():
+            s.pending += n
+
+    def materialize_steps(self):
+        """bring state[p]["step"] up to the device-side step counters"""
+        for gi, s in self._scheds.items():
+            if s.pending:
+                slab = self.slab_for(gi)
+                for i in range(len(slab.params)):
+                    st = self.state[slab.params[i]]
+                    if len(st) == 0:
+                        self.advance(gi, i)
+                        st["step"] += s.pending - 1
+                    else:
+                        st["step"] += s.pending
+                s.pending = 0
+
+    def state_dict(self):
+        self.materialize_steps()
+        return super().state_dict()
 
     def slab_for(self, gi: int) -> ParamSlab:
         return self.moments_for(gi)[0]
@@ -81,6 +162,8 @@ class FusedAdam(torch.optim.Optimizer):
         moments are copied INTO the flat buffers the kernel reads and state[p] re-bound to views of them."""
         super().load_state_dict(state_dict)
         self._moments = {}
+        had_sched = bool(self._scheds)
+        self._scheds = {}
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 st = self.state.get(p)
@@ -88,6 +171,8 @@ class FusedAdam(torch.optim.Optimizer):
                     st.pop("_step_int", None)
                     st["step"] = torch.tensor(float(st["step"]))  # own copy: torch hands the saved tensor through
             self.moments_for(gi)  # adopts the loaded tensors
+        if had_sched:
+            self.enable_device_schedule()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -98,6 +183,22 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             slab, exp_avg, exp_avg_sq = self.moments_for(gi)
             beta1, beta2 = group["betas"]
+            sched = self._scheds.get(gi)
+            if sched is not None:
+                gbase = slab.grad.data_ptr()
+                for i, p in enumerate(slab.params):
+                    if p.grad is None:
+                        raise RuntimeError("device-scheduled Adam steps every parameter of the group: a gradient is missing")
+                    if p.grad.data_ptr() != gbase + 4 * slab.offsets[i]:
+                        slab.view(slab.grad, i).copy_(p.grad)
+                if not capturing():
+                    sched.set_lr(group["lr"])
+                    sched.pending += 1
+                ops.adam_step_sched(slab.data, slab.grad, exp_avg, exp_avg_sq, slab.total, beta1, beta2, group["eps"],
+                                    group["weight_decay"], sched.buf, self.grad_scale)
+                ops.sched_tick(sched.buf)
+                _bump(slab.params)
+                continue
             # collect gradients into the flat slab (zero-copy when backward already wrote there)
             runs: List[Tuple[int, int, int]] = []  # (offset, n, step)
             gbase = slab.grad.data_ptr()

@@ -70,11 +70,13 @@ class PolicyNetworkInputMaker:
         (train_low, train_high) = CONTINUOUS_TRAINING_ACTION_RANGE
         self.train_low = torch.tensor(train_low)
         self.train_high = torch.tensor(train_high)
+        self._on = {}  # device -> the four range tensors resident there (no host-to-device copy per batch)
 
     def __call__(self, batch):
         dev = batch.action.device
-        lo, hi = self.action_low.to(dev), self.action_high.to(dev)
-        tl, th = self.train_low.to(dev), self.train_high.to(dev)
+        if dev not in self._on:
+            self._on[dev] = tuple(t.to(dev) for t in (self.action_low, self.action_high, self.train_low, self.train_high))
+        lo, hi, tl, th = self._on[dev]
         not_terminal = 1.0 - batch.terminal.float()
         action = rescale_actions(batch.action, new_min=tl, new_max=th, prev_min=lo, prev_max=hi)
         next_action = rescale_actions(batch.next_action, new_min=tl, new_max=th, prev_min=lo, prev_max=hi)

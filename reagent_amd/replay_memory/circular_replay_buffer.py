@@ -74,6 +74,10 @@ class ReplayBuffer:
         self._update_horizon = update_horizon
         self._gamma = gamma
         self.device = torch.device(device) if device is not None else torch.device("cuda")
+        if self.device.type == "cuda" and self.device.index is None and torch.cuda.is_available():
+            # the device tensors report "cuda:N": compare like with like (an index-less handle made the cached
+            # device copies look stale, i.e. one host-to-device copy per sampled batch)
+            self.device = torch.device("cuda", torch.cuda.current_device())
 
         self.add_count = np.array(0)
         # `_decays` is computed by torch exactly as the reference does (:373) so that the n-step

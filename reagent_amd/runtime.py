@@ -22,7 +22,98 @@ from .preprocessing import DiscreteDqnInputMaker, Preprocessor
 from .replay_memory import ReplayBuffer
 
 
-class OfflineDqnLoop:
+class _GraphedLoop:
+    """HIP-graph replay of the loop's step (SURVEY.md §8e / VERDICT r1 #6): `capture()` records ONE step — index
+    draw, sampler, forwards, loss head, backward, wgrad, Adam + soft update + re-staging — and returns a callable
+    that replays it; per step the host then issues one graph launch instead of ~10-40 ctypes calls.
+
+    What makes a recorded step valid for every later step:
+      * the index draw (torch.randint on the device) and SAC's N(0,1) draws use torch's graph-safe Philox state;
+      * Adam's step-dependent coefficients are read from HBM (optimizer.AdamSchedule, rg_*_sched entry points) —
+        launch arguments would be frozen at their capture-time values;
+      * every buffer the step touches is either persistent (trainer workspaces) or allocated during capture from
+        the graph's private pool (the batch), so addresses are stable.
+    Data parallel (world > 1): three graphs — sample | update | forward+backward — with the RCCL all-reduce of the
+    gradient slab launched eagerly between them, in the deferred-update order of `step()`: the collective is never
+    captured, the next batch is still gathered under it.
+    `flush()` brings the host-side counters (Adam steps, all_batches_processed) up to date."""
+
+    _graph = None
+    _replays = 0
+
+    def _eager_step(self, indices=None):
+        raise NotImplementedError
+
+    def capture(self, warmup: int = 2, static_indices: bool = False):
+        from .training.dqn_trainer import enable_graph_mode
+
+        tr = self.trainer
+        dev = torch.device(self.rb.device)
+        if dev.type != "cuda":
+            raise RuntimeError("HIP graphs need the GPU")
+        enable_graph_mode(tr)
+        for _ in range(max(2, warmup)):  # eager: allocations, optimizer state, first-step staging; the step
+            self.step()                  # after these is the steady-state launch sequence
+        self.flush()
+        torch.cuda.synchronize()
+        dp = getattr(tr, "_dp_group", None) is not None
+        idx = torch.zeros(self.batch_size, dtype=torch.int64, device=dev) if static_indices else None
+        done = tr.all_batches_processed
+        if not dp:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._eager_step(idx)
+            graphs = (g,)
+        else:
+            if not hasattr(tr, "native_forward_backward"):
+                raise NotImplementedError("data-parallel graph replay is built for the DQN-family native step")
+            pool = torch.cuda.graph_pool_handle()
+            gs, gu, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gs, pool=pool, capture_error_mode="thread_local"):  # captured in replay order (shared pool)
+                batch = self.make_batch(idx)
+            with torch.cuda.graph(gu, pool=pool, capture_error_mode="thread_local"):
+                tr.native_update()
+            with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
+                out = tr.native_forward_backward(batch)
+            graphs = (gs, gu, gc)
+            self._graph_batch = batch
+        tr.all_batches_processed = done  # the capture call ran the host side of a step, not the step
+        self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None)
+        return self.replay
+
+    def replay(self, indices=None):
+        G = self._graph
+        if G["idx"] is not None:
+            G["idx"].copy_(indices)
+        if not G["dp"]:
+            G["graphs"][0].replay()
+            self._replays += 1
+            return G["out"]
+        gs, gu, gc = G["graphs"]
+        tr = self.trainer
+        gs.replay()                    # batch k is gathered while all-reduce k-1 is in flight
+        self._join_update()
+        gc.replay()
+        G["pending"] = torch.distributed.all_reduce(tr._slab.grad, group=tr._dp_group, async_op=True)
+        return G["out"]
+
+    def _join_update(self):
+        G = self._graph
+        if G is not None and G["pending"] is not None:
+            G["pending"].wait()        # the compute stream waits for the collective; the host does not
+            G["pending"] = None
+            G["graphs"][1].replay()
+            self._replays += 1
+
+    def _flush_graph(self):
+        from .training.dqn_trainer import note_graph_replays
+
+        self._join_update()
+        note_graph_replays(self.trainer, self._replays)
+        self._replays = 0
+
+
+class OfflineDqnLoop(_GraphedLoop):
     def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int,
                  state_preprocessor: Optional[Preprocessor] = None, state_dtype=None, prefetch: bool = False):
         self.rb = replay_buffer
@@ -97,8 +188,12 @@ class OfflineDqnLoop:
         self._ready = self._launch_prefetch()  # batch k+1 travels while step k computes
         return loss
 
+    def _eager_step(self, indices=None):
+        return self.trainer.train_step_native(self.make_batch(indices))
+
     def flush(self):
         """apply an update left pending by the last step (call before reading parameters)"""
+        self._flush_graph()
         self.trainer.apply_pending_update()
 
 
@@ -133,7 +228,7 @@ class OfflineTableLoop:
         return loss
 
 
-class OfflinePolicyLoop:
+class OfflinePolicyLoop(_GraphedLoop):
     """The same loop for continuous-action trainers (SAC / TD3, BASELINE C4): uniform index draw ->
     ReplayBuffer.sample_transition_batch (rg_replay_nstep + rg_replay_gather, state rows normalized on the
     way when a 1:1 Preprocessor is given) -> PolicyNetworkInputMaker -> trainer.train_step_native, the
@@ -153,5 +248,8 @@ class OfflinePolicyLoop:
     def step(self, indices: Optional[torch.Tensor] = None, **noise):
         return self.trainer.train_step_native(self.make_batch(indices), **noise)
 
+    def _eager_step(self, indices=None):
+        return self.step(indices)
+
     def flush(self):
-        pass
+        self._flush_graph()

@@ -109,6 +109,28 @@ def publish_gradients(slab, params, held=()):
             p.grad.add_(gv)
 
 
+def enable_graph_mode(tr):
+    """Switch every Adam of the trainer's native step to device-scheduled stepping (optimizer.AdamSchedule): what
+    a HIP-graph capture of the step needs.  Eager steps keep working (and produce the same bits)."""
+    for o in tr.native_optimizers():
+        if hasattr(o, "enable_device_schedule"):
+            o.enable_device_schedule()
+    tr._graph_mode = True
+
+
+def note_graph_replays(tr, n: int):
+    """host-side bookkeeping for n steps that ran as graph replays (no Python in between)"""
+    if n <= 0:
+        return
+    for o in tr.native_optimizers():
+        if hasattr(o, "note_device_steps"):
+            o.note_device_steps(n)
+        for g in o.param_groups:  # the compute-type weight copies of an eager call after the replays are re-staged
+            for p in g["params"]:
+                p._rg_version = getattr(p, "_rg_version", 0) + 1
+    tr.all_batches_processed += n
+
+
 def native_step(fn):
     """decorator for train_step_native of the trainers: the whole call runs as a native step"""
     import functools
@@ -428,6 +450,28 @@ class QStepCore(DQNTrainerBaseLightning):
             self.apply_pending_update()
         return loss
 
+    # ---- the native step in two halves (data-parallel HIP-graph replay, runtime._GraphedLoop) -------------
+    @torch.no_grad()
+    def native_forward_backward(self, training_batch) -> torch.Tensor:
+        """forwards + head + backward + wgrad into the gradient slab; no collective, no update"""
+        if getattr(self, "_cpe", None) is not None:
+            raise NotImplementedError("the two-halves form of the native step does not cover the CPE heads")
+        loss = self._hip_forward(training_batch)
+        for p in self._hip_params:
+            p.grad = None
+        with _NativeStep(self):
+            self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
+            publish_gradients(self._slab, self._hip_params)
+        return loss
+
+    @torch.no_grad()
+    def native_update(self):
+        """Adam (1/world folded in) + soft update + re-staging on the gradient slab as it stands"""
+        self._update_pending = True
+        self._pending_reduce = None
+        with _NativeStep(self):
+            self._apply_pending_update()
+
     _update_pending = False
     _pending_reduce = None
     _fused_plan = None
@@ -481,10 +525,12 @@ class QStepCore(DQNTrainerBaseLightning):
             return False
         group = adam.param_groups[0]
         beta1, beta2 = group["betas"]
-        steps = {adam.advance(0, i) for i in range(len(slab.params))}
-        if len(steps) != 1:
-            raise RuntimeError("fused update needs every parameter at the same Adam step")
-        step = steps.pop()
+        sched = adam.schedule_for(0)
+        if sched is None:
+            steps = {adam.advance(0, i) for i in range(len(slab.params))}
+            if len(steps) != 1:
+                raise RuntimeError("fused update needs every parameter at the same Adam step")
+            step = steps.pop()
         d.param, d.grad = slab.data.data_ptr(), slab.grad.data_ptr()
         d.exp_avg, d.exp_avg_sq = exp_avg.data_ptr(), exp_avg_sq.data_ptr()
         d.target = tslab.data.data_ptr()
@@ -492,10 +538,22 @@ class QStepCore(DQNTrainerBaseLightning):
             d.wfrag_fwd[l], d.wfrag_bwd[l] = qs._wf[l].data_ptr(), qs._wb[l].data_ptr()
             d.target_wfrag_fwd[l] = ts._wf[l].data_ptr()
         tau = soft.param_groups[0]["tau"]
-        ops._run("rg_mlp_update_fused", dict(P=slab.total),
-                 lambda: L.lib().rg_mlp_update_fused(d, group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
-                                                     1.0 - beta1**step, math.sqrt(1.0 - beta2**step),
-                                                     1.0 / self._dp_world, tau, L.stream_ptr()))
+        if sched is not None:  # graph-safe: lr and the bias corrections come from HBM, the step is counted there
+            from ..optimizer import capturing
+
+            if not capturing():
+                sched.set_lr(group["lr"])
+                sched.pending += 1
+            ops._run("rg_mlp_update_fused", dict(P=slab.total),
+                     lambda: L.lib().rg_mlp_update_fused_sched(d, beta1, beta2, group["eps"], group["weight_decay"],
+                                                               1.0 / self._dp_world, tau, sched.buf.data_ptr(),
+                                                               L.stream_ptr()))
+            ops.sched_tick(sched.buf)
+        else:
+            ops._run("rg_mlp_update_fused", dict(P=slab.total),
+                     lambda: L.lib().rg_mlp_update_fused(d, group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
+                                                         1.0 - beta1**step, math.sqrt(1.0 - beta2**step),
+                                                         1.0 / self._dp_world, tau, L.stream_ptr()))
         from ..optimizer import _bump
 
         _bump(slab.params)

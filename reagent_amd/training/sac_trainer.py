@@ -54,6 +54,36 @@ class AdamF64(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, alpha_out=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.alpha_out = alpha_out
+        self._sched = None
+
+    # graph-safe stepping: same protocol as FusedAdam (optimizer/__init__.py)
+    def enable_device_schedule(self):
+        if self._sched is None:
+            from ..optimizer import AdamSchedule
+
+            group = self.param_groups[0]
+            p = group["params"][0]
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            self._sched = AdamSchedule(group["lr"], group["betas"], int(st["step"]), p.device)
+        return self
+
+    def note_device_steps(self, n: int):
+        if self._sched is not None:
+            self._sched.pending += n
+
+    def materialize_steps(self):
+        if self._sched is not None and self._sched.pending:
+            for p in self.param_groups[0]["params"]:
+                self.state[p]["step"] += self._sched.pending
+            self._sched.pending = 0
+
+    def state_dict(self):
+        self.materialize_steps()
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -67,9 +97,19 @@ class AdamF64(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
+                out = self.alpha_out() if callable(self.alpha_out) else self.alpha_out
+                if self._sched is not None:
+                    from ..optimizer import capturing
+
+                    if not capturing():
+                        self._sched.set_lr(group["lr"])
+                        self._sched.pending += 1
+                    ops.adam_step_f64_sched(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], b1, b2, group["eps"],
+                                            self._sched.buf, out)
+                    ops.sched_tick(self._sched.buf)
+                    continue
                 st["step"] += 1
                 t = st["step"]
-                out = self.alpha_out() if callable(self.alpha_out) else self.alpha_out
                 ops.adam_step_f64(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2,
                                   group["eps"], 1.0 - b1**t, math.sqrt(1.0 - b2**t), out)
         return None
