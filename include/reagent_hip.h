@@ -29,7 +29,7 @@ extern "C" {
 typedef void* rg_stream_t; /* hipStream_t */
 
 enum { RG_OK = 0, RG_EINVAL = -1, RG_EALIGN = -2, RG_EUNSUPPORTED = -3, RG_EWORKSPACE = -4 };
-enum { RG_PREC_F32 = 0, RG_PREC_BF16 = 1 };
+enum { RG_PREC_F32 = 0, RG_PREC_BF16 = 1, RG_PREC_BF16X3 = 2 /* fused stack only: rg_mlp_desc.x3 */ };
 enum { RG_DT_F32 = 0, RG_DT_BF16 = 1 };
 enum {
   RG_ACT_LINEAR = 0, RG_ACT_RELU = 1, RG_ACT_LEAKY_RELU = 2, RG_ACT_TANH = 3, RG_ACT_SIGMOID = 4,
@@ -109,6 +109,14 @@ typedef struct {
   float* db[RG_MLP_MAX_LAYERS];               /* backward output: bias gradients [dims[l+1]] (nullable) */
   const float* w[RG_MLP_MAX_LAYERS];          /* fp32 master weights [dims[l+1], dims[l]] (stage_weights_fused) */
   float* dw[RG_MLP_MAX_LAYERS];               /* weight gradients, same shape (wgrad_fused) */
+  int32_t x3;                                 /* 0: bf16 operands.  1: split-bf16 ("bf16x3", RG_PREC_BF16X3) — every
+                                               * operand x is carried as hi = bf16(x), lo = bf16(x - hi) and a product
+                                               * is hi*hi + hi*lo + lo*hi on the bf16 MFMA pipe with fp32 accumulation
+                                               * (~2^-16 relative per product: fp32-class results).  All
+                                               * fragment buffers (wfrag_*, act_frag, dz_frag) then hold TWO planes, hi
+                                               * then lo, i.e. twice the element counts rg_*_elems report; the kernels
+                                               * work on 64-row tiles (both planes of the activation tile share the LDS) */
+  int32_t reserved;
 } rg_mlp_desc; /* host struct */
 
 int rg_mlp_fused_supported(const rg_mlp_desc* d);

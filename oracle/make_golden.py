@@ -182,6 +182,9 @@ def gen_sac(name, c):
         for j, nm in enumerate(["q1_loss", "q2_loss", "actor_loss", "alpha_loss"]):
             arrays[f"step{s}_{nm}"] = _np(losses[j])
         arrays[f"step{s}_log_alpha"] = _np(tr.log_alpha)
+        for j, n in enumerate(["q1", "q2", "actor"]):  # optimizer order (sac_trainer.py:148-193)
+            for i, gr in enumerate(loop.last_grads[j]):
+                _put(arrays, f"step{s}_grad_{n}_{i}", gr)
         for n, m in dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network,
                          q1_target=tr.q1_network_target, q2_target=tr.q2_network_target).items():
             for i, p in enumerate(m.parameters()):
@@ -434,6 +437,8 @@ def _gen_baseline_dqn_loop(name, c):
         losses = loop.step(inp)
         arrays[f"step{s}_loss"] = _np(losses[0])
         arrays[f"step{s}_q"] = _np(tr.all_action_scores)
+        for i, gr in enumerate(loop.last_grads[0]):  # d loss / d q_network parameters, as autograd produced them
+            _put(arrays, f"step{s}_grad_{i}", gr)
         for i, p in enumerate(tr.q_network.parameters()):
             _put(arrays, f"step{s}_param_{i}", p)
         for i, p in enumerate(tr.q_network_target.parameters()):
@@ -466,6 +471,8 @@ def _gen_baseline_qr(name, c):
         arrays[f"step{s}_q_mean"] = _np(z.mean(dim=2))
         losses = loop.step(rb)
         arrays[f"step{s}_loss"] = _np(losses[0])
+        for i, gr in enumerate(loop.last_grads[0]):
+            _put(arrays, f"step{s}_grad_{i}", gr)
         for i, p in enumerate(tr.q_network.parameters()):
             _put(arrays, f"step{s}_param_{i}", p)
         for i, p in enumerate(tr.q_network_target.parameters()):
@@ -508,6 +515,9 @@ def _gen_baseline_sac(name, c):
         for j, nm in enumerate(["q1_loss", "q2_loss", "actor_loss", "alpha_loss"]):
             arrays[f"step{s}_{nm}"] = _np(losses[j])
         arrays[f"step{s}_log_alpha"] = _np(tr.log_alpha)
+        for j, n in enumerate(["q1", "q2", "actor"]):  # optimizer order (sac_trainer.py:148-193)
+            for i, gr in enumerate(loop.last_grads[j]):
+                _put(arrays, f"step{s}_grad_{n}_{i}", gr)
         for n, m in dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network,
                          q1_target=tr.q1_network_target, q2_target=tr.q2_network_target).items():
             for i, p in enumerate(m.parameters()):

@@ -31,6 +31,7 @@ class PLLoop:
         self.trainer = trainer
         self.optimizers = [o["optimizer"] for o in trainer.configure_optimizers()]
         self.batch_idx = 0
+        self.last_grads = {}
 
         class _Logger:  # SACTrainer calls self.logger.log_metrics unconditionally (:343)
             def log_metrics(self, *a, **k):
@@ -63,6 +64,9 @@ class PLLoop:
             if loss is not None:  # PL skips the optimizer step when training_step returns None
                 opt.zero_grad()
                 loss.backward()
+                # what autograd handed the optimizer (golden fixtures pin the backward pass with it)
+                self.last_grads[i] = [p.grad.detach().clone() if p.grad is not None else None
+                                      for g in opt.param_groups for p in g["params"]]
                 opt.step()
             for p, rg in saved.items():
                 p.requires_grad = rg

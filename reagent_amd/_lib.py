@@ -71,6 +71,8 @@ class MlpDesc(ctypes.Structure):
         ("db", c_void_p * MLP_MAX_LAYERS),
         ("w", c_void_p * MLP_MAX_LAYERS),
         ("dw", c_void_p * MLP_MAX_LAYERS),
+        ("x3", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 

@@ -204,9 +204,14 @@ struct WgradFragArgs {
   int MB;             // 32-row blocks in total
   int mb_per_split;   // multiple of WG_MB_STAGE
   int splits;
-  float* partial;     // [splits][N*K]
+  float* partial;     // [splits * terms][N*K]
   long slab;
   int N, K;           // valid extents of dW
+  // split-bf16 operands: terms == 3 and every split is computed three times, on (a_hi, b_hi), (a_hi, b_lo) and
+  // (a_lo, b_hi) — three partial slabs that the reduce sums like any other split.  The three workgroups of a
+  // split land on the same XCD, so the hi operands they share are fetched from HBM once.
+  int terms;
+  long a_lo, b_lo;    // element offsets of the lo planes
 };
 
 __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid, char* smem) {
@@ -218,16 +223,22 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
   // places block b on XCD b % 8), so the second reader of a fragment hits that XCD's L2 instead of
   // HBM (PMC: 700 MB fetched per launch against 420 MB of unique operands without this)
   const int tiles = k_groups * n_groups;
-  int tile, split;
+  int tile, split, term;
   if ((g.splits & 7) == 0) {
     const int xcd = bid & 7, slot = bid >> 3;
-    split = (slot / tiles) * 8 + xcd;
+    const int q = slot / tiles;
+    term = q % g.terms;
+    split = (q / g.terms) * 8 + xcd;
     tile = slot % tiles;
   } else {
     tile = bid % tiles;
-    split = bid / tiles;
+    const int q = bid / tiles;
+    term = q % g.terms;
+    split = q / g.terms;
   }
   if (split >= g.splits) return;  // padding workgroups of a grouped launch (uniform for the workgroup)
+  const bf16_t* const ga_frag = g.a_frag + (term == 2 ? g.a_lo : 0);
+  const bf16_t* const gb_frag = g.b_frag + (term == 1 ? g.b_lo : 0);
   const int kg = tile % k_groups;
   const int ng = tile / k_groups;
   const int mb_begin = split * g.mb_per_split;
@@ -261,8 +272,8 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
       constexpr int i = decltype(i_c)::value;
       constexpr bool is_b = i * WG_THREADS >= 1024;
       const int off = (tid + i * WG_THREADS) & 1023, tile = off >> 7;
-      const bf16_t* src = is_b ? g.b_frag + ((long)mb * g.NTb + tb0 + (tile < nb ? tile : nb - 1)) * 1024
-                               : g.a_frag + ((long)mb * g.NTa + ta0 + (tile < na ? tile : na - 1)) * 1024;
+      const bf16_t* src = is_b ? gb_frag + ((long)mb * g.NTb + tb0 + (tile < nb ? tile : nb - 1)) * 1024
+                               : ga_frag + ((long)mb * g.NTa + ta0 + (tile < na ? tile : na - 1)) * 1024;
       global_load_lds_b128(src + (off & 127) * 8, smem + slot * WG_STAGE_BYTES + (wave * 64 + i * WG_THREADS) * 16);
     });
   };
@@ -307,7 +318,7 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
     RG_WAIT_VMCNT(0);
   }
 
-  float* part = g.partial + (long)split * g.slab;
+  float* part = g.partial + ((long)split * g.terms + term) * g.slab;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -386,6 +397,7 @@ __global__ void reduce_group_kernel(ReduceGroupArgs R) {
 
 struct StageGroupArgs {
   int n;
+  int x3;  // also write the lo planes (bf16(w - hi)) behind the hi planes
   long begin[FB_MAXL + 1];
   const float* w[FB_MAXL];
   int N[FB_MAXL], K[FB_MAXL];
@@ -448,7 +460,7 @@ __global__ void reduce_splits2_kernel(const float* __restrict__ partials, long s
 
 // fp32 master weights -> B-fragment order for forward (W) and backward (W^T), zero padded
 __device__ __forceinline__ void stage_weight_elem(const float* __restrict__ w, int N, int K, bf16_t* __restrict__ wf,
-                                                  bf16_t* __restrict__ wb, long i) {
+                                                  bf16_t* __restrict__ wb, long i, int x3 = 0) {
   const int KCf = (K + 15) / 16, NTf = (N + 31) / 32;
   const int KCb = (N + 15) / 16, NTb = (K + 31) / 32;
   const long tf = (long)NTf * KCf * 512, tb = (long)NTb * KCb * 512;
@@ -457,12 +469,18 @@ __device__ __forceinline__ void stage_weight_elem(const float* __restrict__ w, i
   if (wf && i < tf) {
     const int kc = (int)(blk % KCf), nt = (int)(blk / KCf);
     const int n = nt * 32 + (lane & 31), k = kc * 16 + (lane >> 5) * 8 + e;
-    wf[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
+    const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
+    const bf16_t hi = f32_to_bf16(v);
+    wf[i] = hi;
+    if (x3) wf[tf + i] = f32_to_bf16(v - bf16_to_f32(hi));
   }
   if (wb && i < tb) {
     const int kc = (int)(blk % KCb), nt = (int)(blk / KCb);
     const int k = nt * 32 + (lane & 31), n = kc * 16 + (lane >> 5) * 8 + e;  // "weight" = W^T [K][N]
-    wb[i] = (n < N && k < K) ? f32_to_bf16(w[(long)n * K + k]) : (bf16_t)0;
+    const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
+    const bf16_t hi = f32_to_bf16(v);
+    wb[i] = hi;
+    if (x3) wb[tb + i] = f32_to_bf16(v - bf16_to_f32(hi));
   }
 }
 
@@ -479,7 +497,7 @@ __global__ void stage_group_kernel(StageGroupArgs G) {
     if (k < G.n && i >= G.begin[k]) {
       w = G.w[k]; N = G.N[k]; K = G.K[k]; wf = G.wf[k]; wb = G.wb[k]; base = G.begin[k];
     }
-  stage_weight_elem(w, N, K, wf, wb, i - base);
+  stage_weight_elem(w, N, K, wf, wb, i - base, G.x3);
 }
 
 __global__ void stage_weights_frag_kernel(const float* __restrict__ w, int N, int K, bf16_t* __restrict__ wf,
@@ -720,28 +738,6 @@ int rg_stage_weights_frag(const float* w, int out_features, int in_features, voi
   return (int)hipGetLastError();
 }
 
-static int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int backward) {
-  a.n_layers = d->n_layers;
-  a.batch = batch;
-  for (int l = 0; l <= d->n_layers; ++l) a.dims[l] = d->dims[l];
-  for (int l = 0; l < d->n_layers; ++l) {
-    a.acts[l] = d->acts[l];
-    a.wfrag[l] = (const bf16_t*)(backward ? d->wfrag_bwd[l] : d->wfrag_fwd[l]);
-    a.bias[l] = d->bias[l];
-    a.dz_frag[l] = (bf16_t*)d->dz_frag[l];
-    // the sign plane of layer l's input only exists when layer l-1 has a sign-based activation
-    const bool sign_ok = l >= 1 && (d->acts[l - 1] == RG_ACT_RELU || d->acts[l - 1] == RG_ACT_LEAKY_RELU);
-    a.act_sign[l] = sign_ok ? (unsigned*)d->act_sign[l] : nullptr;
-    a.db_part[l] = nullptr;
-    if (!a.wfrag[l] && !(backward && l == 0)) return RG_EINVAL;
-  }
-  for (int l = 0; l <= d->n_layers; ++l) a.act_frag[l] = (bf16_t*)(l < d->n_layers ? d->act_frag[l] : nullptr);
-  a.pitch = fused_pitch(d);
-  a.x = nullptr; a.ldx = 0; a.x_is_f32 = 0; a.out32 = nullptr; a.ldo = 0; a.dout32 = nullptr; a.lddo = 0;
-  a.dx32 = nullptr; a.lddx = 0; a.save = 0;
-  return RG_OK;
-}
-
 int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64_t ldx, int batch, float* out32,
                          int64_t ldo, int save, rg_stream_t stream) {
   const int tn = fused_supported(d);
@@ -754,6 +750,7 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
     for (int l = 0; l < d->n_layers; ++l)
       if (!d->act_frag[l]) return RG_EINVAL;
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
+  if (d->x3) return x3_forward_launch(d, a, (hipStream_t)stream);
   const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
   const dim3 grid((batch + FB_BM - 1) / FB_BM);
   RG_LAUNCH_FUSED(mlp_fwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
@@ -764,7 +761,8 @@ size_t rg_mlp_backward_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   if (!d || batch <= 0) return 0;
   size_t cols = 0;
   for (int l = 0; l < d->n_layers; ++l) cols += (size_t)d->dims[l + 1];
-  return (size_t)((batch + FB_BM - 1) / FB_BM) * cols * sizeof(float);
+  const int n_wg = d->x3 ? (batch + 127) / 128 * (128 / X3_BM) : (batch + FB_BM - 1) / FB_BM;
+  return (size_t)n_wg * cols * sizeof(float);
 }
 
 int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch, float* dx32,
@@ -782,7 +780,7 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
     if (d->db[l]) want_db = true;
   }
   if (dx32 && !d->wfrag_bwd[0]) return RG_EINVAL;
-  const int n_wg = (batch + FB_BM - 1) / FB_BM;
+  const int n_wg = d->x3 ? (batch + 127) / 128 * (128 / X3_BM) : (batch + FB_BM - 1) / FB_BM;
   if (want_db) {
     if (!workspace || workspace_bytes < rg_mlp_backward_fused_workspace_bytes(d, batch)) return RG_EWORKSPACE;
     float* p = (float*)workspace;
@@ -792,10 +790,14 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
     }
   }
   a.dout32 = dout32; a.lddo = lddo; a.dx32 = dx32; a.lddx = lddx;
-  const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
-  const dim3 grid(n_wg);
-  RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
-  rc = (int)hipGetLastError();
+  if (d->x3) {
+    rc = x3_backward_launch(d, a, (hipStream_t)stream);
+  } else {
+    const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
+    const dim3 grid(n_wg);
+    RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+    rc = (int)hipGetLastError();
+  }
   if (rc) return rc;
   ReduceColsGroupArgs G;
   G.n = 0;
@@ -852,6 +854,7 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   g.a_frag = (const bf16_t*)dz_frag; g.b_frag = (const bf16_t*)x_frag;
   g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
+  g.terms = 1; g.a_lo = g.b_lo = 0;
   const int grid = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
   const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
@@ -869,6 +872,7 @@ int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t s
   if (!d || d->n_layers < 1 || d->n_layers > FB_MAXL) return RG_EINVAL;
   StageGroupArgs G;
   G.n = d->n_layers;
+  G.x3 = d->x3;
   long off = 0;
   for (int l = 0; l < FB_MAXL; ++l) {
     G.begin[l] = off;
@@ -910,8 +914,9 @@ size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   if (!d || batch <= 0) return 0;
   size_t total = 0;
   for (int l = 0; l < d->n_layers; ++l) {
-    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, 128);
-    total += (size_t)p.splits * p.slab;
+    const int terms = d->x3 ? 3 : 1;
+    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, 128 / terms);
+    total += (size_t)p.splits * terms * p.slab;
   }
   return total * sizeof(float);
 }
@@ -933,14 +938,18 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     if (l < d->n_layers) {
       if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
       const int out_f = d->dims[l + 1], in_f = d->dims[l];
-      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, 128);
+      const int terms = d->x3 ? 3 : 1;
+      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, 128 / terms);
       WgradFragArgs& g = G.layer[l];
       g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
       g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
       g.partial = part; g.slab = p.slab; g.N = out_f; g.K = in_f;
-      R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
-      part += (size_t)p.splits * p.slab;
-      wg += ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
+      g.terms = terms;
+      g.a_lo = d->x3 ? (long)frag_elems(batch, out_f) : 0;
+      g.b_lo = d->x3 ? (long)frag_elems(batch, in_f) : 0;
+      R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits * terms; R.out[l] = d->dw[l];
+      part += (size_t)p.splits * terms * p.slab;
+      wg += ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits * terms;
       wg = (wg + 7) / 8 * 8;  // keep (block id % 8) == (layer-local id % 8) == XCD
       el += p.slab;
     } else {

@@ -1,0 +1,500 @@
+// mlp_fused_x3.hip — the fused FullyConnected stack in split-bf16 ("bf16x3") arithmetic: fp32-class
+// results from the bf16 MFMA pipe.
+//
+// Why: BASELINE.json's north_star asks for Q-values within 1e-4 of the fp32 reference AND for the dense layers
+// on the bf16 matrix cores.  Plain bf16 operands are ~2e-2 away (8 mantissa bits); exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s.  Here every operand x travels as two bf16 numbers,
+//     hi = bf16(x),  lo = bf16(x - hi)          (x - hi is exact in fp32; hi + lo carries 16 mantissa bits)
+// and a product a*b is evaluated as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  by three v_mfma_f32_32x32x16_bf16
+// into the same fp32 accumulator (the dropped lo*lo term and the truncation of lo are ~2^-16 relative).
+// Measured on the reference's C2 network (BASELINE.md §2 probe): max |dQ| 4e-5.
+//
+// Layout differences from mlp_fused.hip (everything else — C-fragment order of saved activations, weights in
+// B-fragment order streamed L2 -> VGPR with a register ring, two-phase epilogue, sign planes, K rotation — is
+// shared through rg_mlp_frag.h):
+//   * the LDS tile holds BOTH planes, so a workgroup owns 64 rows instead of 128:
+//       hi plane 64 x PITCH bf16 at offset 0, lo plane at offset 64*PITCH   (2 * 64 * 520 * 2 B = 133 KB)
+//   * every fragment buffer in HBM (weights, saved activations, dZ) is [hi plane | lo plane];
+//   * a wave still owns 32*TN output columns, now 2 x TN accumulator tiles; per K chunk it issues
+//     3 * 2 * TN MFMAs for 2*TN weight fragments (hi, lo) and 4 LDS fragments: the MFMA : load ratio is 1.5x
+//     that of the bf16 kernel, weight traffic per MFMA 4/3 of it.
+// Replaces: FullyConnectedNetwork.forward (reagent/models/fully_connected_network.py:157-163) and its
+// autograd backward, in the accuracy class of the reference's fp32 CPU arithmetic.
+#include "rg_mlp_frag.h"
+
+namespace rg {
+
+constexpr int X3_TM = X3_BM / 32;
+
+// (v0, v1) -> packed hi pair and packed lo pair
+__device__ __forceinline__ void split_pack(float v0, float v1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2(v0, v1);
+  const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = pack_bf16x2(v0 - h0, v1 - h1);
+}
+
+// rows [row_base, row_base+64) x cols [0, ncols_pad) of a row-major matrix -> hi / lo LDS planes
+template <typename T, int THREADS, int LO>
+__device__ __forceinline__ void load_tile_split(bf16_t* act, int pitch, const T* src, long ld, int row_base, int nrows,
+                                                int ncols, int ncols_pad, int tid) {
+  const int cpr = ncols_pad / 8;
+  const int total = X3_BM * cpr;
+  const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (int c = tid; c < total; c += THREADS) {
+    const int r = c / cpr, k0 = (c % cpr) * 8;
+    const int grow = row_base + r;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    if (grow < nrows && k0 < ncols) {
+      const T* p = src + (long)grow * ld + k0;
+      if (vec && k0 + 8 <= ncols) {
+        if (sizeof(T) == 4) {
+          const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[e] = a[e];
+            f[4 + e] = b[e];
+          }
+        } else {
+          const u16x8 v = *(const u16x8*)p;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(v[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k0 + e < ncols) f[e] = cvt_in(p[e]);
+      }
+    }
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned hh, ll;
+      split_pack(f[2 * e], f[2 * e + 1], hh, ll);
+      h[e] = hh;
+      l[e] = ll;
+    }
+    *(u32x4*)&act[r * pitch + k0] = h;
+    *(u32x4*)&act[LO + r * pitch + k0] = l;
+  }
+}
+
+// LDS plane (64 rows x ntiles*32 cols) -> C-fragment order in global memory (two 32-row blocks per workgroup)
+__device__ __forceinline__ void emit_frags_x3(const bf16_t* plane, int pitch, int ntiles, bf16_t* dst, int mb_base,
+                                              int wave, int n_waves, int lane) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const int total = X3_TM * ntiles * 2;
+  for (int f = wave; f < total; f += n_waves) {
+    const int h = f & 1, nt = (f >> 1) % ntiles, mbl = (f >> 1) / ntiles;
+    u16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = plane[(mbl * 32 + frag_row(h, e, lg)) * pitch + nt * 32 + lr];
+    *(u16x8*)(dst + frag_offset(mb_base + mbl, nt, ntiles, h, lane)) = v;
+  }
+}
+
+// ---- main loop: this wave's [64 x 32*TN] slice over K, three MFMAs per (A, B) fragment pair -------------
+// Same software pipeline as wide_mainloop (rg_mlp_frag.h): weight fragments (hi and lo) prefetched RING-1
+// chunks ahead from L2 into a register ring, activation fragments (hi and lo) one chunk ahead from LDS.
+// The three terms of a chunk are issued term-major (all tiles' lo*hi, then hi*lo, then hi*hi), so that
+// consecutive MFMAs never wait on each other's accumulator.
+template <int TN, int RING, int LO>
+__device__ __forceinline__ void x3_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave, long wlo,
+                                            long nt_stride, f32x16 (&acc)[X3_TM][TN], int lane, int rot,
+                                            int prio_phase = 0) {
+  static_assert(RING >= 2 && RING % 2 == 0, "the A double buffer alternates with the ring slot parity");
+  const int lr = lane & 31, lg = lane >> 5;
+  auto kx = [&](int kc) { const int k = kc + rot; return k >= KC ? k - KC : k; };
+  const bf16_t* arow = act + lr * pitch + lg * 8;
+  const int tm_stride = 32 * pitch;
+  u16x8 ah[2][X3_TM], al[2][X3_TM], bh[RING][TN], bl[RING][TN];
+  auto loadB = [&](int s, int kc) {
+    const bf16_t* chunk = wf_wave + (long)kx(kc) * 512;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      bh[s][tn] = *(const u16x8*)(chunk + tn * nt_stride + lane * 8);
+      bl[s][tn] = *(const u16x8*)(chunk + wlo + tn * nt_stride + lane * 8);
+    }
+  };
+  auto loadA = [&](int s, int kc) {
+    const int off = kx(kc) * 16;
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm) {
+      ah[s][tm] = *(const u16x8*)(arow + tm * tm_stride + off);
+      al[s][tm] = *(const u16x8*)(arow + LO + tm * tm_stride + off);
+    }
+  };
+  auto mma = [&](int sa, int sb) {
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(al[sa][tm], bh[sb][tn], acc[tm][tn]);
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(ah[sa][tm], bl[sb][tn], acc[tm][tn]);
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(ah[sa][tm], bh[sb][tn], acc[tm][tn]);
+  };
+  if (KC % RING == 0) {
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) loadB(s, s);
+    loadA(0, 0);
+    int kc = 0;
+    for (; kc < KC - RING; kc += RING) {
+      if (prio_phase && kc * 2 < KC) RG_SETPRIO(1);
+      else RG_SETPRIO(0);
+#pragma unroll
+      for (int s = 0; s < RING; ++s) {
+        loadB((s + RING - 1) % RING, kc + s + RING - 1);
+        loadA((s + 1) & 1, kc + s + 1);
+        sched_fence();
+        mma(s & 1, s);
+        sched_fence();
+      }
+    }
+    RG_SETPRIO(0);
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {  // last block: only the loads that are still in range
+      if (s == 0) loadB(RING - 1, kc + RING - 1);
+      if (s < RING - 1) loadA((s + 1) & 1, kc + s + 1);
+      sched_fence();
+      mma(s & 1, s);
+      sched_fence();
+    }
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < RING - 1; ++s)
+    if (s < KC) loadB(s, s);
+  loadA(0, 0);
+  for (int kc = 0; kc < KC; kc += RING) {
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+      if (kc + s < KC) {
+        if (kc + s + RING - 1 < KC) loadB((s + RING - 1) % RING, kc + s + RING - 1);
+        if (kc + s + 1 < KC) loadA((s + 1) & 1, kc + s + 1);
+        sched_fence();
+        mma(s & 1, s);
+        sched_fence();
+      }
+    }
+  }
+}
+
+// one 32x32 output tile over K (narrow output layers, the input-gradient layer): pairs of chunks, the next
+// pair's four fragments per chunk in flight during the current pair's MFMAs
+template <int LO>
+__device__ __forceinline__ f32x16 x3_tile_kloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf, long wlo, int tm,
+                                                int nt, int lane) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8;
+  const bf16_t* wl = wf + (long)nt * KC * 512 + lane * 8;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int G = 2;
+  u16x8 ah[2][G], al[2][G], bh[2][G], bl[2][G];
+  auto load = [&](int s, int kc0) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int kc = kc0 + i < KC ? kc0 + i : KC - 1;  // clamped; the extra products are skipped below
+      bh[s][i] = *(const u16x8*)(wl + (long)kc * 512);
+      bl[s][i] = *(const u16x8*)(wl + wlo + (long)kc * 512);
+      ah[s][i] = *(const u16x8*)(arow + kc * 16);
+      al[s][i] = *(const u16x8*)(arow + LO + kc * 16);
+    }
+  };
+  auto mma = [&](int s, int kc0) {
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+      if (kc0 + i < KC) {
+        acc = mfma_32x32x16_bf16(al[s][i], bh[s][i], acc);
+        acc = mfma_32x32x16_bf16(ah[s][i], bl[s][i], acc);
+        acc = mfma_32x32x16_bf16(ah[s][i], bh[s][i], acc);
+      }
+  };
+  load(0, 0);
+  for (int kc = 0; kc < KC; kc += 2 * G) {
+    if (kc + G < KC) load(1, kc + G);
+    sched_fence();
+    mma(0, kc);
+    sched_fence();
+    if (kc + G < KC) {
+      if (kc + 2 * G < KC) load(0, kc + 2 * G);
+      sched_fence();
+      mma(1, kc + G);
+      sched_fence();
+    }
+  }
+  return acc;
+}
+
+// sign bits of a wave's [64 x 32*TN] slice: TN dwords per lane, dword tn: bit tm*16 + r
+__device__ __forceinline__ long x3_sign_offset(int wg, int wave, int lane, int TN, int width) {
+  return (long)wg * (2 * width) + ((long)wave * 64 + lane) * TN;
+}
+
+template <int TN>
+__device__ __forceinline__ void x3_store_packed_tiles(bf16_t* plane, int pitch, const unsigned (&PK)[X3_TM][TN][8],
+                                                      int wave, int lane) {
+  const int lr = lane & 31;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    const int col = (wave * TN + tn) * 32 + lr;
+    static_for<0, X3_TM>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      store_packed_to_lds(plane, pitch, tm * 32, col, lane, PK[tm][tn]);
+    });
+  });
+}
+
+template <int TN, int ACT>
+__device__ __forceinline__ void x3_fwd_pack(f32x16 (&acc)[X3_TM][TN], const float* bias, bf16_t* save_dst, long save_lo,
+                                            unsigned* sign_dst, int NT, int mb_base, int wave, int lane,
+                                            unsigned (&PH)[X3_TM][TN][8], unsigned (&PL)[X3_TM][TN][8]) {
+  lane = opaque(lane);
+  const int lr = lane & 31;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    const int nt = wave * TN + tn, col = nt * 32 + lr;
+    const float b = bias ? bias[col] : 0.f;
+    unsigned sg = 0u;
+    static_for<0, X3_TM>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) split_pack(v[2 * i], v[2 * i + 1], PH[tm][tn][i], PL[tm][tn][i]);
+      if (save_dst) {
+        store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, PH[tm][tn]);
+        store_packed_frags(save_dst + save_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
+        if (act_is_sign_based<ACT>()) sg |= positive_bits<ACT == ACT_RELU>(v) << (tm * 16);
+      }
+    });
+    if (act_is_sign_based<ACT>() && sign_dst) sign_dst[x3_sign_offset(mb_base / X3_TM, wave, lane, TN, NT * 32) + tn] = sg;
+  });
+}
+
+// dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
+template <int TN, int ACT, bool USE_SIGN>
+__device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16_t* h_frag, long h_lo,
+                                            const unsigned (&sg)[TN], bf16_t* dz_dst, long dz_lo, float* db_part, int NT,
+                                            int mb_base, int wave, int lane, unsigned (&PH)[X3_TM][TN][8],
+                                            unsigned (&PL)[X3_TM][TN][8]) {
+  lane = opaque(lane);
+  const int lr = lane & 31;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    const int nt = wave * TN + tn, col = nt * 32 + lr;
+    float colsum = 0.f;
+    static_for<0, X3_TM>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      float v[16];
+      if (USE_SIGN && act_is_sign_based<ACT>()) {
+        const unsigned bits = sg[tn] >> (tm * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float g = ((bits >> r) & 1u) ? 1.f : (ACT == ACT_RELU ? 0.f : 0.01f);
+          v[r] = acc[tm][tn][r] * g;
+          colsum += v[r];
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const long off = frag_offset(mb_base + tm, nt, NT, h, lane);
+          const u16x8 hf = *(const u16x8*)(h_frag + off), lf = *(const u16x8*)(h_frag + h_lo + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_t<ACT>(bf16_to_f32(hf[e]) + bf16_to_f32(lf[e]));
+            colsum += v[8 * h + e];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) split_pack(v[2 * i], v[2 * i + 1], PH[tm][tn][i], PL[tm][tn][i]);
+      store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PH[tm][tn]);
+      store_packed_frags(dz_dst + dz_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
+    });
+    colsum += shfl_xor(colsum, 32);
+    if (db_part && lane < 32) db_part[col] = colsum;
+  });
+}
+
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
+  constexpr int THREADS = NW * 64, RING = 4, LO = X3_BM * PITCH;
+  RG_DYN_LDS(smem);
+  bf16_t* act = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int lr = lane & 31, lg = lane >> 5;
+  const int row_base = blockIdx.x * X3_BM;
+  constexpr int pitch = PITCH;
+  const int k0p = round_up(a.dims[0], 32);
+  if (a.x_is_f32)
+    load_tile_split<float, THREADS, LO>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
+  else
+    load_tile_split<bf16_t, THREADS, LO>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
+  __syncthreads();
+  if (a.save && a.act_frag[0]) {
+    emit_frags_x3(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * X3_TM, wave, NW, lane);
+    emit_frags_x3(act + LO, pitch, k0p / 32, a.act_frag[0] + a.act_lo[0], blockIdx.x * X3_TM, wave, NW, lane);
+  }
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int K = a.dims[l], N = a.dims[l + 1];
+    const int KC = (K + 15) / 16;
+    if (l < a.n_layers - 1) {  // hidden layer, N == 32 * TN * NW
+      f32x16 acc[X3_TM][TN];
+#pragma unroll
+      for (int tm = 0; tm < X3_TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+      const long nt_stride = (long)KC * 512;
+      x3_mainloop<TN, RING, LO>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, a.wfrag_lo[l], nt_stride, acc,
+                                lane, k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+      unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
+      unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;
+      RG_DISPATCH_ACT(a.acts[l], (x3_fwd_pack<TN, A_>(acc, a.bias[l], (a.save ? a.act_frag[l + 1] : nullptr),
+                                                      a.act_lo[l + 1], sign_dst, N / 32, blockIdx.x * X3_TM, wave, lane, PH,
+                                                      PL)));
+      __syncthreads();  // every wave is done reading the layer input
+      x3_store_packed_tiles<TN>(act, pitch, PH, wave, lane);
+      x3_store_packed_tiles<TN>(act + LO, pitch, PL, wave, lane);
+      __syncthreads();
+    } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
+      const int NTo = (N + 31) / 32;
+      const int out_act = a.acts[l];
+      for (int t = wave; t < X3_TM * NTo; t += NW) {
+        const int tm = t % X3_TM, nt = t / X3_TM;
+        const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, a.wfrag[l], a.wfrag_lo[l], tm, nt, lane);
+        const int col = nt * 32 + lr;
+        if (col < N) {
+          const float b = a.bias[l] ? a.bias[l][col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+            if (row < a.batch) a.out32[(long)row * a.ldo + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
+  constexpr int THREADS = NW * 64, RING = 4, LO = X3_BM * PITCH;
+  RG_DYN_LDS(smem);
+  bf16_t* act = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int lr = lane & 31, lg = lane >> 5;
+  const int row_base = blockIdx.x * X3_BM;
+  constexpr int pitch = PITCH;
+  const int L = a.n_layers;
+  const int nop = round_up(a.dims[L], 32);
+  load_tile_split<float, THREADS, LO>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
+  __syncthreads();
+  emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
+  emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
+  if (a.db_part[L - 1] && tid < a.dims[L]) {
+    float s = 0.f;
+    for (int r = 0; r < X3_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]) + bf16_to_f32(act[LO + r * pitch + tid]);
+    a.db_part[L - 1][(long)blockIdx.x * a.dims[L] + tid] = s;
+  }
+
+  for (int l = L - 1; l >= 1; --l) {
+    // dH = dZ_l (LDS, width dims[l+1]) . W_l -> [64, dims[l]] ; dZ_{l-1} = dH * act'(H_l)
+    const int K = a.dims[l + 1], N = a.dims[l];
+    const int KC = (K + 15) / 16;
+    f32x16 acc[X3_TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    const long nt_stride = (long)KC * 512;
+    unsigned sg[TN];
+    const bool use_sign = a.act_sign[l] != nullptr;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) sg[i] = use_sign ? a.act_sign[l][x3_sign_offset(blockIdx.x, wave, lane, TN, N) + i] : 0u;
+    x3_mainloop<TN, RING, LO>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, a.wfrag_lo[l], nt_stride, acc, lane,
+                              k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+    float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
+    unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
+    if (use_sign) {
+      RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, true>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
+                                                               a.dz_lo[l - 1], dbp, N / 32, blockIdx.x * X3_TM, wave, lane,
+                                                               PH, PL)));
+    } else {
+      RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, false>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
+                                                                a.dz_lo[l - 1], dbp, N / 32, blockIdx.x * X3_TM, wave, lane,
+                                                                PH, PL)));
+    }
+    __syncthreads();  // every wave is done reading dZ_l
+    x3_store_packed_tiles<TN>(act, pitch, PH, wave, lane);
+    x3_store_packed_tiles<TN>(act + LO, pitch, PL, wave, lane);
+    __syncthreads();
+  }
+  if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
+    const int K = a.dims[1], N = a.dims[0];
+    const int KC = (K + 15) / 16, NTi = (N + 31) / 32;
+    for (int t = wave; t < X3_TM * NTi; t += NW) {
+      const int tm = t % X3_TM, nt = t / X3_TM;
+      const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, a.wfrag[0], a.wfrag_lo[0], tm, nt, lane);
+      const int col = nt * 32 + lr;
+      if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (row < a.batch) a.dx32[(long)row * a.lddx + col] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+#define RG_LAUNCH_X3(KERNEL, hidden, pitch, grid, lds, stream, args)                                         \
+  do {                                                                                                       \
+    const dim3 block_(FB_NW * 64);                                                                           \
+    if ((hidden) == 256 && (pitch) == 264) {                                                                 \
+      RG_ALLOW_LDS((KERNEL<256 / (32 * FB_NW), FB_NW, 264>), lds);                                           \
+      RG_LAUNCH_DYN((KERNEL<256 / (32 * FB_NW), FB_NW, 264>), grid, block_, lds, (hipStream_t)stream, args); \
+    } else if ((hidden) == 256) {                                                                            \
+      RG_ALLOW_LDS((KERNEL<256 / (32 * FB_NW), FB_NW, 520>), lds);                                           \
+      RG_LAUNCH_DYN((KERNEL<256 / (32 * FB_NW), FB_NW, 520>), grid, block_, lds, (hipStream_t)stream, args); \
+    } else {                                                                                                 \
+      RG_ALLOW_LDS((KERNEL<512 / (32 * FB_NW), FB_NW, 520>), lds);                                           \
+      RG_LAUNCH_DYN((KERNEL<512 / (32 * FB_NW), FB_NW, 520>), grid, block_, lds, (hipStream_t)stream, args); \
+    }                                                                                                        \
+  } while (0)
+
+// The saved fragment matrices are padded to 128 rows (rg_frag_elems) and the weight-gradient kernel reads every
+// 32-row block of them: a saving forward and the backward therefore cover the padded row count (the extra
+// workgroup sees only out-of-range rows: zero inputs, zero dZ).
+static inline int x3_grid(int batch, bool padded) {
+  return padded ? (batch + 127) / 128 * (128 / X3_BM) : (batch + X3_BM - 1) / X3_BM;
+}
+
+int x3_forward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
+  const dim3 grid(x3_grid(a.batch, a.save != 0));
+  RG_LAUNCH_X3(mlp_fwd_x3_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+int x3_backward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
+  const dim3 grid(x3_grid(a.batch, true));
+  RG_LAUNCH_X3(mlp_bwd_x3_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace rg

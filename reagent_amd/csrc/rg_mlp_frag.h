@@ -49,6 +49,10 @@ struct MlpArgs {
   long lddx;
   int pitch;  // LDS row pitch (elements)
   int save;   // forward: store act_frag[]
+  // split-bf16 ("bf16x3") mode: element offset of the lo plane behind the hi plane of each fragment buffer
+  long wfrag_lo[FB_MAXL];
+  long act_lo[FB_MAXL + 1];
+  long dz_lo[FB_MAXL];
 };
 
 __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -481,5 +485,45 @@ static inline int fused_pitch(const rg_mlp_desc* d) {
   return m <= 256 ? 264 : 520;
 }
 
+
+
+static inline size_t frag_elems(int rows, int cols) {
+  return (size_t)((rows + 127) / 128 * 128) * (size_t)((cols + 31) / 32 * 32);
+}
+static inline size_t wfrag_elems(int out_features, int in_features) {
+  return (size_t)((out_features + 31) / 32) * (size_t)((in_features + 15) / 16) * 512;
+}
+
+static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int backward) {
+  a.n_layers = d->n_layers;
+  a.batch = batch;
+  for (int l = 0; l <= d->n_layers; ++l) a.dims[l] = d->dims[l];
+  for (int l = 0; l < d->n_layers; ++l) {
+    a.acts[l] = d->acts[l];
+    a.wfrag[l] = (const bf16_t*)(backward ? d->wfrag_bwd[l] : d->wfrag_fwd[l]);
+    a.bias[l] = d->bias[l];
+    a.dz_frag[l] = (bf16_t*)d->dz_frag[l];
+    // the sign plane of layer l's input only exists when layer l-1 has a sign-based activation
+    const bool sign_ok = l >= 1 && (d->acts[l - 1] == RG_ACT_RELU || d->acts[l - 1] == RG_ACT_LEAKY_RELU);
+    a.act_sign[l] = sign_ok ? (unsigned*)d->act_sign[l] : nullptr;
+    a.db_part[l] = nullptr;
+    if (!a.wfrag[l] && !(backward && l == 0)) return RG_EINVAL;
+    a.wfrag_lo[l] = d->x3 ? (long)(backward ? wfrag_elems(d->dims[l], d->dims[l + 1]) : wfrag_elems(d->dims[l + 1], d->dims[l])) : 0;
+    a.dz_lo[l] = d->x3 ? (long)frag_elems(batch, d->dims[l + 1]) : 0;
+  }
+  for (int l = 0; l <= d->n_layers; ++l) {
+    a.act_frag[l] = (bf16_t*)(l < d->n_layers ? d->act_frag[l] : nullptr);
+    a.act_lo[l] = d->x3 ? (long)frag_elems(batch, d->dims[l]) : 0;
+  }
+  a.pitch = fused_pitch(d);
+  a.x = nullptr; a.ldx = 0; a.x_is_f32 = 0; a.out32 = nullptr; a.ldo = 0; a.dout32 = nullptr; a.lddo = 0;
+  a.dx32 = nullptr; a.lddx = 0; a.save = 0;
+  return RG_OK;
+}
+
+// split-bf16 kernels (mlp_fused_x3.hip); `a` filled by fill_args, launch geometry decided there
+int x3_forward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream);
+int x3_backward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream);
+constexpr int X3_BM = 64;  // rows per workgroup of the split-bf16 kernels
 
 }  // namespace rg

@@ -255,13 +255,20 @@ class FCStack:
 
 
 class FusedMLP:
-    """bf16 throughput engine for stacks the fused kernels support (hidden width 256/512 shared by
+    """bf16-MFMA engine for stacks the fused kernels support (hidden width 256/512 shared by
     all hidden layers, input <= 512, output <= 128): rg_mlp_forward_fused / rg_mlp_backward_fused /
-    rg_fc_wgrad_frag.  Same interface as FCStack."""
+    rg_mlp_wgrad_fused.  Same interface as FCStack.
 
-    def __init__(self, weights, biases, acts: List[int]):
+    x3=False: bf16 operands (throughput mode, ~2e-2 from fp32).
+    x3=True : split-bf16 operands ("bf16x3", PREC_BF16X3): every operand as hi + lo bf16 planes, three MFMAs
+              per product, fp32-class results (Q within 1e-4 of the reference); every fragment buffer holds
+              two planes."""
+
+    def __init__(self, weights, biases, acts: List[int], x3: bool = False):
         self.weights, self.biases, self.acts = list(weights), list(biases), list(acts)
-        self.precision = L.PREC_BF16
+        self.x3 = bool(x3)
+        self.planes = 2 if self.x3 else 1
+        self.precision = L.PREC_BF16X3 if self.x3 else L.PREC_BF16
         self.cdtype = torch.bfloat16
         self.dims = [self.weights[0].shape[1]] + [w.shape[0] for w in self.weights]
         self.L = len(self.weights)
@@ -301,15 +308,17 @@ class FusedMLP:
         lib = L.lib()
         d = self._desc
         d.n_layers = self.L
+        d.x3 = int(self.x3)
         for i, v in enumerate(self.dims):
             d.dims[i] = v
         need_bwd = bool(need_transposed)
+        P = self.planes
         for i, w in enumerate(self.weights):
             out_f, in_f = w.shape
             if self._wf[i] is None or self._wf[i].device != dev:
-                self._wf[i] = torch.empty(lib.rg_wfrag_elems(out_f, in_f), dtype=torch.bfloat16, device=dev)
+                self._wf[i] = torch.empty(P * lib.rg_wfrag_elems(out_f, in_f), dtype=torch.bfloat16, device=dev)
             if need_bwd and (self._wb[i] is None or self._wb[i].device != dev):
-                self._wb[i] = torch.empty(lib.rg_wfrag_elems(in_f, out_f), dtype=torch.bfloat16, device=dev)
+                self._wb[i] = torch.empty(P * lib.rg_wfrag_elems(in_f, out_f), dtype=torch.bfloat16, device=dev)
             wd = w.detach()
             assert wd.is_contiguous()
             L.require_cuda(wd)
@@ -329,12 +338,14 @@ class FusedMLP:
         ws = {"key": key}
         if training:
             bf = dict(dtype=torch.bfloat16, device=device)
-            ws["act_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l]), **bf) for l in range(self.L)]
-            ws["dz_frag"] = [torch.empty(lib.rg_frag_elems(batch, self.dims[l + 1]), **bf) for l in range(self.L)]
+            P = self.planes
+            ws["act_frag"] = [torch.empty(P * lib.rg_frag_elems(batch, self.dims[l]), **bf) for l in range(self.L)]
+            ws["dz_frag"] = [torch.empty(P * lib.rg_frag_elems(batch, self.dims[l + 1]), **bf) for l in range(self.L)]
             ws["act_sign"] = [torch.empty(lib.rg_sign_bytes(batch, self.dims[l]), dtype=torch.uint8, device=device)
                               if l >= 1 else None for l in range(self.L)]
             dd = L.MlpDesc()
             dd.n_layers = self.L
+            dd.x3 = int(self.x3)
             for i, v in enumerate(self.dims):
                 dd.dims[i] = v
             nbytes = lib.rg_mlp_wgrad_fused_workspace_bytes(dd, batch)
@@ -348,6 +359,7 @@ class FusedMLP:
     def _fill_desc(self):
         d = self._desc
         d.n_layers = self.L
+        d.x3 = int(self.x3)
         for i, v in enumerate(self.dims):
             d.dims[i] = v
         ws = self._ws
@@ -401,7 +413,9 @@ class FusedMLP:
 
 
 def make_stack(weights, biases, acts: List[int], precision: int):
-    """Engine selection: the fused bf16 kernels when the shape allows, else the per-layer GEMMs."""
-    if precision == L.PREC_BF16 and FusedMLP.supported(weights, acts):
-        return FusedMLP(weights, biases, acts)
-    return FCStack(weights, biases, acts, precision)
+    """Engine selection: the fused bf16-MFMA kernels when the shape allows (plain bf16 operands for
+    PREC_BF16, split-bf16 for PREC_BF16X3), else the per-layer GEMMs.  A PREC_BF16X3 stack whose shape the
+    fused kernels do not serve runs on the exact-fp32 MFMA GEMMs: the accuracy class is what was asked for."""
+    if precision in (L.PREC_BF16, L.PREC_BF16X3) and FusedMLP.supported(weights, acts):
+        return FusedMLP(weights, biases, acts, x3=precision == L.PREC_BF16X3)
+    return FCStack(weights, biases, acts, L.PREC_F32 if precision == L.PREC_BF16X3 else precision)

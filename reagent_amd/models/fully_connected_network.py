@@ -23,9 +23,10 @@ _DEFAULT_PRECISION = L.PREC_F32
 
 
 def set_default_precision(precision: int):
-    """PREC_F32 (exact-fp32 MFMA, parity mode) or PREC_BF16 (bf16 MFMA, throughput mode)."""
+    """PREC_F32 (exact-fp32 MFMA, parity mode), PREC_BF16 (bf16 MFMA, throughput mode) or PREC_BF16X3
+    (split-bf16 operands on the bf16 MFMA pipe: fp32-class results at a third of the bf16 rate)."""
     global _DEFAULT_PRECISION
-    assert precision in (L.PREC_F32, L.PREC_BF16)
+    assert precision in (L.PREC_F32, L.PREC_BF16, L.PREC_BF16X3)
     _DEFAULT_PRECISION = precision
 
 
@@ -107,10 +108,11 @@ class FullyConnectedNetwork(ModelBase):
         return [m[0] for m in self.dnn]
 
     def stack(self):
-        if self._stack is None or self._stack.precision != self.precision:
+        if self._stack is None or getattr(self, "_stack_precision", None) != self.precision:
             lin = self.linears()
             self._stack = make_stack([l.weight for l in lin], [l.bias for l in lin],
                                      [L.ACT[a] for a in self.activation_names], self.precision)
+            self._stack_precision = self.precision  # the engine may run a different one (x3 on odd shapes: fp32)
         return self._stack
 
     def __deepcopy__(self, memo):

@@ -91,6 +91,12 @@ class FusedAdam(torch.optim.Optimizer):
             self._scheds[gi] = AdamSchedule(group["lr"], group["betas"], steps.pop(), slab.data.device)
         return self
 
+    def disable_device_schedule(self):
+        """back to per-launch scalar coefficients (no rg_sched_tick launch per step)"""
+        self.materialize_steps()
+        self._scheds = {}
+        return self
+
     def schedule_for(self, gi: int):
         return self._scheds.get(gi)
 

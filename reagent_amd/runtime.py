@@ -105,6 +105,14 @@ class _GraphedLoop:
             G["graphs"][1].replay()
             self._replays += 1
 
+    def release_graph(self):
+        """drop the captured graph(s) and return the optimizers to scalar-argument launches"""
+        from .training.dqn_trainer import disable_graph_mode
+
+        self.flush()
+        self._graph = None
+        disable_graph_mode(self.trainer)
+
     def _flush_graph(self):
         from .training.dqn_trainer import note_graph_replays
 

@@ -118,6 +118,14 @@ def enable_graph_mode(tr):
     tr._graph_mode = True
 
 
+def disable_graph_mode(tr):
+    """back to scalar-argument Adam launches (host step counters brought up to date first)"""
+    for o in tr.native_optimizers():
+        if hasattr(o, "disable_device_schedule"):
+            o.disable_device_schedule()
+    tr._graph_mode = False
+
+
 def note_graph_replays(tr, n: int):
     """host-side bookkeeping for n steps that ran as graph replays (no Python in between)"""
     if n <= 0:
@@ -488,7 +496,8 @@ class QStepCore(DQNTrainerBaseLightning):
         qs, ts = self._qs, self._ts
         plan = self._fused_plan
         if plan is None:
-            ok = (isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and len(adam.param_groups) == 1
+            ok = (isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and not qs.x3 and not ts.x3
+                  and len(adam.param_groups) == 1
                   and len(soft.param_groups) == 1)
             if ok:
                 sp = soft.param_groups[0]["params"]

@@ -71,6 +71,11 @@ class AdamF64(torch.optim.Optimizer):
             self._sched = AdamSchedule(group["lr"], group["betas"], int(st["step"]), p.device)
         return self
 
+    def disable_device_schedule(self):
+        self.materialize_steps()
+        self._sched = None
+        return self
+
     def note_device_steps(self, n: int):
         if self._sched is not None:
             self._sched.pending += n

@@ -57,6 +57,23 @@ def frac_beyond(t, g, key, tol=2e-5):
     return float(((digest(t) - g.t(key)).abs() > tol).double().mean())
 
 
+def grad_err(grads, g, prefix):
+    """max over the tensors of max|dg| / max|g_ref| on the digests — the backward pass against what the
+    reference's autograd handed its optimizer (well conditioned, unlike post-Adam weights)"""
+    worst_rel = 0.0
+    for i, gr in enumerate(grads):
+        ref = g.t(f"{prefix}{i}")
+        worst_rel = max(worst_rel, ((digest(gr) - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item())
+    return worst_rel
+
+
+# Gradient bounds (relative to the tensor's largest entry), ~3x what the MI355X measures.  fp32: rounding only.
+# bf16x3: its own rounding is ~1e-5, the bound is set by ReLU masks — a forward error of 1e-5 puts ~30 of the
+# 3.1 M hidden pre-activations of a 2048-row batch on the other side of zero, and each flipped unit changes one
+# row of dW by that sample's whole contribution (1e-3 of the row's largest entry at these batch sizes).
+GRAD_TOL = {"f32": 3e-5, "bf16x3": 3e-3, "bf16": 3e-1}
+
+
 def check_regenerated(t, g, key):
     """inputs / initial weights are regenerated from seeds on both sides: must be the same bits"""
     assert torch.equal(digest(t), g.t(key)), key
@@ -142,10 +159,22 @@ def test_c2_loop_matches_reference(backend, mode):
         dl = abs(loss.item() - ref_loss) / abs(ref_loss)
         dw = max(digest_err(p, g, f"step{s}_param_{i}") for i, p in enumerate(tr.q_network.parameters()))
         dt = max(digest_err(p, g, f"step{s}_target_{i}") for i, p in enumerate(tr.q_network_target.parameters()))
-        print(f"\n[baseline_c2 {mode} {backend.name} step {s}] max|dQ| {dq:.3e}  rel dloss {dl:.3e}  "
-              f"max|dW| {dw:.3e}  max|dW_target| {dt:.3e}")
-        if mode in ACCURATE:
-            assert dq <= 1e-4 and dl <= 1e-4 and dw <= 2e-5 and dt <= 2e-5
+        dg = grad_err(tr._slab.grad_views(), g, f"step{s}_grad_")
+        frac = max(frac_beyond(p, g, f"step{s}_param_{i}") for i, p in enumerate(tr.q_network.parameters()))
+        print(f"\n[baseline_c2 {mode} {backend.name} step {s}] max|dQ| {dq:.3e}  rel dloss {dl:.3e}  max|dg|/max|g| {dg:.3e}  "
+              f"max|dW| {dw:.3e} ({100 * frac:.2f} % of the sampled weights beyond 2e-5)  max|dW_target| {dt:.3e}")
+        if mode == "f32":
+            assert dq <= 1e-4 and dl <= 1e-4 and dw <= 2e-5 and dt <= 2e-5 and dg <= GRAD_TOL[mode]
+        elif mode == "bf16x3":
+            # Q, loss and the GRADIENT are fp32-class.  Post-Adam weights: the first steps move every weight by
+            # lr * g / (|g| + 1e-8), i.e. by +-lr whatever |g| is, so the ~1e-5 relative gradient error of the
+            # split-bf16 products flips the direction of the few weights whose gradient is smaller than that
+            # error; those differ by 2 * lr, every other one agrees to 2e-5
+            if s == 0:
+                assert dq <= 1e-4 and dl <= 1e-4 and dg <= GRAD_TOL[mode]
+                assert dw <= 2.0 * g.cfg["lr"] * 1.05 and frac <= 0.01 and dt <= 1e-5
+            else:  # starts from weights that differ by 2 * lr at the 0.2 % direction-flipped elements of step 0
+                assert dq <= 1e-2 and dl <= 1e-2 and dw <= 2.0 * (s + 1) * g.cfg["lr"] * 1.05 and frac <= 0.1
         else:
             # bf16 inputs, fp32 accumulate: SURVEY.md §7.3 measured 1.9e-2 on this net.  A first Adam step
             # moves every weight by +-lr whatever the gradient's size, so an element whose tiny gradient
@@ -189,10 +218,11 @@ def test_c3_qrdqn_matches_reference(mode):
         dl = abs(loss.item() - ref) / abs(ref)
         dw = max(digest_err(p, g, f"step{s}_param_{i}") for i, p in enumerate(tr.q_network.parameters()))
         dt = max(digest_err(p, g, f"step{s}_target_{i}") for i, p in enumerate(tr.q_network_target.parameters()))
+        dg = grad_err(tr._slab.grad_views(), g, f"step{s}_grad_")
         print(f"\n[baseline_c3 {mode} step {s}] max|dquantile| {dz:.3e} max|dQmean| {dq:.3e} rel dloss {dl:.3e} "
-              f"max|dW| {dw:.3e} max|dW_target| {dt:.3e}")
-        if mode in ACCURATE:
-            assert dz <= 1e-4 and dq <= 1e-4 and dl <= 1e-4 and dw <= 2e-5 and dt <= 2e-5
+              f"max|dg|/max|g| {dg:.3e} max|dW| {dw:.3e} max|dW_target| {dt:.3e}")
+        if mode in ACCURATE:  # the 3200-wide head is outside the fused kernels' shape set: bf16x3 runs exact fp32 here
+            assert dz <= 1e-4 and dq <= 1e-4 and dl <= 1e-4 and dw <= 2e-5 and dt <= 2e-5 and dg <= GRAD_TOL["f32"]
         else:
             assert dz <= 6e-2 and dl <= 3e-2 and dw <= 2.0 * (s + 1) * c["lr"] * 1.05 and dt <= 1e-5
 
@@ -252,14 +282,25 @@ def test_c4_sac_matches_reference(mode):
               f"rel dloss { {k: float('%.2e' % v) for k, v in dl.items()} } max|dW| { {k: float('%.2e' % v) for k, v in dw.items()} } "
               f"|dlog_alpha| {d_alpha:.2e}")
         actor_frac = max(frac_beyond(p, g, f"step{s}_actor_{i}") for i, p in enumerate(tr.actor_network.parameters()))
-        print(f"  actor weights beyond 2e-5: {100 * actor_frac:.2f} % of the sampled elements (worst tensor)")
-        if mode in ACCURATE:
-            assert d_loc <= 1e-4 * (1 + 20 * s) and d_sl <= 1e-4 * (1 + 20 * s) and d_q1 <= 1e-4 * (1 + 20 * s)
-            assert all(v <= 2e-4 * (1 + 20 * s) for v in dl.values()), dl
-            if s == 0:  # later steps start from actor weights that differ at the sign-undetermined elements
-                assert all(v <= 2e-5 for k, v in dw.items() if k != "actor"), dw
-            assert dw["actor"] <= 2.0 * (s + 1) * c["lr"] * 1.05 and actor_frac <= 0.02 * (s + 1), (dw, actor_frac)
-            assert d_alpha <= 1e-6 * (1 + 100 * s)
+        dg = {n: grad_err(tr._e[n]["slab"].grad_views(), g, f"step{s}_grad_{n}_") for n in ("q1", "q2", "actor")}
+        print(f"  max|dg|/max|g| { {k: float('%.2e' % v) for k, v in dg.items()} }; actor weights beyond 2e-5: "
+              f"{100 * actor_frac:.2f} % of the sampled elements (worst tensor)")
+        if mode in ACCURATE and s == 0:
+            # (later steps start from actor weights that differ at the sign-undetermined elements — see the header —
+            # and are printed, not bounded: the reference itself is not reproducible there across thread counts)
+            assert d_loc <= 1e-4 and d_sl <= 1e-4 and d_q1 <= 1e-4
+            assert all(v <= 2e-4 for v in dl.values()), dl
+            crit_tol = GRAD_TOL[mode] * (10 if mode == "bf16x3" else 1)  # B = 1024: a flipped mask weighs more
+            assert dg["q1"] <= crit_tol and dg["q2"] <= crit_tol and dg["actor"] <= 6e-2, dg
+            crit = {k: v for k, v in dw.items() if k != "actor"}
+            if mode == "f32":
+                assert all(v <= 2e-5 for v in crit.values()), dw
+            else:  # bf16x3: a handful of critic weights with |g| below the split-product error (see test_c2)
+                assert all(v <= 2.0 * c["lr"] * 1.05 for v in crit.values()), dw
+            assert dw["actor"] <= 2.0 * c["lr"] * 1.05 and actor_frac <= 0.02, (dw, actor_frac)
+            assert d_alpha <= 1e-6
+        elif mode in ACCURATE:
+            assert d_loc <= 0.1 and d_q1 <= 0.1 and all(v <= 1e-2 for v in dl.values())
         else:
             # step 0 is the clean bf16 figure; later steps start from weights +-2 lr apart at sign-flipped elements
             assert d_loc <= 6e-2 * (1 + 2 * s) and d_sl <= 6e-2 * (1 + 2 * s) and d_q1 <= 6e-2 * (1 + 2 * s)

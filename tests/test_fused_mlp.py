@@ -124,3 +124,67 @@ def test_unsupported_shapes_fall_back_to_per_layer(backend):
     assert isinstance(make_stack(ws, bs, [1, 1, 0], L.PREC_BF16), FCStack)
     ws, bs = _net([16, 256, 256, 4], ["relu", "relu", "linear"], 0, dev)
     assert isinstance(make_stack(ws, bs, [1, 1, 0], L.PREC_F32), FCStack)
+
+
+# ---- split-bf16 ("bf16x3") mode: fp32-class results from the bf16 MFMA pipe ----------------------------
+def _ref64(ws, bs, acts, x, dout):
+    """float64 statement of the exact math (no rounding anywhere)"""
+    W = [w.detach().cpu().double() for w in ws]
+    Bv = [b.detach().cpu().double() for b in bs]
+    hs = [x.cpu().double()]
+    for w, b, a in zip(W, Bv, acts):
+        hs.append(ACTS[a](hs[-1] @ w.t() + b))
+    dz = dout.cpu().double()
+    dws, dbs = [None] * len(W), [None] * len(W)
+    for l in range(len(W) - 1, -1, -1):
+        dws[l] = dz.t() @ hs[l]
+        dbs[l] = dz.sum(0)
+        dh = dz @ W[l]
+        if l > 0:
+            dz = dh * DACT[acts[l - 1]](hs[l])
+    return hs[-1], dws, dbs, dh
+
+
+@pytest.mark.parametrize("dims,acts,batch", [
+    ([24, 256, 256, 16], ["relu", "relu", "linear"], 100),
+    ([128, 512, 512, 512, 16], ["relu", "relu", "relu", "linear"], 200),
+    ([130, 256, 256, 70], ["leaky_relu", "tanh", "linear"], 129),
+    ([288, 512, 512, 1], ["relu", "relu", "linear"], 70),
+])
+def test_fused_x3_is_fp32_class(backend, dims, acts, batch):
+    """hi/lo split operands, three MFMAs per product: every result within ~1e-5 (relative Frobenius) of the
+    float64 statement — against 2e-3 for plain bf16 operands — and max-abs output error <= 1e-4."""
+    dev = backend.device
+    ws, bs = _net(dims, acts, 1, dev)
+    codes = [L.ACT[a] for a in acts]
+    st = make_stack(ws, bs, codes, L.PREC_BF16X3)
+    assert isinstance(st, FusedMLP) and st.x3
+    st.set_need_input_grad(True)
+    st.stage_weights(need_transposed=True)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(batch, dims[0], generator=g).to(dev)
+    dout = (torch.randn(batch, dims[-1], generator=g) / batch).to(dev)
+    out = torch.zeros(batch, dims[-1], device=dev)
+    xc, xt = st.stage_input(x, True)
+    st.forward(xc, out, save=True)
+    dw = [torch.zeros_like(w) for w in ws]
+    db = [torch.zeros_like(b) for b in bs]
+    dx = torch.zeros(batch, dims[0], device=dev)
+    st.backward(dout, xt, dw, db, dx32=dx)
+    ref_out, ref_dw, ref_db, ref_dx = _ref64(ws, bs, acts, x, dout)
+    print(f"\n[x3 {dims}] out rel {_rel(out, ref_out):.2e} max-abs {(out.double().cpu() - ref_out).abs().max():.2e}; "
+          f"dw rel {[float('%.1e' % _rel(dw[l], ref_dw[l])) for l in range(len(ws))]}; dx rel {_rel(dx, ref_dx):.2e}")
+    assert _rel(out, ref_out) < 2e-5 and (out.double().cpu() - ref_out).abs().max() <= 1e-4
+    for l in range(len(ws)):
+        assert _rel(dw[l], ref_dw[l]) < 3e-5, (l, _rel(dw[l], ref_dw[l]))
+        assert _rel(db[l], ref_db[l]) < 3e-5, (l, _rel(db[l], ref_db[l]))
+    assert _rel(dx, ref_dx) < 3e-5
+    out2 = torch.zeros_like(out)
+    st.forward(xc, out2, save=False)
+    assert torch.equal(out2, out)
+
+
+def test_x3_on_an_unserved_shape_runs_exact_fp32(backend):
+    ws, bs = _net([16, 128, 64, 4], ["relu", "relu", "linear"], 0, backend.device)
+    st = make_stack(ws, bs, [1, 1, 0], L.PREC_BF16X3)
+    assert isinstance(st, FCStack) and st.precision == L.PREC_F32

@@ -281,3 +281,19 @@ def test_data_parallel_three_graph_replay_on_a_one_rank_rccl_group():
             assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+def test_leaving_graph_mode_keeps_the_step_count(emu_lib):
+    from reagent_amd.training.dqn_trainer import disable_graph_mode, enable_graph_mode
+
+    a, b = _dqn("cpu"), _dqn("cpu")
+    enable_graph_mode(b)
+    for s in range(5):
+        if s == 3:
+            disable_graph_mode(b)
+            assert b.native_optimizers()[0].schedule_for(0) is None
+        batch = synthetic.dqn_batch(64, 12, 4, seed=20 + s, p_impossible=0.2)
+        a.train_step_native(synthetic.to_dqn_input(batch, "cpu"))
+        b.train_step_native(synthetic.to_dqn_input(batch, "cpu"))
+    for x, y in zip(a.parameters(), b.parameters()):
+        assert torch.equal(x, y)
