@@ -1,0 +1,139 @@
+// Calibration microbenchmark (not product code): what rate does the fused forward's MAIN LOOP sustain when its
+// operand feeds are switched on one by one?  Same shape as mlp_fused.hip's wide_mainloop: 8 waves per workgroup,
+// one workgroup per CU, each wave 4 x 2 accumulator tiles, per K chunk 4 A fragments (LDS) + 2 B fragments
+// (global, B-fragment order, 512 KB "weight" per layer shared by every workgroup) -> 8 MFMAs, ring of 4 / double
+// buffer.  No epilogue, no barriers: pure main loop, K = 512 x `layers`.
+// Build: hipcc --offload-arch=gfx950 -O3 mfma_feed.hip -o mfma_feed ; run: ./mfma_feed
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ f32x16 mfma(u16x8 a, u16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int PITCH = 520, KC = 32;
+
+// MODE bit 0: A fragments from LDS each chunk; bit 1: B fragments from global each chunk; bit 2: rotate K per (wg, wave)
+template <int MODE, int NWAVES, int TM, int TN, int RING>
+__global__ void __launch_bounds__(NWAVES * 64, 1) feed(const unsigned short* __restrict__ wf, float* out, int layers) {
+  extern __shared__ char smem[];
+  unsigned short* act = (unsigned short*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < TM * 32 * PITCH; i += NWAVES * 64) act[i] = (unsigned short)(0x3c00 + ((i * 2654435761u) >> 20));
+  __syncthreads();
+  const int lr = lane & 31, lg = lane >> 5;
+  const unsigned short* arow = act + lr * PITCH + lg * 8;
+  const long nt_stride = (long)KC * 512;
+  const unsigned short* wf_wave = wf + (long)(wave * TN) * nt_stride;
+  const int rot = (MODE & 4) ? (blockIdx.x * 5 + wave * 11) % KC : 0;
+  auto kx = [&](int kc) { const int k = kc + rot; return k >= KC ? k - KC : k; };
+  f32x16 acc[TM][TN];
+  for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  u16x8 a[2][TM], b[RING][TN];
+  auto loadB = [&](int s, int kc) {
+    const unsigned short* chunk = wf_wave + (long)kx(kc) * 512;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[s][tn] = *(const u16x8*)(chunk + tn * nt_stride + lane * 8);
+  };
+  auto loadA = [&](int s, int kc) {
+    const int off = kx(kc) * 16;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[s][tm] = *(const u16x8*)(arow + tm * 32 * PITCH + off);
+  };
+  // MODE bit 3: every MFMA reads the SAME two operand registers (random data); bit 4: tn-major issue order
+  auto mma = [&](int sa, int sb) {
+    if (MODE & 8) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma(a[0][0], b[0][0], acc[tm][tn]);
+    } else if (MODE & 16) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = mfma(a[sa][tm], b[sb][tn], acc[tm][tn]);
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma(a[sa][tm], b[sb][tn], acc[tm][tn]);
+    }
+  };
+  for (int s = 0; s < RING; ++s) loadB(s, s % KC);
+  loadA(0, 0);
+  loadA(1, 1);
+  for (int l = 0; l < layers; ++l) {
+    if (MODE & 2) {
+#pragma unroll
+      for (int s = 0; s < RING - 1; ++s) loadB(s, s);
+    }
+    if (MODE & 1) loadA(0, 0);
+    for (int kc = 0; kc < KC; kc += RING) {
+#pragma unroll
+      for (int s = 0; s < RING; ++s) {
+        if ((MODE & 2) && kc + s + RING - 1 < KC) loadB((s + RING - 1) % RING, kc + s + RING - 1);
+        if ((MODE & 1) && kc + s + 1 < KC) loadA((s + 1) & 1, kc + s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(s & 1, s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <int MODE, int NWAVES, int TM, int TN, int RING = 4>
+void run(const char* what, const unsigned short* wf, float* out, int grid, int lds) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int layers = 12;
+  auto k = feed<MODE, NWAVES, TM, TN, RING>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  k<<<grid, NWAVES * 64, lds>>>(wf, out, layers);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int reps = 10;
+  for (int r = 0; r < reps; ++r) k<<<grid, NWAVES * 64, lds>>>(wf, out, layers);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / reps;
+  const double flop = (double)grid * NWAVES * layers * KC * TM * TN * 32768.0;
+  printf("%-58s ring %d waves %d tile %dx%d grid %4d: %8.1f us  %7.1f TFLOP/s  (%.3f of 2500)\n", what, RING, NWAVES, TM, TN, grid, us,
+         flop / us * 1e-6, flop / us * 1e-6 / 2500.0);
+}
+
+int main() {
+  float* out;
+  hipMalloc(&out, 4);
+  const size_t n = (size_t)16 * KC * 512 * 2;  // 16 n-tiles x KC chunks x 512 elements, x2 slack
+  std::vector<unsigned short> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = (unsigned short)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
+  unsigned short* wf;
+  hipMalloc(&wf, n * 2);
+  hipMemcpy(wf, h.data(), n * 2, hipMemcpyHostToDevice);
+  const int lds128 = 128 * PITCH * 2, lds64 = 64 * PITCH * 2;
+  run<0, 8, 4, 2>("registers only (random operands)", wf, out, 512, lds128);
+  run<8, 8, 4, 2>("registers only, ONE operand pair for every MFMA (random data)", wf, out, 512, lds128);
+  run<16, 8, 4, 2>("registers only, tn-major issue order", wf, out, 512, lds128);
+  run<0, 4, 4, 2>("registers only, 4 waves (1 per SIMD)", wf, out, 512, lds128);
+  run<0, 8, 4, 2>("registers only, grid 64", wf, out, 64, lds128);
+  run<0, 8, 4, 2>("registers only, grid 256", wf, out, 256, lds128);
+  run<2, 8, 4, 2, 2>("B from L2 ring 2", wf, out, 512, lds128);
+  run<3, 8, 4, 2, 2>("A from LDS + B from L2 ring 2", wf, out, 512, lds128);
+  run<18, 8, 4, 2, 2>("B from L2 ring 2, tn-major", wf, out, 512, lds128);
+  return 0;
+}

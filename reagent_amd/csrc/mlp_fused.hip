@@ -31,7 +31,7 @@ template <int NW> struct MlpCfg {
 #ifdef RG_FUSED_RING
   static constexpr int RING = RG_FUSED_RING;
 #else
-  static constexpr int RING = NW == 4 ? 8 : 4;
+  static constexpr int RING = NW == 4 ? 8 : 2;
 #endif
 };
 
@@ -710,6 +710,13 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
 
 }  // namespace rg
 
+namespace rg {
+static int padded_wgs(const rg_mlp_desc* d, int batch) {
+  const int bm = d->x3 ? X3_BM : FB_BM;
+  return (batch + 127) / 128 * (128 / bm);
+}
+}  // namespace rg
+
 using namespace rg;
 
 extern "C" {
@@ -761,8 +768,7 @@ size_t rg_mlp_backward_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   if (!d || batch <= 0) return 0;
   size_t cols = 0;
   for (int l = 0; l < d->n_layers; ++l) cols += (size_t)d->dims[l + 1];
-  const int n_wg = d->x3 ? (batch + 127) / 128 * (128 / X3_BM) : (batch + FB_BM - 1) / FB_BM;
-  return (size_t)n_wg * cols * sizeof(float);
+  return (size_t)padded_wgs(d, batch) * cols * sizeof(float);
 }
 
 int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch, float* dx32,
@@ -780,7 +786,7 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
     if (d->db[l]) want_db = true;
   }
   if (dx32 && !d->wfrag_bwd[0]) return RG_EINVAL;
-  const int n_wg = d->x3 ? (batch + 127) / 128 * (128 / X3_BM) : (batch + FB_BM - 1) / FB_BM;
+  const int n_wg = padded_wgs(d, batch);
   if (want_db) {
     if (!workspace || workspace_bytes < rg_mlp_backward_fused_workspace_bytes(d, batch)) return RG_EWORKSPACE;
     float* p = (float*)workspace;

@@ -22,6 +22,10 @@
 // autograd backward, in the accuracy class of the reference's fp32 CPU arithmetic.
 #include "rg_mlp_frag.h"
 
+#ifndef RG_X3_RING
+#define RG_X3_RING 4
+#endif
+
 namespace rg {
 
 constexpr int X3_TM = X3_BM / 32;
@@ -327,7 +331,7 @@ __device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16
 
 template <int TN, int NW, int PITCH>
 __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
-  constexpr int THREADS = NW * 64, RING = 4, LO = X3_BM * PITCH;
+  constexpr int THREADS = NW * 64, RING = RG_X3_RING, LO = X3_BM * PITCH;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -390,7 +394,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
 
 template <int TN, int NW, int PITCH>
 __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
-  constexpr int THREADS = NW * 64, RING = 4, LO = X3_BM * PITCH;
+  constexpr int THREADS = NW * 64, RING = RG_X3_RING, LO = X3_BM * PITCH;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);

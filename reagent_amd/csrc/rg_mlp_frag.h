@@ -255,6 +255,12 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
   if (KC % RING == 0) {
     // fast path: no conditionals around the loads in the steady state, so the compiler keeps exact
     // s_waitcnt vmcnt(N)/lgkmcnt(N) counts and (RING-1)*TN weight loads stay in flight.
+    // Round 2 (profiles/microbench/mfma_feed.hip, this loop without epilogues or barriers, random data, whole
+    // chip): MFMAs fed from registers only 0.62-0.66 of the nominal 2.5 PFLOP/s (0.84 per CU when only 64 CUs
+    // run: the chip clocks down under dense MFMA load on real data), + A fragments from LDS 0.54, + B
+    // fragments from L2 0.39 with RING = 4, 0.42-0.45 with RING = 2 (a deeper ring only lengthens the L2
+    // queues); in the step RING = 2 measured 168-171 us for the two non-saving forwards against 173-179 with
+    // RING = 4 (same box), so 2 is the default for the 8-wave kernels.
     // Measured alternatives (profiles/microbench/fwd_phases, K=512 main loop, cycles of the early /
     // late wave of a SIMD): this loop 12.5k / 20.3k; RING=8 13.4k / 21.1k; rotation per block of 4
     // chunks with all addresses as immediates (a quarter of the scalar instructions) 16.4k / 22.9k;
