@@ -117,6 +117,15 @@ typedef struct {
                                                * then lo, i.e. twice the element counts rg_*_elems report; the kernels
                                                * work on 64-row tiles (both planes of the activation tile share the LDS) */
   int32_t reserved;
+  /* Two-panel network input (FullyConnectedCritic: cat(state, action), reagent/models/critic.py:79-92) without
+   * materialising the concatenation: when x2 != NULL the forward reads input columns [0, x_split) from its `x`
+   * argument and columns [x_split, dims[0]) from x2 (row pitch ldx2, same dtype); x_split a multiple of 32. */
+  const void* x2;
+  int64_t ldx2;
+  int32_t x_split;
+  /* backward: dx32 receives d loss / d input columns [dx_col0, dims[0]) only (dx32[0] is column dx_col0; a
+   * multiple of 32) — SAC's actor step needs the action columns of the critic's input gradient, not the state's */
+  int32_t dx_col0;
 } rg_mlp_desc; /* host struct */
 
 int rg_mlp_fused_supported(const rg_mlp_desc* d);

@@ -52,7 +52,16 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
   constexpr int pitch = PITCH;
   const int k0p = round_up(a.dims[0], 32);
   RG_STAMP(0);
-  if (a.x_is_f32)
+  if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
+    const int n2 = a.dims[0] - a.x_split;
+    if (a.x_is_f32) {
+      load_tile_to_lds<float, THREADS>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
+      load_tile_to_lds<float, THREADS>(act + a.x_split, pitch, (const float*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
+    } else {
+      load_tile_to_lds<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
+      load_tile_to_lds<bf16_t, THREADS>(act + a.x_split, pitch, (const bf16_t*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
+    }
+  } else if (a.x_is_f32)
     load_tile_to_lds<float, THREADS>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   else
     load_tile_to_lds<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
@@ -170,16 +179,16 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
   }
   if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
     const int K = a.dims[1], N = a.dims[0];
-    const int KC = (K + 15) / 16, NTi = (N + 31) / 32;
-    for (int t = wave; t < 4 * NTi; t += NW) {
-      const int tm = t & 3, nt = t >> 2;
+    const int KC = (K + 15) / 16, NTi = (N + 31) / 32, nt0 = a.dx_col0 / 32;  // only the tiles from dx_col0 on
+    for (int t = wave; t < 4 * (NTi - nt0); t += NW) {
+      const int tm = t & 3, nt = nt0 + (t >> 2);
       const f32x16 acc = tile_kloop(act, pitch, KC, a.wfrag[0], tm, nt, lane);
       const int col = nt * 32 + lr;
       if (col < N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-          if (row < a.batch) a.dx32[(long)row * a.lddx + col] = acc[r];
+          if (row < a.batch) a.dx32[(long)row * a.lddx + col - a.dx_col0] = acc[r];
         }
       }
     }
@@ -756,6 +765,7 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   if (save)
     for (int l = 0; l < d->n_layers; ++l)
       if (!d->act_frag[l]) return RG_EINVAL;
+  if (d->x2 && (d->x_split <= 0 || d->x_split >= d->dims[0] || (d->x_split % 32) != 0)) return RG_EINVAL;
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
   if (d->x3) return x3_forward_launch(d, a, (hipStream_t)stream);
   const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
@@ -786,6 +796,7 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
     if (d->db[l]) want_db = true;
   }
   if (dx32 && !d->wfrag_bwd[0]) return RG_EINVAL;
+  if (d->dx_col0 < 0 || d->dx_col0 >= d->dims[0] || (d->dx_col0 % 32) != 0) return RG_EINVAL;
   const int n_wg = padded_wgs(d, batch);
   if (want_db) {
     if (!workspace || workspace_bytes < rg_mlp_backward_fused_workspace_bytes(d, batch)) return RG_EWORKSPACE;

@@ -339,7 +339,16 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   const int row_base = blockIdx.x * X3_BM;
   constexpr int pitch = PITCH;
   const int k0p = round_up(a.dims[0], 32);
-  if (a.x_is_f32)
+  if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
+    const int n2 = a.dims[0] - a.x_split;
+    if (a.x_is_f32) {
+      load_tile_split<float, THREADS, LO>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
+      load_tile_split<float, THREADS, LO>(act + a.x_split, pitch, (const float*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
+    } else {
+      load_tile_split<bf16_t, THREADS, LO>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
+      load_tile_split<bf16_t, THREADS, LO>(act + a.x_split, pitch, (const bf16_t*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
+    }
+  } else if (a.x_is_f32)
     load_tile_split<float, THREADS, LO>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   else
     load_tile_split<bf16_t, THREADS, LO>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
@@ -449,16 +458,16 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
   }
   if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
     const int K = a.dims[1], N = a.dims[0];
-    const int KC = (K + 15) / 16, NTi = (N + 31) / 32;
-    for (int t = wave; t < X3_TM * NTi; t += NW) {
-      const int tm = t % X3_TM, nt = t / X3_TM;
+    const int KC = (K + 15) / 16, NTi = (N + 31) / 32, nt0 = a.dx_col0 / 32;  // only the tiles from dx_col0 on
+    for (int t = wave; t < X3_TM * (NTi - nt0); t += NW) {
+      const int tm = t % X3_TM, nt = nt0 + t / X3_TM;
       const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, a.wfrag[0], a.wfrag_lo[0], tm, nt, lane);
       const int col = nt * 32 + lr;
       if (col < N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-          if (row < a.batch) a.dx32[(long)row * a.lddx + col] = acc[r];
+          if (row < a.batch) a.dx32[(long)row * a.lddx + col - a.dx_col0] = acc[r];
         }
       }
     }

@@ -40,6 +40,10 @@ struct MlpArgs {
   float* db_part[FB_MAXL];        // backward: [n_workgroups][dims[l+1]] bias-gradient partials (nullable)
   const void* x;                  // forward input [batch, dims[0]] row-major, bf16 or fp32
   long ldx;
+  const void* x2;                 // optional second input panel: columns [x_split, dims[0]) come from here
+  long ldx2;
+  int x_split;
+  int dx_col0;                    // backward: first input column whose gradient is produced (dx32[0])
   int x_is_f32;
   float* out32;  // forward output [batch, dims[L]] fp32
   long ldo;
@@ -522,6 +526,7 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
     a.act_lo[l] = d->x3 ? (long)frag_elems(batch, d->dims[l]) : 0;
   }
   a.pitch = fused_pitch(d);
+  a.x2 = d->x2; a.ldx2 = d->ldx2; a.x_split = d->x2 ? d->x_split : 0; a.dx_col0 = d->dx_col0;
   a.x = nullptr; a.ldx = 0; a.x_is_f32 = 0; a.out32 = nullptr; a.ldo = 0; a.dout32 = nullptr; a.lddo = 0;
   a.dx32 = nullptr; a.lddx = 0; a.save = 0;
   return RG_OK;

@@ -360,6 +360,7 @@ class FusedMLP:
         d = self._desc
         d.n_layers = self.L
         d.x3 = int(self.x3)
+        d.dx_col0 = 0
         for i, v in enumerate(self.dims):
             d.dims[i] = v
         ws = self._ws
@@ -376,12 +377,22 @@ class FusedMLP:
     def stage_input(self, x32: torch.Tensor, need_transposed: bool):
         return x32, None  # the kernel reads fp32 (or bf16) rows directly and casts in flight
 
-    def forward(self, xc: torch.Tensor, out32: torch.Tensor, save: bool = False):
+    def forward(self, xc: torch.Tensor, out32: torch.Tensor, save: bool = False, x2: Optional[torch.Tensor] = None):
+        """x2 (optional): second input panel — the network input is cat(xc, x2) (FullyConnectedCritic's
+        cat(state, action), critic.py:79-92) read in place by the kernel; xc.shape[1] must be a multiple of 32."""
         L.require_cuda(xc)
         B = xc.shape[0]
         self._ensure_ws(B, xc.device, training=save)
         d = self._fill_desc()
         assert xc.stride(1) == 1 and out32.stride(1) == 1
+        if x2 is not None:
+            L.require_cuda(x2)
+            assert x2.dtype == xc.dtype and x2.stride(1) == 1 and xc.shape[1] % 32 == 0
+            assert xc.shape[1] + x2.shape[1] == self.dims[0] and x2.shape[0] == B
+            d.x2, d.ldx2, d.x_split = x2.data_ptr(), x2.stride(0), xc.shape[1]
+        else:
+            assert xc.shape[1] == self.dims[0]
+            d.x2, d.ldx2, d.x_split = None, 0, 0
         ops._run("rg_mlp_forward_fused", dict(B=B, save=int(save), dims=tuple(self.dims)),
                  lambda: L.lib().rg_mlp_forward_fused(d, xc.data_ptr(), ops.dt_code(xc.dtype), xc.stride(0), B,
                                                       out32.data_ptr(), out32.stride(0), int(save),
@@ -390,11 +401,16 @@ class FusedMLP:
 
     def backward(self, dout32: torch.Tensor, xt, dw: List[torch.Tensor], db: List[torch.Tensor],
                  dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False,
-                 out32: Optional[torch.Tensor] = None):
+                 out32: Optional[torch.Tensor] = None, dx_col0: int = 0):
+        """dx_col0: dx32 receives the gradient of input columns [dx_col0, in_features) only (a multiple of 32)"""
         dout32 = _through_output_activation(self.acts[-1], dout32, out32)
         B = dout32.shape[0]
         assert self._ws.get("key") == (B, dout32.device, True), "backward needs a saving forward first"
         d = self._fill_desc()
+        d.x2, d.ldx2, d.x_split = None, 0, 0
+        d.dx_col0 = dx_col0
+        if dx32 is not None:
+            assert dx_col0 % 32 == 0 and dx32.shape[1] == self.dims[0] - dx_col0
         lib = L.lib()
         ws = self._ws
         for l in range(self.L):

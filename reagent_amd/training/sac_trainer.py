@@ -221,17 +221,27 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         for k in ("q1", "q2"):
             if k in self._e:
                 self._e[k]["stack"].set_need_input_grad(True)
+        from ..engine import FusedMLP
+
+        # cat(state, action) is read in place by the fused kernels as two K-panels (critic.py:79-92) when every
+        # critic stack runs on them; the per-layer GEMM engine takes the assembled [B, S + A] matrix
+        self._panels = S % 32 == 0 and all(isinstance(st, FusedMLP) for st in
+                                          [self._e[k]["stack"] for k in ("q1", "q2") if k in self._e] + list(self._t.values()))
         if self._ws_batch != B or self._x.device != dev:
             f = dict(dtype=torch.float32, device=dev)
             P = ops.sac_partials(B)
-            self._x, self._xn, self._xa = (torch.empty(B, S + A, **f) for _ in range(3))
+            cat_shape = (0, S + A) if self._panels else (B, S + A)  # assembled inputs: per-layer GEMM engine only
+            self._x, self._xn, self._xa = (torch.empty(*cat_shape, **f) for _ in range(3))
             self._ls, self._lsn, self._dls = (torch.empty(B, 2 * A, **f) for _ in range(3))
             self._lp, self._lpn = torch.empty(B, **f), torch.empty(B, **f)
             names = ["q1v", "q2v", "q1t", "q2t", "q1a", "q2a", "dq1", "dq2", "dq1a", "dq2a", "y", "glp"]
             for n in names:
                 setattr(self, "_" + n, torch.empty(B, 1, **f))
-            self._dx1, self._dx2 = torch.empty(B, S + A, **f), torch.empty(B, S + A, **f)
+            self._dx1, self._dx2 = torch.empty(*cat_shape, **f), torch.empty(*cat_shape, **f)
             self._ga = torch.empty(B, A, **f)
+            # two-panel critic input (fused kernels): the actor's actions and the action part of dQ/dx on their own
+            self._an, self._api = torch.empty(B, A, **f), torch.empty(B, A, **f)
+            self._dxa1, self._dxa2 = torch.empty(B, A, **f), torch.empty(B, A, **f)
             self._parts = {n: torch.empty(P, **f) for n in ("l1", "l2", "la", "ent")}
             self._losses = {n: torch.empty(1, **f) for n in ("q1", "q2", "actor")}
             self._alpha_grad = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -267,22 +277,32 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         # a' = actor(s'), log_prob'  (actor frozen in this segment)
         xn_s, _ = act.stage_input(next_state, need_transposed=False)
         act.forward(xn_s, self._lsn, save=False)
-        self._xn[:, :S].copy_(next_state)
-        a_next = self._xn[:, S:]
-        ops.gaussian_head_forward(self._lsn, noise_next, a_next, self._lpn, None)
-        xn_c, _ = t["q1"].stage_input(self._xn, need_transposed=False)
-        t["q1"].forward(xn_c, self._q1t, save=False)
-        if "q2" in t:
-            t["q2"].forward(xn_c, self._q2t, save=False)
-        # q_i(s, a)
-        self._x[:, :S].copy_(state)
-        self._x[:, S:].copy_(action)
         q1s = e["q1"]["stack"]
-        x_c, self._x_t = q1s.stage_input(self._x, need_transposed=True)
-        q1s.forward(x_c, self._q1v, save=True)
         has_q2 = "q2" in e
-        if has_q2:
-            e["q2"]["stack"].forward(x_c, self._q2v, save=True)
+        if self._panels:
+            ops.gaussian_head_forward(self._lsn, noise_next, self._an, self._lpn, None)
+            t["q1"].forward(next_state, self._q1t, save=False, x2=self._an)
+            if "q2" in t:
+                t["q2"].forward(next_state, self._q2t, save=False, x2=self._an)
+            self._x_t = None
+            q1s.forward(state, self._q1v, save=True, x2=action)  # q_i(s, a)
+            if has_q2:
+                e["q2"]["stack"].forward(state, self._q2v, save=True, x2=action)
+        else:
+            self._xn[:, :S].copy_(next_state)
+            a_next = self._xn[:, S:]
+            ops.gaussian_head_forward(self._lsn, noise_next, a_next, self._lpn, None)
+            xn_c, _ = t["q1"].stage_input(self._xn, need_transposed=False)
+            t["q1"].forward(xn_c, self._q1t, save=False)
+            if "q2" in t:
+                t["q2"].forward(xn_c, self._q2t, save=False)
+            # q_i(s, a)
+            self._x[:, :S].copy_(state)
+            self._x[:, S:].copy_(action)
+            x_c, self._x_t = q1s.stage_input(self._x, need_transposed=True)
+            q1s.forward(x_c, self._q1v, save=True)
+            if has_q2:
+                e["q2"]["stack"].forward(x_c, self._q2v, save=True)
         ops.sac_critic_head(self._q1v, self._q2v if has_q2 else None, self._q1t, self._q2t if has_q2 else None,
                             self._lpn, self._f32c(b.reward).reshape(-1), self._f32c(b.not_terminal).reshape(-1),
                             self.gamma, alpha, self._y, self._dq1, self._dq2 if has_q2 else None, self._parts["l1"],
@@ -311,15 +331,21 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         act = e["actor"]["stack"]
         xs_c, self._xs_t = act.stage_input(state, need_transposed=True)
         act.forward(xs_c, self._ls, save=True)
-        self._xa[:, :S].copy_(state)
         self._noise_cur = noise_cur
-        ops.gaussian_head_forward(self._ls, noise_cur, self._xa[:, S:], self._lp, None)
         q1s = e["q1"]["stack"]
-        xa_c, _ = q1s.stage_input(self._xa, need_transposed=False)
-        q1s.forward(xa_c, self._q1a, save=True)
         has_q2 = "q2" in e
-        if has_q2:
-            e["q2"]["stack"].forward(xa_c, self._q2a, save=True)
+        if self._panels:
+            ops.gaussian_head_forward(self._ls, noise_cur, self._api, self._lp, None)
+            q1s.forward(state, self._q1a, save=True, x2=self._api)
+            if has_q2:
+                e["q2"]["stack"].forward(state, self._q2a, save=True, x2=self._api)
+        else:
+            self._xa[:, :S].copy_(state)
+            ops.gaussian_head_forward(self._ls, noise_cur, self._xa[:, S:], self._lp, None)
+            xa_c, _ = q1s.stage_input(self._xa, need_transposed=False)
+            q1s.forward(xa_c, self._q1a, save=True)
+            if has_q2:
+                e["q2"]["stack"].forward(xa_c, self._q2a, save=True)
         ops.sac_actor_head(self._lp, self._q1a, self._q2a if has_q2 else None, self._alpha(dev),
                            self.target_entropy, self._glp, self._dq1a, self._dq2a if has_q2 else None,
                            self._parts["la"], self._parts["ent"])
@@ -328,10 +354,16 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
     def _actor_backward(self, grad_out=None):
         e, S = self._e, self._S
         has_q2 = "q2" in e
-        e["q1"]["stack"].backward(self._dq1a, None, None, None, dx32=self._dx1, skip_wgrad=True)
-        if has_q2:
-            e["q2"]["stack"].backward(self._dq2a, None, None, None, dx32=self._dx2, skip_wgrad=True)
-        ops.add_cols(self._dx1[:, S:], self._dx2[:, S:] if has_q2 else None, self._ga)
+        if self._panels:  # only the action columns of dQ/d(input) are produced
+            e["q1"]["stack"].backward(self._dq1a, None, None, None, dx32=self._dxa1, skip_wgrad=True, dx_col0=S)
+            if has_q2:
+                e["q2"]["stack"].backward(self._dq2a, None, None, None, dx32=self._dxa2, skip_wgrad=True, dx_col0=S)
+            ops.add_cols(self._dxa1, self._dxa2 if has_q2 else None, self._ga)
+        else:
+            e["q1"]["stack"].backward(self._dq1a, None, None, None, dx32=self._dx1, skip_wgrad=True)
+            if has_q2:
+                e["q2"]["stack"].backward(self._dq2a, None, None, None, dx32=self._dx2, skip_wgrad=True)
+            ops.add_cols(self._dx1[:, S:], self._dx2[:, S:] if has_q2 else None, self._ga)
         ops.gaussian_head_backward(self._ls, self._noise_cur, self._ga, self._glp.reshape(-1), self._dls)
         dls = self._dls if grad_out is None else self._dls * grad_out
         a = e["actor"]

@@ -180,7 +180,7 @@ def test_c2_loop_matches_reference(backend, mode):
             # moves every weight by +-lr whatever the gradient's size, so an element whose tiny gradient
             # changes sign under bf16 rounding differs by 2*lr; the target moves by tau times that
             assert dq <= 6e-2 and dl <= 3e-2 and dw <= 2.0 * (s + 1) * g.cfg["lr"] * 1.05 and dt <= 1e-5
-    if backend.name == "hip" and mode in ACCURATE:
+    if backend.name == "hip" and mode == "f32":  # (bf16x3's second step starts from the direction-flipped weights)
         adam = tr.native_optimizers()[0]
         for i, p in enumerate(tr.q_network.parameters()):
             ref_m, ref_v = g.t(f"final_exp_avg_{i}"), g.t(f"final_exp_avg_sq_{i}")

@@ -188,3 +188,44 @@ def test_x3_on_an_unserved_shape_runs_exact_fp32(backend):
     ws, bs = _net([16, 128, 64, 4], ["relu", "relu", "linear"], 0, backend.device)
     st = make_stack(ws, bs, [1, 1, 0], L.PREC_BF16X3)
     assert isinstance(st, FCStack) and st.precision == L.PREC_F32
+
+
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_BF16X3])
+def test_two_panel_input_and_partial_input_gradient(backend, prec):
+    """cat(state, action) read in place as two K-panels == the assembled matrix, bit for bit; dx restricted to
+    the action columns == that slice of the full input gradient (reagent/models/critic.py:79-92 without the cat)."""
+    dev = backend.device
+    S, A, batch = 64, 20, 150
+    dims, acts = [S + A, 256, 256, 1], ["relu", "relu", "linear"]
+    ws, bs = _net(dims, acts, 4, dev)
+    codes = [L.ACT[a] for a in acts]
+    st = make_stack(ws, bs, codes, prec)
+    assert isinstance(st, FusedMLP)
+    st.set_need_input_grad(True)
+    st.stage_weights(need_transposed=True)
+    g = torch.Generator().manual_seed(6)
+    state, action = torch.randn(batch, S, generator=g).to(dev), torch.randn(batch, A, generator=g).to(dev)
+    dout = (torch.randn(batch, 1, generator=g) / batch).to(dev)
+    cat = torch.cat((state, action), dim=1).contiguous()
+
+    def run(two_panel, col0):
+        out = torch.zeros(batch, 1, device=dev)
+        if two_panel:
+            st.forward(state, out, save=True, x2=action)
+        else:
+            st.forward(cat, out, save=True)
+        dw = [torch.zeros_like(w) for w in ws]
+        db = [torch.zeros_like(b) for b in bs]
+        dx = torch.zeros(batch, S + A - col0, device=dev)
+        st.backward(dout, None, dw, db, dx32=dx, dx_col0=col0)
+        return out, dw, db, dx
+
+    o1, dw1, db1, dx1 = run(False, 0)
+    o2, dw2, db2, dx2 = run(True, S)
+    assert torch.equal(o1, o2)
+    for a, b in zip(dw1 + db1, dw2 + db2):
+        assert torch.equal(a, b)
+    assert torch.equal(dx1[:, S:], dx2)
+    out3 = torch.zeros(batch, 1, device=dev)
+    st.forward(cat, out3, save=False)  # a plain call after a two-panel one: the panel fields do not stick
+    assert torch.equal(out3, o1)
