@@ -4,6 +4,13 @@ Only what the DQN / QR-DQN / SAC hot path touches: FeatureData (:312-347), Extra
 ActorOutput (:245-249), BaseInput (:688-769), DiscreteDqnInput (:772-816), PolicyNetworkInput
 (:899-915) and the tensor-method forwarding of TensorDataClass (:49-108).  The trainers in this
 package only read attributes, so instances of the reference's own classes work as well.
+
+When the reference package itself is importable (a ReAgent installation this package is dropped into), its OWN
+classes are re-exported from here instead of the restatements below: the reference looks trainers' input types up
+by class OBJECT — `make_trainer_preprocessor` reads the annotation of `train_step_gen` and indexes a map keyed by
+`rlt.DiscreteDqnInput` / `rlt.PolicyNetworkInput` (reagent/gym/preprocessors/trainer_preprocessor.py:39-48) — so
+`DQNTrainer.train_step_gen(training_batch: rlt.DiscreteDqnInput, ...)` must name the reference's class there.
+`REAGENT_AMD_OWN_TYPES=1` keeps the restatements.
 """
 import dataclasses
 from dataclasses import dataclass
@@ -181,3 +188,30 @@ class PolicyNetworkInput(BaseInput):
             extras=batch.get("extras", None),
             **base.as_dict_shallow(),
         )
+
+
+# ---- the reference's own classes, when it is importable (see the module docstring) ---------------------------
+def _reference_types():
+    import importlib.util
+    import os
+
+    if os.environ.get("REAGENT_AMD_OWN_TYPES") == "1":
+        return None
+    try:
+        if importlib.util.find_spec("reagent") is None or importlib.util.find_spec("reagent.core.types") is None:
+            return None
+        import reagent.core.types as ref
+
+        return ref
+    except Exception:  # a partial installation (missing dependency of the reference): keep the restatements
+        return None
+
+
+USING_REFERENCE_TYPES = False
+_ref = _reference_types()
+if _ref is not None:
+    for _name in ("TensorDataClass", "ActorOutput", "FeatureData", "ExtraData", "BaseInput", "DiscreteDqnInput",
+                  "PolicyNetworkInput"):
+        globals()[_name] = getattr(_ref, _name)
+    USING_REFERENCE_TYPES = True
+del _ref

@@ -357,3 +357,37 @@ def test_logged_fields_of_the_dqn_step(backend):
     # get_max_q_values: arg-max over q - 1e9 * (1 - possible_actions_mask) (dqn_trainer_base.py:33-77)
     want_idx = (q_ref - 1e9 * (1 - raw["possible_actions_mask"])).argmax(dim=1, keepdim=True)
     assert torch.equal(kw["model_action_idxs"].cpu(), want_idx)
+
+
+def test_per_step_logging_fields(backend):
+    """SURVEY §8 a19 — what DQNTrainer hands its reporter after a step (reagent/training/dqn_trainer.py:306-347):
+    td_loss, the logged action indices, propensities, the (boosted) rewards, the model's Q-values of that step
+    and its greedy actions under the possible-actions mask.  Pinned on the golden batch of `dqn_huber_masks`."""
+    g = Golden("dqn_huber_masks")
+    tr = build(g, backend.device, L.PREC_F32)
+    seen = []
+
+    class Reporter:
+        def log(self, **kw):
+            seen.append(kw)
+
+    tr.set_reporter(Reporter())
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    b = g.batch(0)
+    batch = synthetic.to_dqn_input(b, backend.device)
+    lightning_like_step(tr, opts, batch)
+    assert len(seen) == 1
+    rec = seen[0]
+    assert set(rec) == {"td_loss", "logged_actions", "logged_propensities", "logged_rewards", "logged_values",
+                        "model_values", "model_values_on_logged_actions", "model_action_idxs"}
+    ref_loss = g.t("step0_loss")
+    assert abs(rec["td_loss"].item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item()) + 1e-6
+    assert torch.equal(rec["logged_actions"].cpu(), b["action"].argmax(dim=1, keepdim=True))
+    assert torch.equal(rec["logged_propensities"].cpu(), batch.extras.action_probability.cpu())
+    assert torch.equal(rec["logged_rewards"].cpu(), tr.boost_rewards(batch.reward, batch.action).cpu())
+    assert rec["logged_values"] is None and rec["model_values_on_logged_actions"] is None
+    q = g.t("step0_q")
+    assert (rec["model_values"].cpu() - q).abs().max() <= 1e-4
+    mask = b["possible_actions_mask"] if tr.maxq_learning else b["action"]
+    greedy = (q + (1.0 - mask.float()) * -1e10).argmax(dim=1, keepdim=True)  # dqn_trainer_base.py:147-163
+    assert torch.equal(rec["model_action_idxs"].cpu().reshape(-1, 1), greedy)
