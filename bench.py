@@ -119,6 +119,12 @@ def fc_flops(args, batch):
     """Algorithmic FLOP of one step.  DQN / QR-DQN: 3 forwards + wgrad(all layers) +
     dgrad(all but the first).  SAC: 2 actor fwd + 1 actor bwd + 6 critic fwd + 2 critic full bwd + 2 critic
     dgrad-only passes (down to the action columns of layer 1)."""
+    if args.algo == "qrdqn" and getattr(args, "grouped_head", False):
+        # grouped wide layer (reagent_amd/qr_engine.py): the per-action mean layer replaces the 3200-wide forward of
+        # the a* selection, and only ONE action's [N, H] slice of the wide layer is evaluated / differentiated per row
+        H, A, N = args.hidden, args.actions, args.atoms
+        trunk = [args.state_dim] + [H] * args.layers
+        return 2 * batch * (3 * mac(trunk) + 2 * H * A + 2 * H * N + mac(trunk) + mac(trunk[1:]) + 2 * H * N)
     if args.algo != "sac":
         d = layer_dims(args)
         return 2 * batch * (3 * mac(d) + mac(d) + mac(d[1:]))
@@ -367,7 +373,8 @@ def kernel_profile(args, step, steps):
             step()
     rows = prof.summary()
     fc_names = ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad", "rg_fc_wgrad_frag", "rg_mlp_forward_fused",
-                "rg_mlp_backward_fused", "rg_mlp_wgrad_fused")
+                "rg_mlp_backward_fused", "rg_mlp_wgrad_fused", "rg_group_head_forward", "rg_group_head_dgrad",
+                "rg_group_head_wgrad")
     fc = [r for r in rows if r["name"] in fc_names]
     for r in fc:
         m = r["meta"]
@@ -379,6 +386,9 @@ def kernel_profile(args, step, steps):
             d = m["dims"]
             r["flop_per_launch"] = 2.0 * m["B"] * (mac(d[1:]) + (d[0] * d[1] if m.get("dx") else 0))
             r["label"] = f"rg_mlp_backward_fused B={m['B']} dims={list(d)}"
+        elif r["name"].startswith("rg_group_head"):
+            r["flop_per_launch"] = 2.0 * B * m["Ng"] * m["K"]  # one [Ng, K] slice per batch row
+            r["label"] = f"{r['name']} rows={B} Ng={m['Ng']} K={m['K']}"
         else:
             r["flop_per_launch"] = 2.0 * m["M"] * m["N"] * m["K"]
             r["label"] = f"{r['name']} M={m['M']} N={m['N']} K={m['K']}"
@@ -396,7 +406,11 @@ def kernel_profile(args, step, steps):
             out["roofline"]["executed_frac"] = mfma_per_product * ach / peak
         fc_ms = sum(r["ms"] for r in fc) / steps
         alg = fc_flops(args, B)
-        out["fc_roofline"] = {"algorithmic_gflop_per_step": alg / 1e9, "fc_ms_per_step": fc_ms,
+        out["fc_roofline"] = {"algorithmic_gflop_per_step": alg / 1e9,
+                              **({"dense_reference_gflop_per_step": 2 * B * (4 * mac(layer_dims(args)) + mac(layer_dims(args)[1:])) / 1e9,
+                                  "note": "grouped wide layer: the step evaluates one action's [N, H] slice per row and a per-action "
+                                          "mean layer instead of the dense [B, A*N] logits the reference materialises"}
+                                 if getattr(args, "grouped_head", False) else {}), "fc_ms_per_step": fc_ms,
                               "achieved": alg / (fc_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                               "frac": alg / (fc_ms * 1e-3) / peak}
         if mfma_per_product != 1:
@@ -463,6 +477,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # "nccl" IS RCCL on ROCm
         assert dist.get_world_size() == args.gpus
     loop, trainer, init, cols, norm = build(args, device, rank)
+    if args.algo == "qrdqn":
+        from reagent_amd.qr_engine import GroupedQR
+
+        args.grouped_head = bool(trainer.use_grouped_head and GroupedQR.eligible(trainer))
     if world > 1:
         trainer.enable_data_parallel()
     parity = None

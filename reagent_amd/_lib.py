@@ -78,6 +78,7 @@ class MlpDesc(ctypes.Structure):
         ("ldx2", ctypes.c_int64),
         ("x_split", ctypes.c_int32),
         ("dx_col0", ctypes.c_int32),
+        ("rowmap", c_void_p),
     ]
 
 
@@ -201,6 +202,19 @@ SIGNATURES = {
     "rg_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d,
                               c_d, c_d, c_d, c_void_p]),
     "rg_soft_update": (c_int, [c_void_p, c_void_p, c_i64, c_d, c_void_p]),
+    "rg_group_wfrag_elems": (c_sz, [c_int, c_int, c_int]),
+    "rg_group_weights_stage": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rg_wide_head_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rg_qr_select_action": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rg_group_head_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_i64, c_void_p]),
+    "rg_qr_compact_head": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_d, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
+    "rg_group_head_dgrad": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rg_group_head_wgrad_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "rg_group_head_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_sz,
+                                     c_void_p]),
     "rg_adam_step_sched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d, c_void_p,
                                     c_void_p]),
     "rg_mlp_update_fused_sched": (c_int, [ctypes.POINTER(MlpUpdateDesc)] + [ctypes.c_double] * 6 + [c_void_p, c_void_p]),

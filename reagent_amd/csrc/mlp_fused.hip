@@ -52,7 +52,12 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
   constexpr int pitch = PITCH;
   const int k0p = round_up(a.dims[0], 32);
   RG_STAMP(0);
-  if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
+  if (a.rowmap) {  // grouped space: rows gathered through the map
+    if (a.x_is_f32)
+      load_tile_rows_mapped<float, THREADS>(act, pitch, (const float*)a.x, a.ldx, a.rowmap, row_base, a.dims[0], k0p, tid);
+    else
+      load_tile_rows_mapped<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, a.rowmap, row_base, a.dims[0], k0p, tid);
+  } else if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
     const int n2 = a.dims[0] - a.x_split;
     if (a.x_is_f32) {
       load_tile_to_lds<float, THREADS>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
@@ -223,10 +228,12 @@ struct WgradFragArgs {
   long a_lo, b_lo;    // element offsets of the lo planes
 };
 
+// one workgroup: dW tile (n-group ng, k-group kg) over the 32-row blocks [mb_begin, mb_end) of the operands
+// ga_frag / gb_frag, written to `part` (row-major [N][K] slab)
+__device__ __forceinline__ void wgrad_frag_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end,
+                                                const bf16_t* ga_frag, const bf16_t* gb_frag, float* part, char* smem);
+
 __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid, char* smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int lr = lane & 31, lg = lane >> 5;
-  const int wn = wave >> 2, wk = wave & 3;
   const int n_groups = (g.NTa + 7) / 8, k_groups = (g.NTb + 7) / 8;
   // workgroups that read the same 32-row blocks (the tiles of one split) go to ONE XCD (hardware
   // places block b on XCD b % 8), so the second reader of a fragment hits that XCD's L2 instead of
@@ -252,6 +259,14 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
   const int ng = tile / k_groups;
   const int mb_begin = split * g.mb_per_split;
   const int mb_end = (mb_begin + g.mb_per_split < g.MB) ? mb_begin + g.mb_per_split : g.MB;
+  wgrad_frag_core(g, ng, kg, mb_begin, mb_end, ga_frag, gb_frag, g.partial + ((long)split * g.terms + term) * g.slab, smem);
+}
+
+__device__ __forceinline__ void wgrad_frag_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end,
+                                                const bf16_t* ga_frag, const bf16_t* gb_frag, float* part, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int lr = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 2, wk = wave & 3;
   const int ta0 = ng * 8, tb0 = kg * 8;
   const int na = (g.NTa - ta0 < 8) ? g.NTa - ta0 : 8, nb = (g.NTb - tb0 < 8) ? g.NTb - tb0 : 8;
 
@@ -327,7 +342,6 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
     RG_WAIT_VMCNT(0);
   }
 
-  float* part = g.partial + ((long)split * g.terms + term) * g.slab;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -346,6 +360,46 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
 __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
   RG_DYN_LDS(smem);
   wgrad_frag_body(g, (int)blockIdx.x, smem);
+}
+
+// Weight gradient of a GROUPED layer (QR-DQN's A x N output layer seen as A independent [N, K] layers, one per
+// action; rows of the batch sorted by action and every action's rows padded to whole 128-row tiles,
+// qr_grouped.hip): group a owns the 32-row blocks [4 * tile_begin[a], 4 * tile_begin[a + 1]) of both operands; its
+// block range is cut into `splits` parts.  Workgroup = (group, k-group, split); partial slab index
+// group * splits + split.  The ranges live in HBM (they depend on the sampled batch): no host round trip.
+struct WgradGroupedArgs {
+  WgradFragArgs g;        // a_frag: dZ fragments (NTa tiles of 32 columns), b_frag: activation fragments; N = rows of a group's dW
+  const int* tile_begin;  // [n_groups + 1], in 128-row tiles
+  int n_groups, splits;
+};
+
+__global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_grouped_kernel(WgradGroupedArgs G) {
+  RG_DYN_LDS(smem);
+  const int k_groups = (G.g.NTb + 7) / 8;
+  const int bid = blockIdx.x;
+  const int kg = bid % k_groups, s = (bid / k_groups) % G.splits, a = bid / (k_groups * G.splits);
+  const int mb0 = G.tile_begin[a] * 4, mb1 = G.tile_begin[a + 1] * 4;
+  const int per = (mb1 - mb0 + G.splits - 1) / G.splits;
+  int b0 = mb0 + s * per, b1 = b0 + per;
+  if (b1 > mb1) b1 = mb1;
+  if (b0 > mb1) b0 = mb1;
+  wgrad_frag_core(G.g, 0, kg, b0, b1, G.g.a_frag, G.g.b_frag, G.g.partial + ((long)a * G.splits + s) * G.g.slab, smem);
+}
+
+// out[a * slab + e] = sum_s partial[(a * splits + s) * slab + e]
+__global__ void reduce_grouped_kernel(const float* __restrict__ partial, long slab, int splits, int n_groups,
+                                      float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slab * n_groups) return;
+  const long a = i / slab, e = i % slab;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < splits; k += 2) {
+    s0 += partial[(a * splits + k) * slab + e];
+    s1 += partial[(a * splits + k + 1) * slab + e];
+  }
+  if (k < splits) s0 += partial[(a * splits + k) * slab + e];
+  out[i] = s0 + s1;
 }
 
 // all layers of a stack in ONE launch (workgroups of the small layers fill the CUs the big ones
@@ -465,32 +519,6 @@ __global__ void reduce_splits2_kernel(const float* __restrict__ partials, long s
   float s = 0.f;
   for (int k = 0; k < splits; ++k) s += partials[(long)k * slab + i];
   out[i] = s;
-}
-
-// fp32 master weights -> B-fragment order for forward (W) and backward (W^T), zero padded
-__device__ __forceinline__ void stage_weight_elem(const float* __restrict__ w, int N, int K, bf16_t* __restrict__ wf,
-                                                  bf16_t* __restrict__ wb, long i, int x3 = 0) {
-  const int KCf = (K + 15) / 16, NTf = (N + 31) / 32;
-  const int KCb = (N + 15) / 16, NTb = (K + 31) / 32;
-  const long tf = (long)NTf * KCf * 512, tb = (long)NTb * KCb * 512;
-  const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-  const long blk = i >> 9;
-  if (wf && i < tf) {
-    const int kc = (int)(blk % KCf), nt = (int)(blk / KCf);
-    const int n = nt * 32 + (lane & 31), k = kc * 16 + (lane >> 5) * 8 + e;
-    const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
-    const bf16_t hi = f32_to_bf16(v);
-    wf[i] = hi;
-    if (x3) wf[tf + i] = f32_to_bf16(v - bf16_to_f32(hi));
-  }
-  if (wb && i < tb) {
-    const int kc = (int)(blk % KCb), nt = (int)(blk / KCb);
-    const int k = nt * 32 + (lane & 31), n = kc * 16 + (lane >> 5) * 8 + e;  // "weight" = W^T [K][N]
-    const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
-    const bf16_t hi = f32_to_bf16(v);
-    wb[i] = hi;
-    if (x3) wb[tb + i] = f32_to_bf16(v - bf16_to_f32(hi));
-  }
 }
 
 __global__ void stage_group_kernel(StageGroupArgs G) {
@@ -765,6 +793,7 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   if (save)
     for (int l = 0; l < d->n_layers; ++l)
       if (!d->act_frag[l]) return RG_EINVAL;
+  if (d->rowmap && (d->x2 || d->x3 || (batch % 128) != 0)) return RG_EUNSUPPORTED;
   if (d->x2 && (d->x_split <= 0 || d->x_split >= d->dims[0] || (d->x_split % 32) != 0)) return RG_EINVAL;
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
   if (d->x3) return x3_forward_launch(d, a, (hipStream_t)stream);
@@ -783,8 +812,9 @@ size_t rg_mlp_backward_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
 
 int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch, float* dx32,
                           int64_t lddx, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
-  const int tn = fused_supported(d);
-  if (!tn) return RG_EUNSUPPORTED;
+  // also a TRUNK: every layer hidden-wide, the "output" being the last hidden layer (dout32 = the gradient of its
+  // pre-activation, [batch, H]) — what the grouped output layer of qr_grouped.hip hands back
+  if (!fused_supported(d) && !fused_trunk(d)) return RG_EUNSUPPORTED;
   if (!dout32 || batch <= 0) return RG_EINVAL;
   MlpArgs a;
   int rc = fill_args(d, batch, a, 1);
@@ -881,6 +911,38 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   const long n = p.slab;
   RG_LAUNCH(reduce_splits2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
             (const float*)g.partial, p.slab, p.splits, dw, n);
+  return (int)hipGetLastError();
+}
+
+size_t rg_group_head_wgrad_workspace_bytes(int n_groups, int group_rows, int in_features, int splits) {
+  return (size_t)n_groups * splits * group_rows * in_features * sizeof(float);
+}
+
+/* dw [n_groups * group_rows, in_features] of a grouped layer (qr_grouped.hip): group g's rows are the 32-row blocks
+ * [4 * tile_begin[g], 4 * tile_begin[g + 1]) of dz_frag (batch x group_rows, padded to 32 columns) and h_frag */
+int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* tile_begin, int n_groups, int group_rows,
+                        int in_features, int splits, float* dw, void* workspace, size_t workspace_bytes,
+                        rg_stream_t stream) {
+  if (!dz_frag || !h_frag || !tile_begin || !dw || n_groups <= 0 || group_rows <= 0 || in_features <= 0 || splits <= 0)
+    return RG_EINVAL;
+  if (group_rows > 256) return RG_EUNSUPPORTED;  // one n-group of the 256 x 256 workgroup tile per action
+  if (!workspace || workspace_bytes < rg_group_head_wgrad_workspace_bytes(n_groups, group_rows, in_features, splits))
+    return RG_EWORKSPACE;
+  WgradGroupedArgs G;
+  G.g.a_frag = (const bf16_t*)dz_frag; G.g.b_frag = (const bf16_t*)h_frag;
+  G.g.NTa = (group_rows + 31) / 32; G.g.NTb = (in_features + 31) / 32; G.g.MB = 0; G.g.mb_per_split = 0; G.g.splits = splits;
+  G.g.partial = (float*)workspace; G.g.slab = (long)group_rows * in_features; G.g.N = group_rows; G.g.K = in_features;
+  G.g.terms = 1; G.g.a_lo = G.g.b_lo = 0;
+  G.tile_begin = tile_begin; G.n_groups = n_groups; G.splits = splits;
+  const int k_groups = (G.g.NTb + 7) / 8;
+  const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
+  RG_ALLOW_LDS(wgrad_grouped_kernel, lds);
+  RG_LAUNCH_DYN(wgrad_grouped_kernel, dim3(n_groups * splits * k_groups), dim3(WG_THREADS), lds, (hipStream_t)stream, G);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  const long n = G.g.slab * n_groups;
+  RG_LAUNCH(reduce_grouped_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
+            (const float*)workspace, G.g.slab, splits, n_groups, dw);
   return (int)hipGetLastError();
 }
 

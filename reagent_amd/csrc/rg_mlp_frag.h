@@ -44,6 +44,7 @@ struct MlpArgs {
   long ldx2;
   int x_split;
   int dx_col0;                    // backward: first input column whose gradient is produced (dx32[0])
+  const int* rowmap;              // forward: tile row r reads input row rowmap[r] (-1: zeros); null = identity
   int x_is_f32;
   float* out32;  // forward output [batch, dims[L]] fp32
   long ldo;
@@ -133,6 +134,38 @@ __device__ __forceinline__ void load_tile_to_lds(bf16_t* act, int pitch, const T
     const int grow = row_base + r;
     u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (grow < nrows && k0 < ncols) {
+      const T* p = src + (long)grow * ld + k0;
+      if (sizeof(T) == 2 && vec && k0 + 8 <= ncols) {
+        v = *(const u16x8*)p;
+      } else if (sizeof(T) == 4 && vec && k0 + 8 <= ncols) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = cvt_out<bf16_t>(a[e]);
+          v[4 + e] = cvt_out<bf16_t>(b[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k0 + e < ncols) v[e] = cvt_out<bf16_t>(cvt_in(p[e]));
+      }
+    }
+    *(u16x8*)&act[r * pitch + k0] = v;
+  }
+}
+
+// the same through a row map: tile row r <- src row rowmap[row_base + r] (-1: zeros)
+template <typename T, int THREADS>
+__device__ __forceinline__ void load_tile_rows_mapped(bf16_t* act, int pitch, const T* src, long ld, const int* rowmap,
+                                                      int row_base, int ncols, int ncols_pad, int tid) {
+  const int cpr = ncols_pad / 8;
+  const int total = FB_BM * cpr;
+  const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (int c = tid; c < total; c += THREADS) {
+    const int r = c / cpr, k0 = (c % cpr) * 8;
+    const int grow = rowmap[row_base + r];
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (grow >= 0 && k0 < ncols) {
       const T* p = src + (long)grow * ld + k0;
       if (sizeof(T) == 2 && vec && k0 + 8 <= ncols) {
         v = *(const u16x8*)p;
@@ -485,6 +518,17 @@ static inline int fused_supported(const rg_mlp_desc* d) {
   return H / 256;
 }
 
+// all layers (the last one included) of one hidden width in {256, 512}: the trunk of a stack whose output layer is
+// handled elsewhere (backward only)
+static inline int fused_trunk(const rg_mlp_desc* d) {
+  if (!d || d->n_layers < 2 || d->n_layers > FB_MAXL || d->x3) return 0;
+  const int H = d->dims[1];
+  if (H != 256 && H != 512) return 0;
+  for (int l = 1; l <= d->n_layers; ++l)
+    if (d->dims[l] != H) return 0;
+  return d->dims[0] >= 1 && d->dims[0] <= 512;
+}
+
 // LDS row pitch: widest layer + 8 elements (row stride = 4 banks mod 64: conflict-free 16-byte reads)
 static inline int fused_pitch(const rg_mlp_desc* d) {
   int m = 0;
@@ -495,6 +539,33 @@ static inline int fused_pitch(const rg_mlp_desc* d) {
   return m <= 256 ? 264 : 520;
 }
 
+
+
+// fp32 master weights -> B-fragment order for forward (W) and backward (W^T), zero padded
+__device__ __forceinline__ void stage_weight_elem(const float* __restrict__ w, int N, int K, bf16_t* __restrict__ wf,
+                                                  bf16_t* __restrict__ wb, long i, int x3 = 0) {
+  const int KCf = (K + 15) / 16, NTf = (N + 31) / 32;
+  const int KCb = (N + 15) / 16, NTb = (K + 31) / 32;
+  const long tf = (long)NTf * KCf * 512, tb = (long)NTb * KCb * 512;
+  const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  const long blk = i >> 9;
+  if (wf && i < tf) {
+    const int kc = (int)(blk % KCf), nt = (int)(blk / KCf);
+    const int n = nt * 32 + (lane & 31), k = kc * 16 + (lane >> 5) * 8 + e;
+    const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
+    const bf16_t hi = f32_to_bf16(v);
+    wf[i] = hi;
+    if (x3) wf[tf + i] = f32_to_bf16(v - bf16_to_f32(hi));
+  }
+  if (wb && i < tb) {
+    const int kc = (int)(blk % KCb), nt = (int)(blk / KCb);
+    const int k = nt * 32 + (lane & 31), n = kc * 16 + (lane >> 5) * 8 + e;  // "weight" = W^T [K][N]
+    const float v = (n < N && k < K) ? w[(long)n * K + k] : 0.f;
+    const bf16_t hi = f32_to_bf16(v);
+    wb[i] = hi;
+    if (x3) wb[tb + i] = f32_to_bf16(v - bf16_to_f32(hi));
+  }
+}
 
 
 static inline size_t frag_elems(int rows, int cols) {
@@ -526,6 +597,7 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
     a.act_lo[l] = d->x3 ? (long)frag_elems(batch, d->dims[l]) : 0;
   }
   a.pitch = fused_pitch(d);
+  a.rowmap = d->rowmap;
   a.x2 = d->x2; a.ldx2 = d->ldx2; a.x_split = d->x2 ? d->x_split : 0; a.dx_col0 = d->dx_col0;
   a.x = nullptr; a.ldx = 0; a.x_is_f32 = 0; a.out32 = nullptr; a.ldo = 0; a.dout32 = nullptr; a.lddo = 0;
   a.dx32 = nullptr; a.lddx = 0; a.save = 0;

@@ -377,11 +377,14 @@ class FusedMLP:
     def stage_input(self, x32: torch.Tensor, need_transposed: bool):
         return x32, None  # the kernel reads fp32 (or bf16) rows directly and casts in flight
 
-    def forward(self, xc: torch.Tensor, out32: torch.Tensor, save: bool = False, x2: Optional[torch.Tensor] = None):
+    def forward(self, xc: torch.Tensor, out32: torch.Tensor, save: bool = False, x2: Optional[torch.Tensor] = None,
+                rowmap: Optional[torch.Tensor] = None):
         """x2 (optional): second input panel — the network input is cat(xc, x2) (FullyConnectedCritic's
-        cat(state, action), critic.py:79-92) read in place by the kernel; xc.shape[1] must be a multiple of 32."""
+        cat(state, action), critic.py:79-92) read in place by the kernel; xc.shape[1] must be a multiple of 32.
+        rowmap (optional, int32, length a multiple of 128): the stack runs on len(rowmap) rows, row r reading input
+        row rowmap[r] of xc (-1: zeros) — "grouped space" of qr_engine.py; out32 has len(rowmap) rows."""
         L.require_cuda(xc)
-        B = xc.shape[0]
+        B = xc.shape[0] if rowmap is None else rowmap.shape[0]
         self._ensure_ws(B, xc.device, training=save)
         d = self._fill_desc()
         assert xc.stride(1) == 1 and out32.stride(1) == 1
@@ -393,6 +396,10 @@ class FusedMLP:
         else:
             assert xc.shape[1] == self.dims[0]
             d.x2, d.ldx2, d.x_split = None, 0, 0
+        if rowmap is not None:
+            assert rowmap.dtype == torch.int32 and rowmap.is_contiguous() and B % 128 == 0 and out32.shape[0] == B
+            L.require_cuda(rowmap)
+        d.rowmap = rowmap.data_ptr() if rowmap is not None else None
         ops._run("rg_mlp_forward_fused", dict(B=B, save=int(save), dims=tuple(self.dims)),
                  lambda: L.lib().rg_mlp_forward_fused(d, xc.data_ptr(), ops.dt_code(xc.dtype), xc.stride(0), B,
                                                       out32.data_ptr(), out32.stride(0), int(save),
@@ -426,6 +433,41 @@ class FusedMLP:
             wsb = ws["wgrad"].numel() * 4
             ops._run("rg_mlp_wgrad_fused", dict(B=B, dims=tuple(self.dims)),
                      lambda: lib.rg_mlp_wgrad_fused(d, B, ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
+
+
+def _trunk_desc(st: "FusedMLP") -> "L.MlpDesc":
+    d = st._fill_desc()
+    t = L.MlpDesc()
+    n = st.L - 1
+    t.n_layers = n
+    for i in range(n + 1):
+        t.dims[i] = st.dims[i]
+    for l in range(n):
+        t.acts[l] = st.acts[l]
+        for f in ("wfrag_fwd", "wfrag_bwd", "bias", "act_frag", "dz_frag", "act_sign"):
+            getattr(t, f)[l] = getattr(d, f)[l]
+    return t
+
+
+def fused_backward_trunk(st: "FusedMLP", dz_last32: torch.Tensor, dw: List[torch.Tensor], db: List[torch.Tensor]):
+    """Backward of every layer but the last of a fused stack, started from dz_last32 = d loss / d (pre-activation of
+    the last HIDDEN layer), fp32 [B, H] — for stacks whose output layer is handled by the grouped kernels
+    (qr_engine.py).  Needs the saving forward of the whole stack on the same rows; writes dw / db of layers
+    0 .. L-2."""
+    B = dz_last32.shape[0]
+    assert not st.x3 and st._ws.get("key") == (B, dz_last32.device, True), "needs a saving forward first"
+    t = _trunk_desc(st)
+    lib = L.lib()
+    ws = st._ws
+    n = st.L - 1
+    for l in range(n):
+        t.db[l] = db[l].data_ptr()
+        t.dw[l] = dw[l].data_ptr()
+    ops._run("rg_mlp_backward_fused", dict(B=B, dims=tuple(st.dims[: n + 1])),
+             lambda: lib.rg_mlp_backward_fused(t, dz_last32.data_ptr(), dz_last32.stride(0), B, None, 0,
+                                               ws["bwd"].data_ptr(), ws["bwd"].numel() * 4, L.stream_ptr()))
+    ops._run("rg_mlp_wgrad_fused", dict(B=B, dims=tuple(st.dims[: n + 1])),
+             lambda: lib.rg_mlp_wgrad_fused(t, B, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))
 
 
 def make_stack(weights, biases, acts: List[int], precision: int):

@@ -532,3 +532,74 @@ def add_cols(a, b, out):
     _run("rg_add_cols", dict(B=B, C=C),
          lambda: L.lib().rg_add_cols(L.ptr(a), _ld(a), L.ptr(b), _ld(b) if b is not None else 0, B, C, L.ptr(out),
                                      _ld(out), L.stream_ptr()))
+
+
+# ---- QR-DQN with a grouped output layer (qr_grouped.hip) ------------------------------------------------------
+def group_wfrag_elems(group_rows: int, in_features: int, transposed: bool) -> int:
+    return int(L.lib().rg_group_wfrag_elems(group_rows, in_features, int(transposed)))
+
+
+def group_weights_stage(w, n_groups, group_rows, wf, wb):
+    _chk_dev(w, wf, wb)
+    assert w.is_contiguous() and w.dtype == F32 and w.shape[0] == n_groups * group_rows
+    _run("rg_group_weights_stage", dict(G=n_groups, Ng=group_rows, K=w.shape[1]),
+         lambda: L.lib().rg_group_weights_stage(w.data_ptr(), n_groups, group_rows, w.shape[1], L.ptr(wf), L.ptr(wb),
+                                                L.stream_ptr()))
+
+
+def wide_head_mean(w, b, n_groups, group_rows, wbar, bbar):
+    _chk_dev(w, b, wbar, bbar)
+    assert w.is_contiguous() and wbar.is_contiguous() and wbar.shape == (n_groups, w.shape[1])
+    _run("rg_wide_head_mean", dict(G=n_groups, Ng=group_rows, K=w.shape[1]),
+         lambda: L.lib().rg_wide_head_mean(w.data_ptr(), L.ptr(b), n_groups, group_rows, w.shape[1], wbar.data_ptr(),
+                                           bbar.data_ptr(), L.stream_ptr()))
+
+
+def qr_select_action(q, mask, maxq: bool, key):
+    _chk_dev(q, mask, key)
+    B, A = mask.shape
+    assert mask.is_contiguous() and mask.dtype == F32 and key.dtype == torch.int32 and key.numel() == B
+    _run("rg_qr_select_action", dict(B=B, A=A),
+         lambda: L.lib().rg_qr_select_action(L.ptr(q), _ld(q) if q is not None else 0, mask.data_ptr(), B, A, int(maxq),
+                                             key.data_ptr(), L.stream_ptr()))
+
+
+def group_head_forward(h_frag, rowmap, tile_key, wf, bias, group_rows, in_features, scatter: bool, z):
+    _chk_dev(h_frag, rowmap, tile_key, wf, bias, z)
+    _run("rg_group_head_forward", dict(T=tile_key.numel(), Ng=group_rows, K=in_features),
+         lambda: L.lib().rg_group_head_forward(h_frag.data_ptr(), rowmap.data_ptr(), tile_key.data_ptr(), tile_key.numel(),
+                                               wf.data_ptr(), L.ptr(bias), group_rows, in_features, int(scatter),
+                                               z.data_ptr(), _ld(z), L.stream_ptr()))
+
+
+def qr_compact_head(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma, gamma_exponent, quantiles,
+                    batch, num_atoms, dz, loss_partials, tile_losses=None):
+    _chk_dev(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma_exponent, quantiles, dz, loss_partials,
+             tile_losses)
+    rows = rowmap.numel()
+    assert z.shape[0] == rows and dz.shape[0] == rows and loss_partials.numel() == rows
+    _run("rg_qr_compact_head", dict(rows=rows, N=num_atoms),
+         lambda: L.lib().rg_qr_compact_head(z.data_ptr(), _ld(z), zt.data_ptr(), _ld(zt), rowmap.data_ptr(),
+                                            tile_key.data_ptr(), rows, reward.data_ptr(), L.ptr(reward_boosts),
+                                            not_terminal.data_ptr(), float(gamma), L.ptr(gamma_exponent),
+                                            quantiles.data_ptr(), batch, num_atoms, dz.data_ptr(), _ld(dz),
+                                            loss_partials.data_ptr(), L.ptr(tile_losses), L.stream_ptr()))
+
+
+def group_head_dgrad(dz, tile_key, tile_begin, n_groups, wb, h_frag, group_rows, in_features, leaky: bool, dz3, dzw_frag,
+                     db_partials, db):
+    _chk_dev(dz, tile_key, tile_begin, wb, h_frag, dz3, dzw_frag, db_partials, db)
+    _run("rg_group_head_dgrad", dict(T=tile_key.numel(), Ng=group_rows, K=in_features),
+         lambda: L.lib().rg_group_head_dgrad(dz.data_ptr(), _ld(dz), tile_key.data_ptr(), tile_begin.data_ptr(),
+                                             tile_key.numel(), n_groups, wb.data_ptr(), h_frag.data_ptr(), group_rows,
+                                             in_features, int(leaky), dz3.data_ptr(), _ld(dz3), dzw_frag.data_ptr(),
+                                             L.ptr(db_partials), L.ptr(db), L.stream_ptr()))
+
+
+def group_head_wgrad(dzw_frag, h_frag, tile_begin, n_groups, group_rows, in_features, splits, dw, workspace):
+    _chk_dev(dzw_frag, h_frag, tile_begin, dw, workspace)
+    assert dw.is_contiguous() and dw.shape == (n_groups * group_rows, in_features)
+    _run("rg_group_head_wgrad", dict(G=n_groups, Ng=group_rows, K=in_features),
+         lambda: L.lib().rg_group_head_wgrad(dzw_frag.data_ptr(), h_frag.data_ptr(), tile_begin.data_ptr(), n_groups,
+                                             group_rows, in_features, splits, dw.data_ptr(), workspace.data_ptr(),
+                                             workspace.numel() * 4, L.stream_ptr()))

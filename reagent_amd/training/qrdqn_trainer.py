@@ -62,6 +62,50 @@ class QRDQNTrainer(QStepCore):
     def _out_cols(self) -> int:
         return self.num_actions * self.num_atoms
 
+    # ---- grouped wide layer (qr_engine.py): bf16 fused stacks, no CPE ---------------------------------------
+    use_grouped_head = True  # set False to force the dense [B, A * N] path
+
+    def _grouped(self):
+        from ..qr_engine import GroupedQR
+
+        if not self.use_grouped_head or not GroupedQR.eligible(self):
+            return None
+        g = getattr(self, "_gq", None)
+        if g is None or g.online.lin[-1].weight is not self.q_network.fc.linears()[-1].weight:
+            g = self._gq = GroupedQR(self)
+        return g
+
+    def _engine(self, batch: int, device):
+        g = self._grouped()
+        if g is None:
+            self._gq_active = None
+            return super()._engine(batch, device)
+        from ..engine import ensure_slab
+
+        self._hip_params = list(self.q_network.parameters())
+        self._slab = ensure_slab(self._hip_params)
+        self._qs, self._ts = g, g.target
+        if getattr(self, "_loss", None) is None or self._loss.device != device:
+            self._loss = torch.empty(1, dtype=torch.float32, device=device)
+        self._q = self._loss  # (device marker of the dense path's buffers)
+        self._ws_batch = -1
+        lin = self.q_network.fc.linears()
+        index = {id(p): i for i, p in enumerate(self._hip_params)}
+        self._dw = [self._slab.view(self._slab.grad, index[id(l.weight)]) for l in lin]
+        self._db = [self._slab.view(self._slab.grad, index[id(l.bias)]) for l in lin]
+        self._xs_t = None
+        self._gq_active = g
+
+    def _hip_forward(self, b):
+        state = b.state.float_features
+        self._engine(state.shape[0], state.device)
+        g = self._gq_active
+        if g is None:
+            return super()._hip_forward(b)
+        loss = g.forward(b)
+        self.all_q_values = g.all_q_values()  # [B, A] in batch order (logging / reporters)
+        return loss
+
     def _needs_online_next(self) -> bool:
         return bool(self.maxq_learning and self.double_q_learning)
 
