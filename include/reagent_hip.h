@@ -86,7 +86,7 @@ int rg_act_backward(const float* dy, int64_t ld_dy, const float* y, int64_t ld_y
 /* ---- fused FullyConnected stack (bf16 throughput path) ------------------------------------ */
 
 /* Whole-network kernels for stacks whose hidden layers share one width in {256, 512}, input
- * width <= 512 and output width <= 128 (rg_mlp_fused_supported): a 128-row activation tile stays
+ * width <= 512 and output width <= 256 (rg_mlp_fused_supported): a 128-row activation tile stays
  * in LDS across all layers; weights stream from HBM/L2 in MFMA B-fragment order
  * (rg_stage_weights_frag); what backward needs is saved in MFMA C-fragment order
  * (rg_frag_elems(batch, width) bf16 elements per saved matrix), which rg_fc_wgrad_frag
@@ -130,6 +130,18 @@ typedef struct {
    * `batch` is then the length of rowmap.  Lets a stack run in "grouped space" (rows sorted by a key and padded to
    * whole 128-row tiles, qr_grouped.hip) without materialising the permuted input. */
   const int32_t* rowmap;
+  /* Grouped OUTPUT layer (qr_grouped.hip): with tile_key != NULL the last layer is one of n_groups layers
+   * [dims[L], dims[L-1]] chosen per 128-row tile, group g = tile_key[tile] (-1: an empty tile, whose output is
+   * skipped): wfrag_fwd[L-1] / wfrag_bwd[L-1] / bias[L-1] point at group 0 and advance by group_stride_fwd /
+   * group_stride_bwd elements / dims[L] per group (rg_group_weights_stage lays them out so).  out_scatter != 0
+   * writes output row r of the forward to out32[rowmap[r]] (rows with rowmap[r] < 0 are dropped).  The backward
+   * reduces the last layer's bias gradient per group (db[L-1]: [n_groups * dims[L]], tile_begin required) and
+   * leaves the last layer's weight gradient to rg_group_head_wgrad (dz_frag[L-1] is its operand). */
+  const int32_t* tile_key;
+  const int32_t* tile_begin;
+  int32_t n_groups;
+  int32_t out_scatter;
+  int64_t group_stride_fwd, group_stride_bwd;
 } rg_mlp_desc; /* host struct */
 
 int rg_mlp_fused_supported(const rg_mlp_desc* d);
@@ -429,23 +441,25 @@ int rg_c51_head(const float* q, const float* qn_online, const float* qn_target, 
  *   rowmap     [128 * n_tiles] int32 : batch row of each grouped row, -1 for padding
  *   tile_key   [n_tiles] int32       : group of each tile, -1 for an empty tail tile
  *   tile_begin [n_groups + 1] int32  : first tile of each group
- * all built on the device.  h_frag is the saved input of the stack's last layer (rg_mlp_desc.act_frag[L-1]) of a
- * forward that ran in grouped space (rg_mlp_desc.rowmap).
+ * all built on the device.  Forward and input gradient of the grouped layer run inside the fused stack kernels
+ * (rg_mlp_desc.rowmap / tile_key); h_frag below is the saved input of the stack's last layer (act_frag[L-1]) and
+ * dz_frag the dz_frag[L-1] that backward wrote.
  * rg_group_weights_stage : w [n_groups * group_rows, in] fp32 -> per-group B fragments of W_g (forward) and of
  *                          W_g^T (input gradient); rg_group_wfrag_elems(...) bf16 elements per group.
  * rg_wide_head_mean      : wbar [n_groups, in], bbar [n_groups] = mean over each group's rows of w and b — the
  *                          per-action mean over quantiles is the linear layer (wbar, bbar) (fp32, row order).
  * rg_qr_select_action    : key[b] = arg max_a (q[b,a] - 1e9 (1 - mask[b,a])) (maxq != 0, :210-214) or the position of
  *                          the 1 in mask[b,:] (SARSA, mask = next_action), num_actions for an all-zero row.
- * rg_group_head_forward  : z[dst(r), 0:group_rows] = h[r,:] . W_g^T + b_g, dst(r) = rowmap[r] (scatter != 0) or r.
  * rg_qr_compact_head     : quantile-Huber loss (:143-160, :217-218) of z [grouped rows] against
  *                          T = reward (+ boost of the group's action) + gamma^e * not_terminal * zt[rowmap[r], :];
  *                          dz [padded_rows, lddz] (padding rows and columns zero), loss_partials [padded_rows];
  *                          tile_losses (nullable) [padded_rows / 128] = their sums per 128-row tile.
- * rg_group_head_dgrad    : dz3[r,:] = (dz[r,:] . W_g) * act'(h[r,:]) (ReLU / leaky ReLU), fp32 [padded_rows, in];
- *                          dzw_frag = dz in C-fragment order (rg_frag_elems(padded_rows, group_rows) elements);
- *                          db (nullable) [n_groups * group_rows] through db_partials [n_tiles * round_up(group_rows, 32)].
  * rg_group_head_wgrad    : dw [n_groups * group_rows, in] = per group dz^T h over the group's rows. */
+/* rg_group_rows: the grouped space of `key` [batch] int32 in [0, n_groups] (n_groups = "no group": dropped) — a
+ * stable counting sort (rows keep batch order inside a group), n_tiles >= ceil(batch / 128) + n_groups. */
+size_t rg_group_rows_workspace_bytes(int batch, int n_groups);
+int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int32_t* rowmap, int32_t* tile_key,
+                  int32_t* tile_begin, void* workspace, size_t workspace_bytes, rg_stream_t stream);
 size_t rg_group_wfrag_elems(int group_rows, int in_features, int transposed);
 int rg_group_weights_stage(const float* w, int n_groups, int group_rows, int in_features, void* wfrag_fwd,
                            void* wfrag_bwd, rg_stream_t stream);
@@ -453,18 +467,11 @@ int rg_wide_head_mean(const float* w, const float* b, int n_groups, int group_ro
                       float* bbar, rg_stream_t stream);
 int rg_qr_select_action(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
                         int32_t* key, rg_stream_t stream);
-int rg_group_head_forward(const void* h_frag, const int32_t* rowmap, const int32_t* tile_key, int n_tiles,
-                          const void* wfrag_fwd, const float* bias, int group_rows, int in_features, int scatter,
-                          float* z, int64_t ldz, rg_stream_t stream);
 int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldzt, const int32_t* rowmap,
                        const int32_t* tile_key, int padded_rows, const float* reward, const float* reward_boosts,
                        const float* not_terminal, double gamma, const float* gamma_exponent,
                        const float* quantiles, int batch, int num_atoms, float* dz, int64_t lddz,
                        float* loss_partials, float* tile_losses, rg_stream_t stream);
-int rg_group_head_dgrad(const float* dz, int64_t lddz, const int32_t* tile_key, const int32_t* tile_begin,
-                        int n_tiles, int n_groups, const void* wfrag_bwd, const void* h_frag, int group_rows,
-                        int in_features, int leaky_relu, float* dz3, int64_t lddz3, void* dzw_frag,
-                        float* db_partials, float* db, rg_stream_t stream);
 size_t rg_group_head_wgrad_workspace_bytes(int n_groups, int group_rows, int in_features, int splits);
 int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* tile_begin, int n_groups,
                         int group_rows, int in_features, int splits, float* dw, void* workspace,

@@ -79,6 +79,12 @@ class MlpDesc(ctypes.Structure):
         ("x_split", ctypes.c_int32),
         ("dx_col0", ctypes.c_int32),
         ("rowmap", c_void_p),
+        ("tile_key", c_void_p),
+        ("tile_begin", c_void_p),
+        ("n_groups", ctypes.c_int32),
+        ("out_scatter", ctypes.c_int32),
+        ("group_stride_fwd", ctypes.c_int64),
+        ("group_stride_bwd", ctypes.c_int64),
     ]
 
 
@@ -202,16 +208,14 @@ SIGNATURES = {
     "rg_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d,
                               c_d, c_d, c_d, c_void_p]),
     "rg_soft_update": (c_int, [c_void_p, c_void_p, c_i64, c_d, c_void_p]),
+    "rg_group_rows_workspace_bytes": (c_sz, [c_int, c_int]),
+    "rg_group_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
     "rg_group_wfrag_elems": (c_sz, [c_int, c_int, c_int]),
     "rg_group_weights_stage": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_wide_head_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_qr_select_action": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "rg_group_head_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
-                                       c_void_p, c_i64, c_void_p]),
     "rg_qr_compact_head": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_d, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
-    "rg_group_head_dgrad": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
-                                     c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_group_head_wgrad_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "rg_group_head_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_sz,
                                      c_void_p]),

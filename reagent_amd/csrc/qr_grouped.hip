@@ -12,15 +12,14 @@
 //     linear layer (rg_wide_head_mean builds its weights) — an ordinary narrow output layer of the fused stack;
 //   * the rows of the batch are sorted by the action whose quantiles are needed, every action's rows padded to
 //     whole 128-row tiles ("grouped space", built on the device — no host round trip), and the fused trunk runs
-//     in that row order (rg_mlp_desc.rowmap).  A tile then needs ONE action's [N, H] slice of the wide layer:
-//     forward (rg_group_head_forward), input gradient (rg_group_head_dgrad) and weight gradient
-//     (rg_group_head_wgrad) are 1/A of the dense work and touch [B, N] instead of [B, A * N].
+//     in that row order (rg_mlp_desc.rowmap).  A tile then needs ONE action's [N, H] slice of the wide layer: it
+//     becomes the fused stack's OUTPUT layer with per-tile weights (rg_mlp_desc.tile_key: forward and input
+//     gradient inside rg_mlp_forward_fused / rg_mlp_backward_fused), its weight gradient is rg_group_head_wgrad —
+//     1/A of the dense work, [B, N] instead of [B, A * N] bytes.
 // The quantile-Huber loss itself (rg_qr_compact_head) is the N x N pair loop of rg_qr_head on those compact rows.
 #include "rg_mlp_frag.h"
 
 namespace rg {
-
-constexpr int GH_THREADS = 512, GH_NW = 8;
 
 // ---- weights of the grouped layer -------------------------------------------------------------------------
 // wf[g]: B fragments of W_g [Ng, K] (forward), wb[g]: B fragments of W_g^T [K, Ng] (input gradient)
@@ -84,57 +83,83 @@ __global__ void select_action_kernel(const float* __restrict__ q, long ldq, cons
   key[b] = best;
 }
 
-// ---- forward of the grouped layer -------------------------------------------------------------------------
-// z[dst(r), n] = sum_k h[r, k] W_g[n, k] + b_g[n] for the rows r of one 128-row tile (group g = tile_key[tile]);
-// h arrives in C-fragment order (the saved input of the stack's last layer), dst(r) = rowmap[r] (scatter back
-// to batch order) or r (stay in grouped space).
-struct GroupFwdArgs {
-  const bf16_t* h_frag;
-  const int* rowmap;
-  const int* tile_key;
-  const bf16_t* wf;
-  const float* bias;
-  long per_f;
-  int Ng, K, scatter;
-  float* z;
-  long ldz;
-};
+// ---- the grouped row space: a stable counting sort by key, padded per group to whole 128-row tiles -------------
+// rowmap [128 * n_tiles]: batch row of every grouped row (-1: padding); tile_key [n_tiles]: group of each tile (-1:
+// empty tail tile); tile_begin [G + 1].  Keys >= G mean "no group": dropped.  Rows keep their batch order inside a
+// group (rank = rows of the same key in earlier 256-row blocks + earlier rows of the own block), so the layout —
+// and every sum taken over it — is deterministic.  Three launches, no host round trip.
+constexpr int GR_BLOCK = 256, GR_MAX_KEYS = 130;
 
-template <int PITCH>
-__global__ void RG_LAUNCH_BOUNDS(GH_THREADS, 1) group_head_fwd_kernel(GroupFwdArgs a) {
-  RG_DYN_LDS(smem);
-  bf16_t* act = (bf16_t*)smem;
-  const int g = a.tile_key[blockIdx.x];
-  if (g < 0) return;  // an empty tail tile of the grouped space
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int lr = lane & 31, lg = lane >> 5;
-  constexpr int pitch = PITCH;
-  const int NT = a.K / 32, KC = a.K / 16;
-  // fragment order -> row-major LDS tile (a lane holds 8 rows of one column)
-  for (int f = wave; f < 4 * NT * 2; f += GH_NW) {
-    const int h = f & 1, nt = (f >> 1) % NT, mbl = (f >> 1) / NT;
-    const u16x8 v = *(const u16x8*)(a.h_frag + frag_offset((long)blockIdx.x * 4 + mbl, nt, NT, h, lane));
+__global__ void group_count_kernel(const int* __restrict__ key, int batch, int G, int* __restrict__ block_hist,
+                                   int* __restrict__ rowmap, int padded_rows) {
+  __shared__ int hist[GR_MAX_KEYS];
+  const int tid = threadIdx.x, b = blockIdx.x * GR_BLOCK + tid;
+  for (int i = tid; i <= G; i += GR_BLOCK) hist[i] = 0;
+  __syncthreads();
+  if (b < batch) {
+    const int k = key[b];
+    atomicAdd(&hist[k < G ? (k < 0 ? G : k) : G], 1);
+  }
+  for (int j = b; j < padded_rows; j += gridDim.x * GR_BLOCK) rowmap[j] = -1;
+  __syncthreads();
+  for (int i = tid; i <= G; i += GR_BLOCK) block_hist[blockIdx.x * (G + 1) + i] = hist[i];
+}
+
+// one workgroup of 16 waves: block_hist -> exclusive prefix over the blocks (in place; a wave per key, 64 blocks
+// per step), tile_begin, tile_key
+__global__ void group_scan_kernel(int* __restrict__ block_hist, int n_blocks, int G, int n_tiles, int* __restrict__ tile_begin,
+                                  int* __restrict__ tile_key) {
+  __shared__ int tiles[GR_MAX_KEYS];
+  __shared__ int tb[GR_MAX_KEYS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  for (int g = wave; g < G; g += n_waves) {
+    int run = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
+      const int blk = b0 + lane;
+      const int c = blk < n_blocks ? block_hist[blk * (G + 1) + g] : 0;
+      int incl = c;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) act[(mbl * 32 + frag_row(h, e, lg)) * pitch + nt * 32 + lr] = v[e];
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = shfl_idx(incl, lane >= off ? lane - off : lane);
+        if (lane >= off) incl += t;
+      }
+      if (blk < n_blocks) block_hist[blk * (G + 1) + g] = run + incl - c;
+      run += shfl_idx(incl, 63);
+    }
+    if (lane == 0) tiles[g] = (run + 127) / 128;
   }
   __syncthreads();
-  const int NTo = (a.Ng + 31) / 32;
-  const bf16_t* wf = a.wf + (long)g * a.per_f;
-  const float* bias = a.bias ? a.bias + (long)g * a.Ng : nullptr;
-  for (int t = wave; t < 4 * NTo; t += GH_NW) {
-    const int tm = t & 3, nt = t >> 2;
-    const f32x16 acc = tile_kloop(act, pitch, KC, wf, tm, nt, lane);
-    const int col = nt * 32 + lr;
-    if (col < a.Ng) {
-      const float b = bias ? bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = blockIdx.x * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-        const int src = a.rowmap[row];
-        if (src >= 0) a.z[(long)(a.scatter ? src : row) * a.ldz + col] = acc[r] + b;
-      }
+  if (tid == 0) {
+    int run = 0;
+    for (int g = 0; g < G; ++g) {
+      tb[g] = run;
+      run += tiles[g];
     }
+    tb[G] = run;
   }
+  __syncthreads();
+  if (tid <= G) tile_begin[tid] = tb[tid];
+  for (int t = tid; t < n_tiles; t += blockDim.x) {
+    int g = -1;
+    if (t < tb[G])
+      for (int q = 0; q < G; ++q)
+        if (t >= tb[q] && t < tb[q + 1]) g = q;
+    tile_key[t] = g;
+  }
+}
+
+__global__ void group_scatter_kernel(const int* __restrict__ key, int batch, int G, const int* __restrict__ block_base,
+                                     const int* __restrict__ tile_begin, int* __restrict__ rowmap) {
+  __shared__ int keys[GR_BLOCK];
+  const int tid = threadIdx.x, b = blockIdx.x * GR_BLOCK + tid;
+  int k = b < batch ? key[b] : G;
+  if (k < 0 || k > G) k = G;
+  keys[tid] = k;
+  __syncthreads();
+  if (k >= G) return;
+  int rank = block_base[blockIdx.x * (G + 1) + k];
+  for (int i = 0; i < tid; ++i) rank += keys[i] == k ? 1 : 0;
+  rowmap[tile_begin[k] * 128 + rank] = b;
 }
 
 // ---- quantile-Huber loss on compact rows (qrdqn_trainer.py:137-160, huber :217-218) ---------------------------
@@ -142,7 +167,6 @@ __global__ void RG_LAUNCH_BOUNDS(GH_THREADS, 1) group_head_fwd_kernel(GroupFwdAr
 //   T_i = reward[b] (+ boost of the logged action) + gamma^e[b] * not_terminal[b] * zt[b, i]
 //   C_j = z[r, j]
 //   loss = mean over (i, b, j) of huber(T_i - C_j) * |tau_j - 1{T_i - C_j < 0}|;  dz[r, j] = d loss / d C_j
-constexpr int QC_MAX_ATOMS = 1024;
 struct CompactHeadArgs {
   const float* z;
   const float* zt;
@@ -161,19 +185,14 @@ struct CompactHeadArgs {
   float* loss_partials;
 };
 
-__device__ __forceinline__ float block_sum_256_(float v, float* scratch) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += shfl_xor(v, off);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) scratch[wave] = v;
-  __syncthreads();
-  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
-}
+// One workgroup of 256 threads per row.  (Four rows per 832-thread workgroup — N = 200 fills 3.1 waves, four rows
+// 12.5 of 13 — measured 0.68 ms against 0.46 ms: the T reads stop being workgroup-uniform broadcasts.)
+constexpr int QC_MAX_N = 1024;
 
 __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
-  __shared__ __attribute__((aligned(16))) float T[QC_MAX_ATOMS];
-  __shared__ float C[QC_MAX_ATOMS];
-  __shared__ float scratch[4];
+  __shared__ __attribute__((aligned(16))) float T[QC_MAX_N];
+  __shared__ float C[QC_MAX_N];
+  __shared__ float wsum[4];
   const int r = blockIdx.x, tid = threadIdx.x, N = a.N;
   const int b = a.rowmap[r];
   float* dz = a.dz + (long)r * a.lddz;
@@ -226,8 +245,11 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     }
     dz[j] = -gsum * inv;
   }
-  const float s = block_sum_256_(loss, scratch);
-  if (tid == 0) a.loss_partials[r] = s * inv;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) loss += shfl_xor(loss, off);
+  if ((tid & 63) == 0) wsum[tid >> 6] = loss;
+  __syncthreads();
+  if (tid == 0) a.loss_partials[r] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv;
 }
 
 // tile_sums[t] = sum of loss_partials[128 t .. 128 t + 127] (row order), so that the final deterministic single-
@@ -242,68 +264,6 @@ __global__ void tile_sum_kernel(const float* __restrict__ v, float* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1];
 }
 
-// ---- input gradient of the grouped layer --------------------------------------------------------------------
-// dh[r, k] = sum_n dz[r, n] W_g[n, k]; written as d loss / d (pre-activation of the stack's last hidden layer):
-// dz3[r, k] = dh[r, k] * act'(h[r, k]) (ReLU family: h > 0 read from the saved fragments).  Also emits dz in
-// C-fragment order (the weight-gradient operand) and the per-tile column sums of dz (bias gradient partials).
-struct GroupDgradArgs {
-  const float* dz;
-  long lddz;
-  const int* tile_key;
-  const bf16_t* wb;
-  long per_b;
-  const bf16_t* h_frag;
-  int Ng, K, leaky;
-  float* dz3;
-  long lddz3;
-  bf16_t* dzw_frag;
-  float* db_part;  // [tiles][NgP]
-};
-
-template <int PITCH>
-__global__ void RG_LAUNCH_BOUNDS(GH_THREADS, 1) group_head_dgrad_kernel(GroupDgradArgs a) {
-  RG_DYN_LDS(smem);
-  bf16_t* act = (bf16_t*)smem;
-  const int g = a.tile_key[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int lr = lane & 31, lg = lane >> 5;
-  constexpr int pitch = PITCH;
-  const int NgP = (a.Ng + 31) / 32 * 32, NTz = NgP / 32, NT = a.K / 32;
-  const int row_base = blockIdx.x * 128;
-  if (g < 0) {  // empty tail tile: the trunk backward and the weight gradients still read these rows
-    for (int i = tid; i < 128 * a.K; i += GH_THREADS) a.dz3[(long)(row_base + i / a.K) * a.lddz3 + i % a.K] = 0.f;
-    for (int i = tid; i < 128 * NgP / 8; i += GH_THREADS)
-      *(u16x8*)(a.dzw_frag + ((long)blockIdx.x * 4 * NTz * 2 * 64) * 8 + (long)i * 8) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.db_part && tid < NgP) a.db_part[(long)blockIdx.x * NgP + tid] = 0.f;
-    return;
-  }
-  load_tile_to_lds<float, GH_THREADS>(act, pitch, a.dz, a.lddz, row_base, row_base + 128, a.Ng, NgP, tid);
-  __syncthreads();
-  emit_frags_from_lds(act, pitch, NTz, a.dzw_frag, blockIdx.x * 4, wave, GH_NW, lane);
-  if (a.db_part && tid < NgP) {
-    float s = 0.f;
-    for (int r = 0; r < 128; ++r) s += bf16_to_f32(act[r * pitch + tid]);
-    a.db_part[(long)blockIdx.x * NgP + tid] = s;
-  }
-  const int KC = (a.Ng + 15) / 16;
-  const bf16_t* wb = a.wb + (long)g * a.per_b;
-  for (int t = wave; t < 4 * NT; t += GH_NW) {
-    const int tm = t & 3, nt = t >> 2;
-    const f32x16 acc = tile_kloop(act, pitch, KC, wb, tm, nt, lane);
-    const int col = nt * 32 + lr;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const u16x8 hf = *(const u16x8*)(a.h_frag + frag_offset((long)blockIdx.x * 4 + tm, nt, NT, h, lane));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int row = row_base + tm * 32 + frag_row(h, e, lg);
-        const float gr = bf16_to_f32(hf[e]) > 0.f ? 1.f : (a.leaky ? 0.01f : 0.f);
-        a.dz3[(long)row * a.lddz3 + col] = acc[8 * h + e] * gr;
-      }
-    }
-  }
-}
-
 // db[g * Ng + n] = sum over the tiles of group g of db_part[tile][n]
 __global__ void group_bias_reduce_kernel(const float* __restrict__ db_part, const int* __restrict__ tile_begin, int Ng,
                                          int NgP, float* __restrict__ db) {
@@ -315,7 +275,11 @@ __global__ void group_bias_reduce_kernel(const float* __restrict__ db_part, cons
   }
 }
 
-static int group_pitch(int K) { return K <= 256 ? 264 : 520; }
+void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db,
+                                hipStream_t stream) {
+  RG_LAUNCH(group_bias_reduce_kernel, dim3(n_groups), dim3(256), stream, db_part, tile_begin, Ng, Ng, db);
+}
+
 
 }  // namespace rg
 
@@ -346,32 +310,31 @@ int rg_wide_head_mean(const float* w, const float* b, int n_groups, int group_ro
   return (int)hipGetLastError();
 }
 
+size_t rg_group_rows_workspace_bytes(int batch, int n_groups) {
+  return (size_t)((batch + GR_BLOCK - 1) / GR_BLOCK) * (n_groups + 1) * sizeof(int);
+}
+
+int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int32_t* rowmap, int32_t* tile_key,
+                  int32_t* tile_begin, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
+  if (!key || !rowmap || !tile_key || !tile_begin || batch <= 0 || n_groups <= 0 || n_groups + 1 > GR_MAX_KEYS ||
+      n_tiles < (batch + 127) / 128 + n_groups)
+    return RG_EINVAL;
+  if (!workspace || workspace_bytes < rg_group_rows_workspace_bytes(batch, n_groups)) return RG_EWORKSPACE;
+  const int nblk = (batch + GR_BLOCK - 1) / GR_BLOCK;
+  int* hist = (int*)workspace;
+  RG_LAUNCH(group_count_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, key, batch, n_groups, hist, rowmap,
+            n_tiles * 128);
+  RG_LAUNCH(group_scan_kernel, dim3(1), dim3(1024), (hipStream_t)stream, hist, nblk, n_groups, n_tiles, tile_begin, tile_key);
+  RG_LAUNCH(group_scatter_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, key, batch, n_groups, (const int*)hist,
+            (const int*)tile_begin, rowmap);
+  return (int)hipGetLastError();
+}
+
 int rg_qr_select_action(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq, int32_t* key,
                         rg_stream_t stream) {
   if (!mask || !key || batch <= 0 || num_actions <= 0 || (maxq && !q)) return RG_EINVAL;
   RG_LAUNCH(select_action_kernel, dim3((batch + 255) / 256), dim3(256), (hipStream_t)stream, q, (long)ldq, mask, batch,
             num_actions, maxq, key);
-  return (int)hipGetLastError();
-}
-
-int rg_group_head_forward(const void* h_frag, const int32_t* rowmap, const int32_t* tile_key, int n_tiles,
-                          const void* wfrag_fwd, const float* bias, int group_rows, int in_features, int scatter, float* z,
-                          int64_t ldz, rg_stream_t stream) {
-  if (!h_frag || !rowmap || !tile_key || !wfrag_fwd || !z || n_tiles <= 0 || group_rows <= 0) return RG_EINVAL;
-  if (in_features != 256 && in_features != 512) return RG_EUNSUPPORTED;
-  GroupFwdArgs a;
-  a.h_frag = (const bf16_t*)h_frag; a.rowmap = rowmap; a.tile_key = tile_key; a.wf = (const bf16_t*)wfrag_fwd; a.bias = bias;
-  a.per_f = (long)wfrag_elems(group_rows, in_features); a.Ng = group_rows; a.K = in_features; a.scatter = scatter; a.z = z;
-  a.ldz = ldz;
-  const int pitch = group_pitch(in_features);
-  const size_t lds = (size_t)128 * pitch * sizeof(bf16_t);
-  if (pitch == 264) {
-    RG_ALLOW_LDS(group_head_fwd_kernel<264>, lds);
-    RG_LAUNCH_DYN(group_head_fwd_kernel<264>, dim3(n_tiles), dim3(GH_THREADS), lds, (hipStream_t)stream, a);
-  } else {
-    RG_ALLOW_LDS(group_head_fwd_kernel<520>, lds);
-    RG_LAUNCH_DYN(group_head_fwd_kernel<520>, dim3(n_tiles), dim3(GH_THREADS), lds, (hipStream_t)stream, a);
-  }
   return (int)hipGetLastError();
 }
 
@@ -383,7 +346,7 @@ int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldz
   if (!z || !zt || !rowmap || !tile_key || !reward || !not_terminal || !quantiles || !dz || !loss_partials ||
       padded_rows <= 0 || (padded_rows % 128) != 0 || batch <= 0 || num_atoms <= 0)
     return RG_EINVAL;
-  if (num_atoms > QC_MAX_ATOMS || lddz < num_atoms) return RG_EUNSUPPORTED;
+  if (num_atoms > QC_MAX_N || lddz < num_atoms) return RG_EUNSUPPORTED;
   CompactHeadArgs a;
   a.z = z; a.zt = zt; a.ldz = ldz; a.ldzt = ldzt; a.rowmap = rowmap; a.tile_key = tile_key; a.reward = reward;
   a.reward_boosts = reward_boosts; a.not_terminal = not_terminal; a.gamma_exponent = gamma_exponent; a.quantiles = quantiles;
@@ -392,35 +355,6 @@ int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldz
   int rc = (int)hipGetLastError();
   if (rc || !tile_losses) return rc;
   RG_LAUNCH(tile_sum_kernel, dim3(padded_rows / 128), dim3(128), (hipStream_t)stream, (const float*)loss_partials, tile_losses);
-  return (int)hipGetLastError();
-}
-
-int rg_group_head_dgrad(const float* dz, int64_t lddz, const int32_t* tile_key, const int32_t* tile_begin, int n_tiles,
-                        int n_groups, const void* wfrag_bwd, const void* h_frag, int group_rows, int in_features,
-                        int leaky_relu, float* dz3, int64_t lddz3, void* dzw_frag, float* db_partials, float* db,
-                        rg_stream_t stream) {
-  if (!dz || !tile_key || !wfrag_bwd || !h_frag || !dz3 || !dzw_frag || n_tiles <= 0 || group_rows <= 0) return RG_EINVAL;
-  if (in_features != 256 && in_features != 512) return RG_EUNSUPPORTED;
-  if (db && (!db_partials || !tile_begin)) return RG_EINVAL;
-  const int NgP = (group_rows + 31) / 32 * 32;
-  if (NgP + 8 > group_pitch(in_features)) return RG_EUNSUPPORTED;
-  GroupDgradArgs a;
-  a.dz = dz; a.lddz = lddz; a.tile_key = tile_key; a.wb = (const bf16_t*)wfrag_bwd;
-  a.per_b = (long)wfrag_elems(in_features, group_rows); a.h_frag = (const bf16_t*)h_frag; a.Ng = group_rows; a.K = in_features;
-  a.leaky = leaky_relu; a.dz3 = dz3; a.lddz3 = lddz3; a.dzw_frag = (bf16_t*)dzw_frag; a.db_part = db ? db_partials : nullptr;
-  const int pitch = group_pitch(in_features);
-  const size_t lds = (size_t)128 * pitch * sizeof(bf16_t);
-  if (pitch == 264) {
-    RG_ALLOW_LDS(group_head_dgrad_kernel<264>, lds);
-    RG_LAUNCH_DYN(group_head_dgrad_kernel<264>, dim3(n_tiles), dim3(GH_THREADS), lds, (hipStream_t)stream, a);
-  } else {
-    RG_ALLOW_LDS(group_head_dgrad_kernel<520>, lds);
-    RG_LAUNCH_DYN(group_head_dgrad_kernel<520>, dim3(n_tiles), dim3(GH_THREADS), lds, (hipStream_t)stream, a);
-  }
-  int rc = (int)hipGetLastError();
-  if (rc || !db) return rc;
-  RG_LAUNCH(group_bias_reduce_kernel, dim3(n_groups), dim3(256), (hipStream_t)stream, (const float*)db_partials, tile_begin,
-            group_rows, NgP, db);
   return (int)hipGetLastError();
 }
 

@@ -45,6 +45,9 @@ struct MlpArgs {
   int x_split;
   int dx_col0;                    // backward: first input column whose gradient is produced (dx32[0])
   const int* rowmap;              // forward: tile row r reads input row rowmap[r] (-1: zeros); null = identity
+  const int* tile_key;            // grouped output layer: group of each 128-row tile (-1: empty), null = plain layer
+  long group_stride;              // elements between the groups' fragment sets of the last layer (this direction)
+  int out_scatter;                // forward: output row r goes to out32[rowmap[r]]
   int x_is_f32;
   float* out32;  // forward output [batch, dims[L]] fp32
   long ldo;
@@ -514,7 +517,7 @@ static inline int fused_supported(const rg_mlp_desc* d) {
   for (int l = 1; l < d->n_layers; ++l)
     if (d->dims[l] != H) return 0;
   if (d->dims[0] < 1 || d->dims[0] > 512) return 0;
-  if (d->dims[d->n_layers] < 1 || d->dims[d->n_layers] > 128) return 0;
+  if (d->dims[d->n_layers] < 1 || d->dims[d->n_layers] > 256) return 0;
   return H / 256;
 }
 
@@ -598,11 +601,17 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
   }
   a.pitch = fused_pitch(d);
   a.rowmap = d->rowmap;
+  a.tile_key = d->tile_key; a.group_stride = backward ? d->group_stride_bwd : d->group_stride_fwd;
+  a.out_scatter = d->tile_key ? d->out_scatter : 0;
   a.x2 = d->x2; a.ldx2 = d->ldx2; a.x_split = d->x2 ? d->x_split : 0; a.dx_col0 = d->dx_col0;
   a.x = nullptr; a.ldx = 0; a.x_is_f32 = 0; a.out32 = nullptr; a.ldo = 0; a.dout32 = nullptr; a.lddo = 0;
   a.dx32 = nullptr; a.lddx = 0; a.save = 0;
   return RG_OK;
 }
+
+// db[g * Ng + n] = sum over the tiles of group g of db_part[tile][n] (qr_grouped.hip; db_part row pitch Ng)
+void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db,
+                                hipStream_t stream);
 
 // split-bf16 kernels (mlp_fused_x3.hip); `a` filled by fill_args, launch geometry decided there
 int x3_forward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream);

@@ -435,39 +435,102 @@ class FusedMLP:
                      lambda: lib.rg_mlp_wgrad_fused(d, B, ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
 
 
-def _trunk_desc(st: "FusedMLP") -> "L.MlpDesc":
-    d = st._fill_desc()
-    t = L.MlpDesc()
-    n = st.L - 1
-    t.n_layers = n
-    for i in range(n + 1):
-        t.dims[i] = st.dims[i]
-    for l in range(n):
-        t.acts[l] = st.acts[l]
-        for f in ("wfrag_fwd", "wfrag_bwd", "bias", "act_frag", "dz_frag", "act_sign"):
-            getattr(t, f)[l] = getattr(d, f)[l]
-    return t
+class GroupedHead:
+    """The output layer of a fused stack as n_groups layers [group_rows, H], one per 128-row tile of a grouped row
+    space (qr_engine.py): per-group MFMA fragments of W_g / W_g^T (rg_group_weights_stage), the bias, and the
+    buffers the backward of that layer needs."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, n_groups: int, group_rows: int, need_bwd: bool):
+        self.weight, self.bias, self.G, self.Ng = weight, bias, n_groups, group_rows
+        H = weight.shape[1]
+        dev = weight.device
+        self.H = H
+        self.per_f = ops.group_wfrag_elems(group_rows, H, False)
+        self.per_b = ops.group_wfrag_elems(group_rows, H, True)
+        self.wf = torch.empty(n_groups * self.per_f, dtype=torch.bfloat16, device=dev)
+        self.wb = torch.empty(n_groups * self.per_b, dtype=torch.bfloat16, device=dev) if need_bwd else None
+        self._rows = -1
+
+    def stage(self):
+        ops.group_weights_stage(self.weight.detach(), self.G, self.Ng, self.wf, self.wb)
+
+    def workspace(self, rows: int, st: "FusedMLP"):
+        if self._rows != rows:
+            dev = self.weight.device
+            lib = L.lib()
+            self.dz_frag = torch.empty(lib.rg_frag_elems(rows, self.Ng), dtype=torch.bfloat16, device=dev)
+            d = self.desc(st, None, None, None)
+            self.bwd_ws = torch.empty(lib.rg_mlp_backward_fused_workspace_bytes(d, rows) // 4 + 4, dtype=torch.float32, device=dev)
+            self._rows = rows
+
+    def desc(self, st: "FusedMLP", space, scatter, save_dz) -> "L.MlpDesc":
+        """the stack's descriptor with its last layer replaced by this grouped layer"""
+        src = st._fill_desc()
+        d = L.MlpDesc()
+        ctypes_copy(d, src)
+        n = st.L
+        d.dims[n] = self.Ng
+        d.wfrag_fwd[n - 1] = self.wf.data_ptr()
+        d.wfrag_bwd[n - 1] = self.wb.data_ptr() if self.wb is not None else None
+        d.bias[n - 1] = self.bias.data_ptr()
+        d.group_stride_fwd, d.group_stride_bwd, d.n_groups = self.per_f, self.per_b, self.G
+        if space is not None:
+            d.rowmap, d.tile_key, d.tile_begin = space.rowmap.data_ptr(), space.tile_key.data_ptr(), space.tile_begin.data_ptr()
+            d.out_scatter = int(bool(scatter))
+        if save_dz:
+            d.dz_frag[n - 1] = self.dz_frag.data_ptr()
+        return d
 
 
-def fused_backward_trunk(st: "FusedMLP", dz_last32: torch.Tensor, dw: List[torch.Tensor], db: List[torch.Tensor]):
-    """Backward of every layer but the last of a fused stack, started from dz_last32 = d loss / d (pre-activation of
-    the last HIDDEN layer), fp32 [B, H] — for stacks whose output layer is handled by the grouped kernels
-    (qr_engine.py).  Needs the saving forward of the whole stack on the same rows; writes dw / db of layers
-    0 .. L-2."""
-    B = dz_last32.shape[0]
-    assert not st.x3 and st._ws.get("key") == (B, dz_last32.device, True), "needs a saving forward first"
-    t = _trunk_desc(st)
+def ctypes_copy(dst, src):
+    import ctypes
+
+    ctypes.memmove(ctypes.byref(dst), ctypes.byref(src), ctypes.sizeof(type(src)))
+
+
+def fused_forward_grouped(st: "FusedMLP", head: GroupedHead, x: torch.Tensor, space, out32: torch.Tensor, scatter: bool,
+                          save: bool):
+    """The stack in the grouped row space `space` with `head` as its output layer:
+    out32[dst(r), 0:group_rows] = head_g(trunk(x[rowmap[r]])), dst(r) = rowmap[r] (scatter) or r."""
+    L.require_cuda(x)
+    R = space.rows
+    st._ensure_ws(R, x.device, training=save)
+    head.workspace(R, st)
+    d = head.desc(st, space, scatter, save)
+    d.x2, d.ldx2, d.x_split = None, 0, 0
+    assert x.stride(1) == 1 and out32.stride(1) == 1 and x.shape[1] == st.dims[0]
+    ops._run("rg_mlp_forward_fused", dict(B=R, save=int(save), dims=tuple(st.dims[:-1]) + (head.Ng,)),
+             lambda: L.lib().rg_mlp_forward_fused(d, x.data_ptr(), ops.dt_code(x.dtype), x.stride(0), R, out32.data_ptr(),
+                                                  out32.stride(0), int(save), L.stream_ptr()))
+
+
+def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch.Tensor, dw: List[torch.Tensor],
+                           db: List[torch.Tensor], wgrad_ws: torch.Tensor, splits: int):
+    """Backward of the stack + grouped head from dz32 = d loss / d (head output) [grouped rows, group_rows]:
+    one rg_mlp_backward_fused launch (the head's input gradient is its first layer step, per-tile W_g^T), the
+    trunk's weight gradients by rg_mlp_wgrad_fused, the head's by rg_group_head_wgrad.  dw / db: all L layers."""
+    R = space.rows
+    assert st._ws.get("key") == (R, dz32.device, True), "needs a saving grouped forward first"
     lib = L.lib()
-    ws = st._ws
-    n = st.L - 1
+    n = st.L
+    d = head.desc(st, space, False, True)
     for l in range(n):
-        t.db[l] = db[l].data_ptr()
-        t.dw[l] = dw[l].data_ptr()
-    ops._run("rg_mlp_backward_fused", dict(B=B, dims=tuple(st.dims[: n + 1])),
-             lambda: lib.rg_mlp_backward_fused(t, dz_last32.data_ptr(), dz_last32.stride(0), B, None, 0,
-                                               ws["bwd"].data_ptr(), ws["bwd"].numel() * 4, L.stream_ptr()))
-    ops._run("rg_mlp_wgrad_fused", dict(B=B, dims=tuple(st.dims[: n + 1])),
-             lambda: lib.rg_mlp_wgrad_fused(t, B, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))
+        d.db[l] = db[l].data_ptr()
+    ops._run("rg_mlp_backward_fused", dict(B=R, dims=tuple(st.dims[:-1]) + (head.Ng,)),
+             lambda: lib.rg_mlp_backward_fused(d, dz32.data_ptr(), dz32.stride(0), R, None, 0, head.bwd_ws.data_ptr(),
+                                               head.bwd_ws.numel() * 4, L.stream_ptr()))
+    t = L.MlpDesc()  # the trunk: layers 0 .. L-2
+    t.n_layers = n - 1
+    for i in range(n):
+        t.dims[i] = st.dims[i]
+    for l in range(n - 1):
+        t.acts[l] = st.acts[l]
+        t.act_frag[l], t.dz_frag[l], t.dw[l] = d.act_frag[l], d.dz_frag[l], dw[l].data_ptr()
+    ws = st._ws
+    ops._run("rg_mlp_wgrad_fused", dict(B=R, dims=tuple(st.dims[:n])),
+             lambda: lib.rg_mlp_wgrad_fused(t, R, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))
+    ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.tile_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
+                         wgrad_ws)
 
 
 def make_stack(weights, biases, acts: List[int], precision: int):

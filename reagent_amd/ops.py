@@ -535,6 +535,14 @@ def add_cols(a, b, out):
 
 
 # ---- QR-DQN with a grouped output layer (qr_grouped.hip) ------------------------------------------------------
+def group_rows(key, n_groups, n_tiles, rowmap, tile_key, tile_begin, workspace):
+    _chk_dev(key, rowmap, tile_key, tile_begin, workspace)
+    assert key.dtype == torch.int32 and rowmap.numel() == n_tiles * 128 and tile_key.numel() == n_tiles
+    _run("rg_group_rows", dict(B=key.numel(), G=n_groups),
+         lambda: L.lib().rg_group_rows(key.data_ptr(), key.numel(), n_groups, n_tiles, rowmap.data_ptr(), tile_key.data_ptr(),
+                                       tile_begin.data_ptr(), workspace.data_ptr(), workspace.numel() * 4, L.stream_ptr()))
+
+
 def group_wfrag_elems(group_rows: int, in_features: int, transposed: bool) -> int:
     return int(L.lib().rg_group_wfrag_elems(group_rows, in_features, int(transposed)))
 
@@ -564,14 +572,6 @@ def qr_select_action(q, mask, maxq: bool, key):
                                              key.data_ptr(), L.stream_ptr()))
 
 
-def group_head_forward(h_frag, rowmap, tile_key, wf, bias, group_rows, in_features, scatter: bool, z):
-    _chk_dev(h_frag, rowmap, tile_key, wf, bias, z)
-    _run("rg_group_head_forward", dict(T=tile_key.numel(), Ng=group_rows, K=in_features),
-         lambda: L.lib().rg_group_head_forward(h_frag.data_ptr(), rowmap.data_ptr(), tile_key.data_ptr(), tile_key.numel(),
-                                               wf.data_ptr(), L.ptr(bias), group_rows, in_features, int(scatter),
-                                               z.data_ptr(), _ld(z), L.stream_ptr()))
-
-
 def qr_compact_head(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma, gamma_exponent, quantiles,
                     batch, num_atoms, dz, loss_partials, tile_losses=None):
     _chk_dev(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma_exponent, quantiles, dz, loss_partials,
@@ -584,16 +584,6 @@ def qr_compact_head(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal
                                             not_terminal.data_ptr(), float(gamma), L.ptr(gamma_exponent),
                                             quantiles.data_ptr(), batch, num_atoms, dz.data_ptr(), _ld(dz),
                                             loss_partials.data_ptr(), L.ptr(tile_losses), L.stream_ptr()))
-
-
-def group_head_dgrad(dz, tile_key, tile_begin, n_groups, wb, h_frag, group_rows, in_features, leaky: bool, dz3, dzw_frag,
-                     db_partials, db):
-    _chk_dev(dz, tile_key, tile_begin, wb, h_frag, dz3, dzw_frag, db_partials, db)
-    _run("rg_group_head_dgrad", dict(T=tile_key.numel(), Ng=group_rows, K=in_features),
-         lambda: L.lib().rg_group_head_dgrad(dz.data_ptr(), _ld(dz), tile_key.data_ptr(), tile_begin.data_ptr(),
-                                             tile_key.numel(), n_groups, wb.data_ptr(), h_frag.data_ptr(), group_rows,
-                                             in_features, int(leaky), dz3.data_ptr(), _ld(dz3), dzw_frag.data_ptr(),
-                                             L.ptr(db_partials), L.ptr(db), L.stream_ptr()))
 
 
 def group_head_wgrad(dzw_frag, h_frag, tile_begin, n_groups, group_rows, in_features, splits, dw, workspace):

@@ -5,12 +5,13 @@ reagent/training/qrdqn_trainer.py:108-160 computes, without ever writing the [B,
                                                          MEAN of the wide layer's rows (rg_wide_head_mean)
     a*         = arg max with the possible-actions mask   rg_qr_select_action                    (:125-135, :210-214)
     grouped space of a*: rows sorted by a*, each action padded to whole 128-row tiles (index bookkeeping, torch)
-    zt[b, :]   = target_net(next_state)[b, a*, :]         fused trunk in grouped space + rg_group_head_forward (:137-141)
+    zt[b, :]   = target_net(next_state)[b, a*, :]         ONE fused forward in grouped space whose output layer is the
+                                                         tile's action slice of the wide layer        (:137-141)
     grouped space of the logged action
-    z[r, :]    = q_net(state)[b, logged a, :]              fused trunk (saving) + rg_group_head_forward  (:143-146)
+    z[r, :]    = q_net(state)[b, logged a, :]              the same, saving for the backward          (:143-146)
     loss, dz   = quantile Huber on [rows, N]               rg_qr_compact_head                      (:148-160, :217-218)
-    backward   = rg_group_head_dgrad -> trunk backward (rg_mlp_backward_fused on the trunk) + rg_mlp_wgrad_fused,
-                 rg_group_head_wgrad for the wide layer
+    backward   = ONE rg_mlp_backward_fused (the wide layer's input gradient is its first step, per-tile W_g^T),
+                 rg_mlp_wgrad_fused for the trunk, rg_group_head_wgrad for the wide layer
 Arithmetic is that of the bf16 fused stack (bf16 operands, fp32 accumulation); the only algebraic rewrite is
 mean_n(h . W[a, n] + b[a, n]) = h . mean_n W[a, n] + mean_n b[a, n].  A transition whose logged action row is all
 zero contributes nothing (the reference would regress C = 0 for it; one-hot actions are the trainer's contract,
@@ -22,43 +23,28 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .engine import FusedMLP, fused_backward_trunk
+from .engine import FusedMLP, GroupedHead, fused_backward_grouped, fused_forward_grouped
 
 TILE = 128
 
 
 class GroupedSpace:
-    """rows of a batch sorted by an int32 key in [0, G] (G = "no group": dropped) and padded per key to whole tiles;
-    static shapes throughout (no host synchronisation): rowmap [TILE * n_tiles], tile_key [n_tiles], tile_begin [G + 1]"""
+    """rows of a batch sorted by an int32 key in [0, G] (G = "no group": dropped) and padded per key to whole tiles
+    (rg_group_rows: a stable counting sort on the device, static shapes, no host synchronisation):
+    rowmap [TILE * n_tiles], tile_key [n_tiles], tile_begin [G + 1], all int32"""
 
     def __init__(self, B: int, G: int, device):
         self.B, self.G = B, G
         self.n_tiles = (B + TILE - 1) // TILE + G
         self.rows = self.n_tiles * TILE
-        self._ar_b = torch.arange(B, device=device)
-        self._ar_t = torch.arange(self.n_tiles, device=device)
-        self._zero = torch.zeros(1, dtype=torch.int64, device=device)
-        self._ones = torch.ones(B, dtype=torch.int64, device=device)
-        self.rowmap = self.tile_key = self.tile_begin = None
+        i32 = dict(dtype=torch.int32, device=device)
+        self.rowmap = torch.empty(self.rows, **i32)
+        self.tile_key = torch.empty(self.n_tiles, **i32)
+        self.tile_begin = torch.empty(G + 1, **i32)
+        self._ws = torch.empty(max(1, L.lib().rg_group_rows_workspace_bytes(B, G) // 4), **i32)
 
     def build(self, key: torch.Tensor):
-        B, G = self.B, self.G
-        k = key.long()
-        counts = torch.zeros(G + 1, dtype=torch.int64, device=key.device).scatter_add_(0, k, self._ones)  # (bincount syncs)
-        tiles = (counts[:G] + (TILE - 1)) // TILE
-        tile_begin = torch.cat((self._zero, torch.cumsum(tiles, 0)))          # [G + 1]
-        ks, order = torch.sort(k, stable=True)                                 # deterministic: batch order inside a group
-        group_start = torch.cumsum(counts, 0) - counts                         # first sorted position of each key
-        rank = self._ar_b - group_start[ks]
-        grouped = ks < G
-        tb_ext = torch.cat((tile_begin[:G], self._zero))
-        dest = torch.where(grouped, tb_ext[ks] * TILE + rank, torch.full_like(rank, self.rows))
-        rowmap = torch.full((self.rows + 1,), -1, dtype=torch.int32, device=key.device)
-        rowmap[dest] = torch.where(grouped, order, torch.full_like(order, -1)).to(torch.int32)
-        self.rowmap = rowmap[: self.rows]
-        g_of_tile = torch.searchsorted(tile_begin[1:].contiguous(), self._ar_t, right=True)
-        self.tile_key = torch.where(self._ar_t < tile_begin[G], g_of_tile, torch.full_like(g_of_tile, -1)).to(torch.int32)
-        self.tile_begin = tile_begin.to(torch.int32)
+        ops.group_rows(key, self.G, self.n_tiles, self.rowmap, self.tile_key, self.tile_begin, self._ws)
         return self
 
 
@@ -77,8 +63,7 @@ class _Net:
         acts = [L.ACT[a] for a in net.fc.activation_names]
         self.st = FusedMLP([l.weight for l in lin[:-1]] + [self.wbar], [l.bias for l in lin[:-1]] + [self.bbar],
                            acts[:-1] + [L.ACT["linear"]])
-        self.wf = torch.empty(A * ops.group_wfrag_elems(N, H, False), dtype=torch.bfloat16, device=dev)
-        self.wb = torch.empty(A * ops.group_wfrag_elems(N, H, True), dtype=torch.bfloat16, device=dev) if need_bwd else None
+        self.gh = GroupedHead(self.head.weight, self.head.bias, A, N, need_bwd)
         self._staged = None
 
     def stage(self):
@@ -87,11 +72,8 @@ class _Net:
             return
         ops.wide_head_mean(self.head.weight.detach(), self.head.bias.detach(), self.A, self.N, self.wbar, self.bbar)
         self.st.stage_weights(need_transposed=self.need_bwd, force=True)
-        ops.group_weights_stage(self.head.weight.detach(), self.A, self.N, self.wf, self.wb)
+        self.gh.stage()
         self._staged = ver
-
-    def h_frag(self):
-        return self.st._ws["act_frag"][self.st.L - 1]
 
 
 class GroupedQR:
@@ -131,15 +113,10 @@ class GroupedQR:
         self.key_next = torch.empty(B, dtype=torch.int32, device=dev)
         self.key_cur = torch.empty(B, dtype=torch.int32, device=dev)
         self.qbar_next = torch.empty(B, A, **f32)
-        self.qbar_t = torch.empty(R, A, **f32)
-        self.qbar_cur = torch.empty(R, A, **f32)
+        self.qbar_cur = torch.empty(B, A, **f32)
         self.zt = torch.zeros(B, ldz, **f32)
         self.z = torch.empty(R, ldz, **f32)
         self.dz = torch.empty(R, ldz, **f32)
-        self.dz3 = torch.empty(R, H, **f32)
-        NgP = (N + 31) // 32 * 32
-        self.dzw_frag = torch.empty(R * NgP, dtype=torch.bfloat16, device=dev)
-        self.db_part = torch.empty(self.sp_cur.n_tiles * NgP, **f32)
         self.loss_partials = torch.empty(R, **f32)
         self.tile_losses = torch.empty(self.sp_cur.n_tiles, **f32)
         self.splits = 8
@@ -164,14 +141,13 @@ class GroupedQR:
         else:  # SARSA: the logged next action (qrdqn_trainer.py:139-141); terminal rows carry none
             ops.qr_select_action(None, tr._f32c(b.next_action), False, self.key_next)
         sp2 = self.sp_next.build(self.key_next)
-        tg.st.forward(next_state, self.qbar_t, save=True, rowmap=sp2.rowmap)
-        self.zt.zero_()
-        ops.group_head_forward(tg.h_frag(), sp2.rowmap, sp2.tile_key, tg.wf, tg.head.bias.detach(), self.N, tg.H, True, self.zt)
-        # current quantiles of the logged action
+        self.zt.zero_()  # rows without a next action (SARSA, terminal) keep zero quantiles
+        fused_forward_grouped(tg.st, tg.gh, next_state, sp2, self.zt, scatter=True, save=False)
+        # current quantiles of the logged action (grouped space of the logged action; saved for the backward)
         ops.qr_select_action(None, tr._f32c(b.action), False, self.key_cur)
         sp1 = self.sp_cur.build(self.key_cur)
-        on.st.forward(state, self.qbar_cur, save=True, rowmap=sp1.rowmap)
-        ops.group_head_forward(on.h_frag(), sp1.rowmap, sp1.tile_key, on.wf, on.head.bias.detach(), self.N, on.H, False, self.z)
+        fused_forward_grouped(on.st, on.gh, state, sp1, self.z, scatter=False, save=True)
+        self._state = state
         gamma_exp = None
         if tr.use_seq_num_diff_as_time_diff:
             gamma_exp = tr._f32c(b.time_diff).reshape(-1)
@@ -189,20 +165,13 @@ class GroupedQR:
         return tr._loss
 
     def all_q_values(self) -> torch.Tensor:
-        """mean over quantiles of q_network(state), batch order (the trainer's logged `all_q_values`)"""
+        """q_network(state).mean(dim=2) [B, A] (the trainer's logged `all_q_values`): one more forward with the
+        per-action mean layer, run only when somebody asks (reporters, CPE)"""
         if self._all_q is None:
-            rm = self.sp_cur.rowmap.long()
-            out = torch.zeros(self._B + 1, self.A, device=rm.device)
-            out[torch.where(rm >= 0, rm, torch.full_like(rm, self._B))] = self.qbar_cur
-            self._all_q = out[: self._B]
+            self.online.st.forward(self._state, self.qbar_cur, save=False)
+            self._all_q = self.qbar_cur
         return self._all_q
 
     # the trainer's `_qs.backward(dq, xt, dw, db)` contract
     def backward(self, dq, xt, dw, db, **_):
-        on, sp = self.online, self.sp_cur
-        nl = len(dw) - 1
-        leaky = on.st.acts[nl - 1] == L.ACT["leaky_relu"]
-        ops.group_head_dgrad(dq, sp.tile_key, sp.tile_begin, self.A, on.wb, on.h_frag(), self.N, on.H, leaky, self.dz3,
-                             self.dzw_frag, self.db_part, db[nl])
-        ops.group_head_wgrad(self.dzw_frag, on.h_frag(), sp.tile_begin, self.A, self.N, on.H, self.splits, dw[nl], self.wg_ws)
-        fused_backward_trunk(on.st, self.dz3, dw[:nl], db[:nl])
+        fused_backward_grouped(self.online.st, self.online.gh, self.sp_cur, dq, dw, db, self.wg_ws, self.splits)

@@ -103,8 +103,22 @@ class QRDQNTrainer(QStepCore):
         if g is None:
             return super()._hip_forward(b)
         loss = g.forward(b)
-        self.all_q_values = g.all_q_values()  # [B, A] in batch order (logging / reporters)
+        from .reagent_lightning_module import _NoOpReporter
+
+        # q_network(state).mean(dim=2) is logging output only: with a reporter attached it is evaluated here, with the
+        # step's weights like the reference; otherwise on first read (one extra forward with the mean layer)
+        self._all_q_values = None if isinstance(self._reporter, _NoOpReporter) else g.all_q_values()
         return loss
+
+    @property
+    def all_q_values(self):
+        if getattr(self, "_all_q_values", None) is None and getattr(self, "_gq_active", None) is not None:
+            self._all_q_values = self._gq_active.all_q_values()
+        return getattr(self, "_all_q_values", None)
+
+    @all_q_values.setter
+    def all_q_values(self, v):
+        self._all_q_values = v
 
     def _needs_online_next(self) -> bool:
         return bool(self.maxq_learning and self.double_q_learning)

@@ -126,6 +126,7 @@ static inline unsigned perm_bytes(unsigned hi, unsigned lo, unsigned sel) {
 static inline int wave_uniform(int x) { return x; }
 // fibers are cooperative (one runs at a time), so an atomic is a plain read-modify-write
 static inline int atomicMax(int* addr, int v) { const int old = *addr; if (v > old) *addr = v; return old; }
+static inline int atomicAdd(int* addr, int v) { const int old = *addr; *addr = old + v; return old; }
 static inline float shfl_down(float v, int d) {
   int l = lane_id();
   return gather_from(v, (l + d < 64) ? l + d : l);

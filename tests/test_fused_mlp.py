@@ -58,6 +58,7 @@ def _rel(a, b):
     ([128, 256, 256, 8], ["relu", "relu", "linear"], 700),
     ([130, 256, 256, 70], ["leaky_relu", "tanh", "linear"], 129),
     ([40, 512, 512, 3], ["tanh", "relu", "linear"], 64),
+    ([64, 256, 256, 200], ["relu", "relu", "linear"], 140),  # 7 output column tiles: the pipelined output layer
 ])
 def test_fused_forward_backward_wgrad(backend, dims, acts, batch):
     dev = backend.device

@@ -168,12 +168,13 @@ def test_grouped_head_equals_dense_path(backend, rl, double_q):
     assert torch.isfinite(losses[0]).all()
 
 
-def test_grouped_space_layout():
+@pytest.mark.parametrize("B,G", [(1000, 5), (37, 3), (4096, 16)])
+def test_grouped_space_layout(backend, B, G):
     from reagent_amd.qr_engine import TILE, GroupedSpace
 
-    B, G = 1000, 5
     key = torch.randint(0, G + 1, (B,), generator=torch.Generator().manual_seed(0)).to(torch.int32)  # G = "no group"
-    sp = GroupedSpace(B, G, "cpu").build(key)
+    sp = GroupedSpace(B, G, backend.device).build(key.to(backend.device))
+    sp.rowmap, sp.tile_key, sp.tile_begin = sp.rowmap.cpu(), sp.tile_key.cpu(), sp.tile_begin.cpu()
     rm, tk, tb = sp.rowmap, sp.tile_key, sp.tile_begin
     assert rm.shape == (sp.n_tiles * TILE,) and tk.shape == (sp.n_tiles,) and tb.shape == (G + 1,)
     seen = rm[rm >= 0]
