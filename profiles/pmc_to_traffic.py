@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""PMC passes (gpu_pmc.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of bench.py, kernel trace
+only) -> profiles/traffic.json, the per-launch HBM bytes bench.py reports as `roofline.traffic`.
+
+Corrections as the guide prescribes (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): both counters are in KB;
+on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is.
+The file is stamped with the hash of the kernel sources it was measured on (bench.source_stamp()): bench.py reports
+the figure only while that hash matches what is running.
+
+usage: python profiles/pmc_to_traffic.py gpurun_out/pmc_<tag> <config> <precision> ["<where it came from>"]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def per_dispatch(pmc_dir, counter):
+    out = collections.defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(pmc_dir, "g*", "**", "*counter_collection.csv"), recursive=True)):
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+        rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+        for r in rows:
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("rg::", "").strip()
+            out[name].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    pmc_dir, config, prec = sys.argv[1], sys.argv[2], sys.argv[3]
+    where = sys.argv[4] if len(sys.argv) > 4 else pmc_dir
+    import bench
+
+    fetch, write = per_dispatch(pmc_dir, "FETCH_SIZE"), per_dispatch(pmc_dir, "WRITE_SIZE")
+    kernels, raw = {}, {}
+
+    def put(key, names, select=lambda i, n: True):
+        total_f = total_w = 0.0
+        for nm in names:
+            fs = [v for i, v in enumerate(fetch.get(nm, [])) if select(i, len(fetch[nm]))]
+            wsz = [v for i, v in enumerate(write.get(nm, [])) if select(i, len(write[nm]))]
+            if not fs or not wsz:
+                return
+            total_f += sum(fs) / len(fs)
+            total_w += sum(wsz) / len(wsz)
+        kernels[f"{config}:{prec}:{key}"] = int(round((2.0 * total_f + total_w) * 1024))
+        raw[key] = {"fetch_size_kb_raw": round(total_f, 1), "write_size_kb_raw": round(total_w, 1)}
+
+    fwd = [n for n in fetch if n.startswith("mlp_fwd_fused_kernel") or n.startswith("mlp_fwd_x3_kernel")]
+    bwd = [n for n in fetch if n.startswith("mlp_bwd_fused_kernel") or n.startswith("mlp_bwd_x3_kernel")]
+    # a DQN step launches the forward three times: next state online, next state target (save = 0), state (save = 1)
+    put("rg_mlp_forward_fused:save=0", fwd[:1], lambda i, n: i % 3 != 2)
+    put("rg_mlp_forward_fused:save=1", fwd[:1], lambda i, n: i % 3 == 2)
+    put("rg_mlp_backward_fused", bwd[:1])
+    put("rg_mlp_wgrad_fused", ["wgrad_group_kernel", "reduce_group_kernel"])
+    put("rg_replay_dqn_batch", [n for n in fetch if n.startswith("replay_dqn_batch_kernel")][:1])
+    put("rg_mlp_update_fused", [n for n in fetch if n.startswith("mlp_update_tiles_kernel")][:1])
+    put("rg_dqn_head", [n for n in fetch if n.startswith("dqn_head")][:1])
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    stamp = bench.source_stamp()
+    merged = dict(old.get("kernels", {})) if old.get("source_stamp") == stamp else {}
+    merged.update(kernels)
+    doc = {"source_stamp": stamp, "from": where,
+           "correction": "KB units; FETCH_SIZE x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section); "
+                         "hbm bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE",
+           "kernels": merged, "raw": {**(old.get("raw", {}) if old.get("source_stamp") == stamp else {}),
+                                      **{f"{config}:{prec}:{k}": v for k, v in raw.items()}}}
+    json.dump(doc, open(path, "w"), indent=1)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
