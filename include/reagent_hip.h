@@ -541,10 +541,10 @@ int rg_sac_critic_head(const float* q1, const float* q2, const float* q1_target,
 /* Actor segment, sac_trainer.py:254-280: loss = mean(alpha*clamp(log_prob,-2,2) - min(q1a, q2a));
  * outputs d loss / d log_prob, d loss / d q1a, d loss / d q2a, loss partials and partial sums of
  * (clamp(log_prob) + target_entropy) for the temperature segment (:311-320). */
-int rg_sac_actor_head(const float* log_prob, const float* q1_actor, const float* q2_actor,
-                      const double* alpha, double target_entropy, int batch, float* g_log_prob,
-                      float* dq1_actor, float* dq2_actor, float* loss_partials,
-                      float* entropy_partials, rg_stream_t stream);
+int rg_sac_actor_head(const float* log_prob, const float* q1_actor, const float* q2_actor, const double* alpha,
+                      double target_entropy, int batch, const float* v_cur, int crr_mode, double crr_p0,
+                      double crr_clamp, int backprop_log_prob, float* g_log_prob, float* dq1_actor,
+                      float* dq2_actor, float* loss_partials, float* entropy_partials, rg_stream_t stream);
 /* grad[0] = d alpha_loss / d log_alpha = -mean(clamp(log_prob) + target_entropy); alpha_loss
  * (nullable) = -(log_alpha * mean(...)).  fp64 like the reference's log_alpha (:124-126). */
 int rg_sac_alpha_grad(const float* entropy_partials, int batch, const double* log_alpha, double* grad,

@@ -157,17 +157,31 @@ def gen_qr(name, c):
 SAC_CASES = {
     "sac_twin": dict(state_dim=6, action_dim=2, sizes=[32, 24], activations=["relu", "relu"],
                      rl=dict(gamma=0.99, target_update_rate=0.05), lr=0.003, batch=40, steps=3),
+    # value network (target = V_target(s'), value segment), log_prob detached in the actor loss.  (With
+    # logged_action_uniform_prior=False AND the temperature optimizer the reference itself fails in backward — its value
+    # target turns fp64 through log_alpha.exp() — so that combination has no golden.)
+    "sac_value": dict(state_dim=6, action_dim=2, sizes=[32, 24], activations=["relu", "relu"],
+                      rl=dict(gamma=0.95, target_update_rate=0.1), lr=0.003, batch=40, steps=3, value=True,
+                      trainer_kw=dict(backprop_through_log_prob=False)),
+    # CRR actor weights exp(advantage / beta) clamped, uniform prior in the value target
+    "sac_crr": dict(state_dim=5, action_dim=3, sizes=[24, 24], activations=["relu", "tanh"],
+                    rl=dict(gamma=0.9, target_update_rate=0.1), lr=0.002, batch=48, steps=2, value=True,
+                    crr=dict(exponent_beta=0.7, exponent_clamp=3.0), trainer_kw={}),
 }
 
 
 def gen_sac(name, c):
-    tr = rh.build_sac(c["state_dim"], c["action_dim"], c["sizes"], c["activations"], c["rl"], c["lr"], seed=0)
+    tr = rh.build_sac(c["state_dim"], c["action_dim"], c["sizes"], c["activations"], c["rl"], c["lr"], seed=0,
+                      value=c.get("value", False), crr=c.get("crr"), **c.get("trainer_kw", {}))
     arrays = {}
     nets = dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network)
+    if c.get("value"):
+        nets["value"] = tr.value_network
     for n, m in nets.items():
         for i, p in enumerate(m.parameters()):
             arrays[f"init_{n}_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
+    loss_names = ["q1_loss", "q2_loss", "actor_loss", "alpha_loss"] + (["value_loss"] if c.get("value") else [])
     for s in range(c["steps"]):
         b = synthetic.policy_batch(c["batch"], c["state_dim"], c["action_dim"], seed=300 + s)
         for k, v in b.items():
@@ -175,18 +189,26 @@ def gen_sac(name, c):
         # the only RNG on the path: torch.randn_like in GaussianFullyConnectedActor.forward
         # (actor.py:217), called for next_state first, then for state.  Record the draws.
         torch.manual_seed(1000 + s)
-        arrays[f"step{s}_noise_next"] = _np(torch.randn(c["batch"], c["action_dim"]))
-        arrays[f"step{s}_noise_cur"] = _np(torch.randn(c["batch"], c["action_dim"]))
+        if c.get("value"):  # no actor(next_state) in the critic segment (:214-215): ONE draw per step, for actor(state)
+            arrays[f"step{s}_noise_cur"] = _np(torch.randn(c["batch"], c["action_dim"]))
+            arrays[f"step{s}_noise_next"] = np.zeros((c["batch"], c["action_dim"]), dtype=np.float32)
+        else:
+            arrays[f"step{s}_noise_next"] = _np(torch.randn(c["batch"], c["action_dim"]))
+            arrays[f"step{s}_noise_cur"] = _np(torch.randn(c["batch"], c["action_dim"]))
         torch.manual_seed(1000 + s)
         losses = loop.step(rh.policy_batch_to_reference(b))
-        for j, nm in enumerate(["q1_loss", "q2_loss", "actor_loss", "alpha_loss"]):
+        for j, nm in enumerate(loss_names):
             arrays[f"step{s}_{nm}"] = _np(losses[j])
         arrays[f"step{s}_log_alpha"] = _np(tr.log_alpha)
         for j, n in enumerate(["q1", "q2", "actor"]):  # optimizer order (sac_trainer.py:148-193)
             for i, gr in enumerate(loop.last_grads[j]):
                 _put(arrays, f"step{s}_grad_{n}_{i}", gr)
-        for n, m in dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network,
-                         q1_target=tr.q1_network_target, q2_target=tr.q2_network_target).items():
+        after = dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network)
+        if c.get("value"):  # a target value network instead of target critics (:108-112)
+            after.update(value=tr.value_network, value_target=tr.value_network_target)
+        else:
+            after.update(q1_target=tr.q1_network_target, q2_target=tr.q2_network_target)
+        for n, m in after.items():
             for i, p in enumerate(m.parameters()):
                 arrays[f"step{s}_{n}_{i}"] = _np(p)
     _save(name, c, arrays)

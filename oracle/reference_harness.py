@@ -139,16 +139,25 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
     return trainer
 
 
-def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, **trainer_kw):
+def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, value=False, crr=None, **trainer_kw):
+    """value=True adds a value network (FloatFeatureFullyConnected state -> 1, what the reference's value net builder
+    makes); crr = CRRWeightFn arguments."""
     _install()
     from reagent.models.actor import GaussianFullyConnectedActor
     from reagent.models.critic import FullyConnectedCritic
-    from reagent.training.sac_trainer import SACTrainer
+    from reagent.training.sac_trainer import CRRWeightFn, SACTrainer
 
     torch.manual_seed(seed)
     actor = GaussianFullyConnectedActor(state_dim, action_dim, sizes, activations)
     q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
     q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
+    if value:
+        from reagent.models.fully_connected_network import FloatFeatureFullyConnected
+
+        trainer_kw["value_network"] = FloatFeatureFullyConnected(state_dim, 1, sizes, activations)
+        trainer_kw["value_network_optimizer"] = make_adam(lr)
+    if crr is not None:
+        trainer_kw["crr_config"] = CRRWeightFn(**crr)
     return SACTrainer(actor, q1, q2, rl=make_rl_parameters(**rl_kwargs), q_network_optimizer=make_adam(lr),
                       actor_network_optimizer=make_adam(lr), alpha_optimizer=make_adam(lr), **trainer_kw)
 

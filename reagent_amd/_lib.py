@@ -199,7 +199,7 @@ SIGNATURES = {
                                            c_void_p, c_i64, c_void_p]),
     "rg_sac_partials": (c_int, [c_int]),
     "rg_sac_critic_head": (c_int, [c_void_p] * 7 + [c_d, c_void_p, c_int] + [c_void_p] * 5 + [c_void_p]),
-    "rg_sac_actor_head": (c_int, [c_void_p] * 4 + [c_d, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "rg_sac_actor_head": (c_int, [c_void_p] * 4 + [c_d, c_int, c_void_p, c_int, c_d, c_d, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rg_sac_alpha_grad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_adam_step_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d, c_d,
                                   c_void_p, c_void_p]),

@@ -20,6 +20,9 @@
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
 
 #include "rg_mlp_frag.h"
+#ifndef RG_WGRAD_TARGET
+#define RG_WGRAD_TARGET 128  // workgroups per layer of the grouped weight-gradient launch (splits = this / tiles)
+#endif
 
 namespace rg {
 
@@ -1017,7 +1020,7 @@ size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   size_t total = 0;
   for (int l = 0; l < d->n_layers; ++l) {
     const int terms = d->x3 ? 3 : 1;
-    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, 128 / terms);
+    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, RG_WGRAD_TARGET / terms);
     total += (size_t)p.splits * terms * p.slab;
   }
   return total * sizeof(float);
@@ -1041,7 +1044,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
       if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
       const int out_f = d->dims[l + 1], in_f = d->dims[l];
       const int terms = d->x3 ? 3 : 1;
-      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, 128 / terms);
+      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, RG_WGRAD_TARGET / terms);
       WgradFragArgs& g = G.layer[l];
       g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
       g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;

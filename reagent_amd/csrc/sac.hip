@@ -210,9 +210,14 @@ __global__ void sac_critic_head_kernel(const float* __restrict__ q1, const float
 // -> g_lp [B], dq1a / dq2a [B] (torch.minimum's backward: the smaller input takes the gradient,
 // ties are split), loss partials.  Also the temperature segment's input (:311-320):
 // ent_part = partial sums of (clamp(log_prob) + target_entropy).
+// Variants (sac_trainer.py:262-279): backprop_log_prob == 0 detaches log_prob in the actor loss (g_lp = 0);
+// crr_mode != 0 replaces the loss by -(clamp(log_prob) * w), w = CRRWeightFn(min(q1a, q2a) - V(s)) (:23-47):
+// 1 = indicator (advantage >= p0), 2 = exp(advantage / p0) clamped to [0, crr_clamp] when crr_clamp > 0; the
+// critics then receive no gradient.
 __global__ void sac_actor_head_kernel(const float* __restrict__ lp, const float* __restrict__ q1a,
                                       const float* __restrict__ q2a, const double* __restrict__ alpha,
-                                      float target_entropy, int batch, float* __restrict__ g_lp,
+                                      float target_entropy, int batch, const float* __restrict__ v_cur, int crr_mode,
+                                      float crr_p0, float crr_clamp, int backprop_log_prob, float* __restrict__ g_lp,
                                       float* __restrict__ dq1a, float* __restrict__ dq2a,
                                       float* __restrict__ loss_part, float* __restrict__ ent_part) {
   __shared__ float scratch[4];
@@ -221,7 +226,7 @@ __global__ void sac_actor_head_kernel(const float* __restrict__ lp, const float*
   if (b < batch) {
     const float raw = lp[b];
     const float c = clampf(raw, LOG_PROB_MIN, LOG_PROB_MAX);
-    const float inside = (raw >= LOG_PROB_MIN && raw <= LOG_PROB_MAX) ? 1.f : 0.f;
+    const float inside = (raw >= LOG_PROB_MIN && raw <= LOG_PROB_MAX && backprop_log_prob) ? 1.f : 0.f;
     const float a1 = q1a[b];
     float mq = a1, w1 = 1.f, w2 = 0.f;
     if (q2a) {
@@ -231,11 +236,26 @@ __global__ void sac_actor_head_kernel(const float* __restrict__ lp, const float*
       else if (a2 < a1) { w1 = 0.f; w2 = 1.f; }
     }
     const double al = alpha[0];
-    l = (float)(al * (double)c - (double)mq);
     const float invb = 1.f / (float)batch;
-    g_lp[b] = (float)al * inside * invb;
-    dq1a[b] = -w1 * invb;
-    if (dq2a) dq2a[b] = -w2 * invb;
+    if (crr_mode) {
+      const float adv = mq - v_cur[b];
+      float w;
+      if (crr_mode == 1) {
+        w = adv >= crr_p0 ? 1.f : 0.f;
+      } else {
+        w = expf(adv / crr_p0);
+        if (crr_clamp > 0.f) w = fminf(fmaxf(w, 0.f), crr_clamp);
+      }
+      l = -(c * w);
+      g_lp[b] = -w * inside * invb;
+      dq1a[b] = 0.f;
+      if (dq2a) dq2a[b] = 0.f;
+    } else {
+      l = (float)(al * (double)c - (double)mq);
+      g_lp[b] = (float)al * inside * invb;
+      dq1a[b] = -w1 * invb;
+      if (dq2a) dq2a[b] = -w2 * invb;
+    }
     e = c + target_entropy;
   }
   const float sl = block_sum(l, scratch);
@@ -374,15 +394,17 @@ int rg_sac_critic_head(const float* q1, const float* q2, const float* q1_target,
 }
 
 int rg_sac_actor_head(const float* log_prob, const float* q1_actor, const float* q2_actor, const double* alpha,
-                      double target_entropy, int batch, float* g_log_prob, float* dq1_actor, float* dq2_actor,
+                      double target_entropy, int batch, const float* v_cur, int crr_mode, double crr_p0, double crr_clamp,
+                      int backprop_log_prob, float* g_log_prob, float* dq1_actor, float* dq2_actor,
                       float* loss_partials, float* entropy_partials, rg_stream_t stream) {
   if (!log_prob || !q1_actor || !alpha || !g_log_prob || !dq1_actor || !loss_partials || !entropy_partials ||
       batch <= 0)
     return RG_EINVAL;
   if (q2_actor && !dq2_actor) return RG_EINVAL;
+  if (crr_mode < 0 || crr_mode > 2 || (crr_mode && (!v_cur || (crr_mode == 2 && crr_p0 <= 0.0)))) return RG_EINVAL;
   RG_LAUNCH(sac_actor_head_kernel, dim3(rg_sac_partials(batch)), dim3(SAC_THREADS), (hipStream_t)stream,
-            log_prob, q1_actor, q2_actor, alpha, (float)target_entropy, batch, g_log_prob, dq1_actor, dq2_actor,
-            loss_partials, entropy_partials);
+            log_prob, q1_actor, q2_actor, alpha, (float)target_entropy, batch, v_cur, crr_mode, (float)crr_p0,
+            (float)crr_clamp, backprop_log_prob, g_log_prob, dq1_actor, dq2_actor, loss_partials, entropy_partials);
   return (int)hipGetLastError();
 }
 

@@ -494,13 +494,17 @@ def sac_critic_head(q1, q2, q1t, q2t, lp_next, reward, not_terminal, gamma, alph
                                             L.stream_ptr()))
 
 
-def sac_actor_head(lp, q1a, q2a, alpha, target_entropy, g_lp, dq1a, dq2a, loss_part, ent_part):
-    _chk_dev(lp, q1a, q2a, alpha, g_lp, dq1a, dq2a, loss_part, ent_part)
+def sac_actor_head(lp, q1a, q2a, alpha, target_entropy, g_lp, dq1a, dq2a, loss_part, ent_part, v_cur=None, crr_mode=0,
+                   crr_p0=0.0, crr_clamp=0.0, backprop_log_prob=True):
+    """crr_mode 0: alpha * clamp(log_prob) - min q; 1 / 2: -(clamp(log_prob) * CRR weight of (min q - v_cur)), indicator
+    (threshold crr_p0) / exponent (beta crr_p0, clamp crr_clamp)"""
+    _chk_dev(lp, q1a, q2a, alpha, g_lp, dq1a, dq2a, loss_part, ent_part, v_cur)
     B = lp.numel()
     _run("rg_sac_actor_head", dict(B=B),
          lambda: L.lib().rg_sac_actor_head(L.ptr(lp), L.ptr(q1a), L.ptr(q2a), L.ptr(alpha), float(target_entropy),
-                                           B, L.ptr(g_lp), L.ptr(dq1a), L.ptr(dq2a), L.ptr(loss_part),
-                                           L.ptr(ent_part), L.stream_ptr()))
+                                           B, L.ptr(v_cur), int(crr_mode), float(crr_p0), float(crr_clamp),
+                                           int(bool(backprop_log_prob)), L.ptr(g_lp), L.ptr(dq1a), L.ptr(dq2a),
+                                           L.ptr(loss_part), L.ptr(ent_part), L.stream_ptr()))
 
 
 def sac_alpha_grad(ent_part, batch, log_alpha, grad, alpha_loss=None):

@@ -1,6 +1,6 @@
 """SACTrainer with the constructor / generator surface of reagent/training/sac_trainer.py:50-385
-(twin or single critic, no value network, temperature optimizer optional), executed on the HIP
-kernels.
+(twin or single critic, optional value network, CRR actor weights, detached log-prob, temperature optimizer
+optional; only the action-embedding KLD term is not built), executed on the HIP kernels.
 
 One step, in the reference's segment order (each segment = one optimizer under the
 Lightning-1.6 toggle, so other networks are constants inside it):
@@ -9,7 +9,12 @@ Lightning-1.6 toggle, so other networks are constants inside it):
   seg actor : (a_pi, log_prob) = actor(s); loss = mean(alpha*clamp(log_prob) - min(q1,q2)(s, a_pi)) with the
               UPDATED critics; the gradient reaches the actor through the critics' action input -> Adam(actor)
   seg alpha : loss = -mean(log_alpha * (clamp(log_prob) + target_entropy)); alpha = exp(log_alpha)   (fp64)
-  soft update of the target critics.
+  seg value : (value_network only) loss = mse(V(s), min(q1,q2)(s, a_pi) [- alpha*clamp(log_prob) unless
+              logged_action_uniform_prior]) -> Adam(value)                                            (:325-340)
+  soft update of the target critics (of the target value network when there is one, :177-191).
+With a value network the critics regress r + g*V_target(s')*not_done (:214-215) and there are no target critics;
+crr_config replaces the actor loss by -(clamp(log_prob) * w(min q - V(s))) (:265-273, CRRWeightFn :23-47);
+backprop_through_log_prob=False detaches log_prob in the actor loss (:262-263).
 Algorithmic FC work: 2 actor forwards + 1 actor backward, 6 critic forwards, 2 full critic backwards,
 2 input-gradient-only critic backwards (the reference additionally re-evaluates the actor FC inside
 get_log_prob: identical values, not repeated here).
@@ -30,6 +35,33 @@ from ..optimizer import Optimizer__Union, SoftUpdate
 from .dqn_trainer import dp_reduce, held_gradients, native_step, publish_gradients
 from .reagent_lightning_module import ReAgentLightningModule
 from .rl_trainer_pytorch import RLTrainerMixin
+
+
+class CRRWeightFn:
+    """sac_trainer.py:23-47: indicator (advantage >= threshold) or exp(advantage / beta) clamped to [0, exponent_clamp]"""
+
+    def __init__(self, indicator_fn_threshold: Optional[float] = None, exponent_beta: Optional[float] = None,
+                 exponent_clamp: Optional[float] = None):
+        assert exponent_beta or indicator_fn_threshold
+        assert not (exponent_beta and indicator_fn_threshold)
+        if exponent_beta:
+            assert exponent_beta > 1e-6
+        if exponent_clamp:
+            assert exponent_clamp > 1e-6
+        self.indicator_fn_threshold, self.exponent_beta, self.exponent_clamp = indicator_fn_threshold, exponent_beta, exponent_clamp
+
+    def get_weight_from_advantage(self, advantage):
+        if self.indicator_fn_threshold:
+            return (advantage >= self.indicator_fn_threshold).float()
+        exp = torch.exp(advantage / self.exponent_beta)
+        if self.exponent_clamp:
+            exp = torch.clamp(exp, 0.0, self.exponent_clamp)
+        return exp
+
+    def kernel_args(self):
+        if self.indicator_fn_threshold:
+            return 1, float(self.indicator_fn_threshold), 0.0
+        return 2, float(self.exponent_beta), float(self.exponent_clamp or 0.0)
 
 
 class _SegmentLoss(torch.autograd.Function):
@@ -144,21 +176,21 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         backprop_through_log_prob: bool = True,
     ) -> None:
         super().__init__()
-        if value_network is not None or crr_config is not None:
-            raise NotImplementedError("the value-network / CRR variants are not on the MI355X hot path (BASELINE C4)")
         if action_embedding_kld_weight:
             raise NotImplementedError("the action-embedding KLD term needs batch statistics (SURVEY.md §8e): not built")
-        if not backprop_through_log_prob:
-            raise NotImplementedError("backprop_through_log_prob=False is a legacy switch, not built")
         self.rl_parameters = rl if rl is not None else RLParameters()
         d = Optimizer__Union.default
         self.q1_network = q1_network
         self.q2_network = q2_network
         self.q_network_optimizer = q_network_optimizer if q_network_optimizer is not None else d()
-        self.value_network = None
+        self.value_network = value_network
         self.value_network_optimizer = value_network_optimizer if value_network_optimizer is not None else d()
-        self.q1_network_target = copy.deepcopy(self.q1_network)
-        self.q2_network_target = copy.deepcopy(self.q2_network)
+        if self.value_network is not None:  # sac_trainer.py:108-112: a target value network INSTEAD of target critics
+            self.value_network_target = copy.deepcopy(self.value_network)
+            self.q1_network_target = self.q2_network_target = None
+        else:
+            self.q1_network_target = copy.deepcopy(self.q1_network)
+            self.q2_network_target = copy.deepcopy(self.q2_network)
         self.actor_network = actor_network
         self.actor_network_optimizer = actor_network_optimizer if actor_network_optimizer is not None else d()
         self.entropy_temperature = entropy_temperature
@@ -170,7 +202,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             self.target_entropy = target_entropy
         self.logged_action_uniform_prior = logged_action_uniform_prior
         self.add_kld_to_loss = False
-        self.crr_config = None
+        self.crr_config = crr_config
+        if crr_config:
+            assert self.value_network is not None
         self.backprop_through_log_prob = backprop_through_log_prob
         self.minibatch_size = minibatch_size
         self._ws_batch = -1
@@ -188,11 +222,16 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             optimizers.append({"optimizer": AdamF64([self.log_alpha], lr=cfg.lr, betas=tuple(cfg.betas), eps=cfg.eps,
                                                     weight_decay=cfg.weight_decay,
                                                     alpha_out=lambda: self._alpha(self.log_alpha.device))})
-        target_params = list(self.q1_network_target.parameters())
-        source_params = list(self.q1_network.parameters())
-        if self.q2_network:
-            target_params += list(self.q2_network_target.parameters())
-            source_params += list(self.q2_network.parameters())
+        if self.value_network is not None:
+            optimizers.append(self.value_network_optimizer.make_optimizer_scheduler(self.value_network.parameters()))
+            target_params = list(self.value_network_target.parameters())
+            source_params = list(self.value_network.parameters())
+        else:
+            target_params = list(self.q1_network_target.parameters())
+            source_params = list(self.q1_network.parameters())
+            if self.q2_network:
+                target_params += list(self.q2_network_target.parameters())
+                source_params += list(self.q2_network.parameters())
         optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
         return optimizers
 
@@ -215,8 +254,10 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
 
     def _engine(self, B, dev, S, A):
         self._e = {k: self._net_engine(n) for k, n in dict(actor=self.actor_network, q1=self.q1_network,
-                                                           q2=self.q2_network).items() if n is not None}
-        self._t = {k: n.fc.stack() for k, n in dict(q1=self.q1_network_target, q2=self.q2_network_target).items()
+                                                           q2=self.q2_network, value=self.value_network).items()
+                   if n is not None}
+        self._t = {k: n.fc.stack() for k, n in dict(q1=self.q1_network_target, q2=self.q2_network_target,
+                                                    value=getattr(self, "value_network_target", None)).items()
                    if n is not None}
         for k in ("q1", "q2"):
             if k in self._e:
@@ -226,7 +267,8 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         # cat(state, action) is read in place by the fused kernels as two K-panels (critic.py:79-92) when every
         # critic stack runs on them; the per-layer GEMM engine takes the assembled [B, S + A] matrix
         self._panels = S % 32 == 0 and all(isinstance(st, FusedMLP) for st in
-                                          [self._e[k]["stack"] for k in ("q1", "q2") if k in self._e] + list(self._t.values()))
+                                          [self._e[k]["stack"] for k in ("q1", "q2") if k in self._e]
+                                          + [st for k, st in self._t.items() if k != "value"])
         if self._ws_batch != B or self._x.device != dev:
             f = dict(dtype=torch.float32, device=dev)
             P = ops.sac_partials(B)
@@ -234,7 +276,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             self._x, self._xn, self._xa = (torch.empty(*cat_shape, **f) for _ in range(3))
             self._ls, self._lsn, self._dls = (torch.empty(B, 2 * A, **f) for _ in range(3))
             self._lp, self._lpn = torch.empty(B, **f), torch.empty(B, **f)
-            names = ["q1v", "q2v", "q1t", "q2t", "q1a", "q2a", "dq1", "dq2", "dq1a", "dq2a", "y", "glp"]
+            names = ["q1v", "q2v", "q1t", "q2t", "q1a", "q2a", "dq1", "dq2", "dq1a", "dq2a", "y", "glp", "vcur", "vval", "dv", "yv"]
             for n in names:
                 setattr(self, "_" + n, torch.empty(B, 1, **f))
             self._dx1, self._dx2 = torch.empty(*cat_shape, **f), torch.empty(*cat_shape, **f)
@@ -242,8 +284,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             # two-panel critic input (fused kernels): the actor's actions and the action part of dQ/dx on their own
             self._an, self._api = torch.empty(B, A, **f), torch.empty(B, A, **f)
             self._dxa1, self._dxa2 = torch.empty(B, A, **f), torch.empty(B, A, **f)
-            self._parts = {n: torch.empty(P, **f) for n in ("l1", "l2", "la", "ent")}
-            self._losses = {n: torch.empty(1, **f) for n in ("q1", "q2", "actor")}
+            self._parts = {n: torch.empty(P, **f) for n in ("l1", "l2", "la", "ent", "lv")}
+            self._losses = {n: torch.empty(1, **f) for n in ("q1", "q2", "actor", "value")}
+            self._zeros, self._ones = torch.zeros(B, **f), torch.ones(B, **f)
             self._alpha_grad = torch.zeros(1, dtype=torch.float64, device=dev)
             self._alpha_loss = torch.zeros(1, dtype=torch.float64, device=dev)
             self._ws_batch = B
@@ -274,11 +317,35 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             t[k].stage_weights(need_transposed=False)
         alpha = self._alpha(dev)
         act = e["actor"]["stack"]
+        q1s = e["q1"]["stack"]
+        has_q2 = "q2" in e
+        if "value" in t:  # next_state_value = value_network_target(next_state), no entropy term (:214-215)
+            xn_v, _ = t["value"].stage_input(next_state, need_transposed=False)
+            t["value"].forward(xn_v, self._q1t, save=False)
+            if self._panels:
+                self._x_t = None
+                q1s.forward(state, self._q1v, save=True, x2=action)
+                if has_q2:
+                    e["q2"]["stack"].forward(state, self._q2v, save=True, x2=action)
+            else:
+                self._x[:, :S].copy_(state)
+                self._x[:, S:].copy_(action)
+                x_c, self._x_t = q1s.stage_input(self._x, need_transposed=True)
+                q1s.forward(x_c, self._q1v, save=True)
+                if has_q2:
+                    e["q2"]["stack"].forward(x_c, self._q2v, save=True)
+            ops.sac_critic_head(self._q1v, self._q2v if has_q2 else None, self._q1t, None, self._zeros,
+                                self._f32c(b.reward).reshape(-1), self._f32c(b.not_terminal).reshape(-1), self.gamma, alpha,
+                                self._y, self._dq1, self._dq2 if has_q2 else None, self._parts["l1"],
+                                self._parts["l2"] if has_q2 else None)
+            P = self._parts["l1"].numel()
+            ops.reduce_sum(self._parts["l1"], P, 1.0 / B, self._losses["q1"])
+            if has_q2:
+                ops.reduce_sum(self._parts["l2"], P, 1.0 / B, self._losses["q2"])
+            return
         # a' = actor(s'), log_prob'  (actor frozen in this segment)
         xn_s, _ = act.stage_input(next_state, need_transposed=False)
         act.forward(xn_s, self._lsn, save=False)
-        q1s = e["q1"]["stack"]
-        has_q2 = "q2" in e
         if self._panels:
             ops.gaussian_head_forward(self._lsn, noise_next, self._an, self._lpn, None)
             t["q1"].forward(next_state, self._q1t, save=False, x2=self._an)
@@ -346,9 +413,18 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             q1s.forward(xa_c, self._q1a, save=True)
             if has_q2:
                 e["q2"]["stack"].forward(xa_c, self._q2a, save=True)
+        crr_mode, crr_p0, crr_clamp, v_cur = 0, 0.0, 0.0, None
+        if self.crr_config is not None:  # advantage = min q - V(state), both detached (:265-268)
+            vs = e["value"]["stack"]
+            vs.stage_weights(need_transposed=True)
+            xv, _ = vs.stage_input(state, need_transposed=False)
+            vs.forward(xv, self._vcur, save=False)
+            crr_mode, crr_p0, crr_clamp = self.crr_config.kernel_args()
+            v_cur = self._vcur
         ops.sac_actor_head(self._lp, self._q1a, self._q2a if has_q2 else None, self._alpha(dev),
                            self.target_entropy, self._glp, self._dq1a, self._dq2a if has_q2 else None,
-                           self._parts["la"], self._parts["ent"])
+                           self._parts["la"], self._parts["ent"], v_cur=v_cur, crr_mode=crr_mode, crr_p0=crr_p0,
+                           crr_clamp=crr_clamp, backprop_log_prob=self.backprop_through_log_prob)
         ops.reduce_sum(self._parts["la"], self._parts["la"].numel(), 1.0 / B, self._losses["actor"])
 
     def _actor_backward(self, grad_out=None):
@@ -378,6 +454,27 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             self.log_alpha.grad = g.clone()
         else:
             self.log_alpha.grad.add_(g)
+
+    # value segment (:325-340): V(s) regressed on min q (s, a_pi) [- alpha * clamp(log_prob)] — the critic head's
+    # arithmetic with reward 0, discount 1, not_terminal 1 and (q1a, q2a) in the place of the target critics
+    def _value_forward(self, b):
+        state = self._f32c(b.state.float_features)
+        vs = self._e["value"]["stack"]
+        vs.stage_weights(need_transposed=True)
+        xv, self._xv_t = vs.stage_input(state, need_transposed=True)
+        vs.forward(xv, self._vval, save=True)
+        has_q2 = "q2" in self._e
+        lp = self._zeros if self.logged_action_uniform_prior else self._lp
+        ops.sac_critic_head(self._vval, None, self._q1a, self._q2a if has_q2 else None, lp, self._zeros, self._ones, 1.0,
+                            self._alpha(state.device), self._yv, self._dv, None, self._parts["lv"], None)
+        ops.reduce_sum(self._parts["lv"], self._parts["lv"].numel(), 1.0 / self._B, self._losses["value"])
+
+    def _value_backward(self, grad_out=None):
+        e = self._e["value"]
+        dv = self._dv if grad_out is None else self._dv * grad_out
+        held = held_gradients(e["slab"], e["params"])
+        e["stack"].backward(dv, self._xv_t, e["dw"], e["db"])
+        self._publish(e, held)
 
     def _noise(self, B, A, dev, given):
         if given is not None:
@@ -410,6 +507,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             ops.sac_alpha_grad(self._parts["ent"], self._B, self.log_alpha.data, self._alpha_grad, self._alpha_loss)
             yield _SegmentLoss.apply(self._alpha_backward, self._alpha_loss, self.log_alpha)
             self.entropy_temperature = self._alpha(dev)  # = exp(log_alpha), written by AdamF64.step (:322)
+        if self.value_network is not None:
+            self._value_forward(b)
+            yield _SegmentLoss.apply(self._value_backward, self._losses["value"], *self._e["value"]["params"])
         yield self.soft_update_result()
 
     # ---- fused native step ---------------------------------------------------------------------------
@@ -460,7 +560,18 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                 self.log_alpha.grad.mul_(gs)
             next(it).step()
             self.entropy_temperature = self._alpha(dev)
+        if self.value_network is not None:
+            self._value_forward(b)
+            for p in self._e["value"]["params"]:
+                p.grad = None
+            self._value_backward()
+            o = next(it)
+            o.grad_scale = gs
+            o.step()
         next(it).step()  # soft update
         self.all_batches_processed += 1
-        return dict(q1_loss=self._losses["q1"], q2_loss=self._losses["q2"], actor_loss=self._losses["actor"],
-                    alpha_loss=self._alpha_loss)
+        out = dict(q1_loss=self._losses["q1"], q2_loss=self._losses["q2"], actor_loss=self._losses["actor"],
+                   alpha_loss=self._alpha_loss)
+        if self.value_network is not None:
+            out["value_loss"] = self._losses["value"]
+        return out
