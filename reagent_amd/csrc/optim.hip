@@ -81,7 +81,7 @@ int rg_soft_update(float* target, const float* source, int64_t n, double tau, rg
   return (int)hipGetLastError();
 }
 
-int rg_abi_version(void) { return 1; }
+int rg_abi_version(void) { return 2; }  /* 2: rg_mlp_desc grew (x3, panels, rowmap, grouped output layer), _sched and grouped-QR entry points */
 
 const char* rg_strerror(int code) {
   switch (code) {
