@@ -16,6 +16,11 @@ __device__ __forceinline__ f32x16 mfma(u16x8 a, u16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// accumulators pinned to AccVGPRs (a[...]) instead of wherever the register allocator puts them (arch VGPRs here)
+__device__ __forceinline__ void mfma_acc(u16x8 a, u16x8 b, f32x16& c) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 constexpr int PITCH = 520, KC = 32;
 
 // MODE bit 0: A fragments from LDS each chunk; bit 1: B fragments from global each chunk; bit 2: rotate K per (wg, wave)
@@ -49,7 +54,12 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) feed(const unsigned short* __r
   };
   // MODE bit 3: every MFMA reads the SAME two operand registers (random data); bit 4: tn-major issue order
   auto mma = [&](int sa, int sb) {
-    if (MODE & 8) {
+    if (MODE & 32) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) mfma_acc(a[sa][tm], b[sb][tn], acc[tm][tn]);
+    } else if (MODE & 8) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -127,6 +137,9 @@ int main() {
   hipMemcpy(wf, h.data(), n * 2, hipMemcpyHostToDevice);
   const int lds128 = 128 * PITCH * 2, lds64 = 64 * PITCH * 2;
   run<0, 8, 4, 2>("registers only (random operands)", wf, out, 512, lds128);
+  run<32, 8, 4, 2>("registers only, accumulators in AccVGPRs", wf, out, 512, lds128);
+  run<34, 8, 4, 2, 2>("B from L2 ring 2, accumulators in AccVGPRs", wf, out, 512, lds128);
+  run<35, 8, 4, 2, 2>("A from LDS + B from L2 ring 2, accumulators in AccVGPRs", wf, out, 512, lds128);
   run<8, 8, 4, 2>("registers only, ONE operand pair for every MFMA (random data)", wf, out, 512, lds128);
   run<16, 8, 4, 2>("registers only, tn-major issue order", wf, out, 512, lds128);
   run<0, 4, 4, 2>("registers only, 4 waves (1 per SIMD)", wf, out, 512, lds128);
