@@ -186,7 +186,9 @@ struct CompactHeadArgs {
 };
 
 // One workgroup of 256 threads per row.  (Four rows per 832-thread workgroup — N = 200 fills 3.1 waves, four rows
-// 12.5 of 13 — measured 0.68 ms against 0.46 ms: the T reads stop being workgroup-uniform broadcasts.)
+// 12.5 of 13 — measured 0.68 ms against 0.46 ms: the T reads stop being workgroup-uniform broadcasts.  The pair
+// loop written on float2 so that the compiler emits v_pk_add / v_pk_mul / v_pk_fma_f32 for five of its eight
+// operations measured 0.58 ms: no gain from packed fp32 here.)
 constexpr int QC_MAX_N = 1024;
 
 __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
