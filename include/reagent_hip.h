@@ -453,7 +453,8 @@ int rg_c51_head(const float* q, const float* qn_online, const float* qn_target, 
  * rg_qr_compact_head     : quantile-Huber loss (:143-160, :217-218) of z [grouped rows] against
  *                          T = reward (+ boost of the group's action) + gamma^e * not_terminal * zt[rowmap[r], :];
  *                          dz [padded_rows, lddz] (padding rows and columns zero), loss_partials [padded_rows];
- *                          tile_losses (nullable) [padded_rows / 128] = their sums per 128-row tile.
+ *                          tile_losses (nullable) [padded_rows / 128] = their sums per 128-row tile.  num_atoms <= 256.
+ *                          O(N log N) per row (sorted targets + prefix sums), not the N x N pair loop.
  * rg_group_head_wgrad    : dw [n_groups * group_rows, in] = per group dz^T h over the group's rows. */
 /* rg_group_rows: the grouped space of `key` [batch] int32 in [0, n_groups] (n_groups = "no group": dropped) — a
  * stable counting sort (rows keep batch order inside a group), n_tiles >= ceil(batch / 128) + n_groups. */

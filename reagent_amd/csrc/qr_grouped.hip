@@ -16,7 +16,7 @@
 //     becomes the fused stack's OUTPUT layer with per-tile weights (rg_mlp_desc.tile_key: forward and input
 //     gradient inside rg_mlp_forward_fused / rg_mlp_backward_fused), its weight gradient is rg_group_head_wgrad —
 //     1/A of the dense work, [B, N] instead of [B, A * N] bytes.
-// The quantile-Huber loss itself (rg_qr_compact_head) is the N x N pair loop of rg_qr_head on those compact rows.
+// The quantile-Huber loss itself (rg_qr_compact_head) runs on those compact rows — in O(N log N) per row, see there.
 #include "rg_mlp_frag.h"
 
 namespace rg {
@@ -185,73 +185,146 @@ struct CompactHeadArgs {
   float* loss_partials;
 };
 
-// One workgroup of 256 threads per row.  (Four rows per 832-thread workgroup — N = 200 fills 3.1 waves, four rows
-// 12.5 of 13 — measured 0.68 ms against 0.46 ms: the T reads stop being workgroup-uniform broadcasts.  The pair
-// loop written on float2 so that the compiler emits v_pk_add / v_pk_mul / v_pk_fma_f32 for five of its eight
-// operations measured 0.58 ms: no gain from packed fp32 here.)
-constexpr int QC_MAX_N = 1024;
+// One workgroup of 256 threads per row, and NOT the N x N pair loop: for a fixed C_j the pairs fall into four
+// ranges of T_i - C_j — (-inf, -1], (-1, 0), [0, 1), [1, inf) — on each of which huber(td) * weight is a polynomial
+// in T_i of degree <= 2 with coefficients that depend on C_j and tau_j only:
+//     td <= -1 : (1 - tau) (C - 1/2 - T)        -1 < td < 0 : (1 - tau) (T - C)^2 / 2
+//     0 <= td < 1 : tau (T - C)^2 / 2            td >= 1     : tau (T - C - 1/2)
+// So the row's T is sorted once (bitonic, in LDS), prefix sums of T and T^2 are taken over the sorted order (fp64:
+// the range sums are differences of prefixes), and every j needs three binary searches and a handful of operations:
+// O(N log N) per row instead of O(N^2) — 2.6e9 pairs per 65536-row batch at N = 200 made the pair loop the largest
+// kernel of the C3 step (0.46 ms, VALU-bound).  Values agree with the pair loop to fp32 rounding (the sum is taken
+// in a different order; at td = +-1 and td = 0 the neighbouring polynomials and their derivatives coincide, so the
+// side a boundary element is counted on does not matter).
+// One WAVE per row (four rows per 256-thread workgroup) and no workgroup barrier anywhere: a lane holds four of the
+// row's (padded) 256 targets, the bitonic network exchanges across lanes by shuffles and inside a lane in registers,
+// the sorted targets and their prefix sums go to the wave's own slice of LDS (the binary searches need random access).
+constexpr int QC_MAX_N = 256, QC_WAVES = 4;
 
 __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
-  __shared__ __attribute__((aligned(16))) float T[QC_MAX_N];
-  __shared__ float C[QC_MAX_N];
-  __shared__ float wsum[4];
-  const int r = blockIdx.x, tid = threadIdx.x, N = a.N;
+  __shared__ float Ts[QC_WAVES][QC_MAX_N];
+  __shared__ double P1[QC_WAVES][QC_MAX_N + 1], P2[QC_WAVES][QC_MAX_N + 1];
+  __shared__ double L1[QC_WAVES][64], L2[QC_WAVES][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = a.N;
+  const int r = blockIdx.x * QC_WAVES + wv;
   const int b = a.rowmap[r];
   float* dz = a.dz + (long)r * a.lddz;
-  if (b < 0) {
-    for (int j = tid; j < a.lddz; j += 256) dz[j] = 0.f;
-    if (tid == 0) a.loss_partials[r] = 0.f;
+  if (b < 0) {  // wave-uniform
+    for (int j = lane; j < a.lddz; j += 64) dz[j] = 0.f;
+    if (lane == 0) a.loss_partials[r] = 0.f;
     return;
   }
   const int g = a.tile_key[r >> 7];
   const float rew = a.reward[b] + (a.reward_boosts ? a.reward_boosts[g] : 0.f);
   const float disc = a.gamma_exponent ? powf(a.gamma, a.gamma_exponent[b]) : a.gamma;
   const float dn = disc * a.not_terminal[b];
-  for (int j = tid; j < N; j += 256) {
-    T[j] = rew + dn * a.zt[(long)b * a.ldzt + j];
-    C[j] = a.z[(long)r * a.ldz + j];
-  }
-  __syncthreads();
-  const float inv = 1.f / ((float)N * (float)a.batch * (float)N);
-  float loss = 0.f;
-  // per pair, with td = T_i - C_j and c = clamp(td, -1, 1):
-  //   huber(td) = c * (td - c / 2)   (= td^2 / 2 inside [-1, 1], |td| - 1/2 outside),   huber'(td) = c,
-  //   weight |tau_j - 1{td < 0}| = td < 0 ? 1 - tau_j : tau_j
-  // eight VALU operations per pair; the N x N pairs of the batch are the whole cost of this kernel
-  const int N4 = N & ~3;
-  for (int j = tid; j < a.lddz; j += 256) {
-    float gsum = 0.f;
-    if (j < N) {
-      const float cj = C[j], tau = a.quantiles[j], omt = 1.f - tau;
-      float l = 0.f;
-      int i = 0;
-      for (; i < N4; i += 4) {
-        const f32x4 t4 = *(const f32x4*)&T[i];
+  float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float td = t4[u] - cj;
-          const float c = fminf(fmaxf(td, -1.f), 1.f);
-          const float w = td < 0.f ? omt : tau;
-          l = fmaf(c * fmaf(-0.5f, c, td), w, l);
-          gsum = fmaf(c, w, gsum);
+  for (int k = 0; k < 4; ++k) {
+    const int e = lane * 4 + k;
+    v[k] = e < N ? rew + dn * a.zt[(long)b * a.ldzt + e] : __builtin_inff();
+  }
+  // bitonic sort, ascending, element index e = 4 * lane + k
+  for (int K = 2; K <= QC_MAX_N; K <<= 1)
+    for (int j = K >> 1; j > 0; j >>= 1) {
+      if (j >= 4) {
+        const int lm = j >> 2;
+        const bool lower = (lane & lm) == 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float other = shfl_xor(v[k], lm);
+          const bool up = ((lane * 4 + k) & K) == 0;
+          v[k] = (lower == up) ? fminf(v[k], other) : fmaxf(v[k], other);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = k ^ j;
+          if (q > k) {
+            const bool up = ((lane * 4 + k) & K) == 0;
+            const float lo = fminf(v[k], v[q]), hi = fmaxf(v[k], v[q]);
+            v[k] = up ? lo : hi;
+            v[q] = up ? hi : lo;
+          }
         }
       }
-      for (; i < N; ++i) {
-        const float td = T[i] - cj;
-        const float c = fminf(fmaxf(td, -1.f), 1.f);
-        const float w = td < 0.f ? omt : tau;
-        l = fmaf(c * fmaf(-0.5f, c, td), w, l);
-        gsum = fmaf(c, w, gsum);
-      }
-      loss += l;
+    }
+  // exclusive prefix sums of T and T^2 in sorted order (fp64; the +inf padding counts as 0)
+  double t1[4], t2[4], s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double t = (lane * 4 + k) < N ? (double)v[k] : 0.0;
+    t1[k] = s1;  // exclusive within the lane
+    t2[k] = s2;
+    s1 += t;
+    s2 += t * t;
+  }
+  L1[wv][lane] = s1;
+  L2[wv][lane] = s2;
+  wave_lds_sync();
+  for (int off = 1; off < 64; off <<= 1) {  // inclusive scan of the lane totals within the wave
+    double a1 = 0.0, a2 = 0.0;
+    if (lane >= off) {
+      a1 = L1[wv][lane - off];
+      a2 = L2[wv][lane - off];
+    }
+    wave_lds_sync();
+    if (lane >= off) {
+      L1[wv][lane] += a1;
+      L2[wv][lane] += a2;
+    }
+    wave_lds_sync();
+  }
+  const double base1 = L1[wv][lane] - s1, base2 = L2[wv][lane] - s2;  // totals of the lanes before this one
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = lane * 4 + k;
+    Ts[wv][e] = v[k];
+    P1[wv][e] = base1 + t1[k];
+    P2[wv][e] = base2 + t2[k];
+  }
+  if (lane == 63) {
+    P1[wv][QC_MAX_N] = L1[wv][63];
+    P2[wv][QC_MAX_N] = L2[wv][63];
+  }
+  wave_lds_sync();
+  const float* T = Ts[wv];
+  const double* Q1 = P1[wv];
+  const double* Q2 = P2[wv];
+  const float inv = 1.f / ((float)N * (float)a.batch * (float)N);
+  float loss = 0.f;
+  for (int j = lane; j < a.lddz; j += 64) {
+    float gsum = 0.f;
+    if (j < N) {
+      const float c = a.z[(long)r * a.ldz + j], tau = a.quantiles[j];
+      // number of sorted targets that are <= x (upper) / < x (lower): binary search over T[0 .. N)
+      auto count = [&](float x, bool upper) {
+        int lo = 0, hi = N;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const float tv = T[mid];
+          if (upper ? tv <= x : tv < x) lo = mid + 1;
+          else hi = mid;
+        }
+        return lo;
+      };
+      const int p1 = count(c - 1.f, true), p2 = count(c, false), p3 = count(c + 1.f, false);
+      const double cd = (double)c, omt = 1.0 - (double)tau, td_ = (double)tau;
+      const double n1 = p1, n2 = p2 - p1, n3 = p3 - p2, n4 = N - p3;
+      const double s1_1 = Q1[p1], s1_2 = Q1[p2] - Q1[p1], s1_3 = Q1[p3] - Q1[p2], s1_4 = Q1[N] - Q1[p3];
+      const double s2_2 = Q2[p2] - Q2[p1], s2_3 = Q2[p3] - Q2[p2];
+      const double l = omt * (n1 * (cd - 0.5) - s1_1) + omt * 0.5 * (s2_2 - 2.0 * cd * s1_2 + n2 * cd * cd) +
+                       td_ * 0.5 * (s2_3 - 2.0 * cd * s1_3 + n3 * cd * cd) + td_ * (s1_4 - n4 * (cd + 0.5));
+      // sum_i huber'(T_i - C) * weight:  -1, (T - C), (T - C), +1 on the four ranges
+      const double gs = -omt * n1 + omt * (s1_2 - n2 * cd) + td_ * (s1_3 - n3 * cd) + td_ * n4;
+      loss += (float)l;
+      gsum = (float)gs;
     }
     dz[j] = -gsum * inv;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) loss += shfl_xor(loss, off);
-  if ((tid & 63) == 0) wsum[tid >> 6] = loss;
-  __syncthreads();
-  if (tid == 0) a.loss_partials[r] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv;
+  if (lane == 0) a.loss_partials[r] = loss * inv;
 }
 
 // tile_sums[t] = sum of loss_partials[128 t .. 128 t + 127] (row order), so that the final deterministic single-
@@ -353,7 +426,7 @@ int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldz
   a.z = z; a.zt = zt; a.ldz = ldz; a.ldzt = ldzt; a.rowmap = rowmap; a.tile_key = tile_key; a.reward = reward;
   a.reward_boosts = reward_boosts; a.not_terminal = not_terminal; a.gamma_exponent = gamma_exponent; a.quantiles = quantiles;
   a.gamma = (float)gamma; a.batch = batch; a.N = num_atoms; a.dz = dz; a.lddz = lddz; a.loss_partials = loss_partials;
-  RG_LAUNCH(qr_compact_head_kernel, dim3(padded_rows), dim3(256), (hipStream_t)stream, a);
+  RG_LAUNCH(qr_compact_head_kernel, dim3(padded_rows / QC_WAVES), dim3(QC_WAVES * 64), (hipStream_t)stream, a);
   int rc = (int)hipGetLastError();
   if (rc || !tile_losses) return rc;
   RG_LAUNCH(tile_sum_kernel, dim3(padded_rows / 128), dim3(128), (hipStream_t)stream, (const float*)loss_partials, tile_losses);

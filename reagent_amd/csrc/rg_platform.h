@@ -60,6 +60,14 @@ __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, s
 __device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 64); }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// LDS hand-off between the lanes of ONE wave: the wave's earlier ds_writes are complete and visible to its later
+// ds_reads (the lanes run in lockstep and LDS operations of a wave retire in order; this pins the compiler and
+// drains the counter).  No s_barrier: other waves are not involved.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // value the optimiser must treat as unknown here: keeps address arithmetic that depends on it from
 // being hoisted out of an enclosing loop and parked in VGPRs across an MFMA main loop

@@ -126,6 +126,8 @@ static inline unsigned perm_bytes(unsigned hi, unsigned lo, unsigned sel) {
 static inline int wave_uniform(int x) { return x; }
 // fibers are cooperative (one runs at a time), so an atomic is a plain read-modify-write
 static inline int atomicMax(int* addr, int v) { const int old = *addr; if (v > old) *addr = v; return old; }
+// lanes are fibers here: a wave-level gather is the point where all lanes of the wave have run up to
+static inline void wave_lds_sync() { int x = 0; (void)::emu::wave_gather(&x, sizeof(x)); }
 static inline int atomicAdd(int* addr, int v) { const int old = *addr; *addr = old + v; return old; }
 static inline float shfl_down(float v, int d) {
   int l = lane_id();

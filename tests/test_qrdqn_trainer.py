@@ -188,3 +188,53 @@ def test_grouped_space_layout(backend, B, G):
             assert tb[tk[t]] <= t < tb[tk[t] + 1] and (key[rows.long()] == tk[t]).all()
             if rows.numel() > 1:  # batch order inside a group: deterministic
                 assert (rows[1:] > rows[:-1]).all()
+
+
+def test_compact_head_against_the_pair_loop(backend):
+    """rg_qr_compact_head (sorted targets + prefix sums, O(N log N) per row) == the N x N pair loop of
+    qrdqn_trainer.py:143-160 evaluated in float64 — values chosen so that T_i - C_j hits -1, 0 and 1 exactly and
+    repeats, where the ranges of the closed form meet."""
+    from reagent_amd import ops
+    from reagent_amd.qr_engine import TILE, GroupedSpace
+
+    dev = backend.device
+    B, G, N = 150, 3, 37
+    g = torch.Generator().manual_seed(4)
+    key = torch.randint(0, G, (B,), generator=g).to(torch.int32)
+    sp = GroupedSpace(B, G, dev).build(key.to(dev))
+    R = sp.rows
+    z = torch.randn(R, 40, generator=g) * 1.5
+    zt = torch.randn(B, 40, generator=g) * 1.5
+    z[:, :5] = torch.round(z[:, :5])      # integers: differences of exactly 0 and +-1 against ...
+    zt[:, :7] = torch.round(zt[:, :7])    # ... integer targets (reward 0, discount 1 below for half of the rows)
+    reward = torch.where(torch.arange(B) % 2 == 0, torch.zeros(B), torch.randn(B, generator=g))
+    nt = torch.where(torch.arange(B) % 5 == 0, torch.zeros(B), torch.ones(B))
+    boosts = torch.tensor([0.0, 0.25, -0.5])
+    gamma = 1.0
+    tau = ((0.5 + torch.arange(N).float()) / N)
+    dz = torch.full((R, 40), 7.0)
+    lp, tl = torch.zeros(R), torch.zeros(sp.n_tiles)
+    D = lambda t: t.to(dev)  # noqa: E731
+    dzd, lpd, tld = D(dz), D(lp), D(tl)
+    ops.qr_compact_head(D(z), D(zt), sp.rowmap, sp.tile_key, D(reward), D(boosts), D(nt), gamma, None, D(tau), B, N, dzd,
+                        lpd, tld)
+    rm, tk = sp.rowmap.cpu(), sp.tile_key.cpu()
+    ref_dz = torch.zeros(R, 40, dtype=torch.float64)
+    ref_l = torch.zeros(R, dtype=torch.float64)
+    for r in range(R):
+        b = int(rm[r])
+        if b < 0:
+            continue
+        T = (reward[b] + boosts[int(tk[r // TILE])]).double() + gamma * nt[b].double() * zt[b, :N].double()
+        C = z[r, :N].double()
+        td = T[:, None] - C[None, :]                       # [i, j]
+        ad = td.abs()
+        hub = torch.where(ad < 1, 0.5 * td * td, ad - 0.5)
+        dh = torch.where(ad < 1, td, torch.sign(td))
+        w = (tau.double()[None, :] - (td < 0).double()).abs()
+        inv = 1.0 / (N * B * N)
+        ref_l[r] = (hub * w).sum() * inv
+        ref_dz[r, :N] = -(dh * w).sum(0) * inv
+    assert (dzd.cpu().double() - ref_dz).abs().max() <= 1e-6 * ref_dz.abs().max() + 1e-9
+    assert (lpd.cpu().double() - ref_l).abs().max() <= 2e-6 * ref_l.abs().max()
+    assert abs(tld.cpu().double().sum() - ref_l.sum()) <= 1e-6 * ref_l.sum()
