@@ -435,6 +435,14 @@ int rg_c51_head(const float* q, const float* qn_online, const float* qn_target, 
                 double qmin, double qmax, int batch, int num_actions, int num_atoms, int maxq, float* dq,
                 float* loss_partials, float* all_q, rg_stream_t stream);
 
+/* Dueling aggregation, reagent/models/dueling_q_network.py:96-107: value [B, num_atoms], advantage [B, A * num_atoms]
+ * viewed (B, A, N) (num_atoms = 1 for plain DQN): q = value + advantage - mean over (actions, atoms) of advantage;
+ * rg_dueling_split is its adjoint (dadvantage = dq - mean(dq), dvalue[b, n] = sum over actions of dq[b, a, n]). */
+int rg_dueling_combine(const float* value, int64_t ldv, const float* advantage, int64_t lda, int batch,
+                       int num_actions, int num_atoms, float* q, int64_t ldq, rg_stream_t stream);
+int rg_dueling_split(const float* dq, int64_t lddq, int batch, int num_actions, int num_atoms, float* dadvantage,
+                     int64_t ldda, float* dvalue, int64_t lddv, rg_stream_t stream);
+
 /* ---- QR-DQN with a grouped output layer (qr_grouped.hip; reagent/training/qrdqn_trainer.py:108-160) ---------
  * The [A * N, H] output layer is treated as A layers [N, H] ("groups"); the batch rows are sorted by the action
  * whose quantiles are needed and each action's rows padded to whole 128-row tiles — "grouped space", described by

@@ -66,13 +66,18 @@ DQN_CASES = {
                          rl=dict(gamma=0.9, target_update_rate=0.5, maxq_learning=True,
                                  q_network_loss="huber", use_seq_num_diff_as_time_diff=True),
                          lr=0.002, double_q=True, batch=33, steps=2, p_impossible=0.2, with_steps=True),
+    # DuelingQNetwork.make_fully_connected (the default DQN net builder): trunk [12 -> 48 -> 32], two [32 -> 16 -> .] streams
+    "dqn_dueling": dict(state_dim=12, num_actions=4, sizes=[48, 32], activations=["relu", "leaky_relu"],
+                        rl=dict(gamma=0.95, target_update_rate=0.1, maxq_learning=True, q_network_loss="huber"),
+                        lr=0.003, double_q=True, batch=72, steps=3, p_impossible=0.2, with_steps=False, dueling=True),
 }
 
 
 def gen_dqn(name, c):
     cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
-                      double_q=c["double_q"], seed=0, cpe_metrics=cpe_metrics, bcq_threshold=c.get("bcq_threshold"))
+                      double_q=c["double_q"], seed=0, cpe_metrics=cpe_metrics, bcq_threshold=c.get("bcq_threshold"),
+                      dueling=c.get("dueling", False))
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
@@ -93,6 +98,9 @@ def gen_dqn(name, c):
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
         arrays[f"step{s}_q"] = _np(tr.all_action_scores)
+        if c.get("dueling"):  # d loss / d parameters as autograd produced them (newer fixtures carry them)
+            for i, gr in enumerate(loop.last_grads[0]):
+                arrays[f"step{s}_grad_{i}"] = _np(gr)
         for i, p in enumerate(tr.q_network.parameters()):
             arrays[f"step{s}_param_{i}"] = _np(p)
         for i, p in enumerate(tr.q_network_target.parameters()):
@@ -120,13 +128,18 @@ QR_CASES = {
     "qrdqn_single_sarsa": dict(state_dim=5, num_actions=4, num_atoms=7, sizes=[24], activations=["leaky_relu"],
                                rl=dict(gamma=0.9, target_update_rate=0.3, maxq_learning=False), lr=0.002,
                                double_q=False, batch=40, steps=2, p_impossible=0.0),
+    # dueling streams with atoms: value [B, 1, N] + advantage [B, A, N] - mean over (A, N)
+    "qrdqn_dueling": dict(state_dim=9, num_actions=3, num_atoms=8, sizes=[40, 24], activations=["relu", "relu"],
+                          rl=dict(gamma=0.97, target_update_rate=0.2, maxq_learning=True), lr=0.004,
+                          double_q=True, batch=44, steps=2, p_impossible=0.2, dueling=True),
 }
 
 
 def gen_qr(name, c):
     cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
-                      double_q=c["double_q"], seed=0, num_atoms=c["num_atoms"], cpe_metrics=cpe_metrics)
+                      double_q=c["double_q"], seed=0, num_atoms=c["num_atoms"], cpe_metrics=cpe_metrics,
+                      dueling=c.get("dueling", False))
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
@@ -147,6 +160,9 @@ def gen_qr(name, c):
             for net in CPE_NETS:
                 for i, p in enumerate(getattr(tr, net).parameters()):
                     arrays[f"step{s}_{net}_{i}"] = _np(p)
+        if c.get("dueling"):
+            for i, gr in enumerate(loop.last_grads[0]):
+                arrays[f"step{s}_grad_{i}"] = _np(gr)
         for i, p in enumerate(tr.q_network.parameters()):
             arrays[f"step{s}_param_{i}"] = _np(p)
         for i, p in enumerate(tr.q_network_target.parameters()):

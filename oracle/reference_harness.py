@@ -90,17 +90,23 @@ def make_adam(lr=1e-3, **kw):
 
 
 def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_q=True, seed=0,
-              num_atoms=None, cpe_metrics=None, bcq_threshold=None):
+              num_atoms=None, cpe_metrics=None, bcq_threshold=None, dueling=False):
     """Reference FullyConnectedDQN (+ target) and DQNTrainer / QRDQNTrainer.  cpe_metrics: None = CPE
     off; a list of extra metric names (may be empty) = calc_cpe_in_training with reward_network,
     q_network_cpe and its target of output width (len(cpe_metrics) + 1) * num_actions
-    (model_managers/discrete/discrete_dqn.py:84-104)."""
+    (model_managers/discrete/discrete_dqn.py:84-104).  dueling=True: DuelingQNetwork.make_fully_connected over the
+    same sizes (what net_builder/discrete_dqn/dueling.py:38-46 builds — the reference's default DQN net builder)."""
     _install()
     from reagent.core.parameters import EvaluationParameters
     from reagent.models.dqn import FullyConnectedDQN
 
     torch.manual_seed(seed)
-    q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
+    if dueling:
+        from reagent.models.dueling_q_network import DuelingQNetwork
+
+        q = DuelingQNetwork.make_fully_connected(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
+    else:
+        q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
     qt = q.get_target_network()
     actions = [str(i) for i in range(num_actions)]
     cpe = cpe_metrics is not None

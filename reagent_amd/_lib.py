@@ -208,6 +208,8 @@ SIGNATURES = {
     "rg_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_d, c_d,
                               c_d, c_d, c_d, c_void_p]),
     "rg_soft_update": (c_int, [c_void_p, c_void_p, c_i64, c_d, c_void_p]),
+    "rg_dueling_combine": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "rg_dueling_split": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     "rg_group_rows_workspace_bytes": (c_sz, [c_int, c_int]),
     "rg_group_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
     "rg_group_wfrag_elems": (c_sz, [c_int, c_int, c_int]),

@@ -638,9 +638,61 @@ __global__ void reduce_sum_kernel(const float* __restrict__ in, int n, float sca
 
 }  // namespace rg
 
+namespace rg {
+// Dueling aggregation (reagent/models/dueling_q_network.py:96-107), value [B, N], raw advantage [B, A*N] viewed
+// (B, A, N) (N = 1 without atoms):  q[b,a,n] = value[b,n] + adv[b,a,n] - mean over (a, n) of adv[b].
+// One wave per row: lanes stride the A*N entries, the mean is a wave reduction in fixed order.
+__global__ void dueling_combine_kernel(const float* __restrict__ value, long ldv, const float* __restrict__ adv, long lda,
+                                       int batch, int A, int N, float* __restrict__ q, long ldq) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= batch) return;
+  const int M = A * N;
+  float s = 0.f;
+  for (int i = lane; i < M; i += 64) s += adv[(long)b * lda + i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += shfl_xor(s, off);
+  const float mean = s / (float)M;
+  for (int i = lane; i < M; i += 64) q[(long)b * ldq + i] = value[(long)b * ldv + i % N] + (adv[(long)b * lda + i] - mean);
+}
+// its adjoint: dadv[b,a,n] = dq[b,a,n] - mean over (a, n) of dq[b];  dvalue[b,n] = sum over a of dq[b,a,n]
+__global__ void dueling_split_kernel(const float* __restrict__ dq, long lddq, int batch, int A, int N,
+                                     float* __restrict__ dadv, long ldda, float* __restrict__ dvalue, long lddv) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= batch) return;
+  const int M = A * N;
+  float s = 0.f;
+  for (int i = lane; i < M; i += 64) s += dq[(long)b * lddq + i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += shfl_xor(s, off);
+  const float mean = s / (float)M;
+  for (int i = lane; i < M; i += 64) dadv[(long)b * ldda + i] = dq[(long)b * lddq + i] - mean;
+  for (int n = lane; n < N; n += 64) {
+    float t = 0.f;
+    for (int a = 0; a < A; ++a) t += dq[(long)b * lddq + (long)a * N + n];
+    dvalue[(long)b * lddv + n] = t;
+  }
+}
+}  // namespace rg
+
 using namespace rg;
 
 extern "C" {
+
+int rg_dueling_combine(const float* value, int64_t ldv, const float* advantage, int64_t lda, int batch, int num_actions,
+                       int num_atoms, float* q, int64_t ldq, rg_stream_t stream) {
+  if (!value || !advantage || !q || batch <= 0 || num_actions <= 0 || num_atoms <= 0) return RG_EINVAL;
+  RG_LAUNCH(dueling_combine_kernel, dim3((batch + 3) / 4), dim3(256), (hipStream_t)stream, value, (long)ldv, advantage,
+            (long)lda, batch, num_actions, num_atoms, q, (long)ldq);
+  return (int)hipGetLastError();
+}
+
+int rg_dueling_split(const float* dq, int64_t lddq, int batch, int num_actions, int num_atoms, float* dadvantage,
+                     int64_t ldda, float* dvalue, int64_t lddv, rg_stream_t stream) {
+  if (!dq || !dadvantage || !dvalue || batch <= 0 || num_actions <= 0 || num_atoms <= 0) return RG_EINVAL;
+  RG_LAUNCH(dueling_split_kernel, dim3((batch + 3) / 4), dim3(256), (hipStream_t)stream, dq, (long)lddq, batch, num_actions,
+            num_atoms, dadvantage, (long)ldda, dvalue, (long)lddv);
+  return (int)hipGetLastError();
+}
 
 int rg_dqn_head_partials(int batch) { return (batch + HEAD_THREADS - 1) / HEAD_THREADS; }
 

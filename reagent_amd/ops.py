@@ -597,3 +597,20 @@ def group_head_wgrad(dzw_frag, h_frag, tile_begin, n_groups, group_rows, in_feat
          lambda: L.lib().rg_group_head_wgrad(dzw_frag.data_ptr(), h_frag.data_ptr(), tile_begin.data_ptr(), n_groups,
                                              group_rows, in_features, splits, dw.data_ptr(), workspace.data_ptr(),
                                              workspace.numel() * 4, L.stream_ptr()))
+
+
+# ---- dueling aggregation -------------------------------------------------------------------------------------
+def dueling_combine(value, adv, num_actions, num_atoms, q):
+    _chk_dev(value, adv, q)
+    B = q.shape[0]
+    _run("rg_dueling_combine", dict(B=B, A=num_actions, N=num_atoms),
+         lambda: L.lib().rg_dueling_combine(value.data_ptr(), _ld(value), adv.data_ptr(), _ld(adv), B, num_actions, num_atoms,
+                                            q.data_ptr(), _ld(q), L.stream_ptr()))
+
+
+def dueling_split(dq, num_actions, num_atoms, dadv, dvalue):
+    _chk_dev(dq, dadv, dvalue)
+    B = dq.shape[0]
+    _run("rg_dueling_split", dict(B=B, A=num_actions, N=num_atoms),
+         lambda: L.lib().rg_dueling_split(dq.data_ptr(), _ld(dq), B, num_actions, num_atoms, dadv.data_ptr(), _ld(dadv),
+                                          dvalue.data_ptr(), _ld(dvalue), L.stream_ptr()))

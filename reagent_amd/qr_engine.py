@@ -88,6 +88,8 @@ class GroupedQR:
     def eligible(trainer) -> bool:
         try:
             fc = trainer.q_network.fc
+            if not hasattr(fc, "dnn"):  # a composite (dueling) network: three stacks, not one trunk + head
+                return False
             lin = fc.linears()
             names = fc.activation_names
         except AttributeError:

@@ -24,7 +24,7 @@ def _boosts(cfg):
     return t
 
 
-@pytest.mark.parametrize("name", ["dqn_c1", "dqn_huber_masks", "dqn_sarsa_multistep", "dqn_timediff"])
+@pytest.mark.parametrize("name", ["dqn_c1", "dqn_huber_masks", "dqn_sarsa_multistep", "dqn_timediff", "dqn_dueling"])
 def test_dqn_oracle_matches_reference(name):
     g = Golden(name)
     c = g.cfg
@@ -33,7 +33,7 @@ def test_dqn_oracle_matches_reference(name):
                     loss=c["rl"]["q_network_loss"], double_q=c["double_q"], maxq=c["rl"]["maxq_learning"],
                     lr=c["lr"], reward_boosts=_boosts(c),
                     use_seq_num_diff_as_time_diff=c["rl"].get("use_seq_num_diff_as_time_diff", False),
-                    multi_steps=c["rl"].get("multi_steps"))
+                    multi_steps=c["rl"].get("multi_steps"), dueling=c.get("dueling", False))
     for s in range(c["steps"]):
         out = o.step(g.batch(s))
         torch.testing.assert_close(out["loss"], g.t(f"step{s}_loss"), **TIGHT)
@@ -47,14 +47,14 @@ def test_dqn_oracle_matches_reference(name):
         torch.testing.assert_close(o.opt.state[p]["exp_avg_sq"], g.t(f"final_exp_avg_sq_{i}"), **TIGHT)
 
 
-@pytest.mark.parametrize("name", ["qrdqn_double", "qrdqn_single_sarsa"])
+@pytest.mark.parametrize("name", ["qrdqn_double", "qrdqn_single_sarsa", "qrdqn_dueling"])
 def test_qrdqn_oracle_matches_reference(name):
     g = Golden(name)
     c = g.cfg
     init = g.seq("init_param_")
     o = R.QRDQNOracle(init, init, _acts(c), num_actions=c["num_actions"], num_atoms=c["num_atoms"],
                       gamma=c["rl"]["gamma"], tau=c["rl"]["target_update_rate"], double_q=c["double_q"],
-                      maxq=c["rl"]["maxq_learning"], lr=c["lr"])
+                      maxq=c["rl"]["maxq_learning"], lr=c["lr"], dueling=c.get("dueling", False))
     for s in range(c["steps"]):
         out = o.step(g.batch(s))
         torch.testing.assert_close(out["loss"], g.t(f"step{s}_loss"), **TIGHT)
