@@ -116,7 +116,9 @@ typedef struct {
                                                * fragment buffers (wfrag_*, act_frag, dz_frag) then hold TWO planes, hi
                                                * then lo, i.e. twice the element counts rg_*_elems report; the kernels
                                                * work on 64-row tiles (both planes of the activation tile share the LDS) */
-  int32_t reserved;
+  int32_t dx_only;                            /* backward: 1 = only the input gradient is wanted (a frozen network, e.g.
+                                               * SAC's critics in the actor step, sac_trainer.py:262-279): dz_frag is
+                                               * neither required nor written and no weight gradient may follow */
   /* Two-panel network input (FullyConnectedCritic: cat(state, action), reagent/models/critic.py:79-92) without
    * materialising the concatenation: when x2 != NULL the forward reads input columns [0, x_split) from its `x`
    * argument and columns [x_split, dims[0]) from x2 (row pitch ldx2, same dtype); x_split a multiple of 32. */
@@ -153,13 +155,16 @@ size_t rg_wfrag_elems(int out_features, int in_features);  /* bf16 elements of a
 int rg_stage_weights_frag(const float* w, int out_features, int in_features, void* wfrag_fwd,
                           void* wfrag_bwd, rg_stream_t stream);
 /* out32 [batch, dims[L]] = network(x); x [batch, dims[0]] row-major of dtype x_dtype (RG_DT_*).
- * save != 0 additionally writes act_frag[0..L-1]. */
+ * save = 1 additionally writes act_frag[0..L-1] and the act_sign planes (everything backward + wgrad read).
+ * save = 2 writes only what a dx_only backward reads: the act_sign planes, and act_frag[l] of the layers whose
+ * activation gradient is not a sign test (tanh, sigmoid, softplus) — for a ReLU stack 16 B per lane per layer
+ * instead of the activations themselves. */
 int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64_t ldx, int batch,
                          float* out32, int64_t ldo, int save, rg_stream_t stream);
 /* Given dout32 = d loss / d out32: writes dz_frag[0..L-1] (needs act_frag[1..L-1] from a saving
  * forward of the same batch) and the bias gradients d->db[l] (column sums of dZ_l, reduced
  * deterministically from per-workgroup partials in `workspace`); dx32 (nullable) = d loss / d x,
- * fp32 [batch, dims[0]]. */
+ * fp32 [batch, dims[0]].  With d->dx_only only dx32 is produced (see rg_mlp_desc). */
 size_t rg_mlp_backward_fused_workspace_bytes(const rg_mlp_desc* d, int batch);
 int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch,
                           float* dx32, int64_t lddx, void* workspace, size_t workspace_bytes,

@@ -73,7 +73,7 @@ class MlpDesc(ctypes.Structure):
         ("w", c_void_p * MLP_MAX_LAYERS),
         ("dw", c_void_p * MLP_MAX_LAYERS),
         ("x3", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("dx_only", ctypes.c_int32),
         ("x2", c_void_p),
         ("ldx2", ctypes.c_int64),
         ("x_split", ctypes.c_int32),

@@ -75,7 +75,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
     load_tile_to_lds<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   __syncthreads();
   RG_STAMP(1);
-  if (a.save && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * 4, wave, NW, lane);
+  if (a.save == 1 && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * 4, wave, NW, lane);
 
   for (int l = 0; l < a.n_layers; ++l) {
     const int K = a.dims[l], N = a.dims[l + 1];
@@ -94,7 +94,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       RG_STAMP(2 + 4 * l);
       unsigned PK[4][TN][8];
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
-      RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack<TN, A_>(acc, a.bias[l], (a.save ? a.act_frag[l + 1] : nullptr),
+      RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l),
                                                           sign_dst, N / 32, blockIdx.x * 4, wave, lane, PK)));
       RG_STAMP(3 + 4 * l);
       __syncthreads();  // every wave is done reading the layer input
@@ -148,7 +148,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
   const int nop = round_up(a.dims[L], 32);
   load_tile_to_lds<float, THREADS>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, NW, lane);
+  if (a.dz_frag[L - 1]) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, NW, lane);
   if (a.db_part[L - 1] && tid < a.dims[L]) {
     float s = 0.f;
     for (int r = 0; r < FB_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]);
@@ -810,9 +810,10 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   MlpArgs a;
   int rc = fill_args(d, batch, a, 0);
   if (rc) return rc;
+  if (save < 0 || save > 2) return RG_EINVAL;
   if (save)
-    for (int l = 0; l < d->n_layers; ++l)
-      if (!d->act_frag[l]) return RG_EINVAL;
+    for (int l = (save == 2 ? 1 : 0); l < d->n_layers; ++l)
+      if (!d->act_frag[l]) return RG_EINVAL;  // (save = 2 writes it only where there is no usable sign plane)
   if (d->rowmap && (d->x2 || d->x3 || (batch % 128) != 0)) return RG_EUNSUPPORTED;
   if (d->tile_key && (!d->rowmap || d->n_groups <= 0)) return RG_EINVAL;
   if (d->x2 && (d->x_split <= 0 || d->x_split >= d->dims[0] || (d->x_split % 32) != 0)) return RG_EINVAL;
@@ -842,11 +843,12 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   if (rc) return rc;
   bool want_db = false;
   for (int l = 0; l < d->n_layers; ++l) {
-    if (!d->dz_frag[l]) return RG_EINVAL;
+    if (!d->dx_only && !d->dz_frag[l]) return RG_EINVAL;
     if (l >= 1 && !d->act_frag[l]) return RG_EINVAL;
     if (d->db[l]) want_db = true;
   }
   if (dx32 && !d->wfrag_bwd[0]) return RG_EINVAL;
+  if (d->dx_only && (!dx32 || want_db || d->tile_key)) return RG_EINVAL;
   if (d->dx_col0 < 0 || d->dx_col0 >= d->dims[0] || (d->dx_col0 % 32) != 0) return RG_EINVAL;
   const int n_wg = padded_wgs(d, batch);
   if (want_db) {

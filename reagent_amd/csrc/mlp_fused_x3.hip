@@ -277,8 +277,8 @@ __device__ __forceinline__ void x3_fwd_pack(f32x16 (&acc)[X3_TM][TN], const floa
       if (save_dst) {
         store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, PH[tm][tn]);
         store_packed_frags(save_dst + save_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
-        if (act_is_sign_based<ACT>()) sg |= positive_bits<ACT == ACT_RELU>(v) << (tm * 16);
       }
+      if (act_is_sign_based<ACT>() && sign_dst) sg |= positive_bits<ACT == ACT_RELU>(v) << (tm * 16);
     });
     if (act_is_sign_based<ACT>() && sign_dst) sign_dst[x3_sign_offset(mb_base / X3_TM, wave, lane, TN, NT * 32) + tn] = sg;
   });
@@ -321,8 +321,10 @@ __device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) split_pack(v[2 * i], v[2 * i + 1], PH[tm][tn][i], PL[tm][tn][i]);
-      store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PH[tm][tn]);
-      store_packed_frags(dz_dst + dz_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
+      if (dz_dst) {
+        store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PH[tm][tn]);
+        store_packed_frags(dz_dst + dz_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
+      }
     });
     colsum += shfl_xor(colsum, 32);
     if (db_part && lane < 32) db_part[col] = colsum;
@@ -353,7 +355,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   else
     load_tile_split<bf16_t, THREADS, LO>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   __syncthreads();
-  if (a.save && a.act_frag[0]) {
+  if (a.save == 1 && a.act_frag[0]) {
     emit_frags_x3(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * X3_TM, wave, NW, lane);
     emit_frags_x3(act + LO, pitch, k0p / 32, a.act_frag[0] + a.act_lo[0], blockIdx.x * X3_TM, wave, NW, lane);
   }
@@ -374,7 +376,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
                                 lane, k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
       unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;
-      RG_DISPATCH_ACT(a.acts[l], (x3_fwd_pack<TN, A_>(acc, a.bias[l], (a.save ? a.act_frag[l + 1] : nullptr),
+      RG_DISPATCH_ACT(a.acts[l], (x3_fwd_pack<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l),
                                                       a.act_lo[l + 1], sign_dst, N / 32, blockIdx.x * X3_TM, wave, lane, PH,
                                                       PL)));
       __syncthreads();  // every wave is done reading the layer input
@@ -414,8 +416,10 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
   const int nop = round_up(a.dims[L], 32);
   load_tile_split<float, THREADS, LO>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
-  emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
+  if (a.dz_frag[L - 1]) {
+    emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
+    emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
+  }
   if (a.db_part[L - 1] && tid < a.dims[L]) {
     float s = 0.f;
     for (int r = 0; r < X3_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]) + bf16_to_f32(act[LO + r * pitch + tid]);

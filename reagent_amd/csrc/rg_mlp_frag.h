@@ -413,6 +413,12 @@ __device__ __forceinline__ long sign_offset(int wg, int wave, int lane, int TN, 
   return (long)wg * (4 * width) + ((long)wave * 64 + lane) * (2 * TN);
 }
 template <int ACT> constexpr bool act_is_sign_based() { return ACT == ACT_RELU || ACT == ACT_LEAKY_RELU; }
+// what a saving forward stores of layer l's output: save = 1 everything backward + wgrad read; save = 2 (a dx_only
+// backward follows) the fragments only where the activation gradient needs the values (the sign plane otherwise)
+__device__ __forceinline__ bf16_t* fwd_save_dst(const MlpArgs& a, int l) {
+  const bool sign_based = a.acts[l] == ACT_RELU || a.acts[l] == ACT_LEAKY_RELU;
+  return (a.save == 1 || (a.save == 2 && !(sign_based && a.act_sign[l + 1]))) ? a.act_frag[l + 1] : nullptr;
+}
 
 // The hidden-layer epilogues run in two phases around the barrier that protects the in-place LDS
 // tile.  PACK (before the barrier; touches no LDS): bias/activation (or the activation-gradient
@@ -455,13 +461,11 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
       pack_tile(v, PK[tm][tn]);
-      if (save_dst) {
-        store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
-        if (act_is_sign_based<ACT>()) {
-          const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
-          if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
-          else sg1 |= bits << ((tm & 1) * 16);
-        }
+      if (save_dst) store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
+      if (act_is_sign_based<ACT>() && sign_dst) {
+        const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
+        if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
+        else sg1 |= bits << ((tm & 1) * 16);
       }
     });
     if (act_is_sign_based<ACT>() && sign_dst)
@@ -503,7 +507,7 @@ __device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16
         }
       }
       pack_tile(v, PK[tm][tn]);
-      store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
+      if (dz_dst) store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
     });
     colsum += shfl_xor(colsum, 32);
     if (db_part && lane < 32) db_part[col] = colsum;
@@ -586,7 +590,7 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
     a.acts[l] = d->acts[l];
     a.wfrag[l] = (const bf16_t*)(backward ? d->wfrag_bwd[l] : d->wfrag_fwd[l]);
     a.bias[l] = d->bias[l];
-    a.dz_frag[l] = (bf16_t*)d->dz_frag[l];
+    a.dz_frag[l] = d->dx_only ? nullptr : (bf16_t*)d->dz_frag[l];  // dx_only: the dZ fragments have no reader
     // the sign plane of layer l's input only exists when layer l-1 has a sign-based activation
     const bool sign_ok = l >= 1 && (d->acts[l - 1] == RG_ACT_RELU || d->acts[l - 1] == RG_ACT_LEAKY_RELU);
     a.act_sign[l] = sign_ok ? (unsigned*)d->act_sign[l] : nullptr;

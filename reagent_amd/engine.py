@@ -254,6 +254,9 @@ class FCStack:
                              dx32=dx32, dxt=None)
 
 
+SAVE_FOR_DX = 2  # FusedMLP.forward(save=SAVE_FOR_DX): keep only what a dx-only backward needs (rg_mlp_forward_fused save = 2)
+
+
 class FusedMLP:
     """bf16-MFMA engine for stacks the fused kernels support (hidden width 256/512 shared by
     all hidden layers, input <= 512, output <= 128): rg_mlp_forward_fused / rg_mlp_backward_fused /
@@ -275,6 +278,7 @@ class FusedMLP:
         self._wf = [None] * self.L
         self._wb = [None] * self.L
         self._need_dx = False
+        self._saved = 0
         self._staged_versions = None
         self._wsrc_ptrs = ()
         self._batch = -1
@@ -361,6 +365,7 @@ class FusedMLP:
         d.n_layers = self.L
         d.x3 = int(self.x3)
         d.dx_col0 = 0
+        d.dx_only = 0
         for i, v in enumerate(self.dims):
             d.dims[i] = v
         ws = self._ws
@@ -385,7 +390,8 @@ class FusedMLP:
         row rowmap[r] of xc (-1: zeros) — "grouped space" of qr_engine.py; out32 has len(rowmap) rows."""
         L.require_cuda(xc)
         B = xc.shape[0] if rowmap is None else rowmap.shape[0]
-        self._ensure_ws(B, xc.device, training=save)
+        save = int(save)  # 0 / 1 (everything backward + wgrad read) / SAVE_FOR_DX (what a dx-only backward reads)
+        self._ensure_ws(B, xc.device, training=bool(save))
         d = self._fill_desc()
         assert xc.stride(1) == 1 and out32.stride(1) == 1
         if x2 is not None:
@@ -402,8 +408,9 @@ class FusedMLP:
         d.rowmap = rowmap.data_ptr() if rowmap is not None else None
         ops._run("rg_mlp_forward_fused", dict(B=B, save=int(save), dims=tuple(self.dims)),
                  lambda: L.lib().rg_mlp_forward_fused(d, xc.data_ptr(), ops.dt_code(xc.dtype), xc.stride(0), B,
-                                                      out32.data_ptr(), out32.stride(0), int(save),
+                                                      out32.data_ptr(), out32.stride(0), save,
                                                       L.stream_ptr()))
+        self._saved = save
         return out32
 
     def backward(self, dout32: torch.Tensor, xt, dw: List[torch.Tensor], db: List[torch.Tensor],
@@ -416,6 +423,9 @@ class FusedMLP:
         d = self._fill_desc()
         d.x2, d.ldx2, d.x_split = None, 0, 0
         d.dx_col0 = dx_col0
+        # a frozen network (only dx wanted): the dZ fragments have no reader and are not written
+        d.dx_only = int(skip_wgrad and dx32 is not None and (db is None or all(b is None for b in db)))
+        assert self._saved == 1 or d.dx_only, "a forward saved with SAVE_FOR_DX serves a dx-only backward (skip_wgrad) alone"
         if dx32 is not None:
             assert dx_col0 % 32 == 0 and dx32.shape[1] == self.dims[0] - dx_col0
         lib = L.lib()
@@ -427,6 +437,7 @@ class FusedMLP:
                                                    dx32.data_ptr() if dx32 is not None else None,
                                                    dx32.stride(0) if dx32 is not None else 0,
                                                    ws["bwd"].data_ptr(), ws["bwd"].numel() * 4, L.stream_ptr()))
+        d.dx_only = 0
         if not skip_wgrad:
             for l in range(self.L):
                 d.dw[l] = dw[l].data_ptr()
@@ -531,6 +542,12 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
              lambda: lib.rg_mlp_wgrad_fused(t, R, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))
     ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.tile_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
                          wgrad_ws)
+
+
+def dx_save(stack):
+    """`save` argument of a forward whose backward will be input-gradient only (skip_wgrad): the fused kernels then
+    keep the sign planes instead of the activations"""
+    return SAVE_FOR_DX if isinstance(stack, FusedMLP) else True
 
 
 def make_stack(weights, biases, acts: List[int], precision: int):

@@ -30,7 +30,7 @@ from .. import _lib as L
 from .. import ops
 from ..core import types as rlt
 from ..core.parameters import RLParameters
-from ..engine import ensure_slab
+from ..engine import dx_save, ensure_slab
 from ..optimizer import Optimizer__Union, SoftUpdate
 from .dqn_trainer import dp_reduce, held_gradients, native_step, publish_gradients
 from .reagent_lightning_module import ReAgentLightningModule
@@ -403,16 +403,17 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         has_q2 = "q2" in e
         if self._panels:
             ops.gaussian_head_forward(self._ls, noise_cur, self._api, self._lp, None)
-            q1s.forward(state, self._q1a, save=True, x2=self._api)
+            # the critics are frozen in this segment: only d q / d action comes back (dx_save)
+            q1s.forward(state, self._q1a, save=dx_save(q1s), x2=self._api)
             if has_q2:
-                e["q2"]["stack"].forward(state, self._q2a, save=True, x2=self._api)
+                e["q2"]["stack"].forward(state, self._q2a, save=dx_save(q1s), x2=self._api)
         else:
             self._xa[:, :S].copy_(state)
             ops.gaussian_head_forward(self._ls, noise_cur, self._xa[:, S:], self._lp, None)
             xa_c, _ = q1s.stage_input(self._xa, need_transposed=False)
-            q1s.forward(xa_c, self._q1a, save=True)
+            q1s.forward(xa_c, self._q1a, save=dx_save(q1s))
             if has_q2:
-                e["q2"]["stack"].forward(xa_c, self._q2a, save=True)
+                e["q2"]["stack"].forward(xa_c, self._q2a, save=dx_save(q1s))
         crr_mode, crr_p0, crr_clamp, v_cur = 0, 0.0, 0.0, None
         if self.crr_config is not None:  # advantage = min q - V(state), both detached (:265-268)
             vs = e["value"]["stack"]

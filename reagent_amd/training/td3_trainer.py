@@ -16,7 +16,7 @@ from .. import _lib as L
 from .. import ops
 from ..core import types as rlt
 from ..core.parameters import RLParameters
-from ..engine import ensure_slab
+from ..engine import dx_save, ensure_slab
 from ..optimizer import Optimizer__Union, SoftUpdate
 from .reagent_lightning_module import ReAgentLightningModule
 from .rl_trainer_pytorch import RLTrainerMixin
@@ -196,7 +196,7 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
             self._xa[:, S:].copy_(self._a_out)
         q1s = e["q1"]["stack"]
         xa_c, _ = q1s.stage_input(self._xa, need_transposed=False)
-        q1s.forward(xa_c, self._q1a, save=True)
+        q1s.forward(xa_c, self._q1a, save=dx_save(q1s))  # q1 is frozen here: only d q / d action comes back
         ops.reduce_sum(self._q1a.reshape(-1), B, -1.0 / B, self._losses["actor"])  # -(q1(s, actor(s)).mean())
 
     def _actor_backward(self, grad_out=None):

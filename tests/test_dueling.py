@@ -131,14 +131,16 @@ def test_dueling_module_forward_matches_reference_q(backend):
     assert torch.all(qm[mask == 0] < -1e9) and torch.equal(qm[mask == 1], q[mask == 1])
 
 
-# gradient bounds relative to the largest entry, as tests/test_baseline_shapes.py GRAD_TOL (bf16 rounds dz and flips a few relu masks)
-@pytest.mark.parametrize("precision,tol,gtol", [(L.PREC_BF16, 4e-2, 3e-1), (L.PREC_BF16X3, 2e-4, 3e-3)])
+# gradient bounds in the Frobenius norm (measured over seeds: bf16 0.03-0.09 per layer — dZ is rounded at five layers and a
+# few relu masks flip; bf16x3 0 to 2e-3, one flipped mask being a rank-1 difference)
+@pytest.mark.parametrize("precision,tol,gtol", [(L.PREC_BF16, 4e-2, 0.15), (L.PREC_BF16X3, 2e-4, 5e-3)])
 def test_dueling_mixed_engines_against_torch(backend, precision, tol, gtol):
     """layers [256, 256, 256]: the trunk runs on the fused kernels, the [256 -> 128 -> .] streams on the per-layer
     GEMMs; Q and every parameter gradient against torch fp32 autograd of the reference's formula"""
     from reagent_amd.engine import FCStack, FusedMLP
 
     S, A, B = 40, 5, 130
+    torch.manual_seed(0)
     set_default_precision(precision)
     try:
         q = DuelingQNetwork.make_fully_connected(S, A, [256, 256, 256], ["relu", "relu", "relu"]).to(backend.device)
@@ -175,5 +177,5 @@ def test_dueling_mixed_engines_against_torch(backend, precision, tol, gtol):
     st.backward(dq.to(backend.device), xt, dw, db)
     for i in range(len(lin)):
         gw, gb = ws[i].grad, bs[i].grad
-        assert (dw[i].cpu() - gw).abs().max() <= gtol * max(gw.abs().max().item(), 1e-6), i
-        assert (db[i].cpu() - gb).abs().max() <= gtol * max(gb.abs().max().item(), 1e-6), i
+        assert (dw[i].cpu() - gw).norm() <= gtol * gw.norm(), i
+        assert (db[i].cpu() - gb).norm() <= gtol * gb.norm() + 1e-7, i

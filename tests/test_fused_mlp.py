@@ -230,3 +230,48 @@ def test_two_panel_input_and_partial_input_gradient(backend, prec):
     out3 = torch.zeros(batch, 1, device=dev)
     st.forward(cat, out3, save=False)  # a plain call after a two-panel one: the panel fields do not stick
     assert torch.equal(out3, o1)
+
+
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_BF16X3])
+@pytest.mark.parametrize("acts", [["relu", "leaky_relu", "linear"], ["tanh", "relu", "linear"]])
+def test_dx_only_backward_of_a_frozen_stack(backend, prec, acts):
+    """forward(save=SAVE_FOR_DX) + backward(skip_wgrad) — SAC's / TD3's frozen critics in the actor step — returns the
+    input gradient of the full saving path bit for bit without writing activation or dZ fragments (buffers poisoned
+    to prove it); a tanh layer still gets its activations saved (its gradient needs the values)."""
+    from reagent_amd.engine import SAVE_FOR_DX
+
+    dev = backend.device
+    S, A, batch = 64, 32, 140
+    dims = [S + A, 256, 256, 1]
+    ws, bs = _net(dims, acts, 9, dev)
+    st = make_stack(ws, bs, [L.ACT[a] for a in acts], prec)
+    assert isinstance(st, FusedMLP)
+    st.set_need_input_grad(True)
+    st.stage_weights(need_transposed=True)
+    g = torch.Generator().manual_seed(12)
+    state, action = torch.randn(batch, S, generator=g).to(dev), torch.randn(batch, A, generator=g).to(dev)
+    dout = (torch.randn(batch, 1, generator=g) / batch).to(dev)
+    out_full, out_dx = torch.zeros(batch, 1, device=dev), torch.zeros(batch, 1, device=dev)
+    dx_full, dx_only = torch.zeros(batch, A, device=dev), torch.zeros(batch, A, device=dev)
+    st.forward(state, out_full, save=True, x2=action)
+    st.backward(dout, None, None, None, dx32=dx_full, skip_wgrad=True, dx_col0=S)
+    # poison what the reduced path must neither read (sign-based layers' activations, layer 0's input) nor write
+    frag_names = [k for k, v in st._ws.items() if isinstance(v, (list, tuple))]
+    before = {}
+    for k in frag_names:
+        for i, t in enumerate(st._ws[k]):
+            if isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16:
+                keep = k.startswith("act") and i >= 1 and acts[i - 1] == "tanh"
+                if not keep:
+                    t.fill_(float("nan"))
+                before[(k, i)] = t.clone()
+    st.forward(state, out_dx, save=SAVE_FOR_DX, x2=action)
+    st.backward(dout, None, None, None, dx32=dx_only, skip_wgrad=True, dx_col0=S)
+    assert torch.equal(out_full, out_dx) and torch.equal(dx_full, dx_only) and torch.isfinite(dx_only).all()
+    for (k, i), t in before.items():
+        now = st._ws[k][i]
+        same = torch.equal(now.view(torch.int16), t.view(torch.int16))
+        rewritten_ok = k.startswith("act") and i >= 1 and acts[i - 1] == "tanh"
+        assert same or rewritten_ok, (k, i)
+    with pytest.raises(AssertionError, match="SAVE_FOR_DX"):
+        st.backward(dout, None, [torch.zeros_like(w) for w in ws], [torch.zeros_like(b) for b in bs])
