@@ -238,13 +238,14 @@ struct WgradFragArgs {
   int MB;             // 32-row blocks in total
   int mb_per_split;   // multiple of WG_MB_STAGE
   int splits;
-  float* partial;     // [splits * terms][N*K]
+  float* partial;     // [splits][N*K]
   long slab;
   int N, K;           // valid extents of dW
-  // split-bf16 operands: terms == 3 and every split is computed three times, on (a_hi, b_hi), (a_hi, b_lo) and
-  // (a_lo, b_hi) — three partial slabs that the reduce sums like any other split.  The three workgroups of a
-  // split land on the same XCD, so the hi operands they share are fetched from HBM once.
-  int terms;
+  // split-bf16 operands (x3 != 0): every stage carries the hi AND lo planes of both operands and a tile pair takes
+  // three MFMAs — a_lo.b_hi + a_hi.b_lo + a_hi.b_hi into one accumulator (wgrad_x3_core).  The kernel is bound by its
+  // operand stream (§3.2), so the three products share ONE pass over the four planes instead of three passes over
+  // two planes each (the round-2 first version: three partial slabs per split, 354 us per C2 launch).
+  int x3;
   long a_lo, b_lo;    // element offsets of the lo planes
 };
 
@@ -252,6 +253,8 @@ struct WgradFragArgs {
 // ga_frag / gb_frag, written to `part` (row-major [N][K] slab)
 __device__ __forceinline__ void wgrad_frag_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end,
                                                 const bf16_t* ga_frag, const bf16_t* gb_frag, float* part, char* smem);
+__device__ __forceinline__ void wgrad_x3_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
+                                              char* smem);
 
 __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid, char* smem) {
   const int n_groups = (g.NTa + 7) / 8, k_groups = (g.NTb + 7) / 8;
@@ -259,27 +262,22 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
   // places block b on XCD b % 8), so the second reader of a fragment hits that XCD's L2 instead of
   // HBM (PMC: 700 MB fetched per launch against 420 MB of unique operands without this)
   const int tiles = k_groups * n_groups;
-  int tile, split, term;
+  int tile, split;
   if ((g.splits & 7) == 0) {
     const int xcd = bid & 7, slot = bid >> 3;
-    const int q = slot / tiles;
-    term = q % g.terms;
-    split = (q / g.terms) * 8 + xcd;
+    split = (slot / tiles) * 8 + xcd;
     tile = slot % tiles;
   } else {
     tile = bid % tiles;
-    const int q = bid / tiles;
-    term = q % g.terms;
-    split = q / g.terms;
+    split = bid / tiles;
   }
   if (split >= g.splits) return;  // padding workgroups of a grouped launch (uniform for the workgroup)
-  const bf16_t* const ga_frag = g.a_frag + (term == 2 ? g.a_lo : 0);
-  const bf16_t* const gb_frag = g.b_frag + (term == 1 ? g.b_lo : 0);
   const int kg = tile % k_groups;
   const int ng = tile / k_groups;
   const int mb_begin = split * g.mb_per_split;
   const int mb_end = (mb_begin + g.mb_per_split < g.MB) ? mb_begin + g.mb_per_split : g.MB;
-  wgrad_frag_core(g, ng, kg, mb_begin, mb_end, ga_frag, gb_frag, g.partial + ((long)split * g.terms + term) * g.slab, smem);
+  if (g.x3) wgrad_x3_core(g, ng, kg, mb_begin, mb_end, g.partial + (long)split * g.slab, smem);
+  else wgrad_frag_core(g, ng, kg, mb_begin, mb_end, g.a_frag, g.b_frag, g.partial + (long)split * g.slab, smem);
 }
 
 __device__ __forceinline__ void wgrad_frag_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end,
@@ -375,6 +373,87 @@ __device__ __forceinline__ void wgrad_frag_core(const WgradFragArgs& g, int ng, 
     }
   RG_PHASE(4);
   RG_PHASE_FLUSH();
+}
+
+// Split-bf16 operands.  A stage is HALF a 32-row block (one 16-row MFMA chunk) of all four planes:
+// [a_hi | a_lo | b_hi | b_lo], 8 tiles x 1 KB each = 32 KB — the same ring (four slots, three in flight, four DMAs
+// per thread and stage: thread (wave w, lane) fetches its 16 bytes of tile w of every plane) as the bf16 core, twice
+// the stages, three MFMAs per tile pair: per operand byte 1.5x the MFMA work of the bf16 kernel.
+__device__ __forceinline__ void wgrad_x3_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
+                                              char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int lr = lane & 31, lg = lane >> 5;
+  const int wn = wave >> 2, wk = wave & 3;
+  const int ta0 = ng * 8, tb0 = kg * 8;
+  const int na = (g.NTa - ta0 < 8) ? g.NTa - ta0 : 8, nb = (g.NTb - tb0 < 8) ? g.NTb - tb0 : 8;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int n_stage = 2 * (mb_end - mb_begin);
+  // out-of-range tiles / stages read a clamped valid address (never used), so every wave has exactly four DMAs per stage
+  const int ta = ta0 + (wave < na ? wave : na - 1), tb = tb0 + (wave < nb ? wave : nb - 1);
+  auto issue = [&](int st, int slot) {
+    const int s = st < n_stage ? st : n_stage - 1;
+    const int mb = mb_begin + (s >> 1), h = s & 1;
+    const bf16_t* pa = g.a_frag + (((long)mb * g.NTa + ta) * 2 + h) * 512 + lane * 8;
+    const bf16_t* pb = g.b_frag + (((long)mb * g.NTb + tb) * 2 + h) * 512 + lane * 8;
+    char* dst = smem + slot * WG_STAGE_BYTES + wave * 1024;
+    global_load_lds_b128(pa, dst);
+    global_load_lds_b128(pa + g.a_lo, dst + 8192);
+    global_load_lds_b128(pb, dst + 16384);
+    global_load_lds_b128(pb + g.b_lo, dst + 24576);
+  };
+  const bool wave_has_tiles = wn * 4 < na && wk * 2 < nb;
+  auto compute = [&](int slot) {
+    if (!wave_has_tiles) return;
+    const char* base = smem + slot * WG_STAGE_BYTES + lane * 16;
+    u16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *(const u16x8*)(base + (wn * 4 + i) * 1024);
+      al[i] = *(const u16x8*)(base + 8192 + (wn * 4 + i) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[j] = *(const u16x8*)(base + 16384 + (wk * 2 + j) * 1024);
+      bl[j] = *(const u16x8*)(base + 24576 + (wk * 2 + j) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {  // the small products first
+        acc[i][j] = mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
+        acc[i][j] = mfma_32x32x16_bf16(ah[i], bl[j], acc[i][j]);
+        acc[i][j] = mfma_32x32x16_bf16(ah[i], bh[j], acc[i][j]);
+      }
+  };
+  if (n_stage > 0) {
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    for (int t = 0; t < n_stage; ++t) {
+      RG_WAIT_VMCNT(8);  // three stages of four DMAs outstanding: the oldest has landed
+      raw_barrier();     // ... for every wave, and all are done reading stage t-1, whose slot is refilled next
+      issue(t + 3, (t + 3) & (WG_DMA_SLOTS - 1));
+      compute(t & (WG_DMA_SLOTS - 1));
+    }
+    RG_WAIT_VMCNT(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (tb0 + wk * 2 + j) * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (ta0 + wn * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
+      }
+    }
 }
 
 __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
@@ -929,7 +1008,7 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   g.a_frag = (const bf16_t*)dz_frag; g.b_frag = (const bf16_t*)x_frag;
   g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
-  g.terms = 1; g.a_lo = g.b_lo = 0;
+  g.x3 = 0; g.a_lo = g.b_lo = 0;
   const int grid = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
   const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
@@ -960,7 +1039,7 @@ int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* 
   G.g.a_frag = (const bf16_t*)dz_frag; G.g.b_frag = (const bf16_t*)h_frag;
   G.g.NTa = (group_rows + 31) / 32; G.g.NTb = (in_features + 31) / 32; G.g.MB = 0; G.g.mb_per_split = 0; G.g.splits = splits;
   G.g.partial = (float*)workspace; G.g.slab = (long)group_rows * in_features; G.g.N = group_rows; G.g.K = in_features;
-  G.g.terms = 1; G.g.a_lo = G.g.b_lo = 0;
+  G.g.x3 = 0; G.g.a_lo = G.g.b_lo = 0;
   G.tile_begin = tile_begin; G.n_groups = n_groups; G.splits = splits;
   const int k_groups = (G.g.NTb + 7) / 8;
   const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
@@ -1021,9 +1100,8 @@ size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   if (!d || batch <= 0) return 0;
   size_t total = 0;
   for (int l = 0; l < d->n_layers; ++l) {
-    const int terms = d->x3 ? 3 : 1;
-    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, RG_WGRAD_TARGET / terms);
-    total += (size_t)p.splits * terms * p.slab;
+    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, RG_WGRAD_TARGET);
+    total += (size_t)p.splits * p.slab;
   }
   return total * sizeof(float);
 }
@@ -1045,18 +1123,17 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     if (l < d->n_layers) {
       if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
       const int out_f = d->dims[l + 1], in_f = d->dims[l];
-      const int terms = d->x3 ? 3 : 1;
-      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, RG_WGRAD_TARGET / terms);
+      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, RG_WGRAD_TARGET);
       WgradFragArgs& g = G.layer[l];
       g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
       g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
       g.partial = part; g.slab = p.slab; g.N = out_f; g.K = in_f;
-      g.terms = terms;
+      g.x3 = d->x3 ? 1 : 0;
       g.a_lo = d->x3 ? (long)frag_elems(batch, out_f) : 0;
       g.b_lo = d->x3 ? (long)frag_elems(batch, in_f) : 0;
-      R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits * terms; R.out[l] = d->dw[l];
-      part += (size_t)p.splits * terms * p.slab;
-      wg += ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits * terms;
+      R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
+      part += (size_t)p.splits * p.slab;
+      wg += ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
       wg = (wg + 7) / 8 * 8;  // keep (block id % 8) == (layer-local id % 8) == XCD
       el += p.slab;
     } else {
