@@ -542,6 +542,21 @@ int rg_gaussian_log_prob(const float* loc_scale, int64_t ldls, const float* acti
 int rg_gaussian_head_backward(const float* loc_scale, int64_t ldls, const float* noise,
                               const float* g_action, int64_t ldga, const float* g_log_prob, int batch,
                               int action_dim, float* d_loc_scale, int64_t lddls, rg_stream_t stream);
+/* Same with the action-embedding KLD term's gradient (sac_trainer.py:282-306) folded in: kld_coef (nullable) [2A] =
+ * (c0, c1) from rg_sac_kld; the term's gradient c0_d + c1_d x reaches the action (kld_on_mean == 0) or, through
+ * the squashed mean x = clamp(tanh(loc)), loc alone (kld_on_mean != 0). */
+int rg_gaussian_head_backward_kld(const float* loc_scale, int64_t ldls, const float* noise, const float* g_action,
+                                  int64_t ldga, const float* g_log_prob, int batch, int action_dim,
+                                  float* d_loc_scale, int64_t lddls, const float* kld_coef, int kld_on_mean,
+                                  rg_stream_t stream);
+/* The KLD term itself, sac_trainer.py:282-306: per action dimension d, m = mean over the batch of x[:, d] and v its
+ * unbiased variance (x = the sampled action, or with squash != 0 clamp(tanh(x)) of the actor's loc output: the
+ * squashed mean); kld = 0.5 * sum_d ((v + (m - emb_mean)^2) / emb_var - 1 + log emb_var - log v).
+ * Writes coef [2A] (the gradient coefficients above, `weight` folded in), kld_terms [A] (scratch: per-dimension
+ * terms), kld [1] (nullable) and adds weight * kld to loss_inout [1] (nullable: the actor loss mean). */
+int rg_sac_kld(const float* x, int64_t ldx, int squash, int batch, int action_dim, const float* emb_mean,
+               const float* emb_var, double weight, float* coef, float* kld_terms, float* kld, float* loss_inout,
+               rg_stream_t stream);
 
 /* Critic segment of SACTrainer.train_step_gen, reagent/training/sac_trainer.py:217-248:
  * y = r + gamma * (min(q1_t, q2_t) - alpha * clamp(log_prob', -2, 2)) * not_done (y = r if gamma == 0);

@@ -183,6 +183,15 @@ SAC_CASES = {
     "sac_crr": dict(state_dim=5, action_dim=3, sizes=[24, 24], activations=["relu", "tanh"],
                     rl=dict(gamma=0.9, target_update_rate=0.1), lr=0.002, batch=48, steps=2, value=True,
                     crr=dict(exponent_beta=0.7, exponent_clamp=3.0), trainer_kw={}),
+    # action-embedding KLD term on the sampled actions' batch statistics (:282-306), and on the squashed means
+    "sac_kld": dict(state_dim=6, action_dim=3, sizes=[32, 24], activations=["relu", "relu"],
+                    rl=dict(gamma=0.97, target_update_rate=0.1), lr=0.003, batch=56, steps=3,
+                    trainer_kw=dict(action_embedding_kld_weight=0.35, action_embedding_mean=[0.1, -0.2, 0.05],
+                                    action_embedding_variance=[0.3, 0.5, 0.8])),
+    "sac_kld_mean": dict(state_dim=6, action_dim=2, sizes=[24, 24], activations=["relu", "relu"],
+                         rl=dict(gamma=0.97, target_update_rate=0.1), lr=0.003, batch=48, steps=2,
+                         trainer_kw=dict(action_embedding_kld_weight=0.2, apply_kld_on_mean=True,
+                                         action_embedding_mean=[0.0, 0.3], action_embedding_variance=[0.6, 0.4])),
 }
 
 

@@ -197,6 +197,9 @@ SIGNATURES = {
     "rg_gaussian_log_prob": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p]),
     "rg_gaussian_head_backward": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int,
                                            c_void_p, c_i64, c_void_p]),
+    "rg_gaussian_head_backward_kld": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int,
+                                               c_void_p, c_i64, c_void_p, c_int, c_void_p]),
+    "rg_sac_kld": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p, c_d] + [c_void_p] * 4 + [c_void_p]),
     "rg_sac_partials": (c_int, [c_int]),
     "rg_sac_critic_head": (c_int, [c_void_p] * 7 + [c_d, c_void_p, c_int] + [c_void_p] * 5 + [c_void_p]),
     "rg_sac_actor_head": (c_int, [c_void_p] * 4 + [c_d, c_int, c_void_p, c_int, c_d, c_d, c_int] + [c_void_p] * 5 + [c_void_p]),

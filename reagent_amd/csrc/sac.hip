@@ -125,10 +125,13 @@ __global__ void gaussian_log_prob_rows_kernel(const float* __restrict__ ls, long
 // d log_prob, produce d loss / d loc_scale [B, 2A].  Both uses of (loc, scale_log) in the reference
 // (sampling and the second FC evaluation inside get_log_prob) are the same values, so their
 // gradients add.
+// kld_coef (nullable) [2A] = (c0, c1) of the action-embedding KLD term (rg_sac_kld): its gradient is c0_d + c1_d x with
+// x the action (kld_on_mean == 0) or the squashed mean clamp(tanh(loc)) (kld_on_mean != 0).
 __global__ void gaussian_head_bwd_kernel(const float* __restrict__ ls, long ldls,
                                          const float* __restrict__ noise, const float* __restrict__ g_a,
                                          long ldga, const float* __restrict__ g_lp, int batch, int A,
-                                         float* __restrict__ d_ls, long lddls) {
+                                         float* __restrict__ d_ls, long lddls, const float* __restrict__ kld_coef,
+                                         int kld_on_mean) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)batch * A) return;
   const int b = (int)(i / A), d = (int)(i % A);
@@ -150,9 +153,20 @@ __global__ void gaussian_head_bwd_kernel(const float* __restrict__ ls, long ldls
   const float dlp_dloc = r2 / sigma;
   const float dlp_ds = r2 * r2 - 1.f;
   const float glp = g_lp ? g_lp[b] : 0.f;
-  const float ga = g_a ? g_a[(long)b * ldga + d] : 0.f;
+  float ga = g_a ? g_a[(long)b * ldga + d] : 0.f;
+  float d_loc_kld = 0.f;
+  if (kld_coef) {
+    const float c0 = kld_coef[d], c1 = kld_coef[A + d];
+    if (kld_on_mean) {
+      const float tm = tanhf(loc);
+      const float inside = (tm >= -1.f + ACT_EPS && tm <= 1.f - ACT_EPS) ? 1.f : 0.f;
+      d_loc_kld = (c0 + c1 * clampf(tm, -1.f + ACT_EPS, 1.f - ACT_EPS)) * inside * (1.f - tm * tm);
+    } else {
+      ga += c0 + c1 * a;
+    }
+  }
   const float tot_a = ga + glp * dlp_da;  // everything that reaches `action`
-  const float d_loc = glp * dlp_dloc + tot_a * da_draw;
+  const float d_loc = glp * dlp_dloc + tot_a * da_draw + d_loc_kld;
   const float d_s = glp * dlp_ds + tot_a * da_draw * r * sigma;
   d_ls[(long)b * lddls + d] = d_loc;
   d_ls[(long)b * lddls + A + d] = d_s * ds_dsl;
@@ -366,14 +380,92 @@ int rg_gaussian_log_prob(const float* loc_scale, int64_t ldls, const float* acti
   return (int)hipGetLastError();
 }
 
-int rg_gaussian_head_backward(const float* loc_scale, int64_t ldls, const float* noise, const float* g_action,
-                              int64_t ldga, const float* g_log_prob, int batch, int action_dim,
-                              float* d_loc_scale, int64_t lddls, rg_stream_t stream) {
+int rg_gaussian_head_backward_kld(const float* loc_scale, int64_t ldls, const float* noise, const float* g_action,
+                                  int64_t ldga, const float* g_log_prob, int batch, int action_dim,
+                                  float* d_loc_scale, int64_t lddls, const float* kld_coef, int kld_on_mean,
+                                  rg_stream_t stream) {
   if (!loc_scale || !noise || !d_loc_scale || batch <= 0 || action_dim <= 0) return RG_EINVAL;
   const long n = (long)batch * action_dim;
   RG_LAUNCH(gaussian_head_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)stream,
             loc_scale, (long)ldls, noise, g_action, (long)ldga, g_log_prob, batch, action_dim, d_loc_scale,
-            (long)lddls);
+            (long)lddls, kld_coef, kld_on_mean);
+  return (int)hipGetLastError();
+}
+
+int rg_gaussian_head_backward(const float* loc_scale, int64_t ldls, const float* noise, const float* g_action,
+                              int64_t ldga, const float* g_log_prob, int batch, int action_dim,
+                              float* d_loc_scale, int64_t lddls, rg_stream_t stream) {
+  return rg_gaussian_head_backward_kld(loc_scale, ldls, noise, g_action, ldga, g_log_prob, batch, action_dim,
+                                       d_loc_scale, lddls, nullptr, 0, stream);
+}
+
+// ---- action-embedding KLD term of the actor loss (sac_trainer.py:282-306) ---------------------------------
+// per action dimension d over the batch: m = mean(x), v = var(x) (unbiased), x = the sampled action or the squashed
+// mean; kld = 0.5 * sum_d ((v + (m - mu)^2) / s2 - 1 + log s2 - log v), loss += weight * kld.
+// d (weight * kld) / d x[b, d] = c0_d + c1_d x[b, d] with
+//   c1 = weight * (1 / s2 - 1 / v) / (B - 1),   c0 = weight * (m - mu) / (B * s2) - c1 * m
+// One workgroup per action dimension: two passes (mean, then centred squares) with fp64 partials combined in a
+// fixed order; the per-dimension terms are summed by one thread of the finishing launch.
+constexpr int KLD_THREADS = 256;
+__device__ __forceinline__ double block_sum_f64(double v, double* scratch) {
+  // wave reduction through shuffles of the two halves
+  for (int off = 32; off >= 1; off >>= 1) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = shfl_xor((int)bits, off), hi = shfl_xor((int)(bits >> 32), off);
+    v += __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+  }
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double s = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  __syncthreads();
+  return s;
+}
+
+__global__ void sac_kld_cols_kernel(const float* __restrict__ x, long ldx, int squash, int batch, int A,
+                                    const float* __restrict__ emb_mean, const float* __restrict__ emb_var, float weight,
+                                    float* __restrict__ coef, float* __restrict__ kld_terms) {
+  __shared__ double scratch[4];
+  const int d = blockIdx.x;
+  auto value = [&](int b) {
+    const float raw = x[(long)b * ldx + d];
+    return squash ? clampf(tanhf(raw), -1.f + ACT_EPS, 1.f - ACT_EPS) : raw;
+  };
+  double s = 0.0;
+  for (int b = threadIdx.x; b < batch; b += KLD_THREADS) s += (double)value(b);
+  const double m = block_sum_f64(s, scratch) / (double)batch;
+  double q = 0.0;
+  for (int b = threadIdx.x; b < batch; b += KLD_THREADS) {
+    const double c = (double)value(b) - m;
+    q += c * c;
+  }
+  const double v = block_sum_f64(q, scratch) / (double)(batch - 1);
+  if (threadIdx.x == 0) {
+    const double mu = emb_mean[d], s2 = emb_var[d];
+    const double c1 = (double)weight * (1.0 / s2 - 1.0 / v) / (double)(batch - 1);
+    const double c0 = (double)weight * (m - mu) / ((double)batch * s2) - c1 * m;
+    coef[d] = (float)c0;
+    coef[A + d] = (float)c1;
+    kld_terms[d] = (float)(0.5 * ((v + (m - mu) * (m - mu)) / s2 - 1.0 + log(s2) - log(v)));
+  }
+}
+
+__global__ void sac_kld_finish_kernel(const float* __restrict__ kld_terms, int A, float weight, float* __restrict__ kld,
+                                      float* __restrict__ loss_inout) {
+  if (threadIdx.x || blockIdx.x) return;
+  float s = 0.f;
+  for (int d = 0; d < A; ++d) s += kld_terms[d];
+  if (kld) kld[0] = s;
+  if (loss_inout) loss_inout[0] += weight * s;
+}
+
+int rg_sac_kld(const float* x, int64_t ldx, int squash, int batch, int action_dim, const float* emb_mean,
+               const float* emb_var, double weight, float* coef, float* kld_terms, float* kld, float* loss_inout,
+               rg_stream_t stream) {
+  if (!x || !emb_mean || !emb_var || !coef || !kld_terms || batch < 2 || action_dim <= 0) return RG_EINVAL;
+  RG_LAUNCH(sac_kld_cols_kernel, dim3(action_dim), dim3(KLD_THREADS), (hipStream_t)stream, x, (long)ldx, squash, batch,
+            action_dim, emb_mean, emb_var, (float)weight, coef, kld_terms);
+  RG_LAUNCH(sac_kld_finish_kernel, dim3(1), dim3(64), (hipStream_t)stream, (const float*)kld_terms, action_dim,
+            (float)weight, kld, loss_inout);
   return (int)hipGetLastError();
 }
 

@@ -470,14 +470,26 @@ def gaussian_log_prob(loc_scale, action, log_prob):
                                               L.ptr(log_prob), L.stream_ptr()))
 
 
-def gaussian_head_backward(loc_scale, noise, g_action, g_log_prob, d_loc_scale):
-    _chk_dev(loc_scale, noise, g_action, g_log_prob, d_loc_scale)
+def gaussian_head_backward(loc_scale, noise, g_action, g_log_prob, d_loc_scale, kld_coef=None, kld_on_mean=False):
+    _chk_dev(loc_scale, noise, g_action, g_log_prob, d_loc_scale, kld_coef)
     B, A = noise.shape
     _run("rg_gaussian_head_backward", dict(B=B, A=A),
-         lambda: L.lib().rg_gaussian_head_backward(L.ptr(loc_scale), _ld(loc_scale), L.ptr(noise),
-                                                   L.ptr(g_action), _ld(g_action) if g_action is not None else 0,
-                                                   L.ptr(g_log_prob), B, A, L.ptr(d_loc_scale),
-                                                   _ld(d_loc_scale), L.stream_ptr()))
+         lambda: L.lib().rg_gaussian_head_backward_kld(L.ptr(loc_scale), _ld(loc_scale), L.ptr(noise),
+                                                       L.ptr(g_action), _ld(g_action) if g_action is not None else 0,
+                                                       L.ptr(g_log_prob), B, A, L.ptr(d_loc_scale),
+                                                       _ld(d_loc_scale), L.ptr(kld_coef), int(kld_on_mean),
+                                                       L.stream_ptr()))
+
+
+def sac_kld(x, squash, emb_mean, emb_var, weight, coef, kld_terms, kld=None, loss_inout=None):
+    """action-embedding KLD term (sac_trainer.py:282-306) over the columns of x [B, A]: gradient coefficients into
+    coef [2A], the value into kld [1], weight * kld added to loss_inout [1]"""
+    _chk_dev(x, emb_mean, emb_var, coef, kld_terms, kld, loss_inout)
+    B, A = x.shape[0], emb_mean.numel()
+    assert coef.numel() == 2 * A and kld_terms.numel() >= A and x.stride(1) == 1
+    _run("rg_sac_kld", dict(B=B, A=A),
+         lambda: L.lib().rg_sac_kld(L.ptr(x), x.stride(0), int(squash), B, A, L.ptr(emb_mean), L.ptr(emb_var), float(weight),
+                                    L.ptr(coef), L.ptr(kld_terms), L.ptr(kld), L.ptr(loss_inout), L.stream_ptr()))
 
 
 def sac_partials(batch: int) -> int:

@@ -176,8 +176,6 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         backprop_through_log_prob: bool = True,
     ) -> None:
         super().__init__()
-        if action_embedding_kld_weight:
-            raise NotImplementedError("the action-embedding KLD term needs batch statistics (SURVEY.md §8e): not built")
         self.rl_parameters = rl if rl is not None else RLParameters()
         d = Optimizer__Union.default
         self.q1_network = q1_network
@@ -201,7 +199,15 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         else:
             self.target_entropy = target_entropy
         self.logged_action_uniform_prior = logged_action_uniform_prior
-        self.add_kld_to_loss = False
+        # action-embedding KLD term of the actor loss (sac_trainer.py:130-140, 282-306)
+        self.add_kld_to_loss = bool(action_embedding_kld_weight)
+        self.apply_kld_on_mean = apply_kld_on_mean
+        if self.add_kld_to_loss:
+            self.kld_weight = action_embedding_kld_weight
+            self.register_buffer("action_emb_mean", None)
+            self.register_buffer("action_emb_variance", None)
+            self.action_emb_mean = torch.tensor(action_embedding_mean)
+            self.action_emb_variance = torch.tensor(action_embedding_variance)
         self.crr_config = crr_config
         if crr_config:
             assert self.value_network is not None
@@ -427,6 +433,17 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                            self._parts["la"], self._parts["ent"], v_cur=v_cur, crr_mode=crr_mode, crr_p0=crr_p0,
                            crr_clamp=crr_clamp, backprop_log_prob=self.backprop_through_log_prob)
         ops.reduce_sum(self._parts["la"], self._parts["la"].numel(), 1.0 / B, self._losses["actor"])
+        if self.add_kld_to_loss:  # + kld_weight * KLD(batch statistics of the action || embedding prior), :282-306
+            A = self.action_emb_mean.numel()
+            if getattr(self, "_kld_coef", None) is None or self._kld_coef.device != dev:
+                f32 = dict(dtype=torch.float32, device=dev)
+                self._kld_coef, self._kld_terms, self._kld = torch.empty(2 * A, **f32), torch.empty(A, **f32), torch.empty(1, **f32)
+            if self.apply_kld_on_mean:  # statistics of squashed_mean = clamp(tanh(loc))
+                x, squash = self._ls[:, :A], True
+            else:
+                x, squash = (self._api if self._panels else self._xa[:, S:]), False
+            ops.sac_kld(x, squash, self.action_emb_mean.to(dev), self.action_emb_variance.to(dev), self.kld_weight,
+                        self._kld_coef, self._kld_terms, self._kld, self._losses["actor"])
 
     def _actor_backward(self, grad_out=None):
         e, S = self._e, self._S
@@ -441,7 +458,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             if has_q2:
                 e["q2"]["stack"].backward(self._dq2a, None, None, None, dx32=self._dx2, skip_wgrad=True)
             ops.add_cols(self._dx1[:, S:], self._dx2[:, S:] if has_q2 else None, self._ga)
-        ops.gaussian_head_backward(self._ls, self._noise_cur, self._ga, self._glp.reshape(-1), self._dls)
+        ops.gaussian_head_backward(self._ls, self._noise_cur, self._ga, self._glp.reshape(-1), self._dls,
+                                   kld_coef=self._kld_coef if self.add_kld_to_loss else None,
+                                   kld_on_mean=self.add_kld_to_loss and self.apply_kld_on_mean)
         dls = self._dls if grad_out is None else self._dls * grad_out
         a = e["actor"]
         held = held_gradients(a["slab"], a["params"])

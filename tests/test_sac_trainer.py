@@ -31,7 +31,8 @@ def build(g, device, precision=L.PREC_F32):
                 p.copy_(init)
     adam = lambda: Optimizer__Union.default(lr=c["lr"])  # noqa: E731
     tr = SACTrainer(actor.to(device), q1.to(device), q2.to(device), rl=RLParameters(**c["rl"]),
-                    q_network_optimizer=adam(), actor_network_optimizer=adam(), alpha_optimizer=adam())
+                    q_network_optimizer=adam(), actor_network_optimizer=adam(), alpha_optimizer=adam(),
+                    **c.get("trainer_kw", {}))
     return tr.to(device)
 
 
@@ -155,3 +156,57 @@ def test_crr_weight_fn_is_the_reference_arithmetic():
     assert torch.equal(w, torch.clamp(torch.exp(adv / 0.7), 0.0, 3.0))
     with pytest.raises(AssertionError):
         CRRWeightFn()
+
+
+# ---- action-embedding KLD term (sac_trainer.py:130-140, 282-306) ----
+@pytest.mark.parametrize("name", ["sac_kld", "sac_kld_mean"])
+@pytest.mark.parametrize("path", ["generator", "native"])
+def test_sac_action_embedding_kld(backend, name, path):
+    g = Golden(name)
+    tr = build(g, backend.device)
+    assert tr.add_kld_to_loss and "action_emb_mean" in tr.state_dict() and "action_emb_variance" in tr.state_dict()
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    names = ["q1_loss", "q2_loss", "actor_loss", "alpha_loss"]
+    for s in range(g.cfg["steps"]):
+        batch = synthetic.to_policy_input(g.batch(s), backend.device)
+        if path == "generator":
+            tr.set_noise(g.t(f"step{s}_noise_next"), g.t(f"step{s}_noise_cur"))
+            got = dict(zip(names, lightning_like_step(tr, opts, batch)))
+        else:
+            got = tr.train_step_native(batch, g.t(f"step{s}_noise_next"), g.t(f"step{s}_noise_cur"))
+        for nm in names:
+            ref = float(g.t(f"step{s}_{nm}"))
+            assert abs(float(got[nm]) - ref) <= 1e-4 * abs(ref) + 2e-6, (s, nm, float(got[nm]), ref)
+        check(tr, g, s)
+
+
+@pytest.mark.parametrize("on_mean", [False, True])
+def test_kld_kernels_against_autograd(backend, on_mean):
+    """rg_sac_kld + the KLD branch of the head backward against torch autograd of the reference formula"""
+    from reagent_amd import ops
+
+    B, A, w = 77, 4, 0.6
+    gen = torch.Generator().manual_seed(5)
+    ls = torch.randn(B, 2 * A, generator=gen)
+    noise = torch.randn(B, A, generator=gen)
+    mu, s2 = torch.randn(A, generator=gen) * 0.3, torch.rand(A, generator=gen) + 0.2
+    lsr = ls.clone().requires_grad_()
+    loc, sl = lsr[:, :A], lsr[:, A:].clamp(-2, 2)
+    eps = 1e-6
+    act = torch.tanh(loc + noise * sl.exp()).clamp(-1 + eps, 1 - eps)
+    x = torch.tanh(loc).clamp(-1 + eps, 1 - eps) if on_mean else act
+    m, v = x.mean(0), x.var(0)
+    kld = 0.5 * ((v + (m - mu) ** 2) / s2 - 1 + s2.log() - v.log()).sum()
+    (w * kld).backward()
+
+    d = backend.device
+    lsd, nd = ls.to(d), noise.to(d)
+    action = torch.empty(B, A, device=d)
+    ops.gaussian_head_forward(lsd, nd, action, None, None)
+    coef, terms, out, loss = torch.empty(2 * A, device=d), torch.empty(A, device=d), torch.empty(1, device=d), torch.full((1,), 2.0, device=d)
+    ops.sac_kld(lsd[:, :A] if on_mean else action, on_mean, mu.to(d), s2.to(d), w, coef, terms, out, loss)
+    assert abs(out.item() - kld.item()) <= 1e-5 * max(1.0, abs(kld.item()))
+    assert abs(loss.item() - (2.0 + w * kld.item())) <= 1e-5 * max(1.0, abs(kld.item()))
+    dls = torch.empty(B, 2 * A, device=d)
+    ops.gaussian_head_backward(lsd, nd, None, None, dls, kld_coef=coef, kld_on_mean=on_mean)
+    assert (dls.cpu() - lsr.grad).abs().max() <= 1e-6 + 1e-4 * lsr.grad.abs().max()
