@@ -135,8 +135,9 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
   }
 }
 
-template <int TN, int NW, int PITCH>
-__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
+// DX_ONLY: a frozen stack — only the input gradient is produced, no dZ fragments are written (rg_mlp_desc.dx_only)
+template <int TN, int NW, int PITCH, bool DX_ONLY>
+__device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
   constexpr int THREADS = MlpCfg<NW>::THREADS, RING = MlpCfg<NW>::RING;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
@@ -148,7 +149,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
   const int nop = round_up(a.dims[L], 32);
   load_tile_to_lds<float, THREADS>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  if (a.dz_frag[L - 1]) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, NW, lane);
+  if (!DX_ONLY) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, NW, lane);
   if (a.db_part[L - 1] && tid < a.dims[L]) {
     float s = 0.f;
     for (int r = 0; r < FB_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]);
@@ -192,11 +193,11 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
     unsigned PK[4][TN][8];
     if (use_sign) {
-      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, true>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
-                                                                   N / 32, blockIdx.x * 4, wave, lane, PK)));
+      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, true, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
+                                                                             N / 32, blockIdx.x * 4, wave, lane, PK)));
     } else {
-      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, false>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
-                                                                    N / 32, blockIdx.x * 4, wave, lane, PK)));
+      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, false, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
+                                                                              N / 32, blockIdx.x * 4, wave, lane, PK)));
     }
     __syncthreads();  // every wave is done reading dZ_l
     store_packed_tiles<TN>(act, pitch, PK, wave, lane);
@@ -218,6 +219,15 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
       }
     }
   }
+}
+
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
+  mlp_bwd_fused_body<TN, NW, PITCH, false>(a);
+}
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_dx_kernel(MlpArgs a) {
+  mlp_bwd_fused_body<TN, NW, PITCH, true>(a);
 }
 
 // ---- weight gradient from fragment-ordered operands ------------------------------------------
@@ -944,7 +954,8 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   } else {
     const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
     const dim3 grid(n_wg);
-    RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+    if (d->dx_only) RG_LAUNCH_FUSED(mlp_bwd_dx_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+    else RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
     rc = (int)hipGetLastError();
   }
   if (rc) return rc;

@@ -285,7 +285,7 @@ __device__ __forceinline__ void x3_fwd_pack(f32x16 (&acc)[X3_TM][TN], const floa
 }
 
 // dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
-template <int TN, int ACT, bool USE_SIGN>
+template <int TN, int ACT, bool USE_SIGN, bool STORE_DZ = true>
 __device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16_t* h_frag, long h_lo,
                                             const unsigned (&sg)[TN], bf16_t* dz_dst, long dz_lo, float* db_part, int NT,
                                             int mb_base, int wave, int lane, unsigned (&PH)[X3_TM][TN][8],
@@ -321,9 +321,12 @@ __device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) split_pack(v[2 * i], v[2 * i + 1], PH[tm][tn][i], PL[tm][tn][i]);
-      if (dz_dst) {
+      if (STORE_DZ) {
         store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PH[tm][tn]);
         store_packed_frags(dz_dst + dz_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
+      } else {
+        pin_packed(PH[tm][tn]);
+        pin_packed(PL[tm][tn]);
       }
     });
     colsum += shfl_xor(colsum, 32);
@@ -403,8 +406,8 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   }
 }
 
-template <int TN, int NW, int PITCH>
-__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
+template <int TN, int NW, int PITCH, bool DX_ONLY>
+__device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
   constexpr int THREADS = NW * 64, RING = RG_X3_RING, LO = X3_BM * PITCH;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
@@ -416,7 +419,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
   const int nop = round_up(a.dims[L], 32);
   load_tile_split<float, THREADS, LO>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  if (a.dz_frag[L - 1]) {
+  if (!DX_ONLY) {
     emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
     emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
   }
@@ -447,11 +450,11 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
     unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
     if (use_sign) {
-      RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, true>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
+      RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, true, !DX_ONLY>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
                                                                a.dz_lo[l - 1], dbp, N / 32, blockIdx.x * X3_TM, wave, lane,
                                                                PH, PL)));
     } else {
-      RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, false>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
+      RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, false, !DX_ONLY>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
                                                                 a.dz_lo[l - 1], dbp, N / 32, blockIdx.x * X3_TM, wave, lane,
                                                                 PH, PL)));
     }
@@ -476,6 +479,15 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
       }
     }
   }
+}
+
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
+  mlp_bwd_x3_body<TN, NW, PITCH, false>(a);
+}
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_dx_kernel(MlpArgs a) {
+  mlp_bwd_x3_body<TN, NW, PITCH, true>(a);
 }
 
 #define RG_LAUNCH_X3(KERNEL, hidden, pitch, grid, lds, stream, args)                                         \
@@ -510,7 +522,8 @@ int x3_forward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
 int x3_backward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
   const dim3 grid(x3_grid(a.batch, true));
-  RG_LAUNCH_X3(mlp_bwd_x3_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+  if (d->dx_only) RG_LAUNCH_X3(mlp_bwd_x3_dx_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+  else RG_LAUNCH_X3(mlp_bwd_x3_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();
 }
 

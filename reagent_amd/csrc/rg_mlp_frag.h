@@ -474,7 +474,9 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
 }
 
 // dZ_below = dH * act'(H_below); column sums of dZ_below (bias gradient) for this workgroup
-template <int TN, int ACT, bool USE_SIGN>
+// STORE_DZ is a compile-time property (a run-time test of dz_dst inside the unrolled tile loops cost the 512-wide
+// kernel 245 spilled registers and 124 MB of scratch traffic per launch)
+template <int TN, int ACT, bool USE_SIGN, bool STORE_DZ = true>
 __device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16_t* h_frag,
                                                 const unsigned (&sg)[2 * TN], bf16_t* dz_dst, float* db_part, int NT,
                                                 int mb_base, int wave, int lane, unsigned (&PK)[4][TN][8]) {
@@ -507,7 +509,9 @@ __device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16
         }
       }
       pack_tile(v, PK[tm][tn]);
-      if (dz_dst) store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
+      if (STORE_DZ) store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
+      else pin_packed(PK[tm][tn]);  // the stores force the bf16 packing here; without them the compiler keeps all
+                                    // eight tiles in fp32 until the LDS pass after the barrier and spills 497 registers
     });
     colsum += shfl_xor(colsum, 32);
     if (db_part && lane < 32) db_part[col] = colsum;

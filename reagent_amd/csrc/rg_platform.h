@@ -75,6 +75,10 @@ __device__ __forceinline__ int opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// "these eight registers are needed now": an empty asm that consumes them (forces a computation to be finished here)
+__device__ __forceinline__ void pin_packed(const unsigned (&P)[8]) {
+  asm volatile("" ::"v"(P[0]), "v"(P[1]), "v"(P[2]), "v"(P[3]), "v"(P[4]), "v"(P[5]), "v"(P[6]), "v"(P[7]));
+}
 // scheduling fence: nothing is moved across it (pins "issue the loads, then the MFMA block")
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // ---- LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS at

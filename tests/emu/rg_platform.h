@@ -113,6 +113,7 @@ static inline T gather_from(T v, int src_lane) {
   const T* all = (const T*)::emu::wave_gather(&v, sizeof(T));
   return all[src_lane & 63];
 }
+static inline void pin_packed(const unsigned (&)[8]) {}
 static inline float shfl_xor(float v, int mask) { return gather_from(v, lane_id() ^ mask); }
 static inline int shfl_xor(int v, int mask) { return gather_from(v, lane_id() ^ mask); }
 static inline float swap_adjacent_lanes(float v) { return gather_from(v, lane_id() ^ 1); }
