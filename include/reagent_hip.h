@@ -278,6 +278,14 @@ int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const u
                       const float* log_prob, int batch, int num_actions, float* action_onehot,
                       float* next_action_onehot, float* not_terminal, float* action_probability,
                       rg_stream_t stream);
+/* PolicyNetworkInputMaker.__call__ (gym/preprocessors/trainer_preprocessor.py:161-227, dense path) in one launch:
+ * action_out / next_action_out [B, A] = rescale_actions(training/utils.py:13-29) from the environment's range to the
+ * training range, next_action rows of terminal transitions zeroed; not_terminal [B] = 1 - terminal;
+ * action_probability [B] (nullable) = exp(log_prob).  ranges [4 * A] = prev_min | prev_max | new_min | new_max per
+ * action dimension.  Same operation order and roundings as the torch expression it replaces. */
+int rg_make_policy_input(const float* action, int64_t lda, const float* next_action, int64_t ldna, const uint8_t* terminal,
+                         const float* log_prob, const float* ranges, int batch, int action_dim, float* action_out,
+                         float* next_action_out, float* not_terminal, float* action_probability, rg_stream_t stream);
 
 /* ---- dense feature normalization ---------------------------------------------------------- */
 

@@ -772,6 +772,38 @@ def gen_policy_batch():
     _save("policy_batch", dict(norm=_norm_cfg(norm), action_norm=_norm_cfg(act_norm), sorted_features=feats), arrays)
 
 
+def gen_policy_input_maker():
+    """PolicyNetworkInputMaker.__call__ of the reference (gym/preprocessors/trainer_preprocessor.py:161-227) on a sampled
+    replay batch: per-dimension environment ranges, terminal rows"""
+    rh._install()
+    import collections
+
+    from oracle.stubs import install_gym
+
+    install_gym()
+    from reagent.gym.preprocessors.trainer_preprocessor import PolicyNetworkInputMaker
+
+    B, S, A = 300, 5, 4
+    g = torch.Generator().manual_seed(33)
+    low = np.array([-2.0, -1.0, 0.0, -0.5], dtype=np.float32)
+    high = np.array([2.0, 3.0, 10.0, 0.5], dtype=np.float32)
+    Batch = collections.namedtuple("Batch", "state next_state action next_action reward terminal log_prob")
+    span = torch.tensor(high - low)
+    batch = Batch(state=torch.randn(B, S, generator=g), next_state=torch.randn(B, S, generator=g),
+                  action=torch.rand(B, A, generator=g) * span + torch.tensor(low),  # inside the range: rescale_actions asserts it
+                  next_action=torch.rand(B, A, generator=g) * span + torch.tensor(low),  # inside the range: rescale_actions asserts it
+                  reward=torch.randn(B, 1, generator=g), terminal=torch.rand(B, 1, generator=g) > 0.7,
+                  log_prob=-torch.rand(B, 1, generator=g) * 3)
+    out = PolicyNetworkInputMaker(low, high)(batch)
+    arrays = {f"in_{k}": _np(getattr(batch, k)) for k in Batch._fields}
+    arrays.update(action_low=low, action_high=high)
+    for k in ("state", "next_state", "action", "next_action"):
+        arrays[f"out_{k}"] = _np(getattr(out, k).float_features)
+    arrays["out_reward"], arrays["out_not_terminal"] = _np(out.reward), _np(out.not_terminal)
+    arrays["out_action_probability"] = _np(out.extras.action_probability)
+    _save("policy_input_maker", dict(batch=B, state_dim=S, action_dim=A), arrays)
+
+
 def gen_sum_tree():
     """reference SumTree (sum_tree.py) driven by seeded numpy / `random`: tree contents after a stream
     of sets, descents for fixed query values, seeded stratified samples."""
@@ -909,6 +941,7 @@ def main():
     gen_preprocessor()
     gen_offline_table()
     gen_policy_batch()
+    gen_policy_input_maker()
     gen_sum_tree()
     gen_prioritized()
 

@@ -173,6 +173,8 @@ SIGNATURES = {
     "rg_sumtree_get": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_make_dqn_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rg_make_policy_input": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_normalize_dense": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,
                                     c_void_p, c_i64, c_int, c_void_p]),
     "rg_table_dqn_batch": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_int, c_void_p,

@@ -223,6 +223,34 @@ __global__ void make_dqn_input_kernel(const int64_t* __restrict__ action,
   }
 }
 
+// PolicyNetworkInputMaker (trainer_preprocessor.py:161-227, dense path) in one launch:
+//   action, next_action = rescale_actions(., new = training range, prev = the environment's range)
+//                       = ((a - prev_min) / (prev_max - prev_min)) * (new_max - new_min) + new_min   (training/utils.py:13-29),
+//   next_action rows of terminal transitions are zero, not_terminal = 1 - terminal, action_probability = exp(log_prob).
+// ranges [4][A] = prev_min, prev_max, new_min, new_max per action dimension.  The arithmetic keeps the reference's
+// operation order with every product and sum rounded on its own (no fused multiply-add), so the fp32 results are torch's.
+__global__ void make_policy_input_kernel(const float* __restrict__ action, long lda, const float* __restrict__ next_action,
+                                         long ldna, const uint8_t* __restrict__ terminal, const float* __restrict__ log_prob,
+                                         const float* __restrict__ ranges, int batch, int A, float* __restrict__ action_out,
+                                         float* __restrict__ next_action_out, float* __restrict__ not_terminal,
+                                         float* __restrict__ action_probability) {
+  const long total = (long)batch * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / A;
+    const int d = (int)(i % A);
+    const float lo = ranges[d], hi = ranges[A + d], tl = ranges[2 * A + d], th = ranges[3 * A + d];
+    const float prev_range = __fsub_rn(hi, lo), new_range = __fsub_rn(th, tl);
+    const float nt = 1.0f - (terminal[b] ? 1.f : 0.f);
+    const float a = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(action[b * lda + d], lo), prev_range), new_range), tl);
+    const float n = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(next_action[b * ldna + d], lo), prev_range), new_range), tl);
+    action_out[i] = a;
+    next_action_out[i] = terminal[b] ? 0.f : n;  // zeros_like + assignment of the non-terminal rows (:186-196)
+    if (d == 0) {
+      not_terminal[b] = nt;
+      if (action_probability) action_probability[b] = expf(log_prob[b]);
+    }
+  }
+}
 
 // ---- sampled indices -> rlt.DiscreteDqnInput in one launch --------------------------------------
 // ReplayBuffer.sample_transition_batch (:614-706, stack_size 1) + DiscreteDqnInputMaker
@@ -412,6 +440,21 @@ int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const u
   if (blocks > 8192) blocks = 8192;
   RG_LAUNCH(make_dqn_input_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, action,
             next_action, terminal, log_prob, batch, num_actions, action_onehot, next_action_onehot,
+            not_terminal, action_probability);
+  return (int)hipGetLastError();
+}
+
+int rg_make_policy_input(const float* action, int64_t lda, const float* next_action, int64_t ldna, const uint8_t* terminal,
+                         const float* log_prob, const float* ranges, int batch, int action_dim, float* action_out,
+                         float* next_action_out, float* not_terminal, float* action_probability, rg_stream_t stream) {
+  if (!action || !next_action || !terminal || !ranges || !action_out || !next_action_out || !not_terminal ||
+      (action_probability && !log_prob) || batch < 0 || action_dim <= 0)
+    return RG_EINVAL;
+  if (batch == 0) return RG_OK;
+  long blocks = ((long)batch * action_dim + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  RG_LAUNCH(make_policy_input_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, action, (long)lda,
+            next_action, (long)ldna, terminal, log_prob, ranges, batch, action_dim, action_out, next_action_out,
             not_terminal, action_probability);
   return (int)hipGetLastError();
 }

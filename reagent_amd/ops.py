@@ -234,6 +234,20 @@ def make_dqn_input(action, next_action, terminal, log_prob, num_actions, action_
                                            L.ptr(not_terminal), L.ptr(action_probability), L.stream_ptr()))
 
 
+def make_policy_input(action, next_action, terminal, log_prob, ranges, action_out, next_action_out, not_terminal,
+                      action_probability=None):
+    """PolicyNetworkInputMaker's arithmetic in one launch; ranges [4, A] = prev_min, prev_max, new_min, new_max"""
+    _chk_dev(action, next_action, terminal, log_prob, ranges, action_out, next_action_out, not_terminal, action_probability)
+    B, A = action.shape
+    assert action.stride(1) == 1 and next_action.stride(1) == 1 and action_out.is_contiguous() and next_action_out.is_contiguous()
+    assert ranges.is_contiguous() and ranges.numel() == 4 * A and terminal.element_size() == 1
+    _run("rg_make_policy_input", dict(B=B, A=A),
+         lambda: L.lib().rg_make_policy_input(L.ptr(action), action.stride(0), L.ptr(next_action), next_action.stride(0),
+                                              L.ptr(terminal), L.ptr(log_prob), L.ptr(ranges), B, A, L.ptr(action_out),
+                                              L.ptr(next_action_out), L.ptr(not_terminal), L.ptr(action_probability),
+                                              L.stream_ptr()))
+
+
 def normalize_dense(x, presence_u8, cols_dev, n_out, quantiles, out):
     _chk_dev(x, presence_u8, cols_dev, quantiles, out)
     _run("rg_normalize_dense", dict(B=x.shape[0], n_out=n_out),

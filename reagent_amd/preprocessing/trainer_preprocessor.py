@@ -72,19 +72,41 @@ class PolicyNetworkInputMaker:
         self.train_high = torch.tensor(train_high)
         self._on = {}  # device -> the four range tensors resident there (no host-to-device copy per batch)
 
+    def _ranges(self, dev, A):
+        """[4, A] = prev_min, prev_max, new_min, new_max per action dimension, resident on `dev`"""
+        r = self._on.get((dev, A))
+        if r is None:
+            rows = [t.reshape(-1).float().expand(A) if t.numel() == 1 else t.reshape(-1).float()
+                    for t in (self.action_low, self.action_high, self.train_low, self.train_high)]
+            r = self._on[(dev, A)] = torch.stack(rows).contiguous().to(dev)
+        return r
+
     def __call__(self, batch):
-        dev = batch.action.device
-        if dev not in self._on:
-            self._on[dev] = tuple(t.to(dev) for t in (self.action_low, self.action_high, self.train_low, self.train_high))
-        lo, hi, tl, th = self._on[dev]
-        not_terminal = 1.0 - batch.terminal.float()
-        action = rescale_actions(batch.action, new_min=tl, new_max=th, prev_min=lo, prev_max=hi)
-        next_action = rescale_actions(batch.next_action, new_min=tl, new_max=th, prev_min=lo, prev_max=hi)
-        next_action = next_action * not_terminal  # zero rows of terminal transitions (:190-198)
+        """one launch (rg_make_policy_input): the operations and roundings of
+        rescale_actions(...) / next_action * not_terminal / 1 - terminal / log_prob.exp()"""
+        def f32(t):
+            t = t if t.dtype == torch.float32 else t.float()
+            return t if t.stride(-1) == 1 else t.contiguous()
+
+        a, na, lp = f32(batch.action), f32(batch.next_action), f32(batch.log_prob).contiguous()
+        term = batch.terminal if batch.terminal.element_size() == 1 else (batch.terminal != 0)
+        term = term.contiguous()
+        assert a.dim() == 2 and na.shape == a.shape, "dense [batch, action_dim] actions"
+        dev = a.device
+        B, A = a.shape
+        action = torch.empty(B, A, dtype=torch.float32, device=dev)
+        next_action = torch.empty(B, A, dtype=torch.float32, device=dev)
+        not_terminal = torch.empty(batch.terminal.shape, dtype=torch.float32, device=dev)
+        prob = torch.empty(lp.shape, dtype=torch.float32, device=dev)
+        ops.make_policy_input(a, na, term, lp, self._ranges(dev, A), action, next_action, not_terminal, prob)
+        return self._pack(batch, action, next_action, not_terminal, prob)
+
+    @staticmethod
+    def _pack(batch, action, next_action, not_terminal, action_probability):
         return rlt.PolicyNetworkInput(
             state=rlt.FeatureData(batch.state), next_state=rlt.FeatureData(batch.next_state),
             action=rlt.FeatureData(action), next_action=rlt.FeatureData(next_action), reward=batch.reward,
             not_terminal=not_terminal, step=None, time_diff=None,
-            extras=rlt.ExtraData(mdp_id=None, sequence_number=None, action_probability=batch.log_prob.exp(),
+            extras=rlt.ExtraData(mdp_id=None, sequence_number=None, action_probability=action_probability,
                                  max_num_actions=None, metrics=None),
         )

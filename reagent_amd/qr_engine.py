@@ -143,7 +143,8 @@ class GroupedQR:
         else:  # SARSA: the logged next action (qrdqn_trainer.py:139-141); terminal rows carry none
             ops.qr_select_action(None, tr._f32c(b.next_action), False, self.key_next)
         sp2 = self.sp_next.build(self.key_next)
-        self.zt.zero_()  # rows without a next action (SARSA, terminal) keep zero quantiles
+        if not tr.maxq_learning:  # rows without a next action (SARSA: terminal) keep zero quantiles; the
+            self.zt.zero_()       # masked arg max gives every row one, and the scatter then writes every row
         fused_forward_grouped(tg.st, tg.gh, next_state, sp2, self.zt, scatter=True, save=False)
         # current quantiles of the logged action (grouped space of the logged action; saved for the backward)
         ops.qr_select_action(None, tr._f32c(b.action), False, self.key_cur)

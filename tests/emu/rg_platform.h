@@ -113,6 +113,11 @@ static inline T gather_from(T v, int src_lane) {
   const T* all = (const T*)::emu::wave_gather(&v, sizeof(T));
   return all[src_lane & 63];
 }
+// individually rounded fp32 operations (HIP intrinsics; the host target has no fused multiply-add to contract into)
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 static inline void pin_packed(const unsigned (&)[8]) {}
 static inline float shfl_xor(float v, int mask) { return gather_from(v, lane_id() ^ mask); }
 static inline int shfl_xor(int v, int mask) { return gather_from(v, lane_id() ^ mask); }

@@ -275,3 +275,26 @@ def test_offline_table_loop_trains_over_epochs(emu_lib):
     for _ in range(6):
         shuffled.run_epoch()
     assert float(tb.train_step_native(probe)) < first
+
+
+def test_policy_network_input_maker_matches_reference(backend):
+    """PolicyNetworkInputMaker (one launch, rg_make_policy_input) against the reference class on the same sampled batch
+    (tests/golden/policy_input_maker.npz): rescaled actions, zeroed terminal next-actions and not_terminal bit-exact
+    (same operations, each rounded on its own), exp(log_prob) within one ulp of torch's"""
+    import collections
+
+    from reagent_amd.preprocessing import PolicyNetworkInputMaker
+
+    g = Golden("policy_input_maker")
+    Batch = collections.namedtuple("Batch", "state next_state action next_action reward terminal log_prob")
+    dev = backend.device
+    batch = Batch(**{k: g.t(f"in_{k}").to(dev) for k in Batch._fields})
+    out = PolicyNetworkInputMaker(g.a("action_low"), g.a("action_high"))(batch)
+    assert torch.equal(out.action.float_features.cpu(), g.t("out_action"))
+    assert torch.equal(out.next_action.float_features.cpu(), g.t("out_next_action"))
+    assert torch.equal(out.not_terminal.cpu(), g.t("out_not_terminal")) and out.not_terminal.shape == (g.cfg["batch"], 1)
+    assert torch.equal(out.state.float_features.cpu(), g.t("out_state")) and torch.equal(out.reward.cpu(), g.t("out_reward"))
+    p, ref = out.extras.action_probability.cpu(), g.t("out_action_probability")
+    assert p.shape == ref.shape and ((p - ref).abs() <= 1.2e-7 * ref.abs()).all()
+    term = g.t("in_terminal").reshape(-1)
+    assert (out.next_action.float_features.cpu()[term] == 0).all() and term.any()
