@@ -77,6 +77,22 @@ int rg_fc_wgrad(const void* dzt, int64_t lddzt, const void* xt, int64_t ldxt, fl
 int rg_transpose_cast(const void* src, int src_dt, int64_t ld_src, int rows, int cols, void* dst,
                       int64_t ld_dst, void* dst_t, int64_t ld_t, int dst_dt, rg_stream_t stream);
 
+/* nn.LayerNorm(n) between a Linear and its activation — FullyConnectedNetwork's use_layer_norm option
+ * (reagent/models/fully_connected_network.py:128-130).  z [batch, n] fp32 = the Linear's output (rg_fc_forward with
+ * RG_ACT_LINEAR); y (nullable, element type y_dtype) and / or y32 (nullable) = act(((z - mean) / sqrt(var + eps)) *
+ * gamma + beta) with the row's mean and biased variance; mean / rstd [batch] (nullable) are what the backward reads. */
+int rg_layer_norm_forward(const float* z, int64_t ldz, const float* gamma, const float* beta, double eps, int act,
+                          int batch, int n, void* y, int y_dtype, int64_t ldy, float* y32, int64_t ldy32, float* mean,
+                          float* rstd, rg_stream_t stream);
+/* g [batch, n] = d loss / d (LayerNorm output, i.e. with the activation's derivative already applied): writes
+ * dz (nullable, dz_dtype) and / or dz32 = d loss / d z, dgamma [n] and dbeta [n] (overwritten; per-workgroup partials in
+ * `workspace`, summed in a fixed order). */
+size_t rg_layer_norm_backward_workspace_bytes(int batch, int n);
+int rg_layer_norm_backward(const float* g, int64_t ldg, const float* z, int64_t ldz, const float* mean, const float* rstd,
+                           const float* gamma, int batch, int n, void* dz, int dz_dtype, int64_t lddz, float* dz32,
+                           int64_t lddz32, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                           rg_stream_t stream);
+
 /* dz = dy * act'(z) written through the activation output y = act(z), fp32 [rows, cols]: turns the
  * gradient w.r.t. a non-linear OUTPUT layer (FullyConnectedActor's tanh head,
  * reagent/models/actor.py:71-75) into the pre-activation gradient the backward entry points take. */

@@ -70,6 +70,10 @@ DQN_CASES = {
     "dqn_dueling": dict(state_dim=12, num_actions=4, sizes=[48, 32], activations=["relu", "leaky_relu"],
                         rl=dict(gamma=0.95, target_update_rate=0.1, maxq_learning=True, q_network_loss="huber"),
                         lr=0.003, double_q=True, batch=72, steps=3, p_impossible=0.2, with_steps=False, dueling=True),
+    # use_layer_norm: Linear -> LayerNorm -> activation on the hidden layers
+    "dqn_layernorm": dict(state_dim=11, num_actions=4, sizes=[40, 24], activations=["relu", "tanh"],
+                          rl=dict(gamma=0.95, target_update_rate=0.1, maxq_learning=True, q_network_loss="huber"),
+                          lr=0.003, double_q=True, batch=64, steps=3, p_impossible=0.2, with_steps=False, layer_norm=True),
 }
 
 
@@ -77,7 +81,7 @@ def gen_dqn(name, c):
     cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
                       double_q=c["double_q"], seed=0, cpe_metrics=cpe_metrics, bcq_threshold=c.get("bcq_threshold"),
-                      dueling=c.get("dueling", False))
+                      dueling=c.get("dueling", False), layer_norm=c.get("layer_norm", False))
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
@@ -98,7 +102,7 @@ def gen_dqn(name, c):
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
         arrays[f"step{s}_q"] = _np(tr.all_action_scores)
-        if c.get("dueling"):  # d loss / d parameters as autograd produced them (newer fixtures carry them)
+        if c.get("dueling") or c.get("layer_norm"):  # d loss / d parameters as autograd produced them (newer fixtures carry them)
             for i, gr in enumerate(loop.last_grads[0]):
                 arrays[f"step{s}_grad_{i}"] = _np(gr)
         for i, p in enumerate(tr.q_network.parameters()):
@@ -192,12 +196,16 @@ SAC_CASES = {
                          rl=dict(gamma=0.97, target_update_rate=0.1), lr=0.003, batch=48, steps=2,
                          trainer_kw=dict(action_embedding_kld_weight=0.2, apply_kld_on_mean=True,
                                          action_embedding_mean=[0.0, 0.3], action_embedding_variance=[0.6, 0.4])),
+    # layer-normed critics (FullyConnectedCritic(use_layer_norm=True)), plain actor
+    "sac_ln_critics": dict(state_dim=6, action_dim=2, sizes=[32, 24], activations=["relu", "relu"],
+                           rl=dict(gamma=0.98, target_update_rate=0.1), lr=0.003, batch=48, steps=3, critic_layer_norm=True),
 }
 
 
 def gen_sac(name, c):
     tr = rh.build_sac(c["state_dim"], c["action_dim"], c["sizes"], c["activations"], c["rl"], c["lr"], seed=0,
-                      value=c.get("value", False), crr=c.get("crr"), **c.get("trainer_kw", {}))
+                      value=c.get("value", False), crr=c.get("crr"), critic_layer_norm=c.get("critic_layer_norm", False),
+                      **c.get("trainer_kw", {}))
     arrays = {}
     nets = dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network)
     if c.get("value"):

@@ -90,7 +90,7 @@ def make_adam(lr=1e-3, **kw):
 
 
 def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_q=True, seed=0,
-              num_atoms=None, cpe_metrics=None, bcq_threshold=None, dueling=False):
+              num_atoms=None, cpe_metrics=None, bcq_threshold=None, dueling=False, layer_norm=False):
     """Reference FullyConnectedDQN (+ target) and DQNTrainer / QRDQNTrainer.  cpe_metrics: None = CPE
     off; a list of extra metric names (may be empty) = calc_cpe_in_training with reward_network,
     q_network_cpe and its target of output width (len(cpe_metrics) + 1) * num_actions
@@ -105,8 +105,8 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
         from reagent.models.dueling_q_network import DuelingQNetwork
 
         q = DuelingQNetwork.make_fully_connected(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
-    else:
-        q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
+    else:  # layer_norm: Linear -> LayerNorm -> activation on the hidden layers (fully_connected_network.py:128-130)
+        q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms, use_layer_norm=layer_norm)
     qt = q.get_target_network()
     actions = [str(i) for i in range(num_actions)]
     cpe = cpe_metrics is not None
@@ -145,7 +145,8 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
     return trainer
 
 
-def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, value=False, crr=None, **trainer_kw):
+def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, value=False, crr=None,
+              critic_layer_norm=False, **trainer_kw):
     """value=True adds a value network (FloatFeatureFullyConnected state -> 1, what the reference's value net builder
     makes); crr = CRRWeightFn arguments."""
     _install()
@@ -155,8 +156,8 @@ def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, 
 
     torch.manual_seed(seed)
     actor = GaussianFullyConnectedActor(state_dim, action_dim, sizes, activations)
-    q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
-    q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
+    q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm)
+    q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm)
     if value:
         from reagent.models.fully_connected_network import FloatFeatureFullyConnected
 

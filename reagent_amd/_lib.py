@@ -173,6 +173,11 @@ SIGNATURES = {
     "rg_sumtree_get": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_make_dqn_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rg_layer_norm_forward": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_d, c_int, c_int, c_int, c_void_p, c_int, c_i64,
+                                       c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
+    "rg_layer_norm_backward_workspace_bytes": (c_sz, [c_int, c_int]),
+    "rg_layer_norm_backward": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
     "rg_make_policy_input": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_normalize_dense": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,

@@ -110,9 +110,14 @@ class FCStack:
     activation code of layer i (the last one is the output activation).
     """
 
-    def __init__(self, weights, biases, acts: List[int], precision: int):
+    def __init__(self, weights, biases, acts: List[int], precision: int, layer_norms=None):
+        """layer_norms (optional): per layer None or an nn.LayerNorm-like holder (.weight, .bias, .eps) applied between
+        the Linear and its activation (fully_connected_network.py:128-130)"""
         assert len(weights) == len(biases) == len(acts)
         self.weights, self.biases, self.acts = list(weights), list(biases), list(acts)
+        self.lns = list(layer_norms) if layer_norms is not None else [None] * len(weights)
+        assert len(self.lns) == len(weights)
+        self._ln_grads = [None] * len(weights)  # (dgamma, dbeta) destinations, bound by the trainer (bind_ln_grads)
         self.precision = precision
         self.cdtype = ops.compute_dtype(precision)
         self.dims = [self.weights[0].shape[1]] + [w.shape[0] for w in self.weights]
@@ -179,8 +184,23 @@ class FCStack:
             for i in range(self.L)
         )
         ws["wgrad"] = torch.empty(_round_up(nbytes, 16) // 4, dtype=torch.float32, device=device)
+        if any(ln is not None for ln in self.lns):
+            f32 = dict(dtype=torch.float32, device=device)
+            ws["ln_z"] = [_mat(batch, self.dims[i + 1], torch.float32, device) if ln is not None else None
+                          for i, ln in enumerate(self.lns)]  # pre-norm outputs of the Linear, kept for the backward
+            ws["ln_mean"] = [torch.empty(batch, **f32) if ln is not None else None for ln in self.lns]
+            ws["ln_rstd"] = [torch.empty(batch, **f32) if ln is not None else None for ln in self.lns]
+            ws["ln_g"] = _mat(batch, dmax, torch.float32, device)  # d loss / d (LayerNorm output) of the layer at hand
+            nb = max(L.lib().rg_layer_norm_backward_workspace_bytes(batch, self.dims[i + 1])
+                     for i, ln in enumerate(self.lns) if ln is not None)
+            ws["ln_ws"] = torch.empty(_round_up(nb, 16) // 4, **f32)
         self._ws = ws
         self._batch = batch
+
+    def bind_ln_grads(self, dst):
+        """dst[i] = (dgamma, dbeta) fp32 destinations (gradient-slab views) of layer i's LayerNorm, or None"""
+        assert len(dst) == self.L and all((d is None) == (ln is None) for d, ln in zip(dst, self.lns))
+        self._ln_grads = list(dst)
 
     def stage_input(self, x32: torch.Tensor, need_transposed: bool):
         """fp32 [B, in] network input -> (row-major compute-type operand, transposed copy or None)."""
@@ -206,7 +226,18 @@ class FCStack:
         for i in range(self.L):
             last = i == self.L - 1
             out_f = self.dims[i + 1]
-            if last:
+            ln = self.lns[i]
+            if ln is not None:  # Linear (fp32 out) -> LayerNorm -> activation
+                z = ws["ln_z"][i]
+                ops.fc_forward(cur, self._wc[i], self.biases[i].detach(), L.ACT["linear"], self.precision, y=None, y32=z, yt=None)
+                y = None if last else ws["h"][i % 2][:, :out_f]
+                ops.layer_norm_forward(z, ln.weight.detach(), ln.bias.detach(), ln.eps, self.acts[i], y=y,
+                                       y32=out32 if last else None, mean=ws["ln_mean"][i], rstd=ws["ln_rstd"][i])
+                if not last:
+                    if save:
+                        ops.transpose_cast(y, None, ws["ht"][i])
+                    cur = y
+            elif last:
                 ops.fc_forward(cur, self._wc[i], self.biases[i].detach(), self.acts[i], self.precision,
                                y=None, y32=out32, yt=None)
             else:
@@ -236,7 +267,10 @@ class FCStack:
         n_last = self.dims[-1]
         dz = ws["dz"][0][:, :n_last]
         dzt = ws["dzt"][0][:n_last]
-        ops.transpose_cast(dout32, dz, dzt)
+        if self.lns[-1] is not None:  # the gradient first passes the output layer's LayerNorm
+            self._ln_backward(self.L - 1, dout32, dz, dzt, skip_wgrad)
+        else:
+            ops.transpose_cast(dout32, dz, dzt)
         for i in range(self.L - 1, -1, -1):
             in_f, out_f = self.dims[i], self.dims[i + 1]
             x_t = xt if i == 0 else ws["ht"][i - 1]
@@ -246,13 +280,37 @@ class FCStack:
                 nxt = (self.L - i) % 2
                 dz_n = ws["dz"][nxt][:, :in_f]
                 dzt_n = ws["dzt"][nxt][:in_f]
-                ops.fc_dgrad(dz, self._wtc[i], ws["ht"][i - 1], self.acts[i - 1], self.precision,
-                             dx=dz_n, dx32=None, dxt=dzt_n)
+                if self.lns[i - 1] is not None:  # dgrad x act' gives d loss / d (LayerNorm output) in fp32 ...
+                    g = ws["ln_g"][:, :in_f]
+                    ops.fc_dgrad(dz, self._wtc[i], ws["ht"][i - 1], self.acts[i - 1], self.precision, dx=None, dx32=g,
+                                 dxt=None)
+                    self._ln_backward(i - 1, g, dz_n, dzt_n, skip_wgrad)  # ... which its backward turns into dZ
+                else:
+                    ops.fc_dgrad(dz, self._wtc[i], ws["ht"][i - 1], self.acts[i - 1], self.precision,
+                                 dx=dz_n, dx32=None, dxt=dzt_n)
                 dz, dzt = dz_n, dzt_n
             elif dx32 is not None:
                 ops.fc_dgrad(dz, self._wtc[0], None, L.ACT["linear"], self.precision, dx=None,
                              dx32=dx32, dxt=None)
 
+
+def _ln_backward(self, i: int, g32: torch.Tensor, dz: torch.Tensor, dzt: torch.Tensor, skip_wgrad: bool):
+    """LayerNorm backward of layer i: g32 = d loss / d (LN output) -> dz (compute type, + transposed copy); the
+    parameter gradients go to the bound destinations (scratch when the stack is frozen)"""
+    ws, ln = self._ws, self.lns[i]
+    dst = self._ln_grads[i]
+    if dst is None or skip_wgrad:
+        n = self.dims[i + 1]
+        scratch = ws.setdefault("ln_scratch", torch.empty(2 * max(self.dims[1:]), dtype=torch.float32, device=g32.device))
+        if dst is None and not skip_wgrad:
+            raise RuntimeError("LayerNorm gradients have no destination: the trainer did not call bind_ln_grads")
+        dst = (scratch[:n], scratch[n : 2 * n])
+    ops.layer_norm_backward(g32, ws["ln_z"][i], ws["ln_mean"][i], ws["ln_rstd"][i], ln.weight.detach(), dst[0], dst[1],
+                            ws["ln_ws"], dz=dz)
+    ops.transpose_cast(dz, None, dzt)
+
+
+FCStack._ln_backward = _ln_backward
 
 SAVE_FOR_DX = 2  # FusedMLP.forward(save=SAVE_FOR_DX): keep only what a dx-only backward needs (rg_mlp_forward_fused save = 2)
 
@@ -550,10 +608,24 @@ def dx_save(stack):
     return SAVE_FOR_DX if isinstance(stack, FusedMLP) else True
 
 
-def make_stack(weights, biases, acts: List[int], precision: int):
+def make_stack(weights, biases, acts: List[int], precision: int, layer_norms=None):
     """Engine selection: the fused bf16-MFMA kernels when the shape allows (plain bf16 operands for
     PREC_BF16, split-bf16 for PREC_BF16X3), else the per-layer GEMMs.  A PREC_BF16X3 stack whose shape the
     fused kernels do not serve runs on the exact-fp32 MFMA GEMMs: the accuracy class is what was asked for."""
-    if precision in (L.PREC_BF16, L.PREC_BF16X3) and FusedMLP.supported(weights, acts):
+    has_ln = layer_norms is not None and any(ln is not None for ln in layer_norms)
+    if not has_ln and precision in (L.PREC_BF16, L.PREC_BF16X3) and FusedMLP.supported(weights, acts):
         return FusedMLP(weights, biases, acts, x3=precision == L.PREC_BF16X3)
-    return FCStack(weights, biases, acts, L.PREC_F32 if precision == L.PREC_BF16X3 else precision)
+    # (a stack with LayerNorm between its layers is not of the fused kernels' shape: per-layer GEMMs + rg_layer_norm_*)
+    return FCStack(weights, biases, acts, L.PREC_F32 if precision == L.PREC_BF16X3 else precision, layer_norms=layer_norms)
+
+
+def grad_views(fc, slab, params):
+    """(dw, db): views of the flat gradient slab for every linear layer of `fc`, in layer order; a stack with
+    LayerNorm also gets the destinations of its gamma / beta gradients bound (FCStack.bind_ln_grads)"""
+    index = {id(p): i for i, p in enumerate(params)}
+    view = lambda p: slab.view(slab.grad, index[id(p)])  # noqa: E731
+    lin = fc.linears()
+    lns = fc.layer_norms() if hasattr(fc, "layer_norms") else []
+    if any(ln is not None for ln in lns):
+        fc.stack().bind_ln_grads([(view(ln.weight), view(ln.bias)) if ln is not None else None for ln in lns])
+    return [view(l.weight) for l in lin], [view(l.bias) for l in lin]

@@ -1,11 +1,12 @@
 """FullyConnectedNetwork / FloatFeatureFullyConnected on the HIP FC kernels.
 
-Same constructor arguments, parameter names (``dnn.{i}.0.weight`` / ``.bias``, nn.Linear layout) and
-initialisation (Gaussian with gain, zero bias) as reagent/models/fully_connected_network.py:67-217.
-``forward`` runs rg_fc_forward launches (inference: no autograd graph is recorded — training goes
-through the trainers' fused step, which writes ``.grad`` directly).  Batch-norm, layer-norm,
-dropout and skip connections are off in every configuration on the hot path and
-are rejected here instead of silently falling back to torch.
+Same constructor arguments, parameter names (``dnn.{i}.0.weight`` / ``.bias``, nn.Linear layout; with
+``use_layer_norm`` the layer's nn.LayerNorm sits at ``dnn.{i}.1``) and initialisation (Gaussian with gain, zero bias)
+as reagent/models/fully_connected_network.py:67-217.  ``forward`` runs rg_fc_forward launches (inference: no autograd
+graph is recorded — training goes through the trainers' fused step, which writes ``.grad`` directly).  Layer-norm
+(Linear -> LayerNorm -> activation, :128-130) runs on the per-layer path with rg_layer_norm_*; batch-norm, dropout and
+skip connections are off in every configuration on the hot path and are rejected here instead of
+silently falling back to torch.
 """
 import math
 from typing import List, Optional
@@ -73,10 +74,10 @@ class FullyConnectedNetwork(ModelBase):
         use_skip_connections: bool = False,
     ) -> None:
         super().__init__()
-        if use_batch_norm or use_layer_norm or dropout_ratio > 0.0 or use_skip_connections:
+        if use_batch_norm or dropout_ratio > 0.0 or use_skip_connections:
             raise NotImplementedError(
-                "batch-norm / layer-norm / dropout / skip connections are not part of the MI355X hot "
-                "path (off in every BASELINE configuration)"
+                "batch-norm / dropout / skip connections are not part of the MI355X hot path (off in every BASELINE "
+                "configuration); layer-norm is (use_layer_norm)"
             )
         self.input_dim = layers[0]
         assert len(layers) == len(activations) + 1, (
@@ -85,7 +86,7 @@ class FullyConnectedNetwork(ModelBase):
         )
         modules: List[nn.Module] = []
         self.activation_names = list(activations)
-        for in_dim, out_dim, activation in zip(layers, layers[1:], activations):
+        for i, (in_dim, out_dim, activation) in enumerate(zip(layers, layers[1:], activations)):
             if activation not in L.ACT:
                 raise NotImplementedError(f"activation {activation} has no HIP epilogue")
             linear = _Linear(in_dim, out_dim)
@@ -98,7 +99,11 @@ class FullyConnectedNetwork(ModelBase):
             else:
                 gaussian_fill_w_gain(linear.weight, gain=gain, dim_in=in_dim, min_std=min_std)
             init.constant_(linear.bias, 0)
-            modules.append(nn.Sequential(linear, _Activation(activation)))
+            # Linear -> [LayerNorm] -> activation (:121-137); the output layer is normalised only with normalize_output
+            if use_layer_norm and (normalize_output or i < len(activations) - 1):
+                modules.append(nn.Sequential(linear, nn.LayerNorm(out_dim), _Activation(activation)))
+            else:
+                modules.append(nn.Sequential(linear, _Activation(activation)))
         self.dnn = nn.Sequential(*modules)
         self.precision = _DEFAULT_PRECISION
         self._stack = None
@@ -107,11 +112,16 @@ class FullyConnectedNetwork(ModelBase):
     def linears(self) -> List[_Linear]:
         return [m[0] for m in self.dnn]
 
+    def layer_norms(self):
+        """per layer: its nn.LayerNorm (a parameter holder here: the arithmetic is rg_layer_norm_*) or None"""
+        return [m[1] if isinstance(m[1], nn.LayerNorm) else None for m in self.dnn]
+
     def stack(self):
         if self._stack is None or getattr(self, "_stack_precision", None) != self.precision:
             lin = self.linears()
             self._stack = make_stack([l.weight for l in lin], [l.bias for l in lin],
-                                     [L.ACT[a] for a in self.activation_names], self.precision)
+                                     [L.ACT[a] for a in self.activation_names], self.precision,
+                                     layer_norms=self.layer_norms())
             self._stack_precision = self.precision  # the engine may run a different one (x3 on odd shapes: fp32)
         return self._stack
 

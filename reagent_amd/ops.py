@@ -157,6 +157,30 @@ def transpose_cast(src, dst=None, dst_t=None):
                                            L.stream_ptr()))
 
 
+# ---- layer norm (use_layer_norm of FullyConnectedNetwork) ------------------------------------------------------
+def layer_norm_forward(z32, gamma, beta, eps, act: int, y=None, y32=None, mean=None, rstd=None):
+    _chk_dev(z32, gamma, beta, y, y32, mean, rstd)
+    B, n = z32.shape
+    _run("rg_layer_norm_forward", dict(B=B, n=n),
+         lambda: L.lib().rg_layer_norm_forward(L.ptr(z32), _ld(z32), L.ptr(gamma), L.ptr(beta), float(eps), act, B, n,
+                                               L.ptr(y), dt_code(y.dtype) if y is not None else 0,
+                                               _ld(y) if y is not None else 0, L.ptr(y32),
+                                               _ld(y32) if y32 is not None else 0, L.ptr(mean), L.ptr(rstd), L.stream_ptr()))
+
+
+def layer_norm_backward(g32, z32, mean, rstd, gamma, dgamma, dbeta, workspace, dz=None, dz32=None):
+    _chk_dev(g32, z32, mean, rstd, gamma, dgamma, dbeta, workspace, dz, dz32)
+    B, n = z32.shape
+    assert dgamma.is_contiguous() and dbeta.is_contiguous()
+    _run("rg_layer_norm_backward", dict(B=B, n=n),
+         lambda: L.lib().rg_layer_norm_backward(L.ptr(g32), _ld(g32), L.ptr(z32), _ld(z32), L.ptr(mean), L.ptr(rstd),
+                                                L.ptr(gamma), B, n, L.ptr(dz), dt_code(dz.dtype) if dz is not None else 0,
+                                                _ld(dz) if dz is not None else 0, L.ptr(dz32),
+                                                _ld(dz32) if dz32 is not None else 0, L.ptr(dgamma), L.ptr(dbeta),
+                                                L.ptr(workspace), workspace.numel() * workspace.element_size(),
+                                                L.stream_ptr()))
+
+
 # ---- replay -----------------------------------------------------------------------------------
 def replay_nstep(indices, terminal_u8, reward, decays, capacity, horizon, steps, next_indices,
                  out_terminal, out_reward):

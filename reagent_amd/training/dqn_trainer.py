@@ -20,7 +20,7 @@ from .. import _lib as L
 from .. import ops
 from ..core import types as rlt
 from ..core.parameters import EvaluationParameters, RLParameters
-from ..engine import ensure_slab
+from ..engine import ensure_slab, grad_views
 from ..optimizer import Optimizer__Union, SoftUpdate
 from .dqn_trainer_base import DQNTrainerBaseLightning
 
@@ -165,11 +165,8 @@ class _CpeEngine:
     def _net_engine(net):
         params = list(net.parameters())
         slab = ensure_slab(params)
-        lin = net.fc.linears()
-        index = {id(p): i for i, p in enumerate(params)}
-        return dict(params=params, slab=slab, stack=net.fc.stack(),
-                    dw=[slab.view(slab.grad, index[id(l.weight)]) for l in lin],
-                    db=[slab.view(slab.grad, index[id(l.bias)]) for l in lin])
+        dw, db = grad_views(net.fc, slab, params)
+        return dict(params=params, slab=slab, stack=net.fc.stack(), dw=dw, db=db)
 
     def _engine(self, B, dev):
         tr = self.tr
@@ -330,10 +327,7 @@ class QStepCore(DQNTrainerBaseLightning):
             self._alloc_head(batch, device)
             self._ws_batch = batch
         # weight/bias gradient destinations = views of the flat gradient slab, in layer order
-        lin = self.q_network.fc.linears()
-        index = {id(p): i for i, p in enumerate(self._hip_params)}
-        self._dw = [self._slab.view(self._slab.grad, index[id(l.weight)]) for l in lin]
-        self._db = [self._slab.view(self._slab.grad, index[id(l.bias)]) for l in lin]
+        self._dw, self._db = grad_views(self.q_network.fc, self._slab, self._hip_params)
 
     @staticmethod
     def _f32c(t: torch.Tensor) -> torch.Tensor:

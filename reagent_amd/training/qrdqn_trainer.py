@@ -80,7 +80,7 @@ class QRDQNTrainer(QStepCore):
         if g is None:
             self._gq_active = None
             return super()._engine(batch, device)
-        from ..engine import ensure_slab
+        from ..engine import ensure_slab, grad_views
 
         self._hip_params = list(self.q_network.parameters())
         self._slab = ensure_slab(self._hip_params)
@@ -89,10 +89,7 @@ class QRDQNTrainer(QStepCore):
             self._loss = torch.empty(1, dtype=torch.float32, device=device)
         self._q = self._loss  # (device marker of the dense path's buffers)
         self._ws_batch = -1
-        lin = self.q_network.fc.linears()
-        index = {id(p): i for i, p in enumerate(self._hip_params)}
-        self._dw = [self._slab.view(self._slab.grad, index[id(l.weight)]) for l in lin]
-        self._db = [self._slab.view(self._slab.grad, index[id(l.bias)]) for l in lin]
+        self._dw, self._db = grad_views(self.q_network.fc, self._slab, self._hip_params)
         self._xs_t = None
         self._gq_active = g
 

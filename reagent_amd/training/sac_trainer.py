@@ -30,7 +30,7 @@ from .. import _lib as L
 from .. import ops
 from ..core import types as rlt
 from ..core.parameters import RLParameters
-from ..engine import dx_save, ensure_slab
+from ..engine import dx_save, ensure_slab, grad_views
 from ..optimizer import Optimizer__Union, SoftUpdate
 from .dqn_trainer import dp_reduce, held_gradients, native_step, publish_gradients
 from .reagent_lightning_module import ReAgentLightningModule
@@ -252,10 +252,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
     def _net_engine(self, net):
         params = list(net.parameters())
         slab = ensure_slab(params)
-        lin = net.fc.linears()
-        index = {id(p): i for i, p in enumerate(params)}
-        dw = [slab.view(slab.grad, index[id(l.weight)]) for l in lin]
-        db = [slab.view(slab.grad, index[id(l.bias)]) for l in lin]
+        dw, db = grad_views(net.fc, slab, params)
         return dict(params=params, slab=slab, stack=net.fc.stack(), dw=dw, db=db)
 
     def _engine(self, B, dev, S, A):

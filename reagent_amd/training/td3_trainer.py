@@ -16,7 +16,7 @@ from .. import _lib as L
 from .. import ops
 from ..core import types as rlt
 from ..core.parameters import RLParameters
-from ..engine import dx_save, ensure_slab
+from ..engine import dx_save, ensure_slab, grad_views
 from ..optimizer import Optimizer__Union, SoftUpdate
 from .reagent_lightning_module import ReAgentLightningModule
 from .rl_trainer_pytorch import RLTrainerMixin
@@ -83,11 +83,8 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
     def _net_engine(net):
         params = list(net.parameters())
         slab = ensure_slab(params)
-        lin = net.fc.linears()
-        index = {id(p): i for i, p in enumerate(params)}
-        return dict(params=params, slab=slab, stack=net.fc.stack(),
-                    dw=[slab.view(slab.grad, index[id(l.weight)]) for l in lin],
-                    db=[slab.view(slab.grad, index[id(l.bias)]) for l in lin])
+        dw, db = grad_views(net.fc, slab, params)
+        return dict(params=params, slab=slab, stack=net.fc.stack(), dw=dw, db=db)
 
     def _engine(self, B, dev, S, A):
         nets = dict(actor=self.actor_network, q1=self.q1_network, q2=self.q2_network)
