@@ -254,6 +254,9 @@ REPLAY_CASES = {
                          num_actions=2, p_terminal=0.1, batch=48),
     "replay_stack": dict(stack_size=4, replay_capacity=40, update_horizon=2, gamma=0.95, n_add=97, obs_dim=3,
                          num_actions=4, p_terminal=0.07, batch=30),
+    # return_everything_as_stack: `reward` is the stack of stored rewards at the sampled index, not the n-step sum
+    "replay_all_stack": dict(stack_size=3, replay_capacity=48, update_horizon=2, gamma=0.9, n_add=110, obs_dim=3,
+                             num_actions=3, p_terminal=0.08, batch=32, return_everything_as_stack=True),
 }
 
 
@@ -585,7 +588,8 @@ def gen_replay(name, c):
     from reagent.replay_memory.circular_replay_buffer import ReplayBuffer
 
     rb = ReplayBuffer(stack_size=c["stack_size"], replay_capacity=c["replay_capacity"], batch_size=c["batch"],
-                      update_horizon=c["update_horizon"], gamma=c["gamma"])
+                      update_horizon=c["update_horizon"], gamma=c["gamma"],
+                      return_everything_as_stack=c.get("return_everything_as_stack", False))
     rng = np.random.RandomState(7)
     adds = dict(observation=[], action=[], reward=[], terminal=[], possible_actions_mask=[], log_prob=[],
                 mdp_id=[])

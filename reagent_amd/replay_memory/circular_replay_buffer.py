@@ -61,10 +61,8 @@ class ReplayBuffer:
     ) -> None:
         if replay_capacity < update_horizon + stack_size:
             raise ValueError("There is not enough capacity to cover update_horizon and stack_size.")
-        if return_as_timeline_format or return_everything_as_stack:
-            raise NotImplementedError(
-                "return_as_timeline_format / return_everything_as_stack are not on the MI355X hot path"
-            )
+        if return_as_timeline_format:  # ragged python lists per transition (:716-741): a host-side export format
+            raise NotImplementedError("return_as_timeline_format is not on the MI355X hot path")
         self._initialized_buffer = False
         self._stack_size = stack_size
         self._return_everything_as_stack = return_everything_as_stack
@@ -315,6 +313,8 @@ class ReplayBuffer:
                 key, idx = "observation", indices
             elif name == "next_state":
                 key, idx = "observation", next_indices
+            elif name == "reward" and self._return_everything_as_stack:
+                key, idx = "reward", indices  # the stored rewards as a stack at `indices`, not the n-step sum (:680-683)
             elif name in ("indices", "terminal", "reward", "step"):
                 continue
             elif name in self._store:
@@ -330,7 +330,8 @@ class ReplayBuffer:
             cols.append((self._store[key], dst, idx, norm) if is_state else (self._store[key], dst, idx))
             results[name] = dst
         ops.replay_gather(cols, self._replay_capacity, S, B)
-        results.update(indices=indices, terminal=terminal, reward=reward, step=steps)
+        results.update(indices=indices, terminal=terminal, step=steps)
+        results.setdefault("reward", reward)
 
         batch_arrays = []
         for name in self._transition_elements:

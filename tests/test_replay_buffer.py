@@ -13,12 +13,13 @@ from reagent_amd.replay_memory import ReplayBuffer
 OBS = (4, 3)
 
 
-@pytest.mark.parametrize("name", ["replay_basic", "replay_nstep", "replay_stack"])
+@pytest.mark.parametrize("name", ["replay_basic", "replay_nstep", "replay_stack", "replay_all_stack"])
 def test_matches_reference_golden_bit_exact(backend, name):
     g = Golden(name)
     c = g.cfg
     rb = ReplayBuffer(stack_size=c["stack_size"], replay_capacity=c["replay_capacity"], batch_size=c["batch"],
-                      update_horizon=c["update_horizon"], gamma=c["gamma"], device=backend.device)
+                      update_horizon=c["update_horizon"], gamma=c["gamma"], device=backend.device,
+                      return_everything_as_stack=c.get("return_everything_as_stack", False))
     keys = ["observation", "action", "reward", "terminal", "possible_actions_mask", "log_prob", "mdp_id"]
     for i in range(c["n_add"]):
         tr = {k: g.a(f"add_{k}")[i] for k in keys}
