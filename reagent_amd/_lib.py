@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RG_LIB: another build of the same library (same-box A/B of compile-time kernel variants); default = the in-tree build
 LIB_PATH = os.environ.get("RG_LIB") or os.path.join(_HERE, "lib", "libreagent_hip.so")
 
+ABI_VERSION = 3  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5}
@@ -265,6 +266,9 @@ def load(path: str = LIB_PATH):
             raise ReagentHipError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.rg_abi_version() != ABI_VERSION:  # struct layouts / argument meanings moved: a stale build must not run
+        raise ReagentHipError(f"{path} has ABI {lib.rg_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild "
+                              "(`make -C reagent_amd/csrc`)")
     return lib
 
 
