@@ -394,7 +394,12 @@ class FusedMLP:
 
     def _ensure_ws(self, batch: int, device, training: bool):
         key = (batch, device, training)
-        if self._ws.get("key") == key or (self._ws.get("key") == (batch, device, True) and not training):
+        if self._ws.get("key") == key:
+            return
+        if not training and self._ws.get("key", (0, device))[1] == device:
+            # a non-saving forward needs no workspace of its own: a training workspace of another batch size (QR-DQN:
+            # 65 536 rows here, B + 128 A rows in the grouped space) stays as it is instead of being rebuilt every step
+            self._ws.setdefault("key", key)
             return
         lib = L.lib()
         ws = {"key": key}

@@ -19,6 +19,8 @@ dqn_trainer_base.py `_check_input`).
 """
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -83,6 +85,8 @@ class GroupedQR:
         self.online = _Net(trainer.q_network, self.A, self.N, need_bwd=True)
         self.target = _Net(trainer.q_network_target, self.A, self.N, need_bwd=False)
         self._B = -1
+        self._side = None
+        self.two_streams = os.environ.get("RG_QR_STREAMS", "1") != "0"  # the forward's two halves on two streams
 
     @staticmethod
     def eligible(trainer) -> bool:
@@ -137,6 +141,16 @@ class GroupedQR:
         on, tg = self.online, self.target
         on.stage()
         tg.stage()
+        # The two halves of the forward are independent until the loss — (1) a* and the target quantiles of next_state,
+        # (2) the current quantiles of the logged action — and each ends in a 528-workgroup launch (B/128 + A tiles:
+        # two full rounds of the 256 CUs plus a sliver).  On two streams the slivers fill each other's tails.
+        main = torch.cuda.current_stream() if state.is_cuda and self.two_streams else None
+        if main is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self._forward_current(b, state)
         # a*: the next action whose target quantiles form the Bellman target
         if tr.maxq_learning:
             sel = on if tr.double_q_learning else tg
@@ -148,10 +162,11 @@ class GroupedQR:
         if not tr.maxq_learning:  # rows without a next action (SARSA: terminal) keep zero quantiles; the
             self.zt.zero_()       # masked arg max gives every row one, and the scatter then writes every row
         fused_forward_grouped(tg.st, tg.gh, next_state, sp2, self.zt, scatter=True, save=False)
-        # current quantiles of the logged action (grouped space of the logged action; saved for the backward)
-        ops.qr_select_action(None, tr._f32c(b.action), False, self.key_cur)
-        sp1 = self.sp_cur.build(self.key_cur)
-        fused_forward_grouped(on.st, on.gh, state, sp1, self.z, scatter=False, save=True)
+        if main is not None:
+            main.wait_stream(self._side)
+        else:
+            self._forward_current(b, state)
+        sp1 = self.sp_cur
         self._state = state
         gamma_exp = None
         if tr.use_seq_num_diff_as_time_diff:
@@ -168,6 +183,13 @@ class GroupedQR:
         tr._dq = self.dz
         self._all_q = None
         return tr._loss
+
+    def _forward_current(self, b, state):
+        """current quantiles of the logged action (grouped space of the logged action; saved for the backward)"""
+        tr, on = self.tr, self.online
+        ops.qr_select_action(None, tr._f32c(b.action), False, self.key_cur)
+        sp1 = self.sp_cur.build(self.key_cur)
+        fused_forward_grouped(on.st, on.gh, state, sp1, self.z, scatter=False, save=True)
 
     def all_q_values(self) -> torch.Tensor:
         """q_network(state).mean(dim=2) [B, A] (the trainer's logged `all_q_values`): one more forward with the
