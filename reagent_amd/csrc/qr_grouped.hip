@@ -216,7 +216,6 @@ constexpr int QC_MAX_N = 256, QC_WAVES = 4;
 __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
   __shared__ float Ts[QC_WAVES][QC_MAX_N];
   __shared__ double P1[QC_WAVES][QC_MAX_N + 1], P2[QC_WAVES][QC_MAX_N + 1];
-  __shared__ double L1[QC_WAVES][64], L2[QC_WAVES][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = a.N;
   const int r = blockIdx.x * QC_WAVES + wv;
   const int b = a.rowmap[r];
@@ -271,23 +270,25 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     s1 += t;
     s2 += t * t;
   }
-  L1[wv][lane] = s1;
-  L2[wv][lane] = s2;
-  wave_lds_sync();
-  for (int off = 1; off < 64; off <<= 1) {  // inclusive scan of the lane totals within the wave
-    double a1 = 0.0, a2 = 0.0;
+  // inclusive scan of the lane totals across the wave, by shuffles (through LDS with a wave hand-off per step it was
+  // eighteen LDS round trips per row)
+  auto lane_read = [&](double x, int src) {
+    const long long bits = __builtin_bit_cast(long long, x);
+    const int lo = shfl_idx((int)bits, src), hi = shfl_idx((int)(bits >> 32), src);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+  };
+  double i1 = s1, i2 = s2;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int src = lane >= off ? lane - off : lane;
+    const double a1 = lane_read(i1, src), a2 = lane_read(i2, src);
     if (lane >= off) {
-      a1 = L1[wv][lane - off];
-      a2 = L2[wv][lane - off];
+      i1 += a1;
+      i2 += a2;
     }
-    wave_lds_sync();
-    if (lane >= off) {
-      L1[wv][lane] += a1;
-      L2[wv][lane] += a2;
-    }
-    wave_lds_sync();
   }
-  const double base1 = L1[wv][lane] - s1, base2 = L2[wv][lane] - s2;  // totals of the lanes before this one
+  const double base1 = i1 - s1, base2 = i2 - s2;  // totals of the lanes before this one
+  const double tot1 = lane_read(i1, 63), tot2 = lane_read(i2, 63);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int e = lane * 4 + k;
@@ -296,8 +297,8 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     P2[wv][e] = base2 + t2[k];
   }
   if (lane == 63) {
-    P1[wv][QC_MAX_N] = L1[wv][63];
-    P2[wv][QC_MAX_N] = L2[wv][63];
+    P1[wv][QC_MAX_N] = tot1;
+    P2[wv][QC_MAX_N] = tot2;
   }
   wave_lds_sync();
   const float* T = Ts[wv];
@@ -305,22 +306,44 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
   const double* Q2 = P2[wv];
   const float inv = 1.f / ((float)N * (float)a.batch * (float)N);
   float loss = 0.f;
-  for (int j = lane; j < a.lddz; j += 64) {
+  // The lane's (up to four) quantiles j = lane + 64 q are searched TOGETHER: for each, the number of sorted targets
+  // <= C - 1, < C and < C + 1.  Branch-free bisection over the padded 256 entries (the +inf padding never counts), the
+  // twelve chains advancing in lock step, so that each of the eight rounds has twelve independent LDS reads in flight
+  // instead of one (three searches after each other per quantile left the wave waiting on a chain of 24 dependent
+  // reads; the counts, hence the results, are the same).
+  constexpr int QJ = QC_MAX_N / 64;
+  float cq[QJ];
+  int c1[QJ], c2[QJ], c3[QJ];
+#pragma unroll
+  for (int q = 0; q < QJ; ++q) {
+    const int j = lane + 64 * q;
+    cq[q] = j < N ? a.z[(long)r * a.ldz + j] : 0.f;
+    c1[q] = c2[q] = c3[q] = 0;
+  }
+#pragma unroll
+  for (int step = QC_MAX_N / 2; step >= 1; step >>= 1) {
+#pragma unroll
+    for (int q = 0; q < QJ; ++q) {
+      const float t1 = T[c1[q] + step - 1], t2 = T[c2[q] + step - 1], t3 = T[c3[q] + step - 1];
+      c1[q] += t1 <= cq[q] - 1.f ? step : 0;
+      c2[q] += t2 < cq[q] ? step : 0;
+      c3[q] += t3 < cq[q] + 1.f ? step : 0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QJ; ++q) {  // the bisection stops at 255: the last entry (a target only when N == 256)
+    c1[q] += (c1[q] == QC_MAX_N - 1 && T[QC_MAX_N - 1] <= cq[q] - 1.f) ? 1 : 0;
+    c2[q] += (c2[q] == QC_MAX_N - 1 && T[QC_MAX_N - 1] < cq[q]) ? 1 : 0;
+    c3[q] += (c3[q] == QC_MAX_N - 1 && T[QC_MAX_N - 1] < cq[q] + 1.f) ? 1 : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < QJ; ++q) {
+    const int j = lane + 64 * q;
+    if (j >= a.lddz) break;
     float gsum = 0.f;
     if (j < N) {
-      const float c = a.z[(long)r * a.ldz + j], tau = a.quantiles[j];
-      // number of sorted targets that are <= x (upper) / < x (lower): binary search over T[0 .. N)
-      auto count = [&](float x, bool upper) {
-        int lo = 0, hi = N;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          const float tv = T[mid];
-          if (upper ? tv <= x : tv < x) lo = mid + 1;
-          else hi = mid;
-        }
-        return lo;
-      };
-      const int p1 = count(c - 1.f, true), p2 = count(c, false), p3 = count(c + 1.f, false);
+      const float c = cq[q], tau = a.quantiles[j];
+      const int p1 = c1[q], p2 = c2[q], p3 = c3[q];
       const double cd = (double)c, omt = 1.0 - (double)tau, td_ = (double)tau;
       const double n1 = p1, n2 = p2 - p1, n3 = p3 - p2, n4 = N - p3;
       const double s1_1 = Q1[p1], s1_2 = Q1[p2] - Q1[p1], s1_3 = Q1[p3] - Q1[p2], s1_4 = Q1[N] - Q1[p3];
@@ -334,6 +357,7 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     }
     dz[j] = -gsum * inv;
   }
+  for (int j = QC_MAX_N + lane; j < a.lddz; j += 64) dz[j] = 0.f;  // row padding beyond the 256 searched columns
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) loss += shfl_xor(loss, off);
   if (lane == 0) a.loss_partials[r] = loss * inv;
