@@ -124,7 +124,28 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       };
       // (A pipelined variant for 4..8 output column tiles — wave w running wide_mainloop<1> on column tile w — was
       // measured on the C3 grouped forward: 171 us against 169 us for this loop, no gain.)
-      {
+      if (NTo == 1 && NW == 8 && KC >= 8 && !a.tile_key) {
+        // one column tile (<= 32 outputs, e.g. 16 Q-values): four 32x32 tiles for eight waves.  The loop is a chain
+        // of L2 round trips (7 % of a workgroup's life with four waves idle), so two waves share a tile, each
+        // summing half of K; the upper four hand their accumulators over through the activation tile, dead by then.
+        const int tm = wave & 3, half = wave >> 2, kc_mid = (KC / 2 + 3) / 4 * 4;
+        f32x16 acc = tile_kloop(act, pitch, KC, wf_out, tm, 0, lane, half ? kc_mid : 0, half ? KC : kc_mid);
+        __syncthreads();  // every wave is done reading the layer input
+        float* hand = (float*)act + (tm * 64 + lane) * 16;
+        if (half) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 4) *(f32x4*)(hand + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+        }
+        __syncthreads();
+        if (!half) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 4) {
+            const f32x4 o = *(const f32x4*)(hand + r);
+            acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
+          }
+          store_tile(acc, tm, 0);
+        }
+      } else {
         for (int t = wave; t < 4 * NTo && grp >= 0; t += NW) {
           const int tm = t & 3, nt = t >> 2;
           store_tile(tile_kloop(act, pitch, KC, wf_out, tm, nt, lane), tm, nt);
@@ -583,18 +604,23 @@ __device__ __forceinline__ void reduce_cols_body(const float* __restrict__ parti
                                                  float* __restrict__ out, int block) {
   __shared__ float red[8][33];
   const int c = block * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
   if (c < N) {
+    // eight rows in flight per thread: the launch is a chain of dependent HBM round trips (S = 512 rows: 8 rounds)
     int r = g;
-    for (; r + 24 < S; r += 32) {
+    for (; r + 56 < S; r += 64) {
       s0 += partials[(long)r * N + c];
       s1 += partials[(long)(r + 8) * N + c];
       s2 += partials[(long)(r + 16) * N + c];
       s3 += partials[(long)(r + 24) * N + c];
+      s4 += partials[(long)(r + 32) * N + c];
+      s5 += partials[(long)(r + 40) * N + c];
+      s6 += partials[(long)(r + 48) * N + c];
+      s7 += partials[(long)(r + 56) * N + c];
     }
     for (; r < S; r += 8) s0 += partials[(long)r * N + c];
   }
-  red[g][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  red[g][threadIdx.x & 31] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   __syncthreads();
   if (g == 0 && c < N) {
     float t = 0.f;

@@ -193,10 +193,11 @@ __device__ __forceinline__ void x3_mainloop(const bf16_t* act, int pitch, int KC
 // pair's four fragments per chunk in flight during the current pair's MFMAs
 template <int LO>
 __device__ __forceinline__ f32x16 x3_tile_kloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf, long wlo, int tm,
-                                                int nt, int lane) {
+                                                int nt, int lane, int kc_lo = 0, int kc_hi = -1) {
   const int lr = lane & 31, lg = lane >> 5;
-  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8;
-  const bf16_t* wl = wf + (long)nt * KC * 512 + lane * 8;
+  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8 + kc_lo * 16;
+  const bf16_t* wl = wf + ((long)nt * KC + kc_lo) * 512 + lane * 8;
+  KC = (kc_hi < 0 ? KC : kc_hi) - kc_lo;  // from here on: the chunks [kc_lo, kc_hi) of this call
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -389,9 +390,38 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
       const int out_act = a.acts[l];
-      for (int t = wave; t < X3_TM * NTo; t += NW) {
-        const int tm = t % X3_TM, nt = t / X3_TM;
-        const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, a.wfrag[l], a.wfrag_lo[l], tm, nt, lane);
+      constexpr int PARTS = NW / X3_TM;  // waves per tile when there is one column tile
+      const bool split = NTo == 1 && KC >= 4 * PARTS;
+      for (int t = wave; t < (split ? NW : X3_TM * NTo); t += NW) {
+        const int tm = t % X3_TM, nt = split ? 0 : t / X3_TM;
+        f32x16 acc;
+        if (split) {
+          // one column tile (<= 32 outputs): two 32x32 tiles for eight waves, a chain of L2 round trips.  Four waves
+          // share a tile, a quarter of K each; parts 1..3 hand their sums over through the (by then dead)
+          // activation planes and part 0 adds them in a fixed order.
+          const int part = wave / X3_TM, per = (KC / PARTS + 1) / 2 * 2;
+          const int lo = part * per, hi = part == PARTS - 1 ? KC : lo + per;
+          acc = x3_tile_kloop<LO>(act, pitch, KC, a.wfrag[l], a.wfrag_lo[l], tm, 0, lane, lo, hi);
+          __syncthreads();  // every wave is done reading the layer input
+          float* hand = (float*)act + ((part * X3_TM + tm) * 64 + lane) * 16;
+          if (part) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) *(f32x4*)(hand + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+          }
+          __syncthreads();
+          if (part) continue;
+#pragma unroll
+          for (int p = 1; p < PARTS; ++p) {
+            const float* other = (const float*)act + ((p * X3_TM + tm) * 64 + lane) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+              const f32x4 o = *(const f32x4*)(other + r);
+              acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
+            }
+          }
+        } else {
+          acc = x3_tile_kloop<LO>(act, pitch, KC, a.wfrag[l], a.wfrag_lo[l], tm, nt, lane);
+        }
         const int col = nt * 32 + lr;
         if (col < N) {
           const float b = a.bias[l] ? a.bias[l][col] : 0.f;

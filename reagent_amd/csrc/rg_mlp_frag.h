@@ -365,11 +365,13 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
 // (Measured alternatives, profiles/microbench/fwd_phases, cycles per wave averaged over the 8 waves:
 // this loop 3.9k; 4 independent accumulators 5.5k; all <= 32 weight chunks requested up front 9.2k —
 // every workgroup reads the same 32 KB, and a burst on that region queues in the L2 channels.)
+// [kc_lo, kc_hi): the K chunks this call sums (a thin output layer splits K over two waves per tile, below)
 __device__ __forceinline__ f32x16 tile_kloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf, int tm,
-                                             int nt, int lane) {
+                                             int nt, int lane, int kc_lo = 0, int kc_hi = -1) {
   const int lr = lane & 31, lg = lane >> 5;
-  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8;
-  const bf16_t* wl = wf + (long)nt * KC * 512 + lane * 8;
+  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8 + kc_lo * 16;
+  const bf16_t* wl = wf + ((long)nt * KC + kc_lo) * 512 + lane * 8;
+  KC = (kc_hi < 0 ? KC : kc_hi) - kc_lo;  // from here on: the number of chunks of this call
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
