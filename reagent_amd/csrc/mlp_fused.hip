@@ -578,11 +578,12 @@ __global__ void reduce_group_kernel(ReduceGroupArgs R) {
   const long e = i - base;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = 0;
+#define RG_LDP(p) stream_load(p)  // the split partials are read exactly once
   for (; k + 3 < splits; k += 4) {
-    s0 += part[(long)k * slab + e];
-    s1 += part[(long)(k + 1) * slab + e];
-    s2 += part[(long)(k + 2) * slab + e];
-    s3 += part[(long)(k + 3) * slab + e];
+    s0 += RG_LDP(part + (long)k * slab + e);
+    s1 += RG_LDP(part + (long)(k + 1) * slab + e);
+    s2 += RG_LDP(part + (long)(k + 2) * slab + e);
+    s3 += RG_LDP(part + (long)(k + 3) * slab + e);
   }
   for (; k < splits; ++k) s0 += part[(long)k * slab + e];
   out[e] = (s0 + s1) + (s2 + s3);

@@ -233,8 +233,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ void store_packed_frags(bf16_t* dst, int mb, int nt, int NT, int lane,
                                                    const unsigned (&P)[8]) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-    *(u32x4*)(dst + frag_offset(mb, nt, NT, h, lane)) = u32x4{P[4 * h], P[4 * h + 1], P[4 * h + 2], P[4 * h + 3]};
+  for (int h = 0; h < 2; ++h) {
+    // streaming store: the fragments are read next by another launch (the weight gradient), never again by this one,
+    // and should not push the weights out of L2 (same-box A/B: the consuming wgrad launch 137 -> 131 us)
+    const u32x4 v = u32x4{P[4 * h], P[4 * h + 1], P[4 * h + 2], P[4 * h + 3]};
+    stream_store(v, (u32x4*)(dst + frag_offset(mb, nt, NT, h, lane)));
+  }
 }
 
 // bit r = (v[r] > 0).  NONNEG (ReLU outputs: v is +0 or a positive float, never -0/NaN): the sign

@@ -118,6 +118,8 @@ static inline float __fadd_rn(float a, float b) { volatile float r = a + b; retu
 static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+template <typename T> static inline void stream_store(T v, T* p) { *p = v; }
+template <typename T> static inline T stream_load(const T* p) { return *p; }
 static inline void pin_packed(const unsigned (&)[8]) {}
 static inline float shfl_xor(float v, int mask) { return gather_from(v, lane_id() ^ mask); }
 static inline int shfl_xor(int v, int mask) { return gather_from(v, lane_id() ^ mask); }
