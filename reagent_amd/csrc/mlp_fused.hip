@@ -525,10 +525,10 @@ __global__ void reduce_grouped_kernel(const float* __restrict__ partial, long sl
   float s0 = 0.f, s1 = 0.f;
   int k = 0;
   for (; k + 1 < splits; k += 2) {
-    s0 += partial[(a * splits + k) * slab + e];
-    s1 += partial[(a * splits + k + 1) * slab + e];
+    s0 += stream_load(partial + (a * splits + k) * slab + e);
+    s1 += stream_load(partial + (a * splits + k + 1) * slab + e);
   }
-  if (k < splits) s0 += partial[(a * splits + k) * slab + e];
+  if (k < splits) s0 += stream_load(partial + (a * splits + k) * slab + e);
   out[i] = s0 + s1;
 }
 

@@ -85,7 +85,7 @@ __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch)
     const int total = nrows * cpr;
     for (int it = threadIdx.x; it < total; it += blockDim.x) {
       const int r = it / cpr, ch = it - r * cpr;
-      const f32x4 raw = *(const f32x4*)((const float*)src + s_idx[r] * epr + ch * 4);
+      const f32x4 raw = stream_load((const f32x4*)((const float*)src + s_idx[r] * epr + ch * 4));  // a sampled row is read once
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = normalize_value(s_nc[ch * 4 + e], raw[e], 1.f, col.norm_quantiles);
@@ -145,7 +145,7 @@ __global__ void replay_gather_kernel(GatherTable t, int64_t capacity, int batch)
 #pragma unroll
       for (int u = 0; u < GU; ++u) {
         const int it = it0 + u * blockDim.x < total ? it0 + u * (int)blockDim.x : total - 1;
-        raw[u] = *(const f32x4*)(src + s_idx[it / cpr] * row_bytes + (long)(it % cpr) * 16);
+        raw[u] = stream_load((const f32x4*)(src + s_idx[it / cpr] * row_bytes + (long)(it % cpr) * 16));
       }
 #pragma unroll
       for (int u = 0; u < GU; ++u) {
