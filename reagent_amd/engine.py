@@ -607,6 +607,96 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
                          wgrad_ws)
 
 
+class FusedUpdate:
+    """Adam [+ the soft update of a target copy] + bf16 re-staging of the network's (and the target's) MFMA fragments
+    in ONE launch (rg_mlp_update_fused) for a network on the fused bf16 kernels whose optimizer is one FusedAdam group
+    over exactly its parameters.  Arithmetic per element is that of the separate launches (rg_adam_step,
+    rg_soft_update, rg_mlp_stage_weights_fused): bit-identical results.  `make` returns None when the shape of the
+    step is not the plain one."""
+
+    @classmethod
+    def make(cls, adam, params, lin, stack, target_params=None, target_stack=None, tau=None):
+        ok = (isinstance(stack, FusedMLP) and not stack.x3 and len(adam.param_groups) == 1
+              and len(adam.param_groups[0]["params"]) == len(params)
+              and all(a is b for a, b in zip(adam.param_groups[0]["params"], params)))
+        if ok and target_params is not None:
+            ok = (isinstance(target_stack, FusedMLP) and not target_stack.x3 and len(target_params) == len(params)
+                  and all(t is not s for t, s in zip(target_params, params)))
+        if not ok:
+            return None
+        slab = ensure_slab(params)
+        tslab = ensure_slab(target_params) if target_params is not None else None
+        if tslab is not None and (tslab.offsets != slab.offsets or tslab.total != slab.total):
+            return None
+        self = cls()
+        self.adam, self.params, self.slab, self.stack = adam, list(params), slab, stack
+        self.tparams, self.tslab, self.tstack, self.tau = target_params, tslab, target_stack, tau
+        index = {id(p): i for i, p in enumerate(params)}
+        d = L.MlpUpdateDesc()
+        d.n_layers = len(lin)
+        for i, v in enumerate(stack.dims):
+            d.dims[i] = v
+        for l, layer in enumerate(lin):
+            d.w_off[l] = slab.offsets[index[id(layer.weight)]]
+            d.b_off[l] = slab.offsets[index[id(layer.bias)]]
+        self.desc = d
+        return self
+
+    def staged(self) -> bool:
+        """fragments staged at least once (their padding is written by the first staging), slabs in place"""
+        st, ts = self.stack, self.tstack
+        if any(w is None for w in st._wf) or any(w is None for w in st._wb):
+            return False
+        if ts is not None and (any(w is None for w in ts._wf) or not self.tslab.is_bound()):
+            return False
+        return self.adam.moments_for(0)[0] is self.slab
+
+    def step(self, grad_scale: float = 1.0):
+        import math
+
+        from .optimizer import _bump, capturing
+
+        adam, d, st, ts = self.adam, self.desc, self.stack, self.tstack
+        assert all(p.grad is not None for p in self.params), "the fused update reads dense gradients from the slab"
+        slab, exp_avg, exp_avg_sq = adam.moments_for(0)
+        group = adam.param_groups[0]
+        beta1, beta2 = group["betas"]
+        sched = adam.schedule_for(0)
+        if sched is None:
+            steps = {adam.advance(0, i) for i in range(len(slab.params))}
+            if len(steps) != 1:
+                raise RuntimeError("fused update needs every parameter at the same Adam step")
+            step = steps.pop()
+        d.param, d.grad = slab.data.data_ptr(), slab.grad.data_ptr()
+        d.exp_avg, d.exp_avg_sq = exp_avg.data_ptr(), exp_avg_sq.data_ptr()
+        d.target = self.tslab.data.data_ptr() if ts is not None else None
+        for l in range(d.n_layers):
+            d.wfrag_fwd[l], d.wfrag_bwd[l] = st._wf[l].data_ptr(), st._wb[l].data_ptr()
+            d.target_wfrag_fwd[l] = ts._wf[l].data_ptr() if ts is not None else None
+        tau = self.tau if ts is not None else 0.0
+        if sched is not None:  # graph-safe: lr and the bias corrections come from HBM, the step is counted there
+            if not capturing():
+                sched.set_lr(group["lr"])
+                sched.pending += 1
+            ops._run("rg_mlp_update_fused", dict(P=slab.total),
+                     lambda: L.lib().rg_mlp_update_fused_sched(d, beta1, beta2, group["eps"], group["weight_decay"],
+                                                               grad_scale, tau, sched.buf.data_ptr(), L.stream_ptr()))
+            ops.sched_tick(sched.buf)
+        else:
+            ops._run("rg_mlp_update_fused", dict(P=slab.total),
+                     lambda: L.lib().rg_mlp_update_fused(d, group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
+                                                         1.0 - beta1**step, math.sqrt(1.0 - beta2**step), grad_scale,
+                                                         tau, L.stream_ptr()))
+        _bump(slab.params)
+        if ts is not None:
+            _bump(self.tparams)
+        # the fragments are current for the bumped versions: no separate staging launch
+        for st_, need_t in ((st, True), (ts, False)):
+            if st_ is not None:
+                st_._staged_versions = tuple((w._version, getattr(w, "_rg_version", 0)) for w in st_.weights) + (need_t,)
+                st_._wsrc_ptrs = [w.data_ptr() for w in st_.weights]
+
+
 def dx_save(stack):
     """`save` argument of a forward whose backward will be input-gradient only (skip_wgrad): the fused kernels then
     keep the sign planes instead of the activations"""

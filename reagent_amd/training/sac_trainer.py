@@ -21,6 +21,7 @@ get_log_prob: identical values, not repeated here).
 """
 import copy
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -213,6 +214,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             assert self.value_network is not None
         self.backprop_through_log_prob = backprop_through_log_prob
         self.minibatch_size = minibatch_size
+        self.use_fused_update = os.environ.get("RG_SAC_FUSED_UPDATE", "1") != "0"  # engine.FusedUpdate in the native step
         self._ws_batch = -1
         self._alpha_dev = None
         self._dp_group, self._dp_world = None, 1
@@ -530,6 +532,41 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         yield self.soft_update_result()
 
     # ---- fused native step ---------------------------------------------------------------------------
+    def _fused_updates(self, opts):
+        """{network: engine.FusedUpdate} when every network of the plain step (twin critics + actor on the fused bf16
+        kernels, one Adam per network, targets = the critics' copies) qualifies, else None.  All or nothing: the soft
+        update of the targets rides in the critics' launches, so a step never mixes the two forms."""
+        plan = getattr(self, "_fused_plan", None)
+        if plan is None:
+            from ..engine import FusedUpdate
+
+            plan = False
+            e = self._e
+            if (self.value_network is None and "q2" in e and self.q1_network_target is not None and len(opts) >= 4
+                    and self.use_fused_update):
+                t = {"q1": self.q1_network_target, "q2": self.q2_network_target}
+                made = {}
+                for k, adam in (("q1", opts[0]), ("q2", opts[1]), ("actor", opts[2])):
+                    net = dict(q1=self.q1_network, q2=self.q2_network, actor=self.actor_network)[k]
+                    tgt = t.get(k)
+                    if not hasattr(adam, "moments_for"):
+                        made = None
+                        break
+                    fu = FusedUpdate.make(adam, e[k]["params"], net.fc.linears(), e[k]["stack"],
+                                          target_params=list(tgt.parameters()) if tgt is not None else None,
+                                          target_stack=self._t[k] if tgt is not None else None, tau=self.tau)
+                    if fu is None:
+                        made = None
+                        break
+                    made[k] = fu
+                if made:
+                    plan = made
+            self._fused_plan = plan
+        if plan is False:
+            return None
+        # (first step: fragments not staged yet -> the separate launches, for every network of the step)
+        return plan if all(fu.staged() for fu in plan.values()) else None
+
     def native_optimizers(self):
         if getattr(self, "_native_opts", None) is None:
             self._native_opts = [o["optimizer"] for o in self.configure_optimizers()]
@@ -554,21 +591,28 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         gs = 1.0 / self._dp_world
         it = iter(opts)
         self._critic_forward(b, self._noise(B, A, dev, noise_next))
+        fused = self._fused_updates(opts)  # Adam (+ soft update) + re-staging per network in one launch, or None
         for k in ("q1", "q2"):
             if k in self._e:
                 for p in self._e[k]["params"]:
                     p.grad = None
                 self._critic_backward(k)
                 o = next(it)
-                o.grad_scale = gs
-                o.step()
+                if fused is not None:
+                    fused[k].step(gs)
+                else:
+                    o.grad_scale = gs
+                    o.step()
         self._actor_forward(b, self._noise(B, A, dev, noise_cur))
         for p in self._e["actor"]["params"]:
             p.grad = None
         self._actor_backward()
         o = next(it)
-        o.grad_scale = gs
-        o.step()
+        if fused is not None:
+            fused["actor"].step(gs)
+        else:
+            o.grad_scale = gs
+            o.step()
         if self.alpha_optimizer is not None:
             self.log_alpha.grad = None
             self._alpha_backward()
@@ -585,7 +629,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             o = next(it)
             o.grad_scale = gs
             o.step()
-        next(it).step()  # soft update
+        soft = next(it)
+        if fused is None:
+            soft.step()  # (the fused critic updates already moved their targets)
         self.all_batches_processed += 1
         out = dict(q1_loss=self._losses["q1"], q2_loss=self._losses["q2"], actor_loss=self._losses["actor"],
                    alpha_loss=self._alpha_loss)

@@ -210,3 +210,45 @@ def test_kld_kernels_against_autograd(backend, on_mean):
     dls = torch.empty(B, 2 * A, device=d)
     ops.gaussian_head_backward(lsd, nd, None, None, dls, kld_coef=coef, kld_on_mean=on_mean)
     assert (dls.cpu() - lsr.grad).abs().max() <= 1e-6 + 1e-4 * lsr.grad.abs().max()
+
+
+def test_fused_network_updates_equal_the_separate_launches(backend, monkeypatch):
+    """native step with Adam + soft update + re-staging in one launch per network (engine.FusedUpdate, fused bf16 stacks)
+    == the same step with rg_adam_step / rg_soft_update / rg_mlp_stage_weights_fused launches, bit for bit"""
+    from reagent_amd.engine import FusedMLP
+
+    def make(flag):
+        torch.manual_seed(7)
+        set_default_precision(L.PREC_BF16)
+        try:
+            S, A, H = 64, 32, [256, 256]
+            actor = GaussianFullyConnectedActor(S, A, H, ["relu", "relu"])
+            q1, q2 = FullyConnectedCritic(S, A, H, ["relu", "relu"]), FullyConnectedCritic(S, A, H, ["relu", "relu"])
+        finally:
+            set_default_precision(L.PREC_F32)
+        adam = lambda: Optimizer__Union.default(lr=1e-3)  # noqa: E731
+        d = backend.device
+        tr = SACTrainer(actor.to(d), q1.to(d), q2.to(d), rl=RLParameters(gamma=0.97, target_update_rate=0.05),
+                        q_network_optimizer=adam(), actor_network_optimizer=adam(), alpha_optimizer=adam()).to(d)
+        tr.use_fused_update = flag
+        return tr
+
+    ta, tb = make(True), make(False)
+    for s in range(3):
+        b = synthetic.to_policy_input(synthetic.policy_batch(160, 64, 32, seed=900 + s), backend.device)
+        g = torch.Generator().manual_seed(50 + s)
+        n1, n2 = torch.randn(160, 32, generator=g), torch.randn(160, 32, generator=g)
+        oa, ob = ta.train_step_native(b, n1, n2), tb.train_step_native(b, n1, n2)
+        for k in oa:
+            assert torch.equal(oa[k].cpu(), ob[k].cpu()), (s, k)
+        for na, nb in ((ta.q1_network, tb.q1_network), (ta.q2_network_target, tb.q2_network_target), (ta.actor_network, tb.actor_network),
+                       (ta.q1_network_target, tb.q1_network_target)):
+            for pa, pb in zip(na.parameters(), nb.parameters()):
+                assert torch.equal(pa.detach().cpu(), pb.detach().cpu()), s
+    assert isinstance(ta._e["q1"]["stack"], FusedMLP) and ta._fused_plan and tb._fused_plan is False
+    launches = []
+    from reagent_amd import ops
+    real = ops._run
+    monkeypatch.setattr(ops, "_run", lambda name, meta, call: (launches.append(name), real(name, meta, call))[1])
+    ta.train_step_native(b, n1, n2)
+    assert launches.count("rg_mlp_update_fused") == 3 and "rg_soft_update" not in launches and "rg_mlp_stage_weights_fused" not in launches
