@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PMC passes (gpu_pmc.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of bench.py, kernel trace
+"""PMC passes (profiles/scripts/gpu_pmc.sh: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of bench.py, kernel trace
 only) -> profiles/traffic.json, the per-launch HBM bytes bench.py reports as `roofline.traffic`.
 
 Corrections as the guide prescribes (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): both counters are in KB;
