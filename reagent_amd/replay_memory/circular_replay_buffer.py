@@ -352,7 +352,8 @@ class ReplayBuffer:
 
         st = self._store
         obs, act = st.get("observation"), st.get("action")
-        if (self._stack_size != 1 or obs is None or obs.dtype != torch.float32 or obs.dim() != 2 or act is None
+        if (self._stack_size != 1 or self._return_everything_as_stack or obs is None or obs.dtype != torch.float32
+                or obs.dim() != 2 or act is None
                 or act.dtype != torch.int64 or act.dim() != 1 or "log_prob" not in st
                 or st["reward"].dtype != torch.float32):
             return None

@@ -49,7 +49,8 @@ def _mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torc
                  precision: str) -> torch.Tensor:
     from .engine import make_stack
 
-    key = tuple(w.data_ptr() for w in weights) + tuple(b.data_ptr() for b in biases) + (tuple(activations), precision)
+    key = (tuple((w.data_ptr(), tuple(w.shape)) for w in weights) + tuple(b.data_ptr() for b in biases)
+           + (tuple(activations), precision, str(x.device)))
     st = _stacks.get(key)
     if st is None:
         if len(_stacks) > 64:
