@@ -105,6 +105,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
       const int out_act = a.acts[l];
+      const bool stream_out = N > 64;
       // grouped output layer: this tile's group selects the weight / bias slice (an empty tile has no output)
       const int grp = a.tile_key ? a.tile_key[blockIdx.x] : 0;
       const bf16_t* wf_out = a.wfrag[l] + (a.tile_key ? (long)(grp < 0 ? 0 : grp) * a.group_stride : 0);
@@ -117,8 +118,13 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
           for (int r = 0; r < 16; ++r) {
             int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
             if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
-            if (row >= 0 && (a.out_scatter || row < a.batch))
-              a.out32[(long)row * a.ldo + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+            if (row >= 0 && (a.out_scatter || row < a.batch)) {
+              const float o = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+              // a wide output (QR-DQN's 200 quantiles per row: 54 MB per launch, read once by the loss head) streams
+              // past the caches (same-box C3 step -1 %); a thin one is a few MB and its reader is next
+              if (stream_out) stream_store(o, a.out32 + (long)row * a.ldo + col);
+              else a.out32[(long)row * a.ldo + col] = o;
+            }
           }
         }
       };
