@@ -218,7 +218,8 @@ def build(args, device, rank, batch=None, cols=None):
         from reagent_amd.preprocessing import PolicyNetworkInputMaker
 
         maker = PolicyNetworkInputMaker(np.full(A, R[0], dtype=np.float32), np.full(A, R[1], dtype=np.float32))
-        loop = OfflinePolicyLoop(rb, trainer, batch, maker, pre)
+        loop = OfflinePolicyLoop(rb, trainer, batch, maker, pre,
+                                 state_dtype=torch.bfloat16 if args.precision == "bf16" else None)
     else:
         loop = OfflineDqnLoop(rb, trainer, batch, pre,
                               state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32,

@@ -137,13 +137,16 @@ typedef struct {
                                                * neither required nor written and no weight gradient may follow */
   /* Two-panel network input (FullyConnectedCritic: cat(state, action), reagent/models/critic.py:79-92) without
    * materialising the concatenation: when x2 != NULL the forward reads input columns [0, x_split) from its `x`
-   * argument and columns [x_split, dims[0]) from x2 (row pitch ldx2, same dtype); x_split a multiple of 32. */
+   * argument and columns [x_split, dims[0]) from x2 (row pitch ldx2, element type x2_dtype); x_split a multiple of 32. */
   const void* x2;
   int64_t ldx2;
   int32_t x_split;
   /* backward: dx32 receives d loss / d input columns [dx_col0, dims[0]) only (dx32[0] is column dx_col0; a
    * multiple of 32) — SAC's actor step needs the action columns of the critic's input gradient, not the state's */
   int32_t dx_col0;
+  int32_t x2_dtype;                           /* element type of x2 (RG_DT_*): the panels may differ — network-ready bf16
+                                               * state rows from the sampler next to fp32 actions */
+  int32_t reserved2;
   /* forward only: row r of the batch the kernels work on reads input row rowmap[r] of x (-1: an all-zero row);
    * `batch` is then the length of rowmap.  Lets a stack run in "grouped space" (rows sorted by a key and padded to
    * whole 128-row tiles, qr_grouped.hip) without materialising the permuted input. */

@@ -62,13 +62,14 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       load_tile_rows_mapped<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, a.rowmap, row_base, a.dims[0], k0p, tid);
   } else if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
     const int n2 = a.dims[0] - a.x_split;
-    if (a.x_is_f32) {
+    if (a.x_is_f32)  // each panel in its own element type (bf16 state rows from the sampler next to fp32 actions)
       load_tile_to_lds<float, THREADS>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
-      load_tile_to_lds<float, THREADS>(act + a.x_split, pitch, (const float*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
-    } else {
+    else
       load_tile_to_lds<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
+    if (a.x2_is_f32)
+      load_tile_to_lds<float, THREADS>(act + a.x_split, pitch, (const float*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
+    else
       load_tile_to_lds<bf16_t, THREADS>(act + a.x_split, pitch, (const bf16_t*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
-    }
   } else if (a.x_is_f32)
     load_tile_to_lds<float, THREADS>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   else

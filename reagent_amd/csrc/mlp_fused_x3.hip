@@ -347,13 +347,14 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   const int k0p = round_up(a.dims[0], 32);
   if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
     const int n2 = a.dims[0] - a.x_split;
-    if (a.x_is_f32) {
+    if (a.x_is_f32)
       load_tile_split<float, THREADS, LO>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
-      load_tile_split<float, THREADS, LO>(act + a.x_split, pitch, (const float*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
-    } else {
+    else
       load_tile_split<bf16_t, THREADS, LO>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
+    if (a.x2_is_f32)
+      load_tile_split<float, THREADS, LO>(act + a.x_split, pitch, (const float*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
+    else
       load_tile_split<bf16_t, THREADS, LO>(act + a.x_split, pitch, (const bf16_t*)a.x2, a.ldx2, row_base, a.batch, n2, k0p - a.x_split, tid);
-    }
   } else if (a.x_is_f32)
     load_tile_split<float, THREADS, LO>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   else

@@ -48,7 +48,7 @@ struct MlpArgs {
   const int* tile_key;            // grouped output layer: group of each 128-row tile (-1: empty), null = plain layer
   long group_stride;              // elements between the groups' fragment sets of the last layer (this direction)
   int out_scatter;                // forward: output row r goes to out32[rowmap[r]]
-  int x_is_f32;
+  int x_is_f32, x2_is_f32;
   float* out32;  // forward output [batch, dims[L]] fp32
   long ldo;
   const float* dout32;  // backward input [batch, dims[L]] fp32
@@ -618,6 +618,7 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
   a.tile_key = d->tile_key; a.group_stride = backward ? d->group_stride_bwd : d->group_stride_fwd;
   a.out_scatter = d->tile_key ? d->out_scatter : 0;
   a.x2 = d->x2; a.ldx2 = d->ldx2; a.x_split = d->x2 ? d->x_split : 0; a.dx_col0 = d->dx_col0;
+  a.x2_is_f32 = d->x2_dtype == RG_DT_F32;
   a.x = nullptr; a.ldx = 0; a.x_is_f32 = 0; a.out32 = nullptr; a.ldo = 0; a.dout32 = nullptr; a.lddo = 0;
   a.dx32 = nullptr; a.lddx = 0; a.save = 0;
   return RG_OK;

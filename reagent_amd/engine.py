@@ -459,9 +459,9 @@ class FusedMLP:
         assert xc.stride(1) == 1 and out32.stride(1) == 1
         if x2 is not None:
             L.require_cuda(x2)
-            assert x2.dtype == xc.dtype and x2.stride(1) == 1 and xc.shape[1] % 32 == 0
+            assert x2.stride(1) == 1 and xc.shape[1] % 32 == 0  # (the panels may differ in element type)
             assert xc.shape[1] + x2.shape[1] == self.dims[0] and x2.shape[0] == B
-            d.x2, d.ldx2, d.x_split = x2.data_ptr(), x2.stride(0), xc.shape[1]
+            d.x2, d.ldx2, d.x_split, d.x2_dtype = x2.data_ptr(), x2.stride(0), xc.shape[1], ops.dt_code(x2.dtype)
         else:
             assert xc.shape[1] == self.dims[0]
             d.x2, d.ldx2, d.x_split = None, 0, 0

@@ -243,14 +243,19 @@ class OfflinePolicyLoop(_GraphedLoop):
     actor's N(0,1) draws taken from the device RNG."""
 
     def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int, input_maker,
-                 state_preprocessor: Optional[Preprocessor] = None):
+                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None):
+        """state_dtype=torch.bfloat16 (with a state_preprocessor, bf16 engine): the gather writes the normalized state
+        rows in the networks' operand type — half the bytes for the sampler to write and for each of the step's eight
+        forwards to read, the same bf16 values the kernels would make of the fp32 rows"""
         self.rb, self.trainer, self.batch_size, self.maker = replay_buffer, trainer, batch_size, input_maker
         self.pre = state_preprocessor
+        self.state_dtype = state_dtype if state_preprocessor is not None else None
         if state_preprocessor is not None and not state_preprocessor.elementwise:
             raise NotImplementedError("normalize-on-gather needs a 1:1 column table")
 
     def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.PolicyNetworkInput:
-        tup = self.rb.sample_transition_batch(self.batch_size, indices=indices, state_preprocessor=self.pre)
+        tup = self.rb.sample_transition_batch(self.batch_size, indices=indices, state_preprocessor=self.pre,
+                                              state_dtype=self.state_dtype)
         return self.maker(tup)
 
     def step(self, indices: Optional[torch.Tensor] = None, **noise):

@@ -301,6 +301,14 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         t = t if t.dtype == torch.float32 else t.float()
         return t if t.is_contiguous() else t.contiguous()
 
+    @staticmethod
+    def _state_in(t):
+        """state rows as a network input: fp32, or the sampler's network-ready bf16 rows (bf16 engine: the fused
+        kernels would round the fp32 rows to the same bf16 values on load)"""
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.float()
+        return t if t.is_contiguous() else t.contiguous()
+
     def _publish(self, e, held=()):
         slab = e["slab"]
         if self._dp_group is not None:
@@ -309,8 +317,8 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
 
     # ---- segments ----------------------------------------------------------------------------------
     def _critic_forward(self, b, noise_next):
-        state, action = self._f32c(b.state.float_features), self._f32c(b.action.float_features)
-        next_state = self._f32c(b.next_state.float_features)
+        state, action = self._state_in(b.state.float_features), self._f32c(b.action.float_features)
+        next_state = self._state_in(b.next_state.float_features)
         L.require_cuda(state, "training_batch.state")
         B, S, A, dev = state.shape[0], state.shape[1], action.shape[1], state.device
         self._engine(B, dev, S, A)
@@ -394,7 +402,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         self._publish(e, held)
 
     def _actor_forward(self, b, noise_cur):
-        state = self._f32c(b.state.float_features)
+        state = self._state_in(b.state.float_features)
         S, B, dev = self._S, self._B, state.device
         e = self._e
         for k in ("q1", "q2"):  # critics were just updated by their Adam steps
@@ -477,7 +485,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
     # value segment (:325-340): V(s) regressed on min q (s, a_pi) [- alpha * clamp(log_prob)] — the critic head's
     # arithmetic with reward 0, discount 1, not_terminal 1 and (q1a, q2a) in the place of the target critics
     def _value_forward(self, b):
-        state = self._f32c(b.state.float_features)
+        state = self._state_in(b.state.float_features)
         vs = self._e["value"]["stack"]
         vs.stage_weights(need_transposed=True)
         xv, self._xv_t = vs.stage_input(state, need_transposed=True)

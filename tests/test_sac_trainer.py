@@ -252,3 +252,55 @@ def test_fused_network_updates_equal_the_separate_launches(backend, monkeypatch)
     monkeypatch.setattr(ops, "_run", lambda name, meta, call: (launches.append(name), real(name, meta, call))[1])
     ta.train_step_native(b, n1, n2)
     assert launches.count("rg_mlp_update_fused") == 3 and "rg_soft_update" not in launches and "rg_mlp_stage_weights_fused" not in launches
+
+
+def test_bf16_state_rows_from_the_sampler_equal_fp32_rows(backend):
+    """OfflinePolicyLoop(state_dtype=bfloat16): the gather writes the normalized state rows in the fused kernels' operand
+    type (the critic's state panel bf16 next to its fp32 action panel) — the kernels round the fp32 rows to the same
+    values, so losses and weights are bit-identical to the fp32-row loop"""
+    import numpy as np
+
+    from reagent_amd.core.parameters import CONTINUOUS_TRAINING_ACTION_RANGE as R
+    from reagent_amd.core.parameters import NormalizationParameters
+    from reagent_amd.engine import FusedMLP
+    from reagent_amd.preprocessing import PolicyNetworkInputMaker, Preprocessor
+    from reagent_amd.replay_memory import ReplayBuffer
+    from reagent_amd.runtime import OfflinePolicyLoop
+
+    dev = backend.device
+    S, A, B, C = 64, 32, 192, 1024
+
+    def build(state_dtype):
+        torch.manual_seed(5)
+        set_default_precision(L.PREC_BF16)
+        try:
+            nets = [GaussianFullyConnectedActor(S, A, [256, 256], ["relu", "relu"]), FullyConnectedCritic(S, A, [256, 256], ["relu", "relu"]),
+                    FullyConnectedCritic(S, A, [256, 256], ["relu", "relu"])]
+        finally:
+            set_default_precision(L.PREC_F32)
+        adam = lambda: Optimizer__Union.default(lr=1e-3)  # noqa: E731
+        tr = SACTrainer(nets[0].to(dev), nets[1].to(dev), nets[2].to(dev), rl=RLParameters(gamma=0.99, target_update_rate=0.05),
+                        q_network_optimizer=adam(), actor_network_optimizer=adam(), alpha_optimizer=adam()).to(dev)
+        cols = synthetic.replay_contents(C, S, A, seed=3)
+        cols["action"] = torch.rand(C, A, generator=torch.Generator().manual_seed(4)) * 1.8 - 0.9
+        del cols["possible_actions_mask"]
+        rb = ReplayBuffer(replay_capacity=C, batch_size=B, device=dev)
+        rb.load_columns({k: v.to(dev) for k, v in cols.items()}, mark_all_valid=True)
+        mean, std = synthetic.normalization_table(S, 7)
+        pre = Preprocessor({i: NormalizationParameters(feature_type="CONTINUOUS", mean=mean[i].item(), stddev=std[i].item())
+                            for i in range(S)}, device=dev)
+        maker = PolicyNetworkInputMaker(np.full(A, R[0], dtype=np.float32), np.full(A, R[1], dtype=np.float32))
+        return OfflinePolicyLoop(rb, tr, B, maker, pre, state_dtype=state_dtype), tr
+
+    (la, ta), (lb, tb) = build(torch.bfloat16), build(None)
+    assert isinstance(ta._e["q1"]["stack"] if hasattr(ta, "_e") else ta.q1_network.fc.stack(), FusedMLP)
+    g = torch.Generator().manual_seed(9)
+    for s in range(3):
+        idx = torch.randint(C, (B,), generator=g)
+        n1, n2 = torch.randn(B, A, generator=g), torch.randn(B, A, generator=g)
+        oa, ob = la.step(idx, noise_next=n1, noise_cur=n2), lb.step(idx, noise_next=n1, noise_cur=n2)
+        for k in oa:
+            assert torch.equal(oa[k].cpu(), ob[k].cpu()), (s, k)
+    assert la.make_batch(idx).state.float_features.dtype == torch.bfloat16 and ta._panels
+    for pa, pb in zip(ta.parameters(), tb.parameters()):
+        assert torch.equal(pa.detach().cpu(), pb.detach().cpu())
