@@ -449,10 +449,10 @@ int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const u
 int rg_make_policy_input(const float* action, int64_t lda, const float* next_action, int64_t ldna, const uint8_t* terminal,
                          const float* log_prob, const float* ranges, int batch, int action_dim, float* action_out,
                          float* next_action_out, float* not_terminal, float* action_probability, rg_stream_t stream) {
+  if (batch == 0) return RG_OK;  // (an empty batch has no buffers to check)
   if (!action || !next_action || !terminal || !ranges || !action_out || !next_action_out || !not_terminal ||
       (action_probability && !log_prob) || batch < 0 || action_dim <= 0)
     return RG_EINVAL;
-  if (batch == 0) return RG_OK;
   long blocks = ((long)batch * action_dim + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   RG_LAUNCH(make_policy_input_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, action, (long)lda,
