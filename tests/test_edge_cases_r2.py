@@ -23,7 +23,9 @@ def test_policy_input_maker_empty_and_single_column(backend):
                   log_prob=-torch.rand(B, 1, generator=g).to(d))
         out = PolicyNetworkInputMaker(lo, hi)(b)
         assert out.action.float_features.shape == (B, A) and out.not_terminal.shape == (B, 1)
-        tl, th = torch.tensor(-1 + 1e-6), torch.tensor(1 - 1e-6)  # fp32 scalars, as the reference's maker holds them
+        from reagent_amd.core.parameters import CONTINUOUS_TRAINING_ACTION_RANGE as R
+
+        tl, th = torch.tensor(R[0]), torch.tensor(R[1])  # fp32 scalars, as the reference's maker holds them
         ref = ((b.action.cpu() - torch.tensor(lo)) / (torch.tensor(hi) - torch.tensor(lo))) * (th - tl) + tl
         assert torch.equal(out.action.float_features.cpu(), ref)
         assert torch.equal(out.not_terminal.cpu(), 1.0 - b.terminal.float().cpu())
