@@ -297,6 +297,14 @@ int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const u
                       const float* log_prob, int batch, int num_actions, float* action_onehot,
                       float* next_action_onehot, float* not_terminal, float* action_probability,
                       rg_stream_t stream);
+/* Sparse replay elements — IDListMetadata / IDScoreListMetadata.sample_to_output (circular_replay_buffer.py:144-274).
+ * A feature's lists sit in padded slots ids [capacity, width] (+ scores [capacity, width]) with lens [capacity].
+ * rg_ragged_offsets: offsets [batch] = exclusive prefix sums of lens[indices[b]], total [1] = their sum.
+ * rg_ragged_copy: ids_out (and scores_out when scores != NULL) receive the sampled rows back to back at `offsets`. */
+int rg_ragged_offsets(const int32_t* lens, const int64_t* indices, int batch, int32_t* offsets, int32_t* total,
+                      rg_stream_t stream);
+int rg_ragged_copy(const int64_t* ids, const float* scores, int width, const int32_t* lens, const int64_t* indices,
+                   const int32_t* offsets, int batch, int64_t* ids_out, float* scores_out, rg_stream_t stream);
 /* PolicyNetworkInputMaker.__call__ (gym/preprocessors/trainer_preprocessor.py:161-227, dense path) in one launch:
  * action_out / next_action_out [B, A] = rescale_actions(training/utils.py:13-29) from the environment's range to the
  * training range, next_action rows of terminal transitions zeroed; not_terminal [B] = 1 - terminal;

@@ -181,6 +181,8 @@ SIGNATURES = {
     "rg_layer_norm_backward_workspace_bytes": (c_sz, [c_int, c_int]),
     "rg_layer_norm_backward": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
+    "rg_ragged_offsets": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "rg_ragged_copy": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_make_policy_input": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_normalize_dense": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p,

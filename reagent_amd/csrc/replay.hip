@@ -223,6 +223,50 @@ __global__ void make_dqn_input_kernel(const int64_t* __restrict__ action,
   }
 }
 
+// ---- sparse replay elements (IDListMetadata / IDScoreListMetadata, circular_replay_buffer.py:144-274) -------------
+// A feature's lists live in padded slots ids [capacity, W] (+ scores [capacity, W]) with lens [capacity] beside them.
+// sample_to_output of a batch = (offsets [B] = exclusive prefix sums of the sampled rows' lengths, the rows' ids
+// (and scores) back to back).  Two launches: the scan (one workgroup, carry over 1024-row chunks: the offsets are
+// sequential by definition) writes offsets and the total; the copy moves one row per wave.
+__global__ void ragged_offsets_kernel(const int* __restrict__ lens, const int64_t* __restrict__ idx, int batch,
+                                      int* __restrict__ offsets, int* __restrict__ total) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int t = threadIdx.x;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < batch; base += 1024) {
+    const int b = base + t;
+    const int v = b < batch ? lens[idx[b]] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the chunk
+      const int add = t >= off ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += add;
+      __syncthreads();
+    }
+    if (b < batch) offsets[b] = carry + part[t] - v;
+    __syncthreads();
+    if (t == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (t == 0) total[0] = carry;
+}
+
+__global__ void ragged_copy_kernel(const int64_t* __restrict__ ids, const float* __restrict__ scores, int W,
+                                   const int* __restrict__ lens, const int64_t* __restrict__ idx, const int* __restrict__ offsets,
+                                   int batch, int64_t* __restrict__ ids_out, float* __restrict__ scores_out) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = lane_id();
+  if (b >= batch) return;
+  const int64_t row = idx[b];
+  const int n = lens[row], o = offsets[b];
+  for (int j = lane; j < n; j += 64) {
+    ids_out[o + j] = ids[row * W + j];
+    if (scores) scores_out[o + j] = scores[row * W + j];
+  }
+}
+
 // PolicyNetworkInputMaker (trainer_preprocessor.py:161-227, dense path) in one launch:
 //   action, next_action = rescale_actions(., new = training range, prev = the environment's range)
 //                       = ((a - prev_min) / (prev_max - prev_min)) * (new_max - new_min) + new_min   (training/utils.py:13-29),
@@ -443,6 +487,22 @@ int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const u
   RG_LAUNCH(make_dqn_input_kernel, dim3((unsigned)blocks), dim3(256), (hipStream_t)stream, action,
             next_action, terminal, log_prob, batch, num_actions, action_onehot, next_action_onehot,
             not_terminal, action_probability);
+  return (int)hipGetLastError();
+}
+
+int rg_ragged_offsets(const int32_t* lens, const int64_t* indices, int batch, int32_t* offsets, int32_t* total,
+                      rg_stream_t stream) {
+  if (!total || batch < 0 || (batch > 0 && (!lens || !indices || !offsets))) return RG_EINVAL;
+  RG_LAUNCH(ragged_offsets_kernel, dim3(1), dim3(1024), (hipStream_t)stream, lens, indices, batch, offsets, total);
+  return (int)hipGetLastError();
+}
+
+int rg_ragged_copy(const int64_t* ids, const float* scores, int width, const int32_t* lens, const int64_t* indices,
+                   const int32_t* offsets, int batch, int64_t* ids_out, float* scores_out, rg_stream_t stream) {
+  if (batch == 0) return RG_OK;
+  if (!ids || !lens || !indices || !offsets || !ids_out || width <= 0 || batch < 0 || (scores && !scores_out)) return RG_EINVAL;
+  RG_LAUNCH(ragged_copy_kernel, dim3((batch + 3) / 4), dim3(256), (hipStream_t)stream, ids, scores, width, lens, indices,
+            offsets, batch, ids_out, scores_out);
   return (int)hipGetLastError();
 }
 

@@ -258,6 +258,25 @@ def make_dqn_input(action, next_action, terminal, log_prob, num_actions, action_
                                            L.ptr(not_terminal), L.ptr(action_probability), L.stream_ptr()))
 
 
+def ragged_gather(ids, scores, lens, indices):
+    """(offsets int32 [B], ids int64 [total], scores float32 [total] or None): the sampled rows of a padded-slot ragged
+    column back to back (IDListMetadata / IDScoreListMetadata.sample_to_output).  One host read: the total length."""
+    _chk_dev(ids, scores, lens, indices)
+    B, dev = indices.numel(), ids.device
+    offsets = torch.empty(B, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    _run("rg_ragged_offsets", dict(B=B),
+         lambda: L.lib().rg_ragged_offsets(L.ptr(lens), L.ptr(indices), B, L.ptr(offsets), L.ptr(total), L.stream_ptr()))
+    n = int(total.item())  # the output's length is data dependent, as in the reference
+    ids_out = torch.empty(n, dtype=torch.int64, device=dev)
+    scores_out = torch.empty(n, dtype=torch.float32, device=dev) if scores is not None else None
+    if n:
+        _run("rg_ragged_copy", dict(B=B),
+             lambda: L.lib().rg_ragged_copy(L.ptr(ids), L.ptr(scores), ids.shape[1], L.ptr(lens), L.ptr(indices), L.ptr(offsets),
+                                            B, L.ptr(ids_out), L.ptr(scores_out), L.stream_ptr()))
+    return offsets, ids_out, scores_out
+
+
 def make_policy_input(action, next_action, terminal, log_prob, ranges, action_out, next_action_out, not_terminal,
                       action_probability=None):
     """PolicyNetworkInputMaker's arithmetic in one launch; ranges [4, A] = prev_min, prev_max, new_min, new_max"""

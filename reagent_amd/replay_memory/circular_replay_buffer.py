@@ -96,6 +96,7 @@ class ReplayBuffer:
         self._transition_elements: List[str] = []
         self._batch_type = collections.namedtuple("filler", [])
         self._zero_transition = {}
+        self._sparse = {}  # sparse (id-list / id-score-list) elements: replay_memory/ragged.py
 
     # ---- storage -----------------------------------------------------------------------------
     def initialize_buffer(self, **kwargs):
@@ -103,10 +104,20 @@ class ReplayBuffer:
         assert set(REQUIRED_KEYS).issubset(kwarg_keys), f"{kwarg_keys} doesn't contain all of {REQUIRED_KEYS}"
         # deterministic order (the reference iterates a set, :394; consumers address fields by name)
         self._extra_keys = sorted(kwarg_keys - set(REQUIRED_KEYS))
+        self._sparse = {}
         for k in REQUIRED_KEYS + self._extra_keys:
             ex = kwargs[k]
-            if isinstance(ex, (dict, torch.Tensor)):
-                raise ValueError(f"Unable to deduce a dense type for {k}: sparse/tensor inputs are not supported")
+            if isinstance(ex, torch.Tensor):
+                raise ValueError(f"Unable to deduce type for {k}: Input shouldn't be tensor")
+            if isinstance(ex, dict):  # IDListMetadata / IDScoreListMetadata (:144-274): ragged columns in HBM
+                if k in REQUIRED_KEYS:
+                    raise ValueError(f"Unable to deduce a dense type for {k}")
+                if self._stack_size != 1:
+                    raise NotImplementedError("sparse replay elements with stack_size > 1 (the reference leaves it TODO, :150)")
+                from .ragged import RaggedElement
+
+                self._sparse[k] = RaggedElement(k, ex, self._replay_capacity, self.device)
+                continue
             arr = np.array(ex)
             dtype = np.dtype("float32") if arr.dtype == np.dtype("float64") else arr.dtype
             if dtype not in _NP2TORCH:
@@ -120,6 +131,7 @@ class ReplayBuffer:
         self._transition_elements = self.get_transition_elements()
         self._batch_type = collections.namedtuple("batch_type", self._transition_elements)
         self._zero_transition = {k: np.zeros(self._shapes[k], dtype=self._np_dtypes[k]) for k in self._store}
+        self._zero_transition.update({k: el.zero_example() for k, el in self._sparse.items()})
         self._initialized_buffer = True
 
     @property
@@ -137,14 +149,16 @@ class ReplayBuffer:
         self._valid_dirty = True
 
     def get_add_args_signature(self):
-        return list(self._store.keys())
+        return list(self._store.keys()) + list(self._sparse.keys())
 
     def _check_args_length(self, **kwargs):
-        if len(kwargs) != len(self._store):
+        if len(kwargs) != len(self._store) + len(self._sparse):
             raise ValueError(f"Add expects: {self.get_add_args_signature()}; received {kwargs}")
 
     def _check_add_types(self, **kwargs):
         self._check_args_length(**kwargs)
+        for k, el in self._sparse.items():
+            el.validate(kwargs[k])
         for k in self._store:
             v = kwargs[k]
             assert not isinstance(v, (dict, torch.Tensor)), f"{k}: {type(v)} is dict or torch.Tensor"
@@ -184,6 +198,9 @@ class ReplayBuffer:
         self._check_args_length(**kwargs)
         cursor = self.cursor()
         for k, v in kwargs.items():
+            if k in self._sparse:
+                self._sparse[k].set(int(cursor), v)
+                continue
             arr = np.array(v, dtype=self._np_dtypes[k])
             if k == "terminal":
                 arr = arr.astype(bool)
@@ -317,6 +334,11 @@ class ReplayBuffer:
                 key, idx = "reward", indices  # the stored rewards as a stack at `indices`, not the n-step sum (:680-683)
             elif name in ("indices", "terminal", "reward", "step"):
                 continue
+            elif name in self._sparse or (name.startswith("next_") and name[len("next_"):] in self._sparse):
+                # Dict[feature -> (offsets, ids[, scores])], circular_replay_buffer.py:178-195, :247-274
+                el = self._sparse.get(name) or self._sparse[name[len("next_"):]]
+                results[name] = el.sample_to_output(indices if name in self._sparse else next_indices)
+                continue
             elif name in self._store:
                 key, idx = name, indices
             elif name.startswith("next_"):
@@ -435,6 +457,8 @@ class ReplayBuffer:
         iterations back is deleted.  Device columns are copied to the host for writing."""
         if not os.path.exists(checkpoint_dir):
             return
+        if self._sparse:  # (the reference's np.save(allow_pickle=False) of their object arrays raises as well)
+            raise ValueError("sparse (id-list) replay elements cannot be checkpointed")
         elements = self._return_checkpointable_elements()
         for name in self._EXTRA_STATE:
             elements[_RG_FILENAME_PREFIX + name] = np.asarray(getattr(self, name))

@@ -434,3 +434,52 @@ def test_stack_slaughter(backend):
         np.testing.assert_array_equal(got.extra1.cpu().numpy(), 3.0 * frames.astype(np.float32))
         np.testing.assert_array_equal(got.terminal.cpu().numpy().reshape(-1), np.array(exp_term))
         np.testing.assert_array_equal(got.reward.cpu().numpy().reshape(-1), 2.0 * np.array(last, dtype=np.float32))
+
+
+def test_reference_known_answers_sparse_input(backend):
+    """extra_replay_buffer_test.py:380-470 (test_sparse_input) restated: id-list and id-score-list elements, their
+    next_ variants, offsets / ids / scores of a sampled batch"""
+    C = 100
+    num = C // 2
+    m = ReplayBuffer(stack_size=1, replay_capacity=C, update_horizon=1, device=backend.device)
+
+    def trans(i):
+        f1, f2 = list(range(0, i % 4)), list(range(i % 4, 4))
+        f3 = (list(range(0, i % 7)), [k + 0.5 for k in range(0, i % 7)])
+        f4 = (list(range(i % 7, 7)), [k + 0.5 for k in range(i % 7, 7)])
+        return dict(observation=np.ones(OBS, dtype=np.uint8), action=int(2 * i), reward=float(3 * i), terminal=i % 4,
+                    id_list={"sparse_feat1": f1, "sparse_feat2": f2}, id_score_list={"sparse_feat3": f3, "sparse_feat4": f4})
+
+    for i in range(num):
+        m.add(**trans(i))
+    indices = list(range(num - 1))
+    batch = m.sample_transition_batch(len(indices), torch.tensor(indices))
+    res = {"id_list": {"sparse_feat1": ([], []), "sparse_feat2": ([], [])},
+           "id_score_list": {"sparse_feat3": ([], [], []), "sparse_feat4": ([], [], [])},
+           "next_id_list": {"sparse_feat1": ([], []), "sparse_feat2": ([], [])},
+           "next_id_score_list": {"sparse_feat3": ([], [], []), "sparse_feat4": ([], [], [])}}
+    for i in range(num - 1):
+        for k, src in (("id_list", trans(i)), ("id_score_list", trans(i)), ("next_id_list", trans(i + 1)), ("next_id_score_list", trans(i + 1))):
+            orig = k[len("next_"):] if k.startswith("next_") else k
+            for feat in res[k]:
+                res[k][feat][0].append(len(res[k][feat][1]))
+                if orig == "id_list":
+                    res[k][feat][1].extend(src[orig][feat])
+                else:
+                    res[k][feat][1].extend(src[orig][feat][0])
+                    res[k][feat][2].extend(src[orig][feat][1])
+    for k in res:
+        got = getattr(batch, k)
+        for feat, want in res[k].items():
+            assert len(got[feat]) == len(want)
+            assert got[feat][0].dtype == torch.int32 and got[feat][1].dtype == torch.int64
+            for g_, w_ in zip(got[feat], want):
+                np.testing.assert_array_equal(g_.cpu().numpy(), np.asarray(w_, dtype=g_.cpu().numpy().dtype))
+    m.sample_transition_batch(10)  # sample random
+    with pytest.raises(AssertionError, match="not in"):
+        m.add(**{**trans(3), "id_list": {"unknown_feature": [1]}})
+    long = trans(5)
+    long["id_list"] = {"sparse_feat1": list(range(37)), "sparse_feat2": []}  # longer than the slots: they grow
+    m.add(**long)
+    got = m.sample_transition_batch(1, torch.tensor([num]))
+    assert got.id_list["sparse_feat1"][1].cpu().tolist() == list(range(37)) and got.id_list["sparse_feat2"][1].numel() == 0
