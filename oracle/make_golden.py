@@ -199,12 +199,16 @@ SAC_CASES = {
     # layer-normed critics (FullyConnectedCritic(use_layer_norm=True)), plain actor
     "sac_ln_critics": dict(state_dim=6, action_dim=2, sizes=[32, 24], activations=["relu", "relu"],
                            rl=dict(gamma=0.98, target_update_rate=0.1), lr=0.003, batch=48, steps=3, critic_layer_norm=True),
+    # layer-normed Gaussian actor: LayerNorm in its FC stack and on loc / scale_log (actor.py:146-155, 194-196)
+    "sac_ln_actor": dict(state_dim=6, action_dim=3, sizes=[32, 24], activations=["relu", "relu"],
+                         rl=dict(gamma=0.98, target_update_rate=0.1), lr=0.003, batch=48, steps=3, actor_layer_norm=True),
 }
 
 
 def gen_sac(name, c):
     tr = rh.build_sac(c["state_dim"], c["action_dim"], c["sizes"], c["activations"], c["rl"], c["lr"], seed=0,
                       value=c.get("value", False), crr=c.get("crr"), critic_layer_norm=c.get("critic_layer_norm", False),
+                      actor_layer_norm=c.get("actor_layer_norm", False),
                       **c.get("trainer_kw", {}))
     arrays = {}
     nets = dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network)

@@ -146,7 +146,7 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
 
 
 def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, value=False, crr=None,
-              critic_layer_norm=False, **trainer_kw):
+              critic_layer_norm=False, actor_layer_norm=False, **trainer_kw):
     """value=True adds a value network (FloatFeatureFullyConnected state -> 1, what the reference's value net builder
     makes); crr = CRRWeightFn arguments."""
     _install()
@@ -155,7 +155,7 @@ def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, 
     from reagent.training.sac_trainer import CRRWeightFn, SACTrainer
 
     torch.manual_seed(seed)
-    actor = GaussianFullyConnectedActor(state_dim, action_dim, sizes, activations)
+    actor = GaussianFullyConnectedActor(state_dim, action_dim, sizes, activations, use_layer_norm=actor_layer_norm)
     q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm)
     q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm)
     if value:

@@ -7,6 +7,7 @@ from typing import List
 
 import torch
 
+from .. import _lib as L
 from .. import ops
 from ..core import types as rlt
 from .base import ModelBase
@@ -31,15 +32,19 @@ class GaussianFullyConnectedActor(ModelBase):
         super().__init__()
         assert state_dim > 0, "state_dim must be > 0, got {}".format(state_dim)
         assert action_dim > 0, "action_dim must be > 0, got {}".format(action_dim)
-        if use_l2_normalization or use_layer_norm or use_batch_norm:
-            raise NotImplementedError("l2 / layer / batch normalisation are off on the MI355X hot path")
+        if use_l2_normalization or use_batch_norm:
+            raise NotImplementedError("l2 / batch normalisation are off on the MI355X hot path")
         self.state_dim = state_dim
         self.action_dim = action_dim
         assert len(sizes) == len(activations), (
             "The numbers of sizes and activations must match; got {} vs {}".format(len(sizes), len(activations))
         )
-        self.fc = FullyConnectedNetwork([state_dim] + list(sizes) + [action_dim * 2], list(activations) + ["linear"])
-        self.use_layer_norm = False
+        self.fc = FullyConnectedNetwork([state_dim] + list(sizes) + [action_dim * 2], list(activations) + ["linear"],
+                                        use_layer_norm=use_layer_norm)
+        self.use_layer_norm = use_layer_norm
+        if self.use_layer_norm:  # actor.py:153-155: loc and scale_log are each normalised over the action dimension
+            self.loc_layer_norm = torch.nn.LayerNorm(action_dim)
+            self.scale_layer_norm = torch.nn.LayerNorm(action_dim)
         self.use_l2_normalization = False
         self.const = math.log(math.sqrt(2 * math.pi))
         self.eps = 1e-6
@@ -48,8 +53,22 @@ class GaussianFullyConnectedActor(ModelBase):
     def input_prototype(self):
         return rlt.FeatureData(torch.randn(1, self.state_dim))
 
-    def _get_loc_and_scale_log(self, state):
+    def head_norm(self, raw: torch.Tensor, out: torch.Tensor, stats=None):
+        """loc_layer_norm / scale_layer_norm (actor.py:194-196) on the two halves of the FC output `raw` [B, 2A] -> `out`;
+        stats = ((mean, rstd), (mean, rstd)) buffers kept for the backward (None: inference)"""
+        A = self.action_dim
+        for h, ln in enumerate((self.loc_layer_norm, self.scale_layer_norm)):
+            m, r = stats[h] if stats is not None else (None, None)
+            ops.layer_norm_forward(raw[:, h * A:(h + 1) * A], ln.weight.detach(), ln.bias.detach(), ln.eps, L.ACT["linear"],
+                                   y32=out[:, h * A:(h + 1) * A], mean=m, rstd=r)
+        return out
+
+    def _fc_out(self, state):
         loc_scale = self.fc(state.float_features)
+        return self.head_norm(loc_scale, torch.empty_like(loc_scale)) if self.use_layer_norm else loc_scale
+
+    def _get_loc_and_scale_log(self, state):
+        loc_scale = self._fc_out(state)
         loc = loc_scale[::, : self.action_dim]
         scale_log = loc_scale[::, self.action_dim :].clamp(LOG_PROB_MIN, LOG_PROB_MAX)
         return loc, scale_log
@@ -62,7 +81,7 @@ class GaussianFullyConnectedActor(ModelBase):
 
     @torch.no_grad()
     def forward(self, state):
-        loc_scale = self.fc(state.float_features)
+        loc_scale = self._fc_out(state)
         B, dev = loc_scale.shape[0], loc_scale.device
         action = torch.empty(B, self.action_dim, device=dev)
         log_prob = torch.empty(B, 1, device=dev)
@@ -72,7 +91,7 @@ class GaussianFullyConnectedActor(ModelBase):
 
     @torch.no_grad()
     def get_log_prob(self, state, squashed_action: torch.Tensor):
-        loc_scale = self.fc(state.float_features)
+        loc_scale = self._fc_out(state)
         log_prob = torch.empty(loc_scale.shape[0], 1, device=loc_scale.device)
         a = squashed_action if squashed_action.stride(-1) == 1 else squashed_action.contiguous()
         ops.gaussian_log_prob(loc_scale, a.float(), log_prob)

@@ -280,6 +280,11 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             cat_shape = (0, S + A) if self._panels else (B, S + A)  # assembled inputs: per-layer GEMM engine only
             self._x, self._xn, self._xa = (torch.empty(*cat_shape, **f) for _ in range(3))
             self._ls, self._lsn, self._dls = (torch.empty(B, 2 * A, **f) for _ in range(3))
+            if getattr(self.actor_network, "use_layer_norm", False):  # raw FC outputs / their gradient + LN statistics
+                self._ls_raw, self._dls_raw = torch.empty(B, 2 * A, **f), torch.empty(B, 2 * A, **f)
+                self._ln_stats = tuple((torch.empty(B, **f), torch.empty(B, **f)) for _ in range(2))
+                nb = L.lib().rg_layer_norm_backward_workspace_bytes(B, A)
+                self._ln_ws = torch.empty((nb + 3) // 4, **f)
             self._lp, self._lpn = torch.empty(B, **f), torch.empty(B, **f)
             names = ["q1v", "q2v", "q1t", "q2t", "q1a", "q2a", "dq1", "dq2", "dq1a", "dq2a", "y", "glp", "vcur", "vval", "dv", "yv"]
             for n in names:
@@ -308,6 +313,15 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         if t.dtype not in (torch.float32, torch.bfloat16):
             t = t.float()
         return t if t.is_contiguous() else t.contiguous()
+
+    def _actor_out(self, act, x, out, save: bool):
+        """actor FC stack -> [loc | scale_log] in `out`; a layer-normed actor passes both halves through their
+        LayerNorm (actor.py:194-196), keeping the raw outputs and the statistics of a saving call"""
+        if not getattr(self.actor_network, "use_layer_norm", False):
+            return act.forward(x, out, save=save)
+        raw = self._ls_raw if save else self._dls_raw  # (the gradient buffer is free during a forward)
+        act.forward(x, raw, save=save)
+        return self.actor_network.head_norm(raw, out, self._ln_stats if save else None)
 
     def _publish(self, e, held=()):
         slab = e["slab"]
@@ -358,7 +372,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             return
         # a' = actor(s'), log_prob'  (actor frozen in this segment)
         xn_s, _ = act.stage_input(next_state, need_transposed=False)
-        act.forward(xn_s, self._lsn, save=False)
+        self._actor_out(act, xn_s, self._lsn, save=False)
         if self._panels:
             ops.gaussian_head_forward(self._lsn, noise_next, self._an, self._lpn, None)
             t["q1"].forward(next_state, self._q1t, save=False, x2=self._an)
@@ -410,7 +424,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                 e[k]["stack"].stage_weights(need_transposed=True)
         act = e["actor"]["stack"]
         xs_c, self._xs_t = act.stage_input(state, need_transposed=True)
-        act.forward(xs_c, self._ls, save=True)
+        self._actor_out(act, xs_c, self._ls, save=True)
         self._noise_cur = noise_cur
         q1s = e["q1"]["stack"]
         has_q2 = "q2" in e
@@ -471,6 +485,16 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         dls = self._dls if grad_out is None else self._dls * grad_out
         a = e["actor"]
         held = held_gradients(a["slab"], a["params"])
+        if getattr(self.actor_network, "use_layer_norm", False):  # through loc_layer_norm / scale_layer_norm first
+            an, A = self.actor_network, self._A
+            index = {id(p): i for i, p in enumerate(a["params"])}
+            view = lambda p: a["slab"].view(a["slab"].grad, index[id(p)])  # noqa: E731
+            for h, ln in enumerate((an.loc_layer_norm, an.scale_layer_norm)):
+                sl = slice(h * A, (h + 1) * A)
+                m, r = self._ln_stats[h]
+                ops.layer_norm_backward(dls[:, sl], self._ls_raw[:, sl], m, r, ln.weight.detach(), view(ln.weight),
+                                        view(ln.bias), self._ln_ws, dz32=self._dls_raw[:, sl])
+            dls = self._dls_raw
         a["stack"].backward(dls, self._xs_t, a["dw"], a["db"])
         self._publish(a, held)
 
