@@ -22,6 +22,25 @@ def _build(kind):
     from reagent_amd.training import DQNTrainer, SACTrainer
 
     torch.manual_seed(0)  # identical initial weights on every rank
+    if kind in ("dqn_fused", "sac_fused"):  # bf16 engine on the fused kernels: the one-launch updates under 1/world scaling
+        import reagent_amd._lib as L
+        from reagent_amd.models import set_default_precision
+
+        set_default_precision(L.PREC_BF16)
+        try:
+            if kind == "dqn_fused":
+                q = FullyConnectedDQN(12, 4, [256, 256], ["relu", "relu"])
+                return DQNTrainer(q, q.get_target_network(), None, actions=["a", "b", "c", "d"],
+                                  rl=RLParameters(gamma=0.9, target_update_rate=0.1, q_network_loss="huber"),
+                                  optimizer=Optimizer__Union.default(lr=0.001),
+                                  evaluation=EvaluationParameters(calc_cpe_in_training=False))
+            nets = [GaussianFullyConnectedActor(32, 2, [256, 256], ["relu", "relu"]), FullyConnectedCritic(32, 2, [256, 256], ["relu", "relu"]),
+                    FullyConnectedCritic(32, 2, [256, 256], ["relu", "relu"])]
+        finally:
+            set_default_precision(L.PREC_F32)
+        adam = lambda: Optimizer__Union.default(lr=0.001)  # noqa: E731
+        return SACTrainer(nets[0], nets[1], nets[2], rl=RLParameters(gamma=0.9, target_update_rate=0.1), q_network_optimizer=adam(),
+                          actor_network_optimizer=adam(), alpha_optimizer=adam())
     if kind.startswith("dqn"):
         q = FullyConnectedDQN(12, 4, [32, 16], ["relu", "relu"])
         return DQNTrainer(q, q.get_target_network(), None, actions=["a", "b", "c", "d"],
@@ -64,6 +83,8 @@ def _build(kind):
 def _batches(kind, B):
     from reagent_amd import synthetic
 
+    if kind == "sac_fused":
+        return synthetic.policy_batch(B, 32, 2, seed=5)
     if kind.startswith("dqn"):
         return synthetic.dqn_batch(B, 12, 4, seed=5, p_impossible=0.2)
     if kind == "crr":
@@ -82,7 +103,7 @@ def _step(kind, tr, d, noise=None):
         lightning_like_step(tr, tr._test_opts, synthetic.to_dqn_input(d))
     elif kind == "dqn_deferred":  # async all-reduce, Adam joined at the start of the next step
         tr.train_step_native(synthetic.to_dqn_input(d), defer_update=True)
-    elif kind in ("dqn", "crr"):
+    elif kind in ("dqn", "crr", "dqn_fused"):
         tr.train_step_native(synthetic.to_dqn_input(d))
     elif kind == "td3":
         tr.train_step_native(synthetic.to_policy_input(d), noise[0])
@@ -106,8 +127,13 @@ def _worker(rank, world, port, kind, out_dir):
     noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
     my_noise = tuple(n[rank * B // 2 : (rank + 1) * B // 2].contiguous() for n in noise)
     tr = _build(kind).enable_data_parallel()
-    for _ in range(2):
+    for _ in range(3 if kind.endswith("_fused") else 2):  # (the one-launch update starts at the second step)
         _step(kind, tr, half, my_noise)
+    if kind.endswith("_fused"):
+        from reagent_amd.engine import FusedMLP
+
+        st = tr._qs if kind == "dqn_fused" else tr._e["q1"]["stack"]
+        assert isinstance(st, FusedMLP) and tr._fused_plan not in (None, False)
     if kind == "dqn_deferred":
         assert tr._update_pending  # the last update is still waiting for its all-reduce
         tr.apply_pending_update()
@@ -207,3 +233,24 @@ def test_rccl_async_reduce_single_rank_group():
             assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["dqn_fused", "sac_fused"])
+def test_two_ranks_on_the_fused_engine_stay_bit_identical(tmp_path, emu_lib, kind):
+    """bf16 fused stacks under data parallelism: the one-launch Adam + soft update + re-staging (rg_mlp_update_fused,
+    engine.FusedUpdate) with the 1/world factor folded in; replicas bit-identical, and close to the single-process
+    run on the concatenated batch (bf16 gradients summed in another order: a few weights move by up to lr per step)"""
+    port = 29500 + (os.getpid() % 2000) + {"dqn_fused": 11, "sac_fused": 12}[kind]
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    B = 64
+    full = _batches(kind, B)
+    g = torch.Generator().manual_seed(9)
+    noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
+    tr = _build(kind)
+    for _ in range(3):
+        _step(kind, tr, full, noise)
+    for a, p in zip(r0, tr.parameters()):
+        assert (a.double() - p.detach().double()).abs().max() <= 3 * 2 * 0.001 + 1e-6, kind
