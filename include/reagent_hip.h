@@ -93,6 +93,35 @@ int rg_layer_norm_backward(const float* g, int64_t ldg, const float* z, int64_t 
                            int64_t lddz32, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                            rg_stream_t stream);
 
+/* nn.BatchNorm1d(n) on a layer's INPUT — FullyConnectedNetwork's use_batch_norm option (SlateBatchNorm1d on
+ * [batch, features], reagent/models/fully_connected_network.py:48-64,107-108).  x, y [batch, n] fp32.
+ * training != 0: y = (x - mean_b) / sqrt(var_b + eps) * gamma + beta with the batch mean and BIASED variance, which are
+ *   kept in save_mean / save_rstd [n] for the backward; running_mean / running_var (nullable) move by `momentum`
+ *   toward the batch mean and the UNBIASED variance (torch.nn.functional.batch_norm), `stat_updates` times (1; 2 for a
+ *   module the reference evaluates twice on the same batch, actor.py:215-231; 0 leaves them alone).  `workspace` holds the
+ *   fixed-order fp64 column partials (rg_batch_norm_workspace_bytes).
+ * training == 0: the running statistics normalise; save_* and workspace are not touched.  gamma / beta nullable. */
+size_t rg_batch_norm_workspace_bytes(int batch, int n);
+int rg_batch_norm_forward(const float* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, int training, int stat_updates, double momentum, double eps, int batch, int n, float* y,
+                          int64_t ldy, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes,
+                          rg_stream_t stream);
+/* g = d loss / d y.  training != 0: mean / rstd are the forward's save_mean / save_rstd and
+ *   dx = gamma * rstd * (g - mean_b(g) - xhat * mean_b(g * xhat)); training == 0: mean = running_mean, rstd null,
+ *   running_var + eps give the scale and dx = gamma * rstd * g.  dgamma = sum_b g * xhat, dbeta = sum_b g
+ *   (each nullable, overwritten); dx nullable. */
+int rg_batch_norm_backward(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* gamma,
+                           const float* mean, const float* rstd, const float* running_var, int training, double eps,
+                           int batch, int n, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* workspace,
+                           size_t workspace_bytes, rg_stream_t stream);
+
+/* nn.Dropout(p) after a layer's activation (fully_connected_network.py:139-141), training mode.
+ * generate != 0: keep [batch * n] bytes ~ Bernoulli(1 - p) from Philox4x32-10 keyed by `seed`, counter (element / 4,
+ *   offset) — a different `offset` per call gives an independent mask — and y = x * keep / (1 - p).
+ * generate == 0: `keep` is read (the backward pass: x = d loss / d y, y = d loss / d x).  x may alias y. */
+int rg_dropout(const float* x, int64_t ldx, int batch, int n, double p, int generate, uint64_t seed, uint64_t offset,
+               uint8_t* keep, float* y, int64_t ldy, rg_stream_t stream);
+
 /* dz = dy * act'(z) written through the activation output y = act(z), fp32 [rows, cols]: turns the
  * gradient w.r.t. a non-linear OUTPUT layer (FullyConnectedActor's tanh head,
  * reagent/models/actor.py:71-75) into the pre-activation gradient the backward entry points take. */

@@ -74,6 +74,16 @@ DQN_CASES = {
     "dqn_layernorm": dict(state_dim=11, num_actions=4, sizes=[40, 24], activations=["relu", "tanh"],
                           rl=dict(gamma=0.95, target_update_rate=0.1, maxq_learning=True, q_network_loss="huber"),
                           lr=0.003, double_q=True, batch=64, steps=3, p_impossible=0.2, with_steps=False, layer_norm=True),
+    # use_batch_norm: BatchNorm1d on every layer's input, all networks in training mode (batch statistics in the online
+    # AND the target forwards; running statistics move in every forward, the post-step one of :268 included)
+    "dqn_batchnorm": dict(state_dim=9, num_actions=3, sizes=[32, 24], activations=["relu", "leaky_relu"],
+                          rl=dict(gamma=0.96, target_update_rate=0.2, maxq_learning=True, q_network_loss="mse"),
+                          lr=0.004, double_q=True, batch=72, steps=3, p_impossible=0.2, with_steps=False, batch_norm=True),
+    # the default net builder's dueling network with use_batch_norm (the trunk's layers are batch-normed,
+    # dueling_q_network.py:60-67)
+    "dqn_dueling_bn": dict(state_dim=10, num_actions=4, sizes=[32, 24], activations=["relu", "relu"],
+                           rl=dict(gamma=0.95, target_update_rate=0.15, maxq_learning=True), lr=0.003, double_q=True,
+                           batch=64, steps=2, p_impossible=0.2, with_steps=False, dueling=True, batch_norm=True),
 }
 
 
@@ -81,7 +91,8 @@ def gen_dqn(name, c):
     cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
                       double_q=c["double_q"], seed=0, cpe_metrics=cpe_metrics, bcq_threshold=c.get("bcq_threshold"),
-                      dueling=c.get("dueling", False), layer_norm=c.get("layer_norm", False))
+                      dueling=c.get("dueling", False), layer_norm=c.get("layer_norm", False),
+                      batch_norm=c.get("batch_norm", False))
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
@@ -102,7 +113,12 @@ def gen_dqn(name, c):
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
         arrays[f"step{s}_q"] = _np(tr.all_action_scores)
-        if c.get("dueling") or c.get("layer_norm"):  # d loss / d parameters as autograd produced them (newer fixtures carry them)
+        if c.get("batch_norm"):  # running_mean / running_var / num_batches_tracked of both networks, module order
+            for i, bf in enumerate(tr.q_network.buffers()):
+                arrays[f"step{s}_qbuf_{i}"] = _np(bf)
+            for i, bf in enumerate(tr.q_network_target.buffers()):
+                arrays[f"step{s}_tbuf_{i}"] = _np(bf)
+        if c.get("dueling") or c.get("layer_norm") or c.get("batch_norm"):  # d loss / d parameters as autograd produced them (newer fixtures carry them)
             for i, gr in enumerate(loop.last_grads[0]):
                 arrays[f"step{s}_grad_{i}"] = _np(gr)
         for i, p in enumerate(tr.q_network.parameters()):
@@ -202,6 +218,11 @@ SAC_CASES = {
     # layer-normed Gaussian actor: LayerNorm in its FC stack and on loc / scale_log (actor.py:146-155, 194-196)
     "sac_ln_actor": dict(state_dim=6, action_dim=3, sizes=[32, 24], activations=["relu", "relu"],
                          rl=dict(gamma=0.98, target_update_rate=0.1), lr=0.003, batch=48, steps=3, actor_layer_norm=True),
+    # batch-normed critics and actor (BatchNorm1d on every layer's input; every network, targets included, stays in
+    # training mode, and the actor's FC stack runs twice per forward: actor.py:215-231 -> get_log_prob :233-261)
+    "sac_bn": dict(state_dim=7, action_dim=3, sizes=[32, 24], activations=["relu", "relu"],
+                   rl=dict(gamma=0.97, target_update_rate=0.1), lr=0.003, batch=56, steps=3, critic_batch_norm=True,
+                   actor_batch_norm=True),
 }
 
 
@@ -209,6 +230,7 @@ def gen_sac(name, c):
     tr = rh.build_sac(c["state_dim"], c["action_dim"], c["sizes"], c["activations"], c["rl"], c["lr"], seed=0,
                       value=c.get("value", False), crr=c.get("crr"), critic_layer_norm=c.get("critic_layer_norm", False),
                       actor_layer_norm=c.get("actor_layer_norm", False),
+                      critic_batch_norm=c.get("critic_batch_norm", False), actor_batch_norm=c.get("actor_batch_norm", False),
                       **c.get("trainer_kw", {}))
     arrays = {}
     nets = dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network)
@@ -248,6 +270,9 @@ def gen_sac(name, c):
         for n, m in after.items():
             for i, p in enumerate(m.parameters()):
                 arrays[f"step{s}_{n}_{i}"] = _np(p)
+            if c.get("critic_batch_norm") or c.get("actor_batch_norm"):  # running statistics, module order
+                for i, bf in enumerate(m.buffers()):
+                    arrays[f"step{s}_{n}_buf_{i}"] = _np(bf)
     _save(name, c, arrays)
 
 
@@ -261,6 +286,13 @@ REPLAY_CASES = {
     # return_everything_as_stack: `reward` is the stack of stored rewards at the sampled index, not the n-step sum
     "replay_all_stack": dict(stack_size=3, replay_capacity=48, update_horizon=2, gamma=0.9, n_add=110, obs_dim=3,
                              num_actions=3, p_terminal=0.08, batch=32, return_everything_as_stack=True),
+    # return_as_timeline_format: next_* elements and `reward` are lists, entry i = the steps[i] rows after transition i
+    # (stored here concatenated: out_<k>_flat, split by out_step)
+    "replay_timeline": dict(stack_size=1, replay_capacity=56, update_horizon=4, gamma=0.9, n_add=130, obs_dim=3,
+                            num_actions=3, p_terminal=0.12, batch=36, return_as_timeline_format=True),
+    "replay_timeline_stack": dict(stack_size=2, replay_capacity=40, update_horizon=3, gamma=0.95, n_add=90, obs_dim=2,
+                                  num_actions=2, p_terminal=0.1, batch=28, return_as_timeline_format=True,
+                                  return_everything_as_stack=True),
 }
 
 
@@ -301,13 +333,17 @@ TD3_CASES = {
     "td3_twin": dict(state_dim=7, action_dim=3, sizes=[32, 24], activations=["relu", "relu"],
                      rl=dict(gamma=0.98, target_update_rate=0.1), lr=0.004, batch=48, steps=4,
                      noise_variance=0.3, noise_clip=0.4, delayed_policy_update=2),
+    # batch-normed deterministic actor (and its target, both in training mode); plain critics — see build_td3
+    "td3_bn": dict(state_dim=6, action_dim=2, sizes=[24, 16], activations=["relu", "tanh"],
+                   rl=dict(gamma=0.97, target_update_rate=0.15), lr=0.003, batch=40, steps=4,
+                   noise_variance=0.2, noise_clip=0.3, delayed_policy_update=2, batch_norm=True),
 }
 
 
 def gen_td3(name, c):
     tr = rh.build_td3(c["state_dim"], c["action_dim"], c["sizes"], c["activations"], c["rl"], c["lr"], seed=0,
                       noise_variance=c["noise_variance"], noise_clip=c["noise_clip"],
-                      delayed_policy_update=c["delayed_policy_update"])
+                      delayed_policy_update=c["delayed_policy_update"], actor_batch_norm=c.get("batch_norm", False))
     arrays = {}
     for n, m in dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network).items():
         for i, p in enumerate(m.parameters()):
@@ -330,6 +366,9 @@ def gen_td3(name, c):
         for n, m in nets.items():
             for i, p in enumerate(m.parameters()):
                 arrays[f"step{s}_{n}_{i}"] = _np(p)
+            if c.get("batch_norm"):
+                for i, bf in enumerate(m.buffers()):
+                    arrays[f"step{s}_{n}_buf_{i}"] = _np(bf)
     _save(name, c, arrays)
 
 
@@ -593,7 +632,8 @@ def gen_replay(name, c):
 
     rb = ReplayBuffer(stack_size=c["stack_size"], replay_capacity=c["replay_capacity"], batch_size=c["batch"],
                       update_horizon=c["update_horizon"], gamma=c["gamma"],
-                      return_everything_as_stack=c.get("return_everything_as_stack", False))
+                      return_everything_as_stack=c.get("return_everything_as_stack", False),
+                      return_as_timeline_format=c.get("return_as_timeline_format", False))
     rng = np.random.RandomState(7)
     adds = dict(observation=[], action=[], reward=[], terminal=[], possible_actions_mask=[], log_prob=[],
                 mdp_id=[])
@@ -622,6 +662,9 @@ def gen_replay(name, c):
         v = getattr(batch, k)
         if isinstance(v, torch.Tensor):
             arrays[f"out_{k}"] = v.numpy()
+        elif isinstance(v, list):  # timeline format: one tensor [steps[i], ...] per transition
+            assert [len(t) for t in v] == batch.step.reshape(-1).tolist()
+            arrays[f"out_{k}_flat"] = torch.cat(v, dim=0).numpy()
     _save(name, c, arrays)
 
 
@@ -890,6 +933,47 @@ def gen_prioritized():
                                      max_sample_attempts=200), arrays)
 
 
+def gen_fc_options():
+    """The reference's FullyConnectedNetwork with batch-norm + layer-norm + residual wrappers (+ dropout, exercised in
+    eval mode where it is the identity): state_dict names, a training-mode forward / backward (batch statistics; the
+    running statistics after it) and an eval-mode forward (fully_connected_network.py:101-163)."""
+    rh._install()
+    from reagent.models.fully_connected_network import FullyConnectedNetwork
+
+    cfg = dict(layers=[12, 20, 20, 20, 5], activations=["relu", "tanh", "leaky_relu", "linear"], dropout_ratio=0.3, batch=40)
+    torch.manual_seed(21)
+    net = FullyConnectedNetwork(cfg["layers"], cfg["activations"], use_batch_norm=True, use_layer_norm=True,
+                                dropout_ratio=0.0, use_skip_connections=True)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.2)
+    arrays = {"names": np.array(list(net.state_dict().keys()))}
+    for i, (k, v) in enumerate(net.state_dict().items()):
+        arrays[f"init_{i}"] = _np(v)
+    gen = torch.Generator().manual_seed(22)
+    x = torch.randn(cfg["batch"], cfg["layers"][0], generator=gen) * 1.5 + 0.3
+    dout = torch.randn(cfg["batch"], cfg["layers"][-1], generator=gen) / cfg["batch"]
+    arrays["x"], arrays["dout"] = _np(x), _np(dout)
+    xr = x.clone().requires_grad_()
+    net.train()
+    y = net(xr)
+    y.backward(dout)
+    arrays["train_out"], arrays["train_dx"] = _np(y), _np(xr.grad)
+    for i, (k, p) in enumerate(net.named_parameters()):
+        arrays[f"train_grad_{i}"] = _np(p.grad)
+    for i, (k, v) in enumerate(net.state_dict().items()):
+        arrays[f"after_{i}"] = _np(v)  # parameters unchanged, running statistics moved once
+    net.eval()
+    with torch.no_grad():
+        arrays["eval_out"] = _np(net(x))
+        # the same weights under a network WITH dropout layers: identity in eval mode, same names otherwise
+        net_d = FullyConnectedNetwork(cfg["layers"], cfg["activations"], use_batch_norm=True, use_layer_norm=True,
+                                      dropout_ratio=cfg["dropout_ratio"], use_skip_connections=True)
+        arrays["names_dropout"] = np.array(list(net_d.state_dict().keys()))
+    _save("fc_options", cfg, arrays)
+
+
 def check():
     """`python -m oracle.make_golden --check`: regenerate every fixture into a scratch directory and compare
     it, array by array, with the committed file — the committed vectors are what the unmodified reference
@@ -958,6 +1042,7 @@ def main():
     gen_offline_table()
     gen_policy_batch()
     gen_policy_input_maker()
+    gen_fc_options()
     gen_sum_tree()
     gen_prioritized()
 

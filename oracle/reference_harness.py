@@ -90,7 +90,7 @@ def make_adam(lr=1e-3, **kw):
 
 
 def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_q=True, seed=0,
-              num_atoms=None, cpe_metrics=None, bcq_threshold=None, dueling=False, layer_norm=False):
+              num_atoms=None, cpe_metrics=None, bcq_threshold=None, dueling=False, layer_norm=False, batch_norm=False):
     """Reference FullyConnectedDQN (+ target) and DQNTrainer / QRDQNTrainer.  cpe_metrics: None = CPE
     off; a list of extra metric names (may be empty) = calc_cpe_in_training with reward_network,
     q_network_cpe and its target of output width (len(cpe_metrics) + 1) * num_actions
@@ -104,9 +104,12 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
     if dueling:
         from reagent.models.dueling_q_network import DuelingQNetwork
 
-        q = DuelingQNetwork.make_fully_connected(state_dim, num_actions, sizes, activations, num_atoms=num_atoms)
+        q = DuelingQNetwork.make_fully_connected(state_dim, num_actions, sizes, activations, num_atoms=num_atoms,
+                                                 use_batch_norm=batch_norm)
     else:  # layer_norm: Linear -> LayerNorm -> activation on the hidden layers (fully_connected_network.py:128-130)
-        q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms, use_layer_norm=layer_norm)
+        # batch_norm: BatchNorm1d on every layer's input (:107-108); the trainer leaves all networks in training mode
+        q = FullyConnectedDQN(state_dim, num_actions, sizes, activations, num_atoms=num_atoms, use_layer_norm=layer_norm,
+                              use_batch_norm=batch_norm)
     qt = q.get_target_network()
     actions = [str(i) for i in range(num_actions)]
     cpe = cpe_metrics is not None
@@ -146,7 +149,7 @@ def build_dqn(state_dim, num_actions, sizes, activations, rl_kwargs, lr, double_
 
 
 def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, value=False, crr=None,
-              critic_layer_norm=False, actor_layer_norm=False, **trainer_kw):
+              critic_layer_norm=False, actor_layer_norm=False, critic_batch_norm=False, actor_batch_norm=False, **trainer_kw):
     """value=True adds a value network (FloatFeatureFullyConnected state -> 1, what the reference's value net builder
     makes); crr = CRRWeightFn arguments."""
     _install()
@@ -155,9 +158,12 @@ def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, 
     from reagent.training.sac_trainer import CRRWeightFn, SACTrainer
 
     torch.manual_seed(seed)
-    actor = GaussianFullyConnectedActor(state_dim, action_dim, sizes, activations, use_layer_norm=actor_layer_norm)
-    q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm)
-    q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm)
+    actor = GaussianFullyConnectedActor(state_dim, action_dim, sizes, activations, use_layer_norm=actor_layer_norm,
+                                        use_batch_norm=actor_batch_norm)
+    q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm,
+                              use_batch_norm=critic_batch_norm)
+    q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations, use_layer_norm=critic_layer_norm,
+                              use_batch_norm=critic_batch_norm)
     if value:
         from reagent.models.fully_connected_network import FloatFeatureFullyConnected
 
@@ -169,14 +175,17 @@ def build_sac(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, 
                       actor_network_optimizer=make_adam(lr), alpha_optimizer=make_adam(lr), **trainer_kw)
 
 
-def build_td3(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, **trainer_kw):
+def build_td3(state_dim, action_dim, sizes, activations, rl_kwargs, lr, seed=0, actor_batch_norm=False, **trainer_kw):
+    """actor_batch_norm: BatchNorm1d on the inputs of the actor's layers.  (Batch-normed CRITICS make TD3's actor loss
+    -mean_b q1(s, actor(s)) constant in the action — the batch mean of a batch-normed layer's output is its beta — so that
+    configuration has an exactly-zero actor gradient and pins nothing but rounding noise.)"""
     _install()
     from reagent.models.actor import FullyConnectedActor
     from reagent.models.critic import FullyConnectedCritic
     from reagent.training.td3_trainer import TD3Trainer
 
     torch.manual_seed(seed)
-    actor = FullyConnectedActor(state_dim, action_dim, sizes, activations)
+    actor = FullyConnectedActor(state_dim, action_dim, sizes, activations, use_batch_norm=actor_batch_norm)
     q1 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
     q2 = FullyConnectedCritic(state_dim, action_dim, sizes, activations)
     return TD3Trainer(actor, q1, q2, rl=make_rl_parameters(**rl_kwargs), q_network_optimizer=make_adam(lr),

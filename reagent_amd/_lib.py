@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RG_LIB: another build of the same library (same-box A/B of compile-time kernel variants); default = the in-tree build
 LIB_PATH = os.environ.get("RG_LIB") or os.path.join(_HERE, "lib", "libreagent_hip.so")
 
-ABI_VERSION = 4  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
+ABI_VERSION = 5  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5}
@@ -181,6 +181,13 @@ SIGNATURES = {
     "rg_layer_norm_backward_workspace_bytes": (c_sz, [c_int, c_int]),
     "rg_layer_norm_backward": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
+    "rg_batch_norm_workspace_bytes": (c_sz, [c_int, c_int]),
+    "rg_batch_norm_forward": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_d, c_d, c_int, c_int,
+                                       c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
+    "rg_batch_norm_backward": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_d,
+                                        c_int, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
+    "rg_dropout": (c_int, [c_void_p, c_i64, c_int, c_int, c_d, c_int, ctypes.c_uint64, ctypes.c_uint64, c_void_p, c_void_p,
+                            c_i64, c_void_p]),
     "rg_ragged_offsets": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_ragged_copy": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_make_policy_input": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int,

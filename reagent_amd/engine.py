@@ -703,11 +703,20 @@ def dx_save(stack):
     return SAVE_FOR_DX if isinstance(stack, FusedMLP) else True
 
 
-def make_stack(weights, biases, acts: List[int], precision: int, layer_norms=None):
+def make_stack(weights, biases, acts: List[int], precision: int, layer_norms=None, batch_norms=None, dropouts=None,
+               residuals=None, training=None):
     """Engine selection: the fused bf16-MFMA kernels when the shape allows (plain bf16 operands for
     PREC_BF16, split-bf16 for PREC_BF16X3), else the per-layer GEMMs.  A PREC_BF16X3 stack whose shape the
-    fused kernels do not serve runs on the exact-fp32 MFMA GEMMs: the accuracy class is what was asked for."""
+    fused kernels do not serve runs on the exact-fp32 MFMA GEMMs: the accuracy class is what was asked for.
+    Batch-norm / dropout / residual layers (off in every BASELINE configuration) go to engine_general."""
     has_ln = layer_norms is not None and any(ln is not None for ln in layer_norms)
+    if ((batch_norms is not None and any(b is not None for b in batch_norms)) or (dropouts is not None and any(dropouts))
+            or (residuals is not None and any(residuals))):
+        from .engine_general import GeneralFCStack
+
+        return GeneralFCStack(weights, biases, acts, L.PREC_F32 if precision == L.PREC_BF16X3 else precision,
+                              layer_norms=layer_norms, batch_norms=batch_norms, dropouts=dropouts, residuals=residuals,
+                              training=training)
     if not has_ln and precision in (L.PREC_BF16, L.PREC_BF16X3) and FusedMLP.supported(weights, acts):
         return FusedMLP(weights, biases, acts, x3=precision == L.PREC_BF16X3)
     # (a stack with LayerNorm between its layers is not of the fused kernels' shape: per-layer GEMMs + rg_layer_norm_*)
@@ -723,4 +732,7 @@ def grad_views(fc, slab, params):
     lns = fc.layer_norms() if hasattr(fc, "layer_norms") else []
     if any(ln is not None for ln in lns):
         fc.stack().bind_ln_grads([(view(ln.weight), view(ln.bias)) if ln is not None else None for ln in lns])
+    bns = fc.batch_norms() if hasattr(fc, "batch_norms") else []
+    if any(bn is not None for bn in bns):
+        fc.stack().bind_bn_grads([(view(bn.weight), view(bn.bias)) if bn is not None else None for bn in bns])
     return [view(l.weight) for l in lin], [view(l.bias) for l in lin]

@@ -32,15 +32,19 @@ class GaussianFullyConnectedActor(ModelBase):
         super().__init__()
         assert state_dim > 0, "state_dim must be > 0, got {}".format(state_dim)
         assert action_dim > 0, "action_dim must be > 0, got {}".format(action_dim)
-        if use_l2_normalization or use_batch_norm:
-            raise NotImplementedError("l2 / batch normalisation are off on the MI355X hot path")
+        if use_l2_normalization:
+            raise NotImplementedError("use_l2_normalization: the reference leaves the log-probability of the normalised "
+                                      "action a TODO (actor.py:237-241); not served on the MI355X path")
         self.state_dim = state_dim
         self.action_dim = action_dim
         assert len(sizes) == len(activations), (
             "The numbers of sizes and activations must match; got {} vs {}".format(len(sizes), len(activations))
         )
         self.fc = FullyConnectedNetwork([state_dim] + list(sizes) + [action_dim * 2], list(activations) + ["linear"],
-                                        use_layer_norm=use_layer_norm)
+                                        use_layer_norm=use_layer_norm, use_batch_norm=use_batch_norm)
+        # the reference's forward() evaluates the stack twice on the same batch (forward :216 and get_log_prob :246): one
+        # evaluation here, but batch-norm layers in training mode move their running statistics twice
+        self.fc.stat_updates = 2
         self.use_layer_norm = use_layer_norm
         if self.use_layer_norm:  # actor.py:153-155: loc and scale_log are each normalised over the action dimension
             self.loc_layer_norm = torch.nn.LayerNorm(action_dim)
@@ -63,8 +67,12 @@ class GaussianFullyConnectedActor(ModelBase):
                                    y32=out[:, h * A:(h + 1) * A], mean=m, rstd=r)
         return out
 
-    def _fc_out(self, state):
-        loc_scale = self.fc(state.float_features)
+    def _fc_out(self, state, evaluations: int = 1):
+        self.fc.stat_updates = evaluations
+        try:
+            loc_scale = self.fc(state.float_features)
+        finally:
+            self.fc.stat_updates = 2
         return self.head_norm(loc_scale, torch.empty_like(loc_scale)) if self.use_layer_norm else loc_scale
 
     def _get_loc_and_scale_log(self, state):
@@ -81,7 +89,7 @@ class GaussianFullyConnectedActor(ModelBase):
 
     @torch.no_grad()
     def forward(self, state):
-        loc_scale = self._fc_out(state)
+        loc_scale = self._fc_out(state, evaluations=2)
         B, dev = loc_scale.shape[0], loc_scale.device
         action = torch.empty(B, self.action_dim, device=dev)
         log_prob = torch.empty(B, 1, device=dev)
@@ -109,8 +117,6 @@ class FullyConnectedActor(ModelBase):
         super().__init__()
         assert state_dim > 0, "state_dim must be > 0, got {}".format(state_dim)
         assert action_dim > 0, "action_dim must be > 0, got {}".format(action_dim)
-        if use_batch_norm:
-            raise NotImplementedError("batch normalisation is off on the MI355X hot path")
         self.state_dim = state_dim
         self.action_dim = action_dim
         assert len(sizes) == len(activations), (
@@ -118,7 +124,7 @@ class FullyConnectedActor(ModelBase):
         )
         self.action_activation = action_activation
         self.fc = FullyConnectedNetwork([state_dim] + list(sizes) + [action_dim],
-                                        list(activations) + [self.action_activation])
+                                        list(activations) + [self.action_activation], use_batch_norm=use_batch_norm)
         self.exploration_variance = exploration_variance
         if exploration_variance is not None:
             assert exploration_variance > 0

@@ -38,6 +38,19 @@ class DuelingStack:
     def set_need_input_grad(self, flag: bool):
         self.s.set_need_input_grad(flag)
 
+    def _bind(self, which: str, dst):
+        """per-layer (dgamma, dbeta) destinations of the three streams' normalisation layers, in layer order"""
+        ns, na = self.ns, self.na
+        for st, part in ((self.s, dst[:ns]), (self.a, dst[ns:ns + na]), (self.v, dst[ns + na:])):
+            if any(d is not None for d in part):
+                getattr(st, which)(part)
+
+    def bind_ln_grads(self, dst):
+        self._bind("bind_ln_grads", dst)
+
+    def bind_bn_grads(self, dst):
+        self._bind("bind_bn_grads", dst)
+
     def stage_weights(self, need_transposed: bool = True, force: bool = False):
         for st in (self.s, self.a, self.v):
             st.stage_weights(need_transposed=need_transposed, force=force)
@@ -99,6 +112,14 @@ class _DuelingFC:
     def linears(self):
         n = self._net
         return n.shared_network.fc.linears() + n.advantage_network.fc.linears() + n.value_network.fc.linears()
+
+    def layer_norms(self):
+        n = self._net
+        return n.shared_network.fc.layer_norms() + n.advantage_network.fc.layer_norms() + n.value_network.fc.layer_norms()
+
+    def batch_norms(self):
+        n = self._net
+        return n.shared_network.fc.batch_norms() + n.advantage_network.fc.batch_norms() + n.value_network.fc.batch_norms()
 
     def stack(self) -> DuelingStack:
         n = self._net

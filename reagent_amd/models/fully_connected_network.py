@@ -4,9 +4,11 @@ Same constructor arguments, parameter names (``dnn.{i}.0.weight`` / ``.bias``, n
 ``use_layer_norm`` the layer's nn.LayerNorm sits at ``dnn.{i}.1``) and initialisation (Gaussian with gain, zero bias)
 as reagent/models/fully_connected_network.py:67-217.  ``forward`` runs rg_fc_forward launches (inference: no autograd
 graph is recorded — training goes through the trainers' fused step, which writes ``.grad`` directly).  Layer-norm
-(Linear -> LayerNorm -> activation, :128-130) runs on the per-layer path with rg_layer_norm_*; batch-norm, dropout and
-skip connections are off in every configuration on the hot path and are rejected here instead of
-silently falling back to torch.
+(Linear -> LayerNorm -> activation, :128-130) runs on the per-layer path with rg_layer_norm_*.  Batch-norm on a layer's
+input (:107-108), dropout after the activation (:139-141) and the residual wrapper (:144-146) — off in every
+configuration on the hot path — run on engine_general.GeneralFCStack (fp32 row sweeps between the
+GEMMs: rg_batch_norm_*, rg_dropout, rg_add_cols); the module layout keeps the reference's parameter names
+(``dnn.{i}.0.vanilla.*`` for the batch norm, ``dnn.{i}.module.{j}.*`` under a residual wrapper).
 """
 import math
 from typing import List, Optional
@@ -59,6 +61,31 @@ class _Activation(nn.Module):
         return self.name
 
 
+class _SlateBatchNorm1d(nn.Module):
+    """Parameter / running-statistics holder with SlateBatchNorm1d's names (:48-64: ``vanilla`` = nn.BatchNorm1d); the
+    arithmetic is rg_batch_norm_* on [batch, features] inputs (the 3-D slate layout is not on this path)"""
+
+    def __init__(self, num_features: int):
+        super().__init__()
+        self.vanilla = nn.BatchNorm1d(num_features)
+
+
+class _Residual(nn.Module):
+    """residual_wrapper.py:17-22: x + module(x); the add is rg_add_cols"""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        self.module = module
+
+
+def _find(layer, kind):
+    seq = layer.module if isinstance(layer, _Residual) else layer
+    for m in seq:
+        if isinstance(m, kind):
+            return m
+    return None
+
+
 class FullyConnectedNetwork(ModelBase):
     def __init__(
         self,
@@ -74,11 +101,6 @@ class FullyConnectedNetwork(ModelBase):
         use_skip_connections: bool = False,
     ) -> None:
         super().__init__()
-        if use_batch_norm or dropout_ratio > 0.0 or use_skip_connections:
-            raise NotImplementedError(
-                "batch-norm / dropout / skip connections are not part of the MI355X hot path (off in every BASELINE "
-                "configuration); layer-norm is (use_layer_norm)"
-            )
         self.input_dim = layers[0]
         assert len(layers) == len(activations) + 1, (
             f"Invalid number of layers {len(layers)} and activations {len(activations)}. "
@@ -89,6 +111,9 @@ class FullyConnectedNetwork(ModelBase):
         for i, (in_dim, out_dim, activation) in enumerate(zip(layers, layers[1:], activations)):
             if activation not in L.ACT:
                 raise NotImplementedError(f"activation {activation} has no HIP epilogue")
+            components: List[nn.Module] = []
+            if use_batch_norm:  # :107-108 on the layer's input
+                components.append(_SlateBatchNorm1d(in_dim))
             linear = _Linear(in_dim, out_dim)
             try:
                 gain = torch.nn.init.calculate_gain(activation)
@@ -99,30 +124,58 @@ class FullyConnectedNetwork(ModelBase):
             else:
                 gaussian_fill_w_gain(linear.weight, gain=gain, dim_in=in_dim, min_std=min_std)
             init.constant_(linear.bias, 0)
-            # Linear -> [LayerNorm] -> activation (:121-137); the output layer is normalised only with normalize_output
-            if use_layer_norm and (normalize_output or i < len(activations) - 1):
-                modules.append(nn.Sequential(linear, nn.LayerNorm(out_dim), _Activation(activation)))
-            else:
-                modules.append(nn.Sequential(linear, _Activation(activation)))
+            # [BatchNorm] -> Linear -> [LayerNorm] -> activation -> [Dropout] (:104-141); the output layer gets the
+            # layer norm and the dropout only with normalize_output
+            components.append(linear)
+            inner = normalize_output or i < len(activations) - 1
+            if use_layer_norm and inner:
+                components.append(nn.LayerNorm(out_dim))
+            components.append(_Activation(activation))
+            if dropout_ratio > 0.0 and inner:
+                components.append(nn.Dropout(p=dropout_ratio))
+            layer: nn.Module = nn.Sequential(*components)
+            if use_skip_connections and in_dim == out_dim:  # :142-150 (other layers keep no skip)
+                layer = _Residual(layer)
+            modules.append(layer)
         self.dnn = nn.Sequential(*modules)
+        self.stat_updates = 1  # evaluations of the reference per forward (batch-norm running statistics; the Gaussian actor: 2)
         self.precision = _DEFAULT_PRECISION
         self._stack = None
 
     # ---- engine plumbing ------------------------------------------------------------------
     def linears(self) -> List[_Linear]:
-        return [m[0] for m in self.dnn]
+        return [_find(m, _Linear) for m in self.dnn]
 
     def layer_norms(self):
         """per layer: its nn.LayerNorm (a parameter holder here: the arithmetic is rg_layer_norm_*) or None"""
-        return [m[1] if isinstance(m[1], nn.LayerNorm) else None for m in self.dnn]
+        return [_find(m, nn.LayerNorm) for m in self.dnn]
+
+    def batch_norms(self):
+        """per layer: the nn.BatchNorm1d holder of its input normalisation, or None"""
+        return [b.vanilla if b is not None else None for b in (_find(m, _SlateBatchNorm1d) for m in self.dnn)]
+
+    def dropouts(self) -> List[float]:
+        return [d.p if d is not None else 0.0 for d in (_find(m, nn.Dropout) for m in self.dnn)]
+
+    def residuals(self) -> List[bool]:
+        return [isinstance(m, _Residual) for m in self.dnn]
+
+    def is_plain(self) -> bool:
+        """Linear -> activation layers only (what the fused kernels and the grouped QR-DQN engine serve)"""
+        return (not any(self.residuals()) and not any(p > 0.0 for p in self.dropouts())
+                and all(b is None for b in self.batch_norms()) and all(n is None for n in self.layer_norms()))
 
     def stack(self):
         if self._stack is None or getattr(self, "_stack_precision", None) != self.precision:
             lin = self.linears()
             self._stack = make_stack([l.weight for l in lin], [l.bias for l in lin],
                                      [L.ACT[a] for a in self.activation_names], self.precision,
-                                     layer_norms=self.layer_norms())
+                                     layer_norms=self.layer_norms(), batch_norms=self.batch_norms(),
+                                     dropouts=self.dropouts(), residuals=self.residuals(),
+                                     training=lambda: self.training)
             self._stack_precision = self.precision  # the engine may run a different one (x3 on odd shapes: fp32)
+        if hasattr(self._stack, "stat_updates"):
+            self._stack.stat_updates = self.stat_updates
         return self._stack
 
     def __deepcopy__(self, memo):

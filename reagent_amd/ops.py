@@ -181,6 +181,49 @@ def layer_norm_backward(g32, z32, mean, rstd, gamma, dgamma, dbeta, workspace, d
                                                 L.stream_ptr()))
 
 
+
+# ---- batch norm / dropout (use_batch_norm, dropout_ratio of FullyConnectedNetwork; fcopts.hip) ------------------
+def batch_norm_workspace(batch: int, n: int, device) -> torch.Tensor:
+    nbytes = L.lib().rg_batch_norm_workspace_bytes(batch, n)
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
+
+
+def batch_norm_forward(x32, gamma, beta, running_mean, running_var, training: bool, momentum, eps, y32, save_mean=None,
+                       save_rstd=None, workspace=None, stat_updates: int = 1):
+    _chk_dev(x32, gamma, beta, running_mean, running_var, y32, save_mean, save_rstd, workspace)
+    B, n = x32.shape
+    assert x32.dtype == y32.dtype == F32 and x32.stride(1) == y32.stride(1) == 1
+    _run("rg_batch_norm_forward", dict(B=B, n=n),
+         lambda: L.lib().rg_batch_norm_forward(L.ptr(x32), _ld(x32), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                                               L.ptr(running_var), int(bool(training)), int(stat_updates), float(momentum),
+                                               float(eps), B, n,
+                                               L.ptr(y32), _ld(y32), L.ptr(save_mean), L.ptr(save_rstd), L.ptr(workspace),
+                                               workspace.numel() * workspace.element_size() if workspace is not None else 0,
+                                               L.stream_ptr()))
+
+
+def batch_norm_backward(g32, x32, gamma, mean, rstd, running_var, training: bool, eps, workspace, dx32=None, dgamma=None,
+                        dbeta=None):
+    _chk_dev(g32, x32, gamma, mean, rstd, running_var, workspace, dx32, dgamma, dbeta)
+    B, n = x32.shape
+    assert g32.dtype == x32.dtype == F32 and g32.stride(1) == x32.stride(1) == 1
+    _run("rg_batch_norm_backward", dict(B=B, n=n),
+         lambda: L.lib().rg_batch_norm_backward(L.ptr(g32), _ld(g32), L.ptr(x32), _ld(x32), L.ptr(gamma), L.ptr(mean),
+                                                L.ptr(rstd), L.ptr(running_var), int(bool(training)), float(eps), B, n,
+                                                L.ptr(dx32), _ld(dx32) if dx32 is not None else 0, L.ptr(dgamma),
+                                                L.ptr(dbeta), L.ptr(workspace),
+                                                workspace.numel() * workspace.element_size(), L.stream_ptr()))
+
+
+def dropout(x32, p: float, keep, y32, seed: int = 0, offset: int = 0, generate: bool = True):
+    """y = x * keep / (1 - p); generate: draw `keep` (uint8 [B * n]) from (seed, offset), else read it (backward)"""
+    _chk_dev(x32, keep, y32)
+    B, n = x32.shape
+    assert x32.dtype == y32.dtype == F32 and keep.dtype == torch.uint8 and keep.numel() >= B * n and keep.is_contiguous()
+    _run("rg_dropout", dict(B=B, n=n),
+         lambda: L.lib().rg_dropout(L.ptr(x32), _ld(x32), B, n, float(p), int(bool(generate)), int(seed) & (2**64 - 1),
+                                    int(offset) & (2**64 - 1), L.ptr(keep), L.ptr(y32), _ld(y32), L.stream_ptr()))
+
 # ---- replay -----------------------------------------------------------------------------------
 def replay_nstep(indices, terminal_u8, reward, decays, capacity, horizon, steps, next_indices,
                  out_terminal, out_reward):

@@ -94,7 +94,7 @@ class GroupedQR:
             fc = trainer.q_network.fc
             if not hasattr(fc, "dnn"):  # a composite (dueling) network: three stacks, not one trunk + head
                 return False
-            if any(ln is not None for ln in fc.layer_norms()):  # LayerNorm between the layers: per-layer path
+            if not fc.is_plain():  # LayerNorm / batch-norm / dropout / residual layers: per-layer path
                 return False
             lin = fc.linears()
             names = fc.activation_names

@@ -8,8 +8,9 @@ launches — rg_replay_nstep (steps / next index / terminal / n-step reward) and
 bit-identical to the reference's namedtuple (same field names, order, dtypes and (B,1) shapes).
 Validity bookkeeping (add rules :468-522) is host-side integer logic, mirrored to the device lazily.
 
-Outside the dense hot path and rejected explicitly: id-list / id-score-list (sparse) elements,
-``return_as_timeline_format`` and ``return_everything_as_stack``.
+Sparse (id-list / id-score-list) elements live in padded device slots (ragged.py); ``return_everything_as_stack`` and
+``return_as_timeline_format`` (next_* elements and rewards as per-transition lists: one gather over all rows, split into
+views on the host) follow the reference's shapes.
 """
 import collections
 import gzip
@@ -61,8 +62,6 @@ class ReplayBuffer:
     ) -> None:
         if replay_capacity < update_horizon + stack_size:
             raise ValueError("There is not enough capacity to cover update_horizon and stack_size.")
-        if return_as_timeline_format:  # ragged python lists per transition (:716-741): a host-side export format
-            raise NotImplementedError("return_as_timeline_format is not on the MI355X hot path")
         self._initialized_buffer = False
         self._stack_size = stack_size
         self._return_everything_as_stack = return_everything_as_stack
@@ -324,10 +323,36 @@ class ReplayBuffer:
             dt = (state_dtype or torch.float32) if normalized else self._store[key].dtype
             return torch.empty(full, dtype=dt, device=dev)
 
+        # return_as_timeline_format (:659-664, :716-741): next_* elements and `reward` are python lists, entry i holding
+        # the steps[i] stored rows that follow transition i (its own rows for `reward`).  One gather over all
+        # sum(steps) rows per element, split into per-transition views on the host (one read of `steps`: the lists'
+        # shapes are data dependent).
+        timeline = self._return_as_timeline_format
+        cols_t, lists = [], {}
+        if timeline:
+            steps_host = steps.tolist()
+            T = sum(steps_host)
+            sample = torch.repeat_interleave(torch.arange(B, device=dev), steps, output_size=T)
+            within = torch.arange(T, device=dev) - (torch.cumsum(steps, 0) - steps)[sample]
+            rows_cur = ((indices[sample] + within) % self._replay_capacity).contiguous()
+            rows_next = ((indices[sample] + 1 + within) % self._replay_capacity).contiguous()
+
+            def list_for(name, key, rows):
+                shape = self._shapes[key]
+                dst = torch.empty((T, *shape, S) if S > 1 else (T, *shape), dtype=self._store[key].dtype, device=dev)
+                cols_t.append((self._store[key], dst, rows))
+                lists[name] = dst
+
         results, cols = {}, []
         for name in self._transition_elements:
             if name == "state":
                 key, idx = "observation", indices
+            elif timeline and (name == "reward" or name == "next_state" or (name.startswith("next_") and name[5:] in self._store)):
+                list_for(name, "observation" if name == "next_state" else name[5:] if name != "reward" else "reward",
+                         rows_cur if name == "reward" else rows_next)
+                continue
+            elif timeline and name.startswith("next_") and name[5:] in self._sparse:
+                raise NotImplementedError("sparse replay elements in the timeline format")
             elif name == "next_state":
                 key, idx = "observation", next_indices
             elif name == "reward" and self._return_everything_as_stack:
@@ -352,6 +377,10 @@ class ReplayBuffer:
             cols.append((self._store[key], dst, idx, norm) if is_state else (self._store[key], dst, idx))
             results[name] = dst
         ops.replay_gather(cols, self._replay_capacity, S, B)
+        if cols_t and T > 0:
+            ops.replay_gather(cols_t, self._replay_capacity, S, T)
+        for name, flat in lists.items():
+            results[name] = list(torch.split(flat, steps_host))
         results.update(indices=indices, terminal=terminal, step=steps)
         results.setdefault("reward", reward)
 
@@ -374,7 +403,8 @@ class ReplayBuffer:
 
         st = self._store
         obs, act = st.get("observation"), st.get("action")
-        if (self._stack_size != 1 or self._return_everything_as_stack or obs is None or obs.dtype != torch.float32
+        if (self._stack_size != 1 or self._return_everything_as_stack or self._return_as_timeline_format or obs is None
+                or obs.dtype != torch.float32
                 or obs.dim() != 2 or act is None
                 or act.dtype != torch.int64 or act.dim() != 1 or "log_prob" not in st
                 or st["reward"].dtype != torch.float32):

@@ -293,6 +293,7 @@ class QStepCore(DQNTrainerBaseLightning):
         (Lightning's optimizer loop) has stepped the q-network, and the CPE targets use
         q_network(next_state) with the NEW weights (dqn_trainer.py:267-281, qrdqn_trainer.py:161-177)"""
         if self._cpe is None:
+            self._post_step_stats_forward(training_batch)
             return
         from .reagent_lightning_module import _NoOpReporter
 
@@ -348,6 +349,22 @@ class QStepCore(DQNTrainerBaseLightning):
 
     def _needs_online_next(self) -> bool:
         return True
+
+    def _q_has_batch_norm(self) -> bool:
+        if getattr(self, "_q_bn", None) is None:
+            self._q_bn = any(isinstance(m, torch.nn.BatchNorm1d) for m in self.q_network.modules())
+        return self._q_bn
+
+    def _post_step_stats_forward(self, training_batch):
+        """dqn_trainer.py:267-268 / qrdqn_trainer.py:161-163 evaluate q_network(next_state) once more after the optimizer
+        step; the values feed only the CPE heads, but batch-norm layers in training mode move their running statistics
+        in that forward too — so a batch-normed network runs it (anything else skips the dead forward)"""
+        if not self._q_has_batch_norm() or not self.q_network.training:
+            return
+        qs = self._qs
+        qs.stage_weights(need_transposed=True)
+        xn, _ = qs.stage_input(self._net_in(training_batch.next_state.float_features), need_transposed=False)
+        qs.forward(xn, self._qn_online, save=False)
 
     @staticmethod
     def _net_in(t: torch.Tensor) -> torch.Tensor:
@@ -447,7 +464,8 @@ class QStepCore(DQNTrainerBaseLightning):
         with _NativeStep(self):
             self._hip_backward(None, async_reduce=deferred)
         self._update_pending = True
-        self._pending_batch = training_batch if getattr(self, "_cpe", None) is not None else None
+        self._pending_batch = (training_batch if getattr(self, "_cpe", None) is not None or self._q_has_batch_norm()
+                               else None)
         if not deferred:
             self.apply_pending_update()
         return loss
@@ -596,7 +614,9 @@ class QStepCore(DQNTrainerBaseLightning):
                 cpe.backward(which)
                 opt.grad_scale = 1.0 / self._dp_world
                 opt.step()
-            self._pending_batch = None
+        elif self._pending_batch is not None:
+            self._post_step_stats_forward(self._pending_batch)
+        self._pending_batch = None
         soft.step()
         self.all_batches_processed += 1
         self._update_pending = False

@@ -317,6 +317,10 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
     def _actor_out(self, act, x, out, save: bool):
         """actor FC stack -> [loc | scale_log] in `out`; a layer-normed actor passes both halves through their
         LayerNorm (actor.py:194-196), keeping the raw outputs and the statistics of a saving call"""
+        if hasattr(act, "stat_updates"):
+            # batch-norm running statistics move once per evaluation of the stack in the reference: forward() evaluates it
+            # twice (actor.py:216,246), and the next-state branch calls get_log_prob() once more (sac_trainer.py:228)
+            act.stat_updates = 2 if save else 3
         if not getattr(self.actor_network, "use_layer_norm", False):
             return act.forward(x, out, save=save)
         raw = self._ls_raw if save else self._dls_raw  # (the gradient buffer is free during a forward)
