@@ -152,6 +152,11 @@ QR_CASES = {
     "qrdqn_dueling": dict(state_dim=9, num_actions=3, num_atoms=8, sizes=[40, 24], activations=["relu", "relu"],
                           rl=dict(gamma=0.97, target_update_rate=0.2, maxq_learning=True), lr=0.004,
                           double_q=True, batch=44, steps=2, p_impossible=0.2, dueling=True),
+    # batch-normed quantile network, single-Q (no online next-state forward in the loss: the running statistics see
+    # target(next), online(state) and the post-step online(next) of :161-163)
+    "qrdqn_bn": dict(state_dim=7, num_actions=3, num_atoms=6, sizes=[28, 20], activations=["relu", "relu"],
+                     rl=dict(gamma=0.95, target_update_rate=0.2, maxq_learning=True), lr=0.003,
+                     double_q=False, batch=52, steps=3, p_impossible=0.2, batch_norm=True),
 }
 
 
@@ -159,7 +164,7 @@ def gen_qr(name, c):
     cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
                       double_q=c["double_q"], seed=0, num_atoms=c["num_atoms"], cpe_metrics=cpe_metrics,
-                      dueling=c.get("dueling", False))
+                      dueling=c.get("dueling", False), batch_norm=c.get("batch_norm", False))
     arrays = {}
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
@@ -180,9 +185,14 @@ def gen_qr(name, c):
             for net in CPE_NETS:
                 for i, p in enumerate(getattr(tr, net).parameters()):
                     arrays[f"step{s}_{net}_{i}"] = _np(p)
-        if c.get("dueling"):
+        if c.get("dueling") or c.get("batch_norm"):
             for i, gr in enumerate(loop.last_grads[0]):
                 arrays[f"step{s}_grad_{i}"] = _np(gr)
+        if c.get("batch_norm"):
+            for i, bf in enumerate(tr.q_network.buffers()):
+                arrays[f"step{s}_qbuf_{i}"] = _np(bf)
+            for i, bf in enumerate(tr.q_network_target.buffers()):
+                arrays[f"step{s}_tbuf_{i}"] = _np(bf)
         for i, p in enumerate(tr.q_network.parameters()):
             arrays[f"step{s}_param_{i}"] = _np(p)
         for i, p in enumerate(tr.q_network_target.parameters()):

@@ -78,7 +78,7 @@ def test_dropout_kernel(backend, B, n, p):
 def _reference_pass(net, x, dout, keeps, training):
     """torch autograd of the reference's layer sequence with this network's parameters (fp32 leaves):
     [BatchNorm1d] -> Linear -> [LayerNorm] -> activation -> [Dropout with the given keep masks] -> [+ input]"""
-    leaves = {k: v.detach().clone().requires_grad_() for k, v in net.named_parameters()}
+    leaves = {k: v.detach().cpu().clone().requires_grad_() for k, v in net.named_parameters()}
     name = {id(p): k for k, p in net.named_parameters()}
     P = lambda p: leaves[name[id(p)]]  # noqa: E731
     xr = x.clone().requires_grad_()
@@ -249,10 +249,11 @@ def test_all_options_match_the_reference_module(backend):
     assert (net_d(x).cpu() - g.t("train_out")).abs().max() > 1e-3
 
 
-@pytest.mark.parametrize("name", ["dqn_batchnorm", "dqn_dueling_bn"])
+@pytest.mark.parametrize("name", ["dqn_batchnorm", "dqn_dueling_bn", "qrdqn_bn"])
 @pytest.mark.parametrize("path", ["generator", "native"])
 def test_dqn_with_batch_norm_matches_reference(backend, path, name):
-    """golden dqn_batchnorm (dqn_dueling_bn: the default builder's dueling network, batch-normed trunk): FullyConnectedDQN(use_batch_norm=True) under DQNTrainer — losses, Q-values, gradients,
+    """golden dqn_batchnorm (dqn_dueling_bn: the default builder's dueling network, batch-normed trunk; qrdqn_bn: a
+    quantile network under QRDQNTrainer, single-Q): FullyConnectedDQN(use_batch_norm=True) under DQNTrainer — losses, Q-values, gradients,
     parameters, target parameters and BOTH networks' running statistics (which include the reference's post-step
     q_network(next_state) forward, dqn_trainer.py:268) over three steps"""
     from golden_util import Golden
@@ -269,16 +270,23 @@ def test_dqn_with_batch_norm_matches_reference(backend, path, name):
 
         q = DuelingQNetwork.make_fully_connected(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], use_batch_norm=True)
     else:
-        q = FullyConnectedDQN(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], use_batch_norm=True)
+        q = FullyConnectedDQN(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], use_batch_norm=True,
+                              num_atoms=c.get("num_atoms"))
     inits = g.seq("init_param_")
     assert [tuple(p.shape) for p in q.parameters()] == [tuple(t.shape) for t in inits]  # BatchNorm, Linear, ... in module order
     with torch.no_grad():
         for p, init in zip(q.parameters(), inits):
             p.copy_(init)
     q = q.to(backend.device)
-    tr = DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(c["num_actions"])], rl=RLParameters(**c["rl"]),
-                    double_q_learning=c["double_q"], optimizer=Optimizer__Union.default(lr=c["lr"]),
-                    evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(backend.device)
+    common = dict(actions=[str(i) for i in range(c["num_actions"])], rl=RLParameters(**c["rl"]),
+                  double_q_learning=c["double_q"], optimizer=Optimizer__Union.default(lr=c["lr"]),
+                  evaluation=EvaluationParameters(calc_cpe_in_training=False))
+    if c.get("num_atoms"):
+        from reagent_amd.training import QRDQNTrainer
+
+        tr = QRDQNTrainer(q, q.get_target_network(), num_atoms=c["num_atoms"], **common).to(backend.device)
+    else:
+        tr = DQNTrainer(q, q.get_target_network(), None, **common).to(backend.device)
     opts = [o["optimizer"] for o in tr.configure_optimizers()]
     for s in range(c["steps"]):
         batch = synthetic.to_dqn_input(g.batch(s), backend.device)
@@ -302,7 +310,8 @@ def test_dqn_with_batch_norm_matches_reference(backend, path, name):
             grads_match()
         ref_loss = g.t(f"step{s}_loss")
         assert abs(loss.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item()) + 1e-6
-        assert (tr.all_action_scores.cpu() - g.t(f"step{s}_q")).abs().max() <= 1e-4
+        if g.has(f"step{s}_q"):
+            assert (tr.all_action_scores.cpu() - g.t(f"step{s}_q")).abs().max() <= 1e-4
         for i, p in enumerate(tr.q_network.parameters()):
             assert (p.detach().cpu() - g.t(f"step{s}_param_{i}")).abs().max() <= 2e-5, (s, i)
         for i, p in enumerate(tr.q_network_target.parameters()):
