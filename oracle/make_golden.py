@@ -754,6 +754,40 @@ def gen_preprocessor():
           dict(x=_np(x), presence=_np(presence), out=_np(out)))
 
 
+def gen_predictor():
+    """The reference's serving module: DiscreteDqnPredictorWrapper (torch.jit trace + script) over
+    DiscreteDqnWithPreprocessor(FullyConnectedDQN, Preprocessor with every feature type) on a batch with missing features
+    (prediction/predictor_wrapper.py:94-152) -> (action_names, q_values)."""
+    rh._install()
+    from reagent.core import types as rlt
+    from reagent.models.dqn import FullyConnectedDQN
+    from reagent.prediction.predictor_wrapper import DiscreteDqnPredictorWrapper, DiscreteDqnWithPreprocessor
+    from reagent.preprocessing.preprocessor import Preprocessor
+
+    norm = _all_types_norm()
+    pre = Preprocessor(norm, device=torch.device("cpu"))
+    pre.eval()
+    feats = pre.sorted_features
+    n_in = pre(torch.zeros(1, len(feats)), torch.ones(1, len(feats), dtype=torch.uint8)).shape[1]
+    cfg = dict(norm=_norm_cfg(norm), sorted_features=feats, state_dim=n_in, num_actions=4, sizes=[48, 24],
+               activations=["relu", "leaky_relu"], action_names=["up", "down", "left", "right"], batch=129)
+    torch.manual_seed(31)
+    q = FullyConnectedDQN(n_in, cfg["num_actions"], cfg["sizes"], cfg["activations"])
+    feature_config = rlt.ModelFeatureConfig(float_feature_infos=[rlt.FloatFeatureInfo(name=f"f{i}", feature_id=i) for i in feats])
+    wrapper = DiscreteDqnPredictorWrapper(DiscreteDqnWithPreprocessor(q.cpu_model().eval(), pre, feature_config),
+                                          cfg["action_names"], feature_config)
+    g = torch.Generator().manual_seed(6)
+    x = torch.stack(_feature_columns(norm, feats, cfg["batch"], g), dim=1)
+    presence = (torch.rand(cfg["batch"], len(feats), generator=g) > 0.1).to(torch.uint8)
+    names, qv = wrapper(rlt.ServingFeatureData(float_features_with_presence=(x, presence), id_list_features={},
+                                               id_score_list_features={}))
+    assert list(names) == cfg["action_names"]
+    arrays = dict(x=_np(x), presence=_np(presence), q_values=_np(qv))
+    for i, p in enumerate(q.parameters()):
+        arrays[f"param_{i}"] = _np(p)
+    _save("predictor_dqn", cfg, arrays)
+
+
 def gen_offline_table():
     """a post-timeline table (select_relevant_columns schema, oss_data_fetcher.py:293-336), a batch of row
     indices with repeats, and what the reference's DiscreteDqnBatchPreprocessor.forward returns for the
@@ -1053,6 +1087,7 @@ def main():
     gen_policy_batch()
     gen_policy_input_maker()
     gen_fc_options()
+    gen_predictor()
     gen_sum_tree()
     gen_prioritized()
 

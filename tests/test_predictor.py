@@ -64,3 +64,31 @@ def test_hip_graph_replay_matches_eager():
         state2 = ServingFeatureData(float_features_with_presence=(x2, p2))
         want2 = wrapper.dqn_with_preprocessor(state2)
         assert torch.equal(wrapper(state2)[1], want2)
+
+
+def test_predictor_matches_the_reference_wrapper(backend):
+    """golden predictor_dqn: the reference's own DiscreteDqnPredictorWrapper (jit-traced DiscreteDqnWithPreprocessor over a
+    Preprocessor with every feature type and a FullyConnectedDQN, prediction/predictor_wrapper.py:94-152) on a batch with
+    missing features: same action names, Q-values within 1e-4"""
+    from types import SimpleNamespace
+
+    from golden_util import Golden
+
+    g = Golden("predictor_dqn")
+    c = g.cfg
+    norm = {int(k): SimpleNamespace(**v) for k, v in c["norm"].items()}
+    pre = Preprocessor(norm, device=backend.device)
+    assert pre.sorted_features == c["sorted_features"]
+    q = FullyConnectedDQN(c["state_dim"], c["num_actions"], c["sizes"], c["activations"])
+    with torch.no_grad():
+        for p, ref in zip(q.parameters(), g.seq("param_")):
+            p.copy_(ref)
+    wrapper = DiscreteDqnPredictorWrapper(DiscreteDqnWithPreprocessor(q.to(backend.device), pre), c["action_names"])
+    state = ServingFeatureData(float_features_with_presence=(g.t("x").to(backend.device), g.t("presence").to(backend.device)))
+    names, qv = wrapper(state)
+    assert list(names) == c["action_names"]
+    ref = g.t("q_values")
+    assert qv.shape == ref.shape and (qv.cpu() - ref).abs().max() <= 1e-4
+    if str(backend.device).startswith("cuda"):  # the captured HIP graph replays the same numbers
+        wrapper.capture(c["batch"])
+        assert torch.equal(wrapper(state)[1], qv)
