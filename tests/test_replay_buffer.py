@@ -412,8 +412,8 @@ def test_stack_slaughter(backend):
     """reagent/test/replay_memory/extra_replay_buffer_test.py:242-256 (test_stack_slaughter): stack_size 7,
     1..9 trajectories of random length, buffer sized as the reference does; every valid transition's frame
     stacks (state, action, extra) must equal the restatement :45-57 — zero frames before the trajectory
-    start, never a frame of the previous trajectory.  (The reward comes back as the n-step sum here:
-    return_everything_as_stack, which would stack it too, is outside the hot path.)"""
+    start, never a frame of the previous trajectory.  (The reward comes back as the n-step sum here; with
+    return_everything_as_stack it is stacked too: test_stack_multistep_flags_slaughter below.)"""
     stack = 7
     rng = np.random.RandomState(0)
     for n_traj in range(1, 10):
@@ -493,3 +493,92 @@ def test_reference_known_answers_sparse_input(backend):
     m.add(**long)
     got = m.sample_transition_batch(1, torch.tensor([num]))
     assert got.id_list["sparse_feat1"][1].cpu().tolist() == list(range(37)) and got.id_list["sparse_feat2"][1].numel() == 0
+
+
+def test_stack_multistep_flags_slaughter(backend):
+    """extra_replay_buffer_test.py:137-240, :258-275 (test_stack_multistep_flags_slaughter) restated: stack_size 5,
+    multi_steps 6, return_everything_as_stack and return_as_timeline_format — stacked state / action / extra of every valid
+    transition, terminal = "the trajectory ends within multi_steps", and the timeline lists: `reward` holds the stacked
+    rewards of the steps[i] transitions from i on, next_* those of the steps[i] transitions after i (the last entry of a
+    terminal transition is undefined and skipped, as in the reference's comparison)."""
+    stack, multi = 5, 6
+    rng = np.random.RandomState(1)
+    for n_traj in range(1, 8):
+        lengths = rng.randint(1, 25, size=n_traj).tolist()
+        cap = max(int(sum(lengths) + (n_traj + 1) * (stack - 1)), stack + multi)
+        rb = ReplayBuffer(device=backend.device, stack_size=stack, replay_capacity=cap, batch_size=1, update_horizon=multi,
+                          return_everything_as_stack=True, return_as_timeline_format=True)
+        i = 0
+        for traj_len in lengths:
+            for j in range(traj_len):
+                rb.add(observation=(np.ones((3, 3)) * i).astype(np.float32), action=np.int64(i), reward=np.float32(2 * i),
+                       terminal=bool(j == traj_len - 1), extra1=np.float32(3 * i))
+                i += 1
+        got = rb.sample_all_valid_transitions()
+        frames = lambda k, start: [0 if w < start else w for w in range(k - stack + 1, k + 1)]  # noqa: E731
+        obs = lambda k, start: np.stack([np.zeros((3, 3)) if w < start else np.ones((3, 3)) * w  # noqa: E731
+                                         for w in range(k - stack + 1, k + 1)], axis=-1).astype(np.float32)
+        steps = got.step.reshape(-1).tolist()
+        t, i = 0, 0
+        for traj_len in lengths:
+            start, end = i, i + traj_len
+            for j in range(traj_len):
+                terminal = j >= traj_len - multi
+                assert bool(got.terminal[t]) == terminal
+                np.testing.assert_array_equal(got.state[t].cpu().numpy(), obs(i, start))
+                np.testing.assert_array_equal(got.action[t].cpu().numpy(), frames(i, start))
+                np.testing.assert_array_equal(got.extra1[t].cpu().numpy(), 3.0 * np.array(frames(i, start), np.float32))
+                rew = [frames(k, start) for k in range(i, i + multi) if k < end]
+                nxt = [k for k in range(i + 1, i + multi + 1) if k <= end]
+                assert steps[t] == len(rew) == len(nxt)
+                for name in ("reward", "next_action", "next_extra1", "next_state"):
+                    assert isinstance(getattr(got, name), list) and getattr(got, name)[t].shape[0] == steps[t], name
+                cut = -1 if terminal else None
+                np.testing.assert_array_equal(got.reward[t].cpu().numpy()[:cut], 2.0 * np.array(rew, np.float32).reshape(len(rew), stack)[:cut])
+                np.testing.assert_array_equal(got.next_action[t].cpu().numpy()[:cut], np.array([frames(k, start) for k in nxt]).reshape(len(nxt), stack)[:cut])
+                np.testing.assert_array_equal(got.next_extra1[t].cpu().numpy()[:cut],
+                                              3.0 * np.array([frames(k, start) for k in nxt], np.float32).reshape(len(nxt), stack)[:cut])
+                np.testing.assert_array_equal(got.next_state[t].cpu().numpy()[:cut], np.stack([obs(k, start) for k in nxt])[:cut])
+                t += 1
+                i += 1
+        assert t == len(steps)
+
+
+def test_reference_known_answers_replay_overflow(backend):
+    """extra_replay_buffer_test.py:277-377 (test_replay_overflow), the reference's exact vectors: capacity 6, stack 2,
+    multi_steps 2, timeline format — validity after every add as the cursor wraps, the stacked actions of the valid
+    transitions and their next_action lists (entries the reference calls garbage are not compared)"""
+    m = ReplayBuffer(stack_size=2, replay_capacity=6, batch_size=1, update_horizon=2, return_everything_as_stack=None,
+                     return_as_timeline_format=True, device=backend.device)
+    trans = lambda i: dict(observation=np.ones(OBS, dtype=np.uint8), action=int(2 * i), reward=float(3 * i))  # noqa: E731
+    valid = lambda: m._is_index_valid.cpu().numpy().tolist()  # noqa: E731
+    F, T = False, True
+    assert valid() == [F] * 6
+    m.add(**trans(0), terminal=False)
+    assert valid() == [F] * 6
+    m.add(**trans(1), terminal=False)
+    assert valid() == [F] * 6
+    m.add(**trans(2), terminal=False)  # s0 becomes valid once its next state is in
+    assert valid() == [F, T, F, F, F, F]
+    b = m.sample_all_valid_transitions()
+    assert b.action.cpu().tolist() == [[0, 0]] and b.next_action[0].cpu().tolist() == [[0, 2], [2, 4]]
+    m.add(**trans(3), terminal=True)  # the episode's end validates the whole episode
+    assert valid() == [F, T, T, T, T, F]
+    b = m.sample_all_valid_transitions()
+    assert b.action.cpu().tolist() == [[0, 0], [0, 2], [2, 4], [4, 6]]
+    assert b.next_action[0].cpu().tolist() == [[0, 2], [2, 4]] and b.next_action[1].cpu().tolist() == [[2, 4], [4, 6]]
+    assert b.next_action[2][0].cpu().tolist() == [4, 6]
+    m.add(**trans(4), terminal=False)  # wraps: s0's previous frame is overwritten
+    assert valid() == [F, F, T, T, T, F]
+    b = m.sample_all_valid_transitions()
+    assert b.action.cpu().tolist() == [[0, 2], [2, 4], [4, 6]]
+    assert b.next_action[0].cpu().tolist() == [[2, 4], [4, 6]] and b.next_action[1][0].cpu().tolist() == [4, 6]
+    m.add(**trans(5), terminal=False)
+    assert valid() == [F, F, F, T, T, F]
+    b = m.sample_all_valid_transitions()
+    assert b.action.cpu().tolist() == [[2, 4], [4, 6]] and b.next_action[0][0].cpu().tolist() == [4, 6]
+    m.add(**trans(6), terminal=True)
+    assert valid() == [T, T, T, F, T, F]
+    b = m.sample_all_valid_transitions()
+    assert b.action.cpu().tolist() == [[0, 8], [8, 10], [10, 12], [4, 6]]
+    assert b.next_action[0].cpu().tolist() == [[8, 10], [10, 12]] and b.next_action[1][0].cpu().tolist() == [10, 12]
