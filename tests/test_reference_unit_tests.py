@@ -124,7 +124,19 @@ MODELS = [  # test_dqn.py / test_critic.py / test_actor.py: sizes [8, 4] (critic
     (lambda: FullyConnectedCritic(8, 4, sizes=[7, 6], activations=["relu", "relu"]), (1, 1)),
     (lambda: FullyConnectedActor(8, 4, sizes=[7, 6], activations=["relu", "relu"]), (1, 4)),
     (lambda: GaussianFullyConnectedActor(8, 4, sizes=[7, 6], activations=["relu", "relu"]), (1, 4)),
+    # test_save_load_batch_norm of the same files (and test_dueling_q_network.py:110-122): batch-normed, frozen by eval()
+    (lambda: FullyConnectedDQN(8, 4, sizes=[8, 4], activations=["relu", "relu"], use_batch_norm=True).eval(), (1, 4)),
+    (lambda: FullyConnectedCritic(8, 4, sizes=[7, 6], activations=["relu", "relu"], use_batch_norm=True).eval(), (1, 1)),
+    (lambda: FullyConnectedActor(8, 4, sizes=[7, 6], activations=["relu", "relu"], use_batch_norm=True).eval(), (1, 4)),
+    (lambda: GaussianFullyConnectedActor(8, 4, sizes=[7, 6], activations=["relu", "relu"], use_batch_norm=True).eval(), (1, 4)),
+    (lambda: _dueling_bn().eval(), (1, 4)),
 ]
+
+
+def _dueling_bn():
+    from reagent_amd.models import DuelingQNetwork
+
+    return DuelingQNetwork.make_fully_connected(8, 4, [8, 4], ["relu", "relu"], use_batch_norm=True)
 
 
 @pytest.mark.parametrize("make,out_shape", MODELS)
@@ -136,8 +148,14 @@ def test_model_basic_and_save_load(backend, make, out_shape):
     inputs = tuple(rlt.FeatureData(x.float_features.to(dev)) for x in inputs)
     assert inputs[0].float_features.shape == (1, 8)
     # check_save_load (models/test_utils.py): a fresh model loading the state dict gives the same output
+    if any(isinstance(m, torch.nn.BatchNorm1d) for m in model.modules()):  # running statistics that are not the defaults
+        with torch.no_grad():
+            for m in [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]:
+                m.running_mean.normal_(0, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
     clone = make().to(dev)
     clone.load_state_dict(model.state_dict())
+    assert [k for k in clone.state_dict()] == [k for k in model.state_dict()]
     if isinstance(model, GaussianFullyConnectedActor):  # same reparameterisation draw on both
         noise = torch.randn(1, 4)
         model.noise_override, clone.noise_override = noise, noise.clone()
