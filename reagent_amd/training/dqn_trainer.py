@@ -112,6 +112,9 @@ def publish_gradients(slab, params, held=()):
 def enable_graph_mode(tr):
     """Switch every Adam of the trainer's native step to device-scheduled stepping (optimizer.AdamSchedule): what
     a HIP-graph capture of the step needs.  Eager steps keep working (and produce the same bits)."""
+    if any(isinstance(m, torch.nn.Dropout) and m.p > 0.0 for m in tr.modules()):
+        # rg_dropout's Philox offset is a host-side launch argument: a replayed graph would repeat one mask forever
+        raise NotImplementedError("networks with dropout layers are not captured into a HIP graph: run the native step eagerly")
     for o in tr.native_optimizers():
         if hasattr(o, "enable_device_schedule"):
             o.enable_device_schedule()

@@ -418,3 +418,18 @@ def test_td3_with_batch_normed_networks_matches_reference(backend, path):
             for i, bf in enumerate(net.buffers()):
                 ref = g.t(f"step{s}_{n}_buf_{i}")
                 assert (bf.cpu().double() - ref.double()).abs().max() <= 3e-5 * max(1.0, ref.double().abs().max().item()), (s, n, i)
+
+
+def test_dropout_networks_refuse_graph_capture(backend):
+    """a captured step would replay ONE dropout mask (the Philox offset is a launch argument): refused loudly"""
+    from reagent_amd.core.parameters import EvaluationParameters, RLParameters
+    from reagent_amd.models import FullyConnectedDQN
+    from reagent_amd.optimizer import Optimizer__Union
+    from reagent_amd.training import DQNTrainer
+    from reagent_amd.training.dqn_trainer import enable_graph_mode
+
+    q = FullyConnectedDQN(6, 3, [16, 16], ["relu", "relu"], dropout_ratio=0.2).to(backend.device)
+    tr = DQNTrainer(q, q.get_target_network(), None, actions=["a", "b", "c"], rl=RLParameters(),
+                    optimizer=Optimizer__Union.default(), evaluation=EvaluationParameters(calc_cpe_in_training=False))
+    with pytest.raises(NotImplementedError, match="dropout"):
+        enable_graph_mode(tr)
