@@ -18,6 +18,8 @@ from .dqn_trainer import QStepCore
 
 
 class C51Trainer(QStepCore):
+    _post_step_forward = False  # c51_trainer.py:100-190 evaluates the network on next_state and state only
+
     def __init__(
         self,
         q_network,

@@ -353,9 +353,13 @@ class QStepCore(DQNTrainerBaseLightning):
     def _needs_online_next(self) -> bool:
         return True
 
+    # the reference's train_step_gen evaluates q_network(next_state) again after the optimizer step (DQN, QR-DQN: yes;
+    # C51: no)
+    _post_step_forward = True
+
     def _q_has_batch_norm(self) -> bool:
         if getattr(self, "_q_bn", None) is None:
-            self._q_bn = any(isinstance(m, torch.nn.BatchNorm1d) for m in self.q_network.modules())
+            self._q_bn = self._post_step_forward and any(isinstance(m, torch.nn.BatchNorm1d) for m in self.q_network.modules())
         return self._q_bn
 
     def _post_step_stats_forward(self, training_batch):
