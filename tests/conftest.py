@@ -14,6 +14,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """A CPU-only run (the kernels on the SIMT interpreter: 8 minutes serially) spreads over four worker processes when
+    pytest-xdist is installed and the caller did not pass -n: about 2 minutes.  A box with a GPU runs serially (one
+    device); RG_TEST_SERIAL=1 or `-n 0` keep a CPU run serial."""
+    try:
+        if (os.environ.get("RG_TEST_SERIAL") or os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput")
+                or not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) is not None
+                or getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False)):
+            return None
+        import torch
+
+        if torch.cuda.is_available():
+            return None
+        config.option.numprocesses = min(4, os.cpu_count() or 1)
+    except Exception:  # never let the convenience break a run
+        pass
+    return None
+
+
 @dataclass
 class Backend:
     name: str
