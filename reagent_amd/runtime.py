@@ -44,6 +44,51 @@ class _GraphedLoop:
     def _eager_step(self, indices=None):
         raise NotImplementedError
 
+    # ---- checkpoint / resume (what pl.Trainer's checkpointing does for the reference: module + optimizer states) ----
+    def checkpoint(self) -> dict:
+        """Everything a bit-identical continuation of the loop needs besides the replay storage (ReplayBuffer.save
+        writes that in the reference's own file layout): the trainer's state_dict (networks, targets, temperature),
+        every optimizer's state_dict (Adam moments and step counts), the step counter and the RNG state the index /
+        noise draws continue from.  A pending deferred update is applied first."""
+        self.flush()
+        tr = self.trainer
+        dev = torch.device(self.rb.device)
+        rng = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else torch.get_rng_state()
+        return dict(
+            trainer=tr.state_dict(),
+            optimizers=[o.state_dict() if hasattr(o, "state_dict") else None for o in tr.native_optimizers()],
+            all_batches_processed=int(getattr(tr, "all_batches_processed", 0)),
+            rng_state=rng,
+            extras=tr.checkpoint_extras() if hasattr(tr, "checkpoint_extras") else None,
+        )
+
+    def load_checkpoint(self, ckpt: dict):
+        """restore `checkpoint()`'s dict into this loop's trainer (built with the same configuration)"""
+        if self._graph is not None:
+            self.release_graph()
+        tr = self.trainer
+        tr.load_state_dict(ckpt["trainer"])
+        for o, sd in zip(tr.native_optimizers(), ckpt["optimizers"]):
+            if sd is not None and hasattr(o, "load_state_dict"):
+                o.load_state_dict(sd)
+        if hasattr(tr, "all_batches_processed"):
+            tr.all_batches_processed = ckpt["all_batches_processed"]
+        if ckpt.get("extras") is not None:
+            tr.load_checkpoint_extras(ckpt["extras"])
+        for p in tr.parameters():  # the engines' staged weight copies follow the version counters
+            p._rg_version = getattr(p, "_rg_version", 0) + 1
+        dev = torch.device(self.rb.device)
+        if dev.type == "cuda":
+            torch.cuda.set_rng_state(ckpt["rng_state"].cpu(), dev)
+        else:
+            torch.set_rng_state(ckpt["rng_state"].cpu())
+
+    def save(self, path: str):
+        torch.save(self.checkpoint(), path)
+
+    def load(self, path: str):
+        self.load_checkpoint(torch.load(path, map_location="cpu", weights_only=False))
+
     def capture(self, warmup: int = 2, static_indices: bool = False):
         from .training.dqn_trainer import enable_graph_mode
 

@@ -243,6 +243,16 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         optimizers.append(SoftUpdate.make_optimizer_scheduler(target_params, source_params, tau=self.tau))
         return optimizers
 
+    # ---- checkpoint extras (runtime loops) ---------------------------------------------------------
+    def checkpoint_extras(self) -> dict:
+        """alpha = exp(log_alpha) as the loss heads read it: like the reference's `entropy_temperature` attribute
+        (sac_trainer.py:322) it is not part of the state_dict, and is the constructor's value until the first
+        temperature step — a resumed run must continue from the current one"""
+        return {"alpha": self._alpha(self.log_alpha.device).detach().cpu().clone()}
+
+    def load_checkpoint_extras(self, extras: dict):
+        self._alpha(self.log_alpha.device).copy_(extras["alpha"])
+
     # ---- engine ----------------------------------------------------------------------------------
     def _alpha(self, device):
         if self._alpha_dev is None or self._alpha_dev.device != device:
