@@ -116,6 +116,22 @@ def test_preprocessor_oracle_matches_reference():
 
 
 @pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/reagent"), reason="needs the reference checkout")
+def test_fc_options_oracle_matches_reference():
+    """restated batch-norm / layer-norm / residual forward (training and eval mode, moved running statistics) against the
+    reference module's outputs in tests/golden/fc_options.npz"""
+    g = Golden("fc_options")
+    c = g.cfg
+    names = [str(n) for n in g.a("names")]
+    state = {n: g.t(f"init_{i}") for i, n in enumerate(names)}
+    kw = dict(use_batch_norm=True, use_layer_norm=True, use_skip_connections=True)
+    out, moved = R.fc_forward_options(state, c["layers"], c["activations"], g.t("x"), training=True, **kw)
+    assert (out - g.t("train_out")).abs().max() <= 2e-5
+    after = {n: g.t(f"after_{i}") for i, n in enumerate(names)}
+    assert moved and all((moved[k] - after[k]).abs().max() <= 1e-6 for k in moved)
+    out_e, _ = R.fc_forward_options(after, c["layers"], c["activations"], g.t("x"), training=False, **kw)
+    assert (out_e - g.t("eval_out")).abs().max() <= 2e-5
+
+
 def test_committed_goldens_are_what_the_reference_produces():
     """`python -m oracle.make_golden --check`: every fixture under tests/golden regenerated from the
     unmodified reference and compared array by array with the committed file (build container only)"""
