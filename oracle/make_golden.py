@@ -269,6 +269,9 @@ def gen_sac(name, c):
         for j, nm in enumerate(loss_names):
             arrays[f"step{s}_{nm}"] = _np(losses[j])
         arrays[f"step{s}_log_alpha"] = _np(tr.log_alpha)
+        for k, v in tr.logger.metrics.items():  # what the step handed to logger.log_metrics (:343-380)
+            arrays[f"step{s}_metric_{k}"] = _np(v.double().reshape(()))
+        tr.logger.metrics.clear()
         for j, n in enumerate(["q1", "q2", "actor"]):  # optimizer order (sac_trainer.py:148-193)
             for i, gr in enumerate(loop.last_grads[j]):
                 _put(arrays, f"step{s}_grad_{n}_{i}", gr)
@@ -626,6 +629,9 @@ def _gen_baseline_sac(name, c):
         for j, nm in enumerate(["q1_loss", "q2_loss", "actor_loss", "alpha_loss"]):
             arrays[f"step{s}_{nm}"] = _np(losses[j])
         arrays[f"step{s}_log_alpha"] = _np(tr.log_alpha)
+        for k, v in tr.logger.metrics.items():  # what the step handed to logger.log_metrics (:343-380)
+            arrays[f"step{s}_metric_{k}"] = _np(v.double().reshape(()))
+        tr.logger.metrics.clear()
         for j, n in enumerate(["q1", "q2", "actor"]):  # optimizer order (sac_trainer.py:148-193)
             for i, gr in enumerate(loop.last_grads[j]):
                 _put(arrays, f"step{s}_grad_{n}_{i}", gr)

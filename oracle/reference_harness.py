@@ -33,9 +33,16 @@ class PLLoop:
         self.batch_idx = 0
         self.last_grads = {}
 
-        class _Logger:  # SACTrainer calls self.logger.log_metrics unconditionally (:343)
-            def log_metrics(self, *a, **k):
-                pass
+        class _Logger:  # SACTrainer calls self.logger.log_metrics unconditionally (:343); the last step's values are kept
+            def __init__(self):
+                self.metrics = {}
+
+            def log_metrics(self, metrics, step=None):
+                for k, v in metrics.items():  # (DQN logs nested dicts too: only scalars are kept)
+                    if isinstance(v, torch.Tensor):
+                        self.metrics[k] = v.detach().clone()
+                    elif isinstance(v, (int, float)):
+                        self.metrics[k] = torch.tensor(float(v))
 
         trainer.logger = _Logger()
         if getattr(trainer, "trainer", None) is None:  # TD3 reads self.trainer.log_every_n_steps (:158)

@@ -32,6 +32,7 @@ from .. import ops
 from ..core import types as rlt
 from ..core.parameters import RLParameters
 from ..engine import dx_save, ensure_slab, grad_views
+from ..models.actor import LOG_PROB_MAX, LOG_PROB_MIN
 from ..optimizer import Optimizer__Union, SoftUpdate
 from .dqn_trainer import dp_reduce, held_gradients, native_step, publish_gradients
 from .reagent_lightning_module import ReAgentLightningModule
@@ -383,6 +384,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             ops.reduce_sum(self._parts["l1"], P, 1.0 / B, self._losses["q1"])
             if has_q2:
                 ops.reduce_sum(self._parts["l2"], P, 1.0 / B, self._losses["q2"])
+            self._critic_metrics(b, alpha)
             return
         # a' = actor(s'), log_prob'  (actor frozen in this segment)
         xn_s, _ = act.stage_input(next_state, need_transposed=False)
@@ -419,6 +421,25 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         ops.reduce_sum(self._parts["l1"], P, 1.0 / B, self._losses["q1"])
         if has_q2:
             ops.reduce_sum(self._parts["l2"], P, 1.0 / B, self._losses["q2"])
+        self._critic_metrics(b, alpha)
+
+    def _critic_metrics(self, b, alpha):
+        """critic-segment means of sac_trainer.py:343-364 for the logger, taken while alpha is still the value the
+        targets were built with (the temperature step of this batch has not run yet)"""
+        if not self.logger:
+            return
+        t, has_q2 = self._t, "q2" in self._e
+        m = self._metrics = {"logged_rewards": b.reward.float().mean(), "q1_value": self._q1v.mean(),
+                             "target_q_value": self._y.mean()}
+        if has_q2:
+            m["q2_value"] = self._q2v.mean()
+        if "value" in t:
+            m["next_state_value"] = self._q1t.mean()
+        else:
+            lpa = self._lpn.clamp(LOG_PROB_MIN, LOG_PROB_MAX)
+            nsv = torch.minimum(self._q1t, self._q2t) if "q2" in t else self._q1t
+            m["log_prob_a"] = lpa.mean()
+            m["next_state_value"] = (nsv.reshape(-1) - alpha.float() * lpa.reshape(-1)).mean()
 
     def _critic_backward(self, which, grad_out=None):
         e = self._e[which]
@@ -575,7 +596,44 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         if self.value_network is not None:
             self._value_forward(b)
             yield _SegmentLoss.apply(self._value_backward, self._losses["value"], *self._e["value"]["params"])
+        self._log_metrics()
         yield self.soft_update_result()
+
+    def _log_metrics(self):
+        """sac_trainer.py:343-380: the step's means handed to `self.logger.log_metrics` (device scalars: no host sync
+        here; a TensorBoard logger reads them out itself).  Evaluated only when a logger is attached."""
+        if not self.logger:
+            return
+        m, has_q2 = self._metrics, "q2" in self._e
+        min_q = torch.minimum(self._q1a, self._q2a) if has_q2 else self._q1a
+        et = self.entropy_temperature
+        step = self.all_batches_processed
+        out = {"td_loss": self._losses["q1"].reshape(()), "logged_rewards": m["logged_rewards"],
+               "model_values_on_logged_actions": m["q1_value"], "q1_value": m["q1_value"],
+               "entropy_temperature": et.reshape(()) if isinstance(et, torch.Tensor) else et}
+        if self.value_network is not None:  # log_prob_a is the value segment's (:331-336)
+            out["log_prob_a"] = (torch.zeros((), device=min_q.device) if self.logged_action_uniform_prior
+                                 else self._lp.clamp(LOG_PROB_MIN, LOG_PROB_MAX).mean())
+        else:
+            out["log_prob_a"] = m["log_prob_a"]
+        actor_loss = self._losses["actor"].reshape(())
+        if self.add_kld_to_loss:  # the logged actor_loss is the mean before the KLD term is added (:280, :308, :357)
+            actor_loss = actor_loss - self.kld_weight * self._kld.reshape(())
+        out.update(next_state_value=m["next_state_value"], target_q_value=m["target_q_value"], min_q_actor_value=min_q.mean(),
+                   actor_output_log_prob=self._lp.mean(), actor_loss=actor_loss)
+        self.logger.log_metrics(out, step=step)
+        if has_q2:
+            self.logger.log_metrics({"q2_value": m["q2_value"]}, step=step)
+        if self.value_network is not None:
+            self.logger.log_metrics({"target_state_value": self._yv.mean()}, step=step)
+        if self.add_kld_to_loss:  # :366-376
+            A, S = self.action_emb_mean.numel(), self._S
+            if self.apply_kld_on_mean:
+                x = torch.tanh(self._ls[:, :A]).clamp(-1.0 + 1e-6, 1.0 - 1e-6)
+            else:
+                x = self._api if self._panels else self._xa[:, S:]
+            self.logger.log_metrics({"action_batch_mean": x.mean(0).mean(), "action_batch_var": x.var(0).mean(),
+                                     "kld": self._kld.reshape(())}, step=step)
 
     # ---- fused native step ---------------------------------------------------------------------------
     def _fused_updates(self, opts):

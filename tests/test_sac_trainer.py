@@ -304,3 +304,36 @@ def test_bf16_state_rows_from_the_sampler_equal_fp32_rows(backend):
     assert la.make_batch(idx).state.float_features.dtype == torch.bfloat16 and ta._panels
     for pa, pb in zip(ta.parameters(), tb.parameters()):
         assert torch.equal(pa.detach().cpu(), pb.detach().cpu())
+
+
+@pytest.mark.parametrize("name", ["sac_twin", "sac_value", "sac_crr", "sac_kld", "sac_kld_mean"])
+def test_per_step_metrics_match_the_reference(emu_lib, name):
+    """SURVEY §8 a19 — what SACTrainer hands `self.logger.log_metrics` each step (reagent/training/sac_trainer.py:343-380):
+    every key and value the reference logged on the golden batches (recorded by the oracle's loop): td_loss, reward /
+    Q-value / target means, entropy temperature, log-prob means, next-state value, min-Q of the actor's action, actor loss
+    (before the KLD term), q2_value, target_state_value (value network), the KLD statistics."""
+    g = Golden(name)
+    tr = build_variant(g, "cpu") if g.cfg.get("value") else build(g, "cpu")
+    logged = {}
+
+    class Logger:
+        def log_metrics(self, metrics, step=None):
+            assert step == tr.all_batches_processed
+            logged.update(metrics)
+
+    tr.logger = Logger()
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    for s in range(g.cfg["steps"]):
+        batch = synthetic.to_policy_input(g.batch(s), "cpu")
+        tr.set_noise(g.t(f"step{s}_noise_next"), g.t(f"step{s}_noise_cur"))
+        logged.clear()
+        lightning_like_step(tr, opts, batch)
+        want = {k[len(f"step{s}_metric_"):]: float(g.t(k)) for k in g.z.files if k.startswith(f"step{s}_metric_")}
+        assert set(logged) == set(want) and len(want) >= 11, (sorted(logged), sorted(want))
+        for k, ref in want.items():
+            got = float(logged[k])
+            assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (s, k, got, ref)
+    tr.logger = None  # no logger: the step evaluates none of it
+    logged.clear()
+    lightning_like_step(tr, opts, batch)
+    assert not logged
