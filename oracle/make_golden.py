@@ -362,6 +362,13 @@ def gen_td3(name, c):
         for i, p in enumerate(m.parameters()):
             arrays[f"init_{n}_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
+    reported = {}
+
+    class _Reporter:  # td3_trainer.py:158-189: logged when batch_idx % log_every_n_steps (50 in the loop) == 0
+        def log(self, **kw):
+            reported.update({k: v.detach().clone() for k, v in kw.items()})
+
+    tr.set_reporter(_Reporter())
     for s in range(c["steps"]):
         b = synthetic.policy_batch(c["batch"], c["state_dim"], c["action_dim"], seed=400 + s)
         for k, v in b.items():
@@ -374,6 +381,9 @@ def gen_td3(name, c):
         for j, nm in enumerate(["q1_loss", "q2_loss", "actor_loss"]):
             if losses[j] is not None:
                 arrays[f"step{s}_{nm}"] = _np(losses[j])
+        for k, v in reported.items():
+            arrays[f"step{s}_report_{k}"] = _np(v)
+        reported.clear()
         nets = dict(actor=tr.actor_network, q1=tr.q1_network, q2=tr.q2_network, actor_target=tr.actor_network_target,
                     q1_target=tr.q1_network_target, q2_target=tr.q2_network_target)
         for n, m in nets.items():

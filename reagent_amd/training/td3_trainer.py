@@ -226,14 +226,30 @@ class TD3Trainer(RLTrainerMixin, ReAgentLightningModule):
         inj = getattr(self, "_injected", None)
         self._injected = None
         self._critic_forward(b, self._noise(B, A, b.action.float_features.device, inj))
+        # td3_trainer.py:158-164, :173-177, :185-189: tensors handed to the reporter every `log_every_n_steps` batches
+        # (no-op reporter: nothing is evaluated)
+        from .reagent_lightning_module import _NoOpReporter
+
+        every = getattr(getattr(self, "trainer", None), "log_every_n_steps", 50)
+        report = not isinstance(self._reporter, _NoOpReporter) and batch_idx % every == 0
+        has_q2 = "q2" in self._e
+        if report:
+            next_q = torch.minimum(self._q1t, self._q2t) if has_q2 else self._q1t
+            self.reporter.log(q1_loss=self._losses["q1"].reshape(()).clone(), q1_value=self._q1v.reshape(-1, 1).clone(),
+                              next_q_value=next_q.reshape(-1, 1), target_q_value=self._y.reshape(-1, 1).clone())
         q1 = self._e["q1"]
         yield _SegmentLoss.apply(lambda g: self._critic_backward("q1", g), self._losses["q1"], *q1["params"])
         if self.q2_network:
+            if report:
+                self.reporter.log(q2_loss=self._losses["q2"].reshape(()).clone(), q2_value=self._q2v.reshape(-1, 1).clone())
             q2 = self._e["q2"]
             yield _SegmentLoss.apply(lambda g: self._critic_backward("q2", g), self._losses["q2"], *q2["params"])
         # only update actor and target networks after a fixed number of Q updates (:176-199)
         if batch_idx % self.delayed_policy_update == 0:
             self._actor_forward(b)
+            if report:
+                self.reporter.log(actor_loss=self._losses["actor"].reshape(()).clone(),
+                                  actor_q1_value=self._q1a.reshape(-1, 1).clone())
             yield _SegmentLoss.apply(self._actor_backward, self._losses["actor"], *self._e["actor"]["params"])
             yield self.soft_update_result()
         else:

@@ -122,3 +122,28 @@ def test_target_action_noise_uses_both_clip_bounds(backend):
     ops.td3_target_action(mu, noise, 0.5, (-0.1, 0.3), -0.95, 0.95, out)
     want = (mu.cpu() + (noise.cpu() * 0.5).clamp(-0.1, 0.3)).clamp(-0.95, 0.95)
     assert (out.cpu() - want).abs().max() <= 1e-7
+
+
+def test_reporter_fields_match_the_reference(emu_lib):
+    """td3_trainer.py:158-189: what the step hands its reporter every `log_every_n_steps` batches (batch 0 of the golden
+    run) — q1/q2 losses and values, the next-state and target Q-values, the actor loss and the Q-values of its action —
+    against what the reference's reporter received; other batches log nothing"""
+    g = Golden("td3_twin")
+    tr = build(g, "cpu")
+    seen = {}
+
+    class Reporter:
+        def log(self, **kw):
+            seen.update(kw)
+
+    tr.set_reporter(Reporter())
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    for s in range(2):
+        tr.set_noise(g.t(f"step{s}_noise"))
+        seen.clear()
+        lightning_like_step(tr, opts, synthetic.to_policy_input(g.batch(s), "cpu"), s)
+        want = {k[len(f"step{s}_report_"):]: g.t(k) for k in g.z.files if k.startswith(f"step{s}_report_")}
+        assert set(seen) == set(want) and (len(want) == 8 if s == 0 else not want)
+        for k, ref in want.items():
+            assert tuple(seen[k].shape) == tuple(ref.shape), k
+            assert (seen[k].cpu() - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item()), k
