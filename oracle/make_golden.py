@@ -113,6 +113,9 @@ def gen_dqn(name, c):
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
         arrays[f"step{s}_q"] = _np(tr.all_action_scores)
+        for k, v in tr.logger.metrics.items():  # what the step handed to logger.log_metrics (dqn_trainer.py:336-347)
+            arrays[f"step{s}_metric_{k}"] = _np(v.double().reshape(-1))
+        tr.logger.metrics.clear()
         if c.get("batch_norm"):  # running_mean / running_var / num_batches_tracked of both networks, module order
             for i, bf in enumerate(tr.q_network.buffers()):
                 arrays[f"step{s}_qbuf_{i}"] = _np(bf)

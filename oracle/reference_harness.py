@@ -38,8 +38,10 @@ class PLLoop:
                 self.metrics = {}
 
             def log_metrics(self, metrics, step=None):
-                for k, v in metrics.items():  # (DQN logs nested dicts too: only scalars are kept)
-                    if isinstance(v, torch.Tensor):
+                for k, v in metrics.items():  # DQN's per-action dicts are flattened to "<metric>/<action name>"
+                    if isinstance(v, dict):
+                        self.log_metrics({f"{k}/{a}": x for a, x in v.items()})
+                    elif isinstance(v, torch.Tensor):
                         self.metrics[k] = v.detach().clone()
                     elif isinstance(v, (int, float)):
                         self.metrics[k] = torch.tensor(float(v))

@@ -748,3 +748,22 @@ class DQNTrainer(QStepCore):
             model_values_on_logged_actions=None,
             model_action_idxs=model_action_idxs,
         )
+        if self.logger:  # :320-347: per-action means as {action name: device scalar} (a TensorBoard logger reads them out)
+            ap = training_batch.extras.action_probability
+            greedy = torch.nn.functional.one_hot(model_action_idxs.reshape(-1), num_classes=self.num_actions).float().mean(dim=0)
+            self.logger.log_metrics(
+                {
+                    "td_loss": td_loss,
+                    "logged_actions": self._dense_to_action_dict(training_batch.action.float().mean(dim=0)),
+                    "logged_propensities": None if ap is None else ap.mean(dim=0),
+                    "logged_rewards": rewards.mean(),
+                    "model_values": self._dense_to_action_dict(self.all_action_scores.mean(dim=0)),
+                    "model_action_idxs": self._dense_to_action_dict(greedy),
+                },
+                step=self.all_batches_processed,
+            )
+
+    def _dense_to_action_dict(self, dense: torch.Tensor):
+        """dqn_trainer.py:349-360: tensor([1.0, 0.0, 1.0]) -> {"1": 1.0, "2": 0.0, "3": 1.0} over the action names"""
+        assert dense.size() == (self.num_actions,), f"Invalid dense size {dense.size()} != {(self.num_actions,)}"
+        return {a: dense[i] for i, a in enumerate(self._actions)}

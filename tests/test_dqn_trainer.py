@@ -391,3 +391,33 @@ def test_per_step_logging_fields(backend):
     mask = b["possible_actions_mask"] if tr.maxq_learning else b["action"]
     greedy = (q + (1.0 - mask.float()) * -1e10).argmax(dim=1, keepdim=True)  # dqn_trainer_base.py:147-163
     assert torch.equal(rec["model_action_idxs"].cpu().reshape(-1, 1), greedy)
+
+
+@pytest.mark.parametrize("name", ["dqn_huber_masks", "dqn_sarsa_multistep", "dqn_c1"])
+def test_logger_metrics_match_the_reference(emu_lib, name):
+    """dqn_trainer.py:320-347: the second logging channel — `self.logger.log_metrics` with td_loss, the mean (boosted)
+    reward, the mean propensity and per-action dicts {action name: mean} of the logged actions, the model's Q-values and
+    its greedy actions — key by key against what the reference's logger received on the golden batches"""
+    g = Golden(name)
+    tr = build(g, "cpu", L.PREC_F32)
+    got = {}
+
+    class Logger:
+        def log_metrics(self, metrics, step=None):
+            assert step == tr.all_batches_processed
+            for k, v in metrics.items():
+                if isinstance(v, dict):
+                    got.update({f"{k}/{a}": x for a, x in v.items()})
+                elif v is not None:
+                    got[k] = v
+
+    tr.logger = Logger()
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    for s in range(g.cfg["steps"]):
+        got.clear()
+        lightning_like_step(tr, opts, synthetic.to_dqn_input(g.batch(s), "cpu"))
+        want = {k[len(f"step{s}_metric_"):]: g.t(k) for k in g.z.files if k.startswith(f"step{s}_metric_")}
+        assert set(got) == set(want) and len(want) >= 3 + 3 * g.cfg["num_actions"], (sorted(got), sorted(want))
+        for k, ref in want.items():
+            v = got[k].detach().double().reshape(-1).cpu()
+            assert v.shape == ref.shape and (v - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item()), (s, k)
