@@ -176,6 +176,13 @@ def gen_qr(name, c):
             for i, p in enumerate(getattr(tr, net).parameters()):
                 arrays[f"init_{net}_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
+    reported = {}
+
+    class _Reporter:  # qrdqn_trainer.py:183-192
+        def log(self, **kw):
+            reported.update({k: v.detach().clone() for k, v in kw.items() if isinstance(v, torch.Tensor)})
+
+    tr.set_reporter(_Reporter())
     for s in range(c["steps"]):
         b = synthetic.dqn_batch(c["batch"], c["state_dim"], c["num_actions"], seed=200 + s,
                                 p_impossible=c["p_impossible"], n_extra_metrics=len(cpe_metrics or []))
@@ -183,6 +190,9 @@ def gen_qr(name, c):
             arrays[f"step{s}_batch_{k}"] = _np(v)
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
+        for k, v in reported.items():
+            arrays[f"step{s}_report_{k}"] = _np(v)
+        reported.clear()
         if cpe_metrics is not None:
             arrays[f"step{s}_reward_loss"], arrays[f"step{s}_cpe_loss"] = _np(losses[1]), _np(losses[2])
             for net in CPE_NETS:

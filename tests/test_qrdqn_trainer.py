@@ -238,3 +238,32 @@ def test_compact_head_against_the_pair_loop(backend):
     assert (dzd.cpu().double() - ref_dz).abs().max() <= 1e-6 * ref_dz.abs().max() + 1e-9
     assert (lpd.cpu().double() - ref_l).abs().max() <= 2e-6 * ref_l.abs().max()
     assert abs(tld.cpu().double().sum() - ref_l.sum()) <= 1e-6 * ref_l.sum()
+
+
+@pytest.mark.parametrize("name", ["qrdqn_double", "qrdqn_single_sarsa"])
+def test_reporter_fields_match_the_reference(emu_lib, name):
+    """qrdqn_trainer.py:178-192: what the step hands its reporter — td_loss, logged action indices, propensities, boosted
+    rewards, the mean-over-atoms Q-values and their masked arg-max — against what the reference's reporter received on the
+    golden batches"""
+    g = Golden(name)
+    tr = build(g, "cpu", L.PREC_F32)
+    seen = {}
+
+    class Reporter:
+        def log(self, **kw):
+            seen.update({k: v for k, v in kw.items() if v is not None})
+
+    tr.set_reporter(Reporter())
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    for s in range(g.cfg["steps"]):
+        seen.clear()
+        lightning_like_step(tr, opts, synthetic.to_dqn_input(g.batch(s), "cpu"))
+        want = {k[len(f"step{s}_report_"):]: g.t(k) for k in g.z.files if k.startswith(f"step{s}_report_")}
+        assert set(seen) == set(want) and len(want) == 6
+        for k, ref in want.items():
+            v = seen[k].detach().cpu()
+            assert v.reshape(ref.shape).dtype == ref.dtype or ref.dtype.is_floating_point, k
+            if ref.dtype.is_floating_point:
+                assert (v.reshape(ref.shape) - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item()), (s, k)
+            else:
+                assert torch.equal(v.reshape(ref.shape), ref), (s, k)
