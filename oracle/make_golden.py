@@ -87,6 +87,24 @@ DQN_CASES = {
 }
 
 
+def _record_reporter(tr):
+    """installs a reporter that keeps the tensors of the step's reporter.log(...) calls; returns the dict it fills"""
+    reported = {}
+
+    class _Reporter:
+        def log(self, **kw):
+            reported.update({k: v.detach().clone() for k, v in kw.items() if isinstance(v, torch.Tensor)})
+
+    tr.set_reporter(_Reporter())
+    return reported
+
+
+def _put_reported(arrays, s, reported):
+    for k, v in reported.items():
+        arrays[f"step{s}_report_{k}"] = _np(v)
+    reported.clear()
+
+
 def gen_dqn(name, c):
     cpe_metrics = c.get("cpe_metrics")
     tr = rh.build_dqn(c["state_dim"], c["num_actions"], c["sizes"], c["activations"], c["rl"], c["lr"],
@@ -341,6 +359,7 @@ def gen_c51(name, c):
     for i, p in enumerate(tr.q_network.parameters()):
         arrays[f"init_param_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
+    reported = _record_reporter(tr)  # c51_trainer.py:179-186
     for s in range(c["steps"]):
         b = synthetic.dqn_batch(c["batch"], c["state_dim"], c["num_actions"], seed=500 + s,
                                 p_impossible=c["p_impossible"])
@@ -348,6 +367,7 @@ def gen_c51(name, c):
             arrays[f"step{s}_batch_{k}"] = _np(v)
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
+        _put_reported(arrays, s, reported)
         for i, p in enumerate(tr.q_network.parameters()):
             arrays[f"step{s}_param_{i}"] = _np(p)
         for i, p in enumerate(tr.q_network_target.parameters()):
@@ -446,6 +466,7 @@ def gen_crr(name, c):
             for i, p in enumerate(m.parameters()):
                 arrays[f"init_{n}_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
+    reported = _record_reporter(tr)  # discrete_crr_trainer.py:375-382
     names = ["q1_loss"] + (["q2_loss"] if c["twin"] else []) + ["actor_loss"]
     names += ["reward_loss", "cpe_loss"] if c["cpe_metrics"] is not None else []
     for s in range(c["steps"]):
@@ -456,6 +477,7 @@ def gen_crr(name, c):
             arrays[f"step{s}_batch_{k}"] = _np(v)
         losses = loop.step(rh.dqn_batch_to_reference(b))
         assert len(losses) == len(names) + 1
+        _put_reported(arrays, s, reported)
         for nm, l in zip(names, losses):
             if l is not None:
                 arrays[f"step{s}_{nm}"] = _np(l)

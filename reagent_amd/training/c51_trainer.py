@@ -74,7 +74,9 @@ class C51Trainer(QStepCore):
 
     def train_step_gen(self, training_batch: rlt.DiscreteDqnInput, batch_idx: int):
         loss = self._hip_loss(training_batch)
-        self._log(loss, training_batch)
+        # c51_trainer.py:178: reported every `log_every_n_steps` batches of the driving trainer (50 without one)
+        if batch_idx % getattr(getattr(self, "trainer", None), "log_every_n_steps", 50) == 0:
+            self._log(loss, training_batch)
         yield loss
         yield self.soft_update_result()
 

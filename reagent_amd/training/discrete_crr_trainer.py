@@ -279,7 +279,17 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
             yield None  # None keeps the actor network from updating
         if self._cpe is not None:
             self._cpe.forward(b)
-            yield self._cpe.loss("reward")
+            reward_loss = self._cpe.loss("reward")
+            yield reward_loss
+            from .reagent_lightning_module import _NoOpReporter
+
+            if not isinstance(self._reporter, _NoOpReporter):  # dqn_trainer_base.py:430-450 (inside _calculate_cpes)
+                from ..core.torch_utils import masked_softmax
+
+                mask = b.possible_actions_mask if self.maxq_learning else b.action
+                self.reporter.log(reward_loss=reward_loss.detach(),
+                                  model_propensities=masked_softmax(self.all_action_scores, mask.float(), self.rl_temperature),
+                                  model_rewards=self._cpe.reward_est[:, : self.num_actions])
             yield self._cpe.loss("cpe")
         self._log_crr(q1_loss, b)
         yield self.soft_update_result()

@@ -33,3 +33,19 @@ class Golden:
     def batch(self, step):
         pre = f"step{step}_batch_"
         return {k[len(pre):]: self.t(k) for k in self.z.files if k.startswith(pre)}
+
+
+def check_reported(g, s, seen, tol=1e-4):
+    """the tensors a step handed its reporter against the reference's (`step{s}_report_*`, recorded by
+    oracle/make_golden.py::_record_reporter): same keys, integers exact, floats within tol of the largest magnitude"""
+    pre = f"step{s}_report_"
+    want = {k[len(pre):]: g.t(k) for k in g.z.files if k.startswith(pre)}
+    got = {k: v for k, v in seen.items() if isinstance(v, torch.Tensor)}
+    assert set(got) == set(want), (s, sorted(got), sorted(want))
+    for k, ref in want.items():
+        v = got[k].detach().cpu().reshape(ref.shape)
+        if ref.dtype.is_floating_point:
+            assert (v.to(ref.dtype) - ref).abs().max() <= tol * max(1.0, ref.abs().max().item()), (s, k)
+        else:
+            assert torch.equal(v, ref), (s, k)
+    return len(want)

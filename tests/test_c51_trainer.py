@@ -66,3 +66,28 @@ def test_c51_native_step(backend):
     assert torch.equal(la.cpu().reshape(()), lb.cpu().reshape(()))
     for pa, pb in zip(tr_a.q_network.parameters(), tr_b.q_network.parameters()):
         assert torch.equal(pa.detach().cpu(), pb.detach().cpu())
+
+
+@pytest.mark.parametrize("name", ["c51_double", "c51_sarsa"])
+def test_reporter_fields_match_the_reference(emu_lib, name):
+    """c51_trainer.py:179-186: the tensors handed to the reporter against what the reference's reporter received"""
+    from golden_util import check_reported
+
+    g = Golden(name)
+    tr = build(g, "cpu")
+    seen = {}
+
+    class Reporter:
+        def log(self, **kw):
+            seen.update(kw)
+
+    tr.set_reporter(Reporter())
+    from test_td3_trainer import lightning_like_step as step_with_batch_idx
+
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    total = 0
+    for s in range(g.cfg["steps"]):  # reported every log_every_n_steps batches (:178): batch 0 here, nothing afterwards
+        seen.clear()
+        step_with_batch_idx(tr, opts, synthetic.to_dqn_input(g.batch(s), "cpu"), s)
+        total += check_reported(g, s, seen)
+    assert total == 6

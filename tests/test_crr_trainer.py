@@ -274,3 +274,27 @@ def test_reference_crr_test_train_step_gen(backend):
     before = [p.detach().clone() for p in tr.actor_network.parameters()]
     lightning_like_step(tr, opts, c.inp, 0)
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, tr.actor_network.parameters()))
+
+
+@pytest.mark.parametrize("name", ["crr_twin_entropy_cpe", "crr_single_delayed"])
+def test_reporter_fields_match_the_reference(emu_lib, name):
+    """discrete_crr_trainer.py:375-382 (and the CPE heads' reporter fields, dqn_trainer_base.py:243-452): the tensors
+    handed to the reporter against what the reference's reporter received"""
+    from golden_util import check_reported
+
+    g = Golden(name)
+    tr = build(g, "cpu")
+    seen = {}
+
+    class Reporter:
+        def log(self, **kw):
+            seen.update(kw)
+
+    tr.set_reporter(Reporter())
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    total = 0
+    for s in range(g.cfg["steps"]):
+        seen.clear()
+        lightning_like_step(tr, opts, synthetic.to_dqn_input(g.batch(s), "cpu"), s)
+        total += check_reported(g, s, seen)
+    assert total >= 6
