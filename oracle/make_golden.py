@@ -122,6 +122,7 @@ def gen_dqn(name, c):
             for i, p in enumerate(getattr(tr, net).parameters()):
                 arrays[f"init_{net}_{i}"] = _np(p)
     loop = rh.PLLoop(tr)
+    reported = _record_reporter(tr)  # dqn_trainer.py:306-319 and, with CPE, dqn_trainer_base.py:430-450
     for s in range(c["steps"]):
         b = synthetic.dqn_batch(c["batch"], c["state_dim"], c["num_actions"], seed=100 + s,
                                 p_impossible=c["p_impossible"], with_steps=c["with_steps"],
@@ -131,6 +132,7 @@ def gen_dqn(name, c):
         losses = loop.step(rh.dqn_batch_to_reference(b))
         arrays[f"step{s}_loss"] = _np(losses[0])
         arrays[f"step{s}_q"] = _np(tr.all_action_scores)
+        _put_reported(arrays, s, reported)
         for k, v in tr.logger.metrics.items():  # what the step handed to logger.log_metrics (dqn_trainer.py:336-347)
             arrays[f"step{s}_metric_{k}"] = _np(v.double().reshape(-1))
         tr.logger.metrics.clear()

@@ -421,3 +421,26 @@ def test_logger_metrics_match_the_reference(emu_lib, name):
         for k, ref in want.items():
             v = got[k].detach().double().reshape(-1).cpu()
             assert v.shape == ref.shape and (v - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item()), (s, k)
+
+
+@pytest.mark.parametrize("name", ["dqn_cpe", "dqn_cpe_sarsa_mse", "dqn_huber_masks", "dqn_timediff"])
+def test_reporter_tensors_match_the_reference(emu_lib, name):
+    """every tensor the step hands its reporter (dqn_trainer.py:306-319; with CPE heads also reward_loss,
+    model_propensities, model_rewards of dqn_trainer_base.py:430-450) against what the reference's reporter received"""
+    from golden_util import check_reported
+
+    g = Golden(name)
+    cpe = g.cfg.get("cpe_metrics") is not None
+    tr = build_cpe(g, "cpu") if cpe else build(g, "cpu", L.PREC_F32)
+    seen = {}
+
+    class Reporter:
+        def log(self, **kw):
+            seen.update(kw)
+
+    tr.set_reporter(Reporter())
+    opts = [o["optimizer"] for o in tr.configure_optimizers()]
+    for s in range(g.cfg["steps"]):
+        seen.clear()
+        lightning_like_step(tr, opts, synthetic.to_dqn_input(g.batch(s), "cpu"))
+        assert check_reported(g, s, seen) >= (9 if cpe else 6)
