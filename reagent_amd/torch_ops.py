@@ -43,6 +43,20 @@ def register_backend(dispatch_key: str):
 
 # ---- fully-connected stacks (fully_connected_network.py:157-163) ------------------------------------------------
 _stacks = {}
+# The package's in-place ops write through kernels: neither torch's version counter nor the trainers' `_rg_version`
+# (which lives on Parameter objects, not on the `.detach()` views a caller may pass) sees them.  They therefore record a
+# write epoch per STORAGE, and a cached stack whose weights' storages were written since its last staging re-stages.
+_write_epoch = {}
+
+
+def _note_write(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        k = t.untyped_storage().data_ptr()
+        _write_epoch[k] = _write_epoch.get(k, 0) + 1
+
+
+def _epochs(tensors) -> tuple:
+    return tuple(_write_epoch.get(t.untyped_storage().data_ptr(), 0) for t in tensors)
 
 
 def _mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torch.Tensor], activations: List[str],
@@ -56,7 +70,11 @@ def _mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torc
         if len(_stacks) > 64:
             _stacks.clear()
         st = _stacks[key] = make_stack(weights, biases, [L.ACT[a] for a in activations], _PREC[precision])
-    st.stage_weights(need_transposed=False)  # re-staged only when a weight's version counter moved
+        st._rg_write_epochs = None
+    ep = _epochs(list(weights) + list(biases))
+    # re-staged only when a weight's version counter moved or one of this package's in-place ops wrote its storage
+    st.stage_weights(need_transposed=False, force=st._rg_write_epochs != ep)
+    st._rg_write_epochs = ep
     xc, _ = st.stage_input(x if x.dtype in (torch.float32, torch.bfloat16) else x.float(), need_transposed=False)
     out = torch.empty(x.shape[0], weights[-1].shape[0], dtype=torch.float32, device=x.device)
     st.forward(xc, out, save=False)
@@ -73,6 +91,7 @@ def _adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, 
     assert param.is_contiguous() and grad.is_contiguous() and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous()
     ops.adam_step(param, grad, exp_avg, exp_avg_sq, param.numel(), lr, beta1, beta2, eps, weight_decay,
                   1.0 - beta1 ** step, math.sqrt(1.0 - beta2 ** step), grad_scale)
+    _note_write(param)
 
 
 _define("adam_step_(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, "
@@ -83,6 +102,7 @@ _define("adam_step_(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!
 def _soft_update_(target: torch.Tensor, source: torch.Tensor, tau: float) -> None:
     assert target.is_contiguous() and source.is_contiguous() and target.numel() == source.numel()
     ops.soft_update(target, source, target.numel(), tau)
+    _note_write(target)
 
 
 _define("soft_update_(Tensor(a!) target, Tensor source, float tau) -> ()", _soft_update_, lambda *a, **k: None)

@@ -483,6 +483,10 @@ class QStepCore(DQNTrainerBaseLightning):
         """forwards + head + backward + wgrad into the gradient slab; no collective, no update"""
         if getattr(self, "_cpe", None) is not None:
             raise NotImplementedError("the two-halves form of the native step does not cover the CPE heads")
+        if self._q_has_batch_norm():
+            # the reference evaluates q_network(next_state) once more after the optimizer step (dqn_trainer.py:267-268),
+            # which moves a batch-normed network's running statistics; the two-halves form has no such forward
+            raise NotImplementedError("the two-halves form of the native step does not cover batch-normed Q-networks")
         loss = self._hip_forward(training_batch)
         for p in self._hip_params:
             p.grad = None

@@ -86,6 +86,10 @@ class AdamF64(torch.optim.Optimizer):
     also publishes alpha = exp(log_alpha) to the device scalar the loss heads read."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, alpha_out=None):
+        if weight_decay != 0.0:
+            # torch.optim.Adam on log_alpha would add weight_decay * log_alpha to the gradient; rg_adam_step_f64 has no
+            # such term, so a non-zero value must not pass silently
+            raise NotImplementedError("alpha_optimizer weight_decay != 0 is not supported by the fp64 temperature step")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.alpha_out = alpha_out
         self._sched = None
@@ -249,10 +253,14 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         """alpha = exp(log_alpha) as the loss heads read it: like the reference's `entropy_temperature` attribute
         (sac_trainer.py:322) it is not part of the state_dict, and is the constructor's value until the first
         temperature step — a resumed run must continue from the current one"""
-        return {"alpha": self._alpha(self.log_alpha.device).detach().cpu().clone()}
+        return {"alpha": self._alpha(self._extras_device()).detach().cpu().clone()}
 
     def load_checkpoint_extras(self, extras: dict):
-        self._alpha(self.log_alpha.device).copy_(extras["alpha"])
+        self._alpha(self._extras_device()).copy_(extras["alpha"])
+
+    def _extras_device(self):
+        # `log_alpha` exists only with an alpha optimizer (a fixed temperature is a supported configuration)
+        return next(self.actor_network.parameters()).device
 
     # ---- engine ----------------------------------------------------------------------------------
     def _alpha(self, device):

@@ -30,7 +30,7 @@ def _dqn_loop(seed=0):
     return OfflineDqnLoop(rb, tr, B, pre), tr
 
 
-def _sac_loop(seed=0):
+def _sac_loop(seed=0, fixed_temperature=False):
     from reagent_amd.core.parameters import CONTINUOUS_TRAINING_ACTION_RANGE as R
     from reagent_amd.preprocessing import PolicyNetworkInputMaker
     from reagent_amd.runtime import OfflinePolicyLoop
@@ -41,7 +41,8 @@ def _sac_loop(seed=0):
     adam = lambda: Optimizer__Union.default(lr=2e-3)  # noqa: E731
     tr = SACTrainer(GaussianFullyConnectedActor(S, A, [32, 24], ["relu", "relu"]), FullyConnectedCritic(S, A, [32, 24], ["relu", "relu"]),
                     FullyConnectedCritic(S, A, [32, 24], ["relu", "relu"]), rl=RLParameters(gamma=0.98, target_update_rate=0.1),
-                    q_network_optimizer=adam(), actor_network_optimizer=adam(), alpha_optimizer=adam())
+                    q_network_optimizer=adam(), actor_network_optimizer=adam(),
+                    alpha_optimizer=None if fixed_temperature else adam())
     cols = synthetic.replay_contents(C, S, A, seed=3)
     cols["action"] = torch.rand(C, A, generator=torch.Generator().manual_seed(4)) * 1.8 - 0.9
     del cols["possible_actions_mask"]
@@ -98,3 +99,10 @@ def test_dqn_loop_resumes_bit_identically(emu_lib, tmp_path):
 
 def test_sac_loop_resumes_bit_identically(emu_lib, tmp_path):
     _run(_sac_loop, tmp_path)
+
+
+def test_sac_loop_with_a_fixed_temperature_resumes_bit_identically(emu_lib, tmp_path):
+    """alpha_optimizer=None (no `log_alpha` parameter, sac_trainer.py:143-150): the checkpoint extras must not reach for it"""
+    from functools import partial
+
+    _run(partial(_sac_loop, fixed_temperature=True), tmp_path)

@@ -115,7 +115,6 @@ def test_preprocessor_oracle_matches_reference():
     torch.testing.assert_close(out, g.t("out"), rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/reagent"), reason="needs the reference checkout")
 def test_fc_options_oracle_matches_reference():
     """restated batch-norm / layer-norm / residual forward (training and eval mode, moved running statistics) against the
     reference module's outputs in tests/golden/fc_options.npz"""
@@ -132,6 +131,7 @@ def test_fc_options_oracle_matches_reference():
     assert (out_e - g.t("eval_out")).abs().max() <= 2e-5
 
 
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/reagent"), reason="needs the reference checkout")
 def test_committed_goldens_are_what_the_reference_produces():
     """`python -m oracle.make_golden --check`: every fixture under tests/golden regenerated from the
     unmodified reference and compared array by array with the committed file (build container only)"""

@@ -45,6 +45,32 @@ def test_mlp_forward_and_optimizer_ops(dev):
     assert torch.allclose(tgt.cpu(), 0.25 * pd.cpu(), atol=1e-7)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_mlp_forward_sees_weights_written_by_the_in_place_ops(dev, precision):
+    """mlp_forward -> adam_step_(w) / soft_update_(w) -> mlp_forward: the staged bf16 fragments of the cached stack must
+    follow weights that this package's own in-place ops wrote (they bump no torch version counter); `.detach()` views
+    of the weights included"""
+    gen = torch.Generator().manual_seed(5)
+    dims = [16, 256, 256, 4]
+    ws = [(torch.randn(o, i, generator=gen) * 0.2).to(dev) for i, o in zip(dims, dims[1:])]
+    bs = [(torch.randn(o, generator=gen) * 0.1).to(dev) for o in dims[1:]]
+    x = torch.randn(40, dims[0], generator=gen).to(dev)
+    acts = ["relu", "relu", "linear"]
+    views = [w.detach() for w in ws]
+    q0 = R.mlp_forward(x, views, bs, acts, precision).clone()
+    g = torch.randn(ws[1].shape, generator=gen).to(dev)
+    m, v = torch.zeros_like(ws[1]), torch.zeros_like(ws[1])
+    R.adam_step_(ws[1], g, m, v, 5e-2, 0.9, 0.999, 1e-8, 0.0, 1)
+    q1 = R.mlp_forward(x, views, bs, acts, precision).clone()
+    fresh = R.mlp_forward(x, [w.clone() for w in ws], [b.clone() for b in bs], acts, precision)
+    assert (q1 - q0).abs().max() > 1e-3  # the step moved every weight of layer 1 by lr
+    assert torch.equal(q1, fresh)
+    R.soft_update_(ws[2], torch.zeros_like(ws[2]), 0.5)
+    q2 = R.mlp_forward(x, views, bs, acts, precision)
+    fresh = R.mlp_forward(x, [w.clone() for w in ws], [b.clone() for b in bs], acts, precision)
+    assert torch.equal(q2, fresh) and not torch.equal(q2, q1)
+
+
 def test_head_ops(dev):
     gen = torch.Generator().manual_seed(4)
     B, A = 50, 6
