@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-accurate", action="store_true",
+                    help="skip the second timed region in the 1e-4-compliant bf16x3 mode (default run, --precision bf16)")
+    ap.add_argument("--no-also", action="store_true", help="skip the short C3 / C4 regions of the default C2 run")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step as a HIP graph at all")
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default=None,
                     help="auto: replay the captured HIP graph or enqueue eagerly, whichever a short calibration finds faster")
@@ -324,6 +327,16 @@ def parity_check(args, device, init, cols, norm):
                                for k in ("q1_loss", "q2_loss", "actor_loss"))
         pairs = list(zip(trainer.actor_network.parameters(), o.actor)) + list(zip(trainer.q1_network.parameters(), o.q1))
     else:
+        if args.algo == "qrdqn":
+            # quantile level: the network's [B, A, N] output before the step against the oracle's on the same rows
+            # (a bounded slice: the dense logits of 4096 rows are 52 MB), and the per-action means the a* selection uses
+            rows = min(B, 512)
+            z = trainer.q_network(batch.state)[:rows].cpu()
+            with torch.no_grad():
+                zr = o.net(o.params, b["state"][:rows])
+            out["max_abs_dquantile"] = (z - zr).abs().max().item()
+            out["max_abs_dq"] = (z.mean(dim=2) - zr.mean(dim=2)).abs().max().item()
+            out["dq_rows"] = rows
         loss = loop.step(idx.to(device))
         loop.flush()
         ref = o.step(b)
@@ -335,7 +348,9 @@ def parity_check(args, device, init, cols, norm):
     dws = [(p.detach().cpu() - r.detach()).abs() for p, r in pairs]
     out["max_abs_dw"] = max(d.max().item() for d in dws)
     out["frac_dw_beyond_2e-5"] = sum((d > 2e-5).sum().item() for d in dws) / sum(d.numel() for d in dws)
-    dq = out.get("max_abs_dq", out.get("max_abs_dlogits", 0.0))
+    dq = max(out.get("max_abs_dq", 0.0), out.get("max_abs_dlogits", 0.0), out.get("max_abs_dquantile", 0.0))
+    # north_star's floating-point bound ("Q-values / policy logits within 1e-4 fp32"; replay index gather bit-exact)
+    out["meets_north_star"] = bool(dq <= 1e-4 and all(exact))
     if args.precision == "f32":
         out["tolerance"] = "Q / logits 1e-4, weights 2e-5 (north_star)"
         if args.algo == "sac":
@@ -350,18 +365,22 @@ def parity_check(args, device, init, cols, norm):
                             "flips the direction of the few weights whose gradient is below it)")
         out["ok"] = bool(dq <= 1e-4 and out["frac_dw_beyond_2e-5"] <= 0.02 and out["max_abs_dw"] <= 2.1e-3)
     else:
-        out["tolerance"] = "bf16 operands: Q ~3e-2, |dW| <= 2*lr after one Adam step (sign flips of tiny gradients)"
-        out["ok"] = bool(dq <= 6e-2 and out["max_abs_dw"] <= 2.1e-3)
-    out["ok"] = bool(out["ok"] and out["gather_fields_bit_exact"])
+        out["tolerance"] = ("NOT north_star's: plain bf16 operands put Q ~3e-2 from the fp32 reference (the bf16x3 mode in "
+                            "`accurate` is the one held to 1e-4); sanity bounds only: Q 6e-2, |dW| <= 2*lr after one Adam step")
+        out["sane"] = bool(dq <= 6e-2 and out["max_abs_dw"] <= 2.1e-3 and out["gather_fields_bit_exact"])
+        out["ok"] = False  # `ok` means north_star's tolerance; this mode does not meet it by construction
+    out["ok"] = bool(out["ok"] and out["gather_fields_bit_exact"] and out["meets_north_star"])
     return out
 
 
 def source_stamp():
     """sha256 of the kernel sources the dominant kernels are built from (stamps profiles/traffic.json)"""
     h = hashlib.sha256()
-    for f in ("mlp_fused.hip", "mlp_fused_x3.hip", "rg_mlp_frag.h", "rg_gemm.h", "fc.hip"):
-        with open(os.path.join(ROOT, "reagent_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    src = os.path.join(ROOT, "reagent_amd", "csrc")
+    for f in sorted(os.listdir(src)):  # every kernel source the file's figures describe (FC stacks, sampler, heads, updates)
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(src, f), "rb") as fh:
+                h.update(fh.read())
     return h.hexdigest()[:16]
 
 
@@ -437,8 +456,129 @@ def kernel_profile(args, step, steps):
         out["gather"] = {"bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": bytes_ / sec / HBM_PEAK, "avg_launch_us": sec * 1e6,
                          "algorithmic_bytes_per_transition": g[0]["meta"]["bytes_per_row"], "kernel": g[0]["name"]}
+    ar = [r for r in rows if r["name"] == "all_reduce"]
+    if ar:
+        out["all_reduce_us"] = ar[0]["ms"] * 1e3 / ar[0]["calls"]
+        out["all_reduce_bytes"] = ar[0]["meta"]["bytes"]
     out["per_call_ms_per_step"] = {f"{r['name']}{tuple(r['meta'].values())}": round(r["ms"] / steps, 4) for r in rows[:18]}
     return out
+
+
+def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
+    """build the workload `args` names on this rank, run the parity step, pick the launch path, time `--repeats` regions
+    of exactly `--steps` steps, run the instrumented pass; returns the numbers (all ranks) for rank 0 to print"""
+    loop, trainer, init, cols, norm = build(args, device, rank, cols=cols)
+    if args.algo == "qrdqn":
+        from reagent_amd.qr_engine import GroupedQR
+
+        args.grouped_head = bool(trainer.use_grouped_head and GroupedQR.eligible(trainer))
+    if world > 1:
+        trainer.enable_data_parallel()
+    parity = None
+    if rank == 0 and not args.no_parity:
+        try:
+            parity = parity_check(args, device, init, cols, norm)
+        except Exception as e:  # reported, never fatal to the measurement
+            parity = {"error": repr(e)}
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = loop.step
+    graph_note = None
+    # data parallel: the eager loop (asynchronous all-reduce, deferred update) is the default — on one GPU the
+    # replayed graph measured slower than eager launches for the DQN step, and the three-graph data-parallel form
+    # has only been exercised on a one-rank RCCL group (tests/test_graph_replay.py); `--launch graph` / `auto` opt in
+    want_graph = not args.no_graph and hasattr(loop, "capture") and not (world > 1 and args.launch is None) and args.launch != "eager"
+    launch = args.launch or "auto"
+    if want_graph:
+        try:
+            replay = loop.capture(warmup=max(2, min(args.warmup, 3)))
+        except Exception as e:
+            replay = None
+            graph_note = f"graph capture failed, eager launches: {e!r}"
+        if replay is not None:
+            # Which launch path is faster depends on the workload: a replayed graph costs the host ~0.02 ms per
+            # step but serialises its kernel nodes a little more loosely than back-to-back stream launches, an
+            # eager step costs the host 0.3-1.2 ms.  Calibrate outside the timed region (every rank takes the same
+            # decision: the slowest rank's times count).
+            def timed(fn, n=8):
+                fn()
+                loop.flush()
+                barrier()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                loop.flush()
+                barrier()
+                return (time.perf_counter() - t) / n
+
+            t_graph, t_eager = timed(replay), timed(loop.step)
+            if dist is not None:
+                tt = torch.tensor([t_graph, t_eager], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_graph, t_eager = tt.tolist()
+            use_graph = launch == "graph" or (launch == "auto" and t_graph <= t_eager)
+            what = ("one HIP graph per step (index draw, sampler, forwards, head, backward, wgrad, update)" if world == 1 else
+                    "three HIP graphs per step (sample | update | forward+backward), the RCCL all-reduce of the gradient "
+                    "slab launched eagerly between them")
+            graph_note = (f"{'graph replay: ' + what if use_graph else 'eager stream launches'}; calibration "
+                          f"{t_graph * 1e3:.3f} ms/step replayed vs {t_eager * 1e3:.3f} ms/step eager")
+            step = replay if use_graph else loop.step
+            if not use_graph:
+                loop.release_graph()  # eager steps then pass Adam's coefficients per launch (no tick kernel)
+    for _ in range(args.warmup):
+        step()
+    loop.flush()
+    # K steps take ~12 ms at C2: one region is at the mercy of a clock ramp or a stray interrupt.  The region of
+    # EXACTLY K steps (barrier + synchronize on both sides, max over ranks) is therefore timed `--repeats` times
+    # back to back and the MEDIAN region is reported; every region's time is listed in `region_ms`.
+    regions, host_regions, own_regions = [], [], []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        loop.flush()  # data parallel: the last step's update joins its all-reduce inside the timed region
+        host_regions.append(time.perf_counter() - t0)  # time the host needed to ENQUEUE the steps (diagnostic)
+        barrier()
+        dt = time.perf_counter() - t0
+        own_regions.append(dt)
+        if dist is not None:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        regions.append(dt)
+    order = sorted(range(len(regions)), key=lambda i: regions[i])
+    mid = order[len(order) // 2]
+    dt, host_dt = regions[mid], host_regions[mid]
+    if isinstance(loss, dict):
+        loss = loss["q1_loss"]
+    loss_val = float(loss.item())
+
+    extra = {}
+    if not args.no_kernel_profile:
+        # every rank runs the instrumented steps (they contain the gradient all-reduce: a pass on rank 0
+        # alone would never return); rank 0 reports.  Eager launches: events bracket each C-ABI call.
+        extra = kernel_profile(args, loop.step, profile_steps or min(args.steps, 10))
+        loop.flush()
+    per_rank = None
+    if dist is not None:
+        # every rank's own view, so a curve measured by the driver explains itself: the rank's wall time for the median
+        # region and the HIP-event time of the gradient all-reduce (instrumented pass)
+        mine = torch.tensor([own_regions[mid] / args.steps * 1e3, host_dt / args.steps * 1e3,
+                             extra.get("all_reduce_us", float("nan"))], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "ms_per_step": t[0].item(), "host_enqueue_ms_per_step": t[1].item(),
+                     "all_reduce_us": t[2].item()} for i, t in enumerate(allr)]
+    return {"value": world * args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+            "timing": f"median of {len(regions)} regions of {args.steps} steps each",
+            "region_ms": [round(r * 1e3, 4) for r in regions], "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+            "final_loss": loss_val, "launch": graph_note or "eager launches", "extra": extra, "parity": parity,
+            "per_rank": per_rank, "init": init, "cols": cols, "cols_cpu": cols, "norm": norm}
 
 
 def main():
@@ -478,127 +618,72 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # "nccl" IS RCCL on ROCm
         assert dist.get_world_size() == args.gpus
-    loop, trainer, init, cols, norm = build(args, device, rank)
-    if args.algo == "qrdqn":
-        from reagent_amd.qr_engine import GroupedQR
-
-        args.grouped_head = bool(trainer.use_grouped_head and GroupedQR.eligible(trainer))
-    if world > 1:
-        trainer.enable_data_parallel()
-    parity = None
-    if rank == 0 and not args.no_parity:
-        try:
-            parity = parity_check(args, device, init, cols, norm)
-        except Exception as e:  # reported, never fatal to the measurement
-            parity = {"error": repr(e)}
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    step = loop.step
-    graph_note = None
-    # data parallel: the eager loop (asynchronous all-reduce, deferred update) is the default — on one GPU the
-    # replayed graph measured slower than eager launches for the DQN step, and the three-graph data-parallel form
-    # has only been exercised on a one-rank RCCL group (tests/test_graph_replay.py); `--launch graph` / `auto` opt in
-    want_graph = not args.no_graph and hasattr(loop, "capture") and not (world > 1 and args.launch is None) and args.launch != "eager"
-    if args.launch is None:
-        args.launch = "auto"
-    if want_graph:
-        try:
-            replay = loop.capture(warmup=max(2, min(args.warmup, 3)))
-        except Exception as e:
-            replay = None
-            graph_note = f"graph capture failed, eager launches: {e!r}"
-        if replay is not None:
-            # Which launch path is faster depends on the workload: a replayed graph costs the host ~0.02 ms per
-            # step but serialises its kernel nodes a little more loosely than back-to-back stream launches, an
-            # eager step costs the host 0.3-1.2 ms.  Calibrate outside the timed region (every rank takes the same
-            # decision: the slowest rank's times count).
-            def timed(fn, n=8):
-                fn()
-                loop.flush()
-                barrier()
-                t = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                loop.flush()
-                barrier()
-                return (time.perf_counter() - t) / n
-
-            t_graph, t_eager = timed(replay), timed(loop.step)
-            if dist is not None:
-                tt = torch.tensor([t_graph, t_eager], device=device, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                t_graph, t_eager = tt.tolist()
-            use_graph = args.launch == "graph" or (args.launch == "auto" and t_graph <= t_eager)
-            what = ("one HIP graph per step (index draw, sampler, forwards, head, backward, wgrad, update)" if world == 1 else
-                    "three HIP graphs per step (sample | update | forward+backward), the RCCL all-reduce of the gradient "
-                    "slab launched eagerly between them")
-            graph_note = (f"{'graph replay: ' + what if use_graph else 'eager stream launches'}; calibration "
-                          f"{t_graph * 1e3:.3f} ms/step replayed vs {t_eager * 1e3:.3f} ms/step eager")
-            step = replay if use_graph else loop.step
-            if not use_graph:
-                loop.release_graph()  # eager steps then pass Adam's coefficients per launch (no tick kernel)
-    for _ in range(args.warmup):
-        step()
-    loop.flush()
-    # K steps take ~12 ms at C2: one region is at the mercy of a clock ramp or a stray interrupt.  The region of
-    # EXACTLY K steps (barrier + synchronize on both sides, max over ranks) is therefore timed `--repeats` times
-    # back to back and the MEDIAN region is reported; every region's time is listed in `region_ms`.
-    regions, host_regions = [], []
-    for _ in range(max(1, args.repeats)):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        loop.flush()  # data parallel: the last step's update joins its all-reduce inside the timed region
-        host_regions.append(time.perf_counter() - t0)  # time the host needed to ENQUEUE the steps (diagnostic)
-        barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
-        regions.append(dt)
-    order = sorted(range(len(regions)), key=lambda i: regions[i])
-    mid = order[len(order) // 2]
-    dt, host_dt = regions[mid], host_regions[mid]
-    if isinstance(loss, dict):
-        loss = loss["q1_loss"]
-    loss_val = float(loss.item())
-
-    extra = {}
-    if not args.no_kernel_profile:
-        # every rank runs the instrumented steps (they contain the gradient all-reduce: a pass on rank 0
-        # alone would never return); rank 0 reports.  Eager launches: events bracket each C-ABI call.
-        extra = kernel_profile(args, loop.step, min(args.steps, 10))
-        loop.flush()
+    m = measure(args, device, rank, world, dist)
     if dist is not None:
         dist.barrier()
     if rank == 0:
         res = {
             "metric": "transitions/sec at batch=65536 state_dim=128; 1/2/4/8 MI355X scaling",
-            "value": world * args.batch * args.steps / dt,
+            "value": m["value"],
             "unit": "transitions/s",
             "n_gpus": world, "rccl_ranks": world if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "timing": f"median of {len(regions)} regions of {args.steps} steps each",
-            "region_ms": [round(r * 1e3, 4) for r in regions],
-            "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
+            "ms_per_step": m["ms_per_step"],
+            "timing": m["timing"],
+            "region_ms": m["region_ms"],
+            "host_enqueue_ms_per_step": m["host_enqueue_ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{CONFIGS[args.config]['name']}; batch={args.batch}/GPU, {args.layers}x{args.hidden} hidden",
                        "name": args.config, "global_batch": world * args.batch, "replay_capacity_per_gpu": args.capacity,
-                       "parallelism": f"dp{world}", "final_loss": loss_val, "launch": graph_note or "eager launches"},
+                       "parallelism": f"dp{world}", "final_loss": m["final_loss"], "launch": m["launch"]},
         }
-        res.update(extra)
-        if parity is not None:
-            res["parity"] = parity
+        if world > 1:
+            res["per_rank"] = m["per_rank"]
+        res.update(m["extra"])
+        if m["parity"] is not None:
+            res["parity"] = m["parity"]
+    # ---- the same K-step region in the mode that meets north_star's floating-point tolerance (Q within 1e-4 of the fp32
+    # reference, dqn_trainer.py:204-238): split-bf16 operands on the bf16 MFMA pipe.  Same shard, same initial weights.
+    if args.precision == "bf16" and not args.no_accurate:
+        a2 = argparse.Namespace(**vars(args))
+        a2.precision = "bf16x3"
+        a2.repeats = max(1, min(args.repeats, 3))
+        ma = measure(a2, device, rank, world, dist, cols=m["cols"], profile_steps=min(args.steps, 6))
+        if rank == 0:
+            res["accurate"] = {"dtype": "bf16x3", "value": ma["value"], "unit": "transitions/s", "ms_per_step": ma["ms_per_step"],
+                               "steps": args.steps, "timing": ma["timing"], "region_ms": ma["region_ms"], "launch": ma["launch"],
+                               "note": "same workload, shard, initial weights and K-step region as `value`, every FC operand "
+                                       "split hi + lo (three bf16 MFMAs per product, fp32 accumulate): the mode held to "
+                                       "north_star's 1e-4",
+                               **{k: ma["extra"][k] for k in ("roofline", "fc_roofline") if k in ma["extra"]},
+                               "parity": ma["parity"]}
+        del ma
+    # ---- the other single-GPU BASELINE configurations, a few regions each, so they are driver-timed numbers too
+    if args.config == "c2" and world == 1 and not args.no_also:
+        also = {}
+        for cfg in ("c3", "c4"):
+            a3 = argparse.Namespace(**vars(args))
+            a3.config, a3.repeats = cfg, 2
+            c = CONFIGS[cfg]
+            a3.state_dim, a3.actions, a3.algo, a3.atoms = c["state_dim"], c["actions"], c["algo"], c["atoms"]
+            a3.no_parity = False
+            try:
+                mo = measure(a3, device, rank, world, dist, cols=m["cols"] if cfg == "c3" else None,
+                             profile_steps=min(args.steps, 4))
+                also[cfg] = {"workload": c["name"], "dtype": a3.precision, "value": mo["value"], "unit": "transitions/s",
+                             "ms_per_step": mo["ms_per_step"], "steps": args.steps, "region_ms": mo["region_ms"],
+                             "launch": mo["launch"],
+                             **{k: mo["extra"][k] for k in ("roofline", "fc_roofline") if k in mo["extra"]},
+                             "parity": mo["parity"]}
+                del mo
+            except Exception as e:  # never fatal to the headline measurement
+                also[cfg] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+        res["also_measured"] = also
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(args, init, cols, norm)
+                res["cpu_baseline"] = cpu_baseline(args, m["init"], m["cols_cpu"], m["norm"])
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))

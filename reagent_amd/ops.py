@@ -82,6 +82,24 @@ def _run(name: str, meta: dict, call):
     _prof.records.append((name, meta, s, e))
 
 
+def profiling() -> bool:
+    return _prof is not None
+
+
+@contextlib.contextmanager
+def profile_span(name: str, meta: dict):
+    """events around a region that is not one C-ABI call (the RCCL all-reduce of the gradient slab); no-op unless
+    a profile() pass is active"""
+    if _prof is None:
+        yield
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    yield
+    e.record()
+    _prof.records.append((name, meta, s, e))
+
+
 # ---- FullyConnected ---------------------------------------------------------------------------
 def fc_forward(x, w, bias, act: int, precision: int, y=None, y32=None, yt=None):
     """y = act(x @ w.T + bias); any of y (compute type), y32 (fp32), yt (transposed) may be given."""

@@ -417,7 +417,12 @@ class QStepCore(DQNTrainerBaseLightning):
         held = held_gradients(self._slab, self._hip_params)
         self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
         if self._dp_group is not None:
-            if async_reduce:  # runs on the collective's own stream; joined by apply_pending_update()
+            if async_reduce and ops.profiling():
+                # instrumented pass (bench.py): the collective joined at once, between two events on the compute stream
+                # (it runs on RCCL's stream; the compute stream waits for it), so its duration is visible per rank
+                with ops.profile_span("all_reduce", dict(bytes=self._slab.grad.numel() * 4, world=self._dp_world)):
+                    dp_reduce(self, self._slab)
+            elif async_reduce:  # runs on the collective's own stream; joined by apply_pending_update()
                 self._pending_reduce = torch.distributed.all_reduce(self._slab.grad, group=self._dp_group,
                                                                    async_op=True)
             else:
