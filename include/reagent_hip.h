@@ -252,6 +252,8 @@ typedef struct {
   void* wfrag_fwd[RG_MLP_MAX_LAYERS];
   void* wfrag_bwd[RG_MLP_MAX_LAYERS];
   void* target_wfrag_fwd[RG_MLP_MAX_LAYERS];
+  int32_t x3;  /* ABI 6: split-bf16 stacks — every fragment buffer is [hi plane | lo plane] (rg_mlp_desc.x3), both
+                * planes of all three fragment sets are re-staged: lo = bf16(w - hi) as rg_mlp_stage_weights_fused */
 } rg_mlp_update_desc; /* host struct */
 int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
                         double weight_decay, double bias_correction1, double bias_correction2_sqrt,

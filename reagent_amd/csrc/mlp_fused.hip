@@ -714,7 +714,33 @@ struct UpdateArgs {
   AdamCoef c;
   float tau, one_minus_tau;
   const double* sched;  // device-resident Adam schedule (rg_optim.h) or null: coefficients as launch arguments
+  // split-bf16 stacks: every fragment buffer is [hi plane | lo plane], lo = bf16(x - hi) (stage_weight_elem); the lo
+  // plane of layer l starts wfrag_elems(N, K) (forward, target) / wfrag_elems(K, N) (backward) elements in
+  int x3;
 };
+
+// the three fragment slots of W[n][k] (online forward / backward, target forward), both planes in split-bf16 mode —
+// element for element what stage_weight_elem writes
+__device__ __forceinline__ void update_store_frags(const UpdateArgs& U, int l, int n, int k, float pn, float tn) {
+  const int N = U.N[l], K = U.K[l];
+  const int KCf = (K + 15) / 16, KCb = (N + 15) / 16;
+  const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+  const long tf = (long)((N + 31) / 32) * KCf * 512, tb = (long)((K + 31) / 32) * KCb * 512;
+  const bf16_t ph = f32_to_bf16(pn), th = f32_to_bf16(tn);
+  if (U.wf[l]) {
+    U.wf[l][jf] = ph;
+    if (U.x3) U.wf[l][tf + jf] = f32_to_bf16(pn - bf16_to_f32(ph));
+  }
+  if (U.twf[l]) {
+    U.twf[l][jf] = th;
+    if (U.x3) U.twf[l][tf + jf] = f32_to_bf16(tn - bf16_to_f32(th));
+  }
+  if (U.wb[l]) {
+    const long jb = ((((long)(k >> 5) * KCb + (n >> 4)) * 64) + ((k & 31) + 32 * ((n & 15) >> 3))) * 8 + (n & 7);
+    U.wb[l][jb] = ph;
+    if (U.x3) U.wb[l][tb + jb] = f32_to_bf16(pn - bf16_to_f32(ph));
+  }
+}
 
 __global__ void mlp_update_kernel(UpdateArgs U) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -743,18 +769,10 @@ __global__ void mlp_update_kernel(UpdateArgs U) {
     U.t[i] = tn;
   }
   if (!is_w) return;
-  const int N = U.N[l], K = U.K[l];
-  const int n = (int)(rel / K), k = (int)(rel % K);
-  const int KCf = (K + 15) / 16, KCb = (N + 15) / 16;
+  const int K = U.K[l];
   // B-fragment slot of W[n][k] (forward) and of W^T[k][n] (backward); padding slots were zeroed by
   // the first staging and are never touched
-  const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
-  if (U.wf[l]) U.wf[l][jf] = f32_to_bf16(pn);
-  if (U.twf[l]) U.twf[l][jf] = f32_to_bf16(tn);
-  if (U.wb[l]) {
-    const long jb = ((((long)(k >> 5) * KCb + (n >> 4)) * 64) + ((k & 31) + 32 * ((n & 15) >> 3))) * 8 + (n & 7);
-    U.wb[l][jb] = f32_to_bf16(pn);
-  }
+  update_store_frags(U, l, (int)(rel / K), (int)(rel % K), pn, tn);
 }
 
 // Tiled form of the update for weight matrices whose rows can be read in 32-byte pieces (in_features a
@@ -791,6 +809,7 @@ __device__ __forceinline__ void update_one(const UpdateArgs& U, const AdamCoef& 
 __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
   const UpdateArgs& U = T.u;
   __shared__ bf16_t tile[UT_ROWS * UT_PITCH];
+  __shared__ bf16_t tile_lo[UT_ROWS * UT_PITCH];  // split-bf16: lo plane of the tile
   const int wg = blockIdx.x, tid = threadIdx.x;
   const AdamCoef coef = sched_coef(U.c, U.sched);
   if (wg >= T.tile_begin[U.n]) {
@@ -805,16 +824,8 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
     float pn, tn;
     update_one(U, coef, (is_w ? U.w_off[l] : U.b_off[l]) + rel, pn, tn);
     if (!is_w) return;
-    const int N = U.N[l], K = U.K[l];
-    const int n = (int)(rel / K), k = (int)(rel % K);
-    const int KCf = (K + 15) / 16, KCb = (N + 15) / 16;
-    const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
-    if (U.wf[l]) U.wf[l][jf] = f32_to_bf16(pn);
-    if (U.twf[l]) U.twf[l][jf] = f32_to_bf16(tn);
-    if (U.wb[l]) {
-      const long jb = ((((long)(k >> 5) * KCb + (n >> 4)) * 64) + ((k & 31) + 32 * ((n & 15) >> 3))) * 8 + (n & 7);
-      U.wb[l][jb] = f32_to_bf16(pn);
-    }
+    const int K = U.K[l];
+    update_store_frags(U, l, (int)(rel / K), (int)(rel % K), pn, tn);
     return;
   }
   int l = 0;
@@ -827,7 +838,7 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
   const int r = tid >> 3, c = (tid & 7) * 4;  // row of the tile, first of this thread's 4 in-features
   const int n = n0 + r, k = k0 + c;
   const bool live = n < N && k < K;  // K % 8 == 0: a piece is entirely inside or outside
-  float pn[4], tn[4];
+  float pn[4], tn[4], pl[4] = {0.f, 0.f, 0.f, 0.f}, tl[4] = {0.f, 0.f, 0.f, 0.f};
   if (live) {
     const long i = U.w_off[l] + (long)n * K + k;
     f32x4 P = *(const f32x4*)(U.p + i), G = *(const f32x4*)(U.g + i), M = *(const f32x4*)(U.m + i);
@@ -851,12 +862,25 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
     if (U.t) *(f32x4*)(U.t + i) = Tg;
     const int KCf = (K + 15) / 16;
     const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+    const long tf = (long)((N + 31) / 32) * KCf * 512;  // lo plane of the forward fragments (split-bf16)
     if (U.wf[l]) *(uint2*)(U.wf[l] + jf) = uint2{pack_bf16x2(pn[0], pn[1]), pack_bf16x2(pn[2], pn[3])};
     if (U.twf[l]) *(uint2*)(U.twf[l] + jf) = uint2{pack_bf16x2(tn[0], tn[1]), pack_bf16x2(tn[2], tn[3])};
+    if (U.x3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pl[e] = pn[e] - bf16_to_f32(f32_to_bf16(pn[e]));
+        tl[e] = tn[e] - bf16_to_f32(f32_to_bf16(tn[e]));
+      }
+      if (U.wf[l]) *(uint2*)(U.wf[l] + tf + jf) = uint2{pack_bf16x2(pl[0], pl[1]), pack_bf16x2(pl[2], pl[3])};
+      if (U.twf[l]) *(uint2*)(U.twf[l] + tf + jf) = uint2{pack_bf16x2(tl[0], tl[1]), pack_bf16x2(tl[2], tl[3])};
+    }
   }
   if (!U.wb[l]) return;  // workgroup-uniform
 #pragma unroll
-  for (int e = 0; e < 4; ++e) tile[r * UT_PITCH + c + e] = live ? f32_to_bf16(pn[e]) : (bf16_t)0;
+  for (int e = 0; e < 4; ++e) {
+    tile[r * UT_PITCH + c + e] = live ? f32_to_bf16(pn[e]) : (bf16_t)0;
+    if (U.x3) tile_lo[r * UT_PITCH + c + e] = live ? f32_to_bf16(pl[e]) : (bf16_t)0;
+  }
   __syncthreads();
   // W^T fragments: thread -> (in-feature kk, group of 8 out-features); a record = 8 consecutive n
   const int kk = tid & 31, ng = tid >> 5;
@@ -869,6 +893,13 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
     const long jb = ((((long)(kt >> 5) * KCb + (nt >> 4)) * 64) + ((kt & 31) + 32 * ((nt & 15) >> 3))) * 8;
     *(u32x4*)(U.wb[l] + jb) = u32x4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
                                     (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+    if (U.x3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (nt + e < N) ? tile_lo[(ng * 8 + e) * UT_PITCH + kk] : (bf16_t)0;
+      const long tb = (long)((K + 31) / 32) * KCb * 512;
+      *(u32x4*)(U.wb[l] + tb + jb) = u32x4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+                                           (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+    }
   }
 }
 
@@ -1227,6 +1258,7 @@ static int mlp_update_launch(const rg_mlp_update_desc* d, double lr, double beta
                  (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale};
   U.tau = (float)tau; U.one_minus_tau = (float)(1.0 - tau);
   U.sched = sched;
+  U.x3 = d->x3 ? 1 : 0;
   // weights with 32-byte-addressable rows go to the tiled kernel, the rest of the slab to its
   // per-element workgroups (same launch)
   UpdateTileArgs T;

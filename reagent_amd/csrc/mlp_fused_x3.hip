@@ -345,6 +345,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   const int row_base = blockIdx.x * X3_BM;
   constexpr int pitch = PITCH;
   const int k0p = round_up(a.dims[0], 32);
+  RG_STAMP(0);
   if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
     const int n2 = a.dims[0] - a.x_split;
     if (a.x_is_f32)
@@ -360,6 +361,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   else
     load_tile_split<bf16_t, THREADS, LO>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   __syncthreads();
+  RG_STAMP(1);
   if (a.save == 1 && a.act_frag[0]) {
     emit_frags_x3(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * X3_TM, wave, NW, lane);
     emit_frags_x3(act + LO, pitch, k0p / 32, a.act_frag[0] + a.act_lo[0], blockIdx.x * X3_TM, wave, NW, lane);
@@ -379,15 +381,19 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
       const long nt_stride = (long)KC * 512;
       x3_mainloop<TN, RING, LO>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, a.wfrag_lo[l], nt_stride, acc,
                                 lane, k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+      RG_STAMP(2 + 4 * l);
       unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;
       RG_DISPATCH_ACT(a.acts[l], (x3_fwd_pack<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l),
                                                       a.act_lo[l + 1], sign_dst, N / 32, blockIdx.x * X3_TM, wave, lane, PH,
                                                       PL)));
+      RG_STAMP(3 + 4 * l);
       __syncthreads();  // every wave is done reading the layer input
+      RG_STAMP(4 + 4 * l);
       x3_store_packed_tiles<TN>(act, pitch, PH, wave, lane);
       x3_store_packed_tiles<TN>(act + LO, pitch, PL, wave, lane);
       __syncthreads();
+      RG_STAMP(5 + 4 * l);
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
       const int out_act = a.acts[l];
@@ -433,6 +439,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
           }
         }
       }
+      RG_STAMP(2 + 4 * l);
     }
   }
 }

@@ -616,11 +616,11 @@ class FusedUpdate:
 
     @classmethod
     def make(cls, adam, params, lin, stack, target_params=None, target_stack=None, tau=None):
-        ok = (isinstance(stack, FusedMLP) and not stack.x3 and len(adam.param_groups) == 1
+        ok = (isinstance(stack, FusedMLP) and len(adam.param_groups) == 1
               and len(adam.param_groups[0]["params"]) == len(params)
               and all(a is b for a, b in zip(adam.param_groups[0]["params"], params)))
         if ok and target_params is not None:
-            ok = (isinstance(target_stack, FusedMLP) and not target_stack.x3 and len(target_params) == len(params)
+            ok = (isinstance(target_stack, FusedMLP) and target_stack.x3 == stack.x3 and len(target_params) == len(params)
                   and all(t is not s for t, s in zip(target_params, params)))
         if not ok:
             return None
@@ -634,6 +634,7 @@ class FusedUpdate:
         index = {id(p): i for i, p in enumerate(params)}
         d = L.MlpUpdateDesc()
         d.n_layers = len(lin)
+        d.x3 = int(stack.x3)  # split-bf16: both planes of every fragment set are re-staged
         for i, v in enumerate(stack.dims):
             d.dims[i] = v
         for l, layer in enumerate(lin):

@@ -524,7 +524,7 @@ class QStepCore(DQNTrainerBaseLightning):
         qs, ts = self._qs, self._ts
         plan = self._fused_plan
         if plan is None:
-            ok = (isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and not qs.x3 and not ts.x3
+            ok = (isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and qs.x3 == ts.x3
                   and len(adam.param_groups) == 1
                   and len(soft.param_groups) == 1)
             if ok:
@@ -544,6 +544,7 @@ class QStepCore(DQNTrainerBaseLightning):
                 lin = self.q_network.fc.linears()
                 d = L.MlpUpdateDesc()
                 d.n_layers = len(lin)
+                d.x3 = int(qs.x3)  # split-bf16: both planes of every fragment set are re-staged
                 for i, v in enumerate(qs.dims):
                     d.dims[i] = v
                 for l, layer in enumerate(lin):

@@ -207,8 +207,9 @@ def test_dqn_cpe_native_step(backend, name):
         _check_cpe_step(tr, g, s, [loss.item(), tr._cpe.losses["reward"].item(), tr._cpe.losses["cpe"].item()])
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])  # bf16x3: both planes (hi, lo) of every fragment set
 @pytest.mark.parametrize("state_dim", [24, 22])  # 22: the first layer's rows are not 32-byte pieces -> per-element path
-def test_fused_update_equals_separate_launches(backend, state_dim):
+def test_fused_update_equals_separate_launches(backend, state_dim, precision):
     """rg_mlp_update_fused (Adam + soft update + bf16 re-staging of both networks in one launch, taken by
     the native step when both stacks are on the fused kernels) leaves the same bits as the four separate
     launches: parameters, target parameters, Adam moments, and the next step's Q-values (= the staged
@@ -216,7 +217,7 @@ def test_fused_update_equals_separate_launches(backend, state_dim):
     from reagent_amd.engine import FusedMLP
 
     def make():
-        set_default_precision(L.PREC_BF16)
+        set_default_precision(L.PREC_BF16 if precision == "bf16" else L.PREC_BF16X3)
         try:
             torch.manual_seed(3)
             q = FullyConnectedDQN(state_dim, 5, [256, 256], ["relu", "relu"]).to(backend.device)
@@ -235,6 +236,7 @@ def test_fused_update_equals_separate_launches(backend, state_dim):
         assert torch.equal(la, lb), s
         assert torch.equal(fused.all_action_scores, separate.all_action_scores), s
     assert isinstance(fused._qs, FusedMLP) and isinstance(fused._fused_plan, dict)  # the fused path really ran
+    assert fused._qs.x3 == (precision == "bf16x3")
     for a, b in zip(fused.q_network.parameters(), separate.q_network.parameters()):
         assert torch.equal(a, b)
     for a, b in zip(fused.q_network_target.parameters(), separate.q_network_target.parameters()):
@@ -247,6 +249,9 @@ def test_fused_update_equals_separate_launches(backend, state_dim):
     x = batch.state
     assert torch.equal(fused.q_network(x), separate.q_network(x))
     assert torch.equal(fused.q_network_target(x), separate.q_network_target(x))
+    separate._qs.stage_weights(need_transposed=True)  # (the separate path stages lazily, before the next use)
+    for a, b in zip(fused._qs._wf + fused._qs._wb + fused._ts._wf, separate._qs._wf + separate._qs._wb + separate._ts._wf):
+        assert torch.equal(a, b)  # the staged fragments themselves, every plane
 
 
 def test_dqn_bcq_matches_reference(backend):
