@@ -331,8 +331,8 @@ def parity_check(args, device, init, cols, norm):
             # quantile level: the network's [B, A, N] output before the step against the oracle's on the same rows
             # (a bounded slice: the dense logits of 4096 rows are 52 MB), and the per-action means the a* selection uses
             rows = min(B, 512)
-            z = trainer.q_network(batch.state)[:rows].cpu()
             with torch.no_grad():
+                z = trainer.q_network(batch.state)[:rows].cpu()
                 zr = o.net(o.params, b["state"][:rows])
             out["max_abs_dquantile"] = (z - zr).abs().max().item()
             out["max_abs_dq"] = (z.mean(dim=2) - zr.mean(dim=2)).abs().max().item()

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
   hipMalloc((void**)&x, (size_t)B * 128 * 4); hipMemset(x, 0x3c, (size_t)B * 128 * 4);
   hipMalloc((void**)&out, (size_t)B * 16 * 4);
   a.x = x; a.ldx = 128; a.x_is_f32 = 1; a.out32 = out; a.ldo = 16; a.pitch = 520; a.save = save;
-  const int n_wg = B / 128, NPH = 16, NWV = FB_NW;
+  const int n_wg = argc > 2 ? atoi(argv[2]) : B / 128, NPH = 16, NWV = FB_NW;  // argv[2]: fewer workgroups (clock / power experiments)
   unsigned long long* stamps;
   hipMalloc((void**)&stamps, (size_t)n_wg * NWV * NPH * 8);
   hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps));
@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
       span += (double)(s[14] - s[0]);
     }
   const double nw = (double)n_wg * NWV;
+  printf("workgroups %d, shader clock %.3f GHz (ticks of one round / launch time)\n", n_wg, (span / nw) * ((n_wg + 255) / 256) / (ms * 1e6 / 20));
   printf("avg s_memtime ticks per wave: %.0f\n", span / nw);
   for (int p = 1; p <= 14; ++p) printf("  %-22s %9.0f ticks  %5.1f %%\n", names[p], tot[p] / nw, 100.0 * tot[p] / span);
   // per wave slot: duration of the L1 main loop (stamps 5 -> 6) and of its wait at the barrier (6 -> 7)

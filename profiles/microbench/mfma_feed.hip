@@ -22,6 +22,7 @@ __device__ __forceinline__ void mfma_acc(u16x8 a, u16x8 b, f32x16& c) {
 }
 
 constexpr int PITCH = 520, KC = 32;
+__device__ unsigned long long g_clock[2];  // s_memtime of wave 0 / workgroup 0 at kernel start and end (shader-clock ticks)
 
 // MODE bit 0: A fragments from LDS each chunk; bit 1: B fragments from global each chunk; bit 2: rotate K per (wg, wave)
 template <int MODE, int NWAVES, int TM, int TN, int RING>
@@ -29,6 +30,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) feed(const unsigned short* __r
   extern __shared__ char smem[];
   unsigned short* act = (unsigned short*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (blockIdx.x == 0 && tid == 0) g_clock[0] = __builtin_amdgcn_s_memtime();
   for (int i = tid; i < TM * 32 * PITCH; i += NWAVES * 64) act[i] = (unsigned short)(0x3c00 + ((i * 2654435761u) >> 20));
   __syncthreads();
   const int lr = lane & 31, lg = lane >> 5;
@@ -101,6 +103,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) feed(const unsigned short* __r
     for (int j = 0; j < TN; ++j)
       for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   if (s == 12345.678f) out[0] = s;
+  if (blockIdx.x == 0 && tid == 0) g_clock[1] = __builtin_amdgcn_s_memtime();
 }
 
 template <int MODE, int NWAVES, int TM, int TN, int RING = 4>
@@ -113,17 +116,26 @@ void run(const char* what, const unsigned short* wf, float* out, int grid, int l
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   k<<<grid, NWAVES * 64, lds>>>(wf, out, layers);
   hipDeviceSynchronize();
+  // SUSTAINED rate: the clock governor reacts within milliseconds (a first launch after idle runs ~15 % faster than the
+  // steady state), so every variant runs for >= 60 ms before the timed launches
+  for (int r = 0; r < 200; ++r) k<<<grid, NWAVES * 64, lds>>>(wf, out, layers);
   hipEventRecord(e0);
-  const int reps = 10;
+  const int reps = 40;
   for (int r = 0; r < reps; ++r) k<<<grid, NWAVES * 64, lds>>>(wf, out, layers);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / reps;
+  unsigned long long clk[2];
+  hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clock), sizeof(clk));
+  const int rounds = (grid + 255) / 256;  // one workgroup per CU at a time (LDS)
+  const double ghz = (double)(clk[1] - clk[0]) * rounds / (us * 1e3);
+  const double mfma_cycles = (double)(NWAVES / 4) * layers * KC * TM * TN * 32.0;  // per SIMD, one workgroup
   const double flop = (double)grid * NWAVES * layers * KC * TM * TN * 32768.0;
-  printf("%-58s ring %d waves %d tile %dx%d grid %4d: %8.1f us  %7.1f TFLOP/s  (%.3f of 2500)\n", what, RING, NWAVES, TM, TN, grid, us,
-         flop / us * 1e-6, flop / us * 1e-6 / 2500.0);
+  printf("%-58s ring %d waves %d tile %dx%d grid %4d: %8.1f us  %7.1f TFLOP/s  (%.3f of 2500)  s_memtime ticks per ns %.2f, 32-cycle MFMA slots per tick %.2f\n",
+         what, RING, NWAVES, TM, TN, grid, us, flop / us * 1e-6, flop / us * 1e-6 / 2500.0, ghz,
+         mfma_cycles / (double)(clk[1] - clk[0]));
 }
 
 int main() {

@@ -11,6 +11,7 @@ from .. import _lib as L
 from .. import ops
 from ..core import types as rlt
 from .base import ModelBase
+from .fully_connected_network import no_autograd_guard
 from .fully_connected_network import FullyConnectedNetwork
 
 LOG_PROB_MIN: float = -2.0
@@ -87,23 +88,27 @@ class GaussianFullyConnectedActor(ModelBase):
             return n.to(device=device, dtype=torch.float32).contiguous()
         return torch.randn(batch, self.action_dim, device=device)
 
-    @torch.no_grad()
     def forward(self, state):
-        loc_scale = self._fc_out(state, evaluations=2)
-        B, dev = loc_scale.shape[0], loc_scale.device
-        action = torch.empty(B, self.action_dim, device=dev)
-        log_prob = torch.empty(B, 1, device=dev)
-        squashed_mean = torch.empty(B, self.action_dim, device=dev)
-        ops.gaussian_head_forward(loc_scale, self._noise(B, dev), action, log_prob, squashed_mean)
-        return rlt.ActorOutput(action=action, log_prob=log_prob, squashed_mean=squashed_mean)
+        """actor.py:215-231.  The sampling head is a HIP kernel outside autograd: under grad mode the outputs carry a
+        node whose backward raises (no silent zero gradient); SACTrainer's step produces the actor's gradients."""
+        with torch.no_grad():
+            loc_scale = self._fc_out(state, evaluations=2)
+            B, dev = loc_scale.shape[0], loc_scale.device
+            action = torch.empty(B, self.action_dim, device=dev)
+            log_prob = torch.empty(B, 1, device=dev)
+            squashed_mean = torch.empty(B, self.action_dim, device=dev)
+            ops.gaussian_head_forward(loc_scale, self._noise(B, dev), action, log_prob, squashed_mean)
+        what = "GaussianFullyConnectedActor.forward"
+        return rlt.ActorOutput(action=no_autograd_guard(action, self, what), log_prob=no_autograd_guard(log_prob, self, what),
+                               squashed_mean=no_autograd_guard(squashed_mean, self, what))
 
-    @torch.no_grad()
     def get_log_prob(self, state, squashed_action: torch.Tensor):
-        loc_scale = self._fc_out(state)
-        log_prob = torch.empty(loc_scale.shape[0], 1, device=loc_scale.device)
-        a = squashed_action if squashed_action.stride(-1) == 1 else squashed_action.contiguous()
-        ops.gaussian_log_prob(loc_scale, a.float(), log_prob)
-        return log_prob
+        with torch.no_grad():
+            loc_scale = self._fc_out(state)
+            log_prob = torch.empty(loc_scale.shape[0], 1, device=loc_scale.device)
+            a = squashed_action if squashed_action.stride(-1) == 1 else squashed_action.contiguous()
+            ops.gaussian_log_prob(loc_scale, a.float(), log_prob)
+        return no_autograd_guard(log_prob, self, "GaussianFullyConnectedActor.get_log_prob")
 
 
 class FullyConnectedActor(ModelBase):
@@ -132,8 +137,8 @@ class FullyConnectedActor(ModelBase):
     def input_prototype(self):
         return rlt.FeatureData(torch.randn(1, self.state_dim))
 
-    @torch.no_grad()
     def forward(self, state) -> rlt.ActorOutput:
+        """actor.py:86-97 (differentiable through the FC stack like the reference module)"""
         action = self.fc(state.float_features)
         batch_size = action.shape[0]
         assert action.shape == (batch_size, self.action_dim), f"{action.shape} != ({batch_size}, {self.action_dim})"

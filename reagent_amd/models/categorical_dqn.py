@@ -23,11 +23,9 @@ class CategoricalDQN(ModelBase):
     def input_prototype(self):
         return self.distributional_network.input_prototype()
 
-    @torch.no_grad()
     def forward(self, state: rlt.FeatureData):
         dist = self.log_dist(state).exp()
         return (dist * self.support.to(dist.device)).sum(2)
 
-    @torch.no_grad()
     def log_dist(self, state: rlt.FeatureData) -> torch.Tensor:
         return F.log_softmax(self.distributional_network(state), -1)

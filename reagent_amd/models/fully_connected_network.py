@@ -199,8 +199,21 @@ class FullyConnectedNetwork(ModelBase):
     def input_prototype(self):
         return torch.randn(1, self.input_dim)
 
-    @torch.no_grad()
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        """fully_connected_network.py:157-163.  Under autograd (grad mode on and the input or a parameter requires grad) a
+        Linear -> activation stack records ONE autograd node whose backward is the HIP backward of the stack
+        (`q_network(state).sum().backward()` fills `.grad` like the reference nn.Module, models/dqn.py:52-63); stacks
+        with norm / dropout / residual layers return a tensor whose backward raises instead of silently yielding no
+        gradient (their training path is the trainers' fused step)."""
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.is_plain():
+                lin = self.linears()
+                return _StackFunction.apply(self, input, *[p for l in lin for p in (l.weight, l.bias)])
+            return no_autograd_guard(self._forward_no_grad(input), self, "a FullyConnectedNetwork with norm / dropout / residual layers")
+        return self._forward_no_grad(input)
+
+    @torch.no_grad()
+    def _forward_no_grad(self, input: torch.Tensor) -> torch.Tensor:
         L.require_cuda(input, "input")
         st = self.stack()
         st.stage_weights(need_transposed=False)
@@ -209,6 +222,79 @@ class FullyConnectedNetwork(ModelBase):
         out = torch.empty(input.shape[0], st.dims[-1], dtype=torch.float32, device=input.device)
         st.forward(xc, out, save=False)
         return out
+
+    _autograd_serial = 0
+
+
+class _StackFunction(torch.autograd.Function):
+    """One autograd node for a plain stack: forward = the saving HIP forward, backward = the stack's HIP backward (input
+    gradient, weight and bias gradients).  The stack keeps ONE set of saved activations, so a backward must follow its
+    own forward before the same network runs another recorded forward (checked: a stale node raises)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        L.require_cuda(x, "input")
+        st = net.stack()
+        need_dx = bool(x.requires_grad)
+        st.set_need_input_grad(need_dx or getattr(st, "_need_dx", False))
+        st.stage_weights(need_transposed=True)
+        x32 = x.detach() if x.dtype == torch.float32 else x.detach().float()
+        xc, xt = st.stage_input(x32.contiguous() if x32.stride(-1) != 1 else x32, need_transposed=True)
+        out = torch.empty(x.shape[0], st.dims[-1], dtype=torch.float32, device=x.device)
+        st.forward(xc, out, save=True)
+        net._autograd_serial += 1
+        ctx.net, ctx.xt, ctx.need_dx, ctx.serial, ctx.in_dtype = net, xt, need_dx, net._autograd_serial, x.dtype
+        ctx.needs = [p.requires_grad for p in params]
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        net = ctx.net
+        if net._autograd_serial != ctx.serial:
+            raise RuntimeError("reagent_amd: this network ran another recorded forward before this backward — the stack "
+                               "keeps one set of saved activations (call backward first, or run the other forward under "
+                               "torch.no_grad())")
+        (out,) = ctx.saved_tensors
+        st = net.stack()
+        lin = net.linears()
+        dw = [torch.empty_like(l.weight) for l in lin]
+        db = [torch.empty_like(l.bias) for l in lin]
+        B = grad_out.shape[0]
+        dx = torch.empty(B, st.dims[0], dtype=torch.float32, device=grad_out.device) if ctx.need_dx else None
+        g = grad_out.detach()
+        g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        with torch.no_grad():
+            st.backward(g.clone(), ctx.xt, dw, db, dx32=dx, out32=out)
+        grads = [t for pair in zip(dw, db) for t in pair]
+        grads = [t if need else None for t, need in zip(grads, ctx.needs)]
+        if dx is not None and ctx.in_dtype != torch.float32:
+            dx = dx.to(ctx.in_dtype)
+        return (None, dx) + tuple(grads)
+
+
+class _NoAutograd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, what, *params):
+        ctx.what = what
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise NotImplementedError(f"reagent_amd: {ctx.what} was evaluated by HIP kernels outside autograd; gradients of this "
+                                  "output are produced by the trainers' steps (train_step_gen / train_step_native), not by "
+                                  "tensor.backward()")
+
+
+def no_autograd_guard(out: torch.Tensor, module: nn.Module, what: str) -> torch.Tensor:
+    """`out` was computed without an autograd graph: under grad mode hand back a tensor whose backward RAISES, so that a
+    caller differentiating through it does not silently get no gradient (intentional deviations)"""
+    if not torch.is_grad_enabled():
+        return out
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return out
+    return _NoAutograd.apply(out, what, *params)
 
 
 class FloatFeatureFullyConnected(ModelBase):

@@ -22,13 +22,13 @@ def _build(kind):
     from reagent_amd.training import DQNTrainer, SACTrainer
 
     torch.manual_seed(0)  # identical initial weights on every rank
-    if kind in ("dqn_fused", "sac_fused"):  # bf16 engine on the fused kernels: the one-launch updates under 1/world scaling
+    if kind in ("dqn_fused", "sac_fused", "dqn_x3"):  # fused kernels (bf16 / split-bf16): the one-launch updates under 1/world scaling
         import reagent_amd._lib as L
         from reagent_amd.models import set_default_precision
 
-        set_default_precision(L.PREC_BF16)
+        set_default_precision(L.PREC_BF16X3 if kind == "dqn_x3" else L.PREC_BF16)
         try:
-            if kind == "dqn_fused":
+            if kind in ("dqn_fused", "dqn_x3"):
                 q = FullyConnectedDQN(12, 4, [256, 256], ["relu", "relu"])
                 return DQNTrainer(q, q.get_target_network(), None, actions=["a", "b", "c", "d"],
                                   rl=RLParameters(gamma=0.9, target_update_rate=0.1, q_network_loss="huber"),
@@ -103,7 +103,7 @@ def _step(kind, tr, d, noise=None):
         lightning_like_step(tr, tr._test_opts, synthetic.to_dqn_input(d))
     elif kind == "dqn_deferred":  # async all-reduce, Adam joined at the start of the next step
         tr.train_step_native(synthetic.to_dqn_input(d), defer_update=True)
-    elif kind in ("dqn", "crr", "dqn_fused"):
+    elif kind in ("dqn", "crr", "dqn_fused", "dqn_x3"):
         tr.train_step_native(synthetic.to_dqn_input(d))
     elif kind == "td3":
         tr.train_step_native(synthetic.to_policy_input(d), noise[0])
@@ -127,13 +127,14 @@ def _worker(rank, world, port, kind, out_dir):
     noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
     my_noise = tuple(n[rank * B // 2 : (rank + 1) * B // 2].contiguous() for n in noise)
     tr = _build(kind).enable_data_parallel()
-    for _ in range(3 if kind.endswith("_fused") else 2):  # (the one-launch update starts at the second step)
+    fused = kind in ("dqn_fused", "sac_fused", "dqn_x3")
+    for _ in range(3 if fused else 2):  # (the one-launch update starts at the second step)
         _step(kind, tr, half, my_noise)
-    if kind.endswith("_fused"):
+    if fused:
         from reagent_amd.engine import FusedMLP
 
-        st = tr._qs if kind == "dqn_fused" else tr._e["q1"]["stack"]
-        assert isinstance(st, FusedMLP) and tr._fused_plan not in (None, False)
+        st = tr._qs if kind.startswith("dqn") else tr._e["q1"]["stack"]
+        assert isinstance(st, FusedMLP) and tr._fused_plan not in (None, False) and st.x3 == (kind == "dqn_x3")
     if kind == "dqn_deferred":
         assert tr._update_pending  # the last update is still waiting for its all-reduce
         tr.apply_pending_update()
@@ -141,7 +142,7 @@ def _worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-def _loop_worker(rank, world, port, out_dir):
+def _loop_worker(rank, world, port, out_dir, kind="dqn"):
     """bench.py's data-parallel flow on two ranks: own replay shard per rank, OfflineDqnLoop.step (one-launch
     sampler, deferred update under the asynchronous all-reduce), flush, barrier, max-reduce of a timing"""
     sys.path.insert(0, ROOT)
@@ -159,7 +160,7 @@ def _loop_worker(rank, world, port, out_dir):
     from reagent_amd.runtime import OfflineDqnLoop
 
     S, A, C, B = 12, 4, 512, 64
-    tr = _build("dqn").enable_data_parallel()
+    tr = _build(kind).enable_data_parallel()
     cols = synthetic.replay_contents(C, S, A, seed=100 + rank)  # this rank's shard
     rb = ReplayBuffer(replay_capacity=C, batch_size=B, device="cpu")
     rb.load_columns(cols, mark_all_valid=True)
@@ -177,9 +178,12 @@ def _loop_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_offline_loop_two_ranks_stay_in_lockstep(tmp_path, emu_lib):
-    port = 29500 + (os.getpid() % 2000) + 7
-    mp.spawn(_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("kind", ["dqn", "dqn_fused", "dqn_x3"])
+def test_offline_loop_two_ranks_stay_in_lockstep(tmp_path, emu_lib, kind):
+    """the loop bench.py --gpus N runs (eager, asynchronous all-reduce, deferred one-launch update) on two ranks with
+    different shards and index draws, per-layer fp32 engine and both fused engines: replicas stay bit-identical"""
+    port = 29500 + (os.getpid() % 2000) + {"dqn": 7, "dqn_fused": 8, "dqn_x3": 9}[kind]
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path), kind), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     for a, b in zip(r0, r1):
         assert torch.equal(a, b) and torch.isfinite(a).all()
@@ -235,12 +239,12 @@ def test_rccl_async_reduce_single_rank_group():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["dqn_fused", "sac_fused"])
+@pytest.mark.parametrize("kind", ["dqn_fused", "sac_fused", "dqn_x3"])
 def test_two_ranks_on_the_fused_engine_stay_bit_identical(tmp_path, emu_lib, kind):
     """bf16 fused stacks under data parallelism: the one-launch Adam + soft update + re-staging (rg_mlp_update_fused,
     engine.FusedUpdate) with the 1/world factor folded in; replicas bit-identical, and close to the single-process
     run on the concatenated batch (bf16 gradients summed in another order: a few weights move by up to lr per step)"""
-    port = 29500 + (os.getpid() % 2000) + {"dqn_fused": 11, "sac_fused": 12}[kind]
+    port = 29500 + (os.getpid() % 2000) + {"dqn_fused": 11, "sac_fused": 12, "dqn_x3": 13}[kind]
     mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     for a, b in zip(r0, r1):

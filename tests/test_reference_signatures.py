@@ -1,0 +1,110 @@
+"""the Python surface is the reference's — constructor parameter NAMES, ORDER and DEFAULT VALUES of every
+class on the path equal the reference's own (`inspect.signature`), so a config / call site written for ReAgent binds
+the same way here.  Runs where the reference tree is present (the build container), in a subprocess so that
+`reagent` is importable through oracle/stubs.py.  Allowed additions: keyword parameters this package adds AFTER the
+reference's (listed in EXTRA below, e.g. `device=` of the replay buffers)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (reference class, this package's class, extra trailing keyword parameters allowed here)
+PAIRS = [
+    ("reagent.training.dqn_trainer.DQNTrainer", "reagent_amd.training.DQNTrainer", ()),                    # dqn_trainer.py:50-74
+    ("reagent.training.qrdqn_trainer.QRDQNTrainer", "reagent_amd.training.QRDQNTrainer", ()),              # qrdqn_trainer.py:28-52
+    ("reagent.training.sac_trainer.SACTrainer", "reagent_amd.training.SACTrainer", ()),                    # sac_trainer.py:57-88
+    ("reagent.training.td3_trainer.TD3Trainer", "reagent_amd.training.TD3Trainer", ()),
+    ("reagent.training.c51_trainer.C51Trainer", "reagent_amd.training.C51Trainer", ()),
+    ("reagent.training.discrete_crr_trainer.DiscreteCRRTrainer", "reagent_amd.training.DiscreteCRRTrainer", ()),
+    ("reagent.replay_memory.circular_replay_buffer.ReplayBuffer", "reagent_amd.replay_memory.ReplayBuffer", ("device",)),  # :323-332
+    ("reagent.replay_memory.prioritized_replay_buffer.PrioritizedReplayBuffer",
+     "reagent_amd.replay_memory.PrioritizedReplayBuffer", ("device",)),
+    ("reagent.preprocessing.preprocessor.Preprocessor", "reagent_amd.preprocessing.Preprocessor", ()),
+    ("reagent.models.dqn.FullyConnectedDQN", "reagent_amd.models.FullyConnectedDQN", ()),
+    ("reagent.models.critic.FullyConnectedCritic", "reagent_amd.models.FullyConnectedCritic", ()),
+    ("reagent.models.actor.GaussianFullyConnectedActor", "reagent_amd.models.GaussianFullyConnectedActor", ()),
+    ("reagent.models.actor.FullyConnectedActor", "reagent_amd.models.FullyConnectedActor", ()),
+    ("reagent.models.dueling_q_network.DuelingQNetwork", "reagent_amd.models.DuelingQNetwork", ()),
+    ("reagent.models.categorical_dqn.CategoricalDQN", "reagent_amd.models.CategoricalDQN", ()),
+    ("reagent.models.fully_connected_network.FullyConnectedNetwork", "reagent_amd.models.fully_connected_network.FullyConnectedNetwork", ()),
+    ("reagent.models.fully_connected_network.FloatFeatureFullyConnected",
+     "reagent_amd.models.fully_connected_network.FloatFeatureFullyConnected", ()),
+    ("reagent.optimizer.soft_update.SoftUpdate", "reagent_amd.optimizer.SoftUpdate", ()),
+    ("reagent.gym.preprocessors.trainer_preprocessor.DiscreteDqnInputMaker", "reagent_amd.preprocessing.DiscreteDqnInputMaker", ()),
+    ("reagent.gym.preprocessors.trainer_preprocessor.PolicyNetworkInputMaker", "reagent_amd.preprocessing.PolicyNetworkInputMaker", ()),
+]
+# methods whose parameter lists are part of the contract as well
+METHODS = [
+    ("reagent.replay_memory.circular_replay_buffer.ReplayBuffer", "reagent_amd.replay_memory.ReplayBuffer",
+     ("add", "sample_transition_batch", "sample_index_batch", "save", "load")),
+    ("reagent.training.dqn_trainer.DQNTrainer", "reagent_amd.training.DQNTrainer", ("train_step_gen", "configure_optimizers")),
+    ("reagent.training.sac_trainer.SACTrainer", "reagent_amd.training.SACTrainer", ("train_step_gen", "configure_optimizers")),
+    ("reagent.training.qrdqn_trainer.QRDQNTrainer", "reagent_amd.training.QRDQNTrainer", ("train_step_gen", "configure_optimizers")),
+    ("reagent.preprocessing.preprocessor.Preprocessor", "reagent_amd.preprocessing.Preprocessor", ("forward",)),
+]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/reagent"), reason="needs the reference tree (build container)")
+def test_constructor_and_method_signatures_equal_the_reference():
+    code = textwrap.dedent("""
+        import dataclasses, importlib, inspect, sys
+        sys.path.insert(0, %r)
+        from oracle import stubs
+        stubs.install()
+        stubs.install_gym()                   # the input makers live under reagent.gym (its envs need the uninstalled gym)
+        PAIRS, METHODS = %r, %r
+
+        def resolve(path):
+            mod, name = path.rsplit(".", 1)
+            return getattr(importlib.import_module(mod), name)
+
+        def default_of(p):
+            d = p.default
+            if isinstance(d, dataclasses.Field):            # resolve_defaults' field(default_factory=...): compare the factory
+                f = d.default_factory
+                return ("factory", getattr(f, "__qualname__", repr(f)).split(".")[-1])
+            if d is inspect.Parameter.empty:
+                return ("required",)
+            if dataclasses.is_dataclass(d) or callable(d):
+                return ("object", type(d).__name__ if not callable(d) else getattr(d, "__name__", repr(d)))
+            return ("value", repr(d))
+
+        def params(fn):
+            return [(n, p.kind.name, default_of(p)) for n, p in inspect.signature(fn).parameters.items() if n != "self"]
+
+        def same(ref, own):
+            # the reference writes mutable defaults as field(default_factory=F) under @resolve_defaults
+            # (reagent/core/configuration.py); here such a parameter defaults to None and the constructor calls the same F
+            if len(ref) != len(own):
+                return False
+            for (rn, rk, rd), (on, ok, od) in zip(ref, own):
+                if (rn, rk) != (on, ok):
+                    return False
+                # (SACTrainer.alpha_optimizer: None means "fixed temperature" in both, so the stand-in for the factory there
+                # is the sentinel "default")
+                if rd != od and not (rd[0] == "factory" and od in (("value", "None"), ("value", "'default'"))):
+                    return False
+            return True
+
+        bad = []
+        for ref_path, own_path, extra in PAIRS:
+            ref, own = params(resolve(ref_path).__init__), params(resolve(own_path).__init__)
+            tail = own[len(ref):]
+            if not same(ref, own[:len(ref)]) or [t[0] for t in tail] != list(extra) or any(t[2] == ("required",) for t in tail):
+                bad.append((own_path, "reference: %%r" %% (ref,), "here: %%r" %% (own,)))
+        for ref_path, own_path, names in METHODS:
+            for m in names:
+                ref, own = params(getattr(resolve(ref_path), m)), params(getattr(resolve(own_path), m))
+                if [(n, k) for n, k, _ in own[:len(ref)]] != [(n, k) for n, k, _ in ref] or any(t[2] == ("required",) for t in own[len(ref):]):
+                    bad.append((own_path + "." + m, "reference: %%r" %% (ref,), "here: %%r" %% (own,)))
+        for b in bad:
+            print("MISMATCH", *b, sep="\\n   ")
+        print("ok" if not bad else "failed")
+    """) % (ROOT, PAIRS, METHODS)
+    env = {k: v for k, v in os.environ.items() if k != "REAGENT_AMD_OWN_TYPES"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-6000:] + out.stderr[-3000:]
