@@ -663,7 +663,7 @@ def main():
         also = {}
         for cfg in ("c3", "c4"):
             a3 = argparse.Namespace(**vars(args))
-            a3.config, a3.repeats = cfg, 2
+            a3.config, a3.repeats = cfg, 3
             c = CONFIGS[cfg]
             a3.state_dim, a3.actions, a3.algo, a3.atoms = c["state_dim"], c["actions"], c["algo"], c["atoms"]
             a3.no_parity = False

@@ -192,6 +192,18 @@ typedef struct {
   int32_t n_groups;
   int32_t out_scatter;
   int64_t group_stride_fwd, group_stride_bwd;
+  /* ABI 6 — the step's launch-bound tails folded into the weight gradient's reduce launch.
+   * defer_db != 0: rg_mlp_backward_fused leaves the bias-gradient partials in its workspace and launches no column
+   *   reduce; rg_mlp_wgrad_fused, handed that workspace in db_partials, sums them into db[] in the launch that sums its
+   *   own split partials (same arithmetic, one launch instead of two).  Not with a grouped output layer.
+   * sum_in != NULL: that launch also writes sum_out[0] = sum_scale * sum(sum_in[0 .. sum_n)) — the mean loss of a step
+   *   from the loss head's per-workgroup partials (rg_reduce_sum's arithmetic). */
+  int32_t defer_db;
+  int32_t sum_n;
+  const float* db_partials;
+  const float* sum_in;
+  float* sum_out;
+  double sum_scale;
 } rg_mlp_desc; /* host struct */
 
 int rg_mlp_fused_supported(const rg_mlp_desc* d);

@@ -1,4 +1,2 @@
 cd /root/repo
-timeout 300 python profiles/microbench/mall_chunks.py bf16 2>&1 | tail -5
-timeout 300 python profiles/microbench/mall_chunks.py bf16x3 2>&1 | tail -5
-AB_PREC=bf16x3 bash profiles/scripts/gpu_ab.sh "RG_X=base" "RG_LIB=/root/repo/reagent_amd/lib_x3ring2/libreagent_hip.so"
+timeout 900 python -m pytest tests/test_model_autograd.py tests/test_torch_ops.py tests/test_dqn_trainer.py tests/test_data_parallel.py tests/test_checkpoint_resume.py tests/test_sac_trainer.py tests/test_fused_mlp.py -m gpu -q -x --no-header -p no:cacheprovider > gpurun_out/pt_r03b.log 2>&1; grep -E "passed|failed|error" gpurun_out/pt_r03b.log | tail -3

@@ -3,7 +3,7 @@
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT; TAG=${1:-def}
 timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 t0=$(date +%s.%N)
-timeout 900 python bench.py --gpus 1 --steps ${STEPS:-20} --warmup ${WARMUP:-5} > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "rc=$? wall=$(echo "$(date +%s.%N) - $t0" | bc) s"
+timeout 900 python bench.py --gpus 1 --steps ${STEPS:-20} --warmup ${WARMUP:-5} > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "rc=$? wall=$(python -c "import time,sys; print(round(time.time()-float(sys.argv[1]),1))" $t0) s"
 python - <<PY
 import json
 r=json.load(open("$OUT/bench_$TAG.json"))

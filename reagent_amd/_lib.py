@@ -88,6 +88,12 @@ class MlpDesc(ctypes.Structure):
         ("out_scatter", ctypes.c_int32),
         ("group_stride_fwd", ctypes.c_int64),
         ("group_stride_bwd", ctypes.c_int64),
+        ("defer_db", ctypes.c_int32),
+        ("sum_n", ctypes.c_int32),
+        ("db_partials", c_void_p),
+        ("sum_in", c_void_p),
+        ("sum_out", c_void_p),
+        ("sum_scale", ctypes.c_double),
     ]
 
 

@@ -570,8 +570,7 @@ struct ReduceGroupArgs {
   float* out[FB_MAXL];
 };
 
-__global__ void reduce_group_kernel(ReduceGroupArgs R) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void reduce_group_body(const ReduceGroupArgs& R, long i) {
   if (i >= R.elem_begin[R.n]) return;
   const float* part = R.partial[0];
   long slab = R.slab[0], base = 0;
@@ -595,6 +594,8 @@ __global__ void reduce_group_kernel(ReduceGroupArgs R) {
   for (; k < splits; ++k) s0 += part[(long)k * slab + e];
   out[e] = (s0 + s1) + (s2 + s3);
 }
+
+__global__ void reduce_group_kernel(ReduceGroupArgs R) { reduce_group_body(R, (long)blockIdx.x * blockDim.x + threadIdx.x); }
 
 struct StageGroupArgs {
   int n;
@@ -653,6 +654,46 @@ __global__ void reduce_cols_group_kernel(ReduceColsGroupArgs G) {
   for (int i = 1; i < FB_MAXL; ++i)
     if (i < G.n && (int)blockIdx.x >= G.block_begin[i]) l = i;
   reduce_cols_body(G.partials[l], G.S, G.N[l], G.out[l], (int)blockIdx.x - G.block_begin[l]);
+}
+
+// The weight gradient's split reduce, the bias gradients' column reduce and (optionally) one scaled sum — the mean loss
+// of a step — in ONE launch: blocks [0, elem_blocks) are reduce_group_kernel's, the next cols.block_begin[cols.n] are
+// reduce_cols_group_kernel's, the last one is reduce_sum_kernel's (heads.hip), each with its own arithmetic unchanged:
+// bit-identical to the three launches (5.6 + 4.6 us of launch-bound tails per C2 step).
+struct ReduceTailArgs {
+  ReduceGroupArgs splits;
+  ReduceColsGroupArgs cols;
+  int elem_blocks;
+  const float* sum_in;
+  int sum_n;
+  float sum_scale;
+  float* sum_out;
+};
+
+__global__ void reduce_tail_kernel(ReduceTailArgs T) {
+  const int b = blockIdx.x;
+  if (b < T.elem_blocks) {
+    reduce_group_body(T.splits, (long)b * blockDim.x + threadIdx.x);
+    return;
+  }
+  const int cb = b - T.elem_blocks;
+  if (cb < T.cols.block_begin[T.cols.n]) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < FB_MAXL; ++i)
+      if (i < T.cols.n && cb >= T.cols.block_begin[i]) l = i;
+    reduce_cols_body(T.cols.partials[l], T.cols.S, T.cols.N[l], T.cols.out[l], cb - T.cols.block_begin[l]);
+    return;
+  }
+  // reduce_sum_kernel (heads.hip): strided partial sums, block_sum_256's fixed order
+  __shared__ float scratch[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < T.sum_n; i += 256) acc += T.sum_in[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) T.sum_out[0] = ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3])) * T.sum_scale;
 }
 
 __global__ void reduce_splits2_kernel(const float* __restrict__ partials, long slab, int splits,
@@ -1025,6 +1066,10 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   }
   if (rc) return rc;
   if (d->tile_key && (d->x3 || (d->db[d->n_layers - 1] && !d->tile_begin))) return RG_EINVAL;
+  if (d->defer_db) {  // the partials stay in the workspace: rg_mlp_wgrad_fused (db_partials) sums them in its reduce launch
+    if (d->tile_key || !want_db) return RG_EINVAL;
+    return 0;
+  }
   ReduceColsGroupArgs G;
   G.n = 0;
   G.S = n_wg;
@@ -1225,7 +1270,39 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   RG_LAUNCH_DYN(wgrad_group_kernel, dim3(wg), dim3(WG_THREADS), lds, (hipStream_t)stream, G);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  RG_LAUNCH(reduce_group_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), (hipStream_t)stream, R);
+  const int elem_blocks = (int)((el + 255) / 256);
+  if (!d->db_partials && !d->sum_in) {
+    RG_LAUNCH(reduce_group_kernel, dim3((unsigned)elem_blocks), dim3(256), (hipStream_t)stream, R);
+    return (int)hipGetLastError();
+  }
+  // tails folded into this launch: the bias partials rg_mlp_backward_fused(defer_db) left in ITS workspace (layout as
+  // there: [n_wg][dims[l+1]] per layer with a bias gradient, in layer order) and one scaled sum
+  ReduceTailArgs T;
+  T.splits = R;
+  T.elem_blocks = elem_blocks;
+  ReduceColsGroupArgs& C = T.cols;
+  C.n = 0;
+  C.S = padded_wgs(d, batch);
+  int blocks = 0;
+  if (d->db_partials) {
+    const float* p = d->db_partials;
+    for (int l = 0; l < d->n_layers; ++l) {
+      if (d->db[l]) {
+        const int i = C.n++;
+        C.block_begin[i] = blocks;
+        C.partials[i] = p;
+        C.out[i] = d->db[l];
+        C.N[i] = d->dims[l + 1];
+        blocks += (d->dims[l + 1] + 31) / 32;
+      }
+      p += (size_t)C.S * d->dims[l + 1];
+    }
+  }
+  for (int i = C.n; i <= FB_MAXL; ++i) C.block_begin[i] = blocks;
+  for (int i = C.n; i < FB_MAXL; ++i) { C.partials[i] = nullptr; C.out[i] = nullptr; C.N[i] = 0; }
+  if (d->sum_in && (!d->sum_out || d->sum_n <= 0)) return RG_EINVAL;
+  T.sum_in = d->sum_in; T.sum_n = d->sum_n; T.sum_scale = (float)d->sum_scale; T.sum_out = d->sum_out;
+  RG_LAUNCH(reduce_tail_kernel, dim3((unsigned)(elem_blocks + blocks + (d->sum_in ? 1 : 0))), dim3(256), (hipStream_t)stream, T);
   return (int)hipGetLastError();
 }
 

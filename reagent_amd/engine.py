@@ -343,6 +343,8 @@ class FusedMLP:
         self._ws = {}
         self._desc = L.MlpDesc()
 
+    fold_tails = True  # bias-gradient column reduce inside the weight gradient's reduce launch (False: its own launch)
+
     @staticmethod
     def supported(weights, acts) -> bool:
         d = L.MlpDesc()
@@ -429,6 +431,8 @@ class FusedMLP:
         d.x3 = int(self.x3)
         d.dx_col0 = 0
         d.dx_only = 0
+        d.defer_db, d.sum_n = 0, 0
+        d.db_partials, d.sum_in, d.sum_out = None, None, None
         for i, v in enumerate(self.dims):
             d.dims[i] = v
         ws = self._ws
@@ -478,8 +482,10 @@ class FusedMLP:
 
     def backward(self, dout32: torch.Tensor, xt, dw: List[torch.Tensor], db: List[torch.Tensor],
                  dx32: Optional[torch.Tensor] = None, skip_wgrad: bool = False,
-                 out32: Optional[torch.Tensor] = None, dx_col0: int = 0):
-        """dx_col0: dx32 receives the gradient of input columns [dx_col0, in_features) only (a multiple of 32)"""
+                 out32: Optional[torch.Tensor] = None, dx_col0: int = 0, tail_sum=None):
+        """dx_col0: dx32 receives the gradient of input columns [dx_col0, in_features) only (a multiple of 32).
+        tail_sum = (partials fp32 [n], scale, out fp32 [1]): out = scale * sum(partials) is evaluated in the weight
+        gradient's reduce launch (the mean loss of the step from the loss head's partials: one launch fewer)."""
         dout32 = _through_output_activation(self.acts[-1], dout32, out32)
         B = dout32.shape[0]
         assert self._ws.get("key") == (B, dout32.device, True), "backward needs a saving forward first"
@@ -493,20 +499,38 @@ class FusedMLP:
             assert dx_col0 % 32 == 0 and dx32.shape[1] == self.dims[0] - dx_col0
         lib = L.lib()
         ws = self._ws
+        want_db = False
         for l in range(self.L):
             d.db[l] = db[l].data_ptr() if (db is not None and not skip_wgrad and db[l] is not None) else None
+            want_db = want_db or bool(d.db[l])
+        # the bias gradients' column reduce (and the step's loss mean) ride in the weight gradient's reduce launch
+        defer = bool(want_db and not skip_wgrad and self.fold_tails)
+        d.defer_db = int(defer)
+        d.db_partials, d.sum_in, d.sum_out, d.sum_n, d.sum_scale = None, None, None, 0, 0.0
         ops._run("rg_mlp_backward_fused", dict(B=B, dims=tuple(self.dims)),
                  lambda: lib.rg_mlp_backward_fused(d, dout32.data_ptr(), dout32.stride(0), B,
                                                    dx32.data_ptr() if dx32 is not None else None,
                                                    dx32.stride(0) if dx32 is not None else 0,
                                                    ws["bwd"].data_ptr(), ws["bwd"].numel() * 4, L.stream_ptr()))
         d.dx_only = 0
+        d.defer_db = 0
         if not skip_wgrad:
             for l in range(self.L):
                 d.dw[l] = dw[l].data_ptr()
+            if defer:
+                d.db_partials = ws["bwd"].data_ptr()
+            if tail_sum is not None:
+                part, scale, out = tail_sum
+                L.require_cuda(part)
+                L.require_cuda(out)
+                assert part.dtype == torch.float32 and part.is_contiguous() and out.dtype == torch.float32
+                d.sum_in, d.sum_n, d.sum_scale, d.sum_out = part.data_ptr(), part.numel(), float(scale), out.data_ptr()
             wsb = ws["wgrad"].numel() * 4
             ops._run("rg_mlp_wgrad_fused", dict(B=B, dims=tuple(self.dims)),
                      lambda: lib.rg_mlp_wgrad_fused(d, B, ws["wgrad"].data_ptr(), wsb, L.stream_ptr()))
+            d.db_partials, d.sum_in, d.sum_out, d.sum_n = None, None, None, 0
+        else:
+            assert tail_sum is None, "tail_sum rides in the weight gradient's launch"
 
 
 class GroupedHead:

@@ -415,7 +415,7 @@ class QStepCore(DQNTrainerBaseLightning):
         if grad_out is not None:
             self._dq.mul_(grad_out)
         held = held_gradients(self._slab, self._hip_params)
-        self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
+        self._qs.backward(self._dq, self._xs_t, self._dw, self._db, **self._take_loss_tail())
         if self._dp_group is not None:
             if async_reduce and ops.profiling():
                 # instrumented pass (bench.py): the collective joined at once, between two events on the compute stream
@@ -428,6 +428,15 @@ class QStepCore(DQNTrainerBaseLightning):
             else:
                 dp_reduce(self, self._slab)
         publish_gradients(self._slab, self._hip_params, held)
+
+    # the step's mean loss evaluated by the weight gradient's reduce launch instead of its own (native steps on the
+    # fused stacks only: there the loss is not read before the backward has been enqueued)
+    _loss_tail_wanted = False
+    _loss_tail = None
+
+    def _take_loss_tail(self) -> dict:
+        tail, self._loss_tail = self._loss_tail, None
+        return {"tail_sum": tail} if tail is not None else {}
 
     # ---- data parallel -------------------------------------------------------
     def enable_data_parallel(self, process_group=None):
@@ -469,7 +478,11 @@ class QStepCore(DQNTrainerBaseLightning):
         forward k+1); what the caller gains is that whatever it enqueues between two steps (the next
         batch's replay gather) runs under the all-reduce instead of after it."""
         self.apply_pending_update()
-        loss = self._hip_forward(training_batch)
+        self._loss_tail_wanted = True  # the loss mean may ride in the weight gradient's reduce launch (_run_head decides)
+        try:
+            loss = self._hip_forward(training_batch)
+        finally:
+            self._loss_tail_wanted = False
         for p in self._hip_params:
             p.grad = None
         deferred = defer_update and self._dp_group is not None
@@ -492,11 +505,15 @@ class QStepCore(DQNTrainerBaseLightning):
             # the reference evaluates q_network(next_state) once more after the optimizer step (dqn_trainer.py:267-268),
             # which moves a batch-normed network's running statistics; the two-halves form has no such forward
             raise NotImplementedError("the two-halves form of the native step does not cover batch-normed Q-networks")
-        loss = self._hip_forward(training_batch)
+        self._loss_tail_wanted = True
+        try:
+            loss = self._hip_forward(training_batch)
+        finally:
+            self._loss_tail_wanted = False
         for p in self._hip_params:
             p.grad = None
         with _NativeStep(self):
-            self._qs.backward(self._dq, self._xs_t, self._dw, self._db)
+            self._qs.backward(self._dq, self._xs_t, self._dw, self._db, **self._take_loss_tail())
             publish_gradients(self._slab, self._hip_params)
         return loss
 
@@ -703,7 +720,12 @@ class DQNTrainer(QStepCore):
                      self._f32c(b.reward).reshape(-1), boosts, self._f32c(b.not_terminal).reshape(-1),
                      self.gamma, gamma_exp, self.double_q_learning, self._loss_type, self._dq,
                      self._loss_partials, self._next_q, self._next_idx, self._q_sel)
-        ops.reduce_sum(self._loss_partials, self._loss_partials.numel(), 1.0 / B, self._loss)
+        from ..engine import FusedMLP
+
+        if self._loss_tail_wanted and isinstance(self._qs, FusedMLP):
+            self._loss_tail = (self._loss_partials, 1.0 / B, self._loss)  # summed in rg_mlp_wgrad_fused's reduce launch
+        else:
+            ops.reduce_sum(self._loss_partials, self._loss_partials.numel(), 1.0 / B, self._loss)
         self.all_action_scores = self._q
 
     # ---- reference surface --------------------------------------------------------------------

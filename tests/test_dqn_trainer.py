@@ -254,6 +254,52 @@ def test_fused_update_equals_separate_launches(backend, state_dim, precision):
         assert torch.equal(a, b)  # the staged fragments themselves, every plane
 
 
+def test_folded_tails_equal_their_own_launches(backend, monkeypatch):
+    """the bias gradients' column reduce and the loss mean evaluated inside rg_mlp_wgrad_fused's reduce launch
+    (rg_mlp_desc.defer_db / db_partials / sum_in) leave the bits their own launches (reduce_cols_group, rg_reduce_sum) do"""
+    from reagent_amd import ops
+    from reagent_amd.engine import FusedMLP
+
+    def make():
+        set_default_precision(L.PREC_BF16)
+        try:
+            torch.manual_seed(7)
+            q = FullyConnectedDQN(24, 5, [256, 256], ["relu", "relu"]).to(backend.device)
+        finally:
+            set_default_precision(L.PREC_F32)
+        return DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(5)],
+                          rl=RLParameters(gamma=0.9, target_update_rate=0.05, q_network_loss="huber"),
+                          optimizer=Optimizer__Union.default(lr=0.003),
+                          evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(backend.device)
+
+    folded, separate = make(), make()
+    names = []
+    real = ops._run
+    monkeypatch.setattr(ops, "_run", lambda name, meta, call: (names.append(name), real(name, meta, call))[1])
+    for s in range(2):
+        batch = synthetic.to_dqn_input(synthetic.dqn_batch(300, 24, 5, seed=60 + s, p_impossible=0.2), backend.device)
+        del names[:]
+        la = folded.train_step_native(batch)
+        assert "rg_reduce_sum" not in names and isinstance(folded._qs, FusedMLP)
+        # the same step with both tails in their own launches
+        separate.apply_pending_update()
+        if s:
+            separate._qs.fold_tails = False
+        lb = separate._hip_forward(batch)  # (no native-step flag: rg_reduce_sum runs)
+        if not s:
+            separate._qs.fold_tails = False
+        for p in separate._hip_params:
+            p.grad = None
+        separate._hip_backward(None)
+        separate._update_pending = True
+        separate.apply_pending_update()
+        assert torch.equal(la, lb), s
+        for a, b in zip(folded._slab.grad_views(), separate._slab.grad_views()):
+            assert torch.equal(a, b), s
+    for a, b in zip(folded.q_network.parameters(), separate.q_network.parameters()):
+        assert torch.equal(a, b)
+
+
 def test_dqn_bcq_matches_reference(backend):
     """batch-constrained q-learning (dqn_trainer.py:113-117, 209-215; imitator_training.py:12-25): next
     actions whose imitator probability is below drop_threshold x the row maximum leave the max.
