@@ -20,8 +20,14 @@
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
 
 #include "rg_mlp_frag.h"
+// workgroups per layer of the grouped weight-gradient launch (splits = this / tiles).
+// Round 3, same-box A/B in the C2 step (wgrad + reduce, us): this uniform 128 per layer 132-134; workgroups shared out in
+// proportion to the operand bytes a layer's tiles stream — 256 in all (one round on the chip, 52 MB of partials
+// instead of 84) 143-144, 384 in all 157, 512 in all 165; the tiles that share an operand half walking their split's
+// blocks 2 / 4 / 8 blocks apart (so that the second reader finds the line in L2 instead of joining the in-flight miss)
+// 143-145 / 162-164 / 172-173: the lockstep second reader is the cheap one.  Not kept.
 #ifndef RG_WGRAD_TARGET
-#define RG_WGRAD_TARGET 128  // workgroups per layer of the grouped weight-gradient launch (splits = this / tiles)
+#define RG_WGRAD_TARGET 128
 #endif
 
 namespace rg {

@@ -22,8 +22,11 @@
 // autograd backward, in the accuracy class of the reference's fp32 CPU arithmetic.
 #include "rg_mlp_frag.h"
 
+// weight-fragment ring depth of the 8-wave kernels.  Round 3, same box, C2 step: ring 2 1.128-1.139 ms against 1.143-1.144
+// with ring 4 (saving forward 234 -> 227 us, backward 192 -> 188) — as for the bf16 kernels, a deeper ring only lengthens
+// the L2 queues.
 #ifndef RG_X3_RING
-#define RG_X3_RING 4
+#define RG_X3_RING 2
 #endif
 
 namespace rg {
@@ -149,6 +152,8 @@ __device__ __forceinline__ void x3_mainloop(const bf16_t* act, int pitch, int KC
     loadA(0, 0);
     int kc = 0;
     for (; kc < KC - RING; kc += RING) {
+      // (round 3, same-box A/B in the C2 step: no priorities at all, or waves 0-3 at priority 3 for the whole loop,
+      // measured 1.126-1.128 ms/step against 1.129-1.133 with this hand-off — within the run-to-run spread)
       if (prio_phase && kc * 2 < KC) RG_SETPRIO(1);
       else RG_SETPRIO(0);
 #pragma unroll
