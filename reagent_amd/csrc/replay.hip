@@ -321,6 +321,10 @@ __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __rest
   const rg_dqn_batch_out& o = a.o;
   const int row0 = blockIdx.x * GATHER_ROWS_PER_WG;
   const int nrows = (batch - row0 < GATHER_ROWS_PER_WG) ? batch - row0 : GATHER_ROWS_PER_WG;
+  // (Round 3, same-box A/B at C2, 39-40 us per launch in every form: one workgroup reading BOTH rows of a transition — two
+  // loads in flight per thread, the next-state row the store neighbour of the state row — and two independent row pieces
+  // in flight per thread measured the same as this one-piece-per-thread loop: with eight waves per SIMD the launch is not
+  // short of requests in flight, it runs at what random 512-byte rows get from the HBM.)
   const int piece = blockIdx.y;  // 0 = state, 1 = next_state, 2 = everything else
   const int F = v.n_features, A = v.n_actions, H = v.update_horizon;
   const int64_t C = v.capacity;

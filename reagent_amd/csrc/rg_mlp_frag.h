@@ -270,6 +270,35 @@ __device__ __forceinline__ int k_rotation(int wg, int wave, int KC) { return (wg
 // (Hoisting the ring fill of a layer ahead of the previous epilogue / the input-tile load was
 // measured with profiles/microbench/fwd_phases: the epilogues got 1.2k cycles slower each and the
 // main loops no faster, so the fill stays at the top of the main loop.)
+// RG_ACC_AGPR (experiment, off): the main loop's accumulators pinned to AccVGPRs.  profiles/microbench/mfma_feed measured
+// this loop ALONE at 0.51-0.52 of the nominal peak with them against 0.42-0.44 with the accumulators in arch VGPRs (where
+// the register allocator keeps them for kernels that fit 256 registers).  The MFMA is opaque inline asm then, so the
+// hazard recognizer does not see it: mfma_drain() supplies the wait states an MFMA result needs before a VALU /
+// v_accvgpr_read may read it (18 for the 16-pass 32x32 MFMA).
+// Round 3 in the product kernels (numerics tests green; profiles/microbench/out/r03e/fwd_phases*.txt, same box): the
+// 512-wide kernels are left 128 arch registers — 20 (forward) / 14 (backward) values spill to scratch, every
+// accumulator passes through a copy on its way to the VALU — and every phase got SLOWER, the main loop included
+// (K = 512 loop 18.4k -> 19.8k ticks, pack 3.6k -> 4.4k, LDS store 2.5k -> 3.5k, output layer 8.7k -> 13.0k; forward
+// 83.5 -> 100 us in the step).  The gain of the isolated loop does not survive the epilogues' register needs.
+// with the accumulators in AccVGPRs every value passes through an arch VGPR on its way to the VALU: the epilogues
+// then take one accumulator tile at a time (no overlap of a tile's copies with its neighbour's arithmetic), which
+// keeps the arch side under its 128 registers
+#ifdef RG_ACC_AGPR
+#define RG_TILE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RG_TILE_FENCE() ((void)0)
+#endif
+#ifdef RG_ACC_AGPR
+__device__ __forceinline__ f32x16 mfma_main(u16x8 a, u16x8 b, f32x16 c) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  return c;
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
+#else
+__device__ __forceinline__ f32x16 mfma_main(u16x8 a, u16x8 b, f32x16 c) { return mfma_32x32x16_bf16(a, b, c); }
+__device__ __forceinline__ void mfma_drain() {}
+#endif
+
 template <int TN, int RING>
 __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave,
                                               long nt_stride, f32x16 (&acc)[4][TN], int lane, int rot,
@@ -294,7 +323,7 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn]);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_main(af[tm], bf[tn], acc[tm][tn]);
   };
   if (KC % RING == 0) {
     // fast path: no conditionals around the loads in the steady state, so the compiler keeps exact
@@ -343,6 +372,7 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
       mma(a[s & 1], b[s]);
       sched_fence();
     }
+    mfma_drain();
     return;
   }
   // generic K: same ring with guarded loads
@@ -362,6 +392,7 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
       }
     }
   }
+  mfma_drain();
 }
 
 // one 32x32 output tile (row tile tm, weight n-tile nt) over K; used for narrow / irregular widths.
@@ -464,6 +495,7 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
     static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
       constexpr int tm = decltype(tm_c)::value;
       float v[16];
+      RG_TILE_FENCE();
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
       pack_tile(v, PK[tm][tn]);
@@ -495,6 +527,7 @@ __device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16
     static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
       constexpr int tm = decltype(tm_c)::value;
       float v[16];
+      RG_TILE_FENCE();
       if (USE_SIGN && act_is_sign_based<ACT>()) {
         const unsigned bits = sg[tn * 2 + (tm >> 1)] >> ((tm & 1) * 16);
 #pragma unroll

@@ -40,9 +40,34 @@ class _GraphedLoop:
 
     _graph = None
     _replays = 0
+    # Index draws of `index_pool_steps` steps come from ONE torch.randint launch (the per-step draw was the last
+    # torch kernel on the C2 step: 5 us of 540); a step then only slices the pool.  1 = a draw per step.  Inside a
+    # graph capture the per-step draw stays (torch's graph-safe Philox state is what makes a replay draw afresh).
+    index_pool_steps = 32
+    _pool = None
+    _pool_pos = 0
+    _pool_key = None
 
     def _eager_step(self, indices=None):
         raise NotImplementedError
+
+    def _draw_indices(self):
+        """indices of the next batch from the pool, or None = let the buffer draw (sample_index_batch).  Same
+        distribution as sample_index_batch: uniform with replacement over the valid slots."""
+        rb = self.rb
+        dev = torch.device(rb.device)
+        if self.index_pool_steps <= 1 or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            return None
+        n, cap = rb._num_valid_indices, rb._replay_capacity
+        if n == 0:
+            return None  # the buffer raises its own error
+        key = (n, cap, self.batch_size, self.index_pool_steps)
+        if self._pool is None or self._pool_key != key or self._pool_pos >= self._pool.shape[0]:
+            self._pool = torch.randint(n, (self.index_pool_steps, self.batch_size), device=dev)
+            self._pool_pos, self._pool_key = 0, key
+        pick = self._pool[self._pool_pos]
+        self._pool_pos += 1
+        return pick if n == cap else rb._valid_indices()[pick]
 
     # ---- checkpoint / resume (what pl.Trainer's checkpointing does for the reference: module + optimizer states) ----
     def checkpoint(self) -> dict:
@@ -60,6 +85,8 @@ class _GraphedLoop:
             all_batches_processed=int(getattr(tr, "all_batches_processed", 0)),
             rng_state=rng,
             extras=tr.checkpoint_extras() if hasattr(tr, "checkpoint_extras") else None,
+            # the undrawn rest of the index pool: the continuation draws what this loop would have drawn
+            index_pool=None if self._pool is None else dict(pool=self._pool[self._pool_pos:].cpu(), key=self._pool_key),
         )
 
     def load_checkpoint(self, ckpt: dict):
@@ -82,6 +109,13 @@ class _GraphedLoop:
             torch.cuda.set_rng_state(ckpt["rng_state"].cpu(), dev)
         else:
             torch.set_rng_state(ckpt["rng_state"].cpu())
+        ip = ckpt.get("index_pool")
+        self._pool = self._pool_key = None
+        self._pool_pos = 0
+        if ip is not None and ip["pool"].shape[0] > 0:
+            # the rest is shorter than a full pool: it is used up, then a fresh pool is drawn from the restored RNG
+            # state — exactly what the saved loop would have done
+            self._pool, self._pool_key = ip["pool"].to(dev), tuple(ip["key"])
 
     def save(self, path: str):
         torch.save(self.checkpoint(), path)
@@ -231,7 +265,7 @@ class OfflineDqnLoop(_GraphedLoop):
         # data parallel: the previous step's gradient all-reduce is still in flight here, and the
         # gather does not depend on it — the trainer joins it right before Adam
         if not self.prefetch or indices is not None:
-            batch = self.make_batch(indices)
+            batch = self.make_batch(indices if indices is not None else self._draw_indices())
             return self.trainer.train_step_native(batch, defer_update=True)
         if self._ready is None:
             self._ready = self._launch_prefetch()
@@ -242,7 +276,7 @@ class OfflineDqnLoop(_GraphedLoop):
         return loss
 
     def _eager_step(self, indices=None):
-        return self.trainer.train_step_native(self.make_batch(indices))
+        return self.trainer.train_step_native(self.make_batch(indices if indices is not None else self._draw_indices()))
 
     def flush(self):
         """apply an update left pending by the last step (call before reading parameters)"""
@@ -304,7 +338,7 @@ class OfflinePolicyLoop(_GraphedLoop):
         return self.maker(tup)
 
     def step(self, indices: Optional[torch.Tensor] = None, **noise):
-        return self.trainer.train_step_native(self.make_batch(indices), **noise)
+        return self.trainer.train_step_native(self.make_batch(indices if indices is not None else self._draw_indices()), **noise)
 
     def _eager_step(self, indices=None):
         return self.step(indices)

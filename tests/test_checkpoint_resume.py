@@ -56,8 +56,14 @@ def _state(tr):
     return {k: v.detach().clone() for k, v in tr.state_dict().items()}
 
 
-def _run(make, tmp_path):
+def _run(make, tmp_path, pool=None):
     # uninterrupted: 3 + 3 steps
+    base = make
+    if pool is not None:  # index draws of `pool` steps per torch.randint launch (runtime._GraphedLoop.index_pool_steps)
+        def make(**kw):
+            loop, tr = base(**kw)
+            loop.index_pool_steps = pool
+            return loop, tr
     loop, tr = make()
     torch.manual_seed(123)
     for _ in range(3):
@@ -106,3 +112,28 @@ def test_sac_loop_with_a_fixed_temperature_resumes_bit_identically(emu_lib, tmp_
     from functools import partial
 
     _run(partial(_sac_loop, fixed_temperature=True), tmp_path)
+
+
+def test_loops_resume_bit_identically_across_an_index_pool_boundary(emu_lib, tmp_path):
+    """the checkpoint lands inside a pool of index draws (2 steps per draw: saved after step 3 = one row left) and the
+    continuation crosses into the next pool; and with a draw per step (pool 1)"""
+    _run(_dqn_loop, tmp_path, pool=2)
+    _run(_sac_loop, tmp_path, pool=2)
+    _run(_dqn_loop, tmp_path, pool=1)
+
+
+def test_index_pool_draws_are_uniform_picks_of_valid_slots(emu_lib):
+    loop, _ = _dqn_loop()
+    loop.index_pool_steps = 4
+    torch.manual_seed(5)
+    seen = [loop._draw_indices().clone() for _ in range(9)]  # three pools
+    assert all(i.shape == (loop.batch_size,) and i.dtype == torch.int64 and 0 <= int(i.min()) and int(i.max()) < 256 for i in seen)
+    assert len({tuple(i.tolist()) for i in seen}) == 9  # every step its own batch
+    # a store with invalid slots: the picks go through the valid table
+    rb = loop.rb
+    rb._valid_host[:] = False
+    rb._valid_host[10:40] = True
+    rb._num_valid_indices, rb._valid_dirty = 30, True
+    idx = torch.cat([loop._draw_indices() for _ in range(5)])
+    assert int(idx.min()) >= 10 and int(idx.max()) < 40 and len(idx.unique()) > 20
+

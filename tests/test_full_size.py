@@ -208,3 +208,26 @@ def test_offline_table_batch_at_full_size():
     assert torch.equal(out.step, t["step"][idx].float().unsqueeze(1))
     assert torch.equal(out.extras.mdp_id, t["mdp_id"][idx].unsqueeze(1))
     assert torch.equal(out.possible_actions_mask, t["possible_actions_mask"][idx].float())
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_c2_step_against_the_oracle_at_full_size(precision, monkeypatch):
+    """The whole C2 step at B = 65 536 (not a slice): one-launch sampler on the 2^20-row shard, three forwards, TD / Huber
+    head, backward, Adam, soft update — against oracle/restated.py on the same indices, with north_star's bounds: gather
+    fields bit exact, Q-values within 1e-4 (bf16x3: max 5e-5 measured; f32: 4e-6), loss 1e-4 relative, post-Adam weights
+    2e-5 in exact-fp32 mode (bf16x3: the bound on direction-flipped weights of tests/test_baseline_shapes.py).
+    The oracle's step takes ~3 s on the box's host cores."""
+    import sys
+
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "c2", "--precision", precision, "--parity-batch", str(B)])
+    args = bench.parse()
+    dev = torch.device("cuda:0")
+    _, _, init, cols, norm = bench.build(args, dev, 0, batch=256)  # the shard + the initial weights
+    out = bench.parity_check(args, dev, init, cols, norm)
+    assert out["batch"] == B and out["gather_fields_bit_exact"]
+    assert out["max_abs_dq"] <= 1e-4 and out["rel_dloss"] <= 1e-4, out
+    assert out["meets_north_star"] and out["ok"], out
+    if precision == "f32":
+        assert out["max_abs_dw"] <= 2e-5, out

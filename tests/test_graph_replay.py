@@ -167,6 +167,7 @@ def test_dqn_loop_graph_replay_equals_eager(draw):
     params = {}
     for mode in ("eager", "graph"):
         loop, tr = _c2_loop(dev)
+        loop.index_pool_steps = 1  # a draw per step, as inside the captured graph (the eager loop's default draws 32 steps' worth at once)
         torch.cuda.manual_seed(77)
         out = []
         if mode == "eager":
@@ -226,6 +227,7 @@ def test_sac_loop_graph_replay_equals_eager():
     res = {}
     for mode in ("eager", "graph"):
         loop, tr = build()
+        loop.index_pool_steps = 1
         torch.cuda.manual_seed(11)
         out = []
         if mode == "eager":
