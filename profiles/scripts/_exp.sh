@@ -1,3 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_full_size.py tests/test_graph_replay.py tests/test_checkpoint_resume.py tests/test_data_parallel.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -4
-bash profiles/scripts/gpu_default_bench.sh r03e
+run() { python bench.py --config c2 --precision $1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --launch eager --no-graph --no-accurate --no-also --no-kernel-profile $2 2>/dev/null | python -c "
+import json,sys; r=json.loads(sys.stdin.read()); print('$1 $2', r['ms_per_step'], r['region_ms'])"; }
+for rep in 1 2; do run bf16 ""; run bf16 "--prefetch wgrad"; run bf16 "--prefetch all"; done
+for rep in 1 2; do run bf16x3 ""; run bf16x3 "--prefetch wgrad"; done

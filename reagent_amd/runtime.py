@@ -12,6 +12,11 @@ Everything is enqueued on torch's current stream; the loss stays on the device.
 while step k computes.  Measured on one MI355X (same box, C2): 0.642 ms/step with it against 0.615
 without — the fused MLP kernels fill every CU's registers and LDS, so the gather only runs in their
 tails and slows them more than it hides; it is therefore OFF by default and kept as an option.
+(Round 3: releasing the next batch's sampler only beside the step's WEIGHT GRADIENT — bound by its operand stream,
+167 registers per wave, so the sampler's waves fit next to it on every CU — through a hook before that launch measured
+0.616-0.622 ms/step against 0.568-0.571 without any prefetch and 0.607-0.610 with the free-running one, same box; bf16x3
+1.237-1.241 against 1.179-1.181.  Two kernels sharing the memory system plus two cross-stream waits per step cost more
+than the 40 us they hide; not kept.)
 """
 from typing import Optional
 
