@@ -266,6 +266,10 @@ typedef struct {
   void* target_wfrag_fwd[RG_MLP_MAX_LAYERS];
   int32_t x3;  /* ABI 6: split-bf16 stacks — every fragment buffer is [hi plane | lo plane] (rg_mlp_desc.x3), both
                 * planes of all three fragment sets are re-staged: lo = bf16(w - hi) as rg_mlp_stage_weights_fused */
+  int32_t group_rows[RG_MLP_MAX_LAYERS]; /* ABI 7: group_rows[l] > 0 = layer l is a GROUPED layer (QR-DQN's A x N output
+                * layer, reagent/training/qrdqn_trainer.py:108-194, as dims[l+1] / group_rows[l] independent
+                * [group_rows[l], dims[l]] layers): its three fragment buffers are laid out as rg_group_weights_stage
+                * writes them (group g at g * rg_group_wfrag_elems elements).  bf16 stacks only (x3 == 0). */
 } rg_mlp_update_desc; /* host struct */
 int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
                         double weight_decay, double bias_correction1, double bias_correction2_sqrt,
@@ -557,6 +561,10 @@ int rg_group_weights_stage(const float* w, int n_groups, int group_rows, int in_
                            void* wfrag_bwd, rg_stream_t stream);
 int rg_wide_head_mean(const float* w, const float* b, int n_groups, int group_rows, int in_features, float* wbar,
                       float* bbar, rg_stream_t stream);
+/* ABI 7: the same, and the means also written as the forward B fragments of the [n_groups, in] mean layer (the slots
+ * rg_stage_weights_frag(wbar, n_groups, in, wfrag_fwd, NULL) fills for rows < n_groups; wfrag_fwd staged once before) */
+int rg_wide_head_mean_staged(const float* w, const float* b, int n_groups, int group_rows, int in_features, float* wbar,
+                             float* bbar, void* wfrag_fwd, rg_stream_t stream);
 int rg_qr_select_action(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
                         int32_t* key, rg_stream_t stream);
 int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldzt, const int32_t* rowmap,

@@ -764,14 +764,28 @@ struct UpdateArgs {
   // split-bf16 stacks: every fragment buffer is [hi plane | lo plane], lo = bf16(x - hi) (stage_weight_elem); the lo
   // plane of layer l starts wfrag_elems(N, K) (forward, target) / wfrag_elems(K, N) (backward) elements in
   int x3;
+  // grouped layers (qr_grouped.hip: QR-DQN's A x N output layer as A independent [Ng, K] layers): Ng[l] > 0 = the rows
+  // of layer l fall into groups of Ng, group g's fragments start g * per_f[l] (forward, target) / g * per_b[l] (backward)
+  // elements in — what rg_group_weights_stage writes.  bf16 stacks only.
+  int Ng[FB_MAXL];
+  long per_f[FB_MAXL], per_b[FB_MAXL];
 };
 
 // the three fragment slots of W[n][k] (online forward / backward, target forward), both planes in split-bf16 mode —
 // element for element what stage_weight_elem writes
 __device__ __forceinline__ void update_store_frags(const UpdateArgs& U, int l, int n, int k, float pn, float tn) {
-  const int N = U.N[l], K = U.K[l];
+  int N = U.N[l];
+  const int K = U.K[l];
+  long gf = 0, gb = 0;
+  if (U.Ng[l] > 0) {  // this row's group, its row inside the group
+    const int g = n / U.Ng[l];
+    n -= g * U.Ng[l];
+    N = U.Ng[l];
+    gf = g * U.per_f[l];
+    gb = g * U.per_b[l];
+  }
   const int KCf = (K + 15) / 16, KCb = (N + 15) / 16;
-  const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+  const long jf = gf + ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
   const long tf = (long)((N + 31) / 32) * KCf * 512, tb = (long)((K + 31) / 32) * KCb * 512;
   const bf16_t ph = f32_to_bf16(pn), th = f32_to_bf16(tn);
   if (U.wf[l]) {
@@ -783,7 +797,7 @@ __device__ __forceinline__ void update_store_frags(const UpdateArgs& U, int l, i
     if (U.x3) U.twf[l][tf + jf] = f32_to_bf16(tn - bf16_to_f32(th));
   }
   if (U.wb[l]) {
-    const long jb = ((((long)(k >> 5) * KCb + (n >> 4)) * 64) + ((k & 31) + 32 * ((n & 15) >> 3))) * 8 + (n & 7);
+    const long jb = gb + ((((long)(k >> 5) * KCb + (n >> 4)) * 64) + ((k & 31) + 32 * ((n & 15) >> 3))) * 8 + (n & 7);
     U.wb[l][jb] = ph;
     if (U.x3) U.wb[l][tb + jb] = f32_to_bf16(pn - bf16_to_f32(ph));
   }
@@ -908,7 +922,14 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
     *(f32x4*)(U.v + i) = V;
     if (U.t) *(f32x4*)(U.t + i) = Tg;
     const int KCf = (K + 15) / 16;
-    const long jf = ((((long)(n >> 5) * KCf + (k >> 4)) * 64) + ((n & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+    int nl = n;  // row inside its group (grouped layer) / the row itself
+    long gf = 0;
+    if (U.Ng[l] > 0) {
+      const int g = n / U.Ng[l];
+      nl = n - g * U.Ng[l];
+      gf = g * U.per_f[l];
+    }
+    const long jf = gf + ((((long)(nl >> 5) * KCf + (k >> 4)) * 64) + ((nl & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
     const long tf = (long)((N + 31) / 32) * KCf * 512;  // lo plane of the forward fragments (split-bf16)
     if (U.wf[l]) *(uint2*)(U.wf[l] + jf) = uint2{pack_bf16x2(pn[0], pn[1]), pack_bf16x2(pn[2], pn[3])};
     if (U.twf[l]) *(uint2*)(U.twf[l] + jf) = uint2{pack_bf16x2(tn[0], tn[1]), pack_bf16x2(tn[2], tn[3])};
@@ -936,8 +957,12 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
     unsigned short h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = (nt + e < N) ? tile[(ng * 8 + e) * UT_PITCH + kk] : (bf16_t)0;
-    const int KCb = (N + 15) / 16;
-    const long jb = ((((long)(kt >> 5) * KCb + (nt >> 4)) * 64) + ((kt & 31) + 32 * ((nt & 15) >> 3))) * 8;
+    // grouped layer (Ng % 8 == 0, checked by the host): a record of 8 out-features lies inside one group
+    const int grp = U.Ng[l] > 0 ? nt / U.Ng[l] : 0;
+    const int ntl = nt - grp * (U.Ng[l] > 0 ? U.Ng[l] : 0);
+    const int KCb = ((U.Ng[l] > 0 ? U.Ng[l] : N) + 15) / 16;
+    const long jb = grp * (U.Ng[l] > 0 ? U.per_b[l] : 0) +
+                    ((((long)(kt >> 5) * KCb + (ntl >> 4)) * 64) + ((kt & 31) + 32 * ((ntl & 15) >> 3))) * 8;
     *(u32x4*)(U.wb[l] + jb) = u32x4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
                                     (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
     if (U.x3) {
@@ -1327,11 +1352,17 @@ static int mlp_update_launch(const rg_mlp_update_desc* d, double lr, double beta
       U.N[l] = N; U.K[l] = K;
       U.w_off[l] = d->w_off[l]; U.b_off[l] = d->b_off[l];
       U.wf[l] = (bf16_t*)d->wfrag_fwd[l]; U.wb[l] = (bf16_t*)d->wfrag_bwd[l]; U.twf[l] = (bf16_t*)d->target_wfrag_fwd[l];
+      const int Ng = d->group_rows[l];
+      if (Ng < 0 || (Ng > 0 && (N % Ng != 0 || d->x3))) return RG_EINVAL;
+      U.Ng[l] = Ng;
+      U.per_f[l] = Ng > 0 ? (long)wfrag_elems(Ng, K) : 0;
+      U.per_b[l] = Ng > 0 ? (long)wfrag_elems(K, Ng) : 0;
       const long we = d->w_off[l] + (long)N * K, be = d->b_off[l] + N;
       total = we > total ? we : total;
       total = be > total ? be : total;
     } else {
       U.N[l] = U.K[l] = 0; U.w_off[l] = U.b_off[l] = 0; U.wf[l] = U.wb[l] = U.twf[l] = nullptr;
+      U.Ng[l] = 0; U.per_f[l] = U.per_b[l] = 0;
     }
   }
   U.total = total;
@@ -1353,7 +1384,7 @@ static int mlp_update_launch(const rg_mlp_update_desc* d, double lr, double beta
     T.tiled[l] = 0;
     if (l < d->n_layers) {
       const int K = U.K[l], N = U.N[l];
-      const bool ok = (K % 8) == 0 && (U.w_off[l] % 4) == 0 && ((((uintptr_t)U.p | (uintptr_t)U.g | (uintptr_t)U.m |
+      const bool ok = (K % 8) == 0 && (U.Ng[l] % 8) == 0 && (U.w_off[l] % 4) == 0 && ((((uintptr_t)U.p | (uintptr_t)U.g | (uintptr_t)U.m |
                                                                   (uintptr_t)U.v | (uintptr_t)U.t) & 15) == 0) &&
                       ((((uintptr_t)U.wf[l] | (uintptr_t)U.wb[l] | (uintptr_t)U.twf[l]) & 15) == 0);
       if (ok) {

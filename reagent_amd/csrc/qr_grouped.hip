@@ -34,8 +34,10 @@ __global__ void group_stage_kernel(const float* __restrict__ w, int G, int Ng, i
 
 // wbar[g][k] = mean_n w[(g * Ng + n) * K + k], bbar[g] = mean_n b[g * Ng + n]  (fp32; 8 row strides per column
 // summed separately and combined in fixed order)
+// wfrag (nullable): the forward B fragments of the [G, K] mean layer, written with the means (what a separate
+// rg_stage_weights_frag of wbar would write to the slots of rows < G; the padding rows were zeroed by the first staging)
 __global__ void wide_mean_kernel(const float* __restrict__ w, const float* __restrict__ b, int G, int Ng, int K,
-                                 float* __restrict__ wbar, float* __restrict__ bbar) {
+                                 float* __restrict__ wbar, float* __restrict__ bbar, bf16_t* __restrict__ wfrag) {
   __shared__ float red[8][33];
   const int g = blockIdx.y, c = threadIdx.x & 31, rg = threadIdx.x >> 5, k = blockIdx.x * 32 + c;
   float s = 0.f;
@@ -59,7 +61,12 @@ __global__ void wide_mean_kernel(const float* __restrict__ w, const float* __res
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += red[i][c];
-    wbar[(long)g * K + k] = t / (float)Ng;
+    const float mean = t / (float)Ng;
+    wbar[(long)g * K + k] = mean;
+    if (wfrag) {
+      const int KCf = (K + 15) / 16;
+      wfrag[((((long)(g >> 5) * KCf + (k >> 4)) * 64) + ((g & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7)] = f32_to_bf16(mean);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // the group's bias mean: one wave, lane-strided partial sums
     float t = 0.f;
@@ -425,7 +432,15 @@ int rg_wide_head_mean(const float* w, const float* b, int n_groups, int group_ro
                       float* bbar, rg_stream_t stream) {
   if (!w || !wbar || !bbar || n_groups <= 0 || group_rows <= 0 || in_features <= 0) return RG_EINVAL;
   RG_LAUNCH(wide_mean_kernel, dim3((in_features + 31) / 32, n_groups), dim3(256), (hipStream_t)stream, w, b, n_groups,
-            group_rows, in_features, wbar, bbar);
+            group_rows, in_features, wbar, bbar, (bf16_t*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int rg_wide_head_mean_staged(const float* w, const float* b, int n_groups, int group_rows, int in_features, float* wbar,
+                             float* bbar, void* wfrag_fwd, rg_stream_t stream) {
+  if (!w || !wbar || !bbar || !wfrag_fwd || n_groups <= 0 || group_rows <= 0 || in_features <= 0) return RG_EINVAL;
+  RG_LAUNCH(wide_mean_kernel, dim3((in_features + 31) / 32, n_groups), dim3(256), (hipStream_t)stream, w, b, n_groups,
+            group_rows, in_features, wbar, bbar, (bf16_t*)wfrag_fwd);
   return (int)hipGetLastError();
 }
 

@@ -689,12 +689,19 @@ def group_weights_stage(w, n_groups, group_rows, wf, wb):
                                                 L.stream_ptr()))
 
 
-def wide_head_mean(w, b, n_groups, group_rows, wbar, bbar):
+def wide_head_mean(w, b, n_groups, group_rows, wbar, bbar, wfrag_fwd=None):
+    """wfrag_fwd: the (already staged once) forward fragments of the [n_groups, in] mean layer, rewritten in the same launch"""
     _chk_dev(w, b, wbar, bbar)
     assert w.is_contiguous() and wbar.is_contiguous() and wbar.shape == (n_groups, w.shape[1])
-    _run("rg_wide_head_mean", dict(G=n_groups, Ng=group_rows, K=w.shape[1]),
-         lambda: L.lib().rg_wide_head_mean(w.data_ptr(), L.ptr(b), n_groups, group_rows, w.shape[1], wbar.data_ptr(),
-                                           bbar.data_ptr(), L.stream_ptr()))
+    if wfrag_fwd is None:
+        _run("rg_wide_head_mean", dict(G=n_groups, Ng=group_rows, K=w.shape[1]),
+             lambda: L.lib().rg_wide_head_mean(w.data_ptr(), L.ptr(b), n_groups, group_rows, w.shape[1], wbar.data_ptr(),
+                                               bbar.data_ptr(), L.stream_ptr()))
+    else:
+        _chk_dev(wfrag_fwd)
+        _run("rg_wide_head_mean", dict(G=n_groups, Ng=group_rows, K=w.shape[1]),
+             lambda: L.lib().rg_wide_head_mean_staged(w.data_ptr(), L.ptr(b), n_groups, group_rows, w.shape[1],
+                                                      wbar.data_ptr(), bbar.data_ptr(), wfrag_fwd.data_ptr(), L.stream_ptr()))
 
 
 def qr_select_action(q, mask, maxq: bool, key):

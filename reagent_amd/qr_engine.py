@@ -67,15 +67,35 @@ class _Net:
                            acts[:-1] + [L.ACT["linear"]])
         self.gh = GroupedHead(self.head.weight, self.head.bias, A, N, need_bwd)
         self._staged = None
+        self._mean_stale = False
+
+    def _versions(self):
+        return tuple((p._version, getattr(p, "_rg_version", 0), p.data_ptr()) for l in self.lin for p in (l.weight, l.bias))
 
     def stage(self):
-        ver = tuple((p._version, getattr(p, "_rg_version", 0), p.data_ptr()) for l in self.lin for p in (l.weight, l.bias))
+        ver = self._versions()
         if ver == self._staged:
             return
         ops.wide_head_mean(self.head.weight.detach(), self.head.bias.detach(), self.A, self.N, self.wbar, self.bbar)
         self.st.stage_weights(need_transposed=self.need_bwd, force=True)
         self.gh.stage()
         self._staged = ver
+        self._mean_stale = False
+
+    def fragments_updated(self, mean_now: bool):
+        """after the one-launch update (rg_mlp_update_fused with this network's fragment buffers as destinations): trunk
+        and grouped-head fragments are those of the new parameters; the per-action mean layer (wbar, bbar and its forward
+        fragments) follows in one more launch — now, or when somebody needs it (`ensure_mean`)"""
+        self._staged = self._versions()
+        self._mean_stale = True
+        if mean_now:
+            self.ensure_mean()
+
+    def ensure_mean(self):
+        if self._mean_stale:
+            ops.wide_head_mean(self.head.weight.detach(), self.head.bias.detach(), self.A, self.N, self.wbar, self.bbar,
+                               wfrag_fwd=self.st._wf[self.st.L - 1])
+            self._mean_stale = False
 
 
 class GroupedQR:
@@ -87,6 +107,14 @@ class GroupedQR:
         self._B = -1
         self._side = None
         self.two_streams = os.environ.get("RG_QR_STREAMS", "1") != "0"  # the forward's two halves on two streams
+
+    def after_fused_update(self):
+        """DQNTrainer._fused_update ran Adam + soft update + re-staging of both networks' trunk and grouped-head
+        fragments in one launch; the mean layer of the network that selects a* follows (the other one's on demand)"""
+        tr = self.tr
+        sel_online = (not tr.maxq_learning) or tr.double_q_learning
+        self.online.fragments_updated(mean_now=True)  # a* under double-Q, and all_q_values()
+        self.target.fragments_updated(mean_now=not sel_online)
 
     @staticmethod
     def eligible(trainer) -> bool:
@@ -154,6 +182,7 @@ class GroupedQR:
         # a*: the next action whose target quantiles form the Bellman target
         if tr.maxq_learning:
             sel = on if tr.double_q_learning else tg
+            sel.ensure_mean()
             sel.st.forward(next_state, self.qbar_next, save=False)
             ops.qr_select_action(self.qbar_next, tr._f32c(b.possible_next_actions_mask), True, self.key_next)
         else:  # SARSA: the logged next action (qrdqn_trainer.py:139-141); terminal rows carry none
@@ -195,6 +224,7 @@ class GroupedQR:
         """q_network(state).mean(dim=2) [B, A] (the trainer's logged `all_q_values`): one more forward with the
         per-action mean layer, run only when somebody asks (reporters, CPE)"""
         if self._all_q is None:
+            self.online.ensure_mean()
             self.online.st.forward(self._state, self.qbar_cur, save=False)
             self._all_q = self.qbar_cur
         return self._all_q

@@ -14,6 +14,8 @@ import logging
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
+import os
+
 import torch
 
 from .. import _lib as L
@@ -537,8 +539,15 @@ class QStepCore(DQNTrainerBaseLightning):
         import math
 
         from ..engine import FusedMLP, ensure_slab
+        from ..qr_engine import GroupedQR
 
         qs, ts = self._qs, self._ts
+        # QR-DQN's grouped engine (qr_engine.py): trunk stacks + the wide layer as a grouped last layer of the same launch
+        grouped = qs if isinstance(qs, GroupedQR) else None
+        if grouped is not None:
+            qs, ts = grouped.online.st, grouped.target.st
+            if self._fused_plan is None and os.environ.get("RG_QR_FUSED_UPDATE", "1") == "0":  # same-box A/B switch
+                self._fused_plan = False
         plan = self._fused_plan
         if plan is None:
             ok = (isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and qs.x3 == ts.x3
@@ -564,6 +573,9 @@ class QStepCore(DQNTrainerBaseLightning):
                 d.x3 = int(qs.x3)  # split-bf16: both planes of every fragment set are re-staged
                 for i, v in enumerate(qs.dims):
                     d.dims[i] = v
+                if grouped is not None:  # the trunk stack ends in the per-action mean layer; the parameters end in the wide one
+                    d.dims[len(lin)] = lin[-1].weight.shape[0]
+                    d.group_rows[len(lin) - 1] = grouped.N
                 for l, layer in enumerate(lin):
                     d.w_off[l] = self._slab.offsets[index[id(layer.weight)]]
                     d.b_off[l] = self._slab.offsets[index[id(layer.bias)]]
@@ -575,6 +587,8 @@ class QStepCore(DQNTrainerBaseLightning):
                 return False
         if any(w is None for w in qs._wf) or any(w is None for w in qs._wb) or any(w is None for w in ts._wf):
             return False  # fragments not staged yet (their padding is written by the first staging)
+        if grouped is not None and (grouped.online._staged is None or grouped.target._staged is None):
+            return False  # the grouped head's fragments likewise
         (slab, exp_avg, exp_avg_sq), tslab, d = adam.moments_for(0), plan["tslab"], plan["desc"]
         if slab is not self._slab or not tslab.is_bound():
             return False
@@ -592,6 +606,10 @@ class QStepCore(DQNTrainerBaseLightning):
         for l in range(d.n_layers):
             d.wfrag_fwd[l], d.wfrag_bwd[l] = qs._wf[l].data_ptr(), qs._wb[l].data_ptr()
             d.target_wfrag_fwd[l] = ts._wf[l].data_ptr()
+        if grouped is not None:  # last parameter layer = the wide layer: per-action fragment blocks of the grouped heads
+            l = d.n_layers - 1
+            d.wfrag_fwd[l], d.wfrag_bwd[l] = grouped.online.gh.wf.data_ptr(), grouped.online.gh.wb.data_ptr()
+            d.target_wfrag_fwd[l] = grouped.target.gh.wf.data_ptr()
         tau = soft.param_groups[0]["tau"]
         if sched is not None:  # graph-safe: lr and the bias corrections come from HBM, the step is counted there
             from ..optimizer import capturing
@@ -617,6 +635,8 @@ class QStepCore(DQNTrainerBaseLightning):
         for st_, need_t in ((qs, True), (ts, False)):
             st_._staged_versions = tuple((w._version, getattr(w, "_rg_version", 0)) for w in st_.weights) + (need_t,)
             st_._wsrc_ptrs = [w.data_ptr() for w in st_.weights]
+        if grouped is not None:
+            grouped.after_fused_update()  # the per-action mean layer(s) of the updated wide layer
         return True
 
     @torch.no_grad()

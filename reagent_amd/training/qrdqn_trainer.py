@@ -102,8 +102,9 @@ class QRDQNTrainer(QStepCore):
         loss = g.forward(b)
         from .reagent_lightning_module import _NoOpReporter
 
-        # q_network(state).mean(dim=2) is logging output only: with a reporter attached it is evaluated here, with the
-        # step's weights like the reference; otherwise on first read (one extra forward with the mean layer)
+        # q_network(state).mean(dim=2) is logging output only (a local of the reference's step, qrdqn_trainer.py:147,189):
+        # with a reporter attached it is evaluated here, with the step's weights like the reference; otherwise on first
+        # read, with the network as it is then — after the step's update (one extra forward with the mean layer)
         self._all_q_values = None if isinstance(self._reporter, _NoOpReporter) else g.all_q_values()
         return loss
 

@@ -137,6 +137,12 @@ def test_grouped_head_equals_dense_path(backend, rl, double_q):
     S, A, N, B = 24, 4, 10, 300
     tg, td = _qr_pair(dev, S, A, N, [256, 256], rl, double_q)
     assert GroupedQR.eligible(tg)
+
+    class Reporter:  # with a reporter attached the step itself evaluates all_q_values (model_values of qrdqn_trainer.py:189),
+        def log(self, **kw):  # with the step's weights; without one the property evaluates the network on first read
+            pass
+
+    tg.set_reporter(Reporter())
     b = synthetic.dqn_batch(B, S, A, seed=21, p_impossible=0.3)
     # (1) exactly one possible next action per row: a* is forced, so both paths regress the same targets and the
     #     comparison is tight (the trunks are the same kernels; the wide layer is summed in the same K order)
@@ -166,6 +172,59 @@ def test_grouped_head_equals_dense_path(backend, rl, double_q):
     opts = [o["optimizer"] for o in tg.configure_optimizers()]
     losses = lightning_like_step(tg, opts, synthetic.to_dqn_input(b, dev))
     assert torch.isfinite(losses[0]).all()
+
+
+@pytest.mark.parametrize("rl,double_q,N", [
+    (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=True), True, 16),
+    (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=True), False, 16),   # a* from the TARGET network's mean layer
+    (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=False), True, 16),   # SARSA: no mean layer in the step at all
+    (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=True), True, 10),    # 10 rows per action: records of 8 would
+])                                                                              # straddle groups -> per-element path
+def test_grouped_fused_update_equals_separate_launches(backend, rl, double_q, N):
+    """The QR-DQN step's update in ONE launch (rg_mlp_update_fused with the wide layer as a grouped last layer: Adam +
+    soft update + the trunk fragments and the per-action fragment blocks of both networks) + the mean layer by
+    rg_wide_head_mean_staged, against the separate launches (rg_adam_step, rg_soft_update, rg_mlp_stage_weights_fused x 2,
+    rg_group_weights_stage x 2, rg_wide_head_mean x 2): same bits in the parameters, the targets, the Adam moments, every
+    fragment buffer, the mean layer, and the following steps' losses."""
+    from reagent_amd.qr_engine import GroupedQR
+
+    dev = backend.device
+    S, A, B = 24, 4, 300
+
+    def make():
+        tr, _ = _qr_pair(dev, S, A, N, [256, 256], rl, double_q)
+        return tr
+
+    fused, separate = make(), make()
+    separate._fused_plan = False
+    for s in range(3):
+        batch = synthetic.to_dqn_input(synthetic.dqn_batch(B, S, A, seed=60 + s, p_impossible=0.3), dev)
+        la, lb = fused.train_step_native(batch), separate.train_step_native(batch)
+        assert torch.equal(la, lb), s
+    assert isinstance(fused._qs, GroupedQR) and isinstance(fused._fused_plan, dict) and fused._fused_plan["desc"].group_rows[2] == N
+    for a, b in zip(list(fused.q_network.parameters()) + list(fused.q_network_target.parameters()),
+                    list(separate.q_network.parameters()) + list(separate.q_network_target.parameters())):
+        assert torch.equal(a, b)
+    oa, ob = fused.native_optimizers()[0], separate.native_optimizers()[0]
+    for pa, pb in zip(fused.q_network.parameters(), separate.q_network.parameters()):
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+    # the staged state itself: bring both engines fully up to date (the fused path computes a mean layer only when a
+    # forward needs it, the separate path stages lazily before its next forward)
+    gf, gs = fused._gq, separate._gq
+    for net in (gs.online, gs.target):
+        net.stage()
+    for net in (gf.online, gf.target):
+        net.ensure_mean()
+    for nf, ns in ((gf.online, gs.online), (gf.target, gs.target)):
+        assert torch.equal(nf.wbar, ns.wbar) and torch.equal(nf.bbar, ns.bbar)
+        assert torch.equal(nf.gh.wf, ns.gh.wf)
+        for a, b in zip(nf.st._wf, ns.st._wf):
+            assert torch.equal(a, b)
+    assert torch.equal(gf.online.gh.wb, gs.online.gh.wb)
+    for a, b in zip(gf.online.st._wb[:-1], gs.online.st._wb[:-1]):  # (the mean layer has no backward)
+        assert torch.equal(a, b)
+    assert torch.equal(fused.all_q_values, separate.all_q_values)
 
 
 @pytest.mark.parametrize("B,G", [(1000, 5), (37, 3), (4096, 16)])
