@@ -7,7 +7,8 @@ on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is
 The file is stamped with the hash of the kernel sources it was measured on (bench.source_stamp()): bench.py reports
 the figure only while that hash matches what is running.
 
-usage: python profiles/pmc_to_traffic.py gpurun_out/pmc_<tag> <config> <precision> ["<where it came from>"]
+usage: python profiles/pmc_to_traffic.py gpurun_out/pmc_<tag>_<config>_<precision> <config> <precision> ["<where it came from>"]
+(profiles/scripts/gpu_pmc_all.sh <tag> runs the passes of c2 bf16 / c2 bf16x3 / c3 bf16 / c4 bf16 in one call)
 """
 import collections
 import csv
@@ -54,14 +55,48 @@ def main():
 
     fwd = [n for n in fetch if n.startswith("mlp_fwd_fused_kernel") or n.startswith("mlp_fwd_x3_kernel")]
     bwd = [n for n in fetch if n.startswith("mlp_bwd_fused_kernel") or n.startswith("mlp_bwd_x3_kernel")]
-    # a DQN step launches the forward three times: next state online, next state target (save = 0), state (save = 1)
-    put("rg_mlp_forward_fused:save=0", fwd[:1], lambda i, n: i % 3 != 2)
-    put("rg_mlp_forward_fused:save=1", fwd[:1], lambda i, n: i % 3 == 2)
-    put("rg_mlp_backward_fused", bwd[:1])
-    put("rg_mlp_wgrad_fused", ["wgrad_group_kernel", "reduce_group_kernel"])
-    put("rg_replay_dqn_batch", [n for n in fetch if n.startswith("replay_dqn_batch_kernel")][:1])
-    put("rg_mlp_update_fused", [n for n in fetch if n.startswith("mlp_update_tiles_kernel")][:1])
-    put("rg_dqn_head", [n for n in fetch if n.startswith("dqn_head")][:1])
+    # the weight gradient's second launch: reduce_tail_kernel (split reduce + bias column reduce + loss mean, round 3) or
+    # reduce_group_kernel (split reduce alone)
+    reduce_k = "reduce_tail_kernel" if "reduce_tail_kernel" in fetch else "reduce_group_kernel"
+    first = lambda prefix: [n for n in fetch if n.startswith(prefix)][:1]  # noqa: E731
+    if config in ("c2", "c5"):
+        # a DQN step launches the forward three times: next state online, next state target (save = 0), state (save = 1)
+        put("rg_mlp_forward_fused:save=0", fwd[:1], lambda i, n: i % 3 != 2)
+        put("rg_mlp_forward_fused:save=1", fwd[:1], lambda i, n: i % 3 == 2)
+        put("rg_mlp_backward_fused", bwd[:1])
+        put("rg_mlp_wgrad_fused", ["wgrad_group_kernel", reduce_k])
+        put("rg_replay_dqn_batch", first("replay_dqn_batch_kernel"))
+        put("rg_mlp_update_fused", first("mlp_update_tiles_kernel"))
+        put("rg_dqn_head", first("dqn_head"))
+    elif config == "c3":
+        # QR-DQN, grouped wide layer, ONE stream (RG_QR_STREAMS=0 in gpu_pmc_all.sh, so a step's launches keep their order):
+        # forward of the per-action mean layer (a*), grouped forward of the target network, grouped SAVING forward of the
+        # online network
+        put("rg_mlp_forward_fused:save=0", fwd[:1], lambda i, n: i % 3 != 2)
+        put("rg_mlp_forward_fused:save=1", fwd[:1], lambda i, n: i % 3 == 2)
+        put("rg_mlp_backward_fused", bwd[:1])
+        put("rg_mlp_wgrad_fused", ["wgrad_group_kernel", reduce_k])
+        put("rg_group_head_wgrad", ["wgrad_grouped_kernel", "reduce_grouped_kernel"])
+        put("rg_qr_compact_head", first("qr_compact_head_kernel"))
+        put("rg_replay_dqn_batch", first("replay_dqn_batch_kernel"))
+        put("rg_mlp_update_fused", first("mlp_update_tiles_kernel"))
+    elif config == "c4":
+        # SAC: mlp_bwd_fused_kernel runs three times per step — critic q1, critic q2 (full backward, the entry point
+        # bench.py names as dominant), then the actor's
+        put("rg_mlp_backward_fused", bwd[:1], lambda i, n: i % 3 != 2)
+        put("rg_mlp_backward_fused:actor", bwd[:1], lambda i, n: i % 3 == 2)
+        put("rg_mlp_backward_fused:dx_only", first("mlp_bwd_dx_kernel"))
+        put("rg_mlp_forward_fused:all", fwd[:1])
+        put("rg_mlp_wgrad_fused:all", ["wgrad_group_kernel", reduce_k])
+        put("rg_replay_gather", first("replay_gather_kernel"))
+        put("rg_mlp_update_fused:all", first("mlp_update_tiles_kernel"))
+    # every rg:: kernel of the run, averaged over its launches (evidence; the keys above are what bench.py looks up)
+    per_kernel = {}
+    for nm in sorted(set(fetch) & set(write)):
+        if nm.startswith("at::") or nm.startswith("__amd") or not fetch[nm] or not write[nm]:
+            continue
+        f, w = sum(fetch[nm]) / len(fetch[nm]), sum(write[nm]) / len(write[nm])
+        per_kernel[nm.split("<")[0]] = {"hbm_bytes_per_launch": int(round((2.0 * f + w) * 1024)), "launches": len(fetch[nm])}
     path = os.path.join(ROOT, "profiles", "traffic.json")
     old = {}
     if os.path.exists(path):
@@ -76,7 +111,9 @@ def main():
            "correction": "KB units; FETCH_SIZE x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section); "
                          "hbm bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE",
            "kernels": merged, "raw": {**(old.get("raw", {}) if old.get("source_stamp") == stamp else {}),
-                                      **{f"{config}:{prec}:{k}": v for k, v in raw.items()}}}
+                                      **{f"{config}:{prec}:{k}": v for k, v in raw.items()}},
+           "per_kernel": {**(old.get("per_kernel", {}) if old.get("source_stamp") == stamp else {}),
+                          f"{config}:{prec}": per_kernel}}
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 
