@@ -26,6 +26,15 @@
 // instead of 84) 143-144, 384 in all 157, 512 in all 165; the tiles that share an operand half walking their split's
 // blocks 2 / 4 / 8 blocks apart (so that the second reader finds the line in L2 instead of joining the in-flight miss)
 // 143-145 / 162-164 / 172-173: the lockstep second reader is the cheap one.  Not kept.
+// Grouped output layer (QR-DQN C3: 7 column tiles of one action's slice): 0 = 32x32 tiles spread over the waves
+// (tile_kloop), R > 0 = wave w runs the hidden layers' main loop on column tile w (4 row tiles, every weight fragment
+// read once per workgroup) with a ring of R chunks.  Round 3, same box, C3 step on one stream / two streams (ms):
+// 0: 1.101 / 1.034; 8: 1.119 / 1.054; 16: 1.121 / 1.052 — the deep-ring main loop is no faster (the round-2 result
+// with the ring of 2), its burst of output stores at the end costs more than the re-read fragments.  Ablations of the
+// 189 us target forward: head MFMAs removed -43 us, output stores removed -20..-28 us.
+#ifndef RG_GROUPED_RING
+#define RG_GROUPED_RING 0
+#endif
 #ifndef RG_WGRAD_TARGET
 #define RG_WGRAD_TARGET 128
 #endif
@@ -50,14 +59,18 @@ template <int NW> struct MlpCfg {
 // during the output layer — were measured: 78.8-79.3 us against 80.1 us per launch in
 // profiles/microbench/fwd_phases, but 92 against 85 us inside the training step, where the static
 // tile assignment loses the dispatcher's load balancing; the kernel stays one tile per workgroup.)
-template <int TN, int NW, int PITCH>
-__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
+// GROUPED: the launch of a stack whose output layer takes per-tile weights (rg_mlp_desc.tile_key, qr_grouped.hip) is its
+// own instantiation — the ordinary kernel does not carry its code paths (or their registers).
+template <int TN, int NW, int PITCH, bool GROUPED>
+__device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
   constexpr int THREADS = MlpCfg<NW>::THREADS, RING = MlpCfg<NW>::RING;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
-  const int row_base = blockIdx.x * FB_BM;
+  const int tile = GROUPED ? grouped_tile(blockIdx.x, (a.batch + FB_BM - 1) / FB_BM) : (int)blockIdx.x;
+  if (GROUPED && tile * FB_BM >= round_up(a.batch, FB_BM)) return;  // padding blocks (workgroup-uniform)
+  const int row_base = tile * FB_BM;
   constexpr int pitch = PITCH;
   const int k0p = round_up(a.dims[0], 32);
   RG_STAMP(0);
@@ -82,7 +95,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
     load_tile_to_lds<bf16_t, THREADS>(act, pitch, (const bf16_t*)a.x, a.ldx, row_base, a.batch, a.dims[0], k0p, tid);
   __syncthreads();
   RG_STAMP(1);
-  if (a.save == 1 && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * 4, wave, NW, lane);
+  if (a.save == 1 && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], tile * 4, wave, NW, lane);
 
   for (int l = 0; l < a.n_layers; ++l) {
     const int K = a.dims[l], N = a.dims[l + 1];
@@ -102,7 +115,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       unsigned PK[4][TN][8];
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
       RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l),
-                                                          sign_dst, N / 32, blockIdx.x * 4, wave, lane, PK)));
+                                                          sign_dst, N / 32, tile * 4, wave, lane, PK)));
       RG_STAMP(3 + 4 * l);
       __syncthreads();  // every wave is done reading the layer input
       RG_STAMP(4 + 4 * l);
@@ -114,9 +127,9 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       const int out_act = a.acts[l];
       const bool stream_out = N > 64;
       // grouped output layer: this tile's group selects the weight / bias slice (an empty tile has no output)
-      const int grp = a.tile_key ? a.tile_key[blockIdx.x] : 0;
-      const bf16_t* wf_out = a.wfrag[l] + (a.tile_key ? (long)(grp < 0 ? 0 : grp) * a.group_stride : 0);
-      const float* b_out = a.bias[l] ? a.bias[l] + (a.tile_key ? (long)(grp < 0 ? 0 : grp) * N : 0) : nullptr;
+      const int grp = GROUPED ? a.tile_key[tile] : 0;
+      const bf16_t* wf_out = a.wfrag[l] + (GROUPED ? (long)(grp < 0 ? 0 : grp) * a.group_stride : 0);
+      const float* b_out = a.bias[l] ? a.bias[l] + (GROUPED ? (long)(grp < 0 ? 0 : grp) * N : 0) : nullptr;
       auto store_tile = [&](const f32x16& acc, int tm, int nt) {
         const int col = nt * 32 + lr;
         if (col < N) {
@@ -137,7 +150,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
       };
       // (A pipelined variant for 4..8 output column tiles — wave w running wide_mainloop<1> on column tile w — was
       // measured on the C3 grouped forward: 171 us against 169 us for this loop, no gain.)
-      if (NTo == 1 && NW == 8 && KC >= 8 && !a.tile_key) {
+      if (!GROUPED && NTo == 1 && NW == 8 && KC >= 8) {
         // one column tile (<= 32 outputs, e.g. 16 Q-values): four 32x32 tiles for eight waves.  The loop is a chain
         // of L2 round trips (7 % of a workgroup's life with four waves idle), so two waves share a tile, each
         // summing half of K; the upper four hand their accumulators over through the activation tile, dead by then.
@@ -158,6 +171,21 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
           }
           store_tile(acc, tm, 0);
         }
+      } else if (GROUPED && RG_GROUPED_RING && NTo <= NW && KC % RG_GROUPED_RING == 0 && KC > RG_GROUPED_RING) {
+        // experiment (RG_GROUPED_RING > 0, see the macro): wave w takes column tile w for all four row tiles through the
+        // main loop of the hidden layers
+        if (wave < NTo && grp >= 0) {
+          f32x16 acc1[4][1];
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[tm][0][r] = 0.f;
+          const long nts = (long)KC * 512;
+          wide_mainloop<1, (RG_GROUPED_RING ? RG_GROUPED_RING : 2)>(act, pitch, KC, wf_out + (long)wave * nts, nts, acc1, lane,
+                                            k_rotation(blockIdx.x, wave, KC), 0);
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) store_tile(acc1[tm][0], tm, wave);
+        }
       } else {
         for (int t = wave; t < 4 * NTo && grp >= 0; t += NW) {
           const int tm = t & 3, nt = t >> 2;
@@ -169,6 +197,15 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
   }
 }
 
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_fused_kernel(MlpArgs a) {
+  mlp_fwd_fused_body<TN, NW, PITCH, false>(a);
+}
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_grouped_kernel(MlpArgs a) {
+  mlp_fwd_fused_body<TN, NW, PITCH, true>(a);
+}
+
 // DX_ONLY: a frozen stack — only the input gradient is produced, no dZ fragments are written (rg_mlp_desc.dx_only)
 template <int TN, int NW, int PITCH, bool DX_ONLY>
 __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
@@ -177,17 +214,19 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
   bf16_t* act = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
-  const int row_base = blockIdx.x * FB_BM;
+  const int tile = a.tile_key ? grouped_tile(blockIdx.x, (a.batch + FB_BM - 1) / FB_BM) : (int)blockIdx.x;
+  if (tile * FB_BM >= round_up(a.batch, FB_BM)) return;  // padding blocks of a grouped launch (workgroup-uniform)
+  const int row_base = tile * FB_BM;
   constexpr int pitch = PITCH;
   const int L = a.n_layers;
   const int nop = round_up(a.dims[L], 32);
   load_tile_to_lds<float, THREADS>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  if (!DX_ONLY) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * 4, wave, NW, lane);
+  if (!DX_ONLY) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], tile * 4, wave, NW, lane);
   if (a.db_part[L - 1] && tid < a.dims[L]) {
     float s = 0.f;
     for (int r = 0; r < FB_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]);
-    a.db_part[L - 1][(long)blockIdx.x * a.dims[L] + tid] = s;
+    a.db_part[L - 1][(long)tile * a.dims[L] + tid] = s;
   }
 
   for (int l = L - 1; l >= 1; --l) {
@@ -206,7 +245,7 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
     unsigned sg[2 * TN];
     const bool use_sign = a.act_sign[l] != nullptr;
     if (use_sign) {
-      const u32x2* sp = (const u32x2*)(a.act_sign[l] + sign_offset(blockIdx.x, wave, lane, TN, N));
+      const u32x2* sp = (const u32x2*)(a.act_sign[l] + sign_offset(tile, wave, lane, TN, N));
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const u32x2 t = sp[i];
@@ -219,19 +258,19 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
     }
     const bf16_t* wl = a.wfrag[l];
     if (l == L - 1 && a.tile_key) {  // grouped output layer: this tile's slice of W^T (an empty tile: dZ is zero)
-      const int grp = a.tile_key[blockIdx.x];
+      const int grp = a.tile_key[tile];
       wl += (long)(grp < 0 ? 0 : grp) * a.group_stride;
     }
     wide_mainloop<TN, RING>(act, pitch, KC, wl + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
                             k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
-    float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
+    float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)tile * N : nullptr;
     unsigned PK[4][TN][8];
     if (use_sign) {
       RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, true, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
-                                                                             N / 32, blockIdx.x * 4, wave, lane, PK)));
+                                                                             N / 32, tile * 4, wave, lane, PK)));
     } else {
       RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, false, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
-                                                                              N / 32, blockIdx.x * 4, wave, lane, PK)));
+                                                                              N / 32, tile * 4, wave, lane, PK)));
     }
     __syncthreads();  // every wave is done reading dZ_l
     store_packed_tiles<TN>(act, pitch, PK, wave, lane);
@@ -1046,8 +1085,10 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
   if (d->x3) return x3_forward_launch(d, a, (hipStream_t)stream);
   const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
-  const dim3 grid((batch + FB_BM - 1) / FB_BM);
-  RG_LAUNCH_FUSED(mlp_fwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+  const int n_tiles = (batch + FB_BM - 1) / FB_BM;
+  const dim3 grid(d->tile_key ? (n_tiles + 7) / 8 * 8 : n_tiles);  // grouped: whole eighths of the tile list (grouped_tile)
+  if (d->tile_key) RG_LAUNCH_FUSED(mlp_fwd_grouped_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+  else RG_LAUNCH_FUSED(mlp_fwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1090,7 +1131,7 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
     rc = x3_backward_launch(d, a, (hipStream_t)stream);
   } else {
     const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
-    const dim3 grid(n_wg);
+    const dim3 grid(d->tile_key ? (n_wg + 7) / 8 * 8 : n_wg);
     if (d->dx_only) RG_LAUNCH_FUSED(mlp_bwd_dx_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
     else RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
     rc = (int)hipGetLastError();

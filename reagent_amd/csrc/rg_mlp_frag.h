@@ -255,6 +255,23 @@ __device__ __forceinline__ unsigned positive_bits(const float (&v)[16]) {
   return bits;
 }
 
+// Grouped launches (rg_mlp_desc.tile_key, qr_grouped.hip): the tiles are sorted by group and every group has its own
+// slice of the output layer's weights (QR-DQN C3: 16 actions x 229 KB of fragments, 3.7 MB next to the trunk's 1.2 MB —
+// more than one XCD's 4 MB L2 when every XCD sees every group).  The hardware places block b on XCD b % 8, so XCD x takes
+// the x-th EIGHTH of the tile list: its L2 then serves the slices of ~G/8 groups.  The launch has 8 * ceil(n_tiles / 8)
+// blocks; those whose tile is past the end return at once.
+#ifndef RG_GROUPED_XCD
+#define RG_GROUPED_XCD 1
+#endif
+__device__ __forceinline__ int grouped_tile(int block, int n_tiles) {
+#if RG_GROUPED_XCD
+  const int per = (n_tiles + 7) >> 3;
+  return (block & 7) * per + (block >> 3);
+#else
+  return block;
+#endif
+}
+
 // ---- main loop of a wide layer: this wave's [128 x 32*TN] slice over K ------------------------
 // `rot` rotates the order in which the K chunks are visited (a sum may be taken in any order):
 // every workgroup streams the SAME weight fragments, and without de-phasing all 256 CUs would
