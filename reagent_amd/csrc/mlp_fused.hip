@@ -35,6 +35,9 @@
 #ifndef RG_GROUPED_RING
 #define RG_GROUPED_RING 0
 #endif
+#ifndef RG_GROUPED_STAGE_OUT
+#define RG_GROUPED_STAGE_OUT 1  // a wide grouped output leaves through the (dead) activation tile as whole rows
+#endif
 #ifndef RG_WGRAD_TARGET
 #define RG_WGRAD_TARGET 128
 #endif
@@ -185,6 +188,36 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
                                             k_rotation(blockIdx.x, wave, KC), 0);
 #pragma unroll
           for (int tm = 0; tm < 4; ++tm) store_tile(acc1[tm][0], tm, wave);
+        }
+      } else if (GROUPED && RG_GROUPED_STAGE_OUT && NTo <= NW && a.stage_out) {
+        // Grouped output layer, wide (QR-DQN: 200 quantiles per row).  Stored straight from the accumulators a wave
+        // instruction writes two 128-byte row segments that start 32 * row bytes off a cache line (rows are 800 bytes):
+        // partial lines, 54 MB of them per launch (-20..-28 us with the stores removed).  Here the output leaves as
+        // whole rows, 16 bytes per lane: one 32-row tile at a time (wave w computes its column tile w) through a staging
+        // area BEHIND the activation tile (32 x (32 NTo + 4) floats, 29 KB of the 30 KB the tile leaves of the CU's LDS).
+        if (grp >= 0) {  // workgroup-uniform: an empty tile has no output and skips the barriers together
+          float* stage = (float*)(act + FB_BM * pitch);
+          const int P = NTo * 32 + 4;  // floats per staged row
+          const int np = N >> 2;       // 16-byte pieces per row
+          for (int tm = 0; tm < 4; ++tm) {
+            if (wave < NTo) {
+              const f32x16 acc = tile_kloop(act, pitch, KC, wf_out, tm, wave, lane);
+              const int col = wave * 32 + lr;
+              const float b = (b_out && col < N) ? b_out[col] : 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+            }
+            __syncthreads();
+            for (int it = tid; it < 32 * np; it += THREADS) {
+              const int r = it / np, c4 = it - r * np;
+              int row = row_base + tm * 32 + r;
+              if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
+              if (row >= 0 && (a.out_scatter || row < a.batch))
+                stream_store(*(const f32x4*)(stage + r * P + c4 * 4), (f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4));
+            }
+            __syncthreads();
+          }
         }
       } else {
         for (int t = wave; t < 4 * NTo && grp >= 0; t += NW) {
@@ -1084,9 +1117,19 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   if (d->x2 && (d->x_split <= 0 || d->x_split >= d->dims[0] || (d->x_split % 32) != 0)) return RG_EINVAL;
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
   if (d->x3) return x3_forward_launch(d, a, (hipStream_t)stream);
-  const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
+  size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
   const int n_tiles = (batch + FB_BM - 1) / FB_BM;
   const dim3 grid(d->tile_key ? (n_tiles + 7) / 8 * 8 : n_tiles);  // grouped: whole eighths of the tile list (grouped_tile)
+  a.stage_out = 0;
+  if (d->tile_key) {
+    // a wide grouped output leaves as whole rows through a staging area behind the activation tile (mlp_fwd_fused_body)
+    const int No = d->dims[d->n_layers], NTo = (No + 31) / 32;
+    const size_t stage = (size_t)32 * (NTo * 32 + 4) * sizeof(float);
+    if (No > 64 && (No & 3) == 0 && (ldo & 3) == 0 && (((uintptr_t)out32) & 15) == 0 && lds + stage <= 160 * 1024) {
+      a.stage_out = 1;
+      lds += stage;
+    }
+  }
   if (d->tile_key) RG_LAUNCH_FUSED(mlp_fwd_grouped_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   else RG_LAUNCH_FUSED(mlp_fwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();

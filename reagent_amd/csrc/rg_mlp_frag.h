@@ -48,6 +48,7 @@ struct MlpArgs {
   const int* tile_key;            // grouped output layer: group of each 128-row tile (-1: empty), null = plain layer
   long group_stride;              // elements between the groups' fragment sets of the last layer (this direction)
   int out_scatter;                // forward: output row r goes to out32[rowmap[r]]
+  int stage_out;                  // grouped forward: the output leaves as whole rows through the LDS behind the activation tile
   int x_is_f32, x2_is_f32;
   float* out32;  // forward output [batch, dims[L]] fp32
   long ldo;

@@ -127,14 +127,15 @@ def _qr_pair(device, S, A, N, hidden, rl, double_q, seed=3):
     (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=True), False),
     (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=False, reward_boost={"1": 0.5}), True),
 ])
-def test_grouped_head_equals_dense_path(backend, rl, double_q):
+@pytest.mark.parametrize("N", [10, 72])  # 72 quantiles: a wide output leaves through the LDS staging area as whole rows
+def test_grouped_head_equals_dense_path(backend, rl, double_q, N):
     """Same bf16 trunk kernels on both sides, so the comparison isolates the grouped machinery: the per-action
     mean layer for a*, the device-built grouped spaces, forward / loss / input gradient / weight gradient of the
     wide layer on [rows, N] instead of [B, A * N]."""
     from reagent_amd.qr_engine import GroupedQR
 
     dev = backend.device
-    S, A, N, B = 24, 4, 10, 300
+    S, A, B = 24, 4, 300
     tg, td = _qr_pair(dev, S, A, N, [256, 256], rl, double_q)
     assert GroupedQR.eligible(tg)
 
