@@ -98,17 +98,21 @@ __device__ __forceinline__ void load_tile_to_lds(bf16_t* act, int pitch, const T
   const int cpr = ncols_pad / 8;  // 8-element chunks per row
   const int total = FB_BM * cpr;
   const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
-  if (vec && ncols == ncols_pad) {
+  if (vec && (ncols & 7) == 0 && ncols > 0) {
     // aligned rows: four chunks per thread in flight (all loads issued before the first use; the
-    // addresses of out-of-range chunks are clamped and their result replaced by zeros)
+    // addresses of out-of-range chunks are clamped and their result replaced by zeros).  Chunks of the padding
+    // columns [ncols, ncols_pad) count as out of range (QR-DQN's dZ tile: 200 of 224 columns — on the one-chunk-at-a-
+    // time path below its seven dependent HBM round trips per thread were ~20 us of the C3 backward).
     constexpr int U = 4;
+    const int kmax = ncols - 8;
     for (int c0 = tid; c0 < total; c0 += THREADS * U) {
       f32x4 raw[U][sizeof(T) == 4 ? 2 : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int cu = c0 + u * THREADS, c = cu < total ? cu : total - 1;
         const int gr = row_base + c / cpr, grow = gr < nrows ? gr : nrows - 1;
-        const T* p = src + (long)grow * ld + (c % cpr) * 8;
+        const int kk = (c % cpr) * 8;
+        const T* p = src + (long)grow * ld + (kk < kmax ? kk : kmax);
         raw[u][0] = *(const f32x4*)p;
         if (sizeof(T) == 4) raw[u][sizeof(T) == 4 ? 1 : 0] = *(const f32x4*)(p + 4);
       }
@@ -127,7 +131,7 @@ __device__ __forceinline__ void load_tile_to_lds(bf16_t* act, int pitch, const T
         } else {
           v = __builtin_bit_cast(u16x8, raw[u][0]);
         }
-        if (row_base + r >= nrows) v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (row_base + r >= nrows || k0 >= ncols) v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
         *(u16x8*)&act[r * pitch + k0] = v;
       }
     }
