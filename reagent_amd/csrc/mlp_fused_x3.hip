@@ -47,6 +47,57 @@ __device__ __forceinline__ void load_tile_split(bf16_t* act, int pitch, const T*
   const int cpr = ncols_pad / 8;
   const int total = X3_BM * cpr;
   const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
+  if (vec && (ncols & 7) == 0 && ncols > 0) {
+    // aligned rows: every chunk of this thread requested before the first is used (C2: two dependent HBM round trips
+    // per thread became one); out-of-range chunks read a clamped address and are replaced by zeros
+    constexpr int U = 2;
+    const int kmax = ncols - 8;
+    for (int c0 = tid; c0 < total; c0 += THREADS * U) {
+      f32x4 raw[U][sizeof(T) == 4 ? 2 : 1];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cu = c0 + u * THREADS, c = cu < total ? cu : total - 1;
+        const int gr = row_base + c / cpr, grow = gr < nrows ? gr : nrows - 1;
+        const int kk = (c % cpr) * 8;
+        const T* p = src + (long)grow * ld + (kk < kmax ? kk : kmax);
+        raw[u][0] = *(const f32x4*)p;
+        if (sizeof(T) == 4) raw[u][sizeof(T) == 4 ? 1 : 0] = *(const f32x4*)(p + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * THREADS;
+        if (c >= total) break;
+        const int r = c / cpr, k0 = (c % cpr) * 8;
+        float f[8];
+        if (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[e] = raw[u][0][e];
+            f[4 + e] = raw[u][sizeof(T) == 4 ? 1 : 0][e];
+          }
+        } else {
+          const u16x8 v = __builtin_bit_cast(u16x8, raw[u][0]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(v[e]);
+        }
+        if (row_base + r >= nrows || k0 >= ncols) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        }
+        u32x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned hh, ll;
+          split_pack(f[2 * e], f[2 * e + 1], hh, ll);
+          h[e] = hh;
+          l[e] = ll;
+        }
+        *(u32x4*)&act[r * pitch + k0] = h;
+        *(u32x4*)&act[LO + r * pitch + k0] = l;
+      }
+    }
+    return;
+  }
   for (int c = tid; c < total; c += THREADS) {
     const int r = c / cpr, k0 = (c % cpr) * 8;
     const int grow = row_base + r;
