@@ -72,8 +72,14 @@ def main():
         # QR-DQN, grouped wide layer, ONE stream (RG_QR_STREAMS=0 in gpu_pmc_all.sh, so a step's launches keep their order):
         # forward of the per-action mean layer (a*), grouped forward of the target network, grouped SAVING forward of the
         # online network
-        put("rg_mlp_forward_fused:save=0", fwd[:1], lambda i, n: i % 3 != 2)
-        put("rg_mlp_forward_fused:save=1", fwd[:1], lambda i, n: i % 3 == 2)
+        grouped = first("mlp_fwd_grouped_kernel")  # round 3: the grouped forwards are their own kernel instantiation
+        if grouped:
+            put("rg_mlp_forward_fused:save=0", grouped, lambda i, n: i % 2 == 0)   # target network, scattered output
+            put("rg_mlp_forward_fused:save=1", grouped, lambda i, n: i % 2 == 1)   # online network, saving
+            put("rg_mlp_forward_fused:save=0:mean_layer", fwd[:1])
+        else:
+            put("rg_mlp_forward_fused:save=0", fwd[:1], lambda i, n: i % 3 != 2)
+            put("rg_mlp_forward_fused:save=1", fwd[:1], lambda i, n: i % 3 == 2)
         put("rg_mlp_backward_fused", bwd[:1])
         put("rg_mlp_wgrad_fused", ["wgrad_group_kernel", reduce_k])
         put("rg_group_head_wgrad", ["wgrad_grouped_kernel", "reduce_grouped_kernel"])
