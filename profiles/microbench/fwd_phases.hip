@@ -6,7 +6,7 @@ __device__ unsigned long long* g_stamps;
 #define RG_STAMP(slot)                                                                                   \
   do {                                                                                                   \
     if ((threadIdx.x & 63) == 0)                                                                         \
-      g_stamps[((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+      g_stamps[((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 20 + (slot)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #include "../../reagent_amd/csrc/mlp_fused.hip"
 // microbench stubs: entry points of the library that live in other translation units and are not exercised here
@@ -41,11 +41,12 @@ int main(int argc, char** argv) {
   hipMalloc((void**)&x, (size_t)B * 128 * 4); hipMemset(x, 0x3c, (size_t)B * 128 * 4);
   hipMalloc((void**)&out, (size_t)B * 16 * 4);
   a.x = x; a.ldx = 128; a.x_is_f32 = 1; a.out32 = out; a.ldo = 16; a.pitch = 520; a.save = save;
-  const int n_wg = argc > 2 ? atoi(argv[2]) : B / 128, NPH = 16, NWV = FB_NW;  // argv[2]: fewer workgroups (clock / power experiments)
+  const int n_wg = argc > 2 ? atoi(argv[2]) : B / 128, NPH = 20, NWV = FB_NW;  // argv[2]: fewer workgroups (clock / power experiments)
   unsigned long long* stamps;
   hipMalloc((void**)&stamps, (size_t)n_wg * NWV * NPH * 8);
   hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps));
-  const size_t lds = (size_t)128 * 520 * 2;
+  a.out_lds = argc > 3 ? atoi(argv[3]) : 0;  // argv[3] = 1: the output layer's weights resident in LDS (round 3)
+  const size_t lds = (size_t)128 * 520 * 2 + (a.out_lds ? 32 * 512 : 0);
   hipFuncSetAttribute((const void*)mlp_fwd_fused_kernel<512 / (32 * FB_NW), FB_NW, 520>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int w = 0; w < 3; ++w) mlp_fwd_fused_kernel<512 / (32 * FB_NW), FB_NW, 520><<<n_wg, FB_NW * 64, lds>>>(a);
@@ -72,6 +73,18 @@ int main(int argc, char** argv) {
   printf("avg s_memtime ticks per wave: %.0f\n", span / nw);
   for (int p = 1; p <= 14; ++p) printf("  %-22s %9.0f ticks  %5.1f %%\n", names[p], tot[p] / nw, 100.0 * tot[p] / span);
   // per wave slot: duration of the L1 main loop (stamps 5 -> 6) and of its wait at the barrier (6 -> 7)
+  {  // inside the output layer (one column tile): K loop | wait for the workgroup | hand-off through LDS + barrier | add + stores
+    double t[4] = {0, 0, 0, 0}, t19 = 0, n19 = 0;
+    for (int g = 0; g < n_wg; ++g)
+      for (int w = 0; w < NWV; ++w) {
+        const unsigned long long* s = &h[((size_t)g * NWV + w) * NPH];
+        if (!s[16]) continue;
+        if (s[19]) { t19 += (double)(s[19] - s[18]); n19 += 1; }
+        t[0] += (double)(s[16] - s[13]); t[1] += (double)(s[17] - s[16]); t[2] += (double)(s[18] - s[17]); t[3] += (double)(s[14] - s[18]);
+      }
+    printf("  storing waves: LDS sum %.0f ticks (of their sum + stores)\n", t19 / (n19 > 0 ? n19 : 1));
+    printf("  output layer split: K loop %.0f | barrier wait %.0f | hand-off + barrier %.0f | sum + stores %.0f ticks\n", t[0] / nw, t[1] / nw, t[2] / nw, t[3] / nw);
+  }
   printf("per-wave L1 main loop / barrier wait (ticks), averaged over workgroups:\n");
   for (int w = 0; w < NWV; ++w) {
     double ml = 0, bw = 0, ep = 0;

@@ -35,6 +35,9 @@
 #ifndef RG_GROUPED_RING
 #define RG_GROUPED_RING 0
 #endif
+#ifndef RG_OUT_LDS
+#define RG_OUT_LDS 1  // a thin output layer's weight fragments resident in LDS (tile_kloop_ldsb)
+#endif
 #ifndef RG_GROUPED_STAGE_OUT
 #define RG_GROUPED_STAGE_OUT 1  // a wide grouped output leaves through the (dead) activation tile as whole rows
 #endif
@@ -99,6 +102,10 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
   __syncthreads();
   RG_STAMP(1);
   if (a.save == 1 && a.act_frag[0]) emit_frags_from_lds(act, pitch, k0p / 32, a.act_frag[0], tile * 4, wave, NW, lane);
+  // a thin output layer's weights travel to LDS while the hidden layers compute (rg_mlp_frag.h: out_lds_prefetch)
+  const bool out_lds = !GROUPED && a.out_lds;
+  char* wo = (char*)(act + FB_BM * pitch);
+  if (out_lds) out_lds_prefetch(a.wfrag[a.n_layers - 1], (a.dims[a.n_layers - 1] + 15) / 16, wo, wave, NW, lane);
 
   for (int l = 0; l < a.n_layers; ++l) {
     const int K = a.dims[l], N = a.dims[l + 1];
@@ -123,7 +130,8 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
       __syncthreads();  // every wave is done reading the layer input
       RG_STAMP(4 + 4 * l);
       store_packed_tiles<TN>(act, pitch, PK, wave, lane);
-      __syncthreads();
+      if (out_lds) RG_WAIT_VMCNT(0);  // this wave's share of the output layer's weights has landed (long ago) ...
+      __syncthreads();                // ... and after the barrier every wave's has
       RG_STAMP(5 + 4 * l);
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
@@ -133,10 +141,13 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
       const int grp = GROUPED ? a.tile_key[tile] : 0;
       const bf16_t* wf_out = a.wfrag[l] + (GROUPED ? (long)(grp < 0 ? 0 : grp) * a.group_stride : 0);
       const float* b_out = a.bias[l] ? a.bias[l] + (GROUPED ? (long)(grp < 0 ? 0 : grp) * N : 0) : nullptr;
+      // the bias of column tile 0, requested BEFORE the K loop: loaded at the point of use it put one more L2 round trip
+      // (~2000 cycles) at the very end of every workgroup whose output is one column tile (16 Q-values, a critic's scalar)
+      const float b_tile0 = (b_out && lr < N) ? b_out[lr] : 0.f;
       auto store_tile = [&](const f32x16& acc, int tm, int nt) {
         const int col = nt * 32 + lr;
         if (col < N) {
-          const float b = b_out ? b_out[col] : 0.f;
+          const float b = nt == 0 ? b_tile0 : (b_out ? b_out[col] : 0.f);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
@@ -158,20 +169,25 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
         // of L2 round trips (7 % of a workgroup's life with four waves idle), so two waves share a tile, each
         // summing half of K; the upper four hand their accumulators over through the activation tile, dead by then.
         const int tm = wave & 3, half = wave >> 2, kc_mid = (KC / 2 + 3) / 4 * 4;
-        f32x16 acc = tile_kloop(act, pitch, KC, wf_out, tm, 0, lane, half ? kc_mid : 0, half ? KC : kc_mid);
+        f32x16 acc = out_lds ? tile_kloop_ldsb(act, pitch, wo, tm, lane, half ? kc_mid : 0, half ? KC : kc_mid)
+                             : tile_kloop(act, pitch, KC, wf_out, tm, 0, lane, half ? kc_mid : 0, half ? KC : kc_mid);
+        RG_STAMP(16);
         __syncthreads();  // every wave is done reading the layer input
+        RG_STAMP(17);
         float* hand = (float*)act + (tm * 64 + lane) * 16;
         if (half) {
 #pragma unroll
           for (int r = 0; r < 16; r += 4) *(f32x4*)(hand + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
         }
         __syncthreads();
+        RG_STAMP(18);
         if (!half) {
 #pragma unroll
           for (int r = 0; r < 16; r += 4) {
             const f32x4 o = *(const f32x4*)(hand + r);
             acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
           }
+          RG_STAMP(19);
           store_tile(acc, tm, 0);
         }
       } else if (GROUPED && RG_GROUPED_RING && NTo <= NW && KC % RG_GROUPED_RING == 0 && KC > RG_GROUPED_RING) {
@@ -1120,7 +1136,16 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
   const int n_tiles = (batch + FB_BM - 1) / FB_BM;
   const dim3 grid(d->tile_key ? (n_tiles + 7) / 8 * 8 : n_tiles);  // grouped: whole eighths of the tile list (grouped_tile)
-  a.stage_out = 0;
+  a.stage_out = a.out_lds = 0;
+  {
+    // a thin output layer (one column tile, the K-split path of the 8-wave kernel) reads its weights from LDS
+    const int L = d->n_layers, KCo = (d->dims[L - 1] + 15) / 16;
+    if (RG_OUT_LDS && !d->tile_key && L >= 2 && d->dims[L] <= 16 && FB_NW == 8 && KCo >= 8 && (KCo & 1) == 0 &&
+        lds + (size_t)KCo * 512 <= 160 * 1024) {
+      a.out_lds = 1;
+      lds += (size_t)KCo * 512;
+    }
+  }
   if (d->tile_key) {
     // a wide grouped output leaves as whole rows through a staging area behind the activation tile (mlp_fwd_fused_body)
     const int No = d->dims[d->n_layers], NTo = (No + 31) / 32;

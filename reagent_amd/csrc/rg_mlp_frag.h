@@ -49,6 +49,7 @@ struct MlpArgs {
   long group_stride;              // elements between the groups' fragment sets of the last layer (this direction)
   int out_scatter;                // forward: output row r goes to out32[rowmap[r]]
   int stage_out;                  // grouped forward: the output leaves as whole rows through the LDS behind the activation tile
+  int out_lds;                    // forward: a thin output layer's weight fragments are copied (LDS-DMA) behind the activation tile
   int x_is_f32, x2_is_f32;
   float* out32;  // forward output [batch, dims[L]] fp32
   long ldo;
@@ -415,6 +416,46 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
     }
   }
   mfma_drain();
+}
+
+// Thin output layer (<= 16 outputs: DQN's Q-values, a critic's scalar) with its weights resident in LDS.  Every workgroup
+// needs the same 16 KB of B fragments at the end of its life, and tile_kloop fetches them from L2 in a chain of ~2000-cycle
+// round trips.  The fragments' valid half (lanes of columns 0..15: 512 bytes per 16-chunk) is instead copied once, by
+// LDS-DMA at the top of the kernel, into the 30 KB of LDS behind the activation tile (out_lds_prefetch), and the loop below
+// reads both operands from LDS.  A lane of a padding column (16..31) reads its neighbour's record: it only feeds output
+// columns that are not stored.  Measured (round 3, profiles/microbench/fwd_phases with its stamps inside the output layer):
+// the K loop of the output layer 3.8k -> 2.2k cycles, the forward launch 84.0 -> 82.8 us (-1.3 %; C2 step same box
+// 0.538 -> 0.531-0.538 ms).  The phase table's "output layer 8.7k" overstates what there was to win: its closing stamp waits
+// (vmcnt(0)) for the output stores, which a wave of the product kernel does not.
+__device__ __forceinline__ void out_lds_prefetch(const bf16_t* wf, int KC, char* wo, int wave, int n_waves, int lane) {
+  const int cl = lane & 31, src_lane = (cl & 15) + 32 * (cl >> 4);
+  for (int i = wave; i < KC / 2; i += n_waves) {  // one DMA = the records of chunks 2i (lanes 0..31) and 2i+1 (lanes 32..63)
+    const int chunk = 2 * i + (lane >> 5);
+    global_load_lds_b128_cached(wf + (long)chunk * 512 + src_lane * 8, wo + i * 1024);
+  }
+}
+__device__ __forceinline__ f32x16 tile_kloop_ldsb(const bf16_t* act, int pitch, const char* wo, int tm, int lane, int kc_lo,
+                                                  int kc_hi) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const bf16_t* arow = act + (tm * 32 + lr) * pitch + lg * 8;
+  const char* brec = wo + ((lr & 15) + 16 * lg) * 16;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int kc = kc_lo;
+  for (; kc + 4 <= kc_hi; kc += 4) {
+    u16x8 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i] = *(const u16x8*)(arow + (kc + i) * 16);
+      bf[i] = *(const u16x8*)(brec + (kc + i) * 512);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma_32x32x16_bf16(af[i], bf[i], acc);
+  }
+  for (; kc < kc_hi; ++kc)
+    acc = mfma_32x32x16_bf16(*(const u16x8*)(arow + kc * 16), *(const u16x8*)(brec + kc * 512), acc);
+  return acc;
 }
 
 // one 32x32 output tile (row tile tm, weight n-tile nt) over K; used for narrow / irregular widths.

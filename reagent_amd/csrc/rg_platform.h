@@ -102,6 +102,16 @@ __device__ __forceinline__ void global_load_lds_b128(const void* gsrc, const voi
                : "v"(gsrc), "s"(dst)
                : "memory");
 }
+// the same without the streaming hint: data every workgroup re-reads (a thin output layer's weights)
+__device__ __forceinline__ void global_load_lds_b128_cached(const void* gsrc, const void* lds_wave_base) {
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
 // wait until at most n vector-memory operations of this wave (LDS-DMA included) are outstanding
 #define RG_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // s_barrier without the waits __syncthreads() attaches

@@ -96,6 +96,9 @@ static inline void sched_fence() {}
 static inline void global_load_lds_b128(const void* gsrc, const void* lds_wave_base) {
   memcpy((char*)lds_wave_base + lane_id() * 16, gsrc, 16);
 }
+static inline void global_load_lds_b128_cached(const void* gsrc, const void* lds_wave_base) {
+  memcpy((char*)lds_wave_base + lane_id() * 16, gsrc, 16);
+}
 #define RG_WAIT_VMCNT(n) ((void)0)
 static inline void raw_barrier() { __syncthreads(); }
 #define RG_SETPRIO(n) ((void)0)
