@@ -388,10 +388,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                                 self._f32c(b.reward).reshape(-1), self._f32c(b.not_terminal).reshape(-1), self.gamma, alpha,
                                 self._y, self._dq1, self._dq2 if has_q2 else None, self._parts["l1"],
                                 self._parts["l2"] if has_q2 else None)
-            P = self._parts["l1"].numel()
-            ops.reduce_sum(self._parts["l1"], P, 1.0 / B, self._losses["q1"])
+            self._loss_mean("q1", self._parts["l1"], 1.0 / B, self._losses["q1"])
             if has_q2:
-                ops.reduce_sum(self._parts["l2"], P, 1.0 / B, self._losses["q2"])
+                self._loss_mean("q2", self._parts["l2"], 1.0 / B, self._losses["q2"])
             self._critic_metrics(b, alpha)
             return
         # a' = actor(s'), log_prob'  (actor frozen in this segment)
@@ -425,11 +424,30 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                             self._lpn, self._f32c(b.reward).reshape(-1), self._f32c(b.not_terminal).reshape(-1),
                             self.gamma, alpha, self._y, self._dq1, self._dq2 if has_q2 else None, self._parts["l1"],
                             self._parts["l2"] if has_q2 else None)
-        P = self._parts["l1"].numel()
-        ops.reduce_sum(self._parts["l1"], P, 1.0 / B, self._losses["q1"])
+        self._loss_mean("q1", self._parts["l1"], 1.0 / B, self._losses["q1"])
         if has_q2:
-            ops.reduce_sum(self._parts["l2"], P, 1.0 / B, self._losses["q2"])
+            self._loss_mean("q2", self._parts["l2"], 1.0 / B, self._losses["q2"])
         self._critic_metrics(b, alpha)
+
+    # The native step evaluates a segment's mean loss inside the reduce launch of that network's weight gradient
+    # (rg_mlp_wgrad_fused's sum_in, the arithmetic of rg_reduce_sum: same bits) instead of its own launch — nobody reads the
+    # loss before the backward of the same segment has been enqueued there.  The generator path (train_step_gen yields the
+    # loss before its backward) and stacks off the fused kernels keep the separate launch.
+    _fold_losses = False
+    _tails: dict = {}  # (replaced by a fresh dict in every native step; empty outside)
+
+    def _loss_mean(self, key, part, scale, out):
+        from ..engine import FusedMLP
+
+        st = self._e[key]["stack"]
+        if self._fold_losses and isinstance(st, FusedMLP) and st.fold_tails and not (key == "actor" and self.add_kld_to_loss):
+            self._tails[key] = (part, scale, out)
+        else:
+            ops.reduce_sum(part, part.numel(), scale, out)
+
+    def _take_tail(self, key) -> dict:
+        tail = self._tails.pop(key, None)
+        return {"tail_sum": tail} if tail is not None else {}
 
     def _critic_metrics(self, b, alpha):
         """critic-segment means of sac_trainer.py:343-364 for the logger, taken while alpha is still the value the
@@ -455,7 +473,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         if grad_out is not None:
             dq = dq * grad_out
         held = held_gradients(e["slab"], e["params"])
-        e["stack"].backward(dq, self._x_t, e["dw"], e["db"])
+        e["stack"].backward(dq, self._x_t, e["dw"], e["db"], **self._take_tail(which))
         self._publish(e, held)
 
     def _actor_forward(self, b, noise_cur):
@@ -496,7 +514,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                            self.target_entropy, self._glp, self._dq1a, self._dq2a if has_q2 else None,
                            self._parts["la"], self._parts["ent"], v_cur=v_cur, crr_mode=crr_mode, crr_p0=crr_p0,
                            crr_clamp=crr_clamp, backprop_log_prob=self.backprop_through_log_prob)
-        ops.reduce_sum(self._parts["la"], self._parts["la"].numel(), 1.0 / B, self._losses["actor"])
+        self._loss_mean("actor", self._parts["la"], 1.0 / B, self._losses["actor"])
         if self.add_kld_to_loss:  # + kld_weight * KLD(batch statistics of the action || embedding prior), :282-306
             A = self.action_emb_mean.numel()
             if getattr(self, "_kld_coef", None) is None or self._kld_coef.device != dev:
@@ -538,7 +556,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                 ops.layer_norm_backward(dls[:, sl], self._ls_raw[:, sl], m, r, ln.weight.detach(), view(ln.weight),
                                         view(ln.bias), self._ln_ws, dz32=self._dls_raw[:, sl])
             dls = self._dls_raw
-        a["stack"].backward(dls, self._xs_t, a["dw"], a["db"])
+        a["stack"].backward(dls, self._xs_t, a["dw"], a["db"], **self._take_tail("actor"))
         self._publish(a, held)
 
     def _alpha_backward(self, grad_out=None):
@@ -702,6 +720,16 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         dev = b.action.float_features.device
         gs = 1.0 / self._dp_world
         it = iter(opts)
+        self._fold_losses, self._tails = True, {}
+        try:
+            return self._native_segments(b, B, A, dev, gs, it, opts, noise_next, noise_cur)
+        finally:
+            self._fold_losses = False
+            for part, scale, out in self._tails.values():  # (a segment whose backward did not take its tail)
+                ops.reduce_sum(part, part.numel(), scale, out)
+            self._tails = {}
+
+    def _native_segments(self, b, B, A, dev, gs, it, opts, noise_next, noise_cur):
         self._critic_forward(b, self._noise(B, A, dev, noise_next))
         fused = self._fused_updates(opts)  # Adam (+ soft update) + re-staging per network in one launch, or None
         for k in ("q1", "q2"):

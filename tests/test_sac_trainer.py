@@ -252,6 +252,9 @@ def test_fused_network_updates_equal_the_separate_launches(backend, monkeypatch)
     monkeypatch.setattr(ops, "_run", lambda name, meta, call: (launches.append(name), real(name, meta, call))[1])
     ta.train_step_native(b, n1, n2)
     assert launches.count("rg_mlp_update_fused") == 3 and "rg_soft_update" not in launches and "rg_mlp_stage_weights_fused" not in launches
+    # the three mean losses (q1, q2, actor) ride in the reduce launches of their networks' weight gradients: no launch of
+    # their own in the native step (alpha's loss is not a reduce_sum); the generator path keeps them
+    assert "rg_reduce_sum" not in launches
 
 
 def test_bf16_state_rows_from_the_sampler_equal_fp32_rows(backend):
