@@ -567,6 +567,12 @@ int rg_wide_head_mean_staged(const float* w, const float* b, int n_groups, int g
                              float* bbar, void* wfrag_fwd, rg_stream_t stream);
 int rg_qr_select_action(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
                         int32_t* key, rg_stream_t stream);
+/* ABI 7: rg_qr_select_action + rg_group_rows(key, n_groups = num_actions) in the launches of the latter (the key is
+ * evaluated by the counting launch and written to `key`): two launches instead of four for the grouped space of a*
+ * (qrdqn_trainer.py:210-214) or of the logged action */
+int rg_qr_select_group_rows(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
+                            int32_t* key, int n_tiles, int32_t* rowmap, int32_t* tile_key, int32_t* tile_begin,
+                            void* workspace, size_t workspace_bytes, rg_stream_t stream);
 int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldzt, const int32_t* rowmap,
                        const int32_t* tile_key, int padded_rows, const float* reward, const float* reward_boosts,
                        const float* not_terminal, double gamma, const float* gamma_exponent,

@@ -247,6 +247,7 @@ SIGNATURES = {
     "rg_wide_head_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_wide_head_mean_staged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rg_qr_select_action": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rg_qr_select_group_rows": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
     "rg_qr_compact_head": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_d, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "rg_group_head_wgrad_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),

@@ -80,10 +80,8 @@ __global__ void wide_mean_kernel(const float* __restrict__ w, const float* __res
 
 // key[b] = arg max_a (q[b, a] - 1e9 (1 - mask[b, a]))  (maxq; qrdqn_trainer.py:210-214, first maximum wins) or the
 // position of the 1 in the one-hot row mask[b, :] (SARSA: mask = next_action), A if the row is all zero
-__global__ void select_action_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ mask, int batch,
-                                     int A, int maxq, int* __restrict__ key) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
+__device__ __forceinline__ int select_action_row(const float* __restrict__ q, long ldq, const float* __restrict__ mask,
+                                                 int b, int A, int maxq) {
   const float* m = mask + (long)b * A;
   int best = A;
   if (maxq) {
@@ -99,24 +97,39 @@ __global__ void select_action_kernel(const float* __restrict__ q, long ldq, cons
     for (int a = A - 1; a >= 0; --a)
       if (m[a] != 0.f) best = a;
   }
-  key[b] = best;
+  return best;
+}
+
+__global__ void select_action_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ mask, int batch,
+                                     int A, int maxq, int* __restrict__ key) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  key[b] = select_action_row(q, ldq, mask, b, A, maxq);
 }
 
 // ---- the grouped row space: a stable counting sort by key, padded per group to whole 128-row tiles -------------
 // rowmap [128 * n_tiles]: batch row of every grouped row (-1: padding); tile_key [n_tiles]: group of each tile (-1:
 // empty tail tile); tile_begin [G + 1].  Keys >= G mean "no group": dropped.  Rows keep their batch order inside a
 // group (rank = rows of the same key in earlier 256-row blocks + earlier rows of the own block), so the layout —
-// and every sum taken over it — is deterministic.  Three launches, no host round trip.
+// and every sum taken over it — is deterministic.  Two launches, no host round trip.
 constexpr int GR_BLOCK = 256, GR_MAX_KEYS = 130;
 
-__global__ void group_count_kernel(const int* __restrict__ key, int batch, int G, int* __restrict__ block_hist,
-                                   int* __restrict__ rowmap, int padded_rows) {
+// sel_mask != null: the key is the row's selected action (rg_qr_select_action's rule, evaluated here and written to `key`)
+__global__ void group_count_kernel(int* __restrict__ key, int batch, int G, int* __restrict__ block_hist,
+                                   int* __restrict__ rowmap, int padded_rows, const float* __restrict__ sel_q, long sel_ldq,
+                                   const float* __restrict__ sel_mask, int sel_maxq) {
   __shared__ int hist[GR_MAX_KEYS];
   const int tid = threadIdx.x, b = blockIdx.x * GR_BLOCK + tid;
   for (int i = tid; i <= G; i += GR_BLOCK) hist[i] = 0;
   __syncthreads();
   if (b < batch) {
-    const int k = key[b];
+    int k;
+    if (sel_mask) {
+      k = select_action_row(sel_q, sel_ldq, sel_mask, b, G, sel_maxq);
+      key[b] = k;
+    } else {
+      k = key[b];
+    }
     atomicAdd(&hist[k < G ? (k < 0 ? G : k) : G], 1);
   }
   for (int j = b; j < padded_rows; j += gridDim.x * GR_BLOCK) rowmap[j] = -1;
@@ -124,61 +137,55 @@ __global__ void group_count_kernel(const int* __restrict__ key, int batch, int G
   for (int i = tid; i <= G; i += GR_BLOCK) block_hist[blockIdx.x * (G + 1) + i] = hist[i];
 }
 
-// one workgroup of 16 waves: block_hist -> exclusive prefix over the blocks (in place; a wave per key, 64 blocks
-// per step), tile_begin, tile_key
-__global__ void group_scan_kernel(int* __restrict__ block_hist, int n_blocks, int G, int n_tiles, int* __restrict__ tile_begin,
-                                  int* __restrict__ tile_key) {
-  __shared__ int tiles[GR_MAX_KEYS];
-  __shared__ int tb[GR_MAX_KEYS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-  for (int g = wave; g < G; g += n_waves) {
-    int run = 0;
-    for (int b0 = 0; b0 < n_blocks; b0 += 64) {
-      const int blk = b0 + lane;
-      const int c = blk < n_blocks ? block_hist[blk * (G + 1) + g] : 0;
-      int incl = c;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = shfl_idx(incl, lane >= off ? lane - off : lane);
-        if (lane >= off) incl += t;
+// Every block derives what it needs from the raw per-block histogram itself — the rows of its keys in earlier blocks
+// (its base ranks) and the groups' totals (tile_begin) — 256 x (G + 1) integers, L2-resident: the single-workgroup scan
+// launch between count and scatter is gone (it was the launch that waited longest for a CU, up to 90 us, while the other
+// stream's forward held them all).  Block 0 also publishes tile_begin and tile_key.  Integer sums: order-independent.
+__global__ void group_scatter_kernel(const int* __restrict__ key, int batch, int G, const int* __restrict__ block_hist,
+                                     int n_blocks, int n_tiles, int* __restrict__ tile_begin, int* __restrict__ tile_key,
+                                     int* __restrict__ rowmap) {
+  __shared__ int keys[GR_BLOCK];
+  __shared__ int total[GR_MAX_KEYS], base[GR_MAX_KEYS], tb[GR_MAX_KEYS];
+  const int tid = threadIdx.x, me = blockIdx.x, b = me * GR_BLOCK + tid;
+  for (int g = tid; g <= G; g += GR_BLOCK) total[g] = base[g] = 0;
+  int k = b < batch ? key[b] : G;
+  if (k < 0 || k > G) k = G;
+  keys[tid] = k;
+  __syncthreads();
+  for (int blk = tid; blk < n_blocks; blk += GR_BLOCK) {
+    const int* h = block_hist + (long)blk * (G + 1);
+    for (int g = 0; g < G; ++g) {
+      const int c = h[g];
+      if (c) {
+        atomicAdd(&total[g], c);
+        if (blk < me) atomicAdd(&base[g], c);
       }
-      if (blk < n_blocks) block_hist[blk * (G + 1) + g] = run + incl - c;
-      run += shfl_idx(incl, 63);
     }
-    if (lane == 0) tiles[g] = (run + 127) / 128;
   }
   __syncthreads();
   if (tid == 0) {
     int run = 0;
     for (int g = 0; g < G; ++g) {
       tb[g] = run;
-      run += tiles[g];
+      run += (total[g] + 127) / 128;
     }
     tb[G] = run;
   }
   __syncthreads();
-  if (tid <= G) tile_begin[tid] = tb[tid];
-  for (int t = tid; t < n_tiles; t += blockDim.x) {
-    int g = -1;
-    if (t < tb[G])
-      for (int q = 0; q < G; ++q)
-        if (t >= tb[q] && t < tb[q + 1]) g = q;
-    tile_key[t] = g;
+  if (me == 0) {
+    if (tid <= G) tile_begin[tid] = tb[tid];
+    for (int t = tid; t < n_tiles; t += GR_BLOCK) {
+      int g = -1;
+      if (t < tb[G])
+        for (int q = 0; q < G; ++q)
+          if (t >= tb[q] && t < tb[q + 1]) g = q;
+      tile_key[t] = g;
+    }
   }
-}
-
-__global__ void group_scatter_kernel(const int* __restrict__ key, int batch, int G, const int* __restrict__ block_base,
-                                     const int* __restrict__ tile_begin, int* __restrict__ rowmap) {
-  __shared__ int keys[GR_BLOCK];
-  const int tid = threadIdx.x, b = blockIdx.x * GR_BLOCK + tid;
-  int k = b < batch ? key[b] : G;
-  if (k < 0 || k > G) k = G;
-  keys[tid] = k;
-  __syncthreads();
   if (k >= G) return;
-  int rank = block_base[blockIdx.x * (G + 1) + k];
+  int rank = base[k];
   for (int i = 0; i < tid; ++i) rank += keys[i] == k ? 1 : 0;
-  rowmap[tile_begin[k] * 128 + rank] = b;
+  rowmap[tb[k] * 128 + rank] = b;
 }
 
 // ---- quantile-Huber loss on compact rows (qrdqn_trainer.py:137-160, huber :217-218) ---------------------------
@@ -456,11 +463,27 @@ int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int3
   if (!workspace || workspace_bytes < rg_group_rows_workspace_bytes(batch, n_groups)) return RG_EWORKSPACE;
   const int nblk = (batch + GR_BLOCK - 1) / GR_BLOCK;
   int* hist = (int*)workspace;
-  RG_LAUNCH(group_count_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, key, batch, n_groups, hist, rowmap,
-            n_tiles * 128);
-  RG_LAUNCH(group_scan_kernel, dim3(1), dim3(1024), (hipStream_t)stream, hist, nblk, n_groups, n_tiles, tile_begin, tile_key);
+  RG_LAUNCH(group_count_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, (int*)key, batch, n_groups, hist, rowmap,
+            n_tiles * 128, (const float*)nullptr, 0L, (const float*)nullptr, 0);
   RG_LAUNCH(group_scatter_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, key, batch, n_groups, (const int*)hist,
-            (const int*)tile_begin, rowmap);
+            nblk, n_tiles, tile_begin, tile_key, rowmap);
+  return (int)hipGetLastError();
+}
+
+int rg_qr_select_group_rows(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
+                            int32_t* key, int n_tiles, int32_t* rowmap, int32_t* tile_key, int32_t* tile_begin,
+                            void* workspace, size_t workspace_bytes, rg_stream_t stream) {
+  const int n_groups = num_actions;
+  if (!mask || !key || !rowmap || !tile_key || !tile_begin || batch <= 0 || n_groups <= 0 || n_groups + 1 > GR_MAX_KEYS ||
+      n_tiles < (batch + 127) / 128 + n_groups || (maxq && !q))
+    return RG_EINVAL;
+  if (!workspace || workspace_bytes < rg_group_rows_workspace_bytes(batch, n_groups)) return RG_EWORKSPACE;
+  const int nblk = (batch + GR_BLOCK - 1) / GR_BLOCK;
+  int* hist = (int*)workspace;
+  RG_LAUNCH(group_count_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, key, batch, n_groups, hist, rowmap,
+            n_tiles * 128, q, (long)ldq, mask, maxq);
+  RG_LAUNCH(group_scatter_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, (const int*)key, batch, n_groups,
+            (const int*)hist, nblk, n_tiles, tile_begin, tile_key, rowmap);
   return (int)hipGetLastError();
 }
 

@@ -713,6 +713,19 @@ def qr_select_action(q, mask, maxq: bool, key):
                                              key.data_ptr(), L.stream_ptr()))
 
 
+def qr_select_group_rows(q, mask, maxq: bool, key, n_tiles, rowmap, tile_key, tile_begin, workspace):
+    """qr_select_action + group_rows (n_groups = number of actions) in two launches"""
+    _chk_dev(q, mask, key, rowmap, tile_key, tile_begin, workspace)
+    B, A = mask.shape
+    assert mask.is_contiguous() and mask.dtype == F32 and key.dtype == torch.int32 and key.numel() == B
+    assert rowmap.numel() == n_tiles * 128 and tile_key.numel() == n_tiles
+    _run("rg_group_rows", dict(B=B, G=A),
+         lambda: L.lib().rg_qr_select_group_rows(L.ptr(q), _ld(q) if q is not None else 0, mask.data_ptr(), B, A, int(maxq),
+                                                 key.data_ptr(), n_tiles, rowmap.data_ptr(), tile_key.data_ptr(),
+                                                 tile_begin.data_ptr(), workspace.data_ptr(), workspace.numel() * 4,
+                                                 L.stream_ptr()))
+
+
 def qr_compact_head(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma, gamma_exponent, quantiles,
                     batch, num_atoms, dz, loss_partials, tile_losses=None):
     _chk_dev(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma_exponent, quantiles, dz, loss_partials,

@@ -49,6 +49,11 @@ class GroupedSpace:
         ops.group_rows(key, self.G, self.n_tiles, self.rowmap, self.tile_key, self.tile_begin, self._ws)
         return self
 
+    def build_selected(self, q, mask, maxq: bool, key: torch.Tensor):
+        """key = rg_qr_select_action(q, mask, maxq), then build(key) — in the two launches of the latter"""
+        ops.qr_select_group_rows(q, mask, maxq, key, self.n_tiles, self.rowmap, self.tile_key, self.tile_begin, self._ws)
+        return self
+
 
 class _Net:
     """one Q-network seen as trunk + grouped wide layer"""
@@ -184,10 +189,9 @@ class GroupedQR:
             sel = on if tr.double_q_learning else tg
             sel.ensure_mean()
             sel.st.forward(next_state, self.qbar_next, save=False)
-            ops.qr_select_action(self.qbar_next, tr._f32c(b.possible_next_actions_mask), True, self.key_next)
+            sp2 = self.sp_next.build_selected(self.qbar_next, tr._f32c(b.possible_next_actions_mask), True, self.key_next)
         else:  # SARSA: the logged next action (qrdqn_trainer.py:139-141); terminal rows carry none
-            ops.qr_select_action(None, tr._f32c(b.next_action), False, self.key_next)
-        sp2 = self.sp_next.build(self.key_next)
+            sp2 = self.sp_next.build_selected(None, tr._f32c(b.next_action), False, self.key_next)
         if not tr.maxq_learning:  # rows without a next action (SARSA: terminal) keep zero quantiles; the
             self.zt.zero_()       # masked arg max gives every row one, and the scatter then writes every row
         fused_forward_grouped(tg.st, tg.gh, next_state, sp2, self.zt, scatter=True, save=False)
@@ -216,8 +220,7 @@ class GroupedQR:
     def _forward_current(self, b, state):
         """current quantiles of the logged action (grouped space of the logged action; saved for the backward)"""
         tr, on = self.tr, self.online
-        ops.qr_select_action(None, tr._f32c(b.action), False, self.key_cur)
-        sp1 = self.sp_cur.build(self.key_cur)
+        sp1 = self.sp_cur.build_selected(None, tr._f32c(b.action), False, self.key_cur)
         fused_forward_grouped(on.st, on.gh, state, sp1, self.z, scatter=False, save=True)
 
     def all_q_values(self) -> torch.Tensor:
