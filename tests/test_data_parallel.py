@@ -22,6 +22,19 @@ def _build(kind):
     from reagent_amd.training import DQNTrainer, SACTrainer
 
     torch.manual_seed(0)  # identical initial weights on every rank
+    if kind == "qr_fused":  # QR-DQN on the grouped engine (qr_engine.py): the one-launch update with the wide layer as a grouped layer
+        import reagent_amd._lib as L
+        from reagent_amd.models import set_default_precision
+        from reagent_amd.training import QRDQNTrainer
+
+        set_default_precision(L.PREC_BF16)
+        try:
+            q = FullyConnectedDQN(12, 4, [256, 256], ["relu", "relu"], num_atoms=16)
+        finally:
+            set_default_precision(L.PREC_F32)
+        return QRDQNTrainer(q, q.get_target_network(), actions=["a", "b", "c", "d"], num_atoms=16,
+                            rl=RLParameters(gamma=0.9, target_update_rate=0.1, maxq_learning=True), double_q_learning=True,
+                            optimizer=Optimizer__Union.default(lr=0.001), evaluation=EvaluationParameters(calc_cpe_in_training=False))
     if kind in ("dqn_fused", "sac_fused", "dqn_x3"):  # fused kernels (bf16 / split-bf16): the one-launch updates under 1/world scaling
         import reagent_amd._lib as L
         from reagent_amd.models import set_default_precision
@@ -85,7 +98,7 @@ def _batches(kind, B):
 
     if kind == "sac_fused":
         return synthetic.policy_batch(B, 32, 2, seed=5)
-    if kind.startswith("dqn"):
+    if kind.startswith("dqn") or kind == "qr_fused":
         return synthetic.dqn_batch(B, 12, 4, seed=5, p_impossible=0.2)
     if kind == "crr":
         return synthetic.dqn_batch(B, 12, 4, seed=5, p_impossible=0.2, with_propensity=True)
@@ -103,7 +116,7 @@ def _step(kind, tr, d, noise=None):
         lightning_like_step(tr, tr._test_opts, synthetic.to_dqn_input(d))
     elif kind == "dqn_deferred":  # async all-reduce, Adam joined at the start of the next step
         tr.train_step_native(synthetic.to_dqn_input(d), defer_update=True)
-    elif kind in ("dqn", "crr", "dqn_fused", "dqn_x3"):
+    elif kind in ("dqn", "crr", "dqn_fused", "dqn_x3", "qr_fused"):
         tr.train_step_native(synthetic.to_dqn_input(d))
     elif kind == "td3":
         tr.train_step_native(synthetic.to_policy_input(d), noise[0])
@@ -127,10 +140,14 @@ def _worker(rank, world, port, kind, out_dir):
     noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
     my_noise = tuple(n[rank * B // 2 : (rank + 1) * B // 2].contiguous() for n in noise)
     tr = _build(kind).enable_data_parallel()
-    fused = kind in ("dqn_fused", "sac_fused", "dqn_x3")
+    fused = kind in ("dqn_fused", "sac_fused", "dqn_x3", "qr_fused")
     for _ in range(3 if fused else 2):  # (the one-launch update starts at the second step)
         _step(kind, tr, half, my_noise)
-    if fused:
+    if kind == "qr_fused":
+        from reagent_amd.qr_engine import GroupedQR
+
+        assert isinstance(tr._qs, GroupedQR) and isinstance(tr._fused_plan, dict) and tr._fused_plan["desc"].group_rows[2] == 16
+    elif fused:
         from reagent_amd.engine import FusedMLP
 
         st = tr._qs if kind.startswith("dqn") else tr._e["q1"]["stack"]
@@ -239,12 +256,12 @@ def test_rccl_async_reduce_single_rank_group():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["dqn_fused", "sac_fused", "dqn_x3"])
+@pytest.mark.parametrize("kind", ["dqn_fused", "sac_fused", "dqn_x3", "qr_fused"])
 def test_two_ranks_on_the_fused_engine_stay_bit_identical(tmp_path, emu_lib, kind):
     """bf16 fused stacks under data parallelism: the one-launch Adam + soft update + re-staging (rg_mlp_update_fused,
     engine.FusedUpdate) with the 1/world factor folded in; replicas bit-identical, and close to the single-process
     run on the concatenated batch (bf16 gradients summed in another order: a few weights move by up to lr per step)"""
-    port = 29500 + (os.getpid() % 2000) + {"dqn_fused": 11, "sac_fused": 12, "dqn_x3": 13}[kind]
+    port = 29500 + (os.getpid() % 2000) + {"dqn_fused": 11, "sac_fused": 12, "dqn_x3": 13, "qr_fused": 14}[kind]
     mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     for a, b in zip(r0, r1):
