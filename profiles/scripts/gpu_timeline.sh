@@ -2,7 +2,7 @@
 # per-kernel timeline of ONE step (rocprofv3 kernel trace): bash profiles/scripts/gpu_timeline.sh <config> <precision> [ENV=..]
 cd /root/repo; OUT=/root/repo/gpurun_out; export TMPDIR=/tmp; CFG=${1:-c2}; PREC=${2:-bf16}; shift 2
 D=$OUT/timeline_${CFG}_${PREC}
-(cd /tmp && env "$@" timeout 600 rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python /root/repo/bench.py --config $CFG --precision $PREC --steps 4 --warmup 3 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also --launch eager --no-graph > $D.log 2>&1; echo rc=$?)
+(cd /tmp && env "$@" timeout 600 rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python /root/repo/bench.py --config $CFG --precision $PREC --steps 4 --warmup 3 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also ${TL_LAUNCH:---launch eager --no-graph} > $D.log 2>&1; echo rc=$?)
 python - $D <<'PY'
 import csv, sys, glob, re
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

@@ -141,7 +141,12 @@ class _GraphedLoop:
         self.flush()
         torch.cuda.synchronize()
         dp = getattr(tr, "_dp_group", None) is not None
-        idx = torch.zeros(self.batch_size, dtype=torch.int64, device=dev) if static_indices else None
+        # Indices: a persistent buffer the captured sampler reads.  Filled by the caller (static_indices) or, by default,
+        # from the loop's index pool right before each replay (one 512 KB device copy) — the in-graph torch.randint was
+        # THREE kernel nodes (Philox offset bookkeeping + the draw: ~23 us per step, what made the replayed C2 step
+        # slower than eager launches).  index_pool_steps <= 1 keeps the draw inside the graph.
+        pooled = not static_indices and self.index_pool_steps > 1
+        idx = torch.zeros(self.batch_size, dtype=torch.int64, device=dev) if (static_indices or pooled) else None
         done = tr.all_batches_processed
         if not dp:
             g = torch.cuda.CUDAGraph()
@@ -162,12 +167,18 @@ class _GraphedLoop:
             graphs = (gs, gu, gc)
             self._graph_batch = batch
         tr.all_batches_processed = done  # the capture call ran the host side of a step, not the step
-        self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None)
+        self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None, pooled=pooled)
         return self.replay
 
     def replay(self, indices=None):
         G = self._graph
         if G["idx"] is not None:
+            if indices is None:
+                if not G["pooled"]:
+                    raise ValueError("this loop was captured with static_indices=True: replay(indices) needs them")
+                indices = self._draw_indices()
+                if indices is None:
+                    indices = self.rb.sample_index_batch(self.batch_size)
             G["idx"].copy_(indices)
         if not G["dp"]:
             G["graphs"][0].replay()

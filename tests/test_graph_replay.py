@@ -157,7 +157,7 @@ def _c2_loop(dev, capacity=8192, batch=1024, precision=L.PREC_BF16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("draw", ["static_indices", "device_rng"])
+@pytest.mark.parametrize("draw", ["static_indices", "device_rng", "device_pool"])
 def test_dqn_loop_graph_replay_equals_eager(draw):
     dev = torch.device("cuda")
     L.lib()
@@ -167,7 +167,10 @@ def test_dqn_loop_graph_replay_equals_eager(draw):
     params = {}
     for mode in ("eager", "graph"):
         loop, tr = _c2_loop(dev)
-        loop.index_pool_steps = 1  # a draw per step, as inside the captured graph (the eager loop's default draws 32 steps' worth at once)
+        if draw != "device_pool":
+            loop.index_pool_steps = 1  # a draw per step, inside the captured graph too
+        # device_pool (the default): eager steps and replays both take their indices from the loop's pool (32 steps per
+        # torch.randint); a replay copies its row into the buffer the captured sampler reads
         torch.cuda.manual_seed(77)
         out = []
         if mode == "eager":
