@@ -149,9 +149,10 @@ class _GraphedLoop:
         idx = torch.zeros(self.batch_size, dtype=torch.int64, device=dev) if (static_indices or pooled) else None
         done = tr.all_batches_processed
         if not dp:
+            extra = self._capture_buffers(dev)  # persistent inputs besides the indices (the policy loop's noise)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self._eager_step(idx)
+                out = self._eager_step(idx, **extra)
             graphs = (g,)
         else:
             if not hasattr(tr, "native_forward_backward"):
@@ -167,8 +168,14 @@ class _GraphedLoop:
             graphs = (gs, gu, gc)
             self._graph_batch = batch
         tr.all_batches_processed = done  # the capture call ran the host side of a step, not the step
-        self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None, pooled=pooled)
+        self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None, pooled=pooled, extra=extra if not dp else {})
         return self.replay
+
+    def _capture_buffers(self, dev) -> dict:
+        return {}
+
+    def _refill_capture_buffers(self, extra: dict):
+        pass
 
     def replay(self, indices=None):
         G = self._graph
@@ -180,6 +187,8 @@ class _GraphedLoop:
                 if indices is None:
                     indices = self.rb.sample_index_batch(self.batch_size)
             G["idx"].copy_(indices)
+        if G["extra"]:
+            self._refill_capture_buffers(G["extra"])
         if not G["dp"]:
             G["graphs"][0].replay()
             self._replays += 1
@@ -353,11 +362,80 @@ class OfflinePolicyLoop(_GraphedLoop):
                                               state_dtype=self.state_dtype)
         return self.maker(tup)
 
-    def step(self, indices: Optional[torch.Tensor] = None, **noise):
-        return self.trainer.train_step_native(self.make_batch(indices if indices is not None else self._draw_indices()), **noise)
+    # The actor's two N(0,1) draws of `noise_pool_steps` steps come from ONE torch.randn launch (SAC: noise_next, noise_cur of
+    # train_step_native; a draw per step is two launches in an eager step and six kernel nodes in a captured one).  1 = a draw
+    # per step inside the trainer.  Same distribution, another position in torch's random stream; the pool is re-drawn from
+    # its recorded RNG state when a checkpoint is restored.
+    noise_pool_steps = 8
+    _npool = None
+    _npool_pos = 0
+    _npool_key = None
+    _npool_rng = None
+    _noise_dim = None
 
-    def _eager_step(self, indices=None):
-        return self.step(indices)
+    def _noise_pooled(self) -> bool:
+        if getattr(self, "_noise_ok", None) is None:
+            import inspect
+
+            params = inspect.signature(self.trainer.train_step_native).parameters
+            self._noise_ok = "noise_next" in params and "noise_cur" in params
+        return self._noise_ok and self.noise_pool_steps > 1
+
+    def _draw_noise(self, A: int, dev) -> dict:
+        if not self._noise_pooled() or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            return {}
+        key = (self.batch_size, A, self.noise_pool_steps)
+        if self._npool is None or self._npool_key != key or self._npool_pos >= self.noise_pool_steps:
+            self._npool_rng = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else torch.get_rng_state()
+            self._npool = torch.randn(self.noise_pool_steps, 2, self.batch_size, A, device=dev)
+            self._npool_pos, self._npool_key = 0, key
+        row = self._npool[self._npool_pos]
+        self._npool_pos += 1
+        return dict(noise_next=row[0], noise_cur=row[1])
+
+    def step(self, indices: Optional[torch.Tensor] = None, **noise):
+        batch = self.make_batch(indices if indices is not None else self._draw_indices())
+        if not noise:
+            a = batch.action.float_features
+            self._noise_dim = a.shape[1]
+            noise = self._draw_noise(a.shape[1], a.device)
+        return self.trainer.train_step_native(batch, **noise)
+
+    def _eager_step(self, indices=None, **noise):
+        return self.step(indices, **noise)
+
+    def _capture_buffers(self, dev) -> dict:
+        if not self._noise_pooled() or self._noise_dim is None:
+            return {}
+        shape = (self.batch_size, self._noise_dim)
+        return dict(noise_next=torch.zeros(shape, device=dev), noise_cur=torch.zeros(shape, device=dev))
+
+    def _refill_capture_buffers(self, extra: dict):
+        dev = extra["noise_next"].device
+        row = self._draw_noise(self._noise_dim, dev)
+        extra["noise_next"].copy_(row["noise_next"])
+        extra["noise_cur"].copy_(row["noise_cur"])
+
+    def checkpoint(self) -> dict:
+        ck = super().checkpoint()
+        if self._npool is not None and self._npool_pos < self.noise_pool_steps:
+            ck["noise_pool"] = dict(rng=self._npool_rng, pos=self._npool_pos, key=self._npool_key)
+        return ck
+
+    def load_checkpoint(self, ckpt: dict):
+        super().load_checkpoint(ckpt)
+        self._npool = self._npool_key = None
+        self._npool_pos = 0
+        np_ = ckpt.get("noise_pool")
+        if np_ is not None:  # re-draw the pool the saved loop was in the middle of, from the RNG state it was drawn at
+            dev = torch.device(self.rb.device)
+            cuda = dev.type == "cuda"
+            now = torch.cuda.get_rng_state(dev) if cuda else torch.get_rng_state()
+            (torch.cuda.set_rng_state(np_["rng"].cpu(), dev) if cuda else torch.set_rng_state(np_["rng"].cpu()))
+            B, A, P = np_["key"]
+            self._npool = torch.randn(P, 2, B, A, device=dev)
+            self._npool_pos, self._npool_key, self._npool_rng = int(np_["pos"]), tuple(np_["key"]), np_["rng"]
+            (torch.cuda.set_rng_state(now, dev) if cuda else torch.set_rng_state(now))
 
     def flush(self):
         self._flush_graph()

@@ -122,6 +122,18 @@ def test_loops_resume_bit_identically_across_an_index_pool_boundary(emu_lib, tmp
     _run(_dqn_loop, tmp_path, pool=1)
 
 
+def test_sac_loop_resumes_across_a_noise_pool_boundary(emu_lib, tmp_path):
+    """the actor's noise comes from a pool too (OfflinePolicyLoop.noise_pool_steps): saved after step 3 of a pool of 4 (re-drawn
+    from its recorded RNG state on restore), the continuation crosses into the next pool; and with a draw per step"""
+    for n in (4, 1):
+        def make(seed=0, n=n, **kw):
+            loop, tr = _sac_loop(seed=seed, **kw)
+            loop.noise_pool_steps = n
+            return loop, tr
+
+        _run(make, tmp_path)
+
+
 def test_index_pool_draws_are_uniform_picks_of_valid_slots(emu_lib):
     loop, _ = _dqn_loop()
     loop.index_pool_steps = 4

@@ -199,7 +199,8 @@ def test_dqn_loop_graph_replay_equals_eager(draw):
 
 
 @pytest.mark.gpu
-def test_sac_loop_graph_replay_equals_eager():
+@pytest.mark.parametrize("draw", ["device_rng", "pools"])
+def test_sac_loop_graph_replay_equals_eager(draw):
     import numpy as np
 
     from reagent_amd.core.parameters import CONTINUOUS_TRAINING_ACTION_RANGE as R
@@ -230,7 +231,10 @@ def test_sac_loop_graph_replay_equals_eager():
     res = {}
     for mode in ("eager", "graph"):
         loop, tr = build()
-        loop.index_pool_steps = 1
+        if draw == "device_rng":  # a draw per step, inside the captured graph too
+            loop.index_pool_steps = loop.noise_pool_steps = 1
+        # pools (the default): indices and the actor's noise of several steps per draw; a replay copies its rows into the
+        # buffers the captured step reads
         torch.cuda.manual_seed(11)
         out = []
         if mode == "eager":
