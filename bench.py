@@ -505,7 +505,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
             # eager step costs the host 0.3-1.2 ms.  Calibrate outside the timed region (every rank takes the same
             # decision: the slowest rank's times count).
             def timed(fn, n=max(8, min(args.steps, 30))):
-                best = None
+                best, host = None, 0.0
                 for _ in range(2):  # the better of two regions: a region of a few ms is at the mercy of a clock ramp
                     fn()
                     loop.flush()
@@ -513,24 +513,30 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
                     t = time.perf_counter()
                     for _ in range(n):
                         fn()
+                    host = max(host, (time.perf_counter() - t) / n)  # what the host needed to enqueue a step
                     loop.flush()
                     barrier()
                     dt = (time.perf_counter() - t) / n
                     best = dt if best is None else min(best, dt)
-                return best
+                return best, host
 
-            t_graph, t_eager = timed(replay), timed(loop.step)
+            (t_graph, _), (t_eager, host_eager) = timed(replay), timed(loop.step)
             if dist is not None:
-                tt = torch.tensor([t_graph, t_eager], device=device, dtype=torch.float64)
+                tt = torch.tensor([t_graph, t_eager, host_eager], device=device, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                t_graph, t_eager = tt.tolist()
-            # a tie goes to the graph: the same GPU time for 0.02 ms instead of 0.3-1.2 ms of host time per step
-            use_graph = launch == "graph" or (launch == "auto" and t_graph <= 1.01 * t_eager)
+                t_graph, t_eager, host_eager = tt.tolist()
+            # A tie goes to the graph: the same GPU time for 0.02 ms instead of 0.3-1.2 ms of host time per step.  And where
+            # the eager path has little margin over its own host time (>= half of the step: one slower or busier host and
+            # the loop is host-bound — seen on a pool box: enqueue 0.58 ms/step, C2 at 0.59 instead of 0.53 ms), the graph
+            # may cost up to 3 % of GPU time.
+            margin = 1.03 if host_eager >= 0.5 * t_eager else 1.01
+            use_graph = launch == "graph" or (launch == "auto" and t_graph <= margin * t_eager)
             what = ("one HIP graph per step (sampler, forwards, head, backward, wgrad, update; its indices copied in from the index pool)" if world == 1 else
                     "three HIP graphs per step (sample | update | forward+backward), the RCCL all-reduce of the gradient "
                     "slab launched eagerly between them")
             graph_note = (f"{'graph replay: ' + what if use_graph else 'eager stream launches'}; calibration "
-                          f"{t_graph * 1e3:.3f} ms/step replayed vs {t_eager * 1e3:.3f} ms/step eager")
+                          f"{t_graph * 1e3:.3f} ms/step replayed vs {t_eager * 1e3:.3f} ms/step eager "
+                          f"(eager host enqueue {host_eager * 1e3:.3f} ms/step)")
             step = replay if use_graph else loop.step
             if not use_graph:
                 loop.release_graph()  # eager steps then pass Adam's coefficients per launch (no tick kernel)
