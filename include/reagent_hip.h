@@ -270,6 +270,14 @@ typedef struct {
                 * layer, reagent/training/qrdqn_trainer.py:108-194, as dims[l+1] / group_rows[l] independent
                 * [group_rows[l], dims[l]] layers): its three fragment buffers are laid out as rg_group_weights_stage
                 * writes them (group g at g * rg_group_wfrag_elems elements).  bf16 stacks only (x3 == 0). */
+  /* ABI 7, replayed steps (a captured HIP graph must not need launch arguments that change from step to step):
+   * sched_pre_ticked != 0 (_sched entry point only): the step is already counted in sched[0] — by the sampler launch of the
+   * same step, rg_replay_dqn_batch_pooled — so the coefficients of step sched[0] apply and no rg_sched_tick follows;
+   * post_tick != NULL: *post_tick = (*post_tick + 1) % post_tick_mod when the launch is done with it (the cursor of the
+   * index pool the next step's sampler reads). */
+  int32_t sched_pre_ticked;
+  int32_t post_tick_mod;
+  int64_t* post_tick;
 } rg_mlp_update_desc; /* host struct */
 int rg_mlp_update_fused(const rg_mlp_update_desc* d, double lr, double beta1, double beta2, double eps,
                         double weight_decay, double bias_correction1, double bias_correction2_sqrt,
@@ -459,6 +467,12 @@ typedef struct {
 } rg_replay_view; /* host struct */
 int rg_replay_dqn_batch(const rg_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
                         const float* quantiles, const rg_dqn_batch_out* out, rg_stream_t stream);
+/* ABI 7: the same launch for a replayed step: index_pool [pool rows][batch] int64, the row sampled is *cursor (device; advanced
+ * by the step's rg_mlp_update_fused_sched through rg_mlp_update_desc.post_tick); pre_tick_sched (nullable): the device-resident
+ * Adam schedule whose step count this launch advances (sched[0] += 1, see rg_mlp_update_desc.sched_pre_ticked). */
+int rg_replay_dqn_batch_pooled(const rg_replay_view* view, const int64_t* index_pool, const int64_t* cursor,
+                               double* pre_tick_sched, int batch, const rg_norm_col* cols, const float* quantiles,
+                               const rg_dqn_batch_out* out, rg_stream_t stream);
 
 /* *bad_flag (device int, zeroed by the caller) becomes 1 if a sampled row holds an action outside
  * [0, n_actions) or a next_action outside [0, n_actions] (F.one_hot would raise), 2 if an index is

@@ -109,6 +109,9 @@ class MlpUpdateDesc(ctypes.Structure):
         ("target_wfrag_fwd", c_void_p * MLP_MAX_LAYERS),
         ("x3", ctypes.c_int32),
         ("group_rows", ctypes.c_int32 * MLP_MAX_LAYERS),
+        ("sched_pre_ticked", ctypes.c_int32),
+        ("post_tick_mod", ctypes.c_int32),
+        ("post_tick", c_void_p),
     ]
 
 
@@ -206,6 +209,8 @@ SIGNATURES = {
                                     ctypes.POINTER(DqnBatchOut), c_void_p]),
     "rg_replay_dqn_batch": (c_int, [ctypes.POINTER(ReplayView), c_void_p, c_int, c_void_p, c_void_p,
                                      ctypes.POINTER(DqnBatchOut), c_void_p]),
+    "rg_replay_dqn_batch_pooled": (c_int, [ctypes.POINTER(ReplayView), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                            ctypes.POINTER(DqnBatchOut), c_void_p]),
     "rg_table_check_actions": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_void_p]),
     "rg_bcq_filter": (c_int, [c_void_p, c_int, c_int, c_d, c_void_p, c_void_p]),
     "rg_dqn_head_partials": (c_int, [c_int]),

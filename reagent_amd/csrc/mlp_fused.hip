@@ -857,6 +857,12 @@ struct UpdateArgs {
   // elements in — what rg_group_weights_stage writes.  bf16 stacks only.
   int Ng[FB_MAXL];
   long per_f[FB_MAXL], per_b[FB_MAXL];
+  // replayed steps (runtime._GraphedLoop): the sampler launch has already counted this step in sched[0]
+  // (sched_pre_ticked), and this launch advances the index pool's cursor for the next one — workgroup 0, when it is
+  // done; no other workgroup of this launch touches it
+  int pre_ticked;
+  long long* post_tick;
+  int post_tick_mod;
 };
 
 // the three fragment slots of W[n][k] (online forward / backward, target forward), both planes in split-bf16 mode —
@@ -906,7 +912,8 @@ __global__ void mlp_update_kernel(UpdateArgs U) {
     }
   }
   if (l < 0) return;
-  const AdamCoef coef = sched_coef(U.c, U.sched);
+  if (U.post_tick && i == 0) U.post_tick[0] = (U.post_tick[0] + 1) % U.post_tick_mod;
+  const AdamCoef coef = sched_coef(U.c, U.sched, U.pre_ticked);
   float mi = U.m[i], vi = U.v[i];
   const float pn = adam_element(coef, U.p[i], U.g[i], mi, vi);
   U.p[i] = pn;
@@ -960,7 +967,8 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
   __shared__ bf16_t tile[UT_ROWS * UT_PITCH];
   __shared__ bf16_t tile_lo[UT_ROWS * UT_PITCH];  // split-bf16: lo plane of the tile
   const int wg = blockIdx.x, tid = threadIdx.x;
-  const AdamCoef coef = sched_coef(U.c, U.sched);
+  const AdamCoef coef = sched_coef(U.c, U.sched, U.pre_ticked);
+  if (U.post_tick && wg == 0 && tid == 0) U.post_tick[0] = (U.post_tick[0] + 1) % U.post_tick_mod;
   if (wg >= T.tile_begin[U.n]) {
     // everything the tiles do not cover (biases; weights with odd shapes): one element per thread
     const long j = (long)(wg - T.tile_begin[U.n]) * blockDim.x + tid;
@@ -1481,6 +1489,10 @@ static int mlp_update_launch(const rg_mlp_update_desc* d, double lr, double beta
                  (float)(-step_size), (float)bias_correction2_sqrt, (float)grad_scale};
   U.tau = (float)tau; U.one_minus_tau = (float)(1.0 - tau);
   U.sched = sched;
+  U.pre_ticked = (sched && d->sched_pre_ticked) ? 1 : 0;
+  U.post_tick = (long long*)d->post_tick;
+  U.post_tick_mod = d->post_tick_mod > 0 ? d->post_tick_mod : 1;
+  if (d->sched_pre_ticked && !sched) return RG_EINVAL;
   U.x3 = d->x3 ? 1 : 0;
   // weights with 32-byte-addressable rows go to the tiled kernel, the rest of the slab to its
   // per-element workgroups (same launch)

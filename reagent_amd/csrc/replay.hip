@@ -309,8 +309,16 @@ struct ReplayBatchArgs {
   rg_dqn_batch_out o;
 };
 
+// cursor != null (rg_replay_dqn_batch_pooled, replayed HIP graphs): `indices` is a POOL of index rows [pool rows][batch]
+// and this launch samples row cursor[0]; pre_tick != null: the launch also counts the step in the device-resident Adam
+// schedule (sched[0] += 1: nobody reads it between this launch and the step's update, which is then told that the count
+// already includes it — rg_mlp_update_desc.sched_pre_ticked).  The update launch advances the cursor in turn
+// (rg_mlp_update_desc.post_tick): a replayed step needs neither an index copy nor a tick launch of its own.
 __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __restrict__ indices, int batch,
-                                        const rg_norm_col* __restrict__ cols, const float* __restrict__ quantiles) {
+                                        const rg_norm_col* __restrict__ cols, const float* __restrict__ quantiles,
+                                        const int64_t* __restrict__ cursor, double* __restrict__ pre_tick) {
+  if (cursor) indices += cursor[0] * (long)batch;
+  if (pre_tick && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) pre_tick[0] = pre_tick[0] + 1.0;
   __shared__ int64_t s_src[GATHER_ROWS_PER_WG];  // the row this piece reads: idx (state), next idx (next_state)
   __shared__ int64_t s_nxt[GATHER_ROWS_PER_WG];
   __shared__ int s_steps[GATHER_ROWS_PER_WG];
@@ -455,8 +463,9 @@ int rg_replay_gather(const rg_gather_col* cols, int ncols, int64_t capacity, int
   return (int)hipGetLastError();
 }
 
-int rg_replay_dqn_batch(const rg_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
-                        const float* quantiles, const rg_dqn_batch_out* out, rg_stream_t stream) {
+static int replay_dqn_batch_launch(const rg_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
+                                   const float* quantiles, const rg_dqn_batch_out* out, const int64_t* cursor,
+                                   double* pre_tick, rg_stream_t stream) {
   if (!view || !out || batch < 0) return RG_EINVAL;
   if (batch == 0) return RG_OK;
   const rg_replay_view& v = *view;
@@ -474,8 +483,20 @@ int rg_replay_dqn_batch(const rg_replay_view* view, const int64_t* indices, int 
     return RG_EUNSUPPORTED;  // callers fall back to rg_replay_nstep + rg_replay_gather + rg_make_dqn_input
   ReplayBatchArgs a{v, o};
   RG_LAUNCH(replay_dqn_batch_kernel, dim3((batch + GATHER_ROWS_PER_WG - 1) / GATHER_ROWS_PER_WG, 3), dim3(256),
-            (hipStream_t)stream, a, indices, batch, cols, quantiles);
+            (hipStream_t)stream, a, indices, batch, cols, quantiles, cursor, pre_tick);
   return (int)hipGetLastError();
+}
+
+int rg_replay_dqn_batch(const rg_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
+                        const float* quantiles, const rg_dqn_batch_out* out, rg_stream_t stream) {
+  return replay_dqn_batch_launch(view, indices, batch, cols, quantiles, out, nullptr, nullptr, stream);
+}
+
+int rg_replay_dqn_batch_pooled(const rg_replay_view* view, const int64_t* index_pool, const int64_t* cursor,
+                               double* pre_tick_sched, int batch, const rg_norm_col* cols, const float* quantiles,
+                               const rg_dqn_batch_out* out, rg_stream_t stream) {
+  if (!cursor) return RG_EINVAL;
+  return replay_dqn_batch_launch(view, index_pool, batch, cols, quantiles, out, cursor, pre_tick_sched, stream);
 }
 
 int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const uint8_t* terminal,

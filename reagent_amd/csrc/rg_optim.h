@@ -39,18 +39,20 @@ __device__ __forceinline__ float adam_element(const AdamCoef& c, float pi, float
 //   in double exactly as for the scalar entry points; steps past n use entry n (the host builds the table up to
 //   the step where both have reached their limit 1.0).
 // The divisions below are IEEE double operations, so the coefficients equal the host-computed ones bit for bit.
-__device__ __forceinline__ void sched_lookup(const double* __restrict__ sched, double& lr, double& bc1, double& bc2_sqrt) {
-  long t = (long)sched[0] + 1;
+// pre_ticked: the step has already been counted in sched[0] (by the sampler launch of a replayed step)
+__device__ __forceinline__ void sched_lookup(const double* __restrict__ sched, double& lr, double& bc1, double& bc2_sqrt,
+                                             int pre_ticked = 0) {
+  long t = (long)sched[0] + (pre_ticked ? 0 : 1);
   const long n = (long)sched[2];
   if (t > n) t = n;
   lr = sched[1];
   bc1 = sched[4 + 2 * (t - 1)];
   bc2_sqrt = sched[5 + 2 * (t - 1)];
 }
-__device__ __forceinline__ AdamCoef sched_coef(AdamCoef c, const double* __restrict__ sched) {
+__device__ __forceinline__ AdamCoef sched_coef(AdamCoef c, const double* __restrict__ sched, int pre_ticked = 0) {
   if (sched) {
     double lr, bc1, bc2s;
-    sched_lookup(sched, lr, bc1, bc2s);
+    sched_lookup(sched, lr, bc1, bc2s, pre_ticked);
     c.neg_step_size = (float)(-(lr / bc1));
     c.bc2_sqrt = (float)bc2s;
   }

@@ -378,10 +378,27 @@ def table_dqn_batch(table, indices, cols_dev, n_out, quantiles, out: dict):
                                             L.ptr(quantiles), ctypes.byref(o), L.stream_ptr()))
 
 
+class PooledIndices:
+    """The indices of a REPLAYED step (runtime._GraphedLoop): row `cursor[0]` (device int64) of `pool` [rows, batch]; the
+    sampler launch also counts the step in the device-resident Adam schedule `sched` (nullable), the step's one-launch update
+    advances the cursor (rg_replay_dqn_batch_pooled / rg_mlp_update_desc.sched_pre_ticked, post_tick)."""
+
+    def __init__(self, pool, cursor, sched=None):
+        assert pool.dtype == torch.int64 and pool.dim() == 2 and pool.is_contiguous() and cursor.dtype == torch.int64
+        self.pool, self.cursor, self.sched = pool, cursor, sched
+
+    def numel(self):
+        return self.pool.shape[1]
+
+
 def replay_dqn_batch(view: "L.ReplayView", indices, cols_dev, quantiles, out: dict) -> bool:
     """one-launch sample + input maker (+ normalize); False = shape not supported by the fused kernel"""
-    _chk_dev(indices, cols_dev, quantiles, *out.values())
-    assert indices.dtype == torch.int64 and indices.is_contiguous()
+    pooled = indices if isinstance(indices, PooledIndices) else None
+    if pooled is not None:
+        _chk_dev(pooled.pool, pooled.cursor, pooled.sched, cols_dev, quantiles, *out.values())
+    else:
+        _chk_dev(indices, cols_dev, quantiles, *out.values())
+        assert indices.dtype == torch.int64 and indices.is_contiguous()
     o = L.DqnBatchOut()
     for name in L.BATCH_OUT_FIELDS:
         t = out.get(name)
@@ -392,8 +409,13 @@ def replay_dqn_batch(view: "L.ReplayView", indices, cols_dev, quantiles, out: di
     rc = [0]
 
     def call():
-        rc[0] = L.lib().rg_replay_dqn_batch(ctypes.byref(view), L.ptr(indices), B, L.ptr(cols_dev), L.ptr(quantiles),
-                                            ctypes.byref(o), L.stream_ptr())
+        if pooled is not None:
+            rc[0] = L.lib().rg_replay_dqn_batch_pooled(ctypes.byref(view), pooled.pool.data_ptr(), pooled.cursor.data_ptr(),
+                                                       L.ptr(pooled.sched), B, L.ptr(cols_dev), L.ptr(quantiles),
+                                                       ctypes.byref(o), L.stream_ptr())
+        else:
+            rc[0] = L.lib().rg_replay_dqn_batch(ctypes.byref(view), L.ptr(indices), B, L.ptr(cols_dev), L.ptr(quantiles),
+                                                ctypes.byref(o), L.stream_ptr())
         return 0 if rc[0] == L.EUNSUPPORTED else rc[0]
 
     F_, A_, H_ = view.n_features, view.n_actions, view.update_horizon

@@ -418,12 +418,15 @@ class ReplayBuffer:
             return None
         if batch_size is None:
             batch_size = self._batch_size
-        if indices is None:
-            indices = self.sample_index_batch(batch_size)
+        if isinstance(indices, ops.PooledIndices):  # a replayed step: the row of an index pool a device cursor points at
+            assert indices.numel() == batch_size and self._num_valid_indices == self._replay_capacity
         else:
-            indices = indices.to(device=self.device, dtype=torch.int64)
-        assert len(indices) == batch_size
-        indices = indices.contiguous()
+            if indices is None:
+                indices = self.sample_index_batch(batch_size)
+            else:
+                indices = indices.to(device=self.device, dtype=torch.int64)
+            assert len(indices) == batch_size
+            indices = indices.contiguous()
         B, dev, F, A = batch_size, self.device, obs.shape[1], num_actions
         if self._decays_dev is None or self._decays_dev.device != dev:
             self._decays_dev = self._decays.reshape(-1).to(device=dev, dtype=torch.float32)

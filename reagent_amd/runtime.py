@@ -18,6 +18,7 @@ tails and slows them more than it hides; it is therefore OFF by default and kept
 1.237-1.241 against 1.179-1.181.  Two kernels sharing the memory system plus two cross-stream waits per step cost more
 than the 40 us they hide; not kept.)
 """
+import os
 from typing import Optional
 
 import torch
@@ -56,6 +57,20 @@ class _GraphedLoop:
     def _eager_step(self, indices=None):
         raise NotImplementedError
 
+    def _ensure_pool(self, dev):
+        """a pool with at least one undrawn row.  A full-size pool is refilled IN PLACE (a replayed graph may hold its
+        address); the shorter rest a checkpoint restored is replaced by a full one once it is used up."""
+        rb = self.rb
+        n, cap = rb._num_valid_indices, rb._replay_capacity
+        key = (n, cap, self.batch_size, self.index_pool_steps)
+        shape = (self.index_pool_steps, self.batch_size)
+        if self._pool is None or self._pool_key != key or (self._pool_pos >= self._pool.shape[0] and tuple(self._pool.shape) != shape):
+            self._pool = torch.randint(n, shape, device=dev)
+            self._pool_pos, self._pool_key = 0, key
+        elif self._pool_pos >= self._pool.shape[0]:
+            torch.randint(n, shape, out=self._pool)
+            self._pool_pos = 0
+
     def _draw_indices(self):
         """indices of the next batch from the pool, or None = let the buffer draw (sample_index_batch).  Same
         distribution as sample_index_batch: uniform with replacement over the valid slots."""
@@ -66,10 +81,7 @@ class _GraphedLoop:
         n, cap = rb._num_valid_indices, rb._replay_capacity
         if n == 0:
             return None  # the buffer raises its own error
-        key = (n, cap, self.batch_size, self.index_pool_steps)
-        if self._pool is None or self._pool_key != key or self._pool_pos >= self._pool.shape[0]:
-            self._pool = torch.randint(n, (self.index_pool_steps, self.batch_size), device=dev)
-            self._pool_pos, self._pool_key = 0, key
+        self._ensure_pool(dev)
         pick = self._pool[self._pool_pos]
         self._pool_pos += 1
         return pick if n == cap else rb._valid_indices()[pick]
@@ -148,11 +160,29 @@ class _GraphedLoop:
         pooled = not static_indices and self.index_pool_steps > 1
         idx = torch.zeros(self.batch_size, dtype=torch.int64, device=dev) if (static_indices or pooled) else None
         done = tr.all_batches_processed
+        cursor = None
         if not dp:
             extra = self._capture_buffers(dev)  # persistent inputs besides the indices (the policy loop's noise)
+            tick = self._cursor_protocol(dev) if pooled else None
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self._eager_step(idx, **extra)
+            if tick is not None:
+                # Device-side index cursor: the captured sampler reads row cursor[0] of the loop's index pool and counts
+                # the step in the Adam schedule, the captured one-launch update advances the cursor — a replay is the
+                # graph launch and nothing else (no index copy, no tick node)
+                from . import ops as _ops
+
+                cursor = tick["cursor"]
+                tr._graph_tick = tick
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        out = self._eager_step(_ops.PooledIndices(self._pool, cursor, tick["sched"]))
+                finally:
+                    tr._graph_tick = None
+                assert tick.get("used"), "the captured step did not take the one-launch update"
+                idx = None
+            else:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = self._eager_step(idx, **extra)
             graphs = (g,)
         else:
             if not hasattr(tr, "native_forward_backward"):
@@ -168,8 +198,14 @@ class _GraphedLoop:
             graphs = (gs, gu, gc)
             self._graph_batch = batch
         tr.all_batches_processed = done  # the capture call ran the host side of a step, not the step
-        self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None, pooled=pooled, extra=extra if not dp else {})
+        self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None, pooled=pooled, extra=extra if not dp else {},
+                           cursor=cursor, dev_pos=None, pool_ptr=self._pool.data_ptr() if cursor is not None else None)
         return self.replay
+
+    def _cursor_protocol(self, dev):
+        """None, or what a capture with a device-side index cursor needs (the DQN-family loop on the one-launch sampler and
+        the one-launch update: overridden there)"""
+        return None
 
     def _capture_buffers(self, dev) -> dict:
         return {}
@@ -179,6 +215,20 @@ class _GraphedLoop:
 
     def replay(self, indices=None):
         G = self._graph
+        if G["cursor"] is not None:
+            if indices is not None:
+                raise ValueError("this loop was captured with a device-side index cursor: replay() draws from the index pool")
+            dev = G["cursor"].device
+            self._ensure_pool(dev)
+            if self._pool.data_ptr() != G["pool_ptr"]:
+                raise RuntimeError("the index pool moved (replay buffer or batch size changed): capture the loop again")
+            if G["dev_pos"] != self._pool_pos:  # first replay, or eager steps in between drew from the pool
+                G["cursor"].fill_(self._pool_pos)
+            G["graphs"][0].replay()
+            self._pool_pos += 1
+            G["dev_pos"] = self._pool_pos % self.index_pool_steps
+            self._replays += 1
+            return G["out"]
         if G["idx"] is not None:
             if indices is None:
                 if not G["pooled"]:
@@ -302,6 +352,24 @@ class OfflineDqnLoop(_GraphedLoop):
 
     def _eager_step(self, indices=None):
         return self.trainer.train_step_native(self.make_batch(indices if indices is not None else self._draw_indices()))
+
+    def _cursor_protocol(self, dev):
+        tr, rb = self.trainer, self.rb
+        if os.environ.get("RG_GRAPH_CURSOR", "1") == "0":  # same-box A/B switch: indices copied in before each replay
+            return None
+        if not (self.fused_sampling and (self.fuse_norm or self.pre is None)) or rb._num_valid_indices != rb._replay_capacity:
+            return None
+        if getattr(tr, "_cpe", None) is not None or not isinstance(getattr(tr, "_fused_plan", None), dict):
+            return None  # (the warm-up steps of capture() have run: the one-launch update has shown itself by now)
+        opts = tr.native_optimizers()
+        sched = opts[0].schedule_for(0) if hasattr(opts[0], "schedule_for") else None
+        if sched is None:
+            return None
+        self._ensure_pool(dev)
+        if tuple(self._pool.shape) != (self.index_pool_steps, self.batch_size):
+            self._pool_pos = self._pool.shape[0]  # (the short rest of a restored checkpoint: start a full pool)
+            self._ensure_pool(dev)
+        return dict(cursor=torch.zeros(1, dtype=torch.int64, device=dev), mod=self.index_pool_steps, sched=sched.buf, used=False)
 
     def flush(self):
         """apply an update left pending by the last step (call before reading parameters)"""

@@ -530,6 +530,7 @@ class QStepCore(DQNTrainerBaseLightning):
     _update_pending = False
     _pending_reduce = None
     _fused_plan = None
+    _graph_tick = None
 
     def _fused_update(self, adam, soft) -> bool:
         """Adam + soft update + bf16 re-staging of both networks in ONE launch (rg_mlp_update_fused)
@@ -611,17 +612,27 @@ class QStepCore(DQNTrainerBaseLightning):
             d.wfrag_fwd[l], d.wfrag_bwd[l] = grouped.online.gh.wf.data_ptr(), grouped.online.gh.wb.data_ptr()
             d.target_wfrag_fwd[l] = grouped.target.gh.wf.data_ptr()
         tau = soft.param_groups[0]["tau"]
+        gt = self._graph_tick  # a step being captured for replay with a device-side index cursor (runtime._GraphedLoop)
+        d.sched_pre_ticked, d.post_tick_mod, d.post_tick = 0, 0, None
+        if gt is not None and sched is None:
+            raise RuntimeError("a replayed step counts its Adam steps on the device: enable_graph_mode first")
         if sched is not None:  # graph-safe: lr and the bias corrections come from HBM, the step is counted there
             from ..optimizer import capturing
 
             if not capturing():
                 sched.set_lr(group["lr"])
                 sched.pending += 1
+            if gt is not None:  # the step's sampler launch has counted it; this launch advances the index cursor
+                assert gt["sched"] is sched.buf
+                d.sched_pre_ticked, d.post_tick_mod, d.post_tick = 1, int(gt["mod"]), gt["cursor"].data_ptr()
             ops._run("rg_mlp_update_fused", dict(P=slab.total),
                      lambda: L.lib().rg_mlp_update_fused_sched(d, beta1, beta2, group["eps"], group["weight_decay"],
                                                                1.0 / self._dp_world, tau, sched.buf.data_ptr(),
                                                                L.stream_ptr()))
-            ops.sched_tick(sched.buf)
+            if gt is None:
+                ops.sched_tick(sched.buf)
+            else:
+                gt["used"] = True
         else:
             ops._run("rg_mlp_update_fused", dict(P=slab.total),
                      lambda: L.lib().rg_mlp_update_fused(d, group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
@@ -658,6 +669,8 @@ class QStepCore(DQNTrainerBaseLightning):
             self.all_batches_processed += 1
             self._update_pending = False
             return
+        if self._graph_tick is not None:  # the sampler launch has already counted the step for the one-launch update
+            raise RuntimeError("a step captured with a device-side index cursor needs the one-launch update")
         adam.grad_scale = 1.0 / self._dp_world
         adam.step()
         if cpe is not None:  # reward network and CPE q-network, in the reference's optimizer order
