@@ -306,3 +306,86 @@ def test_leaving_graph_mode_keeps_the_step_count(emu_lib):
         b.train_step_native(synthetic.to_dqn_input(batch, "cpu"))
     for x, y in zip(a.parameters(), b.parameters()):
         assert torch.equal(x, y)
+
+
+def test_replayed_step_protocol_on_the_interpreter(emu_lib):
+    """What a captured step with a device-side index cursor consists of, launch for launch, issued by hand on the SIMT
+    interpreter (graphs need the GPU; the protocol does not): rg_replay_dqn_batch_pooled reads row cursor[0] of the index pool
+    and counts the step in the Adam schedule, rg_mlp_update_fused_sched(sched_pre_ticked, post_tick) takes the coefficients of
+    the counted step and advances the cursor — and leaves the bits of eager steps on the same pool rows (sampler on explicit
+    indices, update with the count taken afterwards by rg_sched_tick): losses, weights, targets, Adam state, the cursor."""
+    from reagent_amd import ops
+    from reagent_amd.preprocessing import Preprocessor
+    from reagent_amd.replay_memory import ReplayBuffer
+    from reagent_amd.runtime import OfflineDqnLoop
+    from reagent_amd.training import DQNTrainer
+    from reagent_amd.training.dqn_trainer import enable_graph_mode
+
+    S, A, C, B, P = 24, 4, 512, 64, 3
+
+    def make():
+        set_default_precision(L.PREC_BF16)
+        try:
+            torch.manual_seed(3)
+            q = FullyConnectedDQN(S, A, [256, 256], ["relu", "relu"])
+        finally:
+            set_default_precision(L.PREC_F32)
+        tr = DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(A)],
+                        rl=RLParameters(gamma=0.9, target_update_rate=0.05, q_network_loss="huber"),
+                        optimizer=Optimizer__Union.default(lr=0.003), evaluation=EvaluationParameters(calc_cpe_in_training=False))
+        rb = ReplayBuffer(replay_capacity=C, batch_size=B, device="cpu")
+        rb.load_columns(synthetic.replay_contents(C, S, A, seed=9), mark_all_valid=True)
+        mean, std = synthetic.normalization_table(S, 7)
+        pre = Preprocessor({i: NormalizationParameters(feature_type="CONTINUOUS", mean=mean[i].item(), stddev=std[i].item())
+                            for i in range(S)}, device="cpu")
+        loop = OfflineDqnLoop(rb, tr, B, pre, state_dtype=torch.bfloat16)
+        loop.index_pool_steps = P
+        enable_graph_mode(tr)
+        return loop, tr
+
+    eager, te = make()
+    hand, th = make()
+    torch.manual_seed(77)
+    for _ in range(2):  # the warm-up of capture(): the one-launch update shows itself from the second step on
+        eager.step()
+    eager.flush()
+    torch.manual_seed(77)
+    for _ in range(2):
+        hand.step()
+    hand.flush()
+    assert torch.equal(eager._pool, hand._pool) and eager._pool_pos == hand._pool_pos == 2
+    rng = torch.get_rng_state()  # both continuations refill their pools from the same position of the random stream
+    tick = hand._cursor_protocol(torch.device("cpu"))
+    assert tick is not None and tick["mod"] == P
+    cursor, sched = tick["cursor"], tick["sched"]
+    losses_e, losses_h = [], []
+    for k in range(5):  # crosses the pool boundary twice (P = 3)
+        losses_e.append(eager.step().clone())
+        eager.flush()
+    torch.set_rng_state(rng)
+    for k in range(5):
+        # --- one "replay" by hand
+        hand._ensure_pool(torch.device("cpu"))
+        if k == 0:
+            cursor.fill_(hand._pool_pos)
+        assert int(cursor.item()) == hand._pool_pos
+        before = float(sched[0])
+        th._graph_tick = tick
+        try:
+            losses_h.append(hand._eager_step(ops.PooledIndices(hand._pool, cursor, sched)).clone())
+        finally:
+            th._graph_tick = None
+        assert tick["used"] and float(sched[0]) == before + 1.0
+        hand._pool_pos += 1
+        assert int(cursor.item()) == hand._pool_pos % P
+    # (outside a capture the host counts these steps itself; after real replays runtime.flush() does — note_graph_replays)
+    assert all(torch.equal(a, b) for a, b in zip(losses_e, losses_h))
+    for a, b in zip(list(te.q_network.parameters()) + list(te.q_network_target.parameters()),
+                    list(th.q_network.parameters()) + list(th.q_network_target.parameters())):
+        assert torch.equal(a, b)
+    oe, oh = te.native_optimizers()[0], th.native_optimizers()[0]
+    oe.materialize_steps()
+    oh.materialize_steps()
+    for pa, pb in zip(te.q_network.parameters(), th.q_network.parameters()):
+        assert torch.equal(oe.state[pa]["exp_avg"], oh.state[pb]["exp_avg"]) and torch.equal(oe.state[pa]["exp_avg_sq"], oh.state[pb]["exp_avg_sq"])
+        assert float(oe.state[pa]["step"]) == float(oh.state[pb]["step"]) == 7.0
