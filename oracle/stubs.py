@@ -130,10 +130,21 @@ def install_gym():
     install()
     if getattr(sys.modules.get("reagent.gym"), "_oracle_stub", False):
         return
-    spaces = _mod("gym.spaces", Discrete=type("Discrete", (), {}), Box=type("Box", (), {}))
+    spaces = _mod("gym.spaces", Discrete=type("Discrete", (), {}), Box=type("Box", (), {}), Dict=type("Dict", (), {}))
     _mod("gym", Env=type("Env", (), {}), spaces=spaces)
-    for name, sub in (("reagent.gym", "gym"), ("reagent.gym.preprocessors", os.path.join("gym", "preprocessors"))):
+    for name, sub in (("reagent.gym", "gym"), ("reagent.gym.preprocessors", os.path.join("gym", "preprocessors")),
+                      ("reagent.gym.datasets", os.path.join("gym", "datasets"))):
         m = types.ModuleType(name)
         m.__path__ = [os.path.join(REFERENCE_ROOT, "reagent", sub)]
         m._oracle_stub = True
         sys.modules[name] = m
+    # reagent/gym/datasets/replay_buffer_dataset.py:10-15 imports Agent / EnvWrapper (annotations only: their own modules
+    # import every environment and policy) and the two factories from the preprocessors PACKAGE (whose __init__ is bypassed)
+    _mod("reagent.gym.agents")
+    _mod("reagent.gym.agents.agent", Agent=type("Agent", (), {}))
+    _mod("reagent.gym.envs", EnvWrapper=type("EnvWrapper", (), {}))
+    pre = sys.modules["reagent.gym.preprocessors"]
+    ins = importlib.import_module("reagent.gym.preprocessors.replay_buffer_inserters")
+    tp = importlib.import_module("reagent.gym.preprocessors.trainer_preprocessor")
+    pre.make_replay_buffer_inserter = ins.make_replay_buffer_inserter
+    pre.make_replay_buffer_trainer_preprocessor = tp.make_replay_buffer_trainer_preprocessor

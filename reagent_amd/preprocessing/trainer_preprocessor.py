@@ -17,6 +17,14 @@ class DiscreteDqnInputMaker:
         self.num_actions = num_actions
         self.trainer_preprocessor = trainer_preprocessor
 
+    @classmethod
+    def create_for_env(cls, env):
+        """trainer_preprocessor.py:105-117 without importing gym: a discrete action space is one with `n`; an
+        environment may bring its own state preprocessor"""
+        space = env.action_space
+        assert hasattr(space, "n"), f"a discrete action space (with `n`) is needed, got {type(space)}"
+        return cls(num_actions=int(space.n), trainer_preprocessor=getattr(env, "trainer_preprocessor", None))
+
     def __call__(self, batch):
         action, next_action, terminal = batch.action, batch.next_action, batch.terminal
         assert (len(action.shape) == 2 and action.shape[1] == 1 and next_action.shape == action.shape), (
@@ -71,6 +79,13 @@ class PolicyNetworkInputMaker:
         self.train_low = torch.tensor(train_low)
         self.train_high = torch.tensor(train_high)
         self._on = {}  # device -> the four range tensors resident there (no host-to-device copy per batch)
+
+    @classmethod
+    def create_for_env(cls, env):
+        """trainer_preprocessor.py:169-173: a box action space is one with `low` / `high`"""
+        space = env.action_space
+        assert hasattr(space, "low") and hasattr(space, "high"), f"a box action space (low / high) is needed, got {type(space)}"
+        return cls(space.low, space.high)
 
     def _ranges(self, dev, A):
         """[4, A] = prev_min, prev_max, new_min, new_max per action dimension, resident on `dev`"""

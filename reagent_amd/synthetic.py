@@ -3,6 +3,8 @@ the parity tests and bench.py (tensors are created on the CPU from a seeded torc
 then moved), so reference and HIP paths see identical inputs."""
 from typing import Dict
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -120,3 +122,70 @@ def normalization_table(n_features: int, seed: int = 7):
     """(mean, stddev) of n CONTINUOUS features: mean ~ N(0,1), stddev ~ U[0.5, 2)."""
     g = torch.Generator().manual_seed(seed)
     return torch.randn(n_features, generator=g), torch.rand(n_features, generator=g) * 1.5 + 0.5
+
+
+class ScriptedEnv:
+    """A deterministic stand-in for a gym environment with the attributes the replay-buffer training flow touches
+    (`reset`, `step`, `possible_actions_mask`, `action_space`; reagent/gym/datasets/replay_buffer_dataset.py:96-137):
+    observations, rewards and masks are closed forms of (episode, step) with exactly representable values, episodes
+    end after `episode_lengths[episode % len]` steps.  Used by the parity tests and by oracle/make_golden.py, which
+    drives the reference's ReplayBufferDataset with the same script."""
+
+    class _Discrete:
+        def __init__(self, n):
+            self.n = n
+
+    class _Box:
+        def __init__(self, low, high):
+            self.low, self.high = np.asarray(low, dtype=np.float32), np.asarray(high, dtype=np.float32)
+            self.shape = self.low.shape
+
+    def __init__(self, obs_dim: int, num_actions: int = None, action_low=None, action_high=None,
+                 episode_lengths=(5, 3, 7), with_mask: bool = True):
+        self.obs_dim, self.episode_lengths = obs_dim, tuple(episode_lengths)
+        self.action_space = (self._Discrete(num_actions) if num_actions is not None else self._Box(action_low, action_high))
+        self.num_actions, self.with_mask = num_actions, with_mask and num_actions is not None
+        self.episode, self.t = -1, 0
+
+    def _obs(self):
+        i = np.arange(self.obs_dim)
+        return (((self.episode * 31 + self.t * 17 + i * 7) % 23) / 8.0 - 1.0).astype(np.float32)
+
+    @property
+    def possible_actions_mask(self):
+        if not self.with_mask:
+            return None
+        m = np.ones(self.num_actions, dtype=np.float32)
+        m[(self.episode * 3 + self.t) % self.num_actions] = float((self.episode + self.t) % 3 != 0)
+        return m
+
+    def reset(self):
+        self.episode += 1
+        self.t = 0
+        return self._obs()
+
+    def step(self, action):
+        a = float(np.asarray(action, dtype=np.float64).sum())
+        self.t += 1
+        reward = ((self.episode * 5 + self.t * 3) % 11) / 4.0 - 1.0 + 0.125 * a
+        terminal = self.t >= self.episode_lengths[self.episode % len(self.episode_lengths)]
+        return self._obs(), reward, terminal, {"episode": self.episode, "t": self.t}
+
+
+class ScriptedAgent:
+    """(action, log_prob) as a closed form of a call counter; `post_step` is None (replay_buffer_dataset.py:139)"""
+
+    post_step = None
+
+    def __init__(self, env: ScriptedEnv):
+        self.env, self.calls = env, 0
+
+    def act(self, obs, possible_actions_mask=None):
+        k = self.calls
+        self.calls += 1
+        log_prob = -0.125 - 0.25 * (k % 5)
+        if self.env.num_actions is not None:
+            return int((k * 5 + 3) % self.env.num_actions), log_prob
+        sp = self.env.action_space
+        frac = ((k * 3 + np.arange(sp.low.size) * 5) % 8) / 8.0  # inside [low, high): rescale_actions asserts the range
+        return (sp.low + frac.astype(np.float32) * (sp.high - sp.low)).astype(np.float32), log_prob

@@ -36,6 +36,10 @@ PAIRS = [
     ("reagent.optimizer.soft_update.SoftUpdate", "reagent_amd.optimizer.SoftUpdate", ()),
     ("reagent.gym.preprocessors.trainer_preprocessor.DiscreteDqnInputMaker", "reagent_amd.preprocessing.DiscreteDqnInputMaker", ()),
     ("reagent.gym.preprocessors.trainer_preprocessor.PolicyNetworkInputMaker", "reagent_amd.preprocessing.PolicyNetworkInputMaker", ()),
+    ("reagent.gym.datasets.replay_buffer_dataset.ReplayBufferDataset", "reagent_amd.gym.datasets.ReplayBufferDataset", ()),  # :22-48
+    ("reagent.gym.datasets.replay_buffer_dataset.OfflineReplayBufferDataset", "reagent_amd.gym.datasets.OfflineReplayBufferDataset", ()),
+    ("reagent.gym.types.Transition", "reagent_amd.gym.types.Transition", ()),                             # gym/types.py:19-29
+    ("reagent.gym.types.Trajectory", "reagent_amd.gym.types.Trajectory", ()),
 ]
 # methods whose parameter lists are part of the contract as well
 METHODS = [
@@ -45,6 +49,14 @@ METHODS = [
     ("reagent.training.sac_trainer.SACTrainer", "reagent_amd.training.SACTrainer", ("train_step_gen", "configure_optimizers")),
     ("reagent.training.qrdqn_trainer.QRDQNTrainer", "reagent_amd.training.QRDQNTrainer", ("train_step_gen", "configure_optimizers")),
     ("reagent.preprocessing.preprocessor.Preprocessor", "reagent_amd.preprocessing.Preprocessor", ("forward",)),
+    ("reagent.gym.datasets.replay_buffer_dataset.ReplayBufferDataset", "reagent_amd.gym.datasets.ReplayBufferDataset", ("create_for_trainer",)),
+    ("reagent.gym.datasets.replay_buffer_dataset.OfflineReplayBufferDataset", "reagent_amd.gym.datasets.OfflineReplayBufferDataset",
+     ("create_for_trainer",)),
+    ("reagent.gym.preprocessors.trainer_preprocessor.DiscreteDqnInputMaker", "reagent_amd.preprocessing.DiscreteDqnInputMaker",
+     ("create_for_env", "__call__")),
+    ("reagent.gym.preprocessors.trainer_preprocessor.PolicyNetworkInputMaker", "reagent_amd.preprocessing.PolicyNetworkInputMaker",
+     ("create_for_env", "__call__")),
+    ("reagent.gym.types.Trajectory", "reagent_amd.gym.types.Trajectory", ("add_transition", "calculate_cumulative_reward", "to_dict")),
 ]
 
 
