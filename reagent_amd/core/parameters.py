@@ -43,3 +43,19 @@ class NormalizationParameters:
     quantiles: Optional[List[float]] = None
     min_value: Optional[float] = None
     max_value: Optional[float] = None
+
+
+class NormalizationKey:
+    """keys of a normalization_data_map (reagent/core/parameters.py:155-161)"""
+
+    STATE = "state"
+    ACTION = "action"
+    ITEM = "item"
+    CANDIDATE = "candidate"
+
+
+@dataclass(frozen=True)
+class NormalizationData:
+    """reagent/core/parameters.py:164-167: what the net builders size their networks from"""
+
+    dense_normalization_parameters: Dict[int, NormalizationParameters]
