@@ -178,7 +178,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         apply_kld_on_mean: bool = False,
         action_embedding_mean: Optional[List[float]] = None,
         action_embedding_variance: Optional[List[float]] = None,
-        crr_config=None,
+        crr_config: Optional[CRRWeightFn] = None,
         backprop_through_log_prob: bool = True,
     ) -> None:
         super().__init__()
