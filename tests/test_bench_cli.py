@@ -69,3 +69,77 @@ def test_parity_object_on_the_interpreter(emu_lib, config):
     assert bench.fc_flops(sac, 1) == 2 * 10131456  # 20.26 MFLOP / transition
     qr = types.SimpleNamespace(algo="qrdqn", state_dim=128, actions=16, atoms=200, hidden=512, layers=3)
     assert bench.fc_flops(qr, 1) == 2 * 11075584  # 22.15 MFLOP / transition
+
+
+def _measure_worker(rank, world, port, out_dir):
+    """one rank of `bench.measure` on the interpreter: the data-parallel control flow of the benchmark itself (shard per rank,
+    enable_data_parallel, the eager deferred-update loop, max-over-ranks region time, per-rank report), which otherwise only
+    a multi-GPU box runs"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_backend
+
+    emu_backend.install()
+    import torch.distributed as dist
+
+    import bench
+
+    torch.cuda.synchronize = lambda *a, **k: None  # (CPU ranks: the barrier's device synchronisation has nothing to wait for)
+
+    class HostEvent:  # the instrumented pass brackets every call with events: host clocks here
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self, stream=None):
+            import time
+
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    torch.cuda.Event = HostEvent
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    argv = sys.argv
+    sys.argv = ["bench.py", "--config", "c2", "--gpus", str(world), "--capacity", "1024", "--batch", "128", "--parity-batch", "128",
+                "--hidden", "256", "--layers", "2", "--precision", "bf16", "--steps", "2", "--warmup", "1", "--repeats", "2"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    dev = torch.device("cpu")
+    m = bench.measure(args, dev, rank, world, dist)
+    # main()'s second pass: the same shard and initial weights in the split-bf16 mode
+    import argparse
+
+    a2 = argparse.Namespace(**vars(args))
+    a2.precision, a2.repeats = "bf16x3", 1
+    ma = bench.measure(a2, dev, rank, world, dist, cols=m["cols"])
+    dist.barrier()
+    assert m["extra"]["all_reduce_bytes"] > 0 and "roofline" in m["extra"]
+    keep = dict(value=m["value"], ms=m["ms_per_step"], regions=m["region_ms"], per_rank=m["per_rank"], launch=m["launch"],
+                loss=m["final_loss"], parity=m["parity"], x3_value=ma["value"], x3_loss=ma["final_loss"],
+                x3_parity=ma["parity"], shard=float(m["cols"]["observation"].double().sum()))
+    torch.save(keep, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_measure_on_two_ranks(tmp_path, emu_lib):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000) + 11
+    mp.spawn(_measure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    # whole-job value: both ranks' transitions over the slowest rank's time — the same number on every rank
+    assert r0["value"] == r1["value"] and r0["regions"] == r1["regions"] and len(r0["regions"]) == 2
+    assert r0["value"] == pytest.approx(2 * 128 * 2 / (r0["ms"] * 2e-3), rel=1e-6)
+    assert [p["rank"] for p in r0["per_rank"]] == [0, 1] and all(p["ms_per_step"] > 0 for p in r0["per_rank"])
+    assert all(p["all_reduce_us"] > 0 for p in r0["per_rank"])  # the instrumented pass saw the gradient all-reduce on every rank
+    assert "eager" in r0["launch"]  # the replayed graph stays opt-in with more than one rank
+    assert r0["shard"] != r1["shard"]  # disjoint shards of the offline data ...
+    assert r0["parity"] is not None and r1["parity"] is None and "error" not in r0["parity"], r0["parity"]  # ... rank 0 checks parity
+    assert r0["x3_parity"]["meets_north_star"], r0["x3_parity"]
+    for r in (r0, r1):
+        assert r["loss"] == r["loss"] and r["x3_loss"] == r["x3_loss"] and r["x3_value"] > 0  # finite
