@@ -28,8 +28,14 @@ for case in range(cases):
     ws = torch.empty(L.lib().rg_layer_norm_backward_workspace_bytes(B, n) // 4)
     ops.layer_norm_backward(gy, z, mean, rstd, gamma, dg, db, ws, dz32=dz)
     s = lambda t: max(1.0, t.abs().max().item())  # noqa: E731
-    ok &= bool((y - ref.detach()).abs().max() <= 5e-6 * s(ref) and (dz - zr.grad).abs().max() <= 2e-5 * s(zr.grad)
-               and (dg - gr.grad).abs().max() <= 2e-5 * s(gr.grad) and (db - br.grad).abs().max() <= 2e-5 * s(br.grad))
+    # Gradients are held to a float64 evaluation, with torch's own fp32 error as the yardstick: a 1- or 2-wide layer norm
+    # is constant / +-1, its input gradient is rounding noise times rstd (up to 316 = 1 / sqrt(eps)) — torch's fp32 result
+    # is 3e-5 .. 3e-4 off there (the kernel 3e-14 at width 1) and no fixed bound against it means anything.
+    zd, gd, bd = z.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    torch.nn.functional.layer_norm(zd, (n,), gd, bd, 1e-5).backward(gy.double())
+    near = lambda got, t32, t64: (got.double() - t64).abs().max() <= 2e-5 * s(t64) + 2 * (t32.double() - t64).abs().max()  # noqa: E731
+    ok &= bool((y - ref.detach()).abs().max() <= 5e-6 * s(ref) and near(dz, zr.grad, zd.grad)
+               and near(dg, gr.grad, gd.grad) and near(db, br.grad, bd.grad))
     # ---- ragged gather
     C, W = random.choice([5, 64, 300]), random.choice([1, 4, 16, 40])
     lens = torch.randint(0, W + 1, (C,), generator=g).int()
