@@ -1,0 +1,67 @@
+import os, sys, random
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+import torch
+import torch.nn.functional as F
+import emu_backend
+emu_backend.install()
+import reagent_amd._lib as L
+from reagent_amd import ops
+
+# rg_dqn_head on random shapes (batch sizes around the workgroup size, 1 .. 100 actions, masks with rows that allow a single
+# action, terminal rows, n-step discount exponents, reward boosts, both losses, double-Q on / off) against the reference's
+# formulas under torch autograd in float64 (dqn_trainer_base.py:33-77, dqn_trainer.py:179-239): the masked (double-Q) next
+# value and its index, the mean loss, d loss / d Q.
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+random.seed(seed)
+bad = 0
+for case in range(cases):
+    g = torch.Generator().manual_seed(seed * 1000 + case)
+    B = random.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097])
+    A = random.choice([1, 2, 3, 16, 17, 31, 32, 33, 64, 100])
+    double_q, loss = random.random() < 0.5, random.choice(["mse", "huber"])
+    gamma = random.choice([0.0, 0.9, 0.99, 1.0])
+    q, qo, qt = (torch.randn(B, A, generator=g) * random.choice([0.1, 1.0, 30.0]) for _ in range(3))
+    if random.random() < 0.3:  # exact ties between actions: the first maximal index wins (torch.max / argmax on CPU)
+        qo[:, 1:] = qo[:, :1]
+        qt[:, 1:] = qt[:, :1]
+    act = F.one_hot(torch.randint(0, A, (B,), generator=g), A).float()
+    mask = (torch.rand(B, A, generator=g) < random.choice([0.2, 0.7, 1.0])).float()
+    mask[torch.arange(B), torch.randint(0, A, (B,), generator=g)] = 1.0  # at least one possible next action per row
+    reward = torch.randn(B, generator=g)
+    boosts = torch.randn(A, generator=g) if random.random() < 0.4 else None
+    nt = (torch.rand(B, generator=g) < 0.8).float()
+    gexp = torch.randint(1, 4, (B,), generator=g).float() if random.random() < 0.4 else None
+    dq, parts = torch.empty(B, A), torch.empty(ops.dqn_head_partials(B))
+    nq, ni, qs = torch.empty(B), torch.empty(B, dtype=torch.int64), torch.empty(B)
+    ops.dqn_head(q.contiguous(), qo.contiguous(), qt.contiguous(), act, mask, reward, boosts, nt, gamma, gexp, double_q,
+                 L.LOSS[loss], dq, parts, nq, ni, qs)
+    # ---- the reference's formulas, float64
+    qd = q.double().requires_grad_()
+    on, tg = qo.double() + -1e9 * (1 - mask.double()), qt.double() + -1e9 * (1 - mask.double())
+    if double_q:
+        idx = on.argmax(dim=1, keepdim=True)
+        nxt = tg.gather(1, idx)
+    else:
+        nxt, idx = tg.max(dim=1, keepdim=True)
+    r = reward.double().reshape(-1, 1)
+    if boosts is not None:
+        r = r + (act.double() * boosts.double().reshape(1, -1)).sum(1, keepdim=True)
+    disc = torch.full((B, 1), gamma, dtype=torch.float64) if gexp is None else torch.pow(torch.tensor(gamma, dtype=torch.float64), gexp.double().reshape(-1, 1))
+    target = r + nt.double().reshape(-1, 1) * disc * nxt
+    q_sel = (qd * act.double()).sum(1, keepdim=True)
+    lref = F.mse_loss(q_sel, target.detach()) if loss == "mse" else F.smooth_l1_loss(q_sel, target.detach())
+    lref.backward()
+    # the fp32 kernel adds -1e9 to masked entries like the reference (fp32 there too): with every entry of a row masked but
+    # one, ties cannot arise; with exact ties the FIRST index must win
+    scale = max(1.0, q.abs().max().item(), qt.abs().max().item())
+    got_loss = parts.double().sum().item() / B  # per-workgroup sums; the step's reduce launch takes the mean
+    ok = torch.equal(ni, idx.reshape(-1)) and bool((nq.double() - nxt.reshape(-1)).abs().max() <= 1e-6 * scale)
+    ok &= bool((qs.double() - q_sel.detach().reshape(-1)).abs().max() <= 1e-6 * scale)
+    ok &= abs(got_loss - lref.item()) <= 2e-5 * max(1.0, abs(lref.item()))
+    ok &= bool((dq.double() - qd.grad).abs().max() <= 2e-6 * max(1.0, qd.grad.abs().max().item()) + 1e-7 * scale)
+    print(("OK " if ok else "BAD"), dict(B=B, A=A, double_q=double_q, loss=loss, gamma=gamma, boosts=boosts is not None, gexp=gexp is not None),
+          "dq err %.2e" % (dq.double() - qd.grad).abs().max().item(), "loss", got_loss, lref.item())
+    bad += 0 if ok else 1
+print("bad cases:", bad)
+sys.exit(1 if bad else 0)
