@@ -63,5 +63,55 @@ for case in range(cases):
     print(("OK " if ok else "BAD"), dict(B=B, A=A, double_q=double_q, loss=loss, gamma=gamma, boosts=boosts is not None, gexp=gexp is not None),
           "dq err %.2e" % (dq.double() - qd.grad).abs().max().item(), "loss", got_loss, lref.item())
     bad += 0 if ok else 1
+
+# rg_qr_head (the dense QR-DQN head of the fp32 mode): the reference's (N, B, N) quantile-Huber pair loss, its gradient and the
+# masked next-action choice on random (B, A, N) — qrdqn_trainer.py:108-160, :210-218 — in float64 under autograd
+for case in range(max(1, cases // 2)):
+    g = torch.Generator().manual_seed(seed * 1000 + 500 + case)
+    B, A = random.choice([1, 2, 7, 64, 65, 130]), random.choice([1, 2, 3, 16, 17])
+    N = random.choice([1, 2, 3, 7, 32, 51, 64, 200])
+    double_q, maxq, gamma = random.random() < 0.5, random.random() < 0.7, random.choice([0.0, 0.9, 1.0])
+    q, qo, qt = (torch.randn(B, A * N, generator=g) * random.choice([0.2, 1.0, 5.0]) for _ in range(3))
+    if random.random() < 0.3:
+        q = (q * 4).round() / 4  # exact ties between target and current quantiles (td == 0 sits on the indicator's edge)
+        qt = (qt * 4).round() / 4
+    act = F.one_hot(torch.randint(0, A, (B,), generator=g), A).float()
+    if maxq:
+        mask = (torch.rand(B, A, generator=g) < 0.6).float()
+        mask[torch.arange(B), torch.randint(0, A, (B,), generator=g)] = 1.0
+    else:
+        mask = F.one_hot(torch.randint(0, A, (B,), generator=g), A).float()  # SARSA: the logged next action
+    reward = (torch.randn(B, generator=g) * 4).round() / 4
+    boosts = torch.randn(A, generator=g) if random.random() < 0.3 else None
+    nt = (torch.rand(B, generator=g) < 0.8).float()
+    gexp = torch.randint(1, 4, (B,), generator=g).float() if random.random() < 0.3 else None
+    quant = ((0.5 + torch.arange(N)) / float(N)).float()
+    dq, parts, allq = torch.empty(B, A * N), torch.empty(B), torch.empty(B, A)
+    ops.qr_head(q.contiguous(), qo.contiguous() if double_q else None, qt.contiguous(), act, mask, reward, boosts, nt, gamma, gexp,
+                quant, N, maxq, dq, parts, allq)
+    qd = q.double().requires_grad_()
+    cur3, on3, tg3 = qd.view(B, A, N), qo.double().view(B, A, N), qt.double().view(B, A, N)
+    if maxq:
+        sel = (on3 if double_q else tg3).mean(2) + -1e9 * (1 - mask.double())
+        nxt = tg3[torch.arange(B), sel.argmax(1)]
+    else:
+        nxt = (tg3 * mask.double().unsqueeze(-1)).sum(1)
+    r = reward.double().reshape(-1, 1)
+    if boosts is not None:
+        r = r + (act.double() * boosts.double().reshape(1, -1)).sum(1, keepdim=True)
+    disc = torch.full((B, 1), gamma, dtype=torch.float64) if gexp is None else torch.pow(torch.tensor(gamma, dtype=torch.float64), gexp.double().reshape(-1, 1))
+    target = (r + disc * nt.double().reshape(-1, 1) * nxt).detach()
+    cur = (cur3 * act.double().unsqueeze(-1)).sum(1)
+    td = target.t().unsqueeze(-1) - cur
+    hub = torch.where(td.abs() < 1, 0.5 * td.pow(2), td.abs() - 0.5)
+    lref = (hub * (quant.double() - (td.detach() < 0).double()).abs()).mean()
+    lref.backward()
+    gs = max(1e-30, qd.grad.abs().max().item())
+    ok = abs(parts.double().sum().item() - lref.item()) <= 2e-5 * max(1.0, abs(lref.item()))
+    ok &= bool((dq.double() - qd.grad).abs().max() <= 3e-5 * gs + 1e-9)
+    ok &= bool((allq.double() - q.double().view(B, A, N).mean(2)).abs().max() <= 1e-5 * max(1.0, q.abs().max().item()))
+    print(("OK " if ok else "BAD"), "qr", dict(B=B, A=A, N=N, double_q=double_q, maxq=maxq, gamma=gamma),
+          "dq err %.2e of %.2e" % ((dq.double() - qd.grad).abs().max().item(), gs), "loss", parts.double().sum().item(), lref.item())
+    bad += 0 if ok else 1
 print("bad cases:", bad)
 sys.exit(1 if bad else 0)
