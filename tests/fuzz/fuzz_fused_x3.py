@@ -48,8 +48,19 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     errs = [T._rel(out, ro)] + [T._rel(a, b) for a, b in zip(dw, rdw)] + [T._rel(a, b) for a, b in zip(db, rdb)] + [T._rel(dx, rdx)]
     out2 = torch.zeros_like(out)
     st.forward(xc, out2, save=False)
-    ok = max(errs) < max(3e-5, 30 * f32) and torch.equal(out2, out)
+    # A ReLU / leaky-ReLU unit whose pre-activation lies inside the split-bf16 noise (~1e-5 of the sum of |terms|) can take
+    # the other branch of the derivative than float64 does: one such unit moves dZ of its layer by ~sqrt(2 / (B H)) of its
+    # norm (seen: |z| = 1.0e-6 among 65 536 values of mean magnitude 1.2 -> 1.4e-3 on that layer's gradients, every
+    # other tensor at 1e-5).  Count the units within 2e-5 of the mean magnitude (the noise level) and allow for them; cases without any stay at 3e-5.
+    hd, flips = x.double(), 0
+    for w, b, a in zip(ws[:-1], bs[:-1], acts[:-1]):
+        z = hd @ w.double().t() + b.double()
+        if a in ("relu", "leaky_relu"):
+            flips += int((z.abs() < 2e-5 * z.abs().mean()).sum())
+        hd = T.ACTS[a](z)
+    allow = max(3e-5, 30 * f32) + 3 * (2 * flips / (batch * H)) ** 0.5
+    ok = errs[0] < max(3e-5, 30 * f32) and max(errs) < allow and torch.equal(out2, out)
     bad += not ok
-    print("OK " if ok else "BAD", dims, acts, batch, "max err %.1e (fp32 torch %.1e)" % (max(errs), f32), "max|dout| %.1e" % (out.double() - ro).abs().max().item())
+    print("OK " if ok else "BAD", dims, acts, batch, "max err %.1e (fp32 torch %.1e, %d borderline units)" % (max(errs), f32, flips), "max|dout| %.1e" % (out.double() - ro).abs().max().item())
 print("bad cases:", bad)
 sys.exit(1 if bad else 0)
