@@ -113,5 +113,64 @@ for case in range(max(1, cases // 2)):
     print(("OK " if ok else "BAD"), "qr", dict(B=B, A=A, N=N, double_q=double_q, maxq=maxq, gamma=gamma),
           "dq err %.2e of %.2e" % ((dq.double() - qd.grad).abs().max().item(), gs), "loss", parts.double().sum().item(), lref.item())
     bad += 0 if ok else 1
+
+# rg_c51_head: softmax over atoms, masked next action by expected value, the categorical projection with the reference's
+# l == b == u fix-ups (targets planted ON the support grid: reward 0 / terminal rows / gamma 1), cross-entropy and its logit
+# gradient — c51_trainer.py:98-187 in float64 under autograd
+for case in range(max(1, cases // 2)):
+    g = torch.Generator().manual_seed(seed * 1000 + 800 + case)
+    B, A = random.choice([1, 2, 7, 64, 65, 130]), random.choice([1, 2, 3, 16, 17])
+    N = random.choice([2, 3, 7, 32, 51, 64, 200])
+    double_q, maxq, gamma = random.random() < 0.5, random.random() < 0.7, random.choice([0.0, 0.5, 0.9, 1.0])
+    qmin, qmax = random.choice([(-10.0, 10.0), (0.0, 5.0), (-100.0, 200.0)])
+    q, qo, qt = (torch.randn(B, A * N, generator=g) * random.choice([0.2, 1.0, 4.0]) for _ in range(3))
+    act = F.one_hot(torch.randint(0, A, (B,), generator=g), A).float()
+    if maxq:
+        mask = (torch.rand(B, A, generator=g) < 0.6).float()
+        mask[torch.arange(B), torch.randint(0, A, (B,), generator=g)] = 1.0
+    else:
+        mask = F.one_hot(torch.randint(0, A, (B,), generator=g), A).float()
+    reward = torch.randn(B, generator=g) * (qmax - qmin) / 4
+    reward[torch.rand(B, generator=g) < 0.3] = 0.0  # with gamma 1 the target atoms sit exactly on the support
+    boosts = torch.randn(A, generator=g) if random.random() < 0.3 else None
+    nt = (torch.rand(B, generator=g) < 0.8).float()
+    gexp = torch.randint(1, 4, (B,), generator=g).float() if random.random() < 0.3 else None
+    support = torch.linspace(qmin, qmax, N)
+    dq, parts, allq = torch.empty(B, A * N), torch.empty(B), torch.empty(B, A)
+    ops.c51_head(q.contiguous(), qo.contiguous() if double_q else None, qt.contiguous(), act, mask, reward, boosts, nt, gamma, gexp,
+                 support, qmin, qmax, N, maxq, dq, parts, allq)
+    sd = support.double()
+    qd = q.double().requires_grad_()
+    logd = F.log_softmax(qd.view(B, A, N), dim=2)
+    next_dist = F.softmax(qt.double().view(B, A, N), dim=2)
+    if maxq:
+        nq = ((F.softmax(qo.double().view(B, A, N), dim=2) if double_q else next_dist) * sd).sum(2)
+        nd = next_dist[torch.arange(B), (nq + -1e9 * (1 - mask.double())).argmax(1)]
+    else:
+        nd = (next_dist * mask.double().unsqueeze(-1)).sum(1)
+    r = reward.double().reshape(-1, 1)
+    if boosts is not None:
+        r = r + (act.double() * boosts.double().reshape(1, -1)).sum(1, keepdim=True)
+    disc = torch.full((B, 1), gamma, dtype=torch.float64) if gexp is None else torch.pow(torch.tensor(gamma, dtype=torch.float64), gexp.double().reshape(-1, 1))
+    tq = (r + disc * nt.double().reshape(-1, 1) * sd).clamp(qmin, qmax)
+    b = (tq - qmin) / ((qmax - qmin) / (N - 1.0))
+    lo, up = b.floor().to(torch.int64), b.ceil().to(torch.int64)
+    lo[(up > 0) * (lo == up)] -= 1
+    up[(lo < (N - 1)) * (lo == up)] += 1
+    m = torch.zeros_like(nd)
+    m.scatter_add_(1, lo, nd * (up.double() - b))
+    m.scatter_add_(1, up, nd * (b - lo.double()))
+    lref = -(m.detach() * (logd * act.double().unsqueeze(-1)).sum(1)).sum(1).mean()
+    lref.backward()
+    gs = max(1e-30, qd.grad.abs().max().item())
+    want_q = (logd.detach().exp() * sd).sum(2)
+    # fp32 places a target atom that lies within rounding of a grid point on either side of it: the mass moves between
+    # neighbours continuously, so loss and gradient agree to fp32 accuracy of b (~N * 1e-7 of a bin)
+    ok = abs(parts.double().sum().item() - lref.item()) <= 5e-5 * max(1.0, abs(lref.item()))
+    ok &= bool((dq.double() - qd.grad).abs().max() <= 2e-4 * gs + 1e-9)
+    ok &= bool((allq.double() - want_q).abs().max() <= 2e-5 * max(1.0, abs(qmin), abs(qmax)))
+    print(("OK " if ok else "BAD"), "c51", dict(B=B, A=A, N=N, double_q=double_q, maxq=maxq, gamma=gamma, range=(qmin, qmax)),
+          "dq err %.2e of %.2e" % ((dq.double() - qd.grad).abs().max().item(), gs), "loss", parts.double().sum().item(), lref.item())
+    bad += 0 if ok else 1
 print("bad cases:", bad)
 sys.exit(1 if bad else 0)
