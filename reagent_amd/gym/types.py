@@ -1,7 +1,7 @@
 """Transition / Trajectory records with the fields and checks of reagent/gym/types.py:19-106 (no gym import there
 either).  `Transition.asdict()` is what BasicReplayBufferInserter spreads into `ReplayBuffer.add`."""
 import dataclasses
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional
 
 import numpy as np
@@ -31,26 +31,29 @@ def get_optional_fields(cls) -> List[str]:
     return [f.name for f in dataclasses.fields(cls) if type(None) in getattr(f.type, "__args__", ())]
 
 
-@dataclass
-class Trajectory:
-    transitions: List[Transition] = field(default_factory=list)
+_OPTIONAL = tuple(get_optional_fields(Transition))  # log_prob, possible_actions_mask, info
 
-    def __post_init__(self) -> None:
-        self.optional_field_exist: Dict[str, bool] = {f: False for f in get_optional_fields(Transition)}
+
+class Trajectory:
+    """The transitions of one episode (types.py:46-106).  The first transition decides which optional fields every later
+    one must — or must not — fill; `trajectory.<field>` is the list of that field over the episode."""
+
+    def __init__(self, transitions: Optional[List[Transition]] = None):
+        self.optional_field_exist: Dict[str, bool] = dict.fromkeys(_OPTIONAL, False)
+        self.transitions: List[Transition] = []
+        for t in transitions or ():
+            self.add_transition(t)
 
     def __len__(self) -> int:
         return len(self.transitions)
 
     def add_transition(self, transition: Transition) -> None:
-        """the first transition decides which optional fields every later one must (not) fill (types.py:57-73)"""
-        if len(self) == 0:
-            for f in self.optional_field_exist:
-                if getattr(transition, f, None) is not None:
-                    self.optional_field_exist[f] = True
+        filled = {f: getattr(transition, f, None) is not None for f in _OPTIONAL}
+        if not self.transitions:
+            self.optional_field_exist = filled
         for f, should_exist in self.optional_field_exist.items():
-            val = getattr(transition, f, None)
-            if (val is not None) != should_exist:
-                raise ValueError(f"Field {f} given val {val} whereas should_exist is {should_exist}.")
+            if filled[f] != should_exist:
+                raise ValueError(f"Field {f} given val {getattr(transition, f, None)} whereas should_exist is {should_exist}.")
         self.transitions.append(transition)
 
     def __getattr__(self, attr: str):
@@ -59,17 +62,22 @@ class Trajectory:
         return [getattr(t, attr) for t in self.transitions]
 
     def calculate_cumulative_reward(self, gamma: float = 1.0):
+        """(discounted) sum of the episode's rewards"""
         assert len(self) > 0, "called on empty trajectory"
-        return sum(r * gamma**i for i, r in enumerate(self.reward))
+        total, weight = 0.0, 1.0
+        for r in self.reward:
+            total, weight = total + weight * r, weight * gamma
+        return total
 
     def to_dict(self):
-        """types.py:88-106 (the reference one-hots the action over 2 classes there)"""
-        d = {"action": F.one_hot(torch.from_numpy(np.stack(self.action)), 2)}
-        for f in ("observation", "reward", "terminal", "log_prob", "possible_actions_mask"):
-            if self.optional_field_exist.get(f, True):
-                vals = getattr(self, f)
-                d[f] = torch.tensor(vals) if np.isscalar(vals[0]) else torch.from_numpy(np.stack(vals)).float()
-        return d
+        """tensors of the episode (the reference one-hots the action over 2 classes here, types.py:88-106)"""
+        out = {"action": F.one_hot(torch.from_numpy(np.stack(self.action)), 2)}
+        for name in ("observation", "reward", "terminal", "log_prob", "possible_actions_mask"):
+            if not self.optional_field_exist.get(name, True):
+                continue
+            vals = getattr(self, name)
+            out[name] = torch.tensor(vals) if np.isscalar(vals[0]) else torch.from_numpy(np.stack(vals)).float()
+        return out
 
 
 # Transform ReplayBuffer's transition batch to the trainer's input type

@@ -81,6 +81,8 @@ def test_constructor_and_method_signatures_equal_the_reference():
                 return ("factory", getattr(f, "__qualname__", repr(f)).split(".")[-1])
             if d is inspect.Parameter.empty:
                 return ("required",)
+            if repr(d) == "<factory>":                      # the __init__ a @dataclass generates for field(default_factory=...)
+                return ("factory", "dataclass")
             if dataclasses.is_dataclass(d) or callable(d):
                 return ("object", type(d).__name__ if not callable(d) else getattr(d, "__name__", repr(d)))
             return ("value", repr(d))
