@@ -39,58 +39,29 @@ def _sample_for_trainer(replay_buffer: ReplayBuffer, batch_size: int, trainer_pr
 
 
 class ReplayBufferDataset(torch.utils.data.IterableDataset):
-    def __init__(
-        self,
-        env,
-        agent,
-        replay_buffer: ReplayBuffer,
-        batch_size: int,
-        training_frequency: int = 1,
-        num_episodes: Optional[int] = None,
-        max_steps: Optional[int] = None,
-        post_episode_callback: Optional[Callable] = None,
-        trainer_preprocessor=None,
-        replay_buffer_inserter=None,
-    ):
+    def __init__(self, env, agent, replay_buffer: ReplayBuffer, batch_size: int, training_frequency: int = 1,
+                 num_episodes: Optional[int] = None, max_steps: Optional[int] = None,
+                 post_episode_callback: Optional[Callable] = None, trainer_preprocessor=None, replay_buffer_inserter=None):
         super().__init__()
         assert replay_buffer_inserter is not None
-        self._env = env
-        self._agent = agent
-        self._replay_buffer = replay_buffer
-        self._batch_size = batch_size
-        self._training_frequency = training_frequency
-        self._num_episodes = num_episodes
-        self._max_steps = max_steps
+        self._env, self._agent, self._replay_buffer = env, agent, replay_buffer
+        self._batch_size, self._training_frequency = batch_size, training_frequency
+        self._num_episodes, self._max_steps = num_episodes, max_steps
         self._post_episode_callback = post_episode_callback
-        self._trainer_preprocessor = trainer_preprocessor
-        self._replay_buffer_inserter = replay_buffer_inserter
+        self._trainer_preprocessor, self._replay_buffer_inserter = trainer_preprocessor, replay_buffer_inserter
 
     @classmethod
-    def create_for_trainer(
-        cls,
-        trainer,
-        env,
-        agent,
-        replay_buffer: ReplayBuffer,
-        batch_size: int,
-        training_frequency: int = 1,
-        num_episodes: Optional[int] = None,
-        max_steps: Optional[int] = None,
-        post_episode_callback: Optional[Callable] = None,
-        trainer_preprocessor=None,
-        replay_buffer_inserter=None,
-        device=None,
-    ):
+    def create_for_trainer(cls, trainer, env, agent, replay_buffer: ReplayBuffer, batch_size: int, training_frequency: int = 1,
+                           num_episodes: Optional[int] = None, max_steps: Optional[int] = None,
+                           post_episode_callback: Optional[Callable] = None, trainer_preprocessor=None,
+                           replay_buffer_inserter=None, device=None):
         """replay_buffer_dataset.py:50-86; `device` defaults to where the buffer's columns live (the reference: cpu)"""
         device = device or getattr(replay_buffer, "device", None) or torch.device("cpu")
-        if trainer_preprocessor is None:
-            trainer_preprocessor = make_replay_buffer_trainer_preprocessor(trainer, device, env)
-        if replay_buffer_inserter is None:
-            replay_buffer_inserter = make_replay_buffer_inserter(env)
         return cls(env=env, agent=agent, replay_buffer=replay_buffer, batch_size=batch_size,
                    training_frequency=training_frequency, num_episodes=num_episodes, max_steps=max_steps,
-                   post_episode_callback=post_episode_callback, trainer_preprocessor=trainer_preprocessor,
-                   replay_buffer_inserter=replay_buffer_inserter)
+                   post_episode_callback=post_episode_callback,
+                   trainer_preprocessor=trainer_preprocessor or make_replay_buffer_trainer_preprocessor(trainer, device, env),
+                   replay_buffer_inserter=replay_buffer_inserter or make_replay_buffer_inserter(env))
 
     def _episode(self, mdp_id: int, steps_so_far: int):
         """one episode (replay_buffer_dataset.py:96-137): yields training batches, returns (steps, reward sum)"""
