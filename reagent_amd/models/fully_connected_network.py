@@ -178,8 +178,21 @@ class FullyConnectedNetwork(ModelBase):
             self._stack.stat_updates = self.stat_updates
         return self._stack
 
+    def autograd_stack(self):
+        """The engine instance `tensor.backward()` runs on: a SECOND stack over the same parameters with its own weight
+        fragments and its own saved-activation workspace.  `stack()` belongs to the trainers (their native steps and
+        captured HIP graphs hold its buffer addresses), so a grad-mode `q_network(x)` between two training steps — or
+        between a yielded loss and its backward — must not replace that workspace."""
+        if getattr(self, "_ag_stack", None) is None or getattr(self, "_ag_stack_precision", None) != self.precision:
+            lin = self.linears()
+            self._ag_stack = make_stack([l.weight for l in lin], [l.bias for l in lin],
+                                        [L.ACT[a] for a in self.activation_names], self.precision)
+            self._ag_stack_precision = self.precision
+        return self._ag_stack
+
     def __deepcopy__(self, memo):
         stack, self._stack = self._stack, None  # workspaces are not part of the model
+        ag, self._ag_stack = getattr(self, "_ag_stack", None), None
         try:
             cls = self.__class__
             new = cls.__new__(cls)
@@ -189,7 +202,7 @@ class FullyConnectedNetwork(ModelBase):
             for k, v in self.__dict__.items():
                 setattr(new, k, deepcopy(v, memo))
         finally:
-            self._stack = stack
+            self._stack, self._ag_stack = stack, ag
         # deep-copied parameters own fresh storage -> drop any slab association
         for p in new.parameters():
             if hasattr(p, "_rg_slab"):
@@ -228,13 +241,14 @@ class FullyConnectedNetwork(ModelBase):
 
 class _StackFunction(torch.autograd.Function):
     """One autograd node for a plain stack: forward = the saving HIP forward, backward = the stack's HIP backward (input
-    gradient, weight and bias gradients).  The stack keeps ONE set of saved activations, so a backward must follow its
-    own forward before the same network runs another recorded forward (checked: a stale node raises)."""
+    gradient, weight and bias gradients) — on the network's `autograd_stack()`, never on the trainers' `stack()`.  That
+    stack keeps ONE set of saved activations, so a backward must follow its own forward before the same network runs
+    another recorded forward (checked: a stale node raises)."""
 
     @staticmethod
     def forward(ctx, net, x, *params):
         L.require_cuda(x, "input")
-        st = net.stack()
+        st = net.autograd_stack()
         need_dx = bool(x.requires_grad)
         st.set_need_input_grad(need_dx or getattr(st, "_need_dx", False))
         st.stage_weights(need_transposed=True)
@@ -256,7 +270,7 @@ class _StackFunction(torch.autograd.Function):
                                "keeps one set of saved activations (call backward first, or run the other forward under "
                                "torch.no_grad())")
         (out,) = ctx.saved_tensors
-        st = net.stack()
+        st = net.autograd_stack()
         lin = net.linears()
         dw = [torch.empty_like(l.weight) for l in lin]
         db = [torch.empty_like(l.bias) for l in lin]

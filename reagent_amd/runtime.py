@@ -79,12 +79,15 @@ class _GraphedLoop:
         if self.index_pool_steps <= 1 or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             return None
         n, cap = rb._num_valid_indices, rb._replay_capacity
-        if n == 0:
-            return None  # the buffer raises its own error
+        if n != cap:
+            # a buffer that is still filling (online / interleaved add and train) changes its valid set every step:
+            # a pool keyed on it would be redrawn — 32 draws' worth of RNG — per step and its undrawn rows dropped,
+            # so a checkpointed continuation would no longer follow the uninterrupted run.  The buffer draws per step.
+            return None
         self._ensure_pool(dev)
         pick = self._pool[self._pool_pos]
         self._pool_pos += 1
-        return pick if n == cap else rb._valid_indices()[pick]
+        return pick
 
     # ---- checkpoint / resume (what pl.Trainer's checkpointing does for the reference: module + optimizer states) ----
     def checkpoint(self) -> dict:

@@ -18,8 +18,7 @@ from . import ops
 
 _PREC = {"f32": L.PREC_F32, "bf16": L.PREC_BF16, "bf16x3": L.PREC_BF16X3}
 _lib = torch.library.Library("reagent_amd", "DEF")
-_impls = {}
-_extra_keys = set()
+_impls = {}  # name -> python implementation (the suite's interpreter backend serves them from the test side)
 
 
 def _define(schema: str, fn, fake=None):
@@ -31,28 +30,27 @@ def _define(schema: str, fn, fake=None):
         torch.library.register_fake(f"reagent_amd::{name}", fake)
 
 
-def register_backend(dispatch_key: str):
-    """TEST HOOK: also serve `dispatch_key` ("CPU") — for the suite's SIMT-interpreter backend, which patches the
-    library loader; product code never calls this."""
-    if dispatch_key in _extra_keys:
-        return
-    _extra_keys.add(dispatch_key)
-    for name, fn in _impls.items():
-        _lib.impl(name, fn, dispatch_key)
-
-
 # ---- fully-connected stacks (fully_connected_network.py:157-163) ------------------------------------------------
 _stacks = {}
 # The package's in-place ops write through kernels: neither torch's version counter nor the trainers' `_rg_version`
 # (which lives on Parameter objects, not on the `.detach()` views a caller may pass) sees them.  They therefore record a
 # write epoch per STORAGE, and a cached stack whose weights' storages were written since its last staging re-stages.
+# Only storages a cached stack reads are tracked (a write to anything else needs no record), the table is dropped with the
+# stack cache, and a tracked address whose storage has died is re-armed when a stack is built on it — so the table is
+# bounded by the cache (64 stacks) and an address recycled by the allocator cannot hand a stale epoch to an unrelated tensor.
 _write_epoch = {}
 
 
 def _note_write(*tensors: torch.Tensor) -> None:
     for t in tensors:
         k = t.untyped_storage().data_ptr()
-        _write_epoch[k] = _write_epoch.get(k, 0) + 1
+        if k in _write_epoch:
+            _write_epoch[k] += 1
+
+
+def _track(tensors) -> None:
+    for t in tensors:
+        _write_epoch.setdefault(t.untyped_storage().data_ptr(), 0)
 
 
 def _epochs(tensors) -> tuple:
@@ -69,8 +67,10 @@ def _mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], biases: List[torc
     if st is None:
         if len(_stacks) > 64:
             _stacks.clear()
+            _write_epoch.clear()
         st = _stacks[key] = make_stack(weights, biases, [L.ACT[a] for a in activations], _PREC[precision])
         st._rg_write_epochs = None
+        _track(list(weights) + list(biases))
     ep = _epochs(list(weights) + list(biases))
     # re-staged only when a weight's version counter moved or one of this package's in-place ops wrote its storage
     st.stage_weights(need_transposed=False, force=st._rg_write_epochs != ep)

@@ -762,6 +762,9 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                 torch.distributed.all_reduce(self.log_alpha.grad, group=self._dp_group)
                 self.log_alpha.grad.mul_(gs)
             next(it).step()
+            # the aliased gradient IS the kernel's output buffer: never leave it attached — a later generator-path backward
+            # with grads kept (zero_grad(set_to_none=False)) would add the buffer to itself after the kernel rewrote it
+            self.log_alpha.grad = None
             self.entropy_temperature = self._alpha(dev)
         if self.value_network is not None:
             self._value_forward(b)

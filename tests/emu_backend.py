@@ -27,3 +27,22 @@ def install(monkeypatch=None):
         L.require_cuda = lambda t, name="tensor": None
         L.stream_ptr = lambda: None
     return cdll
+
+
+_cpu_library = None
+
+
+def serve_torch_ops_on_cpu():
+    """The registered `torch.ops.reagent_amd.*` ops on CPU tensors, for the interpreter backend: a torch.library fragment
+    created HERE, on the test side, adds a CPU implementation (the package's own python functions, which then reach the
+    patched loader).  The product registers the CUDA (= HIP) key only and carries no dispatch-key switch."""
+    global _cpu_library
+    if _cpu_library is not None:
+        return
+    import torch
+
+    import reagent_amd.torch_ops as T
+
+    _cpu_library = torch.library.Library("reagent_amd", "FRAGMENT")
+    for name, fn in T._impls.items():
+        _cpu_library.impl(name, fn, "CPU")

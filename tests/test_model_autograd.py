@@ -98,3 +98,52 @@ def test_hip_heads_refuse_backward_instead_of_yielding_nothing(backend):
         y.sum().backward()
     with torch.no_grad():
         assert not actor(rlt.FeatureData(torch.randn(10, 6).to(dev))).action.requires_grad
+
+
+def test_grad_mode_inference_leaves_the_trainers_workspace_alone(backend):
+    """`q_network(x)` in default grad mode used to run the SAVING forward on the stack the trainer owns
+    (`trainer._qs`), replacing its (batch, training) workspace — the buffers a captured HIP graph holds addresses of and the
+    activations a yielded loss's backward reads.  The autograd node now has its own engine instance."""
+    from reagent_amd import synthetic
+    from reagent_amd.core.parameters import EvaluationParameters, RLParameters
+    from reagent_amd.optimizer import Optimizer__Union
+    from reagent_amd.training import DQNTrainer
+
+    dev = backend.device
+    S, A, B = 24, 4, 200
+    set_default_precision(L.PREC_BF16)
+    try:
+        torch.manual_seed(3)
+        q = FullyConnectedDQN(S, A, [256, 256], ["relu", "relu"]).to(dev)
+    finally:
+        set_default_precision(L.PREC_F32)
+    tr = DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(A)],
+                    rl=RLParameters(gamma=0.9, target_update_rate=0.1), optimizer=Optimizer__Union.default(lr=1e-3),
+                    evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(dev)
+    batch = synthetic.to_dqn_input(synthetic.dqn_batch(B, S, A, seed=5), dev)
+    tr.train_step_native(batch)
+    st = tr._qs
+    assert st is q.fc.stack()
+    key, ptrs = st._ws["key"], [t.data_ptr() for t in st._ws["act_frag"]]
+    x = torch.randn(1, S).to(dev)
+    out = q(rlt.FeatureData(x))  # default grad mode: a recorded forward
+    assert out.requires_grad
+    assert st._ws["key"] == key and [t.data_ptr() for t in st._ws["act_frag"]] == ptrs
+    assert q.fc.autograd_stack() is not st
+    # a recorded forward between a yielded loss and its backward does not disturb the trainer's saved activations
+    gen = tr.train_step_gen(batch, 0)
+    loss = next(gen)
+    q(rlt.FeatureData(x)).sum().backward()
+    grads_side = [p.grad.clone() for p in q.parameters()]
+    for p in q.parameters():
+        p.grad = None
+    loss.backward()
+    got = [p.grad.clone() for p in q.parameters()]
+    # same step without the interleaved forward
+    for p in q.parameters():
+        p.grad = None
+    gen2 = tr.train_step_gen(batch, 0)
+    next(gen2).backward()
+    for a, b in zip(got, q.parameters()):
+        assert torch.equal(a, b.grad)
+    assert any(g.abs().sum() > 0 for g in grads_side)

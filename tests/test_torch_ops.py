@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-import reagent_amd.torch_ops as T
+import reagent_amd.torch_ops as T  # noqa: F401  (registers the library)
 
 R = torch.ops.reagent_amd
 
@@ -10,7 +10,9 @@ R = torch.ops.reagent_amd
 @pytest.fixture
 def dev(backend):
     if backend.name == "emu":
-        T.register_backend("CPU")  # the interpreter backend serves CPU tensors (test hook)
+        import emu_backend
+
+        emu_backend.serve_torch_ops_on_cpu()  # the interpreter backend serves CPU tensors, registered from the test side
     return backend.device
 
 
