@@ -27,7 +27,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
   parity       — one extra step on a 4096-row slice of the same workload (fresh trainer, same initial
                  weights), outside the timed region, checked against the CPU oracle (oracle/restated.py,
                  itself pinned to the reference's golden vectors by tests/)
-  cpu_baseline — the CPU oracle timed on this box's host cores, rank 0, N == 1 only
+  cpu_baseline — the unmodified reference (oracle/_ref byte code; the restated oracle only when that is absent) timed on
+                 this box's host cores, rank 0, N == 1 only
 """
 import argparse
 import hashlib
@@ -269,11 +270,28 @@ def make_oracle(args, init):
 
 
 def cpu_baseline(args, init, cols, norm):
-    """The reference step restated on torch-CPU (oracle/restated.py) on this box's host cores: gather of the
-    same columns by advanced indexing (`cols[idx]` per column — NOT the reference's sample_transition_batch
-    with its nonzero() + 17 index ops, which is slower still), normalization, trainer step.  Bounded sample."""
+    """The reference's CPU path on this box's host cores, bounded sample.
+
+    kind "reference": the UNMODIFIED reference — ReplayBuffer.sample_transition_batch (its own index draw) ->
+    DiscreteDqnInputMaker / PolicyNetworkInputMaker -> Preprocessor.forward x2 -> {DQN,QRDQN,SAC}Trainer.train_step_gen
+    through the Lightning-1.6 loop emulation — imported from /root/reference where that exists and from its byte code in
+    oracle/_ref (oracle/build_ref.py, built by __graft_entry__.build()) on the GPU box: oracle/reference_bench.py.
+    kind "port": only when neither is present — oracle/restated.py (torch-CPU restatement) with an advanced-index gather."""
     B = args.batch if args.algo != "qrdqn" else min(args.batch, 8192)  # the (N, B, N) tensor: 62 GB hosts (SURVEY §6)
-    steps = args.cpu_steps or (4 if args.algo == "dqn" else 2)
+    steps = args.cpu_steps or 2
+    from oracle import reference_bench as RB
+
+    if RB.available():
+        best, tried = RB.run(args.algo, args.state_dim, args.actions, args.hidden, args.layers, args.atoms, args.capacity, B,
+                             init, cols, norm, steps=steps)
+        return {"value": B / (best["ms_per_step"] * 1e-3), "unit": "transitions/s", "cores": best["threads"],
+                "kind": "reference", "ms_per_step": best["ms_per_step"], "sample_ms": best["sample_ms"],
+                "train_ms": best["train_ms"], "host_cpus": os.cpu_count(), "thread_settings_tried": tried,
+                "reference_from": RB.where(),
+                "sample": f"{best['steps']} steps (after 1 warm-up) at B={B} of the same workload, fp32, the unmodified reference: "
+                          f"ReplayBuffer.sample_transition_batch (own index draw) + input maker + Preprocessor x2 = "
+                          f"{best['sample_ms']:.0f} ms, {args.algo} train_step_gen under the Lightning-loop emulation = "
+                          f"{best['train_ms']:.0f} ms; torch intra-op threads = `cores` (fastest of the listed settings)"}
     o = make_oracle(args, init)
     g = torch.Generator().manual_seed(3)
 
@@ -285,15 +303,24 @@ def cpu_baseline(args, init, cols, norm):
         else:
             o.step(b)
 
-    one()  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    dt = time.perf_counter() - t0
-    return {"value": steps * B / dt, "unit": "transitions/s", "cores": torch.get_num_threads(), "kind": "port",
+    default = torch.get_num_threads()
+    tried = []
+    try:
+        for th in [default] + [t for t in (32, 16) if t < default]:
+            torch.set_num_threads(th)
+            one()  # warm-up
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            tried.append(dict(threads=th, ms_per_step=(time.perf_counter() - t0) / steps * 1e3))
+    finally:
+        torch.set_num_threads(default)
+    best = min(tried, key=lambda r: r["ms_per_step"])
+    return {"value": B / (best["ms_per_step"] * 1e-3), "unit": "transitions/s", "cores": best["threads"], "kind": "port",
+            "ms_per_step": best["ms_per_step"], "host_cpus": os.cpu_count(), "thread_settings_tried": tried,
             "sample": f"{steps} steps at B={B} of the same workload (advanced-index gather of the same columns + "
                       f"normalize + {args.algo} step, fp32, oracle/restated.py = torch-CPU restatement of the reference "
-                      f"trainer; {dt / steps * 1e3:.0f} ms/step)"}
+                      f"trainer — oracle/_ref was not built, so the reference itself could not run here)"}
 
 
 def parity_check(args, device, init, cols, norm):

@@ -19,8 +19,9 @@ from . import stubs
 
 
 def _install():
-    if not stubs.reference_available():
-        raise RuntimeError("reference tree not available (expected in the build container only)")
+    if stubs.runtime_root() is None:
+        raise RuntimeError("reference not available: neither /root/reference (build container) nor oracle/_ref (its byte code, "
+                           "python -m oracle.build_ref) is here")
     stubs.install()
 
 

@@ -1,8 +1,9 @@
 """TEST INFRASTRUCTURE (oracle).  Import shims that let the UNMODIFIED reference trainers under
 /root/reference be imported in a container that lacks pytorch_lightning / torchrec / tensorboard.
 
-Only oracle/reference_harness.py and oracle/make_golden.py use this, and only where
-/root/reference exists (the build container).  Nothing under reagent_amd/ imports it.
+Only oracle/reference_harness.py, oracle/make_golden.py and oracle/build_ref.py use this where /root/reference exists
+(the build container), and bench.py's cpu_baseline leg where only the byte-compiled oracle/_ref exists (the GPU box).
+Nothing under reagent_amd/ imports it.
 The recipe is the one recorded in SURVEY.md §8(c).
 """
 import enum
@@ -12,10 +13,23 @@ import sys
 import types
 
 REFERENCE_ROOT = os.environ.get("REAGENT_REFERENCE_ROOT", "/root/reference")
+# the same reference byte-compiled by oracle/build_ref.py (git-ignored; travels to the GPU box with the snapshot)
+BUILT_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
 
 
 def reference_available() -> bool:
+    """the reference SOURCE tree is here (build container): what the golden-fixture tests and generators need"""
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "reagent"))
+
+
+def runtime_root():
+    """where `install()` imports `reagent` from: the source tree when present, else the byte-compiled `oracle/_ref`
+    (GPU box: bench.py's cpu_baseline leg), else None"""
+    if reference_available():
+        return REFERENCE_ROOT
+    if os.path.isfile(os.path.join(BUILT_ROOT, "reagent", "__init__.pyc")):
+        return BUILT_ROOT
+    return None
 
 
 def _mod(name, **attrs):
@@ -114,11 +128,14 @@ def install():
             torch.utils.tensorboard = tbm
 
     # ---- reference on sys.path; bypass reagent/training/__init__.py (imports ~17 trainers) ----
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    root = runtime_root()
+    if root is None:
+        raise RuntimeError("oracle.stubs: neither the reference tree nor oracle/_ref (python -m oracle.build_ref) is here")
+    if root not in sys.path:
+        sys.path.insert(0, root)
     importlib.import_module("reagent")
     tr = types.ModuleType("reagent.training")
-    tr.__path__ = [os.path.join(REFERENCE_ROOT, "reagent", "training")]
+    tr.__path__ = [os.path.join(root, "reagent", "training")]
     tr._oracle_stub = True
     sys.modules["reagent.training"] = tr
 
@@ -135,7 +152,7 @@ def install_gym():
     for name, sub in (("reagent.gym", "gym"), ("reagent.gym.preprocessors", os.path.join("gym", "preprocessors")),
                       ("reagent.gym.datasets", os.path.join("gym", "datasets"))):
         m = types.ModuleType(name)
-        m.__path__ = [os.path.join(REFERENCE_ROOT, "reagent", sub)]
+        m.__path__ = [os.path.join(runtime_root(), "reagent", sub)]
         m._oracle_stub = True
         sys.modules[name] = m
     # reagent/gym/datasets/replay_buffer_dataset.py:10-15 imports Agent / EnvWrapper (annotations only: their own modules
