@@ -59,6 +59,80 @@ CONFIGS = {
 }
 
 
+class GpuTelemetry:
+    """Shader clock and socket power of ONE GPU sampled by a thread while a timed region runs: sysfs (`pp_dpm_sclk`'s
+    starred level, hwmon `power1_average` / `power1_input` in microwatt) every 20 ms, else `rocm-smi --showclocks
+    --showpower` as fast as it answers.  Reports mean / min / max and the sample count; None when neither is readable."""
+
+    def __init__(self, index=0, period=0.02):
+        import glob
+        import threading
+
+        self.index, self.period = index, period
+        self.sclk, self.power, self.source = [], [], None
+        self._stop = threading.Event()
+        self._thread = None
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        self._dev = cards[index] if index < len(cards) else None
+        self._pw = None
+        if self._dev:
+            for name in ("power1_average", "power1_input"):
+                hits = glob.glob(os.path.join(self._dev, "hwmon", "hwmon*", name))
+                if hits:
+                    self._pw = hits[0]
+                    break
+
+    def _sysfs(self):
+        with open(os.path.join(self._dev, "pp_dpm_sclk")) as fh:
+            for line in fh:
+                if "*" in line:
+                    self.sclk.append(float(line.split(":")[1].lower().split("mhz")[0]))
+        if self._pw:
+            with open(self._pw) as fh:
+                self.power.append(float(fh.read()) * 1e-6)
+
+    def _smi(self):
+        import re
+        import subprocess
+
+        out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower"], capture_output=True, text=True,
+                             timeout=10).stdout
+        m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+        if m:
+            self.sclk.append(float(m.group(1)))
+        m = re.search(r"Power \(W\): ([0-9.]+)", out)
+        if m:
+            self.power.append(float(m.group(1)))
+
+    def _loop(self):
+        read = self._sysfs if self._dev else self._smi
+        self.source = "sysfs pp_dpm_sclk + hwmon power" if self._dev else "rocm-smi --showclocks --showpower"
+        while not self._stop.is_set():
+            try:
+                read()
+            except Exception as e:  # telemetry must never take the measurement down
+                self.source = f"unreadable: {e!r}"
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=15)
+
+    def summary(self):
+        def stat(v):
+            return None if not v else {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "samples": len(v)}
+
+        return {"sclk_mhz": stat(self.sclk), "power_w": stat(self.power), "source": self.source}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default 1; 8 for --config c5)")
@@ -85,6 +159,8 @@ def parse():
     ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--parity-batch", type=int, default=4096)
+    ap.add_argument("--sustained-steps", type=int, default=4000,
+                    help="steps of the one long region reported as `sustained` next to the K-step regions (0: skip)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher self-test: form the process group (gloo when there is no GPU), report its size, exit")
     args = ap.parse_args()
@@ -491,6 +567,33 @@ def kernel_profile(args, step, steps):
     return out
 
 
+def normalise_profile(extra, instrumented_ms, timed_ms):
+    """The instrumented pass brackets every C-ABI call with two HIP events; each kernel then starts from an idle queue
+    (its dispatch latency, ~2 us, lands inside its span instead of under the previous kernel) and the pass as a whole runs
+    slower than the timed region.  Per-call times are therefore scaled by timed / instrumented wall time per step — so
+    that they add up to no more than `ms_per_step` on a single stream — and the roofline fractions use the scaled times;
+    the raw event figures stay alongside."""
+    scale = min(1.0, timed_ms / instrumented_ms) if instrumented_ms > 0 else 1.0
+    extra["instrumented_pass"] = {"ms_per_step": instrumented_ms, "timed_ms_per_step": timed_ms, "scale": scale,
+                                  "note": "per-call and roofline times = HIP-event times x scale (see bench.normalise_profile)"}
+    if scale >= 1.0:
+        return
+    for key in ("roofline", "fc_roofline", "gather"):
+        r = extra.get(key)
+        if not r:
+            continue
+        r["events_raw"] = {k: r[k] for k in ("achieved", "frac", "avg_launch_us", "fc_ms_per_step", "executed_frac") if k in r}
+        for k in ("avg_launch_us", "fc_ms_per_step"):
+            if k in r:
+                r[k] *= scale
+        for k in ("achieved", "frac", "executed_frac"):
+            if k in r:
+                r[k] /= scale
+    if "all_reduce_us" in extra:
+        extra["all_reduce_us"] *= scale
+    extra["per_call_ms_per_step"] = {k: round(v * scale, 4) for k, v in extra.get("per_call_ms_per_step", {}).items()}
+
+
 def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     """build the workload `args` names on this rank, run the parity step, pick the launch path, time `--repeats` regions
     of exactly `--steps` steps, run the instrumented pass; returns the numbers (all ranks) for rank 0 to print"""
@@ -515,6 +618,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
 
     step = loop.step
     graph_note = None
+    calibration = None
     # data parallel: the eager loop (asynchronous all-reduce, deferred update) is the default — on one GPU the
     # replayed graph measured slower than eager launches for the DQN step, and the three-graph data-parallel form
     # has only been exercised on a one-rank RCCL group (tests/test_graph_replay.py); `--launch graph` / `auto` opt in
@@ -564,6 +668,9 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
             graph_note = (f"{'graph replay: ' + what if use_graph else 'eager stream launches'}; calibration "
                           f"{t_graph * 1e3:.3f} ms/step replayed vs {t_eager * 1e3:.3f} ms/step eager "
                           f"(eager host enqueue {host_eager * 1e3:.3f} ms/step)")
+            calibration = {"graph_ms_per_step": t_graph * 1e3, "eager_ms_per_step": t_eager * 1e3,
+                           "eager_host_enqueue_ms_per_step": host_eager * 1e3, "chosen": "graph" if use_graph else "eager",
+                           "rule": f"graph unless it is more than {round((margin - 1) * 100)} % slower than eager launches"}
             step = replay if use_graph else loop.step
             if not use_graph:
                 loop.release_graph()  # eager steps then pass Adam's coefficients per launch (no tick kernel)
@@ -596,12 +703,38 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         loss = loss["q1_loss"]
     loss_val = float(loss.item())
 
+    # ---- one LONG region (default 4000 steps, seconds not milliseconds) with the clock and the power sampled inside it:
+    # the K-step regions above are ~10 ms bursts after an idle gap, and this chip's clock under dense MFMA is power-managed
+    sustained = None
+    n_sus = int(getattr(args, "sustained_steps", 0) or 0)
+    if n_sus > 0:
+        barrier()
+        with GpuTelemetry(device.index or 0) as tele:
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+            loop.flush()
+            barrier()
+            sdt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([sdt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sdt = t.item()
+        sustained = {"steps": n_sus, "seconds": sdt, "ms_per_step": sdt / n_sus * 1e3, "value": world * args.batch * n_sus / sdt,
+                     "unit": "transitions/s", **tele.summary()}
+
     extra = {}
     if not args.no_kernel_profile:
         # every rank runs the instrumented steps (they contain the gradient all-reduce: a pass on rank 0
         # alone would never return); rank 0 reports.  Eager launches: events bracket each C-ABI call.
-        extra = kernel_profile(args, loop.step, profile_steps or min(args.steps, 10))
+        n_prof = profile_steps or min(args.steps, 10)
+        barrier()
+        t0 = time.perf_counter()
+        extra = kernel_profile(args, loop.step, n_prof)  # (its summary() synchronises)
         loop.flush()
+        barrier()
+        inst_ms = (time.perf_counter() - t0) / n_prof * 1e3
+        normalise_profile(extra, inst_ms, dt / args.steps * 1e3)
     per_rank = None
     if dist is not None:
         # every rank's own view, so a curve measured by the driver explains itself: the rank's wall time for the median
@@ -615,7 +748,8 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     return {"value": world * args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
             "timing": f"median of {len(regions)} regions of {args.steps} steps each",
             "region_ms": [round(r * 1e3, 4) for r in regions], "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
-            "final_loss": loss_val, "launch": graph_note or "eager launches", "extra": extra, "parity": parity,
+            "final_loss": loss_val, "launch": graph_note or "eager launches", "launch_calibration": calibration,
+            "sustained": sustained, "extra": extra, "parity": parity,
             "per_rank": per_rank, "init": init, "cols": cols, "cols_cpu": cols, "norm": norm}
 
 
@@ -677,51 +811,74 @@ def main():
         }
         if world > 1:
             res["per_rank"] = m["per_rank"]
+        res["launch_calibration"] = m["launch_calibration"]
+        if m["sustained"] is not None:
+            res["sustained"] = m["sustained"]
         res.update(m["extra"])
         if m["parity"] is not None:
             res["parity"] = m["parity"]
+    def sub_object(mm, a, note=None):
+        """what a secondary region contributes to the line"""
+        o = {"dtype": a.precision, "value": mm["value"], "unit": "transitions/s", "ms_per_step": mm["ms_per_step"],
+             "steps": a.steps, "timing": mm["timing"], "region_ms": mm["region_ms"], "launch": mm["launch"],
+             "launch_calibration": mm["launch_calibration"]}
+        if note:
+            o["note"] = note
+        if mm["sustained"] is not None:
+            o["sustained"] = mm["sustained"]
+        o.update({k: mm["extra"][k] for k in ("roofline", "fc_roofline", "instrumented_pass") if k in mm["extra"]})
+        o["parity"] = mm["parity"]
+        return o
+
+    X3_NOTE = ("same workload, shard, initial weights and K-step region as its bf16 sibling, every FC operand split hi + lo "
+               "(three bf16 MFMAs per product, fp32 accumulate): the mode held to north_star's 1e-4")
+    # Secondary regions run on ONE rank only: with world > 1 a rank-local failure inside one of them (say an OOM) would
+    # leave the other ranks waiting in its collectives; the scaling curve needs the headline value alone.
+    secondary = world == 1
     # ---- the same K-step region in the mode that meets north_star's floating-point tolerance (Q within 1e-4 of the fp32
     # reference, dqn_trainer.py:204-238): split-bf16 operands on the bf16 MFMA pipe.  Same shard, same initial weights.
-    if args.precision == "bf16" and not args.no_accurate:
+    if args.precision == "bf16" and not args.no_accurate and secondary:
         a2 = argparse.Namespace(**vars(args))
         a2.precision = "bf16x3"
         a2.repeats = max(1, min(args.repeats, 3))
+        a2.sustained_steps = args.sustained_steps // 2
         try:
             ma = measure(a2, device, rank, world, dist, cols=m["cols"], profile_steps=min(args.steps, 6))
-        except Exception as e:  # never fatal to the headline measurement (every rank runs the same code: a failure is symmetric)
-            ma = None
-            if rank == 0:
-                res["accurate"] = {"dtype": "bf16x3", "error": repr(e)}
-        if rank == 0 and ma is not None:
-            res["accurate"] = {"dtype": "bf16x3", "value": ma["value"], "unit": "transitions/s", "ms_per_step": ma["ms_per_step"],
-                               "steps": args.steps, "timing": ma["timing"], "region_ms": ma["region_ms"], "launch": ma["launch"],
-                               "note": "same workload, shard, initial weights and K-step region as `value`, every FC operand "
-                                       "split hi + lo (three bf16 MFMAs per product, fp32 accumulate): the mode held to "
-                                       "north_star's 1e-4",
-                               **{k: ma["extra"][k] for k in ("roofline", "fc_roofline") if k in ma["extra"]},
-                               "parity": ma["parity"]}
-        del ma
-    # ---- the other single-GPU BASELINE configurations, a few regions each, so they are driver-timed numbers too
-    if args.config == "c2" and world == 1 and not args.no_also:
+            res["accurate"] = sub_object(ma, a2, X3_NOTE)
+            del ma
+        except Exception as e:  # never fatal to the headline measurement
+            res["accurate"] = {"dtype": "bf16x3", "error": repr(e)}
+        torch.cuda.empty_cache()
+    # ---- the other single-GPU BASELINE configurations, a few regions each in BOTH modes, so that every configuration has a
+    # driver-timed throughput AND a driver-timed 1e-4-compliant throughput (`accurate`)
+    if args.config == "c2" and secondary and not args.no_also:
         also = {}
         for cfg in ("c3", "c4"):
-            a3 = argparse.Namespace(**vars(args))
-            a3.config, a3.repeats = cfg, 3
             c = CONFIGS[cfg]
+            a3 = argparse.Namespace(**vars(args))
+            a3.config, a3.repeats, a3.sustained_steps = cfg, 3, 0
             a3.state_dim, a3.actions, a3.algo, a3.atoms = c["state_dim"], c["actions"], c["algo"], c["atoms"]
             a3.no_parity = False
+            shared_cols = m["cols"] if cfg == "c3" else None
             try:
-                mo = measure(a3, device, rank, world, dist, cols=m["cols"] if cfg == "c3" else None,
-                             profile_steps=min(args.steps, 4))
-                also[cfg] = {"workload": c["name"], "dtype": a3.precision, "value": mo["value"], "unit": "transitions/s",
-                             "ms_per_step": mo["ms_per_step"], "steps": args.steps, "region_ms": mo["region_ms"],
-                             "launch": mo["launch"],
-                             **{k: mo["extra"][k] for k in ("roofline", "fc_roofline") if k in mo["extra"]},
-                             "parity": mo["parity"]}
+                mo = measure(a3, device, rank, world, dist, cols=shared_cols, profile_steps=min(args.steps, 4))
+                also[cfg] = {"workload": c["name"], **sub_object(mo, a3)}
+                shared_cols = mo["cols"]
                 del mo
             except Exception as e:  # never fatal to the headline measurement
                 also[cfg] = {"error": repr(e)}
             torch.cuda.empty_cache()
+            if args.precision == "bf16" and not args.no_accurate and "error" not in also[cfg]:
+                a4 = argparse.Namespace(**vars(a3))
+                a4.precision = "bf16x3"
+                try:
+                    mo = measure(a4, device, rank, world, dist, cols=shared_cols, profile_steps=min(args.steps, 4))
+                    also[cfg]["accurate"] = sub_object(mo, a4, X3_NOTE)
+                    del mo
+                except Exception as e:
+                    also[cfg]["accurate"] = {"dtype": "bf16x3", "error": repr(e)}
+                torch.cuda.empty_cache()
+            del shared_cols
         res["also_measured"] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

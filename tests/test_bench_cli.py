@@ -104,7 +104,7 @@ def _measure_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     argv = sys.argv
     sys.argv = ["bench.py", "--config", "c2", "--gpus", str(world), "--capacity", "1024", "--batch", "128", "--parity-batch", "128",
-                "--hidden", "256", "--layers", "2", "--precision", "bf16", "--steps", "2", "--warmup", "1", "--repeats", "2"]
+                "--hidden", "256", "--layers", "2", "--precision", "bf16", "--steps", "2", "--warmup", "1", "--repeats", "2", "--sustained-steps", "3"]
     try:
         args = bench.parse()
     finally:
@@ -119,6 +119,11 @@ def _measure_worker(rank, world, port, out_dir):
     ma = bench.measure(a2, dev, rank, world, dist, cols=m["cols"])
     dist.barrier()
     assert m["extra"]["all_reduce_bytes"] > 0 and "roofline" in m["extra"]
+    # the long region and its telemetry record (no GPU here: the clock / power fields are None, never an exception)
+    assert m["sustained"]["steps"] == 3 and m["sustained"]["ms_per_step"] > 0 and "sclk_mhz" in m["sustained"]
+    # the instrumented pass is normalised to the timed one: per-call times add up to no more than the timed step
+    ip = m["extra"]["instrumented_pass"]
+    assert 0 < ip["scale"] <= 1.0
     keep = dict(value=m["value"], ms=m["ms_per_step"], regions=m["region_ms"], per_rank=m["per_rank"], launch=m["launch"],
                 loss=m["final_loss"], parity=m["parity"], x3_value=ma["value"], x3_loss=ma["final_loss"],
                 x3_parity=ma["parity"], shard=float(m["cols"]["observation"].double().sum()))
