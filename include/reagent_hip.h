@@ -186,7 +186,8 @@ typedef struct {
    * group_stride_bwd elements / dims[L] per group (rg_group_weights_stage lays them out so).  out_scatter != 0
    * writes output row r of the forward to out32[rowmap[r]] (rows with rowmap[r] < 0 are dropped).  The backward
    * reduces the last layer's bias gradient per group (db[L-1]: [n_groups * dims[L]], tile_begin required) and
-   * leaves the last layer's weight gradient to rg_group_head_wgrad (dz_frag[L-1] is its operand). */
+   * leaves the last layer's weight gradient to rg_group_head_wgrad (dz_frag[L-1] is its operand).
+   * ABI 8: also for split-bf16 stacks (x3): per group [hi plane | lo plane], the strides cover both. */
   const int32_t* tile_key;
   const int32_t* tile_begin;
   int32_t n_groups;
@@ -269,7 +270,8 @@ typedef struct {
   int32_t group_rows[RG_MLP_MAX_LAYERS]; /* ABI 7: group_rows[l] > 0 = layer l is a GROUPED layer (QR-DQN's A x N output
                 * layer, reagent/training/qrdqn_trainer.py:108-194, as dims[l+1] / group_rows[l] independent
                 * [group_rows[l], dims[l]] layers): its three fragment buffers are laid out as rg_group_weights_stage
-                * writes them (group g at g * rg_group_wfrag_elems elements).  bf16 stacks only (x3 == 0). */
+                * writes them (group g at g * rg_group_wfrag_elems elements; ABI 8: with x3 a group's set is
+                * [hi plane | lo plane], twice that). */
   /* ABI 7, replayed steps (a captured HIP graph must not need launch arguments that change from step to step):
    * sched_pre_ticked != 0 (_sched entry point only): the step is already counted in sched[0] — by the sampler launch of the
    * same step, rg_replay_dqn_batch_pooled — so the coefficients of step sched[0] apply and no rg_sched_tick follows;
@@ -571,14 +573,17 @@ size_t rg_group_rows_workspace_bytes(int batch, int n_groups);
 int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int32_t* rowmap, int32_t* tile_key,
                   int32_t* tile_begin, void* workspace, size_t workspace_bytes, rg_stream_t stream);
 size_t rg_group_wfrag_elems(int group_rows, int in_features, int transposed);
-int rg_group_weights_stage(const float* w, int n_groups, int group_rows, int in_features, void* wfrag_fwd,
+/* ABI 8: x3 != 0 = split-bf16 — a group's fragment set is [hi plane | lo plane] (lo = bf16(w - hi)), 2 *
+ * rg_group_wfrag_elems(...) elements per group; rg_mlp_desc.group_stride_* then counts both planes. */
+int rg_group_weights_stage(const float* w, int n_groups, int group_rows, int in_features, int x3, void* wfrag_fwd,
                            void* wfrag_bwd, rg_stream_t stream);
 int rg_wide_head_mean(const float* w, const float* b, int n_groups, int group_rows, int in_features, float* wbar,
                       float* bbar, rg_stream_t stream);
 /* ABI 7: the same, and the means also written as the forward B fragments of the [n_groups, in] mean layer (the slots
  * rg_stage_weights_frag(wbar, n_groups, in, wfrag_fwd, NULL) fills for rows < n_groups; wfrag_fwd staged once before) */
+/* ABI 8: x3 != 0 also writes the lo plane (rg_wfrag_elems(n_groups, in) elements behind the hi plane) */
 int rg_wide_head_mean_staged(const float* w, const float* b, int n_groups, int group_rows, int in_features, float* wbar,
-                             float* bbar, void* wfrag_fwd, rg_stream_t stream);
+                             float* bbar, void* wfrag_fwd, int x3, rg_stream_t stream);
 int rg_qr_select_action(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
                         int32_t* key, rg_stream_t stream);
 /* ABI 7: rg_qr_select_action + rg_group_rows(key, n_groups = num_actions) in the launches of the latter (the key is
@@ -593,8 +598,10 @@ int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldz
                        const float* quantiles, int batch, int num_atoms, float* dz, int64_t lddz,
                        float* loss_partials, float* tile_losses, rg_stream_t stream);
 size_t rg_group_head_wgrad_workspace_bytes(int n_groups, int group_rows, int in_features, int splits);
+/* ABI 8: x3 != 0 = split-bf16 operands, each [hi plane | lo plane] over `rows` (the grouped space's row count: the lo
+ * planes start rg_frag_elems(rows, group_rows) / rg_frag_elems(rows, in_features) elements in), three MFMAs per product */
 int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* tile_begin, int n_groups,
-                        int group_rows, int in_features, int splits, float* dw, void* workspace,
+                        int group_rows, int in_features, int splits, int x3, int rows, float* dw, void* workspace,
                         size_t workspace_bytes, rg_stream_t stream);
 
 /* Discrete CRR heads, reagent/training/discrete_crr_trainer.py.  All matrices [B, A] fp32 contiguous.

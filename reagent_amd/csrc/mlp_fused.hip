@@ -614,7 +614,9 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_grouped_kernel(WgradGroupedArgs G
   int b0 = mb0 + s * per, b1 = b0 + per;
   if (b1 > mb1) b1 = mb1;
   if (b0 > mb1) b0 = mb1;
-  wgrad_frag_core(G.g, 0, kg, b0, b1, G.g.a_frag, G.g.b_frag, G.g.partial + ((long)a * G.splits + s) * G.g.slab, smem);
+  float* part = G.g.partial + ((long)a * G.splits + s) * G.g.slab;
+  if (G.g.x3) wgrad_x3_core(G.g, 0, kg, b0, b1, part, smem);  // split-bf16 operands: both planes of dZ and of the activations
+  else wgrad_frag_core(G.g, 0, kg, b0, b1, G.g.a_frag, G.g.b_frag, part, smem);
 }
 
 // out[a * slab + e] = sum_s partial[(a * splits + s) * slab + e]
@@ -854,7 +856,7 @@ struct UpdateArgs {
   int x3;
   // grouped layers (qr_grouped.hip: QR-DQN's A x N output layer as A independent [Ng, K] layers): Ng[l] > 0 = the rows
   // of layer l fall into groups of Ng, group g's fragments start g * per_f[l] (forward, target) / g * per_b[l] (backward)
-  // elements in — what rg_group_weights_stage writes.  bf16 stacks only.
+  // elements in — what rg_group_weights_stage writes (split-bf16: a group's set is [hi plane | lo plane], per_* covers both).
   int Ng[FB_MAXL];
   long per_f[FB_MAXL], per_b[FB_MAXL];
   // replayed steps (runtime._GraphedLoop): the sampler launch has already counted this step in sched[0]
@@ -1026,7 +1028,8 @@ __global__ void mlp_update_tiles_kernel(UpdateTileArgs T) {
       gf = g * U.per_f[l];
     }
     const long jf = gf + ((((long)(nl >> 5) * KCf + (k >> 4)) * 64) + ((nl & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
-    const long tf = (long)((N + 31) / 32) * KCf * 512;  // lo plane of the forward fragments (split-bf16)
+    // lo plane of the forward fragments (split-bf16): behind the layer's — a grouped layer: the group's — hi plane
+    const long tf = (long)(((U.Ng[l] > 0 ? U.Ng[l] : N) + 31) / 32) * KCf * 512;
     if (U.wf[l]) *(uint2*)(U.wf[l] + jf) = uint2{pack_bf16x2(pn[0], pn[1]), pack_bf16x2(pn[2], pn[3])};
     if (U.twf[l]) *(uint2*)(U.twf[l] + jf) = uint2{pack_bf16x2(tn[0], tn[1]), pack_bf16x2(tn[2], tn[3])};
     if (U.x3) {
@@ -1136,7 +1139,7 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
   if (save)
     for (int l = (save == 2 ? 1 : 0); l < d->n_layers; ++l)
       if (!d->act_frag[l]) return RG_EINVAL;  // (save = 2 writes it only where there is no usable sign plane)
-  if (d->rowmap && (d->x2 || d->x3 || (batch % 128) != 0)) return RG_EUNSUPPORTED;
+  if (d->rowmap && (d->x2 || (d->x3 && !d->tile_key) || (batch % 128) != 0)) return RG_EUNSUPPORTED;
   if (d->tile_key && (!d->rowmap || d->n_groups <= 0)) return RG_EINVAL;
   if (d->x2 && (d->x_split <= 0 || d->x_split >= d->dims[0] || (d->x_split % 32) != 0)) return RG_EINVAL;
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
@@ -1213,7 +1216,7 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
     rc = (int)hipGetLastError();
   }
   if (rc) return rc;
-  if (d->tile_key && (d->x3 || (d->db[d->n_layers - 1] && !d->tile_begin))) return RG_EINVAL;
+  if (d->tile_key && d->db[d->n_layers - 1] && !d->tile_begin) return RG_EINVAL;
   if (d->defer_db) {  // the partials stay in the workspace: rg_mlp_wgrad_fused (db_partials) sums them in its reduce launch
     if (d->tile_key || !want_db) return RG_EINVAL;
     return 0;
@@ -1225,7 +1228,9 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   for (int l = 0; l < d->n_layers; ++l) {
     if (!a.db_part[l]) continue;
     if (d->tile_key && l == d->n_layers - 1) {  // grouped output layer: per-group sums over each group's tiles
-      grouped_bias_reduce_launch(a.db_part[l], d->tile_begin, d->n_groups, d->dims[l + 1], d->db[l], (hipStream_t)stream);
+      // (a 128-row tile of the grouped space is one workgroup of the bf16 kernel, two of the split-bf16 kernel)
+      grouped_bias_reduce_launch(a.db_part[l], d->tile_begin, d->n_groups, d->dims[l + 1], d->db[l], d->x3 ? 128 / X3_BM : 1,
+                                 (hipStream_t)stream);
       continue;
     }
     const int i = G.n++;
@@ -1297,9 +1302,10 @@ size_t rg_group_head_wgrad_workspace_bytes(int n_groups, int group_rows, int in_
 /* dw [n_groups * group_rows, in_features] of a grouped layer (qr_grouped.hip): group g's rows are the 32-row blocks
  * [4 * tile_begin[g], 4 * tile_begin[g + 1]) of dz_frag (batch x group_rows, padded to 32 columns) and h_frag */
 int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* tile_begin, int n_groups, int group_rows,
-                        int in_features, int splits, float* dw, void* workspace, size_t workspace_bytes,
+                        int in_features, int splits, int x3, int rows, float* dw, void* workspace, size_t workspace_bytes,
                         rg_stream_t stream) {
-  if (!dz_frag || !h_frag || !tile_begin || !dw || n_groups <= 0 || group_rows <= 0 || in_features <= 0 || splits <= 0)
+  if (!dz_frag || !h_frag || !tile_begin || !dw || n_groups <= 0 || group_rows <= 0 || in_features <= 0 || splits <= 0 ||
+      (x3 && rows <= 0))
     return RG_EINVAL;
   if (group_rows > 256) return RG_EUNSUPPORTED;  // one n-group of the 256 x 256 workgroup tile per action
   if (!workspace || workspace_bytes < rg_group_head_wgrad_workspace_bytes(n_groups, group_rows, in_features, splits))
@@ -1308,7 +1314,10 @@ int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* 
   G.g.a_frag = (const bf16_t*)dz_frag; G.g.b_frag = (const bf16_t*)h_frag;
   G.g.NTa = (group_rows + 31) / 32; G.g.NTb = (in_features + 31) / 32; G.g.MB = 0; G.g.mb_per_split = 0; G.g.splits = splits;
   G.g.partial = (float*)workspace; G.g.slab = (long)group_rows * in_features; G.g.N = group_rows; G.g.K = in_features;
-  G.g.x3 = 0; G.g.a_lo = G.g.b_lo = 0;
+  // split-bf16: each operand is [hi plane | lo plane] over the `rows` rows of the grouped space (rg_frag_elems apart)
+  G.g.x3 = x3 ? 1 : 0;
+  G.g.a_lo = x3 ? (long)frag_elems(rows, group_rows) : 0;
+  G.g.b_lo = x3 ? (long)frag_elems(rows, in_features) : 0;
   G.tile_begin = tile_begin; G.n_groups = n_groups; G.splits = splits;
   const int k_groups = (G.g.NTb + 7) / 8;
   const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
@@ -1470,10 +1479,11 @@ static int mlp_update_launch(const rg_mlp_update_desc* d, double lr, double beta
       U.w_off[l] = d->w_off[l]; U.b_off[l] = d->b_off[l];
       U.wf[l] = (bf16_t*)d->wfrag_fwd[l]; U.wb[l] = (bf16_t*)d->wfrag_bwd[l]; U.twf[l] = (bf16_t*)d->target_wfrag_fwd[l];
       const int Ng = d->group_rows[l];
-      if (Ng < 0 || (Ng > 0 && (N % Ng != 0 || d->x3))) return RG_EINVAL;
+      if (Ng < 0 || (Ng > 0 && N % Ng != 0)) return RG_EINVAL;
       U.Ng[l] = Ng;
-      U.per_f[l] = Ng > 0 ? (long)wfrag_elems(Ng, K) : 0;
-      U.per_b[l] = Ng > 0 ? (long)wfrag_elems(K, Ng) : 0;
+      // a group's fragment set: [hi plane] (bf16) or [hi plane | lo plane] (split-bf16), what rg_group_weights_stage writes
+      U.per_f[l] = Ng > 0 ? (long)wfrag_elems(Ng, K) * (d->x3 ? 2 : 1) : 0;
+      U.per_b[l] = Ng > 0 ? (long)wfrag_elems(K, Ng) * (d->x3 ? 2 : 1) : 0;
       const long we = d->w_off[l] + (long)N * K, be = d->b_off[l] + N;
       total = we > total ? we : total;
       total = be > total ? be : total;

@@ -138,6 +138,54 @@ __device__ __forceinline__ void load_tile_split(bf16_t* act, int pitch, const T*
   }
 }
 
+// the same through a row map (grouped space, qr_grouped.hip): tile row r <- src row rowmap[row_base + r] (-1: zeros).
+// Two chunks per thread in flight, like the aligned path above.
+template <typename T, int THREADS, int LO>
+__device__ __forceinline__ void load_tile_split_mapped(bf16_t* act, int pitch, const T* src, long ld, const int* rowmap,
+                                                       int row_base, int ncols, int ncols_pad, int tid) {
+  const int cpr = ncols_pad / 8;
+  const int total = X3_BM * cpr;
+  const bool vec = ((ld % 8) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (int c = tid; c < total; c += THREADS) {
+    const int r = c / cpr, k0 = (c % cpr) * 8;
+    const int grow = rowmap[row_base + r];
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    if (grow >= 0 && k0 < ncols) {
+      const T* p = src + (long)grow * ld + k0;
+      if (vec && k0 + 8 <= ncols) {
+        if (sizeof(T) == 4) {
+          const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f[e] = a[e];
+            f[4 + e] = b[e];
+          }
+        } else {
+          const u16x8 v = *(const u16x8*)p;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32(v[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (k0 + e < ncols) f[e] = cvt_in(p[e]);
+      }
+    }
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned hh, ll;
+      split_pack(f[2 * e], f[2 * e + 1], hh, ll);
+      h[e] = hh;
+      l[e] = ll;
+    }
+    *(u32x4*)&act[r * pitch + k0] = h;
+    *(u32x4*)&act[LO + r * pitch + k0] = l;
+  }
+}
+
 // LDS plane (64 rows x ntiles*32 cols) -> C-fragment order in global memory (two 32-row blocks per workgroup)
 __device__ __forceinline__ void emit_frags_x3(const bf16_t* plane, int pitch, int ntiles, bf16_t* dst, int mb_base,
                                               int wave, int n_waves, int lane) {
@@ -391,18 +439,30 @@ __device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16
   });
 }
 
-template <int TN, int NW, int PITCH>
-__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
+// GROUPED: the launch of a stack whose output layer takes per-tile weights (rg_mlp_desc.tile_key, qr_grouped.hip: QR-DQN's
+// wide layer, one action's [N, H] slice per 128-row tile of the grouped row space).  A 64-row workgroup is HALF such a tile:
+// unit u = rows [64 u, 64 u + 64), tile u / 2.  Units go to the XCDs in eighths of the (group-sorted) unit list, as the
+// bf16 kernel's tiles do (grouped_tile), and the launch is its own instantiation.
+template <int TN, int NW, int PITCH, bool GROUPED>
+__device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
   constexpr int THREADS = NW * 64, RING = RG_X3_RING, LO = X3_BM * PITCH;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
-  const int row_base = blockIdx.x * X3_BM;
+  const int n_units = (a.batch + X3_BM - 1) / X3_BM;
+  const int unit = GROUPED ? grouped_tile(blockIdx.x, n_units) : (int)blockIdx.x;
+  if (GROUPED && unit >= n_units) return;  // padding blocks (workgroup-uniform)
+  const int row_base = unit * X3_BM;
   constexpr int pitch = PITCH;
   const int k0p = round_up(a.dims[0], 32);
   RG_STAMP(0);
-  if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
+  if (GROUPED) {  // grouped space: rows gathered through the map
+    if (a.x_is_f32)
+      load_tile_split_mapped<float, THREADS, LO>(act, pitch, (const float*)a.x, a.ldx, a.rowmap, row_base, a.dims[0], k0p, tid);
+    else
+      load_tile_split_mapped<bf16_t, THREADS, LO>(act, pitch, (const bf16_t*)a.x, a.ldx, a.rowmap, row_base, a.dims[0], k0p, tid);
+  } else if (a.x2) {  // two panels (state | action): columns [0, x_split) from x, the rest from x2
     const int n2 = a.dims[0] - a.x_split;
     if (a.x_is_f32)
       load_tile_split<float, THREADS, LO>(act, pitch, (const float*)a.x, a.ldx, row_base, a.batch, a.x_split, a.x_split, tid);
@@ -419,8 +479,8 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   __syncthreads();
   RG_STAMP(1);
   if (a.save == 1 && a.act_frag[0]) {
-    emit_frags_x3(act, pitch, k0p / 32, a.act_frag[0], blockIdx.x * X3_TM, wave, NW, lane);
-    emit_frags_x3(act + LO, pitch, k0p / 32, a.act_frag[0] + a.act_lo[0], blockIdx.x * X3_TM, wave, NW, lane);
+    emit_frags_x3(act, pitch, k0p / 32, a.act_frag[0], unit * X3_TM, wave, NW, lane);
+    emit_frags_x3(act + LO, pitch, k0p / 32, a.act_frag[0] + a.act_lo[0], unit * X3_TM, wave, NW, lane);
   }
 
   for (int l = 0; l < a.n_layers; ++l) {
@@ -441,7 +501,7 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
       unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
       unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;
       RG_DISPATCH_ACT(a.acts[l], (x3_fwd_pack<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l),
-                                                      a.act_lo[l + 1], sign_dst, N / 32, blockIdx.x * X3_TM, wave, lane, PH,
+                                                      a.act_lo[l + 1], sign_dst, N / 32, unit * X3_TM, wave, lane, PH,
                                                       PL)));
       RG_STAMP(3 + 4 * l);
       __syncthreads();  // every wave is done reading the layer input
@@ -450,6 +510,59 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
       x3_store_packed_tiles<TN>(act + LO, pitch, PL, wave, lane);
       __syncthreads();
       RG_STAMP(5 + 4 * l);
+    } else if (GROUPED) {  // grouped output layer: this tile's group selects the weight / bias slice
+      const int NTo = (N + 31) / 32;
+      const int out_act = a.acts[l];
+      const int grp = a.tile_key[unit >> 1];
+      if (grp >= 0) {  // (workgroup-uniform: an empty tile has no output and skips the barriers together)
+        const bf16_t* wf_out = a.wfrag[l] + (long)grp * a.group_stride;
+        const float* b_out = a.bias[l] ? a.bias[l] + (long)grp * N : nullptr;
+        if (a.stage_out && NTo <= NW) {
+          // a wide output (QR-DQN: 200 quantiles, 800-byte rows) leaves as WHOLE ROWS, 16 bytes per lane, through a staging
+          // area behind the two activation planes — one 32-row tile at a time, wave w computing its column tile w (what
+          // mlp_fwd_fused_body does for the bf16 stack: stored straight from the accumulators every wave instruction would
+          // write partial cache lines)
+          float* stage = (float*)(act + 2 * LO);
+          const int P = NTo * 32 + 4;  // floats per staged row
+          const int np = N >> 2;       // 16-byte pieces per row
+          for (int tm = 0; tm < X3_TM; ++tm) {
+            if (wave < NTo) {
+              const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, wf_out, a.wfrag_lo[l], tm, wave, lane);
+              const int col = wave * 32 + lr;
+              const float b = (b_out && col < N) ? b_out[col] : 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+            }
+            __syncthreads();
+            for (int it = tid; it < 32 * np; it += THREADS) {
+              const int r = it / np, c4 = it - r * np;
+              int row = row_base + tm * 32 + r;
+              if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
+              if (row >= 0 && (a.out_scatter || row < a.batch))
+                stream_store(*(const f32x4*)(stage + r * P + c4 * 4), (f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4));
+            }
+            __syncthreads();
+          }
+        } else {
+          for (int t = wave; t < X3_TM * NTo; t += NW) {
+            const int tm = t % X3_TM, nt = t / X3_TM;
+            const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, wf_out, a.wfrag_lo[l], tm, nt, lane);
+            const int col = nt * 32 + lr;
+            if (col < N) {
+              const float b = b_out ? b_out[col] : 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                if (a.out_scatter) row = a.rowmap[row];
+                if (row >= 0 && (a.out_scatter || row < a.batch))
+                  a.out32[(long)row * a.ldo + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+              }
+            }
+          }
+        }
+      }
+      RG_STAMP(2 + 4 * l);
     } else {  // output layer: 32x32 tiles spread over the waves, fp32 result to HBM
       const int NTo = (N + 31) / 32;
       const int out_act = a.acts[l];
@@ -500,6 +613,15 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
   }
 }
 
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_kernel(MlpArgs a) {
+  mlp_fwd_x3_body<TN, NW, PITCH, false>(a);
+}
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_grouped_kernel(MlpArgs a) {
+  mlp_fwd_x3_body<TN, NW, PITCH, true>(a);
+}
+
 template <int TN, int NW, int PITCH, bool DX_ONLY>
 __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
   constexpr int THREADS = NW * 64, RING = RG_X3_RING, LO = X3_BM * PITCH;
@@ -507,20 +629,24 @@ __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
   bf16_t* act = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
-  const int row_base = blockIdx.x * X3_BM;
+  // grouped launch (rg_mlp_desc.tile_key): 64-row units of the group-sorted row space, shared out to the XCDs in eighths
+  const int n_units = round_up(a.batch, 128) / X3_BM;
+  const int unit = a.tile_key ? grouped_tile(blockIdx.x, n_units) : (int)blockIdx.x;
+  if (unit >= n_units) return;  // padding blocks of a grouped launch (workgroup-uniform)
+  const int row_base = unit * X3_BM;
   constexpr int pitch = PITCH;
   const int L = a.n_layers;
   const int nop = round_up(a.dims[L], 32);
   load_tile_split<float, THREADS, LO>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
   if (!DX_ONLY) {
-    emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
-    emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], blockIdx.x * X3_TM, wave, NW, lane);
+    emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], unit * X3_TM, wave, NW, lane);
+    emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], unit * X3_TM, wave, NW, lane);
   }
   if (a.db_part[L - 1] && tid < a.dims[L]) {
     float s = 0.f;
     for (int r = 0; r < X3_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]) + bf16_to_f32(act[LO + r * pitch + tid]);
-    a.db_part[L - 1][(long)blockIdx.x * a.dims[L] + tid] = s;
+    a.db_part[L - 1][(long)unit * a.dims[L] + tid] = s;
   }
 
   for (int l = L - 1; l >= 1; --l) {
@@ -538,18 +664,23 @@ __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
     unsigned sg[TN];
     const bool use_sign = a.act_sign[l] != nullptr;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) sg[i] = use_sign ? a.act_sign[l][x3_sign_offset(blockIdx.x, wave, lane, TN, N) + i] : 0u;
-    x3_mainloop<TN, RING, LO>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, a.wfrag_lo[l], nt_stride, acc, lane,
+    for (int i = 0; i < TN; ++i) sg[i] = use_sign ? a.act_sign[l][x3_sign_offset(unit, wave, lane, TN, N) + i] : 0u;
+    const bf16_t* wl = a.wfrag[l];
+    if (l == L - 1 && a.tile_key) {  // grouped output layer: this tile's slice of W^T (an empty tile: dZ is zero)
+      const int grp = a.tile_key[unit >> 1];
+      wl += (long)(grp < 0 ? 0 : grp) * a.group_stride;
+    }
+    x3_mainloop<TN, RING, LO>(act, pitch, KC, wl + (long)(wave * TN) * nt_stride, a.wfrag_lo[l], nt_stride, acc, lane,
                               k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
-    float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)blockIdx.x * N : nullptr;
+    float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)unit * N : nullptr;
     unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
     if (use_sign) {
       RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, true, !DX_ONLY>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
-                                                               a.dz_lo[l - 1], dbp, N / 32, blockIdx.x * X3_TM, wave, lane,
+                                                               a.dz_lo[l - 1], dbp, N / 32, unit * X3_TM, wave, lane,
                                                                PH, PL)));
     } else {
       RG_DISPATCH_ACT(a.acts[l - 1], (x3_bwd_pack<TN, A_, false, !DX_ONLY>(acc, a.act_frag[l], a.act_lo[l], sg, a.dz_frag[l - 1],
-                                                                a.dz_lo[l - 1], dbp, N / 32, blockIdx.x * X3_TM, wave, lane,
+                                                                a.dz_lo[l - 1], dbp, N / 32, unit * X3_TM, wave, lane,
                                                                 PH, PL)));
     }
     __syncthreads();  // every wave is done reading dZ_l
@@ -607,7 +738,21 @@ static inline int x3_grid(int batch, bool padded) {
 }
 
 int x3_forward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
+  size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
+  a.stage_out = a.out_lds = 0;
+  if (d->tile_key) {
+    // grouped: 64-row units of the padded (multiple of 128) row space, whole eighths of the unit list (grouped_tile)
+    const int n_units = (a.batch + X3_BM - 1) / X3_BM;
+    const dim3 grid((n_units + 7) / 8 * 8);
+    const int No = d->dims[d->n_layers], NTo = (No + 31) / 32;
+    const size_t stage = (size_t)32 * (NTo * 32 + 4) * sizeof(float);
+    if (No > 64 && (No & 3) == 0 && (a.ldo & 3) == 0 && (((uintptr_t)a.out32) & 15) == 0 && lds + stage <= 160 * 1024) {
+      a.stage_out = 1;
+      lds += stage;
+    }
+    RG_LAUNCH_X3(mlp_fwd_x3_grouped_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+    return (int)hipGetLastError();
+  }
   const dim3 grid(x3_grid(a.batch, a.save != 0));
   RG_LAUNCH_X3(mlp_fwd_x3_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();
@@ -615,7 +760,8 @@ int x3_forward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
 
 int x3_backward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
-  const dim3 grid(x3_grid(a.batch, true));
+  const int n_wg = x3_grid(a.batch, true);
+  const dim3 grid(d->tile_key ? (n_wg + 7) / 8 * 8 : n_wg);
   if (d->dx_only) RG_LAUNCH_X3(mlp_bwd_x3_dx_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   else RG_LAUNCH_X3(mlp_bwd_x3_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();

@@ -23,21 +23,25 @@ namespace rg {
 
 // ---- weights of the grouped layer -------------------------------------------------------------------------
 // wf[g]: B fragments of W_g [Ng, K] (forward), wb[g]: B fragments of W_g^T [K, Ng] (input gradient)
+// x3 (split-bf16): a group's set is [hi plane | lo plane], lo = bf16(w - hi) — stage_weight_elem's layout per group
 __global__ void group_stage_kernel(const float* __restrict__ w, int G, int Ng, int K, bf16_t* __restrict__ wf,
-                                   bf16_t* __restrict__ wb, long per_f, long per_b) {
+                                   bf16_t* __restrict__ wb, long per_f, long per_b, int x3) {
   const long per = per_f > per_b ? per_f : per_b;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= per * G) return;
   const int g = (int)(i / per);
-  stage_weight_elem(w + (long)g * Ng * K, Ng, K, wf ? wf + g * per_f : nullptr, wb ? wb + g * per_b : nullptr, i % per);
+  const int planes = x3 ? 2 : 1;
+  stage_weight_elem(w + (long)g * Ng * K, Ng, K, wf ? wf + g * per_f * planes : nullptr, wb ? wb + g * per_b * planes : nullptr,
+                    i % per, x3);
 }
 
 // wbar[g][k] = mean_n w[(g * Ng + n) * K + k], bbar[g] = mean_n b[g * Ng + n]  (fp32; 8 row strides per column
 // summed separately and combined in fixed order)
 // wfrag (nullable): the forward B fragments of the [G, K] mean layer, written with the means (what a separate
 // rg_stage_weights_frag of wbar would write to the slots of rows < G; the padding rows were zeroed by the first staging)
+// x3: the fragments' lo plane (wfrag_elems(G, K) elements behind the hi plane) gets bf16(mean - hi)
 __global__ void wide_mean_kernel(const float* __restrict__ w, const float* __restrict__ b, int G, int Ng, int K,
-                                 float* __restrict__ wbar, float* __restrict__ bbar, bf16_t* __restrict__ wfrag) {
+                                 float* __restrict__ wbar, float* __restrict__ bbar, bf16_t* __restrict__ wfrag, int x3) {
   __shared__ float red[8][33];
   const int g = blockIdx.y, c = threadIdx.x & 31, rg = threadIdx.x >> 5, k = blockIdx.x * 32 + c;
   float s = 0.f;
@@ -65,7 +69,10 @@ __global__ void wide_mean_kernel(const float* __restrict__ w, const float* __res
     wbar[(long)g * K + k] = mean;
     if (wfrag) {
       const int KCf = (K + 15) / 16;
-      wfrag[((((long)(g >> 5) * KCf + (k >> 4)) * 64) + ((g & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7)] = f32_to_bf16(mean);
+      const long j = ((((long)(g >> 5) * KCf + (k >> 4)) * 64) + ((g & 31) + 32 * ((k & 15) >> 3))) * 8 + (k & 7);
+      const bf16_t hi = f32_to_bf16(mean);
+      wfrag[j] = hi;
+      if (x3) wfrag[(long)((G + 31) / 32) * KCf * 512 + j] = f32_to_bf16(mean - bf16_to_f32(hi));
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {  // the group's bias mean: one wave, lane-strided partial sums
@@ -391,9 +398,9 @@ __global__ void tile_sum_kernel(const float* __restrict__ v, float* __restrict__
 
 // db[g * Ng + n] = sum over the tiles of group g of db_part[tile][n]
 __global__ void group_bias_reduce_kernel(const float* __restrict__ db_part, const int* __restrict__ tile_begin, int Ng,
-                                         int NgP, float* __restrict__ db) {
+                                         int NgP, float* __restrict__ db, int wg_per_tile) {
   const int g = blockIdx.x;
-  const int t0 = tile_begin[g], t1 = tile_begin[g + 1];
+  const int t0 = tile_begin[g] * wg_per_tile, t1 = tile_begin[g + 1] * wg_per_tile;
   for (int n = threadIdx.x; n < Ng; n += blockDim.x) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four tiles in flight (a ~30-deep chain of dependent loads was 15 us)
     int t = t0;
@@ -408,9 +415,9 @@ __global__ void group_bias_reduce_kernel(const float* __restrict__ db_part, cons
   }
 }
 
-void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db,
+void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db, int wg_per_tile,
                                 hipStream_t stream) {
-  RG_LAUNCH(group_bias_reduce_kernel, dim3(n_groups), dim3(256), stream, db_part, tile_begin, Ng, Ng, db);
+  RG_LAUNCH(group_bias_reduce_kernel, dim3(n_groups), dim3(256), stream, db_part, tile_begin, Ng, Ng, db, wg_per_tile);
 }
 
 
@@ -424,14 +431,14 @@ size_t rg_group_wfrag_elems(int group_rows, int in_features, int transposed) {
   return transposed ? wfrag_elems(in_features, group_rows) : wfrag_elems(group_rows, in_features);
 }
 
-int rg_group_weights_stage(const float* w, int n_groups, int group_rows, int in_features, void* wfrag_fwd,
+int rg_group_weights_stage(const float* w, int n_groups, int group_rows, int in_features, int x3, void* wfrag_fwd,
                            void* wfrag_bwd, rg_stream_t stream) {
   if (!w || n_groups <= 0 || group_rows <= 0 || in_features <= 0 || (!wfrag_fwd && !wfrag_bwd)) return RG_EINVAL;
   const long per_f = (long)wfrag_elems(group_rows, in_features), per_b = (long)wfrag_elems(in_features, group_rows);
   const long per = per_f > per_b ? per_f : per_b;
   const long total = per * n_groups;
   RG_LAUNCH(group_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (hipStream_t)stream, w, n_groups,
-            group_rows, in_features, (bf16_t*)wfrag_fwd, (bf16_t*)wfrag_bwd, per_f, per_b);
+            group_rows, in_features, (bf16_t*)wfrag_fwd, (bf16_t*)wfrag_bwd, per_f, per_b, x3 ? 1 : 0);
   return (int)hipGetLastError();
 }
 
@@ -439,15 +446,15 @@ int rg_wide_head_mean(const float* w, const float* b, int n_groups, int group_ro
                       float* bbar, rg_stream_t stream) {
   if (!w || !wbar || !bbar || n_groups <= 0 || group_rows <= 0 || in_features <= 0) return RG_EINVAL;
   RG_LAUNCH(wide_mean_kernel, dim3((in_features + 31) / 32, n_groups), dim3(256), (hipStream_t)stream, w, b, n_groups,
-            group_rows, in_features, wbar, bbar, (bf16_t*)nullptr);
+            group_rows, in_features, wbar, bbar, (bf16_t*)nullptr, 0);
   return (int)hipGetLastError();
 }
 
 int rg_wide_head_mean_staged(const float* w, const float* b, int n_groups, int group_rows, int in_features, float* wbar,
-                             float* bbar, void* wfrag_fwd, rg_stream_t stream) {
+                             float* bbar, void* wfrag_fwd, int x3, rg_stream_t stream) {
   if (!w || !wbar || !bbar || !wfrag_fwd || n_groups <= 0 || group_rows <= 0 || in_features <= 0) return RG_EINVAL;
   RG_LAUNCH(wide_mean_kernel, dim3((in_features + 31) / 32, n_groups), dim3(256), (hipStream_t)stream, w, b, n_groups,
-            group_rows, in_features, wbar, bbar, (bf16_t*)wfrag_fwd);
+            group_rows, in_features, wbar, bbar, (bf16_t*)wfrag_fwd, x3 ? 1 : 0);
   return (int)hipGetLastError();
 }
 

@@ -721,7 +721,8 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
 }
 
 // db[g * Ng + n] = sum over the tiles of group g of db_part[tile][n] (qr_grouped.hip; db_part row pitch Ng)
-void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db,
+// wg_per_tile: workgroups (rows of db_part) per 128-row tile — 1 for the bf16 kernels, 2 for the split-bf16 ones
+void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db, int wg_per_tile,
                                 hipStream_t stream);
 
 // split-bf16 kernels (mlp_fused_x3.hip); `a` filled by fill_args, launch geometry decided there

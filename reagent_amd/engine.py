@@ -538,25 +538,27 @@ class GroupedHead:
     space (qr_engine.py): per-group MFMA fragments of W_g / W_g^T (rg_group_weights_stage), the bias, and the
     buffers the backward of that layer needs."""
 
-    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, n_groups: int, group_rows: int, need_bwd: bool):
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, n_groups: int, group_rows: int, need_bwd: bool, x3: bool = False):
         self.weight, self.bias, self.G, self.Ng = weight, bias, n_groups, group_rows
         H = weight.shape[1]
         dev = weight.device
         self.H = H
-        self.per_f = ops.group_wfrag_elems(group_rows, H, False)
-        self.per_b = ops.group_wfrag_elems(group_rows, H, True)
+        # split-bf16 (x3): a group's fragment set is [hi plane | lo plane]; per_f / per_b are the strides between groups
+        self.x3, self.planes = bool(x3), 2 if x3 else 1
+        self.per_f = self.planes * ops.group_wfrag_elems(group_rows, H, False)
+        self.per_b = self.planes * ops.group_wfrag_elems(group_rows, H, True)
         self.wf = torch.empty(n_groups * self.per_f, dtype=torch.bfloat16, device=dev)
         self.wb = torch.empty(n_groups * self.per_b, dtype=torch.bfloat16, device=dev) if need_bwd else None
         self._rows = -1
 
     def stage(self):
-        ops.group_weights_stage(self.weight.detach(), self.G, self.Ng, self.wf, self.wb)
+        ops.group_weights_stage(self.weight.detach(), self.G, self.Ng, self.wf, self.wb, x3=self.x3)
 
     def workspace(self, rows: int, st: "FusedMLP"):
         if self._rows != rows:
             dev = self.weight.device
             lib = L.lib()
-            self.dz_frag = torch.empty(lib.rg_frag_elems(rows, self.Ng), dtype=torch.bfloat16, device=dev)
+            self.dz_frag = torch.empty(self.planes * lib.rg_frag_elems(rows, self.Ng), dtype=torch.bfloat16, device=dev)
             d = self.desc(st, None, None, None)
             self.bwd_ws = torch.empty(lib.rg_mlp_backward_fused_workspace_bytes(d, rows) // 4 + 4, dtype=torch.float32, device=dev)
             self._rows = rows
@@ -619,6 +621,7 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
                                                head.bwd_ws.numel() * 4, L.stream_ptr()))
     t = L.MlpDesc()  # the trunk: layers 0 .. L-2
     t.n_layers = n - 1
+    t.x3 = int(st.x3)
     for i in range(n):
         t.dims[i] = st.dims[i]
     for l in range(n - 1):
@@ -628,7 +631,7 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
     ops._run("rg_mlp_wgrad_fused", dict(B=R, dims=tuple(st.dims[:n])),
              lambda: lib.rg_mlp_wgrad_fused(t, R, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))
     ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.tile_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
-                         wgrad_ws)
+                         wgrad_ws, x3=head.x3, rows=R)
 
 
 class FusedUpdate:

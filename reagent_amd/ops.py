@@ -703,16 +703,18 @@ def group_wfrag_elems(group_rows: int, in_features: int, transposed: bool) -> in
     return int(L.lib().rg_group_wfrag_elems(group_rows, in_features, int(transposed)))
 
 
-def group_weights_stage(w, n_groups, group_rows, wf, wb):
+def group_weights_stage(w, n_groups, group_rows, wf, wb, x3: bool = False):
+    """x3: split-bf16 — every group's fragment set is [hi plane | lo plane] (wf / wb hold 2 x the elements)"""
     _chk_dev(w, wf, wb)
     assert w.is_contiguous() and w.dtype == F32 and w.shape[0] == n_groups * group_rows
     _run("rg_group_weights_stage", dict(G=n_groups, Ng=group_rows, K=w.shape[1]),
-         lambda: L.lib().rg_group_weights_stage(w.data_ptr(), n_groups, group_rows, w.shape[1], L.ptr(wf), L.ptr(wb),
+         lambda: L.lib().rg_group_weights_stage(w.data_ptr(), n_groups, group_rows, w.shape[1], int(x3), L.ptr(wf), L.ptr(wb),
                                                 L.stream_ptr()))
 
 
-def wide_head_mean(w, b, n_groups, group_rows, wbar, bbar, wfrag_fwd=None):
-    """wfrag_fwd: the (already staged once) forward fragments of the [n_groups, in] mean layer, rewritten in the same launch"""
+def wide_head_mean(w, b, n_groups, group_rows, wbar, bbar, wfrag_fwd=None, x3: bool = False):
+    """wfrag_fwd: the (already staged once) forward fragments of the [n_groups, in] mean layer, rewritten in the same launch
+    (x3: both planes)"""
     _chk_dev(w, b, wbar, bbar)
     assert w.is_contiguous() and wbar.is_contiguous() and wbar.shape == (n_groups, w.shape[1])
     if wfrag_fwd is None:
@@ -723,7 +725,8 @@ def wide_head_mean(w, b, n_groups, group_rows, wbar, bbar, wfrag_fwd=None):
         _chk_dev(wfrag_fwd)
         _run("rg_wide_head_mean", dict(G=n_groups, Ng=group_rows, K=w.shape[1]),
              lambda: L.lib().rg_wide_head_mean_staged(w.data_ptr(), L.ptr(b), n_groups, group_rows, w.shape[1],
-                                                      wbar.data_ptr(), bbar.data_ptr(), wfrag_fwd.data_ptr(), L.stream_ptr()))
+                                                      wbar.data_ptr(), bbar.data_ptr(), wfrag_fwd.data_ptr(), int(x3),
+                                                      L.stream_ptr()))
 
 
 def qr_select_action(q, mask, maxq: bool, key):
@@ -762,13 +765,15 @@ def qr_compact_head(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal
                                             loss_partials.data_ptr(), L.ptr(tile_losses), L.stream_ptr()))
 
 
-def group_head_wgrad(dzw_frag, h_frag, tile_begin, n_groups, group_rows, in_features, splits, dw, workspace):
+def group_head_wgrad(dzw_frag, h_frag, tile_begin, n_groups, group_rows, in_features, splits, dw, workspace, x3: bool = False,
+                     rows: int = 0):
+    """x3: split-bf16 operands ([hi plane | lo plane] over the `rows` rows of the grouped space)"""
     _chk_dev(dzw_frag, h_frag, tile_begin, dw, workspace)
     assert dw.is_contiguous() and dw.shape == (n_groups * group_rows, in_features)
     _run("rg_group_head_wgrad", dict(G=n_groups, Ng=group_rows, K=in_features),
          lambda: L.lib().rg_group_head_wgrad(dzw_frag.data_ptr(), h_frag.data_ptr(), tile_begin.data_ptr(), n_groups,
-                                             group_rows, in_features, splits, dw.data_ptr(), workspace.data_ptr(),
-                                             workspace.numel() * 4, L.stream_ptr()))
+                                             group_rows, in_features, splits, int(x3), int(rows), dw.data_ptr(),
+                                             workspace.data_ptr(), workspace.numel() * 4, L.stream_ptr()))
 
 
 # ---- dueling aggregation -------------------------------------------------------------------------------------

@@ -12,8 +12,9 @@ reagent/training/qrdqn_trainer.py:108-160 computes, without ever writing the [B,
     loss, dz   = quantile Huber on [rows, N]               rg_qr_compact_head                      (:148-160, :217-218)
     backward   = ONE rg_mlp_backward_fused (the wide layer's input gradient is its first step, per-tile W_g^T),
                  rg_mlp_wgrad_fused for the trunk, rg_group_head_wgrad for the wide layer
-Arithmetic is that of the bf16 fused stack (bf16 operands, fp32 accumulation); the only algebraic rewrite is
-mean_n(h . W[a, n] + b[a, n]) = h . mean_n W[a, n] + mean_n b[a, n].  A transition whose logged action row is all
+Arithmetic is that of the fused stack in the network's precision — bf16 operands, or split-bf16 ("bf16x3": hi + lo planes,
+three MFMAs per product, quantiles within 1e-4 of the fp32 reference) — with fp32 accumulation; the only algebraic rewrite
+is mean_n(h . W[a, n] + b[a, n]) = h . mean_n W[a, n] + mean_n b[a, n].  A transition whose logged action row is all
 zero contributes nothing (the reference would regress C = 0 for it; one-hot actions are the trainer's contract,
 dqn_trainer_base.py `_check_input`).
 """
@@ -58,8 +59,9 @@ class GroupedSpace:
 class _Net:
     """one Q-network seen as trunk + grouped wide layer"""
 
-    def __init__(self, net, A: int, N: int, need_bwd: bool):
+    def __init__(self, net, A: int, N: int, need_bwd: bool, x3: bool = False):
         lin = net.fc.linears()
+        self.x3 = bool(x3)
         self.lin, self.head = lin, lin[-1]
         self.A, self.N, self.need_bwd = A, N, need_bwd
         H = self.head.weight.shape[1]
@@ -69,8 +71,8 @@ class _Net:
         self.bbar = torch.zeros(A, device=dev)
         acts = [L.ACT[a] for a in net.fc.activation_names]
         self.st = FusedMLP([l.weight for l in lin[:-1]] + [self.wbar], [l.bias for l in lin[:-1]] + [self.bbar],
-                           acts[:-1] + [L.ACT["linear"]])
-        self.gh = GroupedHead(self.head.weight, self.head.bias, A, N, need_bwd)
+                           acts[:-1] + [L.ACT["linear"]], x3=self.x3)
+        self.gh = GroupedHead(self.head.weight, self.head.bias, A, N, need_bwd, x3=self.x3)
         self._staged = None
         self._mean_stale = False
 
@@ -99,7 +101,7 @@ class _Net:
     def ensure_mean(self):
         if self._mean_stale:
             ops.wide_head_mean(self.head.weight.detach(), self.head.bias.detach(), self.A, self.N, self.wbar, self.bbar,
-                               wfrag_fwd=self.st._wf[self.st.L - 1])
+                               wfrag_fwd=self.st._wf[self.st.L - 1], x3=self.x3)
             self._mean_stale = False
 
 
@@ -107,8 +109,11 @@ class GroupedQR:
     def __init__(self, trainer):
         self.tr = trainer
         self.A, self.N = trainer.num_actions, trainer.num_atoms
-        self.online = _Net(trainer.q_network, self.A, self.N, need_bwd=True)
-        self.target = _Net(trainer.q_network_target, self.A, self.N, need_bwd=False)
+        # PREC_BF16X3: the same engine on split-bf16 operands (three MFMAs per product, every fragment buffer two planes) —
+        # the mode held to north_star's 1e-4 on the quantiles; the loss head runs in fp32 / fp64 either way
+        self.x3 = trainer.q_network.fc.precision == L.PREC_BF16X3
+        self.online = _Net(trainer.q_network, self.A, self.N, need_bwd=True, x3=self.x3)
+        self.target = _Net(trainer.q_network_target, self.A, self.N, need_bwd=False, x3=self.x3)
         self._B = -1
         self._side = None
         self.two_streams = os.environ.get("RG_QR_STREAMS", "1") != "0"  # the forward's two halves on two streams
@@ -133,7 +138,9 @@ class GroupedQR:
             names = fc.activation_names
         except AttributeError:
             return False
-        if fc.precision != L.PREC_BF16 or len(lin) < 3 or getattr(trainer, "_cpe", None) is not None:
+        if fc.precision not in (L.PREC_BF16, L.PREC_BF16X3) or len(lin) < 3 or getattr(trainer, "_cpe", None) is not None:
+            return False
+        if getattr(trainer.q_network_target.fc, "precision", fc.precision) != fc.precision:
             return False
         H = lin[0].weight.shape[0]
         A, N = trainer.num_actions, trainer.num_atoms

@@ -53,6 +53,7 @@ class _GraphedLoop:
     _pool = None
     _pool_pos = 0
     _pool_key = None
+    _pool_n = None  # the valid-slot count the pool was drawn for
 
     def _eager_step(self, indices=None):
         raise NotImplementedError
@@ -79,15 +80,21 @@ class _GraphedLoop:
         if self.index_pool_steps <= 1 or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             return None
         n, cap = rb._num_valid_indices, rb._replay_capacity
-        if n != cap:
-            # a buffer that is still filling (online / interleaved add and train) changes its valid set every step:
-            # a pool keyed on it would be redrawn — 32 draws' worth of RNG — per step and its undrawn rows dropped,
-            # so a checkpointed continuation would no longer follow the uninterrupted run.  The buffer draws per step.
+        if n == 0:
+            return None  # the buffer raises its own error
+        if self._pool_n is None:
+            self._pool_n = n
+        elif n != self._pool_n:
+            # The number of valid slots moved since the last draw: a buffer that is still filling (online / interleaved add
+            # and train).  A pool keyed on it would be redrawn — 32 draws' worth of RNG — on every such step and its undrawn
+            # rows dropped, so a checkpointed continuation would stop following the uninterrupted run.  The buffer draws
+            # this step itself; pooling resumes once the count has stayed put for a step (a full or a static store).
+            self._pool_n, self._pool = n, None
             return None
         self._ensure_pool(dev)
         pick = self._pool[self._pool_pos]
         self._pool_pos += 1
-        return pick
+        return pick if n == cap else rb._valid_indices()[pick]
 
     # ---- checkpoint / resume (what pl.Trainer's checkpointing does for the reference: module + optimizer states) ----
     def checkpoint(self) -> dict:

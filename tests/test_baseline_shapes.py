@@ -221,8 +221,25 @@ def test_c3_qrdqn_matches_reference(mode):
         dg = grad_err(tr._slab.grad_views(), g, f"step{s}_grad_")
         print(f"\n[baseline_c3 {mode} step {s}] max|dquantile| {dz:.3e} max|dQmean| {dq:.3e} rel dloss {dl:.3e} "
               f"max|dg|/max|g| {dg:.3e} max|dW| {dw:.3e} max|dW_target| {dt:.3e}")
-        if mode in ACCURATE:  # the 3200-wide head is outside the fused kernels' shape set: bf16x3 runs exact fp32 here
+        if mode == "f32":  # the dense [B, A * N] path on exact-fp32 GEMMs
+            assert tr._gq_active is None
             assert dz <= 1e-4 and dq <= 1e-4 and dl <= 1e-4 and dw <= 2e-5 and dt <= 2e-5 and dg <= GRAD_TOL["f32"]
+        elif mode == "bf16x3":
+            # round 4: the GROUPED engine on split-bf16 operands (qr_engine.py; the dense forward above ran exact fp32 — it is
+            # the model's own stack).  What the STEP computed: the logged action's quantiles in grouped space and the
+            # per-action means a* was chosen from, against the reference's rows; loss; every gradient; weights by the
+            # split-bf16 rule (Adam moves a weight by lr whatever |g|: the few whose gradient is below the arithmetic's
+            # error change direction).
+            gq = tr._gq_active
+            assert gq is not None and gq.x3
+            rowmap, key = gq.sp_cur.rowmap.cpu().long(), gq.key_cur.cpu().long()
+            zq, ref_rows = gq.z.cpu(), g.t(f"step{s}_quantile_rows")
+            dzg = max((zq[r, :N] - ref_rows[b_, key[b_]]).abs().max().item()
+                      for r, b_ in enumerate(rowmap.tolist()) if 0 <= b_ < ref_rows.shape[0])
+            fw = max(frac_beyond(p, g, f"step{s}_param_{i}") for i, p in enumerate(tr.q_network.parameters()))
+            print(f"[baseline_c3 bf16x3 grouped step {s}] max|dquantile| (grouped rows) {dzg:.3e} weights beyond 2e-5 {fw:.4f}")
+            assert dz <= 1e-4 and dq <= 1e-4 and dzg <= 1e-4 and dl <= 1e-4 and dg <= GRAD_TOL["bf16x3"]
+            assert fw <= 0.02 and dw <= 2.0 * (s + 1) * c["lr"] * 1.05 and dt <= 2.1e-6 * (s + 1)
         else:
             assert dz <= 6e-2 and dl <= 3e-2 and dw <= 2.0 * (s + 1) * c["lr"] * 1.05 and dt <= 1e-5
 

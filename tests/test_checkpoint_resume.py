@@ -146,6 +146,14 @@ def test_index_pool_draws_are_uniform_picks_of_valid_slots(emu_lib):
     rb._valid_host[:] = False
     rb._valid_host[10:40] = True
     rb._num_valid_indices, rb._valid_dirty = 30, True
+    # the step on which the count of valid slots moved is drawn by the buffer itself (a filling buffer must not
+    # redraw a whole pool per step); once the count has stayed put the pool is back, its picks going through the valid table
+    assert loop._draw_indices() is None
     idx = torch.cat([loop._draw_indices() for _ in range(5)])
     assert int(idx.min()) >= 10 and int(idx.max()) < 40 and len(idx.unique()) > 20
+    # a buffer that keeps filling never pools
+    for n in (31, 32, 33):
+        rb._valid_host[10:10 + n] = True
+        rb._num_valid_indices, rb._valid_dirty = n, True
+        assert loop._draw_indices() is None
 

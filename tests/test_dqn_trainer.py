@@ -249,7 +249,8 @@ def test_fused_update_equals_separate_launches(backend, state_dim, precision):
     x = batch.state
     assert torch.equal(fused.q_network(x), separate.q_network(x))
     assert torch.equal(fused.q_network_target(x), separate.q_network_target(x))
-    separate._qs.stage_weights(need_transposed=True)  # (the separate path stages lazily, before the next use)
+    separate._qs.stage_weights(need_transposed=True)  # (the separate path stages lazily, before the next use;
+    separate._ts.stage_weights(need_transposed=False)  # the grad-mode forwards above ran on the autograd engine's own copy)
     for a, b in zip(fused._qs._wf + fused._qs._wb + fused._ts._wf, separate._qs._wf + separate._qs._wb + separate._ts._wf):
         assert torch.equal(a, b)  # the staged fragments themselves, every plane
 

@@ -104,10 +104,10 @@ def test_qrdqn_cpe_matches_reference(backend):
 
 
 # ---- grouped wide layer (qr_engine.py / csrc/qr_grouped.hip) against the dense [B, A * N] path -------------------
-def _qr_pair(device, S, A, N, hidden, rl, double_q, seed=3):
+def _qr_pair(device, S, A, N, hidden, rl, double_q, seed=3, precision=L.PREC_BF16):
     def one(grouped):
         torch.manual_seed(seed)
-        set_default_precision(L.PREC_BF16)
+        set_default_precision(precision)
         try:
             q = FullyConnectedDQN(S, A, hidden, ["relu"] * len(hidden), num_atoms=N)
         finally:
@@ -173,6 +173,73 @@ def test_grouped_head_equals_dense_path(backend, rl, double_q, N):
     opts = [o["optimizer"] for o in tg.configure_optimizers()]
     losses = lightning_like_step(tg, opts, synthetic.to_dqn_input(b, dev))
     assert torch.isfinite(losses[0]).all()
+
+
+@pytest.mark.parametrize("rl,double_q", [
+    (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=True), True),
+    (dict(gamma=0.9, target_update_rate=0.1, maxq_learning=False, reward_boost={"1": 0.5}), True),
+])
+@pytest.mark.parametrize("N", [10, 72])  # 72: the wide output leaves through the LDS staging area behind both planes
+def test_grouped_head_split_bf16_meets_the_fp32_bound(backend, rl, double_q, N):
+    """The grouped engine on split-bf16 operands (PREC_BF16X3: what BASELINE config 3 runs in its 1e-4-compliant mode)
+    against the DENSE path of the same trainer, which for a [B, A * N] head runs exact-fp32 GEMMs: quantiles of the
+    logged action and the per-action means within 1e-4, loss within 1e-5 rel, every gradient within the split-bf16 bound
+    (ReLU masks that flip under a 1e-5 forward error), and the update in one launch bit-identical to separate launches."""
+    from reagent_amd.qr_engine import GroupedQR
+
+    dev = backend.device
+    S, A, B = 24, 4, 300
+    tg, td = _qr_pair(dev, S, A, N, [256, 256], rl, double_q, precision=L.PREC_BF16X3)
+    assert GroupedQR.eligible(tg)
+
+    class Reporter:  # with a reporter attached all_q_values is evaluated inside the step, with the step's weights
+        def log(self, **kw):
+            pass
+
+    tg.set_reporter(Reporter())
+    b = synthetic.dqn_batch(B, S, A, seed=21, p_impossible=0.3)
+    g = torch.Generator().manual_seed(5)
+    forced = torch.nn.functional.one_hot(torch.randint(A, (B,), generator=g), A).float()
+    b1 = dict(b, possible_next_actions_mask=forced, next_action=forced * b["not_terminal"])  # a* forced: same targets
+    batch = synthetic.to_dqn_input(b1, dev)
+    with torch.no_grad():
+        z_ref = td.q_network(batch.state)  # [B, A, N], exact fp32
+    lg, ld = tg.train_step_native(batch), td.train_step_native(batch)
+    gq = tg._gq_active
+    assert gq is not None and gq.x3 and gq.online.st.x3 and getattr(td, "_gq_active", None) is None
+    assert abs(lg.item() - ld.item()) <= 1e-5 * abs(ld.item()), (lg.item(), ld.item())
+    # quantiles of the logged action, row by row of the grouped space
+    rowmap, key = gq.sp_cur.rowmap.cpu().long(), gq.key_cur.cpu().long()
+    live = rowmap >= 0
+    rows = rowmap[live]
+    z_got = gq.z.cpu()[live][:, :N]
+    z_want = z_ref.cpu()[rows, key[rows]]
+    assert live.sum().item() == B and (z_got - z_want).abs().max() <= 1e-4, (z_got - z_want).abs().max()
+    assert (tg.all_q_values.cpu() - z_ref.cpu().mean(dim=2)).abs().max() <= 1e-4
+    for i, (x, y) in enumerate(zip(tg._slab.grad_views(), td._slab.grad_views())):
+        rel = ((x - y).abs().max() / (y.abs().max() + 1e-30)).item()
+        assert rel <= 3e-3, (i, rel)
+    assert isinstance(tg._fused_plan, dict) and tg._fused_plan["desc"].x3 == 1 and tg._fused_plan["desc"].group_rows[2] == N
+    # one-launch update == separate launches, bit for bit, in this mode too (both planes of every fragment set)
+    sep, _ = _qr_pair(dev, S, A, N, [256, 256], rl, double_q, precision=L.PREC_BF16X3)
+    sep._fused_plan = False
+    fused, _ = _qr_pair(dev, S, A, N, [256, 256], rl, double_q, precision=L.PREC_BF16X3)
+    for s_ in range(2):
+        bb = synthetic.to_dqn_input(synthetic.dqn_batch(B, S, A, seed=60 + s_, p_impossible=0.3), dev)
+        assert torch.equal(fused.train_step_native(bb), sep.train_step_native(bb)), s_
+    for a_, b_ in zip(list(fused.q_network.parameters()) + list(fused.q_network_target.parameters()),
+                      list(sep.q_network.parameters()) + list(sep.q_network_target.parameters())):
+        assert torch.equal(a_, b_)
+    gf, gs = fused._gq, sep._gq
+    for net in (gs.online, gs.target):
+        net.stage()
+    for net in (gf.online, gf.target):
+        net.ensure_mean()
+    for nf, ns in ((gf.online, gs.online), (gf.target, gs.target)):
+        assert torch.equal(nf.gh.wf, ns.gh.wf)
+        for a_, b_ in zip(nf.st._wf, ns.st._wf):
+            assert torch.equal(a_, b_)
+    assert torch.equal(gf.online.gh.wb, gs.online.gh.wb)
 
 
 @pytest.mark.parametrize("rl,double_q,N", [
