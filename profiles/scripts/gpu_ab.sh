@@ -5,7 +5,7 @@ timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); ass
 CFG=${AB_CONFIG:-c2}; PREC=${AB_PREC:-bf16}
 for rep in 1 2; do
 for envs in "$@"; do
-  env $envs timeout 600 python bench.py --config $CFG --precision $PREC --steps 20 --warmup 5 --no-cpu-baseline --no-parity --launch eager --no-graph > $OUT/ab.json 2> $OUT/ab.err || tail -5 $OUT/ab.err
+  env $envs timeout 600 python bench.py --config $CFG --precision $PREC --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-accurate --no-also --sustained-steps 0 --launch eager --no-graph ${AB_EXTRA} > $OUT/ab.json 2> $OUT/ab.err || tail -5 $OUT/ab.err
   python - "$envs" <<'PY'
 import json, sys
 r = json.load(open("/root/repo/gpurun_out/ab.json"))

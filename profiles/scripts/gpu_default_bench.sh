@@ -16,7 +16,15 @@ line("c2 bf16", r)
 if "accurate" in r: line("c2 x3", r["accurate"])
 for k, d in r.get("also_measured", {}).items():
     if "error" in d: print(k, d)
-    else: line(k, d)
+    else:
+        line(k, d)
+        if "accurate" in d:
+            if "error" in d["accurate"]: print(k, "x3", d["accurate"])
+            else: line(k + " x3", d["accurate"])
+for tag, d in (("c2 bf16", r), ("c2 x3", r.get("accurate", {}))):
+    s = d.get("sustained")
+    if s: print("sustained %-8s %d steps %.3f ms/step  sclk %s  power %s  (%s)" % (tag, s["steps"], s["ms_per_step"], s.get("sclk_mhz"), s.get("power_w"), s.get("source")))
+print("launch_calibration", r.get("launch_calibration"), "| instrumented_pass", r.get("instrumented_pass"))
 print("cpu_baseline", r.get("cpu_baseline"))
 for k,v in r["per_call_ms_per_step"].items(): print("  %-70s %.4f" % (k,v))
 PY
