@@ -123,7 +123,8 @@ def _measure_worker(rank, world, port, out_dir):
     assert m["sustained"]["steps"] == 3 and m["sustained"]["ms_per_step"] > 0 and "sclk_mhz" in m["sustained"]
     # the instrumented pass is normalised to the timed one: per-call times add up to no more than the timed step
     ip = m["extra"]["instrumented_pass"]
-    assert 0 < ip["scale"] <= 1.0
+    assert 0 < ip["scale"] <= 1.0 and ip["event_ms_per_step_sum"] > 0
+    assert sum(m["extra"]["per_call_ms_per_step"].values()) <= m["ms_per_step"] * 1.02 + 1e-3
     keep = dict(value=m["value"], ms=m["ms_per_step"], regions=m["region_ms"], per_rank=m["per_rank"], launch=m["launch"],
                 loss=m["final_loss"], parity=m["parity"], x3_value=ma["value"], x3_loss=ma["final_loss"],
                 x3_parity=ma["parity"], shard=float(m["cols"]["observation"].double().sum()))
@@ -148,3 +149,26 @@ def test_measure_on_two_ranks(tmp_path, emu_lib):
     assert r0["x3_parity"]["meets_north_star"], r0["x3_parity"]
     for r in (r0, r1):
         assert r["loss"] == r["loss"] and r["x3_loss"] == r["x3_loss"] and r["x3_value"] > 0  # finite
+
+
+@pytest.mark.parametrize("config,precision", [("c3", "bf16x3"), ("c3", "bf16"), ("c4", "bf16x3")])
+def test_parity_leg_of_the_other_configurations(emu_lib, monkeypatch, config, precision):
+    """bench.parity_check for C3 / C4 at interpreter sizes: C3's compares what the STEP computed on the grouped engine
+    (logged-action quantiles of every row, next-state per-action means), in split-bf16 mode within north_star's 1e-4"""
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", config, "--precision", precision, "--capacity", "1024",
+                                      "--batch", "128", "--parity-batch", "192", "--hidden", "256", "--layers", "2"])
+    args = bench.parse()
+    if config == "c3":
+        args.atoms = 24
+    dev = torch.device("cpu")
+    _, _, init, cols, norm = bench.build(args, dev, 0, batch=128)
+    out = bench.parity_check(args, dev, init, cols, norm)
+    assert out["gather_fields_bit_exact"], out
+    if config == "c3":
+        assert out["path"].startswith("grouped engine") and out["dq_rows"] == 192, out
+    if precision == "bf16x3":
+        assert out["meets_north_star"] and out["rel_dloss"] <= 1e-4, out
+    else:
+        assert out["sane"], out

@@ -236,3 +236,42 @@ def test_c2_step_against_the_oracle_at_full_size(precision, monkeypatch):
         assert out["frac_dw_beyond_2e-5"] <= 1e-4 and out["max_abs_dw"] <= 2.1e-3, out
     else:
         assert out["ok"], out
+
+
+def test_c3_step_against_the_oracle_at_the_host_limit(monkeypatch):
+    """BASELINE config 3 (QR-DQN, 200 quantiles) in its 1e-4-compliant mode — the GROUPED engine on split-bf16 operands —
+    at B = 8192, the largest batch the reference formula fits in host memory (its (N, B, N) tensor): every
+    transition's logged-action quantiles and next-state per-action means against oracle/restated.py within 1e-4, loss
+    within 1e-4 relative, gather fields bit exact."""
+    import sys
+
+    import bench
+
+    Bq = 8192
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "c3", "--precision", "bf16x3", "--parity-batch", str(Bq)])
+    args = bench.parse()
+    dev = torch.device("cuda:0")
+    _, tr, init, cols, norm = bench.build(args, dev, 0, batch=256)
+    out = bench.parity_check(args, dev, init, cols, norm)
+    assert out["batch"] == Bq and out["gather_fields_bit_exact"] and out["dq_rows"] == Bq, out
+    assert out["path"] == "grouped engine, split-bf16", out
+    assert out["max_abs_dquantile"] <= 1e-4 and out["max_abs_dq"] <= 1e-4 and out["rel_dloss"] <= 1e-4, out
+    assert out["meets_north_star"] and out["ok"], out
+
+
+def test_c4_step_against_the_oracle_at_full_size(monkeypatch):
+    """BASELINE config 4 (SAC, S = 256, A = 32, actor + twin critics, 3 x 512) at B = 65 536 in split-bf16 mode: policy
+    logits (loc, scale_log) within 1e-4 of oracle/restated.py on every row, the three losses within 1e-4 relative, gather
+    fields bit exact, weights by the split-bf16 rule of tests/test_baseline_shapes.py."""
+    import sys
+
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "c4", "--precision", "bf16x3", "--parity-batch", str(B)])
+    args = bench.parse()
+    dev = torch.device("cuda:0")
+    _, _, init, cols, norm = bench.build(args, dev, 0, batch=256)
+    out = bench.parity_check(args, dev, init, cols, norm)
+    assert out["batch"] == B and out["gather_fields_bit_exact"], out
+    assert out["max_abs_dlogits"] <= 1e-4 and out["rel_dloss"] <= 1e-4, out
+    assert out["meets_north_star"] and out["ok"], out
