@@ -346,11 +346,38 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         act.forward(x, raw, save=save)
         return self.actor_network.head_norm(raw, out, self._ln_stats if save else None)
 
-    def _publish(self, e, held=()):
+    def _publish(self, e, held=(), reduce=True):
         slab = e["slab"]
-        if self._dp_group is not None:
-            dp_reduce(self, slab)
+        if self._dp_group is not None and reduce:
+            with ops.profile_span("all_reduce", dict(bytes=slab.grad.numel() * 4, world=self._dp_world)):
+                dp_reduce(self, slab)
         publish_gradients(slab, e["params"], held)
+
+    def _dp_bucket(self):
+        """Data parallel: the gradient slabs of the two critics become the two halves of ONE buffer, so that the native step
+        sums both with a single all-reduce (few, large collectives — at C4 2 x 2.7 MB are latency-bound either
+        way, and a step is a chain of them).  Everything that reads a slab's gradients goes through `slab.grad`."""
+        if "q2" not in self._e:
+            return None
+        s1, s2 = self._e["q1"]["slab"], self._e["q2"]["slab"]
+        b = getattr(self, "_dp_bucket_q", None)
+        ok = (b is not None and b.device == s1.grad.device and b.numel() == s1.total + s2.total
+              and s1.grad.data_ptr() == b.data_ptr() and s2.grad.data_ptr() == b.data_ptr() + 4 * s1.total)
+        if not ok:
+            b = torch.zeros(s1.total + s2.total, dtype=torch.float32, device=s1.grad.device)
+            for slab, off in ((s1, 0), (s2, s1.total)):
+                view = b[off:off + slab.total]
+                view.copy_(slab.grad)
+                old = slab.grad.data_ptr()
+                for i, p in enumerate(slab.params):  # gradients published through the old slab follow it
+                    if p.grad is not None and p.grad.data_ptr() == old + 4 * slab.offsets[i]:
+                        p.grad = slab.view(view, i)
+                slab.grad = view
+            for k in ("q1", "q2"):
+                e = self._e[k]
+                e["dw"], e["db"] = grad_views(getattr(self, f"{k}_network").fc, e["slab"], e["params"])
+            self._dp_bucket_q = b
+        return b
 
     # ---- segments ----------------------------------------------------------------------------------
     def _critic_forward(self, b, noise_next):
@@ -467,14 +494,14 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             m["log_prob_a"] = lpa.mean()
             m["next_state_value"] = (nsv.reshape(-1) - alpha.float() * lpa.reshape(-1)).mean()
 
-    def _critic_backward(self, which, grad_out=None):
+    def _critic_backward(self, which, grad_out=None, reduce=True):
         e = self._e[which]
         dq = self._dq1 if which == "q1" else self._dq2
         if grad_out is not None:
             dq = dq * grad_out
         held = held_gradients(e["slab"], e["params"])
         e["stack"].backward(dq, self._x_t, e["dw"], e["db"], **self._take_tail(which))
-        self._publish(e, held)
+        self._publish(e, held, reduce=reduce)
 
     def _actor_forward(self, b, noise_cur):
         state = self._state_in(b.state.float_features)
@@ -734,18 +761,38 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
     def _native_segments(self, b, B, A, dev, gs, it, opts, noise_next, noise_cur):
         self._critic_forward(b, self._noise(B, A, dev, noise_next))
         fused = self._fused_updates(opts)  # Adam (+ soft update) + re-staging per network in one launch, or None
-        for k in ("q1", "q2"):
-            if k in self._e:
+        dp = self._dp_group is not None
+        bucket = self._dp_bucket() if dp else None
+        critics = [k for k in ("q1", "q2") if k in self._e]
+        if bucket is not None:
+            # data parallel, twin critics: both backward passes first (q2's reads nothing q1's update writes), ONE all-reduce
+            # of the two slabs, then the two updates in the reference's order
+            for k in critics:
+                for p in self._e[k]["params"]:
+                    p.grad = None
+                self._critic_backward(k, reduce=False)
+            with ops.profile_span("all_reduce", dict(bytes=bucket.numel() * 4, world=self._dp_world)):
+                torch.distributed.all_reduce(bucket, group=self._dp_group)
+        for k in critics:
+            if bucket is None:
                 for p in self._e[k]["params"]:
                     p.grad = None
                 self._critic_backward(k)
-                o = next(it)
-                if fused is not None:
-                    fused[k].step(gs)
-                else:
-                    o.grad_scale = gs
-                    o.step()
+            o = next(it)
+            if fused is not None:
+                fused[k].step(gs)
+            else:
+                o.grad_scale = gs
+                o.step()
         self._actor_forward(b, self._noise(B, A, dev, noise_cur))
+        alpha_reduce = None
+        if self.alpha_optimizer is not None and dp:
+            # the temperature's gradient needs the actor FORWARD only (mean of log_prob + target entropy): under data
+            # parallelism it is taken here and its 8-byte all-reduce runs asynchronously under the actor's backward pass
+            # instead of standing, latency-bound, between two optimizer steps
+            self.log_alpha.grad = None
+            self._alpha_backward(alias=True)
+            alpha_reduce = torch.distributed.all_reduce(self.log_alpha.grad, group=self._dp_group, async_op=True)
         for p in self._e["actor"]["params"]:
             p.grad = None
         self._actor_backward()
@@ -756,11 +803,12 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
             o.grad_scale = gs
             o.step()
         if self.alpha_optimizer is not None:
-            self.log_alpha.grad = None
-            self._alpha_backward(alias=True)
-            if self._dp_group is not None:
-                torch.distributed.all_reduce(self.log_alpha.grad, group=self._dp_group)
+            if alpha_reduce is not None:
+                alpha_reduce.wait()  # (the compute stream waits; the host does not)
                 self.log_alpha.grad.mul_(gs)
+            else:
+                self.log_alpha.grad = None
+                self._alpha_backward(alias=True)
             next(it).step()
             # the aliased gradient IS the kernel's output buffer: never leave it attached — a later generator-path backward
             # with grads kept (zero_grad(set_to_none=False)) would add the buffer to itself after the kernel rewrote it

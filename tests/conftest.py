@@ -34,6 +34,16 @@ def pytest_cmdline_main(config):
     return None
 
 
+def free_port() -> int:
+    """a TCP port nobody listens on right now (rendezvous of the world-2 gloo tests: ports derived from the pid collide
+    between pytest-xdist workers, whose pids are neighbours)"""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 @dataclass
 class Backend:
     name: str

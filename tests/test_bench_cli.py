@@ -8,6 +8,8 @@ import sys
 import types
 
 import pytest
+
+from conftest import free_port
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -135,7 +137,7 @@ def _measure_worker(rank, world, port, out_dir):
 def test_measure_on_two_ranks(tmp_path, emu_lib):
     import torch.multiprocessing as mp
 
-    port = 29500 + (os.getpid() % 2000) + 11
+    port = free_port()
     mp.spawn(_measure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     # whole-job value: both ranks' transitions over the slowest rank's time — the same number on every rank

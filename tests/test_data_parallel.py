@@ -7,6 +7,8 @@ import os
 import sys
 
 import pytest
+
+from conftest import free_port
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -141,8 +143,29 @@ def _worker(rank, world, port, kind, out_dir):
     my_noise = tuple(n[rank * B // 2 : (rank + 1) * B // 2].contiguous() for n in noise)
     tr = _build(kind).enable_data_parallel()
     fused = kind in ("dqn_fused", "sac_fused", "dqn_x3", "qr_fused")
-    for _ in range(3 if fused else 2):  # (the one-launch update starts at the second step)
-        _step(kind, tr, half, my_noise)
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append((t.numel(), bool(k.get("async_op", False))))
+        return real_all_reduce(t, *a, **k)
+
+    dist.all_reduce = counting_all_reduce
+    try:
+        for _ in range(3 if fused else 2):  # (the one-launch update starts at the second step)
+            _step(kind, tr, half, my_noise)
+    finally:
+        dist.all_reduce = real_all_reduce
+    if kind in ("sac", "sac_fused"):
+        # the twin critics' gradient slabs are ONE buffer and one collective, the temperature's 8-byte
+        # all-reduce is asynchronous (it runs under the actor's backward pass): three collectives per step, not four
+        n_steps = 3 if fused else 2
+        s1, s2 = tr._e["q1"]["slab"], tr._e["q2"]["slab"]
+        assert tr._dp_bucket_q.numel() == s1.total + s2.total and s1.grad.data_ptr() == tr._dp_bucket_q.data_ptr()
+        assert s2.grad.data_ptr() == tr._dp_bucket_q.data_ptr() + 4 * s1.total
+        per_step = calls[:len(calls) // n_steps]
+        assert len(calls) == 3 * n_steps and per_step[0] == (s1.total + s2.total, False), calls
+        assert per_step[1] == (1, True) and per_step[2] == (tr._e["actor"]["slab"].total, False), calls
     if kind == "qr_fused":
         from reagent_amd.qr_engine import GroupedQR
 
@@ -199,7 +222,7 @@ def _loop_worker(rank, world, port, out_dir, kind="dqn"):
 def test_offline_loop_two_ranks_stay_in_lockstep(tmp_path, emu_lib, kind):
     """the loop bench.py --gpus N runs (eager, asynchronous all-reduce, deferred one-launch update) on two ranks with
     different shards and index draws, per-layer fp32 engine and both fused engines: replicas stay bit-identical"""
-    port = 29500 + (os.getpid() % 2000) + {"dqn": 7, "dqn_fused": 8, "dqn_x3": 9}[kind]
+    port = free_port()
     mp.spawn(_loop_worker, args=(2, port, str(tmp_path), kind), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     for a, b in zip(r0, r1):
@@ -208,7 +231,7 @@ def test_offline_loop_two_ranks_stay_in_lockstep(tmp_path, emu_lib, kind):
 
 @pytest.mark.parametrize("kind", ["dqn", "dqn_deferred", "dqn_generator", "sac", "td3", "crr"])
 def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib, kind):
-    port = 29500 + (os.getpid() % 2000) + {"dqn": 0, "sac": 1, "dqn_deferred": 2, "td3": 3, "crr": 4, "dqn_generator": 5}[kind]
+    port = free_port()
     mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
@@ -261,7 +284,7 @@ def test_two_ranks_on_the_fused_engine_stay_bit_identical(tmp_path, emu_lib, kin
     """bf16 fused stacks under data parallelism: the one-launch Adam + soft update + re-staging (rg_mlp_update_fused,
     engine.FusedUpdate) with the 1/world factor folded in; replicas bit-identical, and close to the single-process
     run on the concatenated batch (bf16 gradients summed in another order: a few weights move by up to lr per step)"""
-    port = 29500 + (os.getpid() % 2000) + {"dqn_fused": 11, "sac_fused": 12, "dqn_x3": 13, "qr_fused": 14}[kind]
+    port = free_port()
     mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     for a, b in zip(r0, r1):
