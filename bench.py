@@ -73,7 +73,18 @@ class GpuTelemetry:
         self._stop = threading.Event()
         self._thread = None
         cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
-        self._dev = cards[index] if index < len(cards) else None
+        # the node shows every GPU's sysfs entry, the container owns one of them: find this device by its PCI address
+        self._dev, self.pci = None, None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            self.pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for d in cards:
+                if os.path.basename(os.path.realpath(d)).lower() == self.pci:
+                    self._dev = d
+        except Exception:
+            pass
+        if self._dev is None and len(cards) == 1:
+            self._dev = cards[0]
         self._pw = None
         if self._dev:
             for name in ("power1_average", "power1_input"):
@@ -106,7 +117,8 @@ class GpuTelemetry:
 
     def _loop(self):
         read = self._sysfs if self._dev else self._smi
-        self.source = "sysfs pp_dpm_sclk + hwmon power" if self._dev else "rocm-smi --showclocks --showpower"
+        self.source = (f"sysfs {self._dev}/pp_dpm_sclk (starred level) + hwmon power" if self._dev
+                       else "rocm-smi --showclocks --showpower (device not found in sysfs by PCI address)")
         while not self._stop.is_set():
             try:
                 read()
@@ -130,7 +142,7 @@ class GpuTelemetry:
         def stat(v):
             return None if not v else {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "samples": len(v)}
 
-        return {"sclk_mhz": stat(self.sclk), "power_w": stat(self.power), "source": self.source}
+        return {"sclk_mhz": stat(self.sclk), "power_w": stat(self.power), "source": self.source, "pci": self.pci}
 
 
 def parse():

@@ -354,14 +354,10 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_dx_kernel(MlpArgs a) {
 
 // ---- weight gradient from fragment-ordered operands ------------------------------------------
 // dW[n][k] = sum_m dZ[m][n] X[m][k].  A = dz_frag tiles (lane = n), B = x_frag tiles (lane = k):
-// per 32-row block and half, one MFMA per (n-tile, k-tile) pair.  Workgroup tile 256(n) x 256(k),
-// waves 2(n) x 4(k), each 4x2 MFMA tiles; operands staged HBM -> VGPR -> LDS (lane-linear 16 B,
-// conflict-free), two 32-row blocks per stage, double buffered, one barrier per stage.
+// per 32-row block and half, one MFMA per (n-tile, k-tile) pair.  Workgroup tile 256(n) x 256(k) — or another shape of
+// <= 64 tiles, wgrad_shape_core — over 8 waves, each 4x2 MFMA tiles; operands staged HBM -> LDS by DMA (lane-linear
+// 16-byte units, conflict-free reads), one 32-row block per stage, a ring of stages, one barrier per stage.
 constexpr int WG_MB_STAGE = 1;                      // 32-row blocks per stage
-constexpr int WG_STAGE_BYTES = WG_MB_STAGE * 32 * 1024;
-constexpr int WG_DMA_SLOTS = 4;                     // LDS ring (128 KB), three stages in flight
-constexpr int WG_DMA_PER_THREAD = 2048 / 512;       // 16-byte units of a stage per thread
-static_assert(3 * WG_DMA_PER_THREAD - WG_DMA_PER_THREAD == 8, "RG_WAIT_VMCNT(8) in wgrad_frag_body");
 
 struct WgradFragArgs {
   const bf16_t* a_frag;
@@ -374,22 +370,292 @@ struct WgradFragArgs {
   long slab;
   int N, K;           // valid extents of dW
   // split-bf16 operands (x3 != 0): every stage carries the hi AND lo planes of both operands and a tile pair takes
-  // three MFMAs — a_lo.b_hi + a_hi.b_lo + a_hi.b_hi into one accumulator (wgrad_x3_core).  The kernel is bound by its
+  // three MFMAs — a_lo.b_hi + a_hi.b_lo + a_hi.b_hi into one accumulator (wgrad_x3_shape_core).  The kernel is bound by its
   // operand stream (§3.2), so the three products share ONE pass over the four planes instead of three passes over
   // two planes each (the round-2 first version: three partial slabs per split, 354 us per C2 launch).
   int x3;
   long a_lo, b_lo;    // element offsets of the lo planes
+  int shape;          // workgroup tile shape (WG_SHAPE_*, wgrad_shape_core / wgrad_x3_shape_core); 0 = 8 x 8 tiles
 };
 
-// one workgroup: dW tile (n-group ng, k-group kg) over the 32-row blocks [mb_begin, mb_end) of the operands
-// ga_frag / gb_frag, written to `part` (row-major [N][K] slab)
-__device__ __forceinline__ void wgrad_frag_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end,
-                                                const bf16_t* ga_frag, const bf16_t* gb_frag, float* part, char* smem);
-__device__ __forceinline__ void wgrad_x3_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
-                                              char* smem);
+
+// ---- workgroup tile shapes ------------------------------------------------------------------------------------------
+// The kernel is bound by its operand stream L2 -> LDS (round 2-3 ablations), and a 256 x 256 tile streams 8 + 8 fragment
+// tiles per 32-row block whatever the layer looks like: for dW0 [512 x 128] half of the B operand was a clamped re-read,
+// for a thin output layer's dW [16 x 512] seven eighths of the A operand — 93 MB of the 804 MB a C2 launch moved into LDS
+// were such junk, and both layers read their long operand through two tiles.  A workgroup now takes GA n-tiles x GB
+// k-tiles (GA * GB <= 64 accumulator tiles over 8 waves = WN x WK, each TA x TB), chosen per layer by the host to minimise
+// the bytes staged (wgrad_pick_shape):
+//   8 x 8   (256 x 256)  square layers                      4 DMAs per thread and 32-row block
+//   16 x 4  (512 x 128)  wide-out / narrow-in (dW0)          5   (dZ0 read by ONE tile)
+//   4 x 16  (128 x 512)  narrow-out / wide-in                5
+//   2 x 16, 1 x 16       thin output layers (<= 64 / <= 32 outputs): 5, with 2 / 1 accumulator tile(s) per wave
+// A stage is (GA + GB) tiles x 2 KB, padded to whole 16-byte units per thread; stages of more than 32 KB ring through
+// three slots (two in flight: measured equal to three in round 2), the 8 x 8 shape keeps four.
+enum { WG_SHAPE_8x8 = 0, WG_SHAPE_16x4 = 1, WG_SHAPE_4x16 = 2, WG_SHAPE_2x16 = 3, WG_SHAPE_1x16 = 4, WG_N_SHAPES = 5 };
+
+template <int GA_, int GB_, int WN_, int WK_> struct WgShape {
+  static constexpr int GA = GA_, GB = GB_, WN = WN_, WK = WK_;
+  static constexpr int TA = GA / WN, TB = GB / WK;
+  static_assert(WN * WK == WG_THREADS / 64 && TA * WN == GA && TB * WK == GB && TA * TB <= 8, "wave layout");
+  static constexpr int DMA = ((GA + GB) * 128 + WG_THREADS - 1) / WG_THREADS;  // 16-byte units per thread and stage
+  static constexpr int STAGE_BYTES = DMA * WG_THREADS * 16;
+  static constexpr int SLOTS = STAGE_BYTES <= 32 * 1024 ? 4 : 3;
+  static constexpr int LDS_BYTES = SLOTS * STAGE_BYTES;
+};
+using WgS8x8 = WgShape<8, 8, 2, 4>;
+using WgS16x4 = WgShape<16, 4, 4, 2>;
+using WgS4x16 = WgShape<4, 16, 1, 8>;
+using WgS2x16 = WgShape<2, 16, 1, 8>;
+using WgS1x16 = WgShape<1, 16, 1, 8>;
+constexpr int WG_SHAPED_LDS = 128 * 1024;  // max over the shapes (8x8: 4 x 32 KB; the 5-DMA shapes: 3 x 40 KB)
+static_assert(WgS8x8::LDS_BYTES <= WG_SHAPED_LDS && WgS16x4::LDS_BYTES <= WG_SHAPED_LDS && WgS4x16::LDS_BYTES <= WG_SHAPED_LDS &&
+              WgS2x16::LDS_BYTES <= WG_SHAPED_LDS && WgS1x16::LDS_BYTES <= WG_SHAPED_LDS, "dynamic LDS of the weight-gradient launches");
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+// one workgroup: dW tile (n-group ng, k-group kg) of shape S over the 32-row blocks [mb_begin, mb_end), written to `part`
+template <typename S>
+__device__ __forceinline__ void wgrad_shape_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
+                                                 char* smem) {
+  constexpr int GA = S::GA, GB = S::GB, TA = S::TA, TB = S::TB, DMA = S::DMA, SLOTS = S::SLOTS, FLY = S::SLOTS - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int lr = lane & 31, lg = lane >> 5;
+  const int wn = wave / S::WK, wk = wave % S::WK;
+  const int ta0 = ng * GA, tb0 = kg * GB;
+  const int na = (g.NTa - ta0 < GA) ? g.NTa - ta0 : GA, nb = (g.NTb - tb0 < GB) ? g.NTb - tb0 : GB;
+  const bf16_t* ga_frag = g.a_frag;
+  const bf16_t* gb_frag = g.b_frag;
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // LDS image of a stage: tile t (A tiles 0 .. GA-1, then the B tiles, then padding) at t * 2 KB, lane-linear 16-byte
+  // units — what the DMA writes (wave-uniform base + lane * 16).  Unit u = tid + i * 512 belongs to tile u / 128, which is
+  // the same for the 64 lanes of a wave; out-of-range tiles / blocks read a clamped valid address (never used), so every
+  // wave issues exactly DMA loads per stage and the vmcnt arithmetic below is exact.
+  const int mb_last = mb_end - 1;
+  // per DMA of a stage (compile-time i): this wave's tile is fixed, only the 32-row block moves — base pointer and block
+  // stride are worked out once, from values already in registers (selecting between the A and the B operand's FIELDS of
+  // the argument block inside the loop made the compiler index them through scratch)
+  const int nta = g.NTa, ntb = g.NTb;
+  const int within = tid & 127;  // (tid + i * 512) & 127: the same for every i
+  const bf16_t* src0[DMA];
+  long blk_stride[DMA];
+  static_for<0, DMA>([&](auto i_c) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value;
+    const int t = i * (WG_THREADS / 128) + (wave >> 1);  // tile of this wave's units (wave-uniform)
+    const bool is_a = t < GA;
+    const int ta = ta0 + (t < na ? t : na - 1);
+    const int tb = tb0 + ((t - GA) < nb ? (t - GA < 0 ? 0 : t - GA) : nb - 1);
+    const long tile = is_a ? (long)ta : (long)tb;
+    const bf16_t* base = is_a ? ga_frag : gb_frag;
+    src0[i] = base + tile * 1024 + within * 8;
+    blk_stride[i] = (long)(is_a ? nta : ntb) * 1024;
+  });
+  auto issue = [&](int blk, int slot) {
+    const int mb = blk < mb_last ? blk : mb_last;
+    static_for<0, DMA>([&](auto i_c) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value;
+      global_load_lds_b128(src0[i] + (long)mb * blk_stride[i], smem + slot * S::STAGE_BYTES + (wave * 64 + i * WG_THREADS) * 16);
+    });
+  };
+  const bool wave_has_tiles = wn * TA < na && wk * TB < nb;  // a wave whose tiles are all padding skips its MFMAs
+  auto compute = [&](int slot) {
+    const char* base = smem + slot * S::STAGE_BYTES;
+    if (!wave_has_tiles) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u16x8 af[TA], bf[TB];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) af[i] = *(const u16x8*)(base + (wn * TA + i) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+      for (int j = 0; j < TB; ++j) bf[j] = *(const u16x8*)(base + (GA + wk * TB + j) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+    }
+  };
+
+  RG_PHASE_INIT();
+  if (mb_begin < mb_end) {
+    const int n_blk = mb_end - mb_begin;
+    static_for<0, FLY>([&](auto f_c) __attribute__((always_inline)) { issue(mb_begin + decltype(f_c)::value, decltype(f_c)::value); });
+    RG_PHASE(0);
+    for (int t = 0; t < n_blk; ++t) {
+      // FLY stages are outstanding: let the oldest land, then meet the other waves — past the barrier block t is complete
+      // in LDS and every wave has finished reading block t-1, whose slot the DMA issued below overwrites
+      wait_vmcnt<(FLY - 1) * DMA>();
+      RG_PHASE(2);
+      raw_barrier();
+      RG_PHASE(3);
+      issue(mb_begin + t + FLY, (t + FLY) % SLOTS);  // before the MFMAs: the requests leave a block time earlier
+      compute(t % SLOTS);
+      RG_PHASE(1);
+    }
+    wait_vmcnt<0>();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int col = (tb0 + wk * TB + j) * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (ta0 + wn * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
+      }
+    }
+  RG_PHASE(4);
+  RG_PHASE_FLUSH();
+}
+
+// tiles per group of a shape, for the host plan and the workgroup decode (value-returning selects: reference outputs of a
+// switch put four dwords of the five-shape kernel into scratch)
+__host__ __device__ __forceinline__ int wgrad_shape_ga(int shape) {
+  return shape == WG_SHAPE_16x4 ? 16 : shape == WG_SHAPE_4x16 ? 4 : shape == WG_SHAPE_2x16 ? 2 : shape == WG_SHAPE_1x16 ? 1 : 8;
+}
+__host__ __device__ __forceinline__ int wgrad_shape_gb(int shape) {
+  return shape == WG_SHAPE_16x4 ? 4 : shape == WG_SHAPE_8x8 ? 8 : 16;
+}
+
+// Split-bf16 operands.  A stage is HALF a 32-row block (one 16-row MFMA chunk) of all four planes,
+// [a_hi (GA tiles) | a_lo (GA) | b_hi (GB) | b_lo (GB)] x 1 KB — the same bytes, ring and DMA count per thread as the bf16
+// core's stage of the same shape, twice the stages, three MFMAs per tile pair: per operand byte 1.5x the MFMA work of the
+// bf16 kernel.  DMA i of a stage moves the 1 KB planes 8 i .. 8 i + 7, one per wave.
+template <typename S>
+__device__ __forceinline__ void wgrad_x3_shape_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
+                                                    char* smem) {
+  constexpr int GA = S::GA, GB = S::GB, TA = S::TA, TB = S::TB, DMA = S::DMA, SLOTS = S::SLOTS, FLY = S::SLOTS - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int lr = lane & 31, lg = lane >> 5;
+  const int wn = wave / S::WK, wk = wave % S::WK;
+  const int ta0 = ng * GA, tb0 = kg * GB;
+  const int na = (g.NTa - ta0 < GA) ? g.NTa - ta0 : GA, nb = (g.NTb - tb0 < GB) ? g.NTb - tb0 : GB;
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int n_stage = 2 * (mb_end - mb_begin);
+  // out-of-range tiles / stages read a clamped valid address (never used), so every wave has exactly DMA loads per stage;
+  // base pointer and block stride of each are worked out once (see wgrad_shape_core)
+  const int nta = g.NTa, ntb = g.NTb;
+  const bf16_t* a_hi = g.a_frag;
+  const bf16_t* b_hi = g.b_frag;
+  const long a_lo = g.a_lo, b_lo = g.b_lo;
+  const bf16_t* src0[DMA];
+  long blk_stride[DMA];
+  static_for<0, DMA>([&](auto i_c) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value;
+    const int q = i * 8 + wave;  // plane of this wave's DMA (wave-uniform)
+    const bool is_a = q < 2 * GA;
+    const int qa = q < GA ? q : q - GA;                  // tile within the A planes
+    int qb = q - 2 * GA;                                 // within the B planes (hi, lo, padding)
+    const bool b_is_lo = qb >= GB;
+    qb = qb >= GB ? qb - GB : qb;
+    qb = qb < 0 ? 0 : qb;
+    const long tile = is_a ? (long)(ta0 + (qa < na ? qa : na - 1)) : (long)(tb0 + (qb < nb ? qb : nb - 1));
+    const long plane = is_a ? (q >= GA ? a_lo : 0) : (b_is_lo ? b_lo : 0);
+    const bf16_t* base = is_a ? a_hi : b_hi;
+    src0[i] = base + plane + tile * 1024 + lane * 8;
+    blk_stride[i] = (long)(is_a ? nta : ntb) * 1024;
+  });
+  auto issue = [&](int st, int slot) {
+    const int sc = st < n_stage ? st : n_stage - 1;
+    const long mb = mb_begin + (sc >> 1);
+    const int h = sc & 1;
+    static_for<0, DMA>([&](auto i_c) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value;
+      global_load_lds_b128(src0[i] + mb * blk_stride[i] + h * 512, smem + slot * S::STAGE_BYTES + (i * 8 + wave) * 1024);
+    });
+  };
+  const bool wave_has_tiles = wn * TA < na && wk * TB < nb;
+  auto compute = [&](int slot) {
+    if (!wave_has_tiles) return;
+    const char* base = smem + slot * S::STAGE_BYTES + lane * 16;
+    u16x8 ah[TA], al[TA], bh[TB], bl[TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+      ah[i] = *(const u16x8*)(base + (wn * TA + i) * 1024);
+      al[i] = *(const u16x8*)(base + (GA + wn * TA + i) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      bh[j] = *(const u16x8*)(base + (2 * GA + wk * TB + j) * 1024);
+      bl[j] = *(const u16x8*)(base + (2 * GA + GB + wk * TB + j) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {  // the small products first
+        acc[i][j] = mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
+        acc[i][j] = mfma_32x32x16_bf16(ah[i], bl[j], acc[i][j]);
+        acc[i][j] = mfma_32x32x16_bf16(ah[i], bh[j], acc[i][j]);
+      }
+  };
+  if (n_stage > 0) {
+    static_for<0, FLY>([&](auto f_c) __attribute__((always_inline)) { issue(decltype(f_c)::value, decltype(f_c)::value); });
+    for (int t = 0; t < n_stage; ++t) {
+      wait_vmcnt<(FLY - 1) * DMA>();  // FLY stages outstanding: the oldest has landed
+      raw_barrier();                  // ... for every wave, and all are done reading stage t-1, whose slot is refilled next
+      issue(t + FLY, (t + FLY) % SLOTS);
+      compute(t % SLOTS);
+    }
+    wait_vmcnt<0>();
+  }
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int col = (tb0 + wk * TB + j) * 32 + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (ta0 + wn * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
+      }
+    }
+}
+
+// the workgroup's core for its layer's operand format and tile shape (all arguments workgroup-uniform)
+__device__ __forceinline__ void wgrad_dispatch(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
+                                               char* smem) {
+  if (g.x3) {
+    switch (g.shape) {
+      case WG_SHAPE_16x4: wgrad_x3_shape_core<WgS16x4>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      case WG_SHAPE_4x16: wgrad_x3_shape_core<WgS4x16>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      case WG_SHAPE_2x16: wgrad_x3_shape_core<WgS2x16>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      case WG_SHAPE_1x16: wgrad_x3_shape_core<WgS1x16>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      default: wgrad_x3_shape_core<WgS8x8>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+    }
+    return;
+  }
+  switch (g.shape) {
+    case WG_SHAPE_16x4: wgrad_shape_core<WgS16x4>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+    case WG_SHAPE_4x16: wgrad_shape_core<WgS4x16>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+    case WG_SHAPE_2x16: wgrad_shape_core<WgS2x16>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+    case WG_SHAPE_1x16: wgrad_shape_core<WgS1x16>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+    default: wgrad_shape_core<WgS8x8>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+  }
+}
 
 __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid, char* smem) {
-  const int n_groups = (g.NTa + 7) / 8, k_groups = (g.NTb + 7) / 8;
+  const int shape = g.shape;
+  const int GA = wgrad_shape_ga(shape), GB = wgrad_shape_gb(shape);
+  const int n_groups = (g.NTa + GA - 1) / GA, k_groups = (g.NTb + GB - 1) / GB;
   // workgroups that read the same 32-row blocks (the tiles of one split) go to ONE XCD (hardware
   // places block b on XCD b % 8), so the second reader of a fragment hits that XCD's L2 instead of
   // HBM (PMC: 700 MB fetched per launch against 420 MB of unique operands without this)
@@ -408,184 +674,7 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
   const int ng = tile / k_groups;
   const int mb_begin = split * g.mb_per_split;
   const int mb_end = (mb_begin + g.mb_per_split < g.MB) ? mb_begin + g.mb_per_split : g.MB;
-  if (g.x3) wgrad_x3_core(g, ng, kg, mb_begin, mb_end, g.partial + (long)split * g.slab, smem);
-  else wgrad_frag_core(g, ng, kg, mb_begin, mb_end, g.a_frag, g.b_frag, g.partial + (long)split * g.slab, smem);
-}
-
-__device__ __forceinline__ void wgrad_frag_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end,
-                                                const bf16_t* ga_frag, const bf16_t* gb_frag, float* part, char* smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int lr = lane & 31, lg = lane >> 5;
-  const int wn = wave >> 2, wk = wave & 3;
-  const int ta0 = ng * 8, tb0 = kg * 8;
-  const int na = (g.NTa - ta0 < 8) ? g.NTa - ta0 : 8, nb = (g.NTb - tb0 < 8) ? g.NTb - tb0 : 8;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // Operand staging by LDS-DMA (global_load_lds_dwordx4): a ring of WG_DMA_SLOTS stages of one 32-row
-  // block each (A: 8 tiles x 2 KB, B: 8 tiles x 2 KB), three stages in flight.  The LDS image of a
-  // fragment record is lane-linear 16-byte units — exactly what the DMA writes (wave-uniform base +
-  // lane*16) — so nothing passes through VGPRs and there is no ds_write pass.  The kernel is HBM-bound
-  // (414 MB of operands per launch): with register staging its phase profile showed 34 % of a
-  // workgroup's life waiting for operands with two stages in flight (profiles/microbench/wgrad_phases).
-  // Out-of-range blocks / tiles read a clamped valid address; the data is never used (tiles >= na only
-  // reach dW rows >= N, which are not stored; stages past the end are not computed), which keeps the
-  // number of DMAs per stage constant and the vmcnt arithmetic below exact.
-  const int mb_last = mb_end - 1;
-  auto issue = [&](int blk, int slot) {
-    const int mb = blk < mb_last ? blk : mb_last;
-    // units 0..1023 of a stage are the A operand, 1024..2047 the B operand: with 512 threads that is a
-    // compile-time property of i, so every wave issues exactly WG_DMA_PER_THREAD DMAs, unconditionally
-    static_for<0, WG_DMA_PER_THREAD>([&](auto i_c) __attribute__((always_inline)) {
-      constexpr int i = decltype(i_c)::value;
-      constexpr bool is_b = i * WG_THREADS >= 1024;
-      const int off = (tid + i * WG_THREADS) & 1023, tile = off >> 7;
-      const bf16_t* src = is_b ? gb_frag + ((long)mb * g.NTb + tb0 + (tile < nb ? tile : nb - 1)) * 1024
-                               : ga_frag + ((long)mb * g.NTa + ta0 + (tile < na ? tile : na - 1)) * 1024;
-      global_load_lds_b128(src + (off & 127) * 8, smem + slot * WG_STAGE_BYTES + (wave * 64 + i * WG_THREADS) * 16);
-    });
-  };
-  // a wave whose tiles are all padding (thin layers: dW 16x512, 512x128) skips its MFMAs
-  const bool wave_has_tiles = wn * 4 < na && wk * 2 < nb;
-  auto compute = [&](int slot) {
-    const char* base = smem + slot * WG_STAGE_BYTES;
-    if (!wave_has_tiles) return;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      u16x8 af[4], bf[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const u16x8*)(base + (wn * 4 + i) * 2048 + h * 1024 + lane * 16);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *(const u16x8*)(base + 16384 + (wk * 2 + j) * 2048 + h * 1024 + lane * 16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
-    }
-  };
-
-  RG_PHASE_INIT();
-  if (mb_begin < mb_end) {
-    const int n_blk = mb_end - mb_begin;
-    issue(mb_begin + 0, 0);
-    issue(mb_begin + 1, 1);
-    issue(mb_begin + 2, 2);
-    RG_PHASE(0);
-    for (int t = 0; t < n_blk; ++t) {
-      // three stages (3 * WG_DMA_PER_THREAD DMAs per thread) are outstanding: let the oldest land,
-      // then meet the other waves — past the barrier block t is complete in LDS and every wave has
-      // finished reading block t-1, whose slot the DMA issued below overwrites
-      RG_WAIT_VMCNT(8);
-      RG_PHASE(2);
-      raw_barrier();
-      RG_PHASE(3);
-      issue(mb_begin + t + 3, (t + 3) & (WG_DMA_SLOTS - 1));  // before the MFMAs: the requests leave a block time earlier
-      compute(t & (WG_DMA_SLOTS - 1));
-      RG_PHASE(1);
-    }
-    RG_WAIT_VMCNT(0);
-  }
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (tb0 + wk * 2 + j) * 32 + lr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (ta0 + wn * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-        if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
-      }
-    }
-  RG_PHASE(4);
-  RG_PHASE_FLUSH();
-}
-
-// Split-bf16 operands.  A stage is HALF a 32-row block (one 16-row MFMA chunk) of all four planes:
-// [a_hi | a_lo | b_hi | b_lo], 8 tiles x 1 KB each = 32 KB — the same ring (four slots, three in flight, four DMAs
-// per thread and stage: thread (wave w, lane) fetches its 16 bytes of tile w of every plane) as the bf16 core, twice
-// the stages, three MFMAs per tile pair: per operand byte 1.5x the MFMA work of the bf16 kernel.
-__device__ __forceinline__ void wgrad_x3_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
-                                              char* smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int lr = lane & 31, lg = lane >> 5;
-  const int wn = wave >> 2, wk = wave & 3;
-  const int ta0 = ng * 8, tb0 = kg * 8;
-  const int na = (g.NTa - ta0 < 8) ? g.NTa - ta0 : 8, nb = (g.NTb - tb0 < 8) ? g.NTb - tb0 : 8;
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int n_stage = 2 * (mb_end - mb_begin);
-  // out-of-range tiles / stages read a clamped valid address (never used), so every wave has exactly four DMAs per stage
-  const int ta = ta0 + (wave < na ? wave : na - 1), tb = tb0 + (wave < nb ? wave : nb - 1);
-  auto issue = [&](int st, int slot) {
-    const int s = st < n_stage ? st : n_stage - 1;
-    const int mb = mb_begin + (s >> 1), h = s & 1;
-    const bf16_t* pa = g.a_frag + (((long)mb * g.NTa + ta) * 2 + h) * 512 + lane * 8;
-    const bf16_t* pb = g.b_frag + (((long)mb * g.NTb + tb) * 2 + h) * 512 + lane * 8;
-    char* dst = smem + slot * WG_STAGE_BYTES + wave * 1024;
-    global_load_lds_b128(pa, dst);
-    global_load_lds_b128(pa + g.a_lo, dst + 8192);
-    global_load_lds_b128(pb, dst + 16384);
-    global_load_lds_b128(pb + g.b_lo, dst + 24576);
-  };
-  const bool wave_has_tiles = wn * 4 < na && wk * 2 < nb;
-  auto compute = [&](int slot) {
-    if (!wave_has_tiles) return;
-    const char* base = smem + slot * WG_STAGE_BYTES + lane * 16;
-    u16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[i] = *(const u16x8*)(base + (wn * 4 + i) * 1024);
-      al[i] = *(const u16x8*)(base + 8192 + (wn * 4 + i) * 1024);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bh[j] = *(const u16x8*)(base + 16384 + (wk * 2 + j) * 1024);
-      bl[j] = *(const u16x8*)(base + 24576 + (wk * 2 + j) * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {  // the small products first
-        acc[i][j] = mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
-        acc[i][j] = mfma_32x32x16_bf16(ah[i], bl[j], acc[i][j]);
-        acc[i][j] = mfma_32x32x16_bf16(ah[i], bh[j], acc[i][j]);
-      }
-  };
-  if (n_stage > 0) {
-    issue(0, 0);
-    issue(1, 1);
-    issue(2, 2);
-    for (int t = 0; t < n_stage; ++t) {
-      RG_WAIT_VMCNT(8);  // three stages of four DMAs outstanding: the oldest has landed
-      raw_barrier();     // ... for every wave, and all are done reading stage t-1, whose slot is refilled next
-      issue(t + 3, (t + 3) & (WG_DMA_SLOTS - 1));
-      compute(t & (WG_DMA_SLOTS - 1));
-    }
-    RG_WAIT_VMCNT(0);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (tb0 + wk * 2 + j) * 32 + lr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (ta0 + wn * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-        if (row < g.N && col < g.K) part[(long)row * g.K + col] = acc[i][j][r];
-      }
-    }
+  wgrad_dispatch(g, ng, kg, mb_begin, mb_end, g.partial + (long)split * g.slab, smem);
 }
 
 __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
@@ -615,8 +704,8 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_grouped_kernel(WgradGroupedArgs G
   if (b1 > mb1) b1 = mb1;
   if (b0 > mb1) b0 = mb1;
   float* part = G.g.partial + ((long)a * G.splits + s) * G.g.slab;
-  if (G.g.x3) wgrad_x3_core(G.g, 0, kg, b0, b1, part, smem);  // split-bf16 operands: both planes of dZ and of the activations
-  else wgrad_frag_core(G.g, 0, kg, b0, b1, G.g.a_frag, G.g.b_frag, part, smem);
+  if (G.g.x3) wgrad_x3_shape_core<WgS8x8>(G.g, 0, kg, b0, b1, part, smem);  // split-bf16: both planes of dZ and of the activations
+  else wgrad_shape_core<WgS8x8>(G.g, 0, kg, b0, b1, part, smem);
 }
 
 // out[a * slab + e] = sum_s partial[(a * splits + s) * slab + e]
@@ -1249,13 +1338,39 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
 struct WgradFragPlan {
   int NTa, NTb, MB, splits, mb_per_split;
   long slab;
+  int shape, tiles;  // workgroup tile shape (WG_SHAPE_*) and the number of such tiles that cover dW
 };
-static WgradFragPlan wgrad_frag_plan(int out_f, int in_f, int batch) {
+// RG_WGRAD_SHAPES = 0: every layer on 256 x 256 tiles (rounds 1-3; same-box A/B switch)
+#ifndef RG_WGRAD_SHAPES
+#define RG_WGRAD_SHAPES 1
+#endif
+// workgroups per layer whose dW is ONE tile of its shape (dW0, thin output layers): their partial slab is the whole dW, so
+// the 128 of the multi-tile layers would double the partial bytes they had as two tiles x 64 splits
+#ifndef RG_WGRAD_TARGET_THIN
+#define RG_WGRAD_TARGET_THIN 64
+#endif
+// the shape that stages the fewest bytes for an NTa x NTb-tile dW: groups x 16-byte units per thread and 32-row block
+static int wgrad_pick_shape(int NTa, int NTb, int x3, int* tiles_out) {
+  static const int dma[WG_N_SHAPES] = {WgS8x8::DMA, WgS16x4::DMA, WgS4x16::DMA, WgS2x16::DMA, WgS1x16::DMA};
+  int best = WG_SHAPE_8x8, best_cost = 0, best_tiles = 0;
+  for (int sh = 0; sh < WG_N_SHAPES; ++sh) {
+    if (sh != WG_SHAPE_8x8 && !RG_WGRAD_SHAPES) continue;
+    (void)x3;  // (the split-bf16 core takes the same shapes: its stage is the same bytes)
+    const int ga = wgrad_shape_ga(sh), gb = wgrad_shape_gb(sh);
+    const int tiles = ((NTa + ga - 1) / ga) * ((NTb + gb - 1) / gb);
+    const int cost = tiles * dma[sh];
+    if (sh == WG_SHAPE_8x8 || cost < best_cost) { best = sh; best_cost = cost; best_tiles = tiles; }
+  }
+  *tiles_out = best_tiles;
+  return best;
+}
+static WgradFragPlan wgrad_frag_plan(int out_f, int in_f, int batch, int x3 = 0) {
   WgradFragPlan p;
   p.NTa = (out_f + 31) / 32;
   p.NTb = (in_f + 31) / 32;
   p.MB = (batch + 127) / 128 * 4;
-  const int tiles = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8);
+  p.shape = wgrad_pick_shape(p.NTa, p.NTb, x3, &p.tiles);
+  const int tiles = p.tiles;
   int want = (256 + tiles - 1) / tiles;  // ~one workgroup per CU
   const int max_splits = (p.MB + WG_MB_STAGE - 1) / WG_MB_STAGE;
   if (want > max_splits) want = max_splits;
@@ -1282,9 +1397,9 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   g.a_frag = (const bf16_t*)dz_frag; g.b_frag = (const bf16_t*)x_frag;
   g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
-  g.x3 = 0; g.a_lo = g.b_lo = 0;
-  const int grid = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
-  const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
+  g.x3 = 0; g.a_lo = g.b_lo = 0; g.shape = p.shape;
+  const int grid = p.tiles * p.splits;
+  const size_t lds = (size_t)WG_SHAPED_LDS;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
   RG_LAUNCH_DYN(wgrad_frag_kernel, dim3(grid), dim3(WG_THREADS), lds, (hipStream_t)stream, g);
   int rc = (int)hipGetLastError();
@@ -1318,9 +1433,10 @@ int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* 
   G.g.x3 = x3 ? 1 : 0;
   G.g.a_lo = x3 ? (long)frag_elems(rows, group_rows) : 0;
   G.g.b_lo = x3 ? (long)frag_elems(rows, in_features) : 0;
+  G.g.shape = WG_SHAPE_8x8;
   G.tile_begin = tile_begin; G.n_groups = n_groups; G.splits = splits;
   const int k_groups = (G.g.NTb + 7) / 8;
-  const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
+  const size_t lds = (size_t)WgS8x8::LDS_BYTES;
   RG_ALLOW_LDS(wgrad_grouped_kernel, lds);
   RG_LAUNCH_DYN(wgrad_grouped_kernel, dim3(n_groups * splits * k_groups), dim3(WG_THREADS), lds, (hipStream_t)stream, G);
   int rc = (int)hipGetLastError();
@@ -1358,9 +1474,10 @@ int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t s
   return (int)hipGetLastError();
 }
 
-static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target_wgs) {
-  WgradFragPlan p = wgrad_frag_plan(out_f, in_f, batch);
-  const int tiles = ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8);
+static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target_wgs, int x3 = 0) {
+  WgradFragPlan p = wgrad_frag_plan(out_f, in_f, batch, x3);
+  const int tiles = p.tiles;
+  if (tiles == 1 && p.shape != WG_SHAPE_8x8 && RG_WGRAD_TARGET_THIN < target_wgs) target_wgs = RG_WGRAD_TARGET_THIN;
   int want = (target_wgs + tiles - 1) / tiles;
   const int max_splits = (p.MB + WG_MB_STAGE - 1) / WG_MB_STAGE;
   if (want > max_splits) want = max_splits;
@@ -1378,7 +1495,7 @@ size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   if (!d || batch <= 0) return 0;
   size_t total = 0;
   for (int l = 0; l < d->n_layers; ++l) {
-    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, RG_WGRAD_TARGET);
+    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, RG_WGRAD_TARGET, d->x3);
     total += (size_t)p.splits * p.slab;
   }
   return total * sizeof(float);
@@ -1401,17 +1518,21 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     if (l < d->n_layers) {
       if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
       const int out_f = d->dims[l + 1], in_f = d->dims[l];
-      const WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, RG_WGRAD_TARGET);
+      WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, RG_WGRAD_TARGET, d->x3);
+#ifdef RG_WGRAD_LAYER_MASK  // timing ablation only (profiles/scripts): layers outside the mask get no workgroups, dW = 0
+      if (!((RG_WGRAD_LAYER_MASK >> l) & 1)) p.splits = 0;
+#endif
       WgradFragArgs& g = G.layer[l];
       g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
       g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
       g.partial = part; g.slab = p.slab; g.N = out_f; g.K = in_f;
       g.x3 = d->x3 ? 1 : 0;
+      g.shape = p.shape;
       g.a_lo = d->x3 ? (long)frag_elems(batch, out_f) : 0;
       g.b_lo = d->x3 ? (long)frag_elems(batch, in_f) : 0;
       R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
       part += (size_t)p.splits * p.slab;
-      wg += ((p.NTa + 7) / 8) * ((p.NTb + 7) / 8) * p.splits;
+      wg += p.tiles * p.splits;
       wg = (wg + 7) / 8 * 8;  // keep (block id % 8) == (layer-local id % 8) == XCD
       el += p.slab;
     } else {
@@ -1422,7 +1543,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   G.wg_begin[FB_MAXL] = wg;
   R.elem_begin[FB_MAXL] = el;
   for (int l = d->n_layers; l <= FB_MAXL; ++l) { G.wg_begin[l] = wg; R.elem_begin[l] = el; }
-  const size_t lds = (size_t)WG_DMA_SLOTS * WG_STAGE_BYTES;
+  const size_t lds = (size_t)WG_SHAPED_LDS;
   RG_ALLOW_LDS(wgrad_group_kernel, lds);
   RG_LAUNCH_DYN(wgrad_group_kernel, dim3(wg), dim3(WG_THREADS), lds, (hipStream_t)stream, G);
   int rc = (int)hipGetLastError();

@@ -59,6 +59,10 @@ def _rel(a, b):
     ([130, 256, 256, 70], ["leaky_relu", "tanh", "linear"], 129),
     ([40, 512, 512, 3], ["tanh", "relu", "linear"], 64),
     ([64, 256, 256, 200], ["relu", "relu", "linear"], 140),  # 7 output column tiles: the pipelined output layer
+    # weight-gradient tile shapes (wgrad_shape_core): the cases above take 8 x 8, 16 x 4 (dW0 of a 512-wide stack) and
+    # 1 x 16 (<= 32 outputs over 512); 64 and 128 outputs over 512 take 2 x 16 and 4 x 16
+    ([32, 512, 512, 64], ["relu", "relu", "linear"], 260),
+    ([96, 512, 512, 128], ["relu", "leaky_relu", "linear"], 130),
 ])
 def test_fused_forward_backward_wgrad(backend, dims, acts, batch):
     dev = backend.device
