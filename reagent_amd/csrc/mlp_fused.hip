@@ -559,8 +559,8 @@ __device__ __forceinline__ void wgrad_x3_shape_core(const WgradFragArgs& g, int 
   const long a_lo = g.a_lo, b_lo = g.b_lo;
   const bf16_t* src0[DMA];
   long blk_stride[DMA];
-  static_for<0, DMA>([&](auto i_c) __attribute__((always_inline)) {
-    constexpr int i = decltype(i_c)::value;
+#pragma unroll
+  for (int i = 0; i < DMA; ++i) {
     const int q = i * 8 + wave;  // plane of this wave's DMA (wave-uniform)
     const bool is_a = q < 2 * GA;
     const int qa = q < GA ? q : q - GA;                  // tile within the A planes
@@ -573,7 +573,7 @@ __device__ __forceinline__ void wgrad_x3_shape_core(const WgradFragArgs& g, int 
     const bf16_t* base = is_a ? a_hi : b_hi;
     src0[i] = base + plane + tile * 1024 + lane * 8;
     blk_stride[i] = (long)(is_a ? nta : ntb) * 1024;
-  });
+  }
   auto issue = [&](int st, int slot) {
     const int sc = st < n_stage ? st : n_stage - 1;
     const long mb = mb_begin + (sc >> 1);
@@ -660,15 +660,9 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
   // places block b on XCD b % 8), so the second reader of a fragment hits that XCD's L2 instead of
   // HBM (PMC: 700 MB fetched per launch against 420 MB of unique operands without this)
   const int tiles = k_groups * n_groups;
-  int tile, split;
-  if ((g.splits & 7) == 0) {
-    const int xcd = bid & 7, slot = bid >> 3;
-    split = (slot / tiles) * 8 + xcd;
-    tile = slot % tiles;
-  } else {
-    tile = bid % tiles;
-    split = bid / tiles;
-  }
+  // the launch has tiles * 8 * ceil(splits / 8) workgroups per layer; those of a split past the end return at once
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
   if (split >= g.splits) return;  // padding workgroups of a grouped launch (uniform for the workgroup)
   const int kg = tile % k_groups;
   const int ng = tile / k_groups;
@@ -1398,7 +1392,7 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
   g.x3 = 0; g.a_lo = g.b_lo = 0; g.shape = p.shape;
-  const int grid = p.tiles * p.splits;
+  const int grid = p.tiles * ((p.splits + 7) / 8 * 8);
   const size_t lds = (size_t)WG_SHAPED_LDS;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
   RG_LAUNCH_DYN(wgrad_frag_kernel, dim3(grid), dim3(WG_THREADS), lds, (hipStream_t)stream, g);
@@ -1487,17 +1481,70 @@ static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target
   per = (per + WG_MB_STAGE - 1) / WG_MB_STAGE * WG_MB_STAGE;
   p.mb_per_split = per;
   p.splits = (p.MB + per - 1) / per;
-  if (p.splits >= 8) p.splits = (p.splits + 7) / 8 * 8;  // empty tail splits write zeros
   return p;
 }
 
-size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
-  if (!d || batch <= 0) return 0;
-  size_t total = 0;
-  for (int l = 0; l < d->n_layers; ++l) {
-    const WgradFragPlan p = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, RG_WGRAD_TARGET, d->x3);
-    total += (size_t)p.splits * p.slab;
+// ---- how many splits per layer --------------------------------------------------------------------------------------
+// Round 4 (profiles/microbench/out/r04a: hbm_roof.txt, wgrad_model.txt).  The staging mechanism alone — the LDS-DMA ring of
+// one workgroup per CU — draws 7.2 TB/s from HBM when every workgroup streams its own bytes (28 B/ns per CU) and 11.7 TB/s
+// into LDS (46 B/ns per CU, 5.9 TB/s of unique bytes) when the tiles of a split sit on one XCD and find each other's operand
+// in its L2; LDS fragment reads and MFMAs cost nothing on top, the partial tiles do: 67 MB of them, written when the
+// workgroups of a round finish together, are 20 us.  The launch of rounds 1-3 gave every layer 128 workgroups: 512 of
+// uneven length (a dW0 workgroup half as long as a hidden layer's) in dispatch order — the CU that drew dW0 then a hidden
+// layer finished last, at 3/2 of a balanced schedule — and 86 MB of partials.  Balanced plan: the splits of each layer are
+// chosen so that ALL workgroups of the launch are one round of the chip (RG_WGRAD_TOTAL, default = the CU count) and
+// take the same time by the rates above: fewer partial bytes, no tail.  (Round 3's "256 in all" experiment lost because a
+// split count that is not a multiple of 8 fell off the XCD-grouped decode: every byte then came from HBM twice.)
+struct WgradTuning { int balanced, total; double shared, unshared; };
+static const WgradTuning& wgrad_tuning() {
+  static const WgradTuning t = [] {
+    WgradTuning v{1, 0, 46.0, 28.0};
+    if (const char* e = getenv("RG_WGRAD_PLAN")) v.balanced = (e[0] != 'l');  // "legacy": 128 workgroups per layer
+    if (const char* e = getenv("RG_WGRAD_TOTAL")) v.total = atoi(e);
+    if (const char* e = getenv("RG_WGRAD_SHARED")) v.shared = atof(e);
+    if (const char* e = getenv("RG_WGRAD_UNSHARED")) v.unshared = atof(e);
+    if (v.total <= 0) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      v.total = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                    ? pr.multiProcessorCount : 256;
+    }
+    return v;
+  }();
+  return t;
+}
+
+static void wgrad_stack_plan(const rg_mlp_desc* d, int batch, WgradFragPlan* out) {
+  const WgradTuning& T = wgrad_tuning();
+  if (!T.balanced) {
+    for (int l = 0; l < d->n_layers; ++l) out[l] = wgrad_group_plan(d->dims[l + 1], d->dims[l], batch, RG_WGRAD_TARGET, d->x3);
+    return;
   }
+  static const int dma[WG_N_SHAPES] = {WgS8x8::DMA, WgS16x4::DMA, WgS4x16::DMA, WgS2x16::DMA, WgS1x16::DMA};
+  double work[FB_MAXL], sum = 0.0;
+  for (int l = 0; l < d->n_layers; ++l) {
+    out[l] = wgrad_frag_plan(d->dims[l + 1], d->dims[l], batch, d->x3);
+    const double stage_bytes = dma[out[l].shape] * WG_THREADS * 16.0;
+    work[l] = (double)out[l].tiles * out[l].MB * stage_bytes / (out[l].tiles > 1 ? T.shared : T.unshared);
+    sum += work[l];
+  }
+  for (int l = 0; l < d->n_layers; ++l) {
+    WgradFragPlan& p = out[l];
+    int want = (int)(T.total * work[l] / sum / p.tiles + 0.5);
+    if (want > p.MB) want = p.MB;
+    if (want < 1) want = 1;
+    const int per = (p.MB + want - 1) / want;
+    p.mb_per_split = per;
+    p.splits = (p.MB + per - 1) / per;
+  }
+}
+
+size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
+  if (!d || batch <= 0 || d->n_layers < 1 || d->n_layers > FB_MAXL) return 0;
+  WgradFragPlan plan[FB_MAXL];
+  wgrad_stack_plan(d, batch, plan);
+  size_t total = 0;
+  for (int l = 0; l < d->n_layers; ++l) total += (size_t)plan[l].splits * plan[l].slab;
   return total * sizeof(float);
 }
 
@@ -1509,6 +1556,8 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   WgradGroupArgs G;
   ReduceGroupArgs R;
   G.n = R.n = d->n_layers;
+  WgradFragPlan plan[FB_MAXL];
+  wgrad_stack_plan(d, batch, plan);
   float* part = (float*)workspace;
   int wg = 0;
   long el = 0;
@@ -1518,7 +1567,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     if (l < d->n_layers) {
       if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
       const int out_f = d->dims[l + 1], in_f = d->dims[l];
-      WgradFragPlan p = wgrad_group_plan(out_f, in_f, batch, RG_WGRAD_TARGET, d->x3);
+      WgradFragPlan p = plan[l];
 #ifdef RG_WGRAD_LAYER_MASK  // timing ablation only (profiles/scripts): layers outside the mask get no workgroups, dW = 0
       if (!((RG_WGRAD_LAYER_MASK >> l) & 1)) p.splits = 0;
 #endif
@@ -1532,8 +1581,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
       g.b_lo = d->x3 ? (long)frag_elems(batch, in_f) : 0;
       R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
       part += (size_t)p.splits * p.slab;
-      wg += p.tiles * p.splits;
-      wg = (wg + 7) / 8 * 8;  // keep (block id % 8) == (layer-local id % 8) == XCD
+      wg += p.tiles * ((p.splits + 7) / 8 * 8);  // the tiles of a split on ONE XCD (wgrad_frag_body), eight splits abreast
       el += p.slab;
     } else {
       G.layer[l] = G.layer[0];

@@ -28,6 +28,10 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return 0; }
+// device query of the weight gradient's launch plan: the interpreter poses as a 256-CU chip
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return 0; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return 0;
