@@ -44,6 +44,12 @@
 #ifndef RG_WGRAD_TARGET
 #define RG_WGRAD_TARGET 128
 #endif
+#ifndef RG_WGRAD_PIPE
+#define RG_WGRAD_PIPE 1  // weight gradient: LDS fragment reads one half ahead of the MFMAs (wgrad_shape_core)
+#endif
+#ifndef RG_WGRAD_PAIR
+#define RG_WGRAD_PAIR 0  // weight gradient, 256 x 256 tiles: two 32-row blocks per barrier (measured +5 %: not the default)
+#endif
 
 namespace rg {
 
@@ -470,40 +476,93 @@ __device__ __forceinline__ void wgrad_shape_core(const WgradFragArgs& g, int ng,
     });
   };
   const bool wave_has_tiles = wn * TA < na && wk * TB < nb;  // a wave whose tiles are all padding skips its MFMAs
-  auto compute = [&](int slot) {
-    const char* base = smem + slot * S::STAGE_BYTES;
-    if (!wave_has_tiles) return;
+  // Round 4 (profiles/microbench/out/r04a/wgrad_phases.txt): an iteration of this loop took ~2700 cycles whatever the stage
+  // held — 16 MFMAs per wave (1024 cycles per SIMD), the rest LDS latency, DMA issue and the barrier: the loop is bound
+  // by its own per-iteration chain, not by the memory system (8 % of it waits for data).  So (a) the fragments of the next
+  // 16-row half are requested from LDS before the MFMAs of the current one (RG_WGRAD_PIPE), and (b) the square shape,
+  // whose ring has four slots, takes TWO blocks per barrier (RG_WGRAD_PAIR): one wait, one barrier and one burst of DMA
+  // issues per 32 MFMAs of a wave instead of per 16, the next pair in flight meanwhile.
+  auto load_half = [&](int slot, int h, u16x8 (&af)[TA], u16x8 (&bf)[TB]) {
+    const char* base = smem + slot * S::STAGE_BYTES + h * 1024 + lane * 16;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      u16x8 af[TA], bf[TB];
+    for (int i = 0; i < TA; ++i) af[i] = *(const u16x8*)(base + (wn * TA + i) * 2048);
 #pragma unroll
-      for (int i = 0; i < TA; ++i) af[i] = *(const u16x8*)(base + (wn * TA + i) * 2048 + h * 1024 + lane * 16);
-#pragma unroll
-      for (int j = 0; j < TB; ++j) bf[j] = *(const u16x8*)(base + (GA + wk * TB + j) * 2048 + h * 1024 + lane * 16);
-#pragma unroll
-      for (int i = 0; i < TA; ++i)
-#pragma unroll
-        for (int j = 0; j < TB; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
-    }
+    for (int j = 0; j < TB; ++j) bf[j] = *(const u16x8*)(base + (GA + wk * TB + j) * 2048);
   };
+  auto mma_half = [&](const u16x8 (&af)[TA], const u16x8 (&bf)[TB]) {
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+  };
+  // the halves of `nb_` consecutive blocks whose first slot is slot0 (slots advance modulo the ring)
+  auto compute = [&](int slot0, auto nb_c) __attribute__((always_inline)) {
+    constexpr int NH = 2 * decltype(nb_c)::value;
+    if (!wave_has_tiles) return;
+#if RG_WGRAD_PIPE
+    u16x8 af[2][TA], bf[2][TB];
+    load_half(slot0, 0, af[0], bf[0]);
+    static_for<0, NH>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value;
+      if constexpr (q + 1 < NH) load_half((slot0 + (q + 1) / 2) % SLOTS, (q + 1) & 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+      sched_fence();  // (without the fences the scheduler requests every half's fragments up front: 256 registers + scratch)
+      mma_half(af[q & 1], bf[q & 1]);
+      sched_fence();
+    });
+#else
+    static_for<0, NH>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value;
+      u16x8 af[TA], bf[TB];
+      load_half((slot0 + q / 2) % SLOTS, q & 1, af, bf);
+      mma_half(af, bf);
+    });
+#endif
+  };
+  using one_t = std::integral_constant<int, 1>;
+  using two_t = std::integral_constant<int, 2>;
+  constexpr bool PAIR = RG_WGRAD_PAIR && SLOTS == 4;
 
   RG_PHASE_INIT();
   if (mb_begin < mb_end) {
     const int n_blk = mb_end - mb_begin;
-    static_for<0, FLY>([&](auto f_c) __attribute__((always_inline)) { issue(mb_begin + decltype(f_c)::value, decltype(f_c)::value); });
-    RG_PHASE(0);
-    for (int t = 0; t < n_blk; ++t) {
-      // FLY stages are outstanding: let the oldest land, then meet the other waves — past the barrier block t is complete
-      // in LDS and every wave has finished reading block t-1, whose slot the DMA issued below overwrites
-      wait_vmcnt<(FLY - 1) * DMA>();
-      RG_PHASE(2);
-      raw_barrier();
-      RG_PHASE(3);
-      issue(mb_begin + t + FLY, (t + FLY) % SLOTS);  // before the MFMAs: the requests leave a block time earlier
-      compute(t % SLOTS);
-      RG_PHASE(1);
+    if constexpr (PAIR) {
+      // pair p = blocks 2p, 2p + 1 in slots (2p) % 4, (2p + 1) % 4; while it is computed pair p + 1 travels into the other
+      // two slots, which every wave left before this iteration's barrier
+      const int n_pair = n_blk >> 1;
+      issue(mb_begin, 0);
+      issue(mb_begin + 1, 1);
+      RG_PHASE(0);
+      for (int p = 0; p < n_pair; ++p) {
+        wait_vmcnt<0>();
+        RG_PHASE(2);
+        raw_barrier();
+        RG_PHASE(3);
+        issue(mb_begin + 2 * p + 2, (2 * p + 2) & 3);
+        issue(mb_begin + 2 * p + 3, (2 * p + 3) & 3);
+        compute((2 * p) & 3, two_t{});
+        RG_PHASE(1);
+      }
+      wait_vmcnt<0>();
+      if (n_blk & 1) {  // an odd tail block (it travelled as the first block of the pair after the last; outside the
+        raw_barrier();  // loop: a second path through the accumulators INSIDE it doubled the kernel's registers)
+        compute((2 * n_pair) & 3, one_t{});
+      }
+    } else {
+      static_for<0, FLY>([&](auto f_c) __attribute__((always_inline)) { issue(mb_begin + decltype(f_c)::value, decltype(f_c)::value); });
+      RG_PHASE(0);
+      for (int t = 0; t < n_blk; ++t) {
+        // FLY stages are outstanding: let the oldest land, then meet the other waves — past the barrier block t is complete
+        // in LDS and every wave has finished reading block t-1, whose slot the DMA issued below overwrites
+        wait_vmcnt<(FLY - 1) * DMA>();
+        RG_PHASE(2);
+        raw_barrier();
+        RG_PHASE(3);
+        issue(mb_begin + t + FLY, (t + FLY) % SLOTS);  // before the MFMAs: the requests leave a block time earlier
+        compute(t % SLOTS, one_t{});
+        RG_PHASE(1);
+      }
+      wait_vmcnt<0>();
     }
-    wait_vmcnt<0>();
   }
 
 #pragma unroll
@@ -1468,22 +1527,6 @@ int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t s
   return (int)hipGetLastError();
 }
 
-static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target_wgs, int x3 = 0) {
-  WgradFragPlan p = wgrad_frag_plan(out_f, in_f, batch, x3);
-  const int tiles = p.tiles;
-  if (tiles == 1 && p.shape != WG_SHAPE_8x8 && RG_WGRAD_TARGET_THIN < target_wgs) target_wgs = RG_WGRAD_TARGET_THIN;
-  int want = (target_wgs + tiles - 1) / tiles;
-  const int max_splits = (p.MB + WG_MB_STAGE - 1) / WG_MB_STAGE;
-  if (want > max_splits) want = max_splits;
-  if (want < 1) want = 1;
-  if (want >= 8) want = want / 8 * 8;
-  int per = (p.MB + want - 1) / want;
-  per = (per + WG_MB_STAGE - 1) / WG_MB_STAGE * WG_MB_STAGE;
-  p.mb_per_split = per;
-  p.splits = (p.MB + per - 1) / per;
-  return p;
-}
-
 // ---- how many splits per layer --------------------------------------------------------------------------------------
 // Round 4 (profiles/microbench/out/r04a: hbm_roof.txt, wgrad_model.txt).  The staging mechanism alone — the LDS-DMA ring of
 // one workgroup per CU — draws 7.2 TB/s from HBM when every workgroup streams its own bytes (28 B/ns per CU) and 11.7 TB/s
@@ -1495,11 +1538,13 @@ static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target
 // chosen so that ALL workgroups of the launch are one round of the chip (RG_WGRAD_TOTAL, default = the CU count) and
 // take the same time by the rates above: fewer partial bytes, no tail.  (Round 3's "256 in all" experiment lost because a
 // split count that is not a multiple of 8 fell off the XCD-grouped decode: every byte then came from HBM twice.)
-struct WgradTuning { int balanced, total; double shared, unshared; };
+struct WgradTuning { int balanced, total; double shared, unshared; int thin, long_first; };
 static const WgradTuning& wgrad_tuning() {
   static const WgradTuning t = [] {
-    WgradTuning v{1, 0, 46.0, 28.0};
-    if (const char* e = getenv("RG_WGRAD_PLAN")) v.balanced = (e[0] != 'l');  // "legacy": 128 workgroups per layer
+    WgradTuning v{0, 0, 46.0, 28.0, RG_WGRAD_TARGET_THIN, 1};
+    if (const char* e = getenv("RG_WGRAD_THIN")) v.thin = atoi(e);
+    if (const char* e = getenv("RG_WGRAD_ORDER")) v.long_first = atoi(e);
+    if (const char* e = getenv("RG_WGRAD_PLAN")) v.balanced = (e[0] == 'b');  // "balanced": one round by the cost model
     if (const char* e = getenv("RG_WGRAD_TOTAL")) v.total = atoi(e);
     if (const char* e = getenv("RG_WGRAD_SHARED")) v.shared = atof(e);
     if (const char* e = getenv("RG_WGRAD_UNSHARED")) v.unshared = atof(e);
@@ -1512,6 +1557,22 @@ static const WgradTuning& wgrad_tuning() {
     return v;
   }();
   return t;
+}
+
+static WgradFragPlan wgrad_group_plan(int out_f, int in_f, int batch, int target_wgs, int x3 = 0) {
+  WgradFragPlan p = wgrad_frag_plan(out_f, in_f, batch, x3);
+  const int tiles = p.tiles;
+  if (tiles == 1 && p.shape != WG_SHAPE_8x8 && wgrad_tuning().thin < target_wgs) target_wgs = wgrad_tuning().thin;
+  int want = (target_wgs + tiles - 1) / tiles;
+  const int max_splits = (p.MB + WG_MB_STAGE - 1) / WG_MB_STAGE;
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  if (want >= 8) want = want / 8 * 8;
+  int per = (p.MB + want - 1) / want;
+  per = (per + WG_MB_STAGE - 1) / WG_MB_STAGE * WG_MB_STAGE;
+  p.mb_per_split = per;
+  p.splits = (p.MB + per - 1) / per;
+  return p;
 }
 
 static void wgrad_stack_plan(const rg_mlp_desc* d, int batch, WgradFragPlan* out) {
@@ -1561,8 +1622,20 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   float* part = (float*)workspace;
   int wg = 0;
   long el = 0;
+  // Launch order: the layers whose workgroups run longest (most 32-row blocks per split) FIRST.  Workgroups are dispatched
+  // in id order, one per CU; in layer order dW0's short workgroups went first and the CUs that drew them started a
+  // hidden layer's long one late — the launch ended 3/2 of a balanced schedule in (profiles/microbench/out/r04a/
+  // wgrad_phases.txt: lifetimes 43 / 74 / 74 / 42 us, launch 117 us).  With the long ones first the short ones fill the tail.
+  int order[FB_MAXL];
+  for (int l = 0; l < FB_MAXL; ++l) order[l] = l;
+  if (wgrad_tuning().long_first)
+    for (int i = 1; i < d->n_layers; ++i)  // stable insertion sort by descending blocks per split
+      for (int j = i; j > 0 && plan[order[j]].mb_per_split > plan[order[j - 1]].mb_per_split; --j) {
+        const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+      }
+  int pos_of[FB_MAXL];
+  for (int j = 0; j < FB_MAXL; ++j) pos_of[order[j]] = j;
   for (int l = 0; l < FB_MAXL; ++l) {
-    G.wg_begin[l] = wg;
     R.elem_begin[l] = el;
     if (l < d->n_layers) {
       if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
@@ -1571,7 +1644,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
 #ifdef RG_WGRAD_LAYER_MASK  // timing ablation only (profiles/scripts): layers outside the mask get no workgroups, dW = 0
       if (!((RG_WGRAD_LAYER_MASK >> l) & 1)) p.splits = 0;
 #endif
-      WgradFragArgs& g = G.layer[l];
+      WgradFragArgs& g = G.layer[pos_of[l]];
       g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
       g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
       g.partial = part; g.slab = p.slab; g.N = out_f; g.K = in_f;
@@ -1581,11 +1654,22 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
       g.b_lo = d->x3 ? (long)frag_elems(batch, in_f) : 0;
       R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
       part += (size_t)p.splits * p.slab;
-      wg += p.tiles * ((p.splits + 7) / 8 * 8);  // the tiles of a split on ONE XCD (wgrad_frag_body), eight splits abreast
       el += p.slab;
     } else {
-      G.layer[l] = G.layer[0];
       R.partial[l] = nullptr; R.slab[l] = 0; R.splits[l] = 0; R.out[l] = nullptr;
+    }
+  }
+  for (int j = 0; j < FB_MAXL; ++j) {  // workgroup ranges in launch order
+    G.wg_begin[j] = wg;
+    if (j < d->n_layers) {
+      const WgradFragPlan& p = plan[order[j]];
+      int splits = p.splits;
+#ifdef RG_WGRAD_LAYER_MASK
+      if (!((RG_WGRAD_LAYER_MASK >> order[j]) & 1)) splits = 0;
+#endif
+      wg += p.tiles * ((splits + 7) / 8 * 8);  // the tiles of a split on ONE XCD (wgrad_frag_body), eight splits abreast
+    } else {
+      G.layer[j] = G.layer[0];
     }
   }
   G.wg_begin[FB_MAXL] = wg;

@@ -628,6 +628,10 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
         t.acts[l] = st.acts[l]
         t.act_frag[l], t.dz_frag[l], t.dw[l] = d.act_frag[l], d.dz_frag[l], dw[l].data_ptr()
     ws = st._ws
+    # the trunk is its own launch plan (the splits of a launch are shared out over ITS layers): its own workspace size
+    need = lib.rg_mlp_wgrad_fused_workspace_bytes(t, R)
+    if ws["wgrad"].numel() * 4 < need:
+        ws["wgrad"] = torch.empty(_round_up(need, 16) // 4, dtype=torch.float32, device=ws["wgrad"].device)
     ops._run("rg_mlp_wgrad_fused", dict(B=R, dims=tuple(st.dims[:n])),
              lambda: lib.rg_mlp_wgrad_fused(t, R, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))
     ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.tile_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
