@@ -582,3 +582,56 @@ def test_reference_known_answers_replay_overflow(backend):
     b = m.sample_all_valid_transitions()
     assert b.action.cpu().tolist() == [[0, 8], [8, 10], [10, 12], [4, 6]]
     assert b.next_action[0].cpu().tolist() == [[8, 10], [10, 12]] and b.next_action[1][0].cpu().tolist() == [10, 12]
+
+
+@pytest.mark.parametrize("horizon", [1, 3])
+def test_add_many_equals_the_same_transitions_added_one_by_one(backend, horizon):
+    """ReplayBuffer.add_many (bulk rows as one indexed device copy per column, the validity rules of add in closed form)
+    against `add` called per transition — and, in the build container, against the REFERENCE class's add: same storage,
+    cursor, validity mask, episode counter, over several calls, episode boundaries at every offset and two wraps of the ring."""
+    import numpy as np
+
+    from reagent_amd.replay_memory import ReplayBuffer
+
+    C, F, A = 97, 5, 3
+    rng = np.random.default_rng(7 + horizon)
+    bulk = ReplayBuffer(replay_capacity=C, batch_size=4, update_horizon=horizon, gamma=0.9, device=backend.device)
+    one = ReplayBuffer(replay_capacity=C, batch_size=4, update_horizon=horizon, gamma=0.9, device=backend.device)
+    ref = None
+    from oracle import stubs
+
+    if stubs.reference_available():
+        stubs.install()
+        from reagent.replay_memory.circular_replay_buffer import ReplayBuffer as RefBuffer
+
+        ref = RefBuffer(replay_capacity=C, batch_size=4, update_horizon=horizon, gamma=0.9)
+    total = 0
+    for T in (1, 2, 40, 7, 60, 97, 13, 1, 30):
+        cols = dict(observation=rng.standard_normal((T, F)).astype(np.float32), action=rng.integers(0, A, T),
+                    reward=rng.random(T).astype(np.float32), terminal=rng.random(T) < 0.15,
+                    possible_actions_mask=(rng.random((T, A)) < 0.8).astype(np.float32), log_prob=rng.random(T).astype(np.float32))
+        bulk.add_many(**{k: torch.from_numpy(v) for k, v in cols.items()})
+        for t in range(T):
+            row = dict(observation=cols["observation"][t], action=np.int64(cols["action"][t]), reward=np.float32(cols["reward"][t]),
+                       terminal=bool(cols["terminal"][t]), possible_actions_mask=cols["possible_actions_mask"][t],
+                       log_prob=np.float32(cols["log_prob"][t]))
+            one.add(**row)
+            if ref is not None:
+                ref.add(**row)
+        total += T
+        assert int(bulk.add_count) == int(one.add_count) == total and bulk.cursor() == one.cursor()
+        assert np.array_equal(bulk._valid_host, one._valid_host), (T, total)
+        assert bulk._num_valid_indices == one._num_valid_indices == int(one._valid_host.sum())
+        assert np.array_equal(bulk._terminal_host, one._terminal_host)
+        assert bulk._num_transitions_in_current_episode == one._num_transitions_in_current_episode
+        for k in one._store:
+            assert torch.equal(bulk._store[k].cpu(), one._store[k].cpu()), k
+        if ref is not None:
+            assert np.array_equal(bulk._valid_host, ref._is_index_valid.numpy()), (T, total)
+            assert bulk._num_valid_indices == ref._num_valid_indices
+    # and the sampler reads the same batch from both
+    idx = bulk._valid_indices()[:8]
+    a, b = bulk.sample_transition_batch(8, indices=idx), one.sample_transition_batch(8, indices=idx)
+    for x, y in zip(a, b):
+        if isinstance(x, torch.Tensor):
+            assert torch.equal(x, y)
