@@ -5,7 +5,7 @@ cd /root/repo; OUT=/root/repo/gpurun_out; TAG=${1:-pmc}; mkdir -p $OUT/pmc_$TAG
 # would otherwise burn the whole GPU budget in core dumps and timeouts
 timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 export TMPDIR=/tmp
-CMD="python /root/repo/bench.py --config ${PMC_CONFIG:-c2} --precision ${PMC_PREC:-bf16} --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-parity --launch eager"
+CMD="python /root/repo/bench.py --config ${PMC_CONFIG:-c2} --precision ${PMC_PREC:-bf16} --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also --sustained-steps 0 --launch eager"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM" \

@@ -12,7 +12,7 @@ G5="TCC_HIT_sum TCC_MISS_sum"; G6="GRBM_GUI_ACTIVE GRBM_COUNT"
 run_cfg() {  # config precision groups...
   local cfg=$1 prec=$2; shift 2
   local D=$OUT/pmc_${TAG}_${cfg}_${prec}; mkdir -p $D
-  local CMD="python /root/repo/bench.py --config $cfg --precision $prec --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also --launch eager --no-graph"
+  local CMD="python /root/repo/bench.py --config $cfg --precision $prec --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also --sustained-steps 0 --launch eager --no-graph"
   local i=0
   for grp in "$@"; do
     i=$((i+1))
