@@ -171,6 +171,8 @@ def parse():
     ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--parity-batch", type=int, default=4096)
+    ap.add_argument("--graph-steps", type=int, default=4,
+                    help="consecutive steps recorded per HIP graph where the loop supports it (must divide --steps)")
     ap.add_argument("--sustained-steps", type=int, default=4000,
                     help="steps of the one long region reported as `sustained` next to the K-step regions (0: skip)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -649,6 +651,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         torch.cuda.synchronize()
 
     step = loop.step
+    steps_per_call = 1  # steps one call of `step` makes (a replayed graph may hold several)
     graph_note = None
     calibration = None
     # data parallel: the eager loop (asynchronous all-reduce, deferred update) is the default — on one GPU the
@@ -657,24 +660,34 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     want_graph = not args.no_graph and hasattr(loop, "capture") and not (world > 1 and args.launch is None) and args.launch != "eager"
     launch = args.launch or "auto"
     if want_graph:
+        # several consecutive steps per graph where the loop supports it (device-side index cursor: the DQN family) and the
+        # step counts of this run divide: the ~8 us the queue idles between two graph launches are paid once per replay
+        spr = args.graph_steps if (world == 1 and args.graph_steps > 1 and args.steps % args.graph_steps == 0
+                                   and args.sustained_steps % args.graph_steps == 0) else 1
         try:
-            replay = loop.capture(warmup=max(2, min(args.warmup, 3)))
+            try:
+                replay = loop.capture(warmup=max(2, min(args.warmup, 3)), steps_per_replay=spr)
+            except (NotImplementedError, ValueError, TypeError):
+                replay = loop.capture(warmup=max(2, min(args.warmup, 3)))
         except Exception as e:
             replay = None
             graph_note = f"graph capture failed, eager launches: {e!r}"
         if replay is not None:
+            per = int(getattr(loop, "replay_steps", 1))
             # Which launch path is faster depends on the workload: a replayed graph costs the host ~0.02 ms per
             # step but serialises its kernel nodes a little more loosely than back-to-back stream launches, an
             # eager step costs the host 0.3-1.2 ms.  Calibrate outside the timed region (every rank takes the same
             # decision: the slowest rank's times count).
-            def timed(fn, n=max(8, min(args.steps, 30))):
+            def timed(fn, k=1, n=max(8, min(args.steps, 30))):
+                """seconds per STEP of n steps (fn makes k steps per call)"""
+                n = max(k, n // k * k)
                 best, host = None, 0.0
                 for _ in range(2):  # the better of two regions: a region of a few ms is at the mercy of a clock ramp
                     fn()
                     loop.flush()
                     barrier()
                     t = time.perf_counter()
-                    for _ in range(n):
+                    for _ in range(n // k):
                         fn()
                     host = max(host, (time.perf_counter() - t) / n)  # what the host needed to enqueue a step
                     loop.flush()
@@ -683,7 +696,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
                     best = dt if best is None else min(best, dt)
                 return best, host
 
-            (t_graph, _), (t_eager, host_eager) = timed(replay), timed(loop.step)
+            (t_graph, _), (t_eager, host_eager) = timed(replay, per), timed(loop.step)
             if dist is not None:
                 tt = torch.tensor([t_graph, t_eager, host_eager], device=device, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -693,7 +706,8 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
             # shows it; the 3 % concession round 3 made there could put the slower path in the headline)
             margin = 1.01
             use_graph = launch == "graph" or (launch == "auto" and t_graph <= margin * t_eager)
-            what = ("one HIP graph per step (sampler, forwards, head, backward, wgrad, update; its indices copied in from the index pool)" if world == 1 else
+            what = ((f"one HIP graph per {per} consecutive steps" if per > 1 else "one HIP graph per step") +
+                    " (sampler, forwards, head, backward, wgrad, update; indices from the loop's index pool)" if world == 1 else
                     "three HIP graphs per step (sample | update | forward+backward), the RCCL all-reduce of the gradient "
                     "slab launched eagerly between them")
             graph_note = (f"{'graph replay: ' + what if use_graph else 'eager stream launches'}; calibration "
@@ -702,10 +716,12 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
             calibration = {"graph_ms_per_step": t_graph * 1e3, "eager_ms_per_step": t_eager * 1e3,
                            "eager_host_enqueue_ms_per_step": host_eager * 1e3, "chosen": "graph" if use_graph else "eager",
                            "rule": f"graph unless it is more than {round((margin - 1) * 100)} % slower than eager launches"}
+            calibration["steps_per_graph"] = per
             step = replay if use_graph else loop.step
+            steps_per_call = per if use_graph else 1
             if not use_graph:
                 loop.release_graph()  # eager steps then pass Adam's coefficients per launch (no tick kernel)
-    for _ in range(args.warmup):
+    for _ in range((args.warmup + steps_per_call - 1) // steps_per_call):
         step()
     loop.flush()
     # K steps take ~12 ms at C2: one region is at the mercy of a clock ramp or a stray interrupt.  The region of
@@ -715,7 +731,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // steps_per_call):  # EXACTLY args.steps steps (steps_per_call divides it, see capture)
             loss = step()
         loop.flush()  # data parallel: the last step's update joins its all-reduce inside the timed region
         host_regions.append(time.perf_counter() - t0)  # time the host needed to ENQUEUE the steps (diagnostic)
@@ -742,7 +758,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         barrier()
         with GpuTelemetry(device.index or 0) as tele:
             t0 = time.perf_counter()
-            for _ in range(n_sus):
+            for _ in range(n_sus // steps_per_call):
                 step()
             loop.flush()
             barrier()

@@ -46,6 +46,7 @@ class _GraphedLoop:
 
     _graph = None
     _replays = 0
+    replay_steps = 1  # steps one replay() makes (capture(steps_per_replay=))
     # Index draws of `index_pool_steps` steps come from ONE torch.randint launch (the per-step draw was the last
     # torch kernel on the C2 step: 5 us of 540); a step then only slices the pool.  1 = a draw per step.  Inside a
     # graph capture the per-step draw stays (torch's graph-safe Philox state is what makes a replay draw afresh).
@@ -150,7 +151,12 @@ class _GraphedLoop:
     def load(self, path: str):
         self.load_checkpoint(torch.load(path, map_location="cpu", weights_only=False))
 
-    def capture(self, warmup: int = 2, static_indices: bool = False):
+    def capture(self, warmup: int = 2, static_indices: bool = False, steps_per_replay: int = 1):
+        """steps_per_replay > 1 (loops with a device-side index cursor only — the DQN family on the one-launch sampler and
+        update): that many CONSECUTIVE steps are recorded as one graph, so a replay is that many steps.  Between two graph
+        launches the queue idles ~8 us (between two kernels of a stream ~1 us); the cursor and the Adam step count live on the
+        device and advance per captured step, so nothing else changes.  Must divide index_pool_steps; `replay.steps` tells
+        the caller how many steps a call makes."""
         from .training.dqn_trainer import enable_graph_mode
 
         tr = self.trainer
@@ -183,13 +189,19 @@ class _GraphedLoop:
 
                 cursor = tick["cursor"]
                 tr._graph_tick = tick
+                n_steps = max(1, int(steps_per_replay))
+                if self.index_pool_steps % n_steps:
+                    raise ValueError(f"steps_per_replay {n_steps} must divide index_pool_steps {self.index_pool_steps}")
                 try:
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        out = self._eager_step(_ops.PooledIndices(self._pool, cursor, tick["sched"]))
+                        for _ in range(n_steps):
+                            out = self._eager_step(_ops.PooledIndices(self._pool, cursor, tick["sched"]))
                 finally:
                     tr._graph_tick = None
                 assert tick.get("used"), "the captured step did not take the one-launch update"
                 idx = None
+                if n_steps > 1:  # replays start on multiples of n_steps: the rows the warm-up left of its group are skipped
+                    self._pool_pos = (self._pool_pos + n_steps - 1) // n_steps * n_steps
             else:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out = self._eager_step(idx, **extra)
@@ -208,8 +220,13 @@ class _GraphedLoop:
             graphs = (gs, gu, gc)
             self._graph_batch = batch
         tr.all_batches_processed = done  # the capture call ran the host side of a step, not the step
+        n_steps = max(1, int(steps_per_replay)) if cursor is not None else 1
+        if steps_per_replay > 1 and cursor is None:
+            raise NotImplementedError("steps_per_replay > 1 needs the device-side index cursor (DQN-family loop, one-launch sampler and update)")
         self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None, pooled=pooled, extra=extra if not dp else {},
-                           cursor=cursor, dev_pos=None, pool_ptr=self._pool.data_ptr() if cursor is not None else None)
+                           cursor=cursor, dev_pos=None, pool_ptr=self._pool.data_ptr() if cursor is not None else None,
+                           steps=n_steps)
+        self.replay_steps = n_steps
         return self.replay
 
     def _cursor_protocol(self, dev):
@@ -229,15 +246,18 @@ class _GraphedLoop:
             if indices is not None:
                 raise ValueError("this loop was captured with a device-side index cursor: replay() draws from the index pool")
             dev = G["cursor"].device
+            n = G["steps"]
+            if n > 1 and self._pool_pos % n:  # eager steps in between drew from the pool: skip to the next group of rows
+                self._pool_pos = (self._pool_pos + n - 1) // n * n
             self._ensure_pool(dev)
             if self._pool.data_ptr() != G["pool_ptr"]:
                 raise RuntimeError("the index pool moved (replay buffer or batch size changed): capture the loop again")
             if G["dev_pos"] != self._pool_pos:  # first replay, or eager steps in between drew from the pool
                 G["cursor"].fill_(self._pool_pos)
             G["graphs"][0].replay()
-            self._pool_pos += 1
+            self._pool_pos += n
             G["dev_pos"] = self._pool_pos % self.index_pool_steps
-            self._replays += 1
+            self._replays += n
             return G["out"]
         if G["idx"] is not None:
             if indices is None:

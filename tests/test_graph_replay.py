@@ -157,7 +157,7 @@ def _c2_loop(dev, capacity=8192, batch=1024, precision=L.PREC_BF16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("draw", ["static_indices", "device_rng", "device_pool"])
+@pytest.mark.parametrize("draw", ["static_indices", "device_rng", "device_pool", "device_pool_2_steps_per_graph"])
 def test_dqn_loop_graph_replay_equals_eager(draw):
     dev = torch.device("cuda")
     L.lib()
@@ -167,7 +167,8 @@ def test_dqn_loop_graph_replay_equals_eager(draw):
     params = {}
     for mode in ("eager", "graph"):
         loop, tr = _c2_loop(dev)
-        if draw != "device_pool":
+        per = 2 if draw == "device_pool_2_steps_per_graph" else 1  # consecutive steps recorded per graph (round 4)
+        if not draw.startswith("device_pool"):
             loop.index_pool_steps = 1  # a draw per step, inside the captured graph too
         # device_pool (the default): eager steps and replays both take their indices from the loop's pool (32 steps per
         # torch.randint); a replay copies its row into the buffer the captured sampler reads
@@ -179,8 +180,9 @@ def test_dqn_loop_graph_replay_equals_eager(draw):
             for k in range(N):
                 out.append(loop.step(idx[k] if draw == "static_indices" else None).clone())
         else:
-            step = loop.capture(warmup=W, static_indices=draw == "static_indices")
-            for k in range(N):
+            step = loop.capture(warmup=W, static_indices=draw == "static_indices", steps_per_replay=per)
+            assert loop.replay_steps == per
+            for k in range(N // per):
                 out.append(step(idx[k] if draw == "static_indices" else None).clone())
         loop.flush()
         torch.cuda.synchronize()
@@ -189,6 +191,8 @@ def test_dqn_loop_graph_replay_equals_eager(draw):
         adam = tr.native_optimizers()[0]
         assert {float(st["step"]) for st in adam.state_dict()["state"].values()} == {float(N + W)}
         assert tr.all_batches_processed == N + W
+    if per > 1:  # a replay returns its LAST step's loss
+        losses["eager"] = losses["eager"][per - 1::per]
     assert torch.equal(losses["eager"], losses["graph"]), (losses["eager"], losses["graph"])
     for a, b in zip(params["eager"], params["graph"]):
         assert torch.equal(a, b)
