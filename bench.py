@@ -171,8 +171,8 @@ def parse():
     ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--parity-batch", type=int, default=4096)
-    ap.add_argument("--graph-steps", type=int, default=4,
-                    help="consecutive steps recorded per HIP graph where the loop supports it (must divide --steps)")
+    ap.add_argument("--graph-steps", type=int, default=1,
+                    help="consecutive steps recorded per HIP graph where the loop supports it (must divide --steps); measured round 4 at 1 / 2 / 4 / 8: 0.5125 / 0.5134 / 0.5126 / 0.5159 ms per C2 step — no gain, default 1")
     ap.add_argument("--sustained-steps", type=int, default=4000,
                     help="steps of the one long region reported as `sustained` next to the K-step regions (0: skip)")
     ap.add_argument("--rendezvous-only", action="store_true",
