@@ -44,6 +44,11 @@
 #ifndef RG_WGRAD_TARGET
 #define RG_WGRAD_TARGET 128
 #endif
+#ifndef RG_FWD_SWAP
+#define RG_FWD_SWAP 0  // non-saving forwards on transposed accumulator tiles (mlp_fwd_swap_kernel).  Round 4, same box: the two
+// non-saving forwards of a C2 step 169 -> 177 us, C4's 100 -> 106 — the 8-byte LDS writes collide two ways on the tile's row
+// pitch and the 16 bias values per tile are re-requested per row tile; bit-identical, slower: not the default.
+#endif
 #ifndef RG_WGRAD_PIPE
 #define RG_WGRAD_PIPE 1  // weight gradient: LDS fragment reads one half ahead of the MFMAs (wgrad_shape_core)
 #endif
@@ -73,7 +78,9 @@ template <int NW> struct MlpCfg {
 // tile assignment loses the dispatcher's load balancing; the kernel stays one tile per workgroup.)
 // GROUPED: the launch of a stack whose output layer takes per-tile weights (rg_mlp_desc.tile_key, qr_grouped.hip) is its
 // own instantiation — the ordinary kernel does not carry its code paths (or their registers).
-template <int TN, int NW, int PITCH, bool GROUPED>
+// SWAP (round 4): the non-saving launch of the plain kernel computes its hidden layers with transposed accumulator tiles
+// (rg_mlp_frag.h: wide_mainloop<.., SWAP>, fwd_hidden_pack_swapped) — same values bit for bit, a cheaper epilogue.
+template <int TN, int NW, int PITCH, bool GROUPED, bool SWAP = false>
 __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
   constexpr int THREADS = MlpCfg<NW>::THREADS, RING = MlpCfg<NW>::RING;
   RG_DYN_LDS(smem);
@@ -125,17 +132,22 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
       const long nt_stride = (long)KC * 512;
-      wide_mainloop<TN, RING>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
-                              k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+      wide_mainloop<TN, RING, SWAP>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
+                                    k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
       RG_STAMP(2 + 4 * l);
       unsigned PK[4][TN][8];
-      unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
-      RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l),
-                                                          sign_dst, N / 32, tile * 4, wave, lane, PK)));
+      if constexpr (SWAP) {
+        RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack_swapped<TN, A_>(acc, a.bias[l], wave, lane, PK)));
+      } else {
+        unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;  // plane base; the lane offset is applied at the store
+        RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l),
+                                                            sign_dst, N / 32, tile * 4, wave, lane, PK)));
+      }
       RG_STAMP(3 + 4 * l);
       __syncthreads();  // every wave is done reading the layer input
       RG_STAMP(4 + 4 * l);
-      store_packed_tiles<TN>(act, pitch, PK, wave, lane);
+      if constexpr (SWAP) store_packed_tiles_swapped<TN>(act, pitch, PK, wave, lane);
+      else store_packed_tiles<TN>(act, pitch, PK, wave, lane);
       if (out_lds) RG_WAIT_VMCNT(0);  // this wave's share of the output layer's weights has landed (long ago) ...
       __syncthreads();                // ... and after the barrier every wave's has
       RG_STAMP(5 + 4 * l);
@@ -260,6 +272,12 @@ template <int TN, int NW, int PITCH>
 __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_grouped_kernel(MlpArgs a) {
   mlp_fwd_fused_body<TN, NW, PITCH, true>(a);
 }
+#if RG_FWD_SWAP
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_swap_kernel(MlpArgs a) {  // save == 0 only
+  mlp_fwd_fused_body<TN, NW, PITCH, false, true>(a);
+}
+#endif
 
 // DX_ONLY: a frozen stack — only the input gradient is produced, no dZ fragments are written (rg_mlp_desc.dx_only)
 template <int TN, int NW, int PITCH, bool DX_ONLY>
@@ -1309,6 +1327,9 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
     }
   }
   if (d->tile_key) RG_LAUNCH_FUSED(mlp_fwd_grouped_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+#if RG_FWD_SWAP
+  else if (save == 0) RG_LAUNCH_FUSED(mlp_fwd_swap_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+#endif
   else RG_LAUNCH_FUSED(mlp_fwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();
 }

@@ -322,7 +322,10 @@ __device__ __forceinline__ f32x16 mfma_main(u16x8 a, u16x8 b, f32x16 c) { return
 __device__ __forceinline__ void mfma_drain() {}
 #endif
 
-template <int TN, int RING>
+// SWAP: the MFMA takes the WEIGHT fragment as its A operand and the activation fragment as B (the two fragment layouts are
+// the same registers: lane = row / column index, 8 consecutive k) — the accumulator tile is then the TRANSPOSE: lane =
+// batch row, register r = feature (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the tile.  Same products, same order over k.
+template <int TN, int RING, bool SWAP = false>
 __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave,
                                               long nt_stride, f32x16 (&acc)[4][TN], int lane, int rot,
                                               int prio_phase = 0) {
@@ -346,7 +349,7 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_main(af[tm], bf[tn], acc[tm][tn]);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = SWAP ? mfma_main(bf[tn], af[tm], acc[tm][tn]) : mfma_main(af[tm], bf[tn], acc[tm][tn]);
   };
   if (KC % RING == 0) {
     // fast path: no conditionals around the loads in the steady state, so the compiler keeps exact
@@ -571,6 +574,53 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
     });
     if (act_is_sign_based<ACT>() && sign_dst)
       ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
+  });
+}
+
+// Non-saving forward with transposed accumulator tiles (wide_mainloop<.., SWAP>): a lane holds ONE batch row and 16 features
+// of a tile in four runs of four consecutive ones, so the bf16 pairs are column neighbours already and the LDS tile takes
+// them as 8-byte writes — no neighbour swap (DPP + v_perm per pair) and half the LDS write instructions of the
+// lane-per-column epilogue.  Nothing is saved in this layout (the fragment records backward and the weight gradient read
+// are lane-per-column): it serves save = 0 launches only.  Bias: 16 values per tile and half-wave, four 16-byte loads.
+template <int TN, int ACT>
+__device__ __forceinline__ void fwd_hidden_pack_swapped(f32x16 (&acc)[4][TN], const float* bias, int wave, int lane,
+                                                        unsigned (&PK)[4][TN][8]) {
+  lane = opaque(lane);
+  const int lg = lane >> 5;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    const int f0 = (wave * TN + tn) * 32 + 4 * lg;
+    // the tile's 16 bias values (four runs of four features) are re-requested per row tile — 16-byte loads of a 2 KB
+    // vector every workgroup of the CU reads, L1-resident — so that they live across ONE tile: kept across the four row
+    // tiles of a column tile their 16 registers were what the 512-wide kernel (128 accumulators) spilled
+    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      sched_fence();  // one tile at a time: 16 accumulator registers die as 8 packed ones are born
+      f32x4 b4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = bias ? *(const f32x4*)(bias + f0 + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b4[r >> 2][r & 3]);
+      pack_tile(v, PK[tm][tn]);
+      pin_packed(PK[tm][tn]);
+    });
+    sched_fence();
+  });
+}
+
+template <int TN>
+__device__ __forceinline__ void store_packed_tiles_swapped(bf16_t* act, int pitch, const unsigned (&PK)[4][TN][8], int wave,
+                                                           int lane) {
+  const int lr = lane & 31, lg = lane >> 5;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      bf16_t* row = act + (tm * 32 + lr) * pitch + (wave * TN + tn) * 32 + 4 * lg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(uint2*)(row + 8 * q) = uint2{PK[tm][tn][2 * q], PK[tm][tn][2 * q + 1]};
+    });
   });
 }
 
