@@ -777,7 +777,8 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         n_prof = profile_steps or min(args.steps, 10)
         extra = kernel_profile(args, loop.step, n_prof)
         loop.flush()
-        two_streams = args.algo == "qrdqn" and getattr(args, "grouped_head", False) and getattr(trainer._grouped(), "two_streams", False)
+        gq = trainer._grouped() if (args.algo == "qrdqn" and getattr(args, "grouped_head", False)) else None
+        two_streams = gq is not None and (getattr(gq, "two_streams", False) or getattr(gq, "wgrad_streams", False))
         normalise_profile(extra, dt / args.steps * 1e3, single_stream=not two_streams)
     per_rank = None
     if dist is not None:

@@ -8,6 +8,7 @@
                  sequence of rg_fc_forward / rg_fc_dgrad / rg_fc_wgrad launches, with the
                  compute-type weight copies and the activation workspace it needs.
 """
+import contextlib
 from typing import List, Optional, Sequence
 
 import torch
@@ -604,8 +605,18 @@ def fused_forward_grouped(st: "FusedMLP", head: GroupedHead, x: torch.Tensor, sp
                                                   out32.stride(0), int(save), L.stream_ptr()))
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch.Tensor, dw: List[torch.Tensor],
-                           db: List[torch.Tensor], wgrad_ws: torch.Tensor, splits: int):
+                           db: List[torch.Tensor], wgrad_ws: torch.Tensor, splits: int, two_streams: bool = False):
     """Backward of the stack + grouped head from dz32 = d loss / d (head output) [grouped rows, group_rows]:
     one rg_mlp_backward_fused launch (the head's input gradient is its first layer step, per-tile W_g^T), the
     trunk's weight gradients by rg_mlp_wgrad_fused, the head's by rg_group_head_wgrad.  dw / db: all L layers."""
@@ -632,10 +643,21 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
     need = lib.rg_mlp_wgrad_fused_workspace_bytes(t, R)
     if ws["wgrad"].numel() * 4 < need:
         ws["wgrad"] = torch.empty(_round_up(need, 16) // 4, dtype=torch.float32, device=ws["wgrad"].device)
+    # The two weight-gradient launches read what the backward launch wrote and nothing of each other: on two streams the
+    # head's (n_groups x splits x 2 workgroups) fills the tail of the trunk's and the other way round (RG_QR_WGRAD_STREAMS=0:
+    # one after the other, as in rounds 2-3).
+    side = None
+    if dz32.is_cuda and two_streams:
+        main = torch.cuda.current_stream()
+        side = _side_stream(dz32.device)
+        side.wait_stream(main)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.tile_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
+                             wgrad_ws, x3=head.x3, rows=R)
     ops._run("rg_mlp_wgrad_fused", dict(B=R, dims=tuple(st.dims[:n])),
              lambda: lib.rg_mlp_wgrad_fused(t, R, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))
-    ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.tile_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
-                         wgrad_ws, x3=head.x3, rows=R)
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
 
 
 class FusedUpdate:

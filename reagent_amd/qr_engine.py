@@ -117,6 +117,7 @@ class GroupedQR:
         self._B = -1
         self._side = None
         self.two_streams = os.environ.get("RG_QR_STREAMS", "1") != "0"  # the forward's two halves on two streams
+        self.wgrad_streams = os.environ.get("RG_QR_WGRAD_STREAMS", "1") != "0"  # the backward's two weight-gradient launches
 
     def after_fused_update(self):
         """DQNTrainer._fused_update ran Adam + soft update + re-staging of both networks' trunk and grouped-head
@@ -241,4 +242,5 @@ class GroupedQR:
 
     # the trainer's `_qs.backward(dq, xt, dw, db)` contract
     def backward(self, dq, xt, dw, db, **_):
-        fused_backward_grouped(self.online.st, self.online.gh, self.sp_cur, dq, dw, db, self.wg_ws, self.splits)
+        fused_backward_grouped(self.online.st, self.online.gh, self.sp_cur, dq, dw, db, self.wg_ws, self.splits,
+                               two_streams=self.wgrad_streams)
