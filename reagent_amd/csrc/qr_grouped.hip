@@ -256,31 +256,36 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     const int e = lane * 4 + k;
     v[k] = e < N ? rew + dn * a.zt[(long)b * a.ldzt + e] : __builtin_inff();
   }
-  // bitonic sort, ascending, element index e = 4 * lane + k
-  for (int K = 2; K <= QC_MAX_N; K <<= 1)
-    for (int j = K >> 1; j > 0; j >>= 1) {
-      if (j >= 4) {
-        const int lm = j >> 2;
-        const bool lower = (lane & lm) == 0;
+  // bitonic sort, ascending, element index e = 4 * lane + k.  Fully unrolled (36 stages); a compare-exchange is ONE v_med3
+  // with the direction as its third operand (-inf keeps the smaller, +inf the larger: the inputs are NaN-free), and the
+  // partner comes by DPP / ds_swizzle for lane distances below 32 (round 4: min + max + select and a ds_bpermute per element
+  // and stage were the largest share of the kernel's ~2000 VALU operations per row).
+  const float NEG = -__builtin_inff(), POS = __builtin_inff();
+  static_for<1, 9>([&](auto kk_c) __attribute__((always_inline)) {
+    constexpr int K = 1 << decltype(kk_c)::value;  // 2 .. 256
+    static_for<0, decltype(kk_c)::value>([&](auto jj_c) __attribute__((always_inline)) {
+      constexpr int j = K >> (1 + decltype(jj_c)::value);  // K/2 .. 1
+      if constexpr (j >= 4) {
+        constexpr int lm = j >> 2;
+        // ascending block (e & K == 0) and lower partner keep the minimum; K >= 8 here, so the direction is the lane's alone
+        const bool keep_min = ((lane & lm) == 0) == (((lane * 4) & K) == 0);
+        const float dir = keep_min ? NEG : POS;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float other = shfl_xor(v[k], lm);
-          const bool up = ((lane * 4 + k) & K) == 0;
-          v[k] = (lower == up) ? fminf(v[k], other) : fmaxf(v[k], other);
-        }
+        for (int k = 0; k < 4; ++k) v[k] = med3(v[k], shfl_xor_c<lm>(v[k]), dir);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int q = k ^ j;
           if (q > k) {
             const bool up = ((lane * 4 + k) & K) == 0;
-            const float lo = fminf(v[k], v[q]), hi = fmaxf(v[k], v[q]);
-            v[k] = up ? lo : hi;
-            v[q] = up ? hi : lo;
+            const float a_ = v[k], b_ = v[q];
+            v[k] = med3(a_, b_, up ? NEG : POS);
+            v[q] = med3(a_, b_, up ? POS : NEG);
           }
         }
       }
-    }
+    });
+  });
   // exclusive prefix sums of T and T^2 in sorted order (fp64; the +inf padding counts as 0)
   double t1[4], t2[4], s1 = 0.0, s2 = 0.0;
 #pragma unroll

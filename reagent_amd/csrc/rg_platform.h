@@ -59,6 +59,21 @@ __device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 64); }
 
+// value of lane ^ MASK for a compile-time MASK: a DPP quad permute (1, 2: a VALU move the consumer can absorb), a
+// ds_swizzle in bit mode (4, 8, 16: the LDS crossbar without the address VGPR ds_bpermute needs), ds_bpermute for 32
+template <int MASK> __device__ __forceinline__ float shfl_xor_c(float v) {
+  const int x = __builtin_bit_cast(int, v);
+  int r;
+  if constexpr (MASK == 1) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+  else if constexpr (MASK == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  else if constexpr (MASK < 32) r = __builtin_amdgcn_ds_swizzle(x, (MASK << 10) | 0x1F);      // and 0x1f, or 0, xor MASK
+  else r = __shfl_xor(x, MASK, 64);
+  return __builtin_bit_cast(float, r);
+}
+// median of three (v_med3_f32): med3(a, b, -inf) = min(a, b), med3(a, b, +inf) = max(a, b) for NaN-free inputs — a
+// compare-exchange whose direction is DATA (the third operand), not control flow
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // LDS hand-off between the lanes of ONE wave: the wave's earlier ds_writes are complete and visible to its later
 // ds_reads (the lanes run in lockstep and LDS operations of a wave retire in order; this pins the compiler and

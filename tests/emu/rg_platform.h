@@ -148,6 +148,11 @@ static inline float shfl_down(float v, int d) {
   int l = lane_id();
   return gather_from(v, (l + d < 64) ? l + d : l);
 }
+template <int MASK> static inline float shfl_xor_c(float v) { return gather_from(v, lane_id() ^ MASK); }
+static inline float med3(float a, float b, float c) {
+  const float lo = a < b ? a : b, hi = a < b ? b : a;
+  return c < lo ? lo : (c > hi ? hi : c);
+}
 static inline float shfl_idx(float v, int src) { return gather_from(v, src); }
 static inline int shfl_idx(int v, int src) { return gather_from(v, src); }
 
