@@ -659,6 +659,27 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     # has only been exercised on a one-rank RCCL group (tests/test_graph_replay.py); `--launch graph` / `auto` opt in
     want_graph = not args.no_graph and hasattr(loop, "capture") and not (world > 1 and args.launch is None) and args.launch != "eager"
     launch = args.launch or "auto"
+    if (world > 1 and args.launch is None and not args.no_graph and device.type == "cuda" and hasattr(loop, "capture")
+            and hasattr(trainer, "native_forward_backward")):
+        # Data parallel without an explicit --launch: eager launches (what the world-2 tests cover) UNLESS this node's host
+        # cannot keep up with them — seen on one box of the pool: 1.3 ms of host time per 0.54 ms C2 step, a loop that would
+        # measure the host.  Then (every rank takes the same decision: the slowest host counts) the three-graph replay.
+        for _ in range(3):
+            loop.step()
+        loop.flush()
+        barrier()
+        t = time.perf_counter()
+        for _ in range(10):
+            loop.step()
+        host = (time.perf_counter() - t) / 10
+        loop.flush()
+        barrier()
+        tot = (time.perf_counter() - t) / 10
+        r = torch.tensor([host / max(tot, 1e-9)], device=device, dtype=torch.float64)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        if r.item() >= 0.85:
+            want_graph, launch = True, "graph"
+            graph_note = f"host-bound eager loop (enqueue {host * 1e3:.3f} of {tot * 1e3:.3f} ms/step on the slowest rank's host)"
     if want_graph:
         # several consecutive steps per graph where the loop supports it (device-side index cursor: the DQN family) and the
         # step counts of this run divide: the ~8 us the queue idles between two graph launches are paid once per replay
