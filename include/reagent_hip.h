@@ -181,15 +181,19 @@ typedef struct {
    * whole 128-row tiles, qr_grouped.hip) without materialising the permuted input. */
   const int32_t* rowmap;
   /* Grouped OUTPUT layer (qr_grouped.hip): with tile_key != NULL the last layer is one of n_groups layers
-   * [dims[L], dims[L-1]] chosen per 128-row tile, group g = tile_key[tile] (-1: an empty tile, whose output is
-   * skipped): wfrag_fwd[L-1] / wfrag_bwd[L-1] / bias[L-1] point at group 0 and advance by group_stride_fwd /
+   * [dims[L], dims[L-1]] chosen per ROW of the grouped space: group g owns the rows [row_begin[g], row_begin[g + 1])
+   * (ABI 9; rows past row_begin[n_groups] belong to no group and have no output), tile_key[tile] = the first group with rows
+   * in a 128-row tile (-1: none) — a tile that spans several groups runs the layer once per group on that group's rows.
+   * wfrag_fwd[L-1] / wfrag_bwd[L-1] / bias[L-1] point at group 0 and advance by group_stride_fwd /
    * group_stride_bwd elements / dims[L] per group (rg_group_weights_stage lays them out so).  out_scatter != 0
    * writes output row r of the forward to out32[rowmap[r]] (rows with rowmap[r] < 0 are dropped).  The backward
-   * reduces the last layer's bias gradient per group (db[L-1]: [n_groups * dims[L]], tile_begin required) and
-   * leaves the last layer's weight gradient to rg_group_head_wgrad (dz_frag[L-1] is its operand).
+   * reduces the last layer's bias gradient per group (db[L-1]: [n_groups * dims[L]]; its workspace holds n_groups more
+   * partial rows for that layer) and leaves the last layer's weight gradient to rg_group_head_wgrad; dz_frag[L-1], its
+   * operand, is a fragment matrix of rows + 32 * n_groups rows: group g's 32-row blocks are written g blocks late, a
+   * block two groups share once per group with the other group's rows zeroed.
    * ABI 8: also for split-bf16 stacks (x3): per group [hi plane | lo plane], the strides cover both. */
   const int32_t* tile_key;
-  const int32_t* tile_begin;
+  const int32_t* row_begin;
   int32_t n_groups;
   int32_t out_scatter;
   int64_t group_stride_fwd, group_stride_bwd;
@@ -548,10 +552,11 @@ int rg_dueling_split(const float* dq, int64_t lddq, int batch, int num_actions, 
 
 /* ---- QR-DQN with a grouped output layer (qr_grouped.hip; reagent/training/qrdqn_trainer.py:108-160) ---------
  * The [A * N, H] output layer is treated as A layers [N, H] ("groups"); the batch rows are sorted by the action
- * whose quantiles are needed and each action's rows padded to whole 128-row tiles — "grouped space", described by
- *   rowmap     [128 * n_tiles] int32 : batch row of each grouped row, -1 for padding
- *   tile_key   [n_tiles] int32       : group of each tile, -1 for an empty tail tile
- *   tile_begin [n_groups + 1] int32  : first tile of each group
+ * whose quantiles are needed — "grouped space", dense (ABI 9: no padding between the groups, ceil(batch / 128) tiles) or with
+ * each action's rows padded to whole 128-row tiles (rounds 2-3), described by
+ *   rowmap    [128 * n_tiles] int32 : batch row of each grouped row, -1 for padding
+ *   tile_key  [n_tiles] int32       : first group with rows in each tile, -1 for none
+ *   row_begin [n_groups + 1] int32  : first grouped row of each group ([n_groups] = end of the last group's range)
  * all built on the device.  Forward and input gradient of the grouped layer run inside the fused stack kernels
  * (rg_mlp_desc.rowmap / tile_key); h_frag below is the saved input of the stack's last layer (act_frag[L-1]) and
  * dz_frag the dz_frag[L-1] that backward wrote.
@@ -562,16 +567,17 @@ int rg_dueling_split(const float* dq, int64_t lddq, int batch, int num_actions, 
  * rg_qr_select_action    : key[b] = arg max_a (q[b,a] - 1e9 (1 - mask[b,a])) (maxq != 0, :210-214) or the position of
  *                          the 1 in mask[b,:] (SARSA, mask = next_action), num_actions for an all-zero row.
  * rg_qr_compact_head     : quantile-Huber loss (:143-160, :217-218) of z [grouped rows] against
- *                          T = reward (+ boost of the group's action) + gamma^e * not_terminal * zt[rowmap[r], :];
+ *                          T = reward (+ boost of action row_key[rowmap[r]], ABI 9) + gamma^e * not_terminal * zt[rowmap[r], :];
  *                          dz [padded_rows, lddz] (padding rows and columns zero), loss_partials [padded_rows];
  *                          tile_losses (nullable) [padded_rows / 128] = their sums per 128-row tile.  num_atoms <= 256.
  *                          O(N log N) per row (sorted targets + prefix sums), not the N x N pair loop.
  * rg_group_head_wgrad    : dw [n_groups * group_rows, in] = per group dz^T h over the group's rows. */
 /* rg_group_rows: the grouped space of `key` [batch] int32 in [0, n_groups] (n_groups = "no group": dropped) — a
- * stable counting sort (rows keep batch order inside a group), n_tiles >= ceil(batch / 128) + n_groups. */
+ * stable counting sort (rows keep batch order inside a group).  dense != 0 (ABI 9): the groups follow each other without
+ * padding, n_tiles >= ceil(batch / 128); dense == 0: every group starts on a tile, n_tiles >= ceil(batch / 128) + n_groups. */
 size_t rg_group_rows_workspace_bytes(int batch, int n_groups);
-int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int32_t* rowmap, int32_t* tile_key,
-                  int32_t* tile_begin, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int dense, int32_t* rowmap, int32_t* tile_key,
+                  int32_t* row_begin, void* workspace, size_t workspace_bytes, rg_stream_t stream);
 size_t rg_group_wfrag_elems(int group_rows, int in_features, int transposed);
 /* ABI 8: x3 != 0 = split-bf16 — a group's fragment set is [hi plane | lo plane] (lo = bf16(w - hi)), 2 *
  * rg_group_wfrag_elems(...) elements per group; rg_mlp_desc.group_stride_* then counts both planes. */
@@ -590,17 +596,19 @@ int rg_qr_select_action(const float* q, int64_t ldq, const float* mask, int batc
  * evaluated by the counting launch and written to `key`): two launches instead of four for the grouped space of a*
  * (qrdqn_trainer.py:210-214) or of the logged action */
 int rg_qr_select_group_rows(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
-                            int32_t* key, int n_tiles, int32_t* rowmap, int32_t* tile_key, int32_t* tile_begin,
+                            int32_t* key, int n_tiles, int dense, int32_t* rowmap, int32_t* tile_key, int32_t* row_begin,
                             void* workspace, size_t workspace_bytes, rg_stream_t stream);
 int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldzt, const int32_t* rowmap,
-                       const int32_t* tile_key, int padded_rows, const float* reward, const float* reward_boosts,
+                       const int32_t* row_key, int padded_rows, const float* reward, const float* reward_boosts,
                        const float* not_terminal, double gamma, const float* gamma_exponent,
                        const float* quantiles, int batch, int num_atoms, float* dz, int64_t lddz,
                        float* loss_partials, float* tile_losses, rg_stream_t stream);
 size_t rg_group_head_wgrad_workspace_bytes(int n_groups, int group_rows, int in_features, int splits);
 /* ABI 8: x3 != 0 = split-bf16 operands, each [hi plane | lo plane] over `rows` (the grouped space's row count: the lo
- * planes start rg_frag_elems(rows, group_rows) / rg_frag_elems(rows, in_features) elements in), three MFMAs per product */
-int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* tile_begin, int n_groups,
+ * planes start rg_frag_elems(rows + 32 * n_groups, group_rows) / rg_frag_elems(rows, in_features) elements in), three MFMAs
+ * per product.  ABI 9: group g reads the blocks [row_begin[g] / 32, ceil(row_begin[g + 1] / 32)) of h_frag and the same
+ * blocks + g of dz_frag (rg_mlp_desc: how the backward launch writes them) */
+int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* row_begin, int n_groups,
                         int group_rows, int in_features, int splits, int x3, int rows, float* dw, void* workspace,
                         size_t workspace_bytes, rg_stream_t stream);
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RG_LIB: another build of the same library (same-box A/B of compile-time kernel variants); default = the in-tree build
 LIB_PATH = os.environ.get("RG_LIB") or os.path.join(_HERE, "lib", "libreagent_hip.so")
 
-ABI_VERSION = 8  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
+ABI_VERSION = 9  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5}
@@ -83,7 +83,7 @@ class MlpDesc(ctypes.Structure):
         ("reserved2", ctypes.c_int32),
         ("rowmap", c_void_p),
         ("tile_key", c_void_p),
-        ("tile_begin", c_void_p),
+        ("row_begin", c_void_p),
         ("n_groups", ctypes.c_int32),
         ("out_scatter", ctypes.c_int32),
         ("group_stride_fwd", ctypes.c_int64),
@@ -246,13 +246,13 @@ SIGNATURES = {
     "rg_dueling_combine": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "rg_dueling_split": (c_int, [c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     "rg_group_rows_workspace_bytes": (c_sz, [c_int, c_int]),
-    "rg_group_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
+    "rg_group_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
     "rg_group_wfrag_elems": (c_sz, [c_int, c_int, c_int]),
     "rg_group_weights_stage": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_wide_head_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rg_wide_head_mean_staged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rg_qr_select_action": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "rg_qr_select_group_rows": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
+    "rg_qr_select_group_rows": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_sz, c_void_p]),
     "rg_qr_compact_head": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_d, c_void_p, c_void_p, c_int, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "rg_group_head_wgrad_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),

@@ -26,15 +26,6 @@
 // instead of 84) 143-144, 384 in all 157, 512 in all 165; the tiles that share an operand half walking their split's
 // blocks 2 / 4 / 8 blocks apart (so that the second reader finds the line in L2 instead of joining the in-flight miss)
 // 143-145 / 162-164 / 172-173: the lockstep second reader is the cheap one.  Not kept.
-// Grouped output layer (QR-DQN C3: 7 column tiles of one action's slice): 0 = 32x32 tiles spread over the waves
-// (tile_kloop), R > 0 = wave w runs the hidden layers' main loop on column tile w (4 row tiles, every weight fragment
-// read once per workgroup) with a ring of R chunks.  Round 3, same box, C3 step on one stream / two streams (ms):
-// 0: 1.101 / 1.034; 8: 1.119 / 1.054; 16: 1.121 / 1.052 — the deep-ring main loop is no faster (the round-2 result
-// with the ring of 2), its burst of output stores at the end costs more than the re-read fragments.  Ablations of the
-// 189 us target forward: head MFMAs removed -43 us, output stores removed -20..-28 us.
-#ifndef RG_GROUPED_RING
-#define RG_GROUPED_RING 0
-#endif
 #ifndef RG_OUT_LDS
 #define RG_OUT_LDS 1  // a thin output layer's weight fragments resident in LDS (tile_kloop_ldsb)
 #endif
@@ -155,85 +146,83 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
       const int NTo = (N + 31) / 32;
       const int out_act = a.acts[l];
       const bool stream_out = N > 64;
-      // grouped output layer: this tile's group selects the weight / bias slice (an empty tile has no output)
-      const int grp = GROUPED ? a.tile_key[tile] : 0;
-      const bf16_t* wf_out = a.wfrag[l] + (GROUPED ? (long)(grp < 0 ? 0 : grp) * a.group_stride : 0);
-      const float* b_out = a.bias[l] ? a.bias[l] + (GROUPED ? (long)(grp < 0 ? 0 : grp) * N : 0) : nullptr;
-      // the bias of column tile 0, requested BEFORE the K loop: loaded at the point of use it put one more L2 round trip
-      // (~2000 cycles) at the very end of every workgroup whose output is one column tile (16 Q-values, a critic's scalar)
-      const float b_tile0 = (b_out && lr < N) ? b_out[lr] : 0.f;
-      auto store_tile = [&](const f32x16& acc, int tm, int nt) {
-        const int col = nt * 32 + lr;
-        if (col < N) {
-          const float b = nt == 0 ? b_tile0 : (b_out ? b_out[col] : 0.f);
+      // grouped output layer: the rows of the tile are cut into segments, one per group (rg_mlp_frag.h: next_segment; a
+      // tile inside one group's range is one segment), and each segment's group selects the weight / bias slice; rows that
+      // belong to no group have no output.  The plain layer is the one segment [0, 128) of "group 0".
+      int seg_g = GROUPED ? a.tile_key[tile] : 0;
+      RowSegment seg{0, 0, FB_BM};
+      // (grouped: the lane-derived addresses of the segment loop are worked out HERE — hoisted out of that loop and above the
+      // hidden layers' main loops they cost the 512-wide kernel 30 spilled registers)
+      const int o_lane = GROUPED ? opaque(lane) : lane, o_tid = GROUPED ? opaque(tid) : tid;
+      while (!GROUPED || next_segment(a.row_begin, a.n_groups, row_base, FB_BM, seg_g, seg)) {
+        const int lane = o_lane, tid = o_tid, lr = lane & 31, lg = lane >> 5;
+        const int grp = seg.grp;
+        const bf16_t* wf_out = a.wfrag[l] + (GROUPED ? (long)grp * a.group_stride : 0);
+        const float* b_out = a.bias[l] ? a.bias[l] + (GROUPED ? (long)grp * N : 0) : nullptr;
+        const int tm0 = GROUPED ? seg.lo >> 5 : 0, tm1 = GROUPED ? (seg.hi + 31) >> 5 : 4;  // the segment's 32-row tiles
+        // the bias of column tile 0, requested BEFORE the K loop: loaded at the point of use it put one more L2 round trip
+        // (~2000 cycles) at the very end of every workgroup whose output is one column tile (16 Q-values, a critic's scalar)
+        const float b_tile0 = (b_out && lr < N) ? b_out[lr] : 0.f;
+        auto store_tile = [&](const f32x16& acc, int tm, int nt) {
+          const int col = nt * 32 + lr;
+          if (col < N) {
+            const float b = nt == 0 ? b_tile0 : (b_out ? b_out[col] : 0.f);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-            if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
-            if (row >= 0 && (a.out_scatter || row < a.batch)) {
-              const float o = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
-              // a wide output (QR-DQN's 200 quantiles per row: 54 MB per launch, read once by the loss head) streams
-              // past the caches (same-box C3 step -1 %); a thin one is a few MB and its reader is next
-              if (stream_out) stream_store(o, a.out32 + (long)row * a.ldo + col);
-              else a.out32[(long)row * a.ldo + col] = o;
+            for (int r = 0; r < 16; ++r) {
+              const int rel = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              if (GROUPED && (rel < seg.lo || rel >= seg.hi)) continue;  // another segment's row
+              int row = row_base + rel;
+              if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
+              if (row >= 0 && (a.out_scatter || row < a.batch)) {
+                const float o = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+                // a wide output (QR-DQN's 200 quantiles per row: 54 MB per launch, read once by the loss head) streams
+                // past the caches (same-box C3 step -1 %); a thin one is a few MB and its reader is next
+                if (stream_out) stream_store(o, a.out32 + (long)row * a.ldo + col);
+                else a.out32[(long)row * a.ldo + col] = o;
+              }
             }
           }
-        }
-      };
-      // (A pipelined variant for 4..8 output column tiles — wave w running wide_mainloop<1> on column tile w — was
-      // measured on the C3 grouped forward: 171 us against 169 us for this loop, no gain.)
-      if (!GROUPED && NTo == 1 && NW == 8 && KC >= 8) {
-        // one column tile (<= 32 outputs, e.g. 16 Q-values): four 32x32 tiles for eight waves.  The loop is a chain
-        // of L2 round trips (7 % of a workgroup's life with four waves idle), so two waves share a tile, each
-        // summing half of K; the upper four hand their accumulators over through the activation tile, dead by then.
-        const int tm = wave & 3, half = wave >> 2, kc_mid = (KC / 2 + 3) / 4 * 4;
-        f32x16 acc = out_lds ? tile_kloop_ldsb(act, pitch, wo, tm, lane, half ? kc_mid : 0, half ? KC : kc_mid)
-                             : tile_kloop(act, pitch, KC, wf_out, tm, 0, lane, half ? kc_mid : 0, half ? KC : kc_mid);
-        RG_STAMP(16);
-        __syncthreads();  // every wave is done reading the layer input
-        RG_STAMP(17);
-        float* hand = (float*)act + (tm * 64 + lane) * 16;
-        if (half) {
+        };
+        // (A pipelined variant for 4..8 output column tiles — wave w running wide_mainloop<1> on column tile w, for all four
+        // row tiles with a ring of 8 / 16 chunks — was measured on the C3 grouped forward in rounds 2 and 3: 171 us against
+        // 169 us for this loop, C3 step 1.119 / 1.121 against 1.101 ms; its burst of output stores at the end costs more than
+        // the re-read fragments.  Ablations of the 189 us target forward: head MFMAs removed -43 us, output stores -20..-28.)
+        if (!GROUPED && NTo == 1 && NW == 8 && KC >= 8) {
+          // one column tile (<= 32 outputs, e.g. 16 Q-values): four 32x32 tiles for eight waves.  The loop is a chain
+          // of L2 round trips (7 % of a workgroup's life with four waves idle), so two waves share a tile, each
+          // summing half of K; the upper four hand their accumulators over through the activation tile, dead by then.
+          const int tm = wave & 3, half = wave >> 2, kc_mid = (KC / 2 + 3) / 4 * 4;
+          f32x16 acc = out_lds ? tile_kloop_ldsb(act, pitch, wo, tm, lane, half ? kc_mid : 0, half ? KC : kc_mid)
+                               : tile_kloop(act, pitch, KC, wf_out, tm, 0, lane, half ? kc_mid : 0, half ? KC : kc_mid);
+          RG_STAMP(16);
+          __syncthreads();  // every wave is done reading the layer input
+          RG_STAMP(17);
+          float* hand = (float*)act + (tm * 64 + lane) * 16;
+          if (half) {
 #pragma unroll
-          for (int r = 0; r < 16; r += 4) *(f32x4*)(hand + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
-        }
-        __syncthreads();
-        RG_STAMP(18);
-        if (!half) {
-#pragma unroll
-          for (int r = 0; r < 16; r += 4) {
-            const f32x4 o = *(const f32x4*)(hand + r);
-            acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
+            for (int r = 0; r < 16; r += 4) *(f32x4*)(hand + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
           }
-          RG_STAMP(19);
-          store_tile(acc, tm, 0);
-        }
-      } else if (GROUPED && RG_GROUPED_RING && NTo <= NW && KC % RG_GROUPED_RING == 0 && KC > RG_GROUPED_RING) {
-        // experiment (RG_GROUPED_RING > 0, see the macro): wave w takes column tile w for all four row tiles through the
-        // main loop of the hidden layers
-        if (wave < NTo && grp >= 0) {
-          f32x16 acc1[4][1];
+          __syncthreads();
+          RG_STAMP(18);
+          if (!half) {
 #pragma unroll
-          for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[tm][0][r] = 0.f;
-          const long nts = (long)KC * 512;
-          wide_mainloop<1, (RG_GROUPED_RING ? RG_GROUPED_RING : 2)>(act, pitch, KC, wf_out + (long)wave * nts, nts, acc1, lane,
-                                            k_rotation(blockIdx.x, wave, KC), 0);
-#pragma unroll
-          for (int tm = 0; tm < 4; ++tm) store_tile(acc1[tm][0], tm, wave);
-        }
-      } else if (GROUPED && RG_GROUPED_STAGE_OUT && NTo <= NW && a.stage_out) {
-        // Grouped output layer, wide (QR-DQN: 200 quantiles per row).  Stored straight from the accumulators a wave
-        // instruction writes two 128-byte row segments that start 32 * row bytes off a cache line (rows are 800 bytes):
-        // partial lines, 54 MB of them per launch (-20..-28 us with the stores removed).  Here the output leaves as
-        // whole rows, 16 bytes per lane: one 32-row tile at a time (wave w computes its column tile w) through a staging
-        // area BEHIND the activation tile (32 x (32 NTo + 4) floats, 29 KB of the 30 KB the tile leaves of the CU's LDS).
-        if (grp >= 0) {  // workgroup-uniform: an empty tile has no output and skips the barriers together
+            for (int r = 0; r < 16; r += 4) {
+              const f32x4 o = *(const f32x4*)(hand + r);
+              acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
+            }
+            RG_STAMP(19);
+            store_tile(acc, tm, 0);
+          }
+        } else if (GROUPED && RG_GROUPED_STAGE_OUT && NTo <= NW && a.stage_out) {
+          // Grouped output layer, wide (QR-DQN: 200 quantiles per row).  Stored straight from the accumulators a wave
+          // instruction writes two 128-byte row segments that start 32 * row bytes off a cache line (rows are 800 bytes):
+          // partial lines, 54 MB of them per launch (-20..-28 us with the stores removed).  Here the output leaves as
+          // whole rows, 16 bytes per lane: one 32-row tile at a time (wave w computes its column tile w) through a staging
+          // area BEHIND the activation tile (32 x (32 NTo + 4) floats, 29 KB of the 30 KB the tile leaves of the CU's LDS).
           float* stage = (float*)(act + FB_BM * pitch);
           const int P = NTo * 32 + 4;  // floats per staged row
           const int np = N >> 2;       // 16-byte pieces per row
-          for (int tm = 0; tm < 4; ++tm) {
+          for (int tm = tm0; tm < tm1; ++tm) {
             if (wave < NTo) {
               const f32x16 acc = tile_kloop(act, pitch, KC, wf_out, tm, wave, lane);
               const int col = wave * 32 + lr;
@@ -245,19 +234,23 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
             __syncthreads();
             for (int it = tid; it < 32 * np; it += THREADS) {
               const int r = it / np, c4 = it - r * np;
-              int row = row_base + tm * 32 + r;
+              const int rel = tm * 32 + r;
+              if (rel < seg.lo || rel >= seg.hi) continue;  // another segment's row
+              int row = row_base + rel;
               if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
               if (row >= 0 && (a.out_scatter || row < a.batch))
                 stream_store(*(const f32x4*)(stage + r * P + c4 * 4), (f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4));
             }
             __syncthreads();
           }
+        } else {
+          for (int t = wave; t < 4 * NTo; t += NW) {
+            const int tm = t & 3, nt = t >> 2;
+            if (tm < tm0 || tm >= tm1) continue;
+            store_tile(tile_kloop(act, pitch, KC, wf_out, tm, nt, lane), tm, nt);
+          }
         }
-      } else {
-        for (int t = wave; t < 4 * NTo && grp >= 0; t += NW) {
-          const int tm = t & 3, nt = t >> 2;
-          store_tile(tile_kloop(act, pitch, KC, wf_out, tm, nt, lane), tm, nt);
-        }
+        if (!GROUPED) break;
       }
       RG_STAMP(2 + 4 * l);
     }
@@ -280,14 +273,20 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_swap_kernel(MlpArgs a) {  /
 #endif
 
 // DX_ONLY: a frozen stack — only the input gradient is produced, no dZ fragments are written (rg_mlp_desc.dx_only)
-template <int TN, int NW, int PITCH, bool DX_ONLY>
+// GROUPED: the stack's output layer takes per-group weights (rg_mlp_desc.tile_key / row_begin): its own instantiation, the
+// plain kernel does not carry the segment walk.  The grouped layer's step — dH = dZ . W_g per row's group — runs once per
+// segment of the tile on a copy of the dZ tile with the other segments' rows zeroed (they add nothing to the shared
+// accumulators); that copy is also what leaves as the segment's dZ fragments (group g's blocks g blocks late: fill_args /
+// grouped_dz_rows) and what the segment's bias-gradient partial sums (row tile + g of db_part).  A tile that lies inside one
+// group's range is one segment and uses the tile itself.
+template <int TN, int NW, int PITCH, bool DX_ONLY, bool GROUPED = false>
 __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
   constexpr int THREADS = MlpCfg<NW>::THREADS, RING = MlpCfg<NW>::RING;
   RG_DYN_LDS(smem);
   bf16_t* act = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
-  const int tile = a.tile_key ? grouped_tile(blockIdx.x, (a.batch + FB_BM - 1) / FB_BM) : (int)blockIdx.x;
+  const int tile = GROUPED ? grouped_tile(blockIdx.x, (a.batch + FB_BM - 1) / FB_BM) : (int)blockIdx.x;
   if (tile * FB_BM >= round_up(a.batch, FB_BM)) return;  // padding blocks of a grouped launch (workgroup-uniform)
   const int row_base = tile * FB_BM;
   constexpr int pitch = PITCH;
@@ -295,11 +294,13 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
   const int nop = round_up(a.dims[L], 32);
   load_tile_to_lds<float, THREADS>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  if (!DX_ONLY) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], tile * 4, wave, NW, lane);
-  if (a.db_part[L - 1] && tid < a.dims[L]) {
-    float s = 0.f;
-    for (int r = 0; r < FB_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]);
-    a.db_part[L - 1][(long)tile * a.dims[L] + tid] = s;
+  if (!GROUPED) {
+    if (!DX_ONLY) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], tile * 4, wave, NW, lane);
+    if (a.db_part[L - 1] && tid < a.dims[L]) {
+      float s = 0.f;
+      for (int r = 0; r < FB_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]);
+      a.db_part[L - 1][(long)tile * a.dims[L] + tid] = s;
+    }
   }
 
   for (int l = L - 1; l >= 1; --l) {
@@ -329,13 +330,48 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
 #pragma unroll
       for (int i = 0; i < 2 * TN; ++i) sg[i] = 0u;
     }
-    const bf16_t* wl = a.wfrag[l];
-    if (l == L - 1 && a.tile_key) {  // grouped output layer: this tile's slice of W^T (an empty tile: dZ is zero)
-      const int grp = a.tile_key[tile];
-      wl += (long)(grp < 0 ? 0 : grp) * a.group_stride;
+    // The grouped layer's FIRST segment (the only one of a tile inside a group's range) goes through the main loop like a
+    // plain layer's tile — one call site, no loop around it (the software-pipelined loop inside a loop over segments spilled
+    // 390-460 registers in the 512-wide kernel, accumulator tiles among them) — any further segment through
+    // segment_accumulate.  What a segment contributes besides its products — its rows of dZ as fragments for the weight
+    // gradient, its bias-gradient partial — is read from the dZ tile with the row range as a mask; only the MFMA operand of a
+    // segment that is not the whole tile needs a copy with the other rows zeroed.
+    const bool grouped_layer = GROUPED && l == L - 1;
+    bf16_t* cp = act + masked_copy_offset<PITCH>(FB_BM * PITCH);
+    int seg_g = grouped_layer ? a.tile_key[tile] : 0;
+    RowSegment seg{0, 0, FB_BM};
+    bool more = grouped_layer ? next_segment(a.row_begin, a.n_groups, row_base, FB_BM, seg_g, seg) : true;
+    auto segment_side = [&]() -> const bf16_t* {  // -> the segment's MFMA operand
+      const bool whole = seg.lo == 0 && seg.hi == FB_BM;
+      if (!whole) {
+        copy_rows_masked<THREADS, FB_BM>(act, cp, pitch, nop, seg.lo, seg.hi, tid);
+        __syncthreads();
+      }
+      const bf16_t* src = whole ? act : cp;
+      emit_frags_from_lds(src, pitch, nop / 32, a.dz_frag[L - 1], tile * 4 + seg.grp, wave, NW, lane, seg.lo >> 5,
+                          (seg.hi + 31) >> 5);
+      if (a.db_part[L - 1] && tid < a.dims[L]) {
+        float s = 0.f;
+        for (int r = seg.lo; r < seg.hi; ++r) s += bf16_to_f32(act[r * pitch + tid]);
+        a.db_part[L - 1][(long)(tile + seg.grp) * a.dims[L] + tid] = s;
+      }
+      return src;
+    };
+    if (more) {
+      const bf16_t* src = act;
+      if (grouped_layer) src = segment_side();
+      const bf16_t* wl = a.wfrag[l] + (grouped_layer ? (long)seg.grp * a.group_stride : 0);  // the group's slice of W^T
+      wide_mainloop<TN, RING>(src, pitch, KC, wl + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
+                              k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
     }
-    wide_mainloop<TN, RING>(act, pitch, KC, wl + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
-                            k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+    if (grouped_layer) {
+      while (more && next_segment(a.row_begin, a.n_groups, row_base, FB_BM, seg_g, seg)) {  // a boundary tile's other groups
+        __syncthreads();  // every wave is done with the previous segment's copy
+        const bf16_t* src = segment_side();
+        segment_accumulate<4, TN>(src, pitch, KC, a.wfrag[l] + (long)seg.grp * a.group_stride + (long)(wave * TN) * nt_stride,
+                                  nt_stride, acc, lane);
+      }
+    }
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)tile * N : nullptr;
     unsigned PK[4][TN][8];
     if (use_sign) {
@@ -374,6 +410,10 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_fused_kernel(MlpArgs a) {
 template <int TN, int NW, int PITCH>
 __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_dx_kernel(MlpArgs a) {
   mlp_bwd_fused_body<TN, NW, PITCH, true>(a);
+}
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_grouped_kernel(MlpArgs a) {
+  mlp_bwd_fused_body<TN, NW, PITCH, false, true>(a);
 }
 
 // ---- weight gradient from fragment-ordered operands ------------------------------------------
@@ -754,13 +794,14 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_frag_kernel(WgradFragArgs g) {
 }
 
 // Weight gradient of a GROUPED layer (QR-DQN's A x N output layer seen as A independent [N, K] layers, one per
-// action; rows of the batch sorted by action and every action's rows padded to whole 128-row tiles,
-// qr_grouped.hip): group a owns the 32-row blocks [4 * tile_begin[a], 4 * tile_begin[a + 1]) of both operands; its
-// block range is cut into `splits` parts.  Workgroup = (group, k-group, split); partial slab index
-// group * splits + split.  The ranges live in HBM (they depend on the sampled batch): no host round trip.
+// action; rows of the batch sorted by action, qr_grouped.hip): group a owns the rows [row_begin[a], row_begin[a + 1]), i.e.
+// the 32-row blocks [row_begin[a] / 32, ceil(row_begin[a + 1] / 32)) of the activation fragments and the same blocks + a of
+// the dZ fragments (where the backward launch put group a's copy of each block, the other groups' rows zeroed:
+// grouped_dz_rows) — no row masks here.  The block range is cut into `splits` parts.  Workgroup = (group, k-group, split);
+// partial slab index group * splits + split.  The ranges live in HBM (they depend on the sampled batch): no host round trip.
 struct WgradGroupedArgs {
-  WgradFragArgs g;        // a_frag: dZ fragments (NTa tiles of 32 columns), b_frag: activation fragments; N = rows of a group's dW
-  const int* tile_begin;  // [n_groups + 1], in 128-row tiles
+  WgradFragArgs g;       // a_frag: dZ fragments (NTa tiles of 32 columns), b_frag: activation fragments; N = rows of a group's dW
+  const int* row_begin;  // [n_groups + 1], in rows of the grouped space
   int n_groups, splits;
 };
 
@@ -769,14 +810,17 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_grouped_kernel(WgradGroupedArgs G
   const int k_groups = (G.g.NTb + 7) / 8;
   const int bid = blockIdx.x;
   const int kg = bid % k_groups, s = (bid / k_groups) % G.splits, a = bid / (k_groups * G.splits);
-  const int mb0 = G.tile_begin[a] * 4, mb1 = G.tile_begin[a + 1] * 4;
+  const int r0 = G.row_begin[a], r1 = G.row_begin[a + 1];
+  const int mb0 = r0 >> 5, mb1 = r1 > r0 ? (r1 + 31) >> 5 : mb0;
   const int per = (mb1 - mb0 + G.splits - 1) / G.splits;
   int b0 = mb0 + s * per, b1 = b0 + per;
   if (b1 > mb1) b1 = mb1;
   if (b0 > mb1) b0 = mb1;
   float* part = G.g.partial + ((long)a * G.splits + s) * G.g.slab;
-  if (G.g.x3) wgrad_x3_shape_core<WgS8x8>(G.g, 0, kg, b0, b1, part, smem);  // split-bf16: both planes of dZ and of the activations
-  else wgrad_shape_core<WgS8x8>(G.g, 0, kg, b0, b1, part, smem);
+  WgradFragArgs g = G.g;
+  g.a_frag += (long)a * g.NTa * 1024;  // this group's dZ blocks sit `a` blocks late (one block = NTa tiles of 2 KB)
+  if (g.x3) wgrad_x3_shape_core<WgS8x8>(g, 0, kg, b0, b1, part, smem);  // split-bf16: both planes of dZ and of the activations
+  else wgrad_shape_core<WgS8x8>(g, 0, kg, b0, b1, part, smem);
 }
 
 // out[a * slab + e] = sum_s partial[(a * splits + s) * slab + e]
@@ -1300,7 +1344,7 @@ int rg_mlp_forward_fused(const rg_mlp_desc* d, const void* x, int x_dtype, int64
     for (int l = (save == 2 ? 1 : 0); l < d->n_layers; ++l)
       if (!d->act_frag[l]) return RG_EINVAL;  // (save = 2 writes it only where there is no usable sign plane)
   if (d->rowmap && (d->x2 || (d->x3 && !d->tile_key) || (batch % 128) != 0)) return RG_EUNSUPPORTED;
-  if (d->tile_key && (!d->rowmap || d->n_groups <= 0)) return RG_EINVAL;
+  if (d->tile_key && (!d->rowmap || !d->row_begin || d->n_groups <= 0)) return RG_EINVAL;
   if (d->x2 && (d->x_split <= 0 || d->x_split >= d->dims[0] || (d->x_split % 32) != 0)) return RG_EINVAL;
   a.x = x; a.ldx = ldx; a.x_is_f32 = (x_dtype == RG_DT_F32); a.out32 = out32; a.ldo = ldo; a.save = save;
   if (d->x3) return x3_forward_launch(d, a, (hipStream_t)stream);
@@ -1338,7 +1382,9 @@ size_t rg_mlp_backward_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   if (!d || batch <= 0) return 0;
   size_t cols = 0;
   for (int l = 0; l < d->n_layers; ++l) cols += (size_t)d->dims[l + 1];
-  return (size_t)padded_wgs(d, batch) * cols * sizeof(float);
+  // (a grouped output layer's partial rows are indexed workgroup + group: n_groups more rows of the LAST block)
+  const size_t extra = d->n_groups > 0 ? (size_t)d->n_groups * d->dims[d->n_layers] : 0;
+  return ((size_t)padded_wgs(d, batch) * cols + extra) * sizeof(float);
 }
 
 int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t lddo, int batch, float* dx32,
@@ -1358,6 +1404,7 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   }
   if (dx32 && !d->wfrag_bwd[0]) return RG_EINVAL;
   if (d->dx_only && (!dx32 || want_db || d->tile_key)) return RG_EINVAL;
+  if (d->tile_key && (!d->row_begin || d->n_groups <= 0 || d->dims[d->n_layers] > 256)) return RG_EINVAL;
   if (d->dx_col0 < 0 || d->dx_col0 >= d->dims[0] || (d->dx_col0 % 32) != 0) return RG_EINVAL;
   const int n_wg = padded_wgs(d, batch);
   if (want_db) {
@@ -1372,14 +1419,15 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   if (d->x3) {
     rc = x3_backward_launch(d, a, (hipStream_t)stream);
   } else {
-    const size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
+    size_t lds = (size_t)FB_BM * a.pitch * sizeof(bf16_t);
     const dim3 grid(d->tile_key ? (n_wg + 7) / 8 * 8 : n_wg);
+    if (d->tile_key && a.pitch < 2 * 256 + 8) lds *= 2;  // a boundary tile's masked dZ copy lives behind a 264-wide tile
     if (d->dx_only) RG_LAUNCH_FUSED(mlp_bwd_dx_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+    else if (d->tile_key) RG_LAUNCH_FUSED(mlp_bwd_grouped_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
     else RG_LAUNCH_FUSED(mlp_bwd_fused_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
     rc = (int)hipGetLastError();
   }
   if (rc) return rc;
-  if (d->tile_key && d->db[d->n_layers - 1] && !d->tile_begin) return RG_EINVAL;
   if (d->defer_db) {  // the partials stay in the workspace: rg_mlp_wgrad_fused (db_partials) sums them in its reduce launch
     if (d->tile_key || !want_db) return RG_EINVAL;
     return 0;
@@ -1390,9 +1438,9 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   int blocks = 0;
   for (int l = 0; l < d->n_layers; ++l) {
     if (!a.db_part[l]) continue;
-    if (d->tile_key && l == d->n_layers - 1) {  // grouped output layer: per-group sums over each group's tiles
-      // (a 128-row tile of the grouped space is one workgroup of the bf16 kernel, two of the split-bf16 kernel)
-      grouped_bias_reduce_launch(a.db_part[l], d->tile_begin, d->n_groups, d->dims[l + 1], d->db[l], d->x3 ? 128 / X3_BM : 1,
+    if (d->tile_key && l == d->n_layers - 1) {  // grouped output layer: per-group sums over each group's segments
+      // (a workgroup covers 128 rows of the grouped space in the bf16 kernel, 64 in the split-bf16 kernel)
+      grouped_bias_reduce_launch(a.db_part[l], d->row_begin, d->n_groups, d->dims[l + 1], d->db[l], d->x3 ? X3_BM : FB_BM,
                                  (hipStream_t)stream);
       continue;
     }
@@ -1489,11 +1537,11 @@ size_t rg_group_head_wgrad_workspace_bytes(int n_groups, int group_rows, int in_
 }
 
 /* dw [n_groups * group_rows, in_features] of a grouped layer (qr_grouped.hip): group g's rows are the 32-row blocks
- * [4 * tile_begin[g], 4 * tile_begin[g + 1]) of dz_frag (batch x group_rows, padded to 32 columns) and h_frag */
-int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* tile_begin, int n_groups, int group_rows,
+ * [row_begin[g] / 32, ceil(row_begin[g + 1] / 32)) of h_frag and the same blocks + g of dz_frag (wgrad_grouped_kernel) */
+int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* row_begin, int n_groups, int group_rows,
                         int in_features, int splits, int x3, int rows, float* dw, void* workspace, size_t workspace_bytes,
                         rg_stream_t stream) {
-  if (!dz_frag || !h_frag || !tile_begin || !dw || n_groups <= 0 || group_rows <= 0 || in_features <= 0 || splits <= 0 ||
+  if (!dz_frag || !h_frag || !row_begin || !dw || n_groups <= 0 || group_rows <= 0 || in_features <= 0 || splits <= 0 ||
       (x3 && rows <= 0))
     return RG_EINVAL;
   if (group_rows > 256) return RG_EUNSUPPORTED;  // one n-group of the 256 x 256 workgroup tile per action
@@ -1505,10 +1553,10 @@ int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* 
   G.g.partial = (float*)workspace; G.g.slab = (long)group_rows * in_features; G.g.N = group_rows; G.g.K = in_features;
   // split-bf16: each operand is [hi plane | lo plane] over the `rows` rows of the grouped space (rg_frag_elems apart)
   G.g.x3 = x3 ? 1 : 0;
-  G.g.a_lo = x3 ? (long)frag_elems(rows, group_rows) : 0;
+  G.g.a_lo = x3 ? (long)frag_elems(grouped_dz_rows(rows, n_groups), group_rows) : 0;
   G.g.b_lo = x3 ? (long)frag_elems(rows, in_features) : 0;
   G.g.shape = WG_SHAPE_8x8;
-  G.tile_begin = tile_begin; G.n_groups = n_groups; G.splits = splits;
+  G.row_begin = row_begin; G.n_groups = n_groups; G.splits = splits;
   const int k_groups = (G.g.NTb + 7) / 8;
   const size_t lds = (size_t)WgS8x8::LDS_BYTES;
   RG_ALLOW_LDS(wgrad_grouped_kernel, lds);

@@ -187,12 +187,13 @@ __device__ __forceinline__ void load_tile_split_mapped(bf16_t* act, int pitch, c
 }
 
 // LDS plane (64 rows x ntiles*32 cols) -> C-fragment order in global memory (two 32-row blocks per workgroup)
+// (only the blocks [mbl0, mbl1) of the plane; block mbl goes to fragment block mb_base + mbl)
 __device__ __forceinline__ void emit_frags_x3(const bf16_t* plane, int pitch, int ntiles, bf16_t* dst, int mb_base,
-                                              int wave, int n_waves, int lane) {
+                                              int wave, int n_waves, int lane, int mbl0 = 0, int mbl1 = X3_TM) {
   const int lr = lane & 31, lg = lane >> 5;
-  const int total = X3_TM * ntiles * 2;
+  const int total = (mbl1 - mbl0) * ntiles * 2;
   for (int f = wave; f < total; f += n_waves) {
-    const int h = f & 1, nt = (f >> 1) % ntiles, mbl = (f >> 1) / ntiles;
+    const int h = f & 1, nt = (f >> 1) % ntiles, mbl = mbl0 + (f >> 1) / ntiles;
     u16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = plane[(mbl * 32 + frag_row(h, e, lg)) * pitch + nt * 32 + lr];
@@ -290,6 +291,35 @@ __device__ __forceinline__ void x3_mainloop(const bf16_t* act, int pitch, int KC
         sched_fence();
       }
     }
+  }
+}
+
+// acc += A . B (three MFMAs per fragment pair) for one MORE segment of a boundary unit of a grouped layer — see
+// segment_accumulate (rg_mlp_frag.h): a plain loop, one chunk at a time, kept small on purpose
+template <int TN, int LO>
+__device__ __forceinline__ void x3_segment_accumulate(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave, long wlo,
+                                                      long nt_stride, f32x16 (&acc)[X3_TM][TN], int lane) {
+  const bf16_t* arow = act + (lane & 31) * pitch + (lane >> 5) * 8;
+  for (int kc = 0; kc < KC; ++kc) {
+    u16x8 ah[X3_TM], al[X3_TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      bh[tn] = *(const u16x8*)(wf_wave + (long)kc * 512 + tn * nt_stride + lane * 8);
+      bl[tn] = *(const u16x8*)(wf_wave + wlo + (long)kc * 512 + tn * nt_stride + lane * 8);
+    }
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm) {
+      ah[tm] = *(const u16x8*)(arow + tm * 32 * pitch + kc * 16);
+      al[tm] = *(const u16x8*)(arow + LO + tm * 32 * pitch + kc * 16);
+    }
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        acc[tm][tn] = mfma_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn]);
+        acc[tm][tn] = mfma_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn]);
+        acc[tm][tn] = mfma_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn]);
+      }
   }
 }
 
@@ -510,11 +540,14 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
       x3_store_packed_tiles<TN>(act + LO, pitch, PL, wave, lane);
       __syncthreads();
       RG_STAMP(5 + 4 * l);
-    } else if (GROUPED) {  // grouped output layer: this tile's group selects the weight / bias slice
+    } else if (GROUPED) {  // grouped output layer: once per segment of the unit's rows, that group's weight / bias slice
       const int NTo = (N + 31) / 32;
       const int out_act = a.acts[l];
-      const int grp = a.tile_key[unit >> 1];
-      if (grp >= 0) {  // (workgroup-uniform: an empty tile has no output and skips the barriers together)
+      int seg_g = a.tile_key[unit >> 1];
+      RowSegment seg;
+      while (next_segment(a.row_begin, a.n_groups, row_base, X3_BM, seg_g, seg)) {  // (workgroup-uniform)
+        const int grp = seg.grp;
+        const int tm0 = seg.lo >> 5, tm1 = (seg.hi + 31) >> 5;  // the segment's 32-row tiles
         const bf16_t* wf_out = a.wfrag[l] + (long)grp * a.group_stride;
         const float* b_out = a.bias[l] ? a.bias[l] + (long)grp * N : nullptr;
         if (a.stage_out && NTo <= NW) {
@@ -525,7 +558,7 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
           float* stage = (float*)(act + 2 * LO);
           const int P = NTo * 32 + 4;  // floats per staged row
           const int np = N >> 2;       // 16-byte pieces per row
-          for (int tm = 0; tm < X3_TM; ++tm) {
+          for (int tm = tm0; tm < tm1; ++tm) {
             if (wave < NTo) {
               const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, wf_out, a.wfrag_lo[l], tm, wave, lane);
               const int col = wave * 32 + lr;
@@ -537,7 +570,9 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
             __syncthreads();
             for (int it = tid; it < 32 * np; it += THREADS) {
               const int r = it / np, c4 = it - r * np;
-              int row = row_base + tm * 32 + r;
+              const int rel = tm * 32 + r;
+              if (rel < seg.lo || rel >= seg.hi) continue;  // another segment's row
+              int row = row_base + rel;
               if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
               if (row >= 0 && (a.out_scatter || row < a.batch))
                 stream_store(*(const f32x4*)(stage + r * P + c4 * 4), (f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4));
@@ -547,13 +582,16 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
         } else {
           for (int t = wave; t < X3_TM * NTo; t += NW) {
             const int tm = t % X3_TM, nt = t / X3_TM;
+            if (tm < tm0 || tm >= tm1) continue;
             const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, wf_out, a.wfrag_lo[l], tm, nt, lane);
             const int col = nt * 32 + lr;
             if (col < N) {
               const float b = b_out ? b_out[col] : 0.f;
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                const int rel = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+                if (rel < seg.lo || rel >= seg.hi) continue;  // another segment's row
+                int row = row_base + rel;
                 if (a.out_scatter) row = a.rowmap[row];
                 if (row >= 0 && (a.out_scatter || row < a.batch))
                   a.out32[(long)row * a.ldo + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
@@ -622,7 +660,9 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_fwd_x3_grouped_kernel(MlpArgs a
   mlp_fwd_x3_body<TN, NW, PITCH, true>(a);
 }
 
-template <int TN, int NW, int PITCH, bool DX_ONLY>
+// GROUPED: see mlp_bwd_fused_body (mlp_fused.hip) — the grouped layer's step once per segment of the unit's 64 rows, on
+// masked copies of both dZ planes
+template <int TN, int NW, int PITCH, bool DX_ONLY, bool GROUPED = false>
 __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
   constexpr int THREADS = NW * 64, RING = RG_X3_RING, LO = X3_BM * PITCH;
   RG_DYN_LDS(smem);
@@ -631,7 +671,7 @@ __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
   const int lr = lane & 31, lg = lane >> 5;
   // grouped launch (rg_mlp_desc.tile_key): 64-row units of the group-sorted row space, shared out to the XCDs in eighths
   const int n_units = round_up(a.batch, 128) / X3_BM;
-  const int unit = a.tile_key ? grouped_tile(blockIdx.x, n_units) : (int)blockIdx.x;
+  const int unit = GROUPED ? grouped_tile(blockIdx.x, n_units) : (int)blockIdx.x;
   if (unit >= n_units) return;  // padding blocks of a grouped launch (workgroup-uniform)
   const int row_base = unit * X3_BM;
   constexpr int pitch = PITCH;
@@ -639,14 +679,16 @@ __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
   const int nop = round_up(a.dims[L], 32);
   load_tile_split<float, THREADS, LO>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
-  if (!DX_ONLY) {
-    emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], unit * X3_TM, wave, NW, lane);
-    emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], unit * X3_TM, wave, NW, lane);
-  }
-  if (a.db_part[L - 1] && tid < a.dims[L]) {
-    float s = 0.f;
-    for (int r = 0; r < X3_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]) + bf16_to_f32(act[LO + r * pitch + tid]);
-    a.db_part[L - 1][(long)unit * a.dims[L] + tid] = s;
+  if (!GROUPED) {
+    if (!DX_ONLY) {
+      emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], unit * X3_TM, wave, NW, lane);
+      emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], unit * X3_TM, wave, NW, lane);
+    }
+    if (a.db_part[L - 1] && tid < a.dims[L]) {
+      float s = 0.f;
+      for (int r = 0; r < X3_BM; ++r) s += bf16_to_f32(act[r * pitch + tid]) + bf16_to_f32(act[LO + r * pitch + tid]);
+      a.db_part[L - 1][(long)unit * a.dims[L] + tid] = s;
+    }
   }
 
   for (int l = L - 1; l >= 1; --l) {
@@ -665,13 +707,47 @@ __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
     const bool use_sign = a.act_sign[l] != nullptr;
 #pragma unroll
     for (int i = 0; i < TN; ++i) sg[i] = use_sign ? a.act_sign[l][x3_sign_offset(unit, wave, lane, TN, N) + i] : 0u;
-    const bf16_t* wl = a.wfrag[l];
-    if (l == L - 1 && a.tile_key) {  // grouped output layer: this tile's slice of W^T (an empty tile: dZ is zero)
-      const int grp = a.tile_key[unit >> 1];
-      wl += (long)(grp < 0 ? 0 : grp) * a.group_stride;
+    // the grouped layer's first segment through the main loop like a plain layer's unit, further segments of a boundary unit
+    // through x3_segment_accumulate (mlp_bwd_fused_body has the reasons)
+    const bool grouped_layer = GROUPED && l == L - 1;
+    bf16_t* cp = act + masked_copy_offset<PITCH>(2 * LO);  // [hi copy | lo copy], LO apart like the planes
+    int seg_g = grouped_layer ? a.tile_key[unit >> 1] : 0;
+    RowSegment seg{0, 0, X3_BM};
+    bool more = grouped_layer ? next_segment(a.row_begin, a.n_groups, row_base, X3_BM, seg_g, seg) : true;
+    auto segment_side = [&]() -> const bf16_t* {  // -> the segment's MFMA operand (hi plane; lo plane LO behind it)
+      const bool whole = seg.lo == 0 && seg.hi == X3_BM;
+      if (!whole) {
+        copy_rows_masked<THREADS, X3_BM>(act, cp, pitch, nop, seg.lo, seg.hi, tid);
+        copy_rows_masked<THREADS, X3_BM>(act + LO, cp + LO, pitch, nop, seg.lo, seg.hi, tid);
+        __syncthreads();
+      }
+      const bf16_t* src = whole ? act : cp;
+      emit_frags_x3(src, pitch, nop / 32, a.dz_frag[L - 1], unit * X3_TM + seg.grp, wave, NW, lane, seg.lo >> 5,
+                    (seg.hi + 31) >> 5);
+      emit_frags_x3(src + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], unit * X3_TM + seg.grp, wave, NW, lane,
+                    seg.lo >> 5, (seg.hi + 31) >> 5);
+      if (a.db_part[L - 1] && tid < a.dims[L]) {
+        float s = 0.f;
+        for (int r = seg.lo; r < seg.hi; ++r) s += bf16_to_f32(act[r * pitch + tid]) + bf16_to_f32(act[LO + r * pitch + tid]);
+        a.db_part[L - 1][(long)(unit + seg.grp) * a.dims[L] + tid] = s;
+      }
+      return src;
+    };
+    if (more) {
+      const bf16_t* src = act;
+      if (grouped_layer) src = segment_side();
+      const bf16_t* wl = a.wfrag[l] + (grouped_layer ? (long)seg.grp * a.group_stride : 0);  // the group's slice of W^T
+      x3_mainloop<TN, RING, LO>(src, pitch, KC, wl + (long)(wave * TN) * nt_stride, a.wfrag_lo[l], nt_stride, acc, lane,
+                                k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
     }
-    x3_mainloop<TN, RING, LO>(act, pitch, KC, wl + (long)(wave * TN) * nt_stride, a.wfrag_lo[l], nt_stride, acc, lane,
-                              k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+    if (grouped_layer) {
+      while (more && next_segment(a.row_begin, a.n_groups, row_base, X3_BM, seg_g, seg)) {  // a boundary unit's other groups
+        __syncthreads();  // every wave is done with the previous segment's copies
+        const bf16_t* src = segment_side();
+        x3_segment_accumulate<TN, LO>(src, pitch, KC, a.wfrag[l] + (long)seg.grp * a.group_stride + (long)(wave * TN) * nt_stride,
+                                      a.wfrag_lo[l], nt_stride, acc, lane);
+      }
+    }
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)unit * N : nullptr;
     unsigned PH[X3_TM][TN][8], PL[X3_TM][TN][8];
     if (use_sign) {
@@ -713,6 +789,10 @@ __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_kernel(MlpArgs a) {
 template <int TN, int NW, int PITCH>
 __global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_dx_kernel(MlpArgs a) {
   mlp_bwd_x3_body<TN, NW, PITCH, true>(a);
+}
+template <int TN, int NW, int PITCH>
+__global__ void RG_LAUNCH_BOUNDS(NW * 64, 1) mlp_bwd_x3_grouped_kernel(MlpArgs a) {
+  mlp_bwd_x3_body<TN, NW, PITCH, false, true>(a);
 }
 
 #define RG_LAUNCH_X3(KERNEL, hidden, pitch, grid, lds, stream, args)                                         \
@@ -759,10 +839,12 @@ int x3_forward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
 }
 
 int x3_backward_launch(const rg_mlp_desc* d, MlpArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
+  size_t lds = (size_t)2 * X3_BM * a.pitch * sizeof(bf16_t);
   const int n_wg = x3_grid(a.batch, true);
   const dim3 grid(d->tile_key ? (n_wg + 7) / 8 * 8 : n_wg);
+  if (d->tile_key && a.pitch < 2 * 256 + 8) lds *= 2;  // a boundary unit's masked dZ copies live behind 264-wide planes
   if (d->dx_only) RG_LAUNCH_X3(mlp_bwd_x3_dx_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
+  else if (d->tile_key) RG_LAUNCH_X3(mlp_bwd_x3_grouped_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   else RG_LAUNCH_X3(mlp_bwd_x3_kernel, d->dims[1], a.pitch, grid, lds, stream, a);
   return (int)hipGetLastError();
 }

@@ -10,12 +10,14 @@
 // and d loss / d logits is zero outside the logged action's N columns.  So:
 //   * mean_n(h . W[a, n] + b[a, n]) = h . mean_n W[a, n] + mean_n b[a, n]: the per-action means are ONE A-wide
 //     linear layer (rg_wide_head_mean builds its weights) — an ordinary narrow output layer of the fused stack;
-//   * the rows of the batch are sorted by the action whose quantiles are needed, every action's rows padded to
-//     whole 128-row tiles ("grouped space", built on the device — no host round trip), and the fused trunk runs
-//     in that row order (rg_mlp_desc.rowmap).  A tile then needs ONE action's [N, H] slice of the wide layer: it
-//     becomes the fused stack's OUTPUT layer with per-tile weights (rg_mlp_desc.tile_key: forward and input
-//     gradient inside rg_mlp_forward_fused / rg_mlp_backward_fused), its weight gradient is rg_group_head_wgrad —
-//     1/A of the dense work, [B, N] instead of [B, A * N] bytes.
+//   * the rows of the batch are sorted by the action whose quantiles are needed ("grouped space", built on the
+//     device — no host round trip), and the fused trunk runs in that row order (rg_mlp_desc.rowmap).  A run of rows
+//     then needs ONE action's [N, H] slice of the wide layer: it becomes the fused stack's OUTPUT layer with
+//     per-group weights (rg_mlp_desc.tile_key / row_begin: forward and input gradient inside rg_mlp_forward_fused /
+//     rg_mlp_backward_fused), its weight gradient is rg_group_head_wgrad — 1/A of the dense work, [B, N] instead of
+//     [B, A * N] bytes.  Rounds 2-3 padded every action's rows to whole 128-row tiles (B / 128 + ~A / 2 tiles: 520 for
+//     C3 — two rounds of the 256 CUs plus a sliver, i.e. THREE rounds per launch); round 4 packs the groups densely
+//     (B / 128 tiles exactly) and a tile that holds rows of several groups runs the layer once per group (next_segment).
 // The quantile-Huber loss itself (rg_qr_compact_head) runs on those compact rows — in O(N log N) per row, see there.
 #include "rg_mlp_frag.h"
 
@@ -114,11 +116,12 @@ __global__ void select_action_kernel(const float* __restrict__ q, long ldq, cons
   key[b] = select_action_row(q, ldq, mask, b, A, maxq);
 }
 
-// ---- the grouped row space: a stable counting sort by key, padded per group to whole 128-row tiles -------------
-// rowmap [128 * n_tiles]: batch row of every grouped row (-1: padding); tile_key [n_tiles]: group of each tile (-1:
-// empty tail tile); tile_begin [G + 1].  Keys >= G mean "no group": dropped.  Rows keep their batch order inside a
-// group (rank = rows of the same key in earlier 256-row blocks + earlier rows of the own block), so the layout —
-// and every sum taken over it — is deterministic.  Two launches, no host round trip.
+// ---- the grouped row space: a stable counting sort by key ------------------------------------------------------
+// rowmap [128 * n_tiles]: batch row of every grouped row (-1: padding); row_begin [G + 1]: group g owns the grouped rows
+// [row_begin[g], row_begin[g + 1]) — its valid rows first, then (dense == 0 only) padding to the next multiple of 128;
+// tile_key [n_tiles]: the first group with rows in each tile (-1: none).  Keys >= G mean "no group": dropped.  Rows keep
+// their batch order inside a group (rank = rows of the same key in earlier 256-row blocks + earlier rows of the own
+// block), so the layout — and every sum taken over it — is deterministic.  Two launches, no host round trip.
 constexpr int GR_BLOCK = 256, GR_MAX_KEYS = 130;
 
 // sel_mask != null: the key is the row's selected action (rg_qr_select_action's rule, evaluated here and written to `key`)
@@ -145,12 +148,12 @@ __global__ void group_count_kernel(int* __restrict__ key, int batch, int G, int*
 }
 
 // Every block derives what it needs from the raw per-block histogram itself — the rows of its keys in earlier blocks
-// (its base ranks) and the groups' totals (tile_begin) — 256 x (G + 1) integers, L2-resident: the single-workgroup scan
+// (its base ranks) and the groups' totals (row_begin) — 256 x (G + 1) integers, L2-resident: the single-workgroup scan
 // launch between count and scatter is gone (it was the launch that waited longest for a CU, up to 90 us, while the other
-// stream's forward held them all).  Block 0 also publishes tile_begin and tile_key.  Integer sums: order-independent.
+// stream's forward held them all).  Block 0 also publishes row_begin and tile_key.  Integer sums: order-independent.
 __global__ void group_scatter_kernel(const int* __restrict__ key, int batch, int G, const int* __restrict__ block_hist,
-                                     int n_blocks, int n_tiles, int* __restrict__ tile_begin, int* __restrict__ tile_key,
-                                     int* __restrict__ rowmap) {
+                                     int n_blocks, int n_tiles, int dense, int* __restrict__ row_begin,
+                                     int* __restrict__ tile_key, int* __restrict__ rowmap) {
   __shared__ int keys[GR_BLOCK];
   __shared__ int total[GR_MAX_KEYS], base[GR_MAX_KEYS], tb[GR_MAX_KEYS];
   const int tid = threadIdx.x, me = blockIdx.x, b = me * GR_BLOCK + tid;
@@ -174,25 +177,24 @@ __global__ void group_scatter_kernel(const int* __restrict__ key, int batch, int
     int run = 0;
     for (int g = 0; g < G; ++g) {
       tb[g] = run;
-      run += (total[g] + 127) / 128;
+      run += dense ? total[g] : (total[g] + 127) / 128 * 128;
     }
     tb[G] = run;
   }
   __syncthreads();
   if (me == 0) {
-    if (tid <= G) tile_begin[tid] = tb[tid];
+    if (tid <= G) row_begin[tid] = tb[tid];
     for (int t = tid; t < n_tiles; t += GR_BLOCK) {
       int g = -1;
-      if (t < tb[G])
-        for (int q = 0; q < G; ++q)
-          if (t >= tb[q] && t < tb[q + 1]) g = q;
+      for (int q = G - 1; q >= 0; --q)  // the first group whose (non-empty) range reaches into the tile
+        if (tb[q + 1] > tb[q] && tb[q + 1] > t * 128 && tb[q] < t * 128 + 128) g = q;
       tile_key[t] = g;
     }
   }
   if (k >= G) return;
   int rank = base[k];
   for (int i = 0; i < tid; ++i) rank += keys[i] == k ? 1 : 0;
-  rowmap[tb[k] * 128 + rank] = b;
+  rowmap[tb[k] + rank] = b;
 }
 
 // ---- quantile-Huber loss on compact rows (qrdqn_trainer.py:137-160, huber :217-218) ---------------------------
@@ -205,7 +207,7 @@ struct CompactHeadArgs {
   const float* zt;
   long ldz, ldzt;
   const int* rowmap;
-  const int* tile_key;
+  const int* row_key;  // [batch]: the group (logged action) of a batch row — only read for the reward boost
   const float* reward;
   const float* reward_boosts;
   const float* not_terminal;
@@ -246,8 +248,7 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     if (lane == 0) a.loss_partials[r] = 0.f;
     return;
   }
-  const int g = a.tile_key[r >> 7];
-  const float rew = a.reward[b] + (a.reward_boosts ? a.reward_boosts[g] : 0.f);
+  const float rew = a.reward[b] + (a.reward_boosts ? a.reward_boosts[a.row_key[b]] : 0.f);
   const float disc = a.gamma_exponent ? powf(a.gamma, a.gamma_exponent[b]) : a.gamma;
   const float dn = disc * a.not_terminal[b];
   float v[4];
@@ -401,11 +402,12 @@ __global__ void tile_sum_kernel(const float* __restrict__ v, float* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1];
 }
 
-// db[g * Ng + n] = sum over the tiles of group g of db_part[tile][n]
-__global__ void group_bias_reduce_kernel(const float* __restrict__ db_part, const int* __restrict__ tile_begin, int Ng,
-                                         int NgP, float* __restrict__ db, int wg_per_tile) {
+// db[g * Ng + n] = sum over the segments of group g of db_part[unit + g][n] (rg_mlp_frag.h: grouped_bias_reduce_launch)
+__global__ void group_bias_reduce_kernel(const float* __restrict__ db_part, const int* __restrict__ row_begin, int Ng,
+                                         int NgP, float* __restrict__ db, int unit_rows) {
   const int g = blockIdx.x;
-  const int t0 = tile_begin[g] * wg_per_tile, t1 = tile_begin[g + 1] * wg_per_tile;
+  const int r0 = row_begin[g], r1 = row_begin[g + 1];
+  const int t0 = r0 / unit_rows + g, t1 = r1 > r0 ? (r1 + unit_rows - 1) / unit_rows + g : t0;
   for (int n = threadIdx.x; n < Ng; n += blockDim.x) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four tiles in flight (a ~30-deep chain of dependent loads was 15 us)
     int t = t0;
@@ -420,9 +422,9 @@ __global__ void group_bias_reduce_kernel(const float* __restrict__ db_part, cons
   }
 }
 
-void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db, int wg_per_tile,
+void grouped_bias_reduce_launch(const float* db_part, const int* row_begin, int n_groups, int Ng, float* db, int unit_rows,
                                 hipStream_t stream) {
-  RG_LAUNCH(group_bias_reduce_kernel, dim3(n_groups), dim3(256), stream, db_part, tile_begin, Ng, Ng, db, wg_per_tile);
+  RG_LAUNCH(group_bias_reduce_kernel, dim3(n_groups), dim3(256), stream, db_part, row_begin, Ng, Ng, db, unit_rows);
 }
 
 
@@ -467,10 +469,10 @@ size_t rg_group_rows_workspace_bytes(int batch, int n_groups) {
   return (size_t)((batch + GR_BLOCK - 1) / GR_BLOCK) * (n_groups + 1) * sizeof(int);
 }
 
-int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int32_t* rowmap, int32_t* tile_key,
-                  int32_t* tile_begin, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
-  if (!key || !rowmap || !tile_key || !tile_begin || batch <= 0 || n_groups <= 0 || n_groups + 1 > GR_MAX_KEYS ||
-      n_tiles < (batch + 127) / 128 + n_groups)
+int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int dense, int32_t* rowmap, int32_t* tile_key,
+                  int32_t* row_begin, void* workspace, size_t workspace_bytes, rg_stream_t stream) {
+  if (!key || !rowmap || !tile_key || !row_begin || batch <= 0 || n_groups <= 0 || n_groups + 1 > GR_MAX_KEYS ||
+      n_tiles < (batch + 127) / 128 + (dense ? 0 : n_groups))
     return RG_EINVAL;
   if (!workspace || workspace_bytes < rg_group_rows_workspace_bytes(batch, n_groups)) return RG_EWORKSPACE;
   const int nblk = (batch + GR_BLOCK - 1) / GR_BLOCK;
@@ -478,16 +480,16 @@ int rg_group_rows(const int32_t* key, int batch, int n_groups, int n_tiles, int3
   RG_LAUNCH(group_count_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, (int*)key, batch, n_groups, hist, rowmap,
             n_tiles * 128, (const float*)nullptr, 0L, (const float*)nullptr, 0);
   RG_LAUNCH(group_scatter_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, key, batch, n_groups, (const int*)hist,
-            nblk, n_tiles, tile_begin, tile_key, rowmap);
+            nblk, n_tiles, dense ? 1 : 0, row_begin, tile_key, rowmap);
   return (int)hipGetLastError();
 }
 
 int rg_qr_select_group_rows(const float* q, int64_t ldq, const float* mask, int batch, int num_actions, int maxq,
-                            int32_t* key, int n_tiles, int32_t* rowmap, int32_t* tile_key, int32_t* tile_begin,
+                            int32_t* key, int n_tiles, int dense, int32_t* rowmap, int32_t* tile_key, int32_t* row_begin,
                             void* workspace, size_t workspace_bytes, rg_stream_t stream) {
   const int n_groups = num_actions;
-  if (!mask || !key || !rowmap || !tile_key || !tile_begin || batch <= 0 || n_groups <= 0 || n_groups + 1 > GR_MAX_KEYS ||
-      n_tiles < (batch + 127) / 128 + n_groups || (maxq && !q))
+  if (!mask || !key || !rowmap || !tile_key || !row_begin || batch <= 0 || n_groups <= 0 || n_groups + 1 > GR_MAX_KEYS ||
+      n_tiles < (batch + 127) / 128 + (dense ? 0 : n_groups) || (maxq && !q))
     return RG_EINVAL;
   if (!workspace || workspace_bytes < rg_group_rows_workspace_bytes(batch, n_groups)) return RG_EWORKSPACE;
   const int nblk = (batch + GR_BLOCK - 1) / GR_BLOCK;
@@ -495,7 +497,7 @@ int rg_qr_select_group_rows(const float* q, int64_t ldq, const float* mask, int 
   RG_LAUNCH(group_count_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, key, batch, n_groups, hist, rowmap,
             n_tiles * 128, q, (long)ldq, mask, maxq);
   RG_LAUNCH(group_scatter_kernel, dim3(nblk), dim3(GR_BLOCK), (hipStream_t)stream, (const int*)key, batch, n_groups,
-            (const int*)hist, nblk, n_tiles, tile_begin, tile_key, rowmap);
+            (const int*)hist, nblk, n_tiles, dense ? 1 : 0, row_begin, tile_key, rowmap);
   return (int)hipGetLastError();
 }
 
@@ -508,16 +510,16 @@ int rg_qr_select_action(const float* q, int64_t ldq, const float* mask, int batc
 }
 
 int rg_qr_compact_head(const float* z, int64_t ldz, const float* zt, int64_t ldzt, const int32_t* rowmap,
-                       const int32_t* tile_key, int padded_rows, const float* reward, const float* reward_boosts,
+                       const int32_t* row_key, int padded_rows, const float* reward, const float* reward_boosts,
                        const float* not_terminal, double gamma, const float* gamma_exponent, const float* quantiles,
                        int batch, int num_atoms, float* dz, int64_t lddz, float* loss_partials, float* tile_losses,
                        rg_stream_t stream) {
-  if (!z || !zt || !rowmap || !tile_key || !reward || !not_terminal || !quantiles || !dz || !loss_partials ||
+  if (!z || !zt || !rowmap || (reward_boosts && !row_key) || !reward || !not_terminal || !quantiles || !dz || !loss_partials ||
       padded_rows <= 0 || (padded_rows % 128) != 0 || batch <= 0 || num_atoms <= 0)
     return RG_EINVAL;
   if (num_atoms > QC_MAX_N || lddz < num_atoms) return RG_EUNSUPPORTED;
   CompactHeadArgs a;
-  a.z = z; a.zt = zt; a.ldz = ldz; a.ldzt = ldzt; a.rowmap = rowmap; a.tile_key = tile_key; a.reward = reward;
+  a.z = z; a.zt = zt; a.ldz = ldz; a.ldzt = ldzt; a.rowmap = rowmap; a.row_key = row_key; a.reward = reward;
   a.reward_boosts = reward_boosts; a.not_terminal = not_terminal; a.gamma_exponent = gamma_exponent; a.quantiles = quantiles;
   a.gamma = (float)gamma; a.batch = batch; a.N = num_atoms; a.dz = dz; a.lddz = lddz; a.loss_partials = loss_partials;
   RG_LAUNCH(qr_compact_head_kernel, dim3(padded_rows / QC_WAVES), dim3(QC_WAVES * 64), (hipStream_t)stream, a);

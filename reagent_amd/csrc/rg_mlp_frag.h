@@ -45,7 +45,9 @@ struct MlpArgs {
   int x_split;
   int dx_col0;                    // backward: first input column whose gradient is produced (dx32[0])
   const int* rowmap;              // forward: tile row r reads input row rowmap[r] (-1: zeros); null = identity
-  const int* tile_key;            // grouped output layer: group of each 128-row tile (-1: empty), null = plain layer
+  const int* tile_key;            // grouped output layer: FIRST group with rows in each 128-row tile (-1: none), null = plain layer
+  const int* row_begin;           // grouped output layer: group g owns rows [row_begin[g], row_begin[g + 1]) of the grouped space
+  int n_groups;
   long group_stride;              // elements between the groups' fragment sets of the last layer (this direction)
   int out_scatter;                // forward: output row r goes to out32[rowmap[r]]
   int stage_out;                  // grouped forward: the output leaves as whole rows through the LDS behind the activation tile
@@ -196,12 +198,13 @@ __device__ __forceinline__ void load_tile_rows_mapped(bf16_t* act, int pitch, co
 }
 
 // LDS tile (128 rows x ntiles*32 cols) -> C-fragment order in global memory
+// (only the 32-row blocks [mbl0, mbl1) of the tile; block mbl goes to fragment block mb_base + mbl)
 __device__ __forceinline__ void emit_frags_from_lds(const bf16_t* act, int pitch, int ntiles, bf16_t* dst,
-                                                    int mb_base, int wave, int n_waves, int lane) {
+                                                    int mb_base, int wave, int n_waves, int lane, int mbl0 = 0, int mbl1 = 4) {
   const int lr = lane & 31, lg = lane >> 5;
-  const int total = 4 * ntiles * 2;
+  const int total = (mbl1 - mbl0) * ntiles * 2;
   for (int f = wave; f < total; f += n_waves) {
-    const int h = f & 1, nt = (f >> 1) % ntiles, mbl = (f >> 1) / ntiles;
+    const int h = f & 1, nt = (f >> 1) % ntiles, mbl = mbl0 + (f >> 1) / ntiles;
     u16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act[(mbl * 32 + frag_row(h, e, lg)) * pitch + nt * 32 + lr];
@@ -276,6 +279,48 @@ __device__ __forceinline__ int grouped_tile(int block, int n_tiles) {
 #else
   return block;
 #endif
+}
+
+// Grouped row space (qr_grouped.hip): group g owns the rows [row_begin[g], row_begin[g + 1]) — padded per group to whole
+// 128-row tiles (then a tile belongs to one group) or DENSE (round 4: no padding between groups, B / 128 tiles exactly; a tile
+// that holds the end of one group and the start of the next is cut into SEGMENTS and the grouped layer runs once per
+// segment).  A window of `rows` rows from row_base is walked segment by segment: g = the window's first group (tile_key),
+// then next_segment() until it returns false.  Everything here is workgroup-uniform.
+struct RowSegment {
+  int grp, lo, hi;  // window-relative rows [lo, hi) of group grp
+};
+__device__ __forceinline__ bool next_segment(const int* row_begin, int n_groups, int row_base, int rows, int& g, RowSegment& s) {
+  while (g >= 0 && g < n_groups) {
+    const int b = row_begin[g], e = row_begin[g + 1];
+    if (b >= row_base + rows) return false;
+    const int lo = b > row_base ? b : row_base, hi = e < row_base + rows ? e : row_base + rows;
+    const int grp = g++;
+    if (hi > lo) {
+      s.grp = grp;
+      s.lo = lo - row_base;
+      s.hi = hi - row_base;
+      return true;
+    }
+  }
+  return false;
+}
+
+// dst[r][0 .. ncols) = lo <= r < hi ? src[r][0 .. ncols) : 0 for the ROWS rows of an LDS tile (ncols a multiple of 8; src and dst
+// 16-byte aligned with the same pitch): the operand of ONE segment of a boundary tile — the other groups' rows contribute zero
+template <int THREADS, int ROWS>
+__device__ __forceinline__ void copy_rows_masked(const bf16_t* src, bf16_t* dst, int pitch, int ncols, int lo, int hi, int tid) {
+  const int cpr = ncols >> 3;
+  for (int c = tid; c < ROWS * cpr; c += THREADS) {
+    const int r = c / cpr, k = (c - r * cpr) * 8;
+    u16x8 v = *(const u16x8*)(src + r * pitch + k);
+    if (r < lo || r >= hi) v = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    *(u16x8*)(dst + r * pitch + k) = v;
+  }
+}
+// where that copy lives: behind the operand inside the rows of a 520-wide tile (the grouped layer is <= 256 columns wide), behind
+// the whole tile of a 264-wide one (the launch asks for the extra LDS)
+template <int PITCH> __device__ __forceinline__ constexpr int masked_copy_offset(int tile_elems) {
+  return PITCH >= 2 * 256 + 8 ? 256 : tile_elems;
 }
 
 // ---- main loop of a wide layer: this wave's [128 x 32*TN] slice over K ------------------------
@@ -417,6 +462,29 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
         sched_fence();
       }
     }
+  }
+  mfma_drain();
+}
+
+// acc += A . B for one MORE segment of a boundary tile of a grouped layer (the first segment went through wide_mainloop):
+// the same products on a plain loop, one chunk of fragments at a time.  Deliberately small — with the software-pipelined
+// main loop inside a loop over segments the 512-wide backward kernel spilled 390-460 registers, accumulator tiles among
+// them inside the K loop; as a second, conditional call site it keeps its registers.  At most one tile per group boundary
+// (<= n_groups - 1 of the B / 128 tiles of a launch) comes here, for the grouped layer's K only.
+template <int TM, int TN>
+__device__ __forceinline__ void segment_accumulate(const bf16_t* act, int pitch, int KC, const bf16_t* wf_wave, long nt_stride,
+                                                   f32x16 (&acc)[TM][TN], int lane) {
+  const bf16_t* arow = act + (lane & 31) * pitch + (lane >> 5) * 8;
+  for (int kc = 0; kc < KC; ++kc) {
+    u16x8 af[TM], bf[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(wf_wave + (long)kc * 512 + tn * nt_stride + lane * 8);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) af[tm] = *(const u16x8*)(arow + tm * 32 * pitch + kc * 16);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_main(af[tm], bf[tn], acc[tm][tn]);
   }
   mfma_drain();
 }
@@ -738,6 +806,12 @@ static inline size_t wfrag_elems(int out_features, int in_features) {
   return (size_t)((out_features + 31) / 32) * (size_t)((in_features + 15) / 16) * 512;
 }
 
+// Rows of the fragment matrix that holds a GROUPED layer's dZ: a 32-row block that two groups share is written once per group
+// (the other group's rows zeroed), group g's copy at block (row / 32) + g — so group g's blocks are contiguous,
+// [row_begin[g] / 32 + g, ceil(row_begin[g + 1] / 32) + g), aligned with the UNSHIFTED blocks of the layer's input fragments,
+// and the weight gradient needs no row masks (rg_group_head_wgrad)
+static inline int grouped_dz_rows(int rows, int n_groups) { return rows + 32 * n_groups; }
+
 static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int backward) {
   a.n_layers = d->n_layers;
   a.batch = batch;
@@ -753,7 +827,8 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
     a.db_part[l] = nullptr;
     if (!a.wfrag[l] && !(backward && l == 0)) return RG_EINVAL;
     a.wfrag_lo[l] = d->x3 ? (long)(backward ? wfrag_elems(d->dims[l], d->dims[l + 1]) : wfrag_elems(d->dims[l + 1], d->dims[l])) : 0;
-    a.dz_lo[l] = d->x3 ? (long)frag_elems(batch, d->dims[l + 1]) : 0;
+    // (a grouped output layer's dZ fragments: group g's 32-row blocks start g blocks late, grouped_dz_rows)
+    a.dz_lo[l] = d->x3 ? (long)frag_elems(d->tile_key && l == d->n_layers - 1 ? grouped_dz_rows(batch, d->n_groups) : batch, d->dims[l + 1]) : 0;
   }
   for (int l = 0; l <= d->n_layers; ++l) {
     a.act_frag[l] = (bf16_t*)(l < d->n_layers ? d->act_frag[l] : nullptr);
@@ -761,7 +836,7 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
   }
   a.pitch = fused_pitch(d);
   a.rowmap = d->rowmap;
-  a.tile_key = d->tile_key; a.group_stride = backward ? d->group_stride_bwd : d->group_stride_fwd;
+  a.tile_key = d->tile_key; a.row_begin = d->row_begin; a.n_groups = d->n_groups; a.group_stride = backward ? d->group_stride_bwd : d->group_stride_fwd;
   a.out_scatter = d->tile_key ? d->out_scatter : 0;
   a.x2 = d->x2; a.ldx2 = d->ldx2; a.x_split = d->x2 ? d->x_split : 0; a.dx_col0 = d->dx_col0;
   a.x2_is_f32 = d->x2_dtype == RG_DT_F32;
@@ -770,9 +845,10 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
   return RG_OK;
 }
 
-// db[g * Ng + n] = sum over the tiles of group g of db_part[tile][n] (qr_grouped.hip; db_part row pitch Ng)
-// wg_per_tile: workgroups (rows of db_part) per 128-row tile — 1 for the bf16 kernels, 2 for the split-bf16 ones
-void grouped_bias_reduce_launch(const float* db_part, const int* tile_begin, int n_groups, int Ng, float* db, int wg_per_tile,
+// db[g * Ng + n] = sum over the segments of group g of db_part[unit + g][n] (qr_grouped.hip; db_part row pitch Ng): the
+// backward kernel's workgroup `unit` (unit_rows rows of the grouped space: 128 for the bf16 kernels, 64 for the split-bf16 ones)
+// writes the column sums of its rows of group g to row unit + g — distinct for distinct segments, contiguous per group
+void grouped_bias_reduce_launch(const float* db_part, const int* row_begin, int n_groups, int Ng, float* db, int unit_rows,
                                 hipStream_t stream);
 
 // split-bf16 kernels (mlp_fused_x3.hip); `a` filled by fill_args, launch geometry decided there

@@ -535,7 +535,7 @@ class FusedMLP:
 
 
 class GroupedHead:
-    """The output layer of a fused stack as n_groups layers [group_rows, H], one per 128-row tile of a grouped row
+    """The output layer of a fused stack as n_groups layers [group_rows, H], one per group of rows of a grouped row
     space (qr_engine.py): per-group MFMA fragments of W_g / W_g^T (rg_group_weights_stage), the bias, and the
     buffers the backward of that layer needs."""
 
@@ -559,7 +559,9 @@ class GroupedHead:
         if self._rows != rows:
             dev = self.weight.device
             lib = L.lib()
-            self.dz_frag = torch.empty(self.planes * lib.rg_frag_elems(rows, self.Ng), dtype=torch.bfloat16, device=dev)
+            # (group g's 32-row blocks are written g blocks late — a block two groups share once per group: ops.grouped_dz_rows)
+            self.dz_frag = torch.zeros(self.planes * lib.rg_frag_elems(ops.grouped_dz_rows(rows, self.G), self.Ng), dtype=torch.bfloat16,
+                                       device=dev)
             d = self.desc(st, None, None, None)
             self.bwd_ws = torch.empty(lib.rg_mlp_backward_fused_workspace_bytes(d, rows) // 4 + 4, dtype=torch.float32, device=dev)
             self._rows = rows
@@ -576,7 +578,7 @@ class GroupedHead:
         d.bias[n - 1] = self.bias.data_ptr()
         d.group_stride_fwd, d.group_stride_bwd, d.n_groups = self.per_f, self.per_b, self.G
         if space is not None:
-            d.rowmap, d.tile_key, d.tile_begin = space.rowmap.data_ptr(), space.tile_key.data_ptr(), space.tile_begin.data_ptr()
+            d.rowmap, d.tile_key, d.row_begin = space.rowmap.data_ptr(), space.tile_key.data_ptr(), space.row_begin.data_ptr()
             d.out_scatter = int(bool(scatter))
         if save_dz:
             d.dz_frag[n - 1] = self.dz_frag.data_ptr()
@@ -652,7 +654,7 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
         side = _side_stream(dz32.device)
         side.wait_stream(main)
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.tile_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
+        ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.row_begin, head.G, head.Ng, head.H, splits, dw[n - 1],
                              wgrad_ws, x3=head.x3, rows=R)
     ops._run("rg_mlp_wgrad_fused", dict(B=R, dims=tuple(st.dims[:n])),
              lambda: lib.rg_mlp_wgrad_fused(t, R, ws["wgrad"].data_ptr(), ws["wgrad"].numel() * 4, L.stream_ptr()))

@@ -691,12 +691,13 @@ def add_cols(a, b, out):
 
 
 # ---- QR-DQN with a grouped output layer (qr_grouped.hip) ------------------------------------------------------
-def group_rows(key, n_groups, n_tiles, rowmap, tile_key, tile_begin, workspace):
-    _chk_dev(key, rowmap, tile_key, tile_begin, workspace)
+def group_rows(key, n_groups, n_tiles, rowmap, tile_key, row_begin, workspace, dense: bool = True):
+    _chk_dev(key, rowmap, tile_key, row_begin, workspace)
     assert key.dtype == torch.int32 and rowmap.numel() == n_tiles * 128 and tile_key.numel() == n_tiles
     _run("rg_group_rows", dict(B=key.numel(), G=n_groups),
-         lambda: L.lib().rg_group_rows(key.data_ptr(), key.numel(), n_groups, n_tiles, rowmap.data_ptr(), tile_key.data_ptr(),
-                                       tile_begin.data_ptr(), workspace.data_ptr(), workspace.numel() * 4, L.stream_ptr()))
+         lambda: L.lib().rg_group_rows(key.data_ptr(), key.numel(), n_groups, n_tiles, int(dense), rowmap.data_ptr(),
+                                       tile_key.data_ptr(), row_begin.data_ptr(), workspace.data_ptr(), workspace.numel() * 4,
+                                       L.stream_ptr()))
 
 
 def group_wfrag_elems(group_rows: int, in_features: int, transposed: bool) -> int:
@@ -738,40 +739,47 @@ def qr_select_action(q, mask, maxq: bool, key):
                                              key.data_ptr(), L.stream_ptr()))
 
 
-def qr_select_group_rows(q, mask, maxq: bool, key, n_tiles, rowmap, tile_key, tile_begin, workspace):
+def qr_select_group_rows(q, mask, maxq: bool, key, n_tiles, rowmap, tile_key, row_begin, workspace, dense: bool = True):
     """qr_select_action + group_rows (n_groups = number of actions) in two launches"""
-    _chk_dev(q, mask, key, rowmap, tile_key, tile_begin, workspace)
+    _chk_dev(q, mask, key, rowmap, tile_key, row_begin, workspace)
     B, A = mask.shape
     assert mask.is_contiguous() and mask.dtype == F32 and key.dtype == torch.int32 and key.numel() == B
     assert rowmap.numel() == n_tiles * 128 and tile_key.numel() == n_tiles
     _run("rg_group_rows", dict(B=B, G=A),
          lambda: L.lib().rg_qr_select_group_rows(L.ptr(q), _ld(q) if q is not None else 0, mask.data_ptr(), B, A, int(maxq),
-                                                 key.data_ptr(), n_tiles, rowmap.data_ptr(), tile_key.data_ptr(),
-                                                 tile_begin.data_ptr(), workspace.data_ptr(), workspace.numel() * 4,
+                                                 key.data_ptr(), n_tiles, int(dense), rowmap.data_ptr(), tile_key.data_ptr(),
+                                                 row_begin.data_ptr(), workspace.data_ptr(), workspace.numel() * 4,
                                                  L.stream_ptr()))
 
 
-def qr_compact_head(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma, gamma_exponent, quantiles,
+def qr_compact_head(z, zt, rowmap, row_key, reward, reward_boosts, not_terminal, gamma, gamma_exponent, quantiles,
                     batch, num_atoms, dz, loss_partials, tile_losses=None):
-    _chk_dev(z, zt, rowmap, tile_key, reward, reward_boosts, not_terminal, gamma_exponent, quantiles, dz, loss_partials,
+    """row_key [batch] int32: the group (logged action) of every batch row — read for the reward boost only"""
+    _chk_dev(z, zt, rowmap, row_key, reward, reward_boosts, not_terminal, gamma_exponent, quantiles, dz, loss_partials,
              tile_losses)
     rows = rowmap.numel()
     assert z.shape[0] == rows and dz.shape[0] == rows and loss_partials.numel() == rows
+    assert reward_boosts is None or (row_key is not None and row_key.numel() == batch)
     _run("rg_qr_compact_head", dict(rows=rows, N=num_atoms),
          lambda: L.lib().rg_qr_compact_head(z.data_ptr(), _ld(z), zt.data_ptr(), _ld(zt), rowmap.data_ptr(),
-                                            tile_key.data_ptr(), rows, reward.data_ptr(), L.ptr(reward_boosts),
+                                            L.ptr(row_key), rows, reward.data_ptr(), L.ptr(reward_boosts),
                                             not_terminal.data_ptr(), float(gamma), L.ptr(gamma_exponent),
                                             quantiles.data_ptr(), batch, num_atoms, dz.data_ptr(), _ld(dz),
                                             loss_partials.data_ptr(), L.ptr(tile_losses), L.stream_ptr()))
 
 
-def group_head_wgrad(dzw_frag, h_frag, tile_begin, n_groups, group_rows, in_features, splits, dw, workspace, x3: bool = False,
+def grouped_dz_rows(rows: int, n_groups: int) -> int:
+    """rows of the fragment matrix that holds a grouped layer's dZ (include/reagent_hip.h, rg_mlp_desc: group g's blocks g late)"""
+    return rows + 32 * n_groups
+
+
+def group_head_wgrad(dzw_frag, h_frag, row_begin, n_groups, group_rows, in_features, splits, dw, workspace, x3: bool = False,
                      rows: int = 0):
     """x3: split-bf16 operands ([hi plane | lo plane] over the `rows` rows of the grouped space)"""
-    _chk_dev(dzw_frag, h_frag, tile_begin, dw, workspace)
+    _chk_dev(dzw_frag, h_frag, row_begin, dw, workspace)
     assert dw.is_contiguous() and dw.shape == (n_groups * group_rows, in_features)
     _run("rg_group_head_wgrad", dict(G=n_groups, Ng=group_rows, K=in_features),
-         lambda: L.lib().rg_group_head_wgrad(dzw_frag.data_ptr(), h_frag.data_ptr(), tile_begin.data_ptr(), n_groups,
+         lambda: L.lib().rg_group_head_wgrad(dzw_frag.data_ptr(), h_frag.data_ptr(), row_begin.data_ptr(), n_groups,
                                              group_rows, in_features, splits, int(x3), int(rows), dw.data_ptr(),
                                              workspace.data_ptr(), workspace.numel() * 4, L.stream_ptr()))
 

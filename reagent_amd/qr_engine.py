@@ -4,7 +4,7 @@ reagent/training/qrdqn_trainer.py:108-160 computes, without ever writing the [B,
     q_next     = sel_net(next_state).mean(dim=2)         one fused forward whose output layer is the per-action
                                                          MEAN of the wide layer's rows (rg_wide_head_mean)
     a*         = arg max with the possible-actions mask   rg_qr_select_action                    (:125-135, :210-214)
-    grouped space of a*: rows sorted by a*, each action padded to whole 128-row tiles (index bookkeeping, torch)
+    grouped space of a*: rows sorted by a* (rg_qr_select_group_rows: on the device)
     zt[b, :]   = target_net(next_state)[b, a*, :]         ONE fused forward in grouped space whose output layer is the
                                                          tile's action slice of the wide layer        (:137-141)
     grouped space of the logged action
@@ -32,27 +32,30 @@ TILE = 128
 
 
 class GroupedSpace:
-    """rows of a batch sorted by an int32 key in [0, G] (G = "no group": dropped) and padded per key to whole tiles
-    (rg_group_rows: a stable counting sort on the device, static shapes, no host synchronisation):
-    rowmap [TILE * n_tiles], tile_key [n_tiles], tile_begin [G + 1], all int32"""
+    """rows of a batch sorted by an int32 key in [0, G] (G = "no group": dropped) — rg_group_rows: a stable counting sort on
+    the device, static shapes, no host synchronisation.  dense (round 4, the default; RG_QR_DENSE=0 for the rounds 2-3
+    layout): the groups follow each other without padding, ceil(B / TILE) tiles — C3: 512, two full rounds of the 256 CUs
+    where the padded layout's ~520 made every grouped launch a third, nearly empty one; otherwise each key's rows are padded
+    to whole tiles.  rowmap [TILE * n_tiles], tile_key [n_tiles] (first group with rows in the tile), row_begin [G + 1], all int32"""
 
-    def __init__(self, B: int, G: int, device):
-        self.B, self.G = B, G
-        self.n_tiles = (B + TILE - 1) // TILE + G
+    def __init__(self, B: int, G: int, device, dense: bool = True):
+        self.B, self.G, self.dense = B, G, bool(dense)
+        self.n_tiles = (B + TILE - 1) // TILE + (0 if dense else G)
         self.rows = self.n_tiles * TILE
         i32 = dict(dtype=torch.int32, device=device)
         self.rowmap = torch.empty(self.rows, **i32)
         self.tile_key = torch.empty(self.n_tiles, **i32)
-        self.tile_begin = torch.empty(G + 1, **i32)
+        self.row_begin = torch.empty(G + 1, **i32)
         self._ws = torch.empty(max(1, L.lib().rg_group_rows_workspace_bytes(B, G) // 4), **i32)
 
     def build(self, key: torch.Tensor):
-        ops.group_rows(key, self.G, self.n_tiles, self.rowmap, self.tile_key, self.tile_begin, self._ws)
+        ops.group_rows(key, self.G, self.n_tiles, self.rowmap, self.tile_key, self.row_begin, self._ws, dense=self.dense)
         return self
 
     def build_selected(self, q, mask, maxq: bool, key: torch.Tensor):
         """key = rg_qr_select_action(q, mask, maxq), then build(key) — in the two launches of the latter"""
-        ops.qr_select_group_rows(q, mask, maxq, key, self.n_tiles, self.rowmap, self.tile_key, self.tile_begin, self._ws)
+        ops.qr_select_group_rows(q, mask, maxq, key, self.n_tiles, self.rowmap, self.tile_key, self.row_begin, self._ws,
+                                 dense=self.dense)
         return self
 
 
@@ -118,6 +121,7 @@ class GroupedQR:
         self._side = None
         self.two_streams = os.environ.get("RG_QR_STREAMS", "1") != "0"  # the forward's two halves on two streams
         self.wgrad_streams = os.environ.get("RG_QR_WGRAD_STREAMS", "1") != "0"  # the backward's two weight-gradient launches
+        self.dense = os.environ.get("RG_QR_DENSE", "1") != "0"  # grouped spaces without per-group padding (GroupedSpace)
 
     def after_fused_update(self):
         """DQNTrainer._fused_update ran Adam + soft update + re-staging of both networks' trunk and grouped-head
@@ -156,7 +160,7 @@ class GroupedQR:
             return
         A, N, H = self.A, self.N, self.online.H
         f32 = dict(dtype=torch.float32, device=dev)
-        self.sp_next, self.sp_cur = GroupedSpace(B, A, dev), GroupedSpace(B, A, dev)
+        self.sp_next, self.sp_cur = GroupedSpace(B, A, dev, self.dense), GroupedSpace(B, A, dev, self.dense)
         R = self.sp_cur.rows
         ldz = (N + 7) // 8 * 8
         self.key_next = torch.empty(B, dtype=torch.int32, device=dev)
@@ -183,8 +187,8 @@ class GroupedQR:
         on.stage()
         tg.stage()
         # The two halves of the forward are independent until the loss — (1) a* and the target quantiles of next_state,
-        # (2) the current quantiles of the logged action — and each ends in a 528-workgroup launch (B/128 + A tiles:
-        # two full rounds of the 256 CUs plus a sliver).  On two streams the slivers fill each other's tails.
+        # (2) the current quantiles of the logged action — and each ends in a launch of B / 128 workgroups (rounds 2-3:
+        # B / 128 + ~A / 2, two full rounds of the 256 CUs plus a sliver).  On two streams their tails fill each other.
         main = torch.cuda.current_stream() if state.is_cuda and self.two_streams else None
         if main is not None:
             if self._side is None:
@@ -217,7 +221,7 @@ class GroupedQR:
         boosts = tr.reward_boosts.reshape(-1).to(dev) if tr._has_reward_boost else None
         if tr.quantiles.device != dev:
             tr.quantiles = tr.quantiles.to(dev)
-        ops.qr_compact_head(self.z, self.zt, sp1.rowmap, sp1.tile_key, tr._f32c(b.reward).reshape(-1), boosts,
+        ops.qr_compact_head(self.z, self.zt, sp1.rowmap, self.key_cur, tr._f32c(b.reward).reshape(-1), boosts,
                             tr._f32c(b.not_terminal).reshape(-1), tr.gamma, gamma_exp, tr.quantiles.reshape(-1), B, self.N,
                             self.dz, self.loss_partials, self.tile_losses)
         ops.reduce_sum(self.tile_losses, self.tile_losses.numel(), 1.0, tr._loss)
