@@ -200,7 +200,9 @@ typedef struct {
   /* ABI 6 — the step's launch-bound tails folded into the weight gradient's reduce launch.
    * defer_db != 0: rg_mlp_backward_fused leaves the bias-gradient partials in its workspace and launches no column
    *   reduce; rg_mlp_wgrad_fused, handed that workspace in db_partials, sums them into db[] in the launch that sums its
-   *   own split partials (same arithmetic, one launch instead of two).  Not with a grouped output layer.
+   *   own split partials (same arithmetic, one launch instead of two).  With a grouped output layer (ABI 9) the last
+   *   layer's per-group reduce is still launched by rg_mlp_backward_fused; the other layers' partials wait for the
+   *   rg_mlp_wgrad_fused call on the trunk (the first n_layers - 1 layers: same workspace layout).
    * sum_in != NULL: that launch also writes sum_out[0] = sum_scale * sum(sum_in[0 .. sum_n)) — the mean loss of a step
    *   from the loss head's per-workgroup partials (rg_reduce_sum's arithmetic). */
   int32_t defer_db;

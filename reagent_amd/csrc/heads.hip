@@ -630,9 +630,8 @@ __global__ void bcq_filter_kernel(const float* __restrict__ logits, int batch, i
 __global__ void reduce_sum_kernel(const float* __restrict__ in, int n, float scale,
                                   float* __restrict__ out) {
   __shared__ float scratch[4];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += HEAD_THREADS) acc += in[i];
-  const float s = block_sum_256(acc, scratch);
+  static_assert(HEAD_THREADS == 256, "strided_sum_256");
+  const float s = block_sum_256(strided_sum_256(in, n, threadIdx.x), scratch);
   if (threadIdx.x == 0) out[0] = s * scale;
 }
 

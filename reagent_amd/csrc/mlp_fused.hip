@@ -20,6 +20,7 @@
 // and its autograd backward for stacks whose hidden layers share one width in {256, 512}.
 
 #include "rg_mlp_frag.h"
+#include "rg_reduce.h"
 // workgroups per layer of the grouped weight-gradient launch (splits = this / tiles).
 // Round 3, same-box A/B in the C2 step (wgrad + reduce, us): this uniform 128 per layer 132-134; workgroups shared out in
 // proportion to the operand bytes a layer's tiles stream — 256 in all (one round on the chip, 52 MB of partials
@@ -987,8 +988,7 @@ __global__ void reduce_tail_kernel(ReduceTailArgs T) {
   }
   // reduce_sum_kernel (heads.hip): strided partial sums, block_sum_256's fixed order
   __shared__ float scratch[4];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < T.sum_n; i += 256) acc += T.sum_in[i];
+  float acc = strided_sum_256(T.sum_in, T.sum_n, threadIdx.x);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += shfl_xor(acc, off);
   if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
@@ -1429,8 +1429,14 @@ int rg_mlp_backward_fused(const rg_mlp_desc* d, const float* dout32, int64_t ldd
   }
   if (rc) return rc;
   if (d->defer_db) {  // the partials stay in the workspace: rg_mlp_wgrad_fused (db_partials) sums them in its reduce launch
-    if (d->tile_key || !want_db) return RG_EINVAL;
-    return 0;
+    if (!want_db) return RG_EINVAL;
+    // (a grouped output layer's per-group sums are not that launch's: reduced here; the trunk's partials wait for the
+    // trunk's weight gradient, whose descriptor is this one's first n_layers - 1 layers — same workspace layout)
+    const int l = d->n_layers - 1;
+    if (d->tile_key && a.db_part[l])
+      grouped_bias_reduce_launch(a.db_part[l], d->row_begin, d->n_groups, d->dims[l + 1], d->db[l], d->x3 ? X3_BM : FB_BM,
+                                 (hipStream_t)stream);
+    return (int)hipGetLastError();
   }
   ReduceColsGroupArgs G;
   G.n = 0;

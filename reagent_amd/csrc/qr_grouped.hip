@@ -89,21 +89,50 @@ __global__ void wide_mean_kernel(const float* __restrict__ w, const float* __res
 
 // key[b] = arg max_a (q[b, a] - 1e9 (1 - mask[b, a]))  (maxq; qrdqn_trainer.py:210-214, first maximum wins) or the
 // position of the 1 in the one-hot row mask[b, :] (SARSA: mask = next_action), A if the row is all zero
+// (the row's values are requested eight at a time: one load per loop turn was a chain of A dependent L2 / HBM round trips per
+// thread — 40-60 us for the counting launch of a C3 step when it shares the chip with a forward)
 __device__ __forceinline__ int select_action_row(const float* __restrict__ q, long ldq, const float* __restrict__ mask,
                                                  int b, int A, int maxq) {
   const float* m = mask + (long)b * A;
+  const float* qr = q ? q + (long)b * ldq : nullptr;  // (only read for maxq)
   int best = A;
   if (maxq) {
     float bv = 0.f;
-    for (int a = 0; a < A; ++a) {
-      const float v = q[(long)b * ldq + a] + -1e9f * (1.f - m[a]);
+    int a = 0;
+    for (; a + 8 <= A; a += 8) {
+      float mv[8], qv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        mv[i] = m[a + i];
+        qv[i] = qr[a + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = qv[i] + -1e9f * (1.f - mv[i]);
+        if (a + i == 0 || v > bv) {
+          bv = v;
+          best = a + i;
+        }
+      }
+    }
+    for (; a < A; ++a) {
+      const float v = qr[a] + -1e9f * (1.f - m[a]);
       if (a == 0 || v > bv) {
         bv = v;
         best = a;
       }
     }
-  } else {
-    for (int a = A - 1; a >= 0; --a)
+  } else {  // the FIRST non-zero entry
+    int a = 0;
+    for (; a + 8 <= A && best == A; a += 8) {
+      float mv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mv[i] = m[a + i];
+#pragma unroll
+      for (int i = 7; i >= 0; --i)
+        if (mv[i] != 0.f) best = a + i;
+    }
+    for (; a < A && best == A; ++a)
       if (m[a] != 0.f) best = a;
   }
   return best;
@@ -151,26 +180,48 @@ __global__ void group_count_kernel(int* __restrict__ key, int batch, int G, int*
 // (its base ranks) and the groups' totals (row_begin) — 256 x (G + 1) integers, L2-resident: the single-workgroup scan
 // launch between count and scatter is gone (it was the launch that waited longest for a CU, up to 90 us, while the other
 // stream's forward held them all).  Block 0 also publishes row_begin and tile_key.  Integer sums: order-independent.
+// Round 4: this launch took 70-110 us of a C3 step's critical path (kernel trace, `profiles/scripts/gpu_timeline.sh c3`) — a
+// chain of G dependent L2 round trips per thread (one histogram row per thread, a load and two LDS atomics per group) and a
+// rank loop of up to 255 dependent LDS reads.  Now the histogram is summed with thread = (group, slice of the blocks), four
+// independent coalesced loads in flight and ONE pair of LDS atomics per thread, and a row's rank inside its block comes from
+// G wave ballots (rows of the same key in lower lanes) plus the lower waves' counts.
 __global__ void group_scatter_kernel(const int* __restrict__ key, int batch, int G, const int* __restrict__ block_hist,
                                      int n_blocks, int n_tiles, int dense, int* __restrict__ row_begin,
                                      int* __restrict__ tile_key, int* __restrict__ rowmap) {
-  __shared__ int keys[GR_BLOCK];
   __shared__ int total[GR_MAX_KEYS], base[GR_MAX_KEYS], tb[GR_MAX_KEYS];
-  const int tid = threadIdx.x, me = blockIdx.x, b = me * GR_BLOCK + tid;
+  __shared__ int wcount[GR_BLOCK / 64][GR_MAX_KEYS];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, me = blockIdx.x, b = me * GR_BLOCK + tid;
   for (int g = tid; g <= G; g += GR_BLOCK) total[g] = base[g] = 0;
   int k = b < batch ? key[b] : G;
   if (k < 0 || k > G) k = G;
-  keys[tid] = k;
   __syncthreads();
-  for (int blk = tid; blk < n_blocks; blk += GR_BLOCK) {
-    const int* h = block_hist + (long)blk * (G + 1);
-    for (int g = 0; g < G; ++g) {
-      const int c = h[g];
-      if (c) {
-        atomicAdd(&total[g], c);
-        if (blk < me) atomicAdd(&base[g], c);
+  {  // totals and base ranks: thread = (group g, slice s) sums the blocks s, s + S, ... (G < GR_BLOCK: GR_MAX_KEYS)
+    const int S = GR_BLOCK / G, g = tid % G, s = tid / G;
+    if (s < S) {
+      int t0 = 0, t1 = 0, t2 = 0, t3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      int blk = s;
+      for (; blk + 3 * S < n_blocks; blk += 4 * S) {
+        const int c0 = block_hist[(long)blk * (G + 1) + g], c1 = block_hist[(long)(blk + S) * (G + 1) + g];
+        const int c2 = block_hist[(long)(blk + 2 * S) * (G + 1) + g], c3 = block_hist[(long)(blk + 3 * S) * (G + 1) + g];
+        t0 += c0; t1 += c1; t2 += c2; t3 += c3;
+        b0 += blk < me ? c0 : 0; b1 += blk + S < me ? c1 : 0; b2 += blk + 2 * S < me ? c2 : 0; b3 += blk + 3 * S < me ? c3 : 0;
       }
+      for (; blk < n_blocks; blk += S) {
+        const int c = block_hist[(long)blk * (G + 1) + g];
+        t0 += c;
+        b0 += blk < me ? c : 0;
+      }
+      const int t = (t0 + t1) + (t2 + t3), bs = (b0 + b1) + (b2 + b3);
+      if (t) atomicAdd(&total[g], t);
+      if (bs) atomicAdd(&base[g], bs);
     }
+  }
+  // rank inside the block: rows of the same key in lower lanes of the wave (ballots), then the lower waves' counts
+  int in_wave = 0;
+  for (int g = 0; g < G; ++g) {
+    const unsigned long long m = wave_ballot(k == g);
+    if (k == g) in_wave = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcount[wv][g] = __builtin_popcountll(m);
   }
   __syncthreads();
   if (tid == 0) {
@@ -192,8 +243,8 @@ __global__ void group_scatter_kernel(const int* __restrict__ key, int batch, int
     }
   }
   if (k >= G) return;
-  int rank = base[k];
-  for (int i = 0; i < tid; ++i) rank += keys[i] == k ? 1 : 0;
+  int rank = base[k] + in_wave;
+  for (int w = 0; w < wv; ++w) rank += wcount[w][k];
   rowmap[tb[k] + rank] = b;
 }
 

@@ -56,6 +56,8 @@ __device__ __forceinline__ unsigned perm_bytes(unsigned hi, unsigned lo, unsigne
 // a value the program knows to be the same in every lane of the wave -> SGPR (scalar address math)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+// bit l = lane l's predicate (all 64 lanes of the wave take part)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl_idx(int v, int src) { return __shfl(v, src, 64); }
 

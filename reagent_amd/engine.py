@@ -618,7 +618,8 @@ def _side_stream(device):
 
 
 def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch.Tensor, dw: List[torch.Tensor],
-                           db: List[torch.Tensor], wgrad_ws: torch.Tensor, splits: int, two_streams: bool = False):
+                           db: List[torch.Tensor], wgrad_ws: torch.Tensor, splits: int, two_streams: bool = False,
+                           tail_sum=None):
     """Backward of the stack + grouped head from dz32 = d loss / d (head output) [grouped rows, group_rows]:
     one rg_mlp_backward_fused launch (the head's input gradient is its first layer step, per-tile W_g^T), the
     trunk's weight gradients by rg_mlp_wgrad_fused, the head's by rg_group_head_wgrad.  dw / db: all L layers."""
@@ -629,6 +630,10 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
     d = head.desc(st, space, False, True)
     for l in range(n):
         d.db[l] = db[l].data_ptr()
+    # the trunk's bias-gradient column reduce and the step's loss mean (tail_sum, FusedMLP.backward) ride in the reduce launch
+    # of the trunk's weight gradient: two launch-bound tails fewer on the step's critical path
+    fold = bool(st.fold_tails)
+    d.defer_db = int(fold)
     ops._run("rg_mlp_backward_fused", dict(B=R, dims=tuple(st.dims[:-1]) + (head.Ng,)),
              lambda: lib.rg_mlp_backward_fused(d, dz32.data_ptr(), dz32.stride(0), R, None, 0, head.bwd_ws.data_ptr(),
                                                head.bwd_ws.numel() * 4, L.stream_ptr()))
@@ -640,6 +645,16 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
     for l in range(n - 1):
         t.acts[l] = st.acts[l]
         t.act_frag[l], t.dz_frag[l], t.dw[l] = d.act_frag[l], d.dz_frag[l], dw[l].data_ptr()
+        if fold:
+            t.db[l] = db[l].data_ptr()
+    if fold:
+        t.db_partials = head.bwd_ws.data_ptr()
+    if tail_sum is not None:
+        part, scale, out = tail_sum
+        if fold:
+            t.sum_in, t.sum_n, t.sum_scale, t.sum_out = part.data_ptr(), part.numel(), float(scale), out.data_ptr()
+        else:
+            ops.reduce_sum(part, part.numel(), scale, out)
     ws = st._ws
     # the trunk is its own launch plan (the splits of a launch are shared out over ITS layers): its own workspace size
     need = lib.rg_mlp_wgrad_fused_workspace_bytes(t, R)

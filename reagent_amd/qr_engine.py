@@ -171,7 +171,6 @@ class GroupedQR:
         self.z = torch.empty(R, ldz, **f32)
         self.dz = torch.empty(R, ldz, **f32)
         self.loss_partials = torch.empty(R, **f32)
-        self.tile_losses = torch.empty(self.sp_cur.n_tiles, **f32)
         self.splits = 8
         nb = L.lib().rg_group_head_wgrad_workspace_bytes(A, N, H, self.splits)
         self.wg_ws = torch.empty(nb // 4, **f32)
@@ -223,8 +222,14 @@ class GroupedQR:
             tr.quantiles = tr.quantiles.to(dev)
         ops.qr_compact_head(self.z, self.zt, sp1.rowmap, self.key_cur, tr._f32c(b.reward).reshape(-1), boosts,
                             tr._f32c(b.not_terminal).reshape(-1), tr.gamma, gamma_exp, tr.quantiles.reshape(-1), B, self.N,
-                            self.dz, self.loss_partials, self.tile_losses)
-        ops.reduce_sum(self.tile_losses, self.tile_losses.numel(), 1.0, tr._loss)
+                            self.dz, self.loss_partials)
+        # the rows' loss terms (padding rows: 0) summed in fixed order — in the native step by the reduce launch of the trunk's
+        # weight gradient (round 4: the per-tile sums and their sum were two launch-bound launches, 13 us, between the loss
+        # head and the backward launch of every step), otherwise here
+        if getattr(tr, "_loss_tail_wanted", False):
+            tr._loss_tail = (self.loss_partials, 1.0, tr._loss)
+        else:
+            ops.reduce_sum(self.loss_partials, self.loss_partials.numel(), 1.0, tr._loss)
         tr._dq = self.dz
         self._all_q = None
         return tr._loss
@@ -245,6 +250,6 @@ class GroupedQR:
         return self._all_q
 
     # the trainer's `_qs.backward(dq, xt, dw, db)` contract
-    def backward(self, dq, xt, dw, db, **_):
+    def backward(self, dq, xt, dw, db, tail_sum=None, **_):
         fused_backward_grouped(self.online.st, self.online.gh, self.sp_cur, dq, dw, db, self.wg_ws, self.splits,
-                               two_streams=self.wgrad_streams)
+                               two_streams=self.wgrad_streams, tail_sum=tail_sum)

@@ -153,6 +153,13 @@ static inline float med3(float a, float b, float c) {
   const float lo = a < b ? a : b, hi = a < b ? b : a;
   return c < lo ? lo : (c > hi ? hi : c);
 }
+static inline unsigned long long wave_ballot(bool p) {
+  const int mine = p ? 1 : 0;
+  const int* all = (const int*)::emu::wave_gather(&mine, sizeof(int));
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) m |= (unsigned long long)(all[l] & 1) << l;
+  return m;
+}
 static inline float shfl_idx(float v, int src) { return gather_from(v, src); }
 static inline int shfl_idx(int v, int src) { return gather_from(v, src); }
 
