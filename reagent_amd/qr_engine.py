@@ -223,10 +223,18 @@ class GroupedQR:
         ops.qr_compact_head(self.z, self.zt, sp1.rowmap, self.key_cur, tr._f32c(b.reward).reshape(-1), boosts,
                             tr._f32c(b.not_terminal).reshape(-1), tr.gamma, gamma_exp, tr.quantiles.reshape(-1), B, self.N,
                             self.dz, self.loss_partials)
-        # the rows' loss terms (padding rows: 0) summed in fixed order — in the native step by the reduce launch of the trunk's
-        # weight gradient (round 4: the per-tile sums and their sum were two launch-bound launches, 13 us, between the loss
-        # head and the backward launch of every step), otherwise here
-        if getattr(tr, "_loss_tail_wanted", False):
+        # the rows' loss terms (padding rows: 0) summed in fixed order.  Nothing on the device waits for the loss, so in the native
+        # step the sum leaves the critical path: on the weight gradients' side stream, under the backward launch (joined where
+        # fused_backward_grouped joins that stream) — or, without it, in the reduce launch of the trunk's weight gradient.
+        # (Rounds 2-3: per-tile sums + their sum, two launch-bound launches = 13 us between the loss head and the backward.)
+        if getattr(tr, "_loss_tail_wanted", False) and state.is_cuda and self.wgrad_streams:
+            from .engine import _side_stream
+
+            side = _side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.reduce_sum(self.loss_partials, self.loss_partials.numel(), 1.0, tr._loss)
+        elif getattr(tr, "_loss_tail_wanted", False):
             tr._loss_tail = (self.loss_partials, 1.0, tr._loss)
         else:
             ops.reduce_sum(self.loss_partials, self.loss_partials.numel(), 1.0, tr._loss)
