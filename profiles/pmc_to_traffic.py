@@ -54,7 +54,9 @@ def main():
         raw[key] = {"fetch_size_kb_raw": round(total_f, 1), "write_size_kb_raw": round(total_w, 1)}
 
     fwd = [n for n in fetch if n.startswith("mlp_fwd_fused_kernel") or n.startswith("mlp_fwd_x3_kernel")]
-    bwd = [n for n in fetch if n.startswith("mlp_bwd_fused_kernel") or n.startswith("mlp_bwd_x3_kernel")]
+    # (round 4: the backward of a stack with a grouped output layer is its own instantiation, mlp_bwd_grouped_kernel)
+    bwd = [n for n in fetch if n.startswith(("mlp_bwd_grouped_kernel", "mlp_bwd_x3_grouped_kernel"))] or \
+          [n for n in fetch if n.startswith("mlp_bwd_fused_kernel") or n.startswith("mlp_bwd_x3_kernel")]
     # the weight gradient's second launch: reduce_tail_kernel (split reduce + bias column reduce + loss mean, round 3) or
     # reduce_group_kernel (split reduce alone)
     reduce_k = "reduce_tail_kernel" if "reduce_tail_kernel" in fetch else "reduce_group_kernel"
