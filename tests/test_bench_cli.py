@@ -126,7 +126,10 @@ def _measure_worker(rank, world, port, out_dir):
     # the instrumented pass is normalised to the timed one: per-call times add up to no more than the timed step
     ip = m["extra"]["instrumented_pass"]
     assert 0 < ip["scale"] <= 1.0 and ip["event_ms_per_step_sum"] > 0
-    assert sum(m["extra"]["per_call_ms_per_step"].values()) <= m["ms_per_step"] * 1.02 + 1e-3
+    # (the collective's span is this rank's wait for the slower rank as much as the transfer: it is reported, not part of the sum
+    # the normalisation holds to the timed step — bench.profile_summary leaves it out of event_ms_per_step_sum)
+    own = sum(v for k, v in m["extra"]["per_call_ms_per_step"].items() if not k.startswith("all_reduce"))
+    assert own <= m["ms_per_step"] * 1.02 + 1e-3, (m["extra"]["per_call_ms_per_step"], m["ms_per_step"], ip, m["per_rank"])
     keep = dict(value=m["value"], ms=m["ms_per_step"], regions=m["region_ms"], per_rank=m["per_rank"], launch=m["launch"],
                 loss=m["final_loss"], parity=m["parity"], x3_value=ma["value"], x3_loss=ma["final_loss"],
                 x3_parity=ma["parity"], shard=float(m["cols"]["observation"].double().sum()))
