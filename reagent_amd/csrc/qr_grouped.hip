@@ -287,11 +287,28 @@ struct CompactHeadArgs {
 // the sorted targets and their prefix sums go to the wave's own slice of LDS (the binary searches need random access).
 constexpr int QC_MAX_N = 256, QC_WAVES = 4;
 
-__global__ void qr_compact_head_kernel(CompactHeadArgs a) {
-  __shared__ float Ts[QC_WAVES][QC_MAX_N];
+// (94 registers = five waves per SIMD.  Forcing six / seven with amdgpu_waves_per_eu — 80 registers + 8 spilled, 72 + 18 —
+// measured 134-135 / 148-150 us against 130 on one box, `profiles/scripts/gpu_batch19.sh`: not kept.)
+__global__ void RG_LAUNCH_BOUNDS(QC_WAVES * 64, 1) qr_compact_head_kernel(CompactHeadArgs a) {
+  // Ts[1 + 256 w + e] = the e-th smallest target of wave w's row ([0] unused).  A bisection keeps its count c as a BYTE offset
+  // 1024 w + 4 c, so that the candidate count c + step is `offset | 4 * step` (disjoint bits) and at once the offset of
+  // T[c + step - 1] in the array: v_or, ds_read, v_cmp, v_cndmask per step (round 4; the shift-add that formed the address from
+  // a count was a fourth VALU operation in each of the 96 steps of a row's twelve bisections — measured: no change in the
+  // kernel's time, which is bound by a row's latency chain at five waves per SIMD as much as by issue)
+  __shared__ float Ts[1 + QC_WAVES * QC_MAX_N];
   __shared__ double P1[QC_WAVES][QC_MAX_N + 1], P2[QC_WAVES][QC_MAX_N + 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = a.N;
   const int r = blockIdx.x * QC_WAVES + wv;
+  // the row's own quantiles C_j, j = lane + 64 q: they depend on r alone, so they are requested FIRST and travel under the
+  // rowmap -> reward / targets chain and the sort (round 4: requested where the bisections start, their HBM round trip was
+  // exposed there — the kernel runs five waves per SIMD and is bound by a row's ~15k cycles of latency as much as by issue)
+  constexpr int QJ = QC_MAX_N / 64;
+  float cq[QJ];
+#pragma unroll
+  for (int q = 0; q < QJ; ++q) {
+    const int j = lane + 64 * q;
+    cq[q] = j < N ? a.z[(long)r * a.ldz + j] : 0.f;
+  }
   const int b = a.rowmap[r];
   float* dz = a.dz + (long)r * a.lddz;
   if (b < 0) {  // wave-uniform
@@ -348,29 +365,15 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     s1 += t;
     s2 += t * t;
   }
-  // inclusive scan of the lane totals across the wave, by shuffles (through LDS with a wave hand-off per step it was
-  // eighteen LDS round trips per row)
-  auto lane_read = [&](double x, int src) {
-    const long long bits = __builtin_bit_cast(long long, x);
-    const int lo = shfl_idx((int)bits, src), hi = shfl_idx((int)(bits >> 32), src);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
-  };
-  double i1 = s1, i2 = s2;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int src = lane >= off ? lane - off : lane;
-    const double a1 = lane_read(i1, src), a2 = lane_read(i2, src);
-    if (lane >= off) {
-      i1 += a1;
-      i2 += a2;
-    }
-  }
+  // inclusive scan of the lane totals across the wave by DPP moves (round 4; before: six steps of four ds_bpermute each, and
+  // through LDS with a wave hand-off per step before that)
+  const double i1 = wave_inclusive_sum_f64(s1), i2 = wave_inclusive_sum_f64(s2);
   const double base1 = i1 - s1, base2 = i2 - s2;  // totals of the lanes before this one
-  const double tot1 = lane_read(i1, 63), tot2 = lane_read(i2, 63);
+  const double tot1 = read_lane_f64<63>(i1), tot2 = read_lane_f64<63>(i2);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int e = lane * 4 + k;
-    Ts[wv][e] = v[k];
+    Ts[1 + wv * QC_MAX_N + e] = v[k];
     P1[wv][e] = base1 + t1[k];
     P2[wv][e] = base2 + t2[k];
   }
@@ -379,7 +382,8 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
     P2[wv][QC_MAX_N] = tot2;
   }
   wave_lds_sync();
-  const float* T = Ts[wv];
+  const char* Tb = (const char*)&Ts[0];
+  const int slice = wv * QC_MAX_N * 4;  // byte offset of this wave's slice
   const double* Q1 = P1[wv];
   const double* Q2 = P2[wv];
   const float inv = 1.f / ((float)N * (float)a.batch * (float)N);
@@ -389,30 +393,29 @@ __global__ void qr_compact_head_kernel(CompactHeadArgs a) {
   // twelve chains advancing in lock step, so that each of the eight rounds has twelve independent LDS reads in flight
   // instead of one (three searches after each other per quantile left the wave waiting on a chain of 24 dependent
   // reads; the counts, hence the results, are the same).
-  constexpr int QJ = QC_MAX_N / 64;
-  float cq[QJ];
-  int c1[QJ], c2[QJ], c3[QJ];
+  int c1[QJ], c2[QJ], c3[QJ];  // byte offsets: slice + 4 * count
 #pragma unroll
-  for (int q = 0; q < QJ; ++q) {
-    const int j = lane + 64 * q;
-    cq[q] = j < N ? a.z[(long)r * a.ldz + j] : 0.f;
-    c1[q] = c2[q] = c3[q] = 0;
-  }
+  for (int q = 0; q < QJ; ++q) c1[q] = c2[q] = c3[q] = slice;
 #pragma unroll
   for (int step = QC_MAX_N / 2; step >= 1; step >>= 1) {
 #pragma unroll
     for (int q = 0; q < QJ; ++q) {
-      const float t1 = T[c1[q] + step - 1], t2 = T[c2[q] + step - 1], t3 = T[c3[q] + step - 1];
-      c1[q] += t1 <= cq[q] - 1.f ? step : 0;
-      c2[q] += t2 < cq[q] ? step : 0;
-      c3[q] += t3 < cq[q] + 1.f ? step : 0;
+      const int n1 = c1[q] | (4 * step), n2 = c2[q] | (4 * step), n3 = c3[q] | (4 * step);  // count + step, as an address
+      const float t1 = *(const float*)(Tb + n1), t2 = *(const float*)(Tb + n2), t3 = *(const float*)(Tb + n3);
+      c1[q] = t1 <= cq[q] - 1.f ? n1 : c1[q];
+      c2[q] = t2 < cq[q] ? n2 : c2[q];
+      c3[q] = t3 < cq[q] + 1.f ? n3 : c3[q];
     }
   }
 #pragma unroll
-  for (int q = 0; q < QJ; ++q) {  // the bisection stops at 255: the last entry (a target only when N == 256)
-    c1[q] += (c1[q] == QC_MAX_N - 1 && T[QC_MAX_N - 1] <= cq[q] - 1.f) ? 1 : 0;
-    c2[q] += (c2[q] == QC_MAX_N - 1 && T[QC_MAX_N - 1] < cq[q]) ? 1 : 0;
-    c3[q] += (c3[q] == QC_MAX_N - 1 && T[QC_MAX_N - 1] < cq[q] + 1.f) ? 1 : 0;
+  for (int q = 0; q < QJ; ++q) {  // back to counts; the bisection stops at 255: the last entry (a target only when N == 256)
+    c1[q] = (c1[q] - slice) >> 2;
+    c2[q] = (c2[q] - slice) >> 2;
+    c3[q] = (c3[q] - slice) >> 2;
+    const float last = *(const float*)(Tb + slice + 4 * QC_MAX_N);
+    c1[q] += (c1[q] == QC_MAX_N - 1 && last <= cq[q] - 1.f) ? 1 : 0;
+    c2[q] += (c2[q] == QC_MAX_N - 1 && last < cq[q]) ? 1 : 0;
+    c3[q] += (c3[q] == QC_MAX_N - 1 && last < cq[q] + 1.f) ? 1 : 0;
   }
 #pragma unroll
   for (int q = 0; q < QJ; ++q) {

@@ -56,6 +56,31 @@ __device__ __forceinline__ unsigned perm_bytes(unsigned hi, unsigned lo, unsigne
 // a value the program knows to be the same in every lane of the wave -> SGPR (scalar address math)
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ float shfl_down(float v, int d) { return __shfl_down(v, d, 64); }
+// Inclusive prefix sum of a double over the 64 lanes by DPP moves (no LDS-pipe permutes): Kogge-Stone inside each row of 16
+// lanes (row_shr 1, 2, 4, 8: a source lane outside the row reads as 0), then lane 15 of rows 0 / 2 into rows 1 / 3
+// (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31).  A double moves as its two dwords.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_inclusive_sum_f64(double v) {
+  v += dpp_move_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_move_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_move_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_move_f64<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_move_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_move_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// lane `src`'s value (src a compile-time lane index), through a scalar register
+template <int SRC> __device__ __forceinline__ double read_lane_f64(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_readlane((int)b, SRC), hi = __builtin_amdgcn_readlane((int)(b >> 32), SRC);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 // bit l = lane l's predicate (all 64 lanes of the wave take part)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ float shfl_idx(float v, int src) { return __shfl(v, src, 64); }

@@ -153,6 +153,26 @@ static inline float med3(float a, float b, float c) {
   const float lo = a < b ? a : b, hi = a < b ? b : a;
   return c < lo ? lo : (c > hi ? hi : c);
 }
+// the device's DPP prefix sum, step by step in the same order (row_shr 1 / 2 / 4 / 8 inside rows of 16, row_bcast:15, row_bcast:31)
+static inline double wave_inclusive_sum_f64(double v) {
+  const int l = lane_id();
+  for (int sh = 1; sh <= 8; sh <<= 1) {
+    const double* all = (const double*)::emu::wave_gather(&v, sizeof(double));
+    const double src = (l & 15) >= sh ? all[l - sh] : 0.0;
+    v += src;
+  }
+  {
+    const double* all = (const double*)::emu::wave_gather(&v, sizeof(double));
+    const int row = l >> 4;
+    v += (row == 1 || row == 3) ? all[(row - 1) * 16 + 15] : 0.0;
+  }
+  {
+    const double* all = (const double*)::emu::wave_gather(&v, sizeof(double));
+    v += (l >= 32) ? all[31] : 0.0;
+  }
+  return v;
+}
+template <int SRC> static inline double read_lane_f64(double x) { return gather_from(x, SRC); }
 static inline unsigned long long wave_ballot(bool p) {
   const int mine = p ? 1 : 0;
   const int* all = (const int*)::emu::wave_gather(&mine, sizeof(int));
