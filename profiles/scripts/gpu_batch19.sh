@@ -4,8 +4,8 @@
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
 timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 timeout 600 python -m pytest tests/test_qrdqn_trainer.py tests/test_baseline_shapes.py -m gpu -q --no-header -p no:cacheprovider -k "qrdqn or c3 or grouped or compact" 2>&1 | tail -2
-for rep in 1 2; do
-for lib in lib_prev lib lib_w6 lib_w7; do
+for rep in 1 2 3; do
+for lib in lib_prev lib; do
   RG_LIB=reagent_amd/$lib/libreagent_hip.so timeout 600 python bench.py --config c3 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-accurate --no-also --no-parity --sustained-steps 0 --launch eager --no-graph > $OUT/b19.json 2> $OUT/b19.err || tail -5 $OUT/b19.err
   python - "$lib" <<'PY'
 import json, sys
