@@ -1,5 +1,6 @@
 #!/bin/bash
 # round check in one call: smoke, pytest -m gpu, the driver's default bench command, rocprofv3 kernel stats of C2 bf16 / bf16x3
+# (320 steps: a 13-step run averages in the clock ramp of a cold GPU — first launches 114 us against 83 steady)
 # bash profiles/scripts/gpu_round.sh <tag> [notest] [norocprof]
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT; TAG=${1:-r03}
 timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
@@ -13,7 +14,7 @@ bash profiles/scripts/gpu_default_bench.sh $TAG
 [ "$3" == "norocprof" ] && exit 0
 for spec in "c2 bf16" "c2 bf16x3"; do
   set -- $spec; prec=$1_$2
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${prec}_$TAG -o bench -- python /root/repo/bench.py --config $1 --precision $2 --repeats 1 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also --sustained-steps 0 --launch eager > $OUT/rocprof_${prec}_$TAG.log 2>&1; echo "rocprof $prec rc=$?")
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${prec}_$TAG -o bench -- python /root/repo/bench.py --config $1 --precision $2 --repeats 1 --steps 300 --warmup 20 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also --sustained-steps 0 --launch eager > $OUT/rocprof_${prec}_$TAG.log 2>&1; echo "rocprof $prec rc=$?")
   for f in $(find $OUT/prof_${prec}_$TAG -name "*kernel_stats.csv" | head -1); do head -16 $f | cut -c1-200; done
-  find $OUT/prof_${prec}_$TAG -name "*kernel_trace.csv" -size +20M -delete
+  find $OUT/prof_${prec}_$TAG -name "*kernel_trace.csv" -delete
 done
