@@ -610,7 +610,9 @@ def fused_forward_grouped(st: "FusedMLP", head: GroupedHead, x: torch.Tensor, sp
 _side_streams = {}
 
 
-def _side_stream(device):
+def side_stream(device):
+    """the engine's second HIP stream of `device` (the grouped head's weight gradient, the QR step's loss sum): one per device,
+    joined by whoever forks it (fused_backward_grouped)"""
     key = (device.type, device.index)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
@@ -666,7 +668,7 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
     side = None
     if dz32.is_cuda and two_streams:
         main = torch.cuda.current_stream()
-        side = _side_stream(dz32.device)
+        side = side_stream(dz32.device)
         side.wait_stream(main)
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         ops.group_head_wgrad(head.dz_frag, ws["act_frag"][n - 1], space.row_begin, head.G, head.Ng, head.H, splits, dw[n - 1],

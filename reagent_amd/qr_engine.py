@@ -228,9 +228,9 @@ class GroupedQR:
         # fused_backward_grouped joins that stream) — or, without it, in the reduce launch of the trunk's weight gradient.
         # (Rounds 2-3: per-tile sums + their sum, two launch-bound launches = 13 us between the loss head and the backward.)
         if getattr(tr, "_loss_tail_wanted", False) and state.is_cuda and self.wgrad_streams:
-            from .engine import _side_stream
+            from .engine import side_stream
 
-            side = _side_stream(dev)
+            side = side_stream(dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ops.reduce_sum(self.loss_partials, self.loss_partials.numel(), 1.0, tr._loss)
