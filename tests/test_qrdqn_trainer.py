@@ -344,7 +344,7 @@ def test_grouped_fused_update_equals_separate_launches(backend, rl, double_q, N)
 
 
 @pytest.mark.parametrize("dense", [True, False])
-@pytest.mark.parametrize("B,G", [(1000, 5), (37, 3), (4096, 16), (300, 40)])
+@pytest.mark.parametrize("B,G", [(1000, 5), (37, 3), (4096, 16), (300, 40), (1500, 129)])  # 129: the most groups the kernels take
 def test_grouped_space_layout(backend, B, G, dense):
     """dense: the groups follow each other without padding (ceil(B / 128) tiles); otherwise every group starts on a tile.
     (300, 40): groups of ~7 rows — a tile holds many groups, and some groups are empty"""
