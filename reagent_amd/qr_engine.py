@@ -171,7 +171,11 @@ class GroupedQR:
         self.z = torch.empty(R, ldz, **f32)
         self.dz = torch.empty(R, ldz, **f32)
         self.loss_partials = torch.empty(R, **f32)
-        self.splits = 8
+        # batch splits of a group's head weight gradient: A groups x 2 k-groups x splits workgroups, run beside the trunk's
+        # weight gradient on the other stream.  Round 4, same box, C3 step in ms (bf16 / split-bf16): 16 splits 0.936 / 1.566,
+        # 8 (rounds 2-4) 0.916 / 1.553, **4: 0.896 / 1.542**, 2: 0.902 / 1.564 — half the partial slabs (26 MB) and half of
+        # their reduce launch against workgroups twice as long (`profiles/scripts/gpu_batch21.sh`)
+        self.splits = int(os.environ.get("RG_QR_HEAD_SPLITS", "4"))
         nb = L.lib().rg_group_head_wgrad_workspace_bytes(A, N, H, self.splits)
         self.wg_ws = torch.empty(nb // 4, **f32)
         self._B = B
