@@ -259,6 +259,54 @@ def test_c3_step_against_the_oracle_at_the_host_limit(monkeypatch):
     assert out["meets_north_star"] and out["ok"], out
 
 
+def test_c3_grouped_engine_equals_the_dense_path_at_full_size():
+    """BASELINE config 3 at its FULL batch (B = 65 536, 16 actions x 200 quantiles, 128-512-512): the reference formula's (N, B, N)
+    tensor does not fit the host there, so the size-independent property carries the parity — the grouped engine (dense grouped
+    spaces: 512 tiles, 15 of them holding the end of one action's rows and the start of the next) in split-bf16 against the DENSE
+    [B, A * N] path of the same trainer, whose head runs exact-fp32 GEMMs and which the goldens pin to the reference: logged-action
+    quantiles of every row within 1e-4, per-action means within 1e-4, loss within 1e-5 relative, every gradient within the
+    split-bf16 bound."""
+    import test_qrdqn_trainer as T
+    from reagent_amd import _lib as L
+    from reagent_amd import synthetic
+    from reagent_amd.qr_engine import GroupedQR
+
+    dev = torch.device("cuda:0")
+    S, A, N = 128, 16, 200
+    rl = dict(gamma=0.99, target_update_rate=0.001, maxq_learning=True)
+    tg, td = T._qr_pair(dev, S, A, N, [512, 512], rl, True, precision=L.PREC_BF16X3)
+    assert GroupedQR.eligible(tg)
+
+    class Reporter:  # with a reporter attached all_q_values is evaluated inside the step, with the step's weights
+        def log(self, **kw):
+            pass
+
+    tg.set_reporter(Reporter())
+    b = synthetic.dqn_batch(B, S, A, seed=77, p_impossible=0.3)
+    g = torch.Generator().manual_seed(9)
+    forced = torch.nn.functional.one_hot(torch.randint(A, (B,), generator=g), A).float()
+    b1 = dict(b, possible_next_actions_mask=forced, next_action=forced * b["not_terminal"])  # a* forced: same targets on both sides
+    batch = synthetic.to_dqn_input(b1, dev)
+    with torch.no_grad():
+        z_ref = td.q_network(batch.state)  # [B, A, N], exact fp32 head
+    lg, ld = tg.train_step_native(batch), td.train_step_native(batch)
+    gq = tg._gq_active
+    assert gq is not None and gq.x3 and gq.dense and gq.sp_cur.n_tiles == B // 128 and getattr(td, "_gq_active", None) is None
+    rb = gq.sp_cur.row_begin.cpu()
+    assert sum(int(rb[a]) % 128 != 0 for a in range(1, A)) >= A - 3  # (nearly) every action's rows start inside a tile
+    assert abs(lg.item() - ld.item()) <= 1e-5 * abs(ld.item()), (lg.item(), ld.item())
+    rowmap, key = gq.sp_cur.rowmap.long(), gq.key_cur.long()
+    live = rowmap >= 0
+    rows = rowmap[live]
+    assert int(live.sum()) == B
+    dz = (gq.z[live][:, :N] - z_ref[rows, key[rows]]).abs().max().item()
+    dq = (tg.all_q_values - z_ref.mean(dim=2)).abs().max().item()
+    assert dz <= 1e-4 and dq <= 1e-4, (dz, dq)
+    for i, (x, y) in enumerate(zip(tg._slab.grad_views(), td._slab.grad_views())):
+        rel = ((x - y).abs().max() / (y.abs().max() + 1e-30)).item()
+        assert rel <= 3e-3, (i, rel)
+
+
 def test_c4_step_against_the_oracle_at_full_size(monkeypatch):
     """BASELINE config 4 (SAC, S = 256, A = 32, actor + twin critics, 3 x 512) at B = 65 536 in split-bf16 mode: policy
     logits (loc, scale_log) within 1e-4 of oracle/restated.py on every row, the three losses within 1e-4 relative, gather
