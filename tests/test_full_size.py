@@ -259,13 +259,15 @@ def test_c3_step_against_the_oracle_at_the_host_limit(monkeypatch):
     assert out["meets_north_star"] and out["ok"], out
 
 
-def test_c3_grouped_engine_equals_the_dense_path_at_full_size():
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_c3_grouped_engine_equals_the_dense_path_at_full_size(mode):
     """BASELINE config 3 at its FULL batch (B = 65 536, 16 actions x 200 quantiles, 128-512-512): the reference formula's (N, B, N)
     tensor does not fit the host there, so the size-independent property carries the parity — the grouped engine (dense grouped
     spaces: 512 tiles, 15 of them holding the end of one action's rows and the start of the next) in split-bf16 against the DENSE
     [B, A * N] path of the same trainer, whose head runs exact-fp32 GEMMs and which the goldens pin to the reference: logged-action
     quantiles of every row within 1e-4, per-action means within 1e-4, loss within 1e-5 relative, every gradient within the
-    split-bf16 bound."""
+    split-bf16 bound.  mode bf16 (the throughput mode): the same against the dense bf16 path — same trunk kernels on both sides, so
+    the comparison isolates the grouped machinery at full size; bounds are the bf16 ones of tests/test_qrdqn_trainer.py."""
     import test_qrdqn_trainer as T
     from reagent_amd import _lib as L
     from reagent_amd import synthetic
@@ -274,7 +276,8 @@ def test_c3_grouped_engine_equals_the_dense_path_at_full_size():
     dev = torch.device("cuda:0")
     S, A, N = 128, 16, 200
     rl = dict(gamma=0.99, target_update_rate=0.001, maxq_learning=True)
-    tg, td = T._qr_pair(dev, S, A, N, [512, 512], rl, True, precision=L.PREC_BF16X3)
+    x3 = mode == "bf16x3"
+    tg, td = T._qr_pair(dev, S, A, N, [512, 512], rl, True, precision=L.PREC_BF16X3 if x3 else L.PREC_BF16)
     assert GroupedQR.eligible(tg)
 
     class Reporter:  # with a reporter attached all_q_values is evaluated inside the step, with the step's weights
@@ -291,20 +294,24 @@ def test_c3_grouped_engine_equals_the_dense_path_at_full_size():
         z_ref = td.q_network(batch.state)  # [B, A, N], exact fp32 head
     lg, ld = tg.train_step_native(batch), td.train_step_native(batch)
     gq = tg._gq_active
-    assert gq is not None and gq.x3 and gq.dense and gq.sp_cur.n_tiles == B // 128 and getattr(td, "_gq_active", None) is None
+    assert gq is not None and gq.x3 == x3 and gq.dense and gq.sp_cur.n_tiles == B // 128 and getattr(td, "_gq_active", None) is None
     rb = gq.sp_cur.row_begin.cpu()
     assert sum(int(rb[a]) % 128 != 0 for a in range(1, A)) >= A - 3  # (nearly) every action's rows start inside a tile
-    assert abs(lg.item() - ld.item()) <= 1e-5 * abs(ld.item()), (lg.item(), ld.item())
+    assert abs(lg.item() - ld.item()) <= (1e-5 if x3 else 1e-4) * abs(ld.item()), (lg.item(), ld.item())
     rowmap, key = gq.sp_cur.rowmap.long(), gq.key_cur.long()
     live = rowmap >= 0
     rows = rowmap[live]
     assert int(live.sum()) == B
     dz = (gq.z[live][:, :N] - z_ref[rows, key[rows]]).abs().max().item()
     dq = (tg.all_q_values - z_ref.mean(dim=2)).abs().max().item()
-    assert dz <= 1e-4 and dq <= 1e-4, (dz, dq)
+    assert dz <= (1e-4 if x3 else 3e-2) and dq <= (1e-4 if x3 else 3e-2), (dz, dq)
     for i, (x, y) in enumerate(zip(tg._slab.grad_views(), td._slab.grad_views())):
-        rel = ((x - y).abs().max() / (y.abs().max() + 1e-30)).item()
-        assert rel <= 3e-3, (i, rel)
+        if x3:
+            rel = ((x - y).abs().max() / (y.abs().max() + 1e-30)).item()
+            assert rel <= 3e-3, (i, rel)
+        else:  # bf16 rounding of dZ at different points of the two backward paths
+            rel = ((x - y).norm() / (y.norm() + 1e-12)).item()
+            assert rel <= 1e-2, (i, rel)
 
 
 def test_c4_step_against_the_oracle_at_full_size(monkeypatch):
