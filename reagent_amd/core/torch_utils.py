@@ -4,11 +4,9 @@ import torch
 
 
 def masked_softmax(x: torch.Tensor, mask: torch.Tensor, temperature: float) -> torch.Tensor:
-    """reagent/core/torch_utils.py:62-73"""
-    x = x / temperature
-    mask_min_x = x - ((1.0 - mask) * 1e20)
-    mask_min_x = mask_min_x - torch.max(mask_min_x, dim=1, keepdim=True)[0]
-    e_x = torch.exp(mask_min_x) * mask
-    out = e_x / e_x.sum(dim=1, keepdim=True)
-    out[out != out] = 0  # a fully masked row
-    return out
+    """Softmax of x / temperature over the entries `mask` keeps, rows with nothing kept -> zeros
+    (the arithmetic, operation for operation, of reagent/core/torch_utils.py:62-73)."""
+    logits = x / temperature - (1.0 - mask) * 1e20  # dropped entries far below any kept one
+    weights = (logits - logits.max(dim=1, keepdim=True).values).exp() * mask
+    probs = weights / weights.sum(dim=1, keepdim=True)
+    return torch.where(torch.isnan(probs), torch.zeros_like(probs), probs)  # 0 / 0 of a fully masked row

@@ -613,7 +613,8 @@ _side_streams = {}
 def side_stream(device):
     """the engine's second HIP stream of `device` (the grouped head's weight gradient, the QR step's loss sum): one per device,
     joined by whoever forks it (fused_backward_grouped)"""
-    key = (device.type, device.index)
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())  # "cuda" == "cuda:<current>"
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]

@@ -238,6 +238,9 @@ class GroupedQR:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ops.reduce_sum(self.loss_partials, self.loss_partials.numel(), 1.0, tr._loss)
+                # whoever hands tr._loss out waits for THIS (train_step_native's finally): the join inside
+                # fused_backward_grouped only happens when that backward runs, with two_streams on
+                tr._loss_side_event = side.record_event()
         elif getattr(tr, "_loss_tail_wanted", False):
             tr._loss_tail = (self.loss_partials, 1.0, tr._loss)
         else:

@@ -234,12 +234,24 @@ class ReplayBuffer:
         n0 = 0 if (self.is_empty() or self._terminal_host[last_idx]) else self._num_transitions_in_current_episode
         pos = (c0 + np.arange(T)) % C
         # ---- rows: one indexed copy per column
-        pos_dev = torch.from_numpy(pos).to(self.device)
+        # every column is checked BEFORE the first copy: a bad column late in the dict must not leave earlier columns
+        # half-written over valid transitions.  Types follow `add` (np.array(v, dtype=...) there: same-kind conversions
+        # only — a float column into an integer element would truncate silently).
+        staged = {}
         for k, v in columns.items():
             col = self._store[k]
-            src = torch.as_tensor(v).to(device=col.device, dtype=col.dtype)
-            assert src.shape == (T, *col.shape[1:]), f"add_many: {k} has shape {tuple(src.shape)}, expected {(T, *col.shape[1:])}"
-            col.index_copy_(0, pos_dev, src)
+            src = torch.as_tensor(v)
+            if tuple(src.shape) != (T, *col.shape[1:]):
+                raise ValueError(f"add_many: {k} has shape {tuple(src.shape)}, expected {(T, *col.shape[1:])}")
+            if k != "terminal" and src.dtype != col.dtype:
+                float_to_int = src.dtype.is_floating_point and not col.dtype.is_floating_point
+                if float_to_int or src.dtype == torch.bool or col.dtype == torch.bool:
+                    raise ValueError(f"add_many: {k} arrives as {src.dtype}, the buffer stores {col.dtype}")
+            staged[k] = src
+        pos_dev = torch.from_numpy(pos).to(self.device)
+        for k, src in staged.items():
+            col = self._store[k]
+            col.index_copy_(0, pos_dev, src.to(device=col.device, dtype=col.dtype))
         # ---- validity (the rules of add, :491-522, for stack_size 1)
         # k[t]: transitions of t's episode before t;  at add t: valid[pos t] = False; if k[t] >= h: valid[pos t - h] = True;
         # at a terminal t: the last min(k[t] + 1, h) indices of the episode become valid.  An index ends up valid iff one

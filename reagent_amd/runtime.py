@@ -115,6 +115,9 @@ class _GraphedLoop:
             extras=tr.checkpoint_extras() if hasattr(tr, "checkpoint_extras") else None,
             # the undrawn rest of the index pool: the continuation draws what this loop would have drawn
             index_pool=None if self._pool is None else dict(pool=self._pool[self._pool_pos:].cpu(), key=self._pool_key),
+            # the valid-slot count the last draw saw: it decides whether the NEXT step draws from a pool or lets the buffer
+            # draw (a still-filling store), so the continuation has to start from the same value
+            index_pool_n=self._pool_n,
         )
 
     def load_checkpoint(self, ckpt: dict):
@@ -140,6 +143,7 @@ class _GraphedLoop:
         ip = ckpt.get("index_pool")
         self._pool = self._pool_key = None
         self._pool_pos = 0
+        self._pool_n = ckpt.get("index_pool_n")  # None (older checkpoints / a loop that never drew): the first draw sets it
         if ip is not None and ip["pool"].shape[0] > 0:
             # the rest is shorter than a full pool: it is used up, then a fresh pool is drawn from the restored RNG
             # state — exactly what the saved loop would have done
@@ -163,17 +167,26 @@ class _GraphedLoop:
         dev = torch.device(self.rb.device)
         if dev.type != "cuda":
             raise RuntimeError("HIP graphs need the GPU")
+        # every argument error BEFORE the trainer is switched to graph mode, warmed up or captured
+        n_steps = max(1, int(steps_per_replay))
+        dp = getattr(tr, "_dp_group", None) is not None
+        pooled = not static_indices and self.index_pool_steps > 1
+        if n_steps > 1:
+            if dp or not pooled or type(self)._cursor_protocol is _GraphedLoop._cursor_protocol:
+                raise NotImplementedError("steps_per_replay > 1 needs the device-side index cursor (DQN-family loop, one-launch sampler and update)")
+            if self.index_pool_steps % n_steps:
+                raise ValueError(f"steps_per_replay {n_steps} must divide index_pool_steps {self.index_pool_steps}")
+        if dp and not hasattr(tr, "native_forward_backward"):
+            raise NotImplementedError("data-parallel graph replay is built for the DQN-family native step")
         enable_graph_mode(tr)
         for _ in range(max(2, warmup)):  # eager: allocations, optimizer state, first-step staging; the step
             self.step()                  # after these is the steady-state launch sequence
         self.flush()
         torch.cuda.synchronize()
-        dp = getattr(tr, "_dp_group", None) is not None
         # Indices: a persistent buffer the captured sampler reads.  Filled by the caller (static_indices) or, by default,
         # from the loop's index pool right before each replay (one 512 KB device copy) — the in-graph torch.randint was
         # THREE kernel nodes (Philox offset bookkeeping + the draw: ~23 us per step, what made the replayed C2 step
         # slower than eager launches).  index_pool_steps <= 1 keeps the draw inside the graph.
-        pooled = not static_indices and self.index_pool_steps > 1
         idx = torch.zeros(self.batch_size, dtype=torch.int64, device=dev) if (static_indices or pooled) else None
         done = tr.all_batches_processed
         cursor = None
@@ -189,9 +202,6 @@ class _GraphedLoop:
 
                 cursor = tick["cursor"]
                 tr._graph_tick = tick
-                n_steps = max(1, int(steps_per_replay))
-                if self.index_pool_steps % n_steps:
-                    raise ValueError(f"steps_per_replay {n_steps} must divide index_pool_steps {self.index_pool_steps}")
                 try:
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         for _ in range(n_steps):
@@ -207,8 +217,6 @@ class _GraphedLoop:
                     out = self._eager_step(idx, **extra)
             graphs = (g,)
         else:
-            if not hasattr(tr, "native_forward_backward"):
-                raise NotImplementedError("data-parallel graph replay is built for the DQN-family native step")
             pool = torch.cuda.graph_pool_handle()
             gs, gu, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(gs, pool=pool, capture_error_mode="thread_local"):  # captured in replay order (shared pool)
@@ -220,9 +228,11 @@ class _GraphedLoop:
             graphs = (gs, gu, gc)
             self._graph_batch = batch
         tr.all_batches_processed = done  # the capture call ran the host side of a step, not the step
-        n_steps = max(1, int(steps_per_replay)) if cursor is not None else 1
-        if steps_per_replay > 1 and cursor is None:
-            raise NotImplementedError("steps_per_replay > 1 needs the device-side index cursor (DQN-family loop, one-launch sampler and update)")
+        if cursor is None:
+            if n_steps > 1:  # the loop's cursor protocol declined at capture time (checked above; kept as a guard)
+                self.release_graph()
+                raise NotImplementedError("steps_per_replay > 1 needs the device-side index cursor (DQN-family loop, one-launch sampler and update)")
+            n_steps = 1
         self._graph = dict(graphs=graphs, out=out, idx=idx, dp=dp, pending=None, pooled=pooled, extra=extra if not dp else {},
                            cursor=cursor, dev_pos=None, pool_ptr=self._pool.data_ptr() if cursor is not None else None,
                            steps=n_steps)

@@ -436,6 +436,15 @@ class QStepCore(DQNTrainerBaseLightning):
     _loss_tail_wanted = False
     _loss_tail = None
 
+    _loss_side_event = None  # recorded after a loss sum that ran on the engine's side stream (qr_engine.py)
+
+    def _join_loss_side(self):
+        """the current stream waits for a loss sum enqueued on the side stream — whether or not the backward that
+        normally joins that stream ran"""
+        ev, self._loss_side_event = self._loss_side_event, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def _take_loss_tail(self) -> dict:
         tail, self._loss_tail = self._loss_tail, None
         return {"tail_sum": tail} if tail is not None else {}
@@ -488,8 +497,11 @@ class QStepCore(DQNTrainerBaseLightning):
         for p in self._hip_params:
             p.grad = None
         deferred = defer_update and self._dp_group is not None
-        with _NativeStep(self):
-            self._hip_backward(None, async_reduce=deferred)
+        try:
+            with _NativeStep(self):
+                self._hip_backward(None, async_reduce=deferred)
+        finally:
+            self._join_loss_side()
         self._update_pending = True
         self._pending_batch = (training_batch if getattr(self, "_cpe", None) is not None or self._q_has_batch_norm()
                                else None)
@@ -514,9 +526,12 @@ class QStepCore(DQNTrainerBaseLightning):
             self._loss_tail_wanted = False
         for p in self._hip_params:
             p.grad = None
-        with _NativeStep(self):
-            self._qs.backward(self._dq, self._xs_t, self._dw, self._db, **self._take_loss_tail())
-            publish_gradients(self._slab, self._hip_params)
+        try:
+            with _NativeStep(self):
+                self._qs.backward(self._dq, self._xs_t, self._dw, self._db, **self._take_loss_tail())
+                publish_gradients(self._slab, self._hip_params)
+        finally:
+            self._join_loss_side()
         return loss
 
     @torch.no_grad()

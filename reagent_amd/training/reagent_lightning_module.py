@@ -85,30 +85,33 @@ class ReAgentLightningModule(nn.Module):
         pass
 
     def training_step(self, batch, batch_idx: int, optimizer_idx: int = 0):
-        assert (optimizer_idx == 0) or (self._num_optimizing_steps > 1)
-
-        if self._training_step_generator is None:
-            if self._training_batch_type and isinstance(batch, dict):
+        """The generator-per-batch protocol of reagent_lightning_module.py:108-130: call k of a batch returns the k-th loss
+        `train_step_gen` yields; the call for the last optimizer closes the batch (and, once per module, checks that the
+        generator has nothing left)."""
+        n_opt = self._num_optimizing_steps
+        assert optimizer_idx == 0 or n_opt > 1
+        gen = self._training_step_generator
+        if gen is None:  # first optimizer of a new batch
+            if isinstance(batch, dict) and self._training_batch_type:
                 batch = self._training_batch_type.from_dict(batch)
-            self._training_step_generator = self.train_step_gen(batch, batch_idx)
+            gen = self._training_step_generator = self.train_step_gen(batch, batch_idx)
+        loss = next(gen)
+        if optimizer_idx != n_opt - 1:
+            return loss
+        if not self._verified_steps:
+            self._require_exhausted(gen, n_opt)
+        self._training_step_generator = None
+        self.all_batches_processed += 1
+        return loss
 
-        ret = next(self._training_step_generator)
-
-        if optimizer_idx == self._num_optimizing_steps - 1:
-            if not self._verified_steps:
-                try:
-                    next(self._training_step_generator)
-                except StopIteration:
-                    self._verified_steps = True
-                if not self._verified_steps:
-                    raise RuntimeError(
-                        "training_step_gen() yields too many times."
-                        "The number of yields should match the number of optimizers,"
-                        f" in this case {self._num_optimizing_steps}"
-                    )
-            self._training_step_generator = None
-            self.all_batches_processed += 1
-        return ret
+    def _require_exhausted(self, gen, n_opt: int):
+        """one loss per optimizer, no more (checked on the first batch only, like the reference)"""
+        leftover = object()
+        if next(gen, leftover) is not leftover:
+            raise RuntimeError("training_step_gen() yields too many times."
+                               "The number of yields should match the number of optimizers,"
+                               f" in this case {n_opt}")
+        self._verified_steps = True
 
     @property
     def _num_optimizing_steps(self) -> int:

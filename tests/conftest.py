@@ -10,6 +10,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# The class under test is the package's OWN restatement of the rlt containers on every box (build container and GPU box
+# alike): core/types.py would otherwise hand out the reference's classes wherever `reagent` happens to be importable.
+# The tests of that re-export strip the variable for their subprocesses.
+os.environ.setdefault("REAGENT_AMD_OWN_TYPES", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

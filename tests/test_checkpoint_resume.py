@@ -157,3 +157,62 @@ def test_index_pool_draws_are_uniform_picks_of_valid_slots(emu_lib):
         rb._num_valid_indices, rb._valid_dirty = n, True
         assert loop._draw_indices() is None
 
+
+
+def test_dqn_loop_resumes_bit_identically_while_the_buffer_is_still_filling(emu_lib, tmp_path):
+    """interleaved add / train.  While the count of valid slots moves, the BUFFER draws a step's indices
+    (`_pool_n` gate in _draw_indices); a restored loop must take the same branch on its first step — `_pool_n` travels
+    in the checkpoint — or it would draw a whole index pool from the RNG where the uninterrupted run drew B indices."""
+    from reagent_amd.runtime import OfflineDqnLoop
+
+    S, A = 12, 4
+    cols = synthetic.replay_contents(400, S, A, seed=21, p_terminal=0.05)
+
+    def row(i):
+        return dict(observation=cols["observation"][i].numpy(), action=int(cols["action"][i]), reward=float(cols["reward"][i]),
+                    terminal=bool(cols["terminal"][i]), possible_actions_mask=cols["possible_actions_mask"][i].numpy(),
+                    log_prob=float(cols["log_prob"][i]))
+
+    def make(seed=0, adds=100):
+        loop0, tr = _dqn_loop(seed)
+        rb = ReplayBuffer(replay_capacity=256, batch_size=loop0.batch_size, device="cpu")
+        for i in range(adds):
+            rb.add(**row(i))
+        loop = OfflineDqnLoop(rb, tr, loop0.batch_size, loop0.pre)
+        loop.index_pool_steps = 4
+        return loop, tr
+
+    def advance(loop, start, steps, adds_per_step=(2, 2, 0, 0, 0, 3)):
+        n = start
+        for k in range(steps):
+            for _ in range(adds_per_step[k % len(adds_per_step)]):
+                loop.rb.add(**row(n))
+                n += 1
+            loop.step()
+        return n
+
+    loop, tr = make()
+    torch.manual_seed(123)
+    n = advance(loop, 100, 4)  # steps 0,1 see a moving count (buffer draws), 2,3 a steady one (pool of 4 drawn at step 3)
+    path = str(tmp_path / "filling.ckpt")
+    loop.save(path)
+    assert loop._pool_n is not None
+    n_end = advance(loop, n, 6)
+    loop.flush()
+    want = _state(tr)
+    loop2, tr2 = make(seed=77, adds=n)
+    torch.manual_seed(999)
+    loop2.load(path)
+    assert loop2._pool_n == torch.load(path, weights_only=False)["index_pool_n"]
+    assert advance(loop2, n, 6) == n_end
+    loop2.flush()
+    got = _state(tr2)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # without the saved gate the continuation diverges (what the finding described)
+    loop3, tr3 = make(seed=77, adds=n)
+    loop3.load(path)
+    loop3._pool_n = None
+    advance(loop3, n, 6)
+    loop3.flush()
+    assert any(not torch.equal(v, want[k]) for k, v in _state(tr3).items())

@@ -177,3 +177,27 @@ def test_head_lane_layouts_against_torch(backend, A, B, double_q, loss):
     assert torch.equal(qsel.cpu(), qs.detach())
     assert abs(parts.sum().item() / B - ref.item()) <= 1e-5 * abs(ref.item()) + 1e-7
     assert (dq.cpu() - qr.grad).abs().max() <= 1e-7
+
+
+def test_masked_softmax_matches_the_reference_function_bit_for_bit():
+    """core/torch_utils.masked_softmax is a restatement; where the reference tree is present (build container) it must give
+    the reference function's bits, everywhere it must be a softmax over the kept entries with zero rows for empty masks."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 7, generator=g) * 4
+    mask = (torch.rand(64, 7, generator=g) < 0.6).float()
+    mask[3] = 0.0
+    mask[4] = 1.0
+    for temp in (1.0, 0.35, 10.0):
+        got = masked_softmax(x, mask, temp)
+        assert torch.equal(got[3], torch.zeros(7)) and not torch.isnan(got).any()
+        live = mask.sum(1) > 0
+        assert torch.allclose(got[live].sum(1), torch.ones(int(live.sum())), atol=1e-6)
+        assert torch.equal(got * (1 - mask), torch.zeros_like(got))
+        assert torch.allclose(got[4], torch.softmax(x[4] / temp, dim=0), atol=1e-6)
+        from oracle import stubs
+
+        if stubs.reference_available():
+            stubs.install()
+            from reagent.core.torch_utils import masked_softmax as ref_fn
+
+            assert torch.equal(got, ref_fn(x, mask, temp))

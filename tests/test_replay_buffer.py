@@ -635,3 +635,32 @@ def test_add_many_equals_the_same_transitions_added_one_by_one(backend, horizon)
     for x, y in zip(a, b):
         if isinstance(x, torch.Tensor):
             assert torch.equal(x, y)
+
+
+def test_add_many_rejects_a_bad_column_before_touching_the_ring(emu_lib):
+    """every column's shape and dtype is checked before the first copy — a bad column late in the dict must not
+    leave earlier columns overwritten over transitions still marked valid; a float column for an integer element is an
+    error as it is for `add`, not a silent truncation."""
+    import numpy as np
+
+    from reagent_amd.replay_memory import ReplayBuffer
+
+    rng = np.random.default_rng(3)
+    rb = ReplayBuffer(replay_capacity=16, batch_size=2, device="cpu")
+    good = lambda T: dict(observation=torch.from_numpy(rng.standard_normal((T, 4)).astype(np.float32)),  # noqa: E731
+                          action=torch.from_numpy(rng.integers(0, 3, T)), reward=torch.rand(T), terminal=torch.zeros(T, dtype=torch.bool))
+    rb.add_many(**good(10))
+    before = {k: v.clone() for k, v in rb._store.items()}
+    state = (int(rb.add_count), rb._valid_host.copy(), rb._terminal_host.copy())
+    bad_shape = good(4)
+    bad_shape["reward"] = torch.rand(4, 2)  # the LAST-but-one key: observation / action come first in the dict
+    bad_dtype = good(4)
+    bad_dtype["action"] = torch.rand(4) * 3  # float for an int64 element
+    for cols in (bad_shape, bad_dtype):
+        with pytest.raises(ValueError, match="add_many"):
+            rb.add_many(**cols)
+        for k, v in rb._store.items():
+            assert torch.equal(v, before[k]), k
+        assert int(rb.add_count) == state[0] and np.array_equal(rb._valid_host, state[1]) and np.array_equal(rb._terminal_host, state[2])
+    rb.add_many(**{k: (v.double() if k == "reward" else v) for k, v in good(3).items()})  # f64 -> f32: same-kind, as add does
+    assert int(rb.add_count) == 13
