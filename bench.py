@@ -17,11 +17,15 @@ Every rank owns a disjoint shard of the offline dataset (its own replay buffer),
 stays 65536 (weak scaling) and the only collective is the gradient all-reduce.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — dominant FC kernel: algorithmic FLOP of its launches / HIP-event time of those
-                 launches (events on the launch stream, measured in a second, instrumented pass of
-                 the same K steps so the timed region itself stays un-instrumented); `traffic` = HBM
-                 bytes per launch from the PMC pass stamped into profiles/traffic.json for exactly this
-                 kernel source (null when the stamp does not match the source that is running)
+  roofline     — dominant FC entry point (largest total time, all its variants merged, call-weighted):
+                 algorithmic FLOP of its launches / HIP-event time of those launches (events on the launch
+                 stream, in a second, instrumented pass so the timed region itself stays un-instrumented;
+                 each instrumented step is enqueued behind a device-side blocker — class QueueAhead — so the
+                 spans are kernel durations, not host gaps, and agree with rocprofv3's kernel trace in
+                 profiles/); `traffic` = HBM bytes per launch from the PMC pass stamped into
+                 profiles/traffic.json for exactly this kernel source (null when the stamp does not match).
+                 Digests of `fc_roofline`, `gather`, `parity`, `accurate` (as `compliant_mode`) and
+                 `also_measured` are repeated inside it, `sustained` inside `config`
   fc_roofline  — all FC kernels together against the algorithmic FLOP of the step; in
                  bf16x3 mode `executed_frac` counts the three MFMAs per product that mode issues
   parity       — one extra step on a 4096-row slice of the same workload (fresh trainer, same initial
@@ -517,21 +521,76 @@ def source_stamp():
     return h.hexdigest()[:16]
 
 
-def kernel_profile(args, step, steps):
-    """Instrumented pass: HIP events around every C-ABI launch (on the launch stream)."""
+FC_ENTRY_POINTS = ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad", "rg_fc_wgrad_frag", "rg_mlp_forward_fused",
+                   "rg_mlp_backward_fused", "rg_mlp_wgrad_fused", "rg_group_head_forward", "rg_group_head_dgrad",
+                   "rg_group_head_wgrad")
+# the __global__ functions an entry point launches (what `rocprofv3 --kernel-trace --stats` lists for it: profiles/)
+KERNELS_OF = {"rg_mlp_forward_fused": "mlp_fwd_fused_kernel", "rg_mlp_backward_fused": "mlp_bwd_fused_kernel",
+              "rg_mlp_wgrad_fused": "wgrad_group_kernel + wgrad_reduce_tail_kernel",
+              "rg_replay_dqn_batch": "replay_dqn_batch_kernel"}
+
+
+class QueueAhead:
+    """Keeps the device busy for a few ms so that the host enqueues a whole instrumented step BEHIND it.
+
+    HIP events around a launch that starts from an idle queue time the launch's dispatch latency and whatever the host
+    did between its two records (round 4: the same binary summed to 0.57 ms one run and 0.78 ms the next, and a rescale
+    hid it).  With the queue kept full, the start event of launch k completes when launch k-1 does and its end event when
+    launch k does: the span is the kernel's own duration plus the two marker packets, whatever the host's pace —
+    reproducible, and what `rocprofv3 --kernel-trace` reports for the same kernels (profiles/).  The blocker is torch's
+    spin kernel (torch.cuda._sleep), calibrated once with events; no blocker off-GPU (the interpreter tests)."""
+
+    def __init__(self, device, ms=3.0):
+        self.on = device.type == "cuda" and hasattr(torch.cuda, "_sleep")
+        self.ms, self.cycles_per_ms, self.marker_us = ms, None, None
+        if not self.on:
+            return
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda._sleep(1_000_000)
+        torch.cuda.synchronize()
+        ev[0].record()
+        torch.cuda._sleep(20_000_000)
+        ev[1].record()
+        torch.cuda.synchronize()
+        self.cycles_per_ms = 20_000_000 / max(ev[0].elapsed_time(ev[1]), 1e-3)
+        # what two back-to-back records cost when nothing lies between them (behind a busy queue): the marker overhead a
+        # span carries; reported, not subtracted
+        self.block()
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
+        for a, b in pairs:
+            a.record()
+            b.record()
+        torch.cuda.synchronize()
+        self.marker_us = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] * 1e3
+
+    def block(self, ms=None):
+        if self.on:
+            torch.cuda._sleep(int((ms or self.ms) * self.cycles_per_ms))
+
+
+def kernel_profile(args, step, steps, device=None):
+    """Instrumented pass: HIP events around every C-ABI launch (on the launch stream), each step enqueued behind a
+    device-side blocker (QueueAhead) so that the spans are kernel durations, not host gaps.  Rows of one entry point are
+    MERGED over its variants (saving / non-saving forwards, the nets of a step): the dominant entry point is the one with
+    the largest total time and its figure the call-weighted average."""
     from reagent_amd import ops
 
     B = args.batch
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    qa = QueueAhead(device)
+    host_ms = []
     with ops.profile() as prof:
         for _ in range(steps):
+            qa.block()
+            t = time.perf_counter()
             step()
+            host_ms.append((time.perf_counter() - t) * 1e3)
     rows = prof.summary()
-    fc_names = ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad", "rg_fc_wgrad_frag", "rg_mlp_forward_fused",
-                "rg_mlp_backward_fused", "rg_mlp_wgrad_fused", "rg_group_head_forward", "rg_group_head_dgrad",
-                "rg_group_head_wgrad")
-    fc = [r for r in rows if r["name"] in fc_names]
-    for r in fc:
+    for r in rows:
         m = r["meta"]
+        if r["name"] not in FC_ENTRY_POINTS:
+            continue
         if r["name"] in ("rg_mlp_forward_fused", "rg_mlp_wgrad_fused"):
             d = m["dims"]
             r["flop_per_launch"] = 2.0 * m["B"] * mac(d)
@@ -546,16 +605,29 @@ def kernel_profile(args, step, steps):
         else:
             r["flop_per_launch"] = 2.0 * m["M"] * m["N"] * m["K"]
             r["label"] = f"{r['name']} M={m['M']} N={m['N']} K={m['K']}"
+    fc = [r for r in rows if r["name"] in FC_ENTRY_POINTS]
     peak = MFMA_PEAK[args.precision]
     mfma_per_product = 3 if args.precision == "bf16x3" else 1
     out = {}
     if fc:
-        dom = fc[0]
+        by_name = {}
+        for r in fc:  # merge an entry point's variants
+            g = by_name.setdefault(r["name"], {"name": r["name"], "ms": 0.0, "calls": 0, "flop": 0.0, "variants": []})
+            g["ms"] += r["ms"]
+            g["calls"] += r["calls"]
+            g["flop"] += r["flop_per_launch"] * r["calls"]
+            g["variants"].append({"label": r["label"], "launches_per_step": r["calls"] / steps,
+                                  "avg_launch_us": r["ms"] * 1e3 / r["calls"],
+                                  "frac": r["flop_per_launch"] / (r["ms"] * 1e-3 / r["calls"]) / peak})
+        dom = max(by_name.values(), key=lambda g: g["ms"])
         sec = dom["ms"] * 1e-3 / dom["calls"]
-        ach = dom["flop_per_launch"] / sec
-        out["roofline"] = {"bound": "mfma", "kernel": dom["label"],
+        ach = dom["flop"] / dom["calls"] / sec
+        out["roofline"] = {"bound": "mfma", "kernel": f"{dom['name']} ({KERNELS_OF.get(dom['name'], dom['name'])})",
                            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
-                           "avg_launch_us": sec * 1e6, "launches_per_step": dom["calls"] / steps, "traffic": None}
+                           "avg_launch_us": sec * 1e6, "launches_per_step": dom["calls"] / steps,
+                           "averaging": "call-weighted over every launch of the entry point in the instrumented steps "
+                                        "(all variants): algorithmic FLOP of those launches / their summed HIP-event time",
+                           "variants": dom["variants"], "traffic": None}
         if mfma_per_product != 1:
             out["roofline"]["executed_frac"] = mfma_per_product * ach / peak
         fc_ms = sum(r["ms"] for r in fc) / steps
@@ -566,22 +638,35 @@ def kernel_profile(args, step, steps):
                                           "mean layer instead of the dense [B, A*N] logits the reference materialises"}
                                  if getattr(args, "grouped_head", False) else {}), "fc_ms_per_step": fc_ms,
                               "achieved": alg / (fc_ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                              "frac": alg / (fc_ms * 1e-3) / peak}
+                              "frac": alg / (fc_ms * 1e-3) / peak,
+                              "entry_points_us_per_step": {g["name"]: round(g["ms"] * 1e3 / steps, 2) for g in by_name.values()}}
         if mfma_per_product != 1:
             out["fc_roofline"]["executed_frac"] = mfma_per_product * out["fc_roofline"]["frac"]
-            out["fc_roofline"]["note"] = "bf16x3: three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulate"
+            out["fc_roofline"]["note"] = ("bf16x3: three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi), fp32 accumulate: the algorithmic "
+                                          "fraction is capped at 1/3, `executed_frac` is the figure of merit of this mode")
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             try:
                 t = json.load(open(traffic_file))
                 if t.get("source_stamp") == source_stamp():
-                    key = dom["label"].split(" ")[0] + (":save=%d" % dom["meta"]["save"] if "save" in dom["meta"] else "")
-                    out["roofline"]["traffic"] = t.get("kernels", {}).get(f"{args.config}:{args.precision}:{key}")
+                    ks = t.get("kernels", {})
+                    per = {}
+                    for v in dom["variants"]:  # the PMC figures are per variant (save=0 / save=1): weight them like the times
+                        lab = v["label"]
+                        key = lab.split(" ")[0] + (":save=%s" % lab.split("save=")[1] if "save=" in lab else "")
+                        per[key] = (ks.get(f"{args.config}:{args.precision}:{key}"), v["launches_per_step"])
+                    if per and all(isinstance(tv, dict) for tv, _ in per.values()):
+                        n = sum(c for _, c in per.values())
+                        keys = set.intersection(*(set(k for k, x in tv.items() if isinstance(x, (int, float))) for tv, _ in per.values()))
+                        out["roofline"]["traffic"] = {k: sum(tv[k] * c for tv, c in per.values()) / n for k in sorted(keys)}
+                        out["roofline"]["traffic"]["per_variant"] = {k: tv for k, (tv, _) in per.items()}
+                    elif per and any(tv is not None for tv, _ in per.values()):
+                        out["roofline"]["traffic"] = {k: tv for k, (tv, _) in per.items()}
                     out["roofline"]["traffic_source"] = t.get("from")
                 else:
                     out["roofline"]["traffic_source"] = "profiles/traffic.json is stamped for other kernel sources: not reported"
-            except Exception:
-                pass
+            except Exception as e:
+                out["roofline"]["traffic_source"] = f"profiles/traffic.json unreadable: {e!r}"
     g = [r for r in rows if r["name"] in ("rg_replay_dqn_batch", "rg_replay_gather")]
     if g:
         sec = g[0]["ms"] * 1e-3 / g[0]["calls"]
@@ -595,37 +680,16 @@ def kernel_profile(args, step, steps):
         out["all_reduce_bytes"] = ar[0]["meta"]["bytes"]
     out["per_call_ms_per_step"] = {f"{r['name']}{tuple(r['meta'].values())}": round(r["ms"] / steps, 4) for r in rows[:18]}
     out["event_ms_per_step_sum"] = sum(r["ms"] for r in rows if r["name"] != "all_reduce") / steps
+    host = sorted(host_ms)[len(host_ms) // 2] if host_ms else None
+    out["instrumented_pass"] = {
+        "steps": steps, "event_ms_per_step_sum": out["event_ms_per_step_sum"],
+        "queue_ahead": {"on": qa.on, "blocker_ms": qa.ms if qa.on else None, "host_enqueue_ms_per_step": host,
+                        "queued_behind_blocker": bool(qa.on and host is not None and host < qa.ms),
+                        "marker_pair_us": qa.marker_us},
+        "note": "HIP events on the launch stream around every C-ABI call; every step is enqueued behind a device-side blocker, "
+                "so a span is the launch's own duration (+ the marker pair), independent of the host's pace; figures are as "
+                "measured (no rescale to the timed step)"}
     return out
-
-
-def normalise_profile(extra, timed_ms, single_stream):
-    """The instrumented pass brackets every C-ABI call with two HIP events on the launch stream.  Each kernel then starts
-    from an idle queue: its dispatch latency (~2 us) lands inside its span instead of under the previous kernel, and on a
-    single stream the spans of a step add up to MORE than the timed step (round 3: 0.569 against 0.548 ms).  When they do,
-    every span is scaled by timed / sum, so that the per-call times add up to `ms_per_step` and the roofline fractions
-    describe the timed region; the raw event figures stay alongside (`events_raw`).  A step whose launches overlap on two
-    streams (C3's forward halves) is left as measured: there the sum exceeds the wall time legitimately."""
-    total = extra.get("event_ms_per_step_sum", 0.0)
-    scale = min(1.0, timed_ms / total) if (single_stream and total > 0) else 1.0
-    extra["instrumented_pass"] = {"event_ms_per_step_sum": total, "timed_ms_per_step": timed_ms, "scale": scale,
-                                  "note": ("per-call and roofline times = HIP-event times x scale (bench.normalise_profile)" if single_stream
-                                           else "two launch streams: spans overlap, not normalised")}
-    if scale >= 1.0:
-        return
-    for key in ("roofline", "fc_roofline", "gather"):
-        r = extra.get(key)
-        if not r:
-            continue
-        r["events_raw"] = {k: r[k] for k in ("achieved", "frac", "avg_launch_us", "fc_ms_per_step", "executed_frac") if k in r}
-        for k in ("avg_launch_us", "fc_ms_per_step"):
-            if k in r:
-                r[k] *= scale
-        for k in ("achieved", "frac", "executed_frac"):
-            if k in r:
-                r[k] /= scale
-    if "all_reduce_us" in extra:
-        extra["all_reduce_us"] *= scale
-    extra["per_call_ms_per_step"] = {k: round(v * scale, 4) for k, v in extra.get("per_call_ms_per_step", {}).items()}
 
 
 def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
@@ -796,11 +860,12 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         # every rank runs the instrumented steps (they contain the gradient all-reduce: a pass on rank 0
         # alone would never return); rank 0 reports.  Eager launches: events bracket each C-ABI call.
         n_prof = profile_steps or min(args.steps, 10)
-        extra = kernel_profile(args, loop.step, n_prof)
+        extra = kernel_profile(args, loop.step, n_prof, device)
         loop.flush()
         gq = trainer._grouped() if (args.algo == "qrdqn" and getattr(args, "grouped_head", False)) else None
         two_streams = gq is not None and (getattr(gq, "two_streams", False) or getattr(gq, "wgrad_streams", False))
-        normalise_profile(extra, dt / args.steps * 1e3, single_stream=not two_streams)
+        extra["instrumented_pass"]["timed_ms_per_step"] = dt / args.steps * 1e3
+        extra["instrumented_pass"]["launch_streams"] = 2 if two_streams else 1
     per_rank = None
     if dist is not None:
         # every rank's own view, so a curve measured by the driver explains itself: the rank's wall time for the median
@@ -817,6 +882,54 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
             "final_loss": loss_val, "launch": graph_note or "eager launches", "launch_calibration": calibration,
             "sustained": sustained, "extra": extra, "parity": parity,
             "per_rank": per_rank, "init": init, "cols": cols, "cols_cpu": cols, "norm": norm}
+
+
+def digest_into_kept_objects(res):
+    """The driver's record keeps `roofline`, `config` and `cpu_baseline` of the line verbatim and only the NAMES of the other
+    objects: the figures a reader needs beside the headline — whole-FC fraction, the sustained region, the 1e-4-compliant
+    mode's throughput / executed fraction / parity, the other configurations — are therefore repeated inside the kept ones
+    (the full objects stay at the top level)."""
+    roof = res.get("roofline")
+    if roof is None:
+        return
+    pick = lambda o, *ks: {k: o[k] for k in ks if isinstance(o, dict) and k in o}  # noqa: E731
+
+    def parity_digest(pp):
+        if not isinstance(pp, dict):
+            return None
+        return pick(pp, "ok", "meets_north_star", "sane", "batch", "max_abs_dq", "max_abs_dquantile", "max_abs_dlogits",
+                    "rel_dloss", "gather_fields_bit_exact", "path", "error")
+
+    def mode_digest(o):
+        d = pick(o, "dtype", "value", "ms_per_step", "error")
+        if isinstance(o.get("fc_roofline"), dict):
+            d["whole_fc"] = pick(o["fc_roofline"], "frac", "executed_frac", "fc_ms_per_step")
+        if isinstance(o.get("roofline"), dict):
+            d["dominant"] = pick(o["roofline"], "kernel", "frac", "executed_frac", "avg_launch_us")
+        if isinstance(o.get("sustained"), dict):
+            d["sustained_ms_per_step"] = o["sustained"].get("ms_per_step")
+        d["parity"] = parity_digest(o.get("parity"))
+        return d
+
+    if "fc_roofline" in res:
+        roof["whole_fc"] = pick(res["fc_roofline"], "frac", "executed_frac", "fc_ms_per_step", "achieved", "algorithmic_gflop_per_step",
+                                "entry_points_us_per_step")
+    if "gather" in res:
+        roof["gather"] = pick(res["gather"], "bound", "frac", "achieved", "unit", "avg_launch_us", "kernel")
+    if "instrumented_pass" in res:
+        roof["instrumented_pass"] = pick(res["instrumented_pass"], "steps", "event_ms_per_step_sum", "timed_ms_per_step", "queue_ahead")
+    roof["parity"] = parity_digest(res.get("parity"))
+    if isinstance(res.get("accurate"), dict):
+        roof["compliant_mode"] = mode_digest(res["accurate"])
+    if isinstance(res.get("also_measured"), dict):
+        roof["other_configs"] = {}
+        for cfg, o in res["also_measured"].items():
+            d = mode_digest(o)
+            if isinstance(o.get("accurate"), dict):
+                d["compliant_mode"] = mode_digest(o["accurate"])
+            roof["other_configs"][cfg] = d
+    if isinstance(res.get("sustained"), dict):
+        res["config"]["sustained"] = pick(res["sustained"], "steps", "seconds", "ms_per_step", "value", "sclk_mhz", "power_w")
 
 
 def main():
@@ -947,6 +1060,7 @@ def main():
             del shared_cols
         res["also_measured"] = also
     if rank == 0:
+        digest_into_kept_objects(res)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, m["init"], m["cols_cpu"], m["norm"])

@@ -123,13 +123,26 @@ def _measure_worker(rank, world, port, out_dir):
     assert m["extra"]["all_reduce_bytes"] > 0 and "roofline" in m["extra"]
     # the long region and its telemetry record (no GPU here: the clock / power fields are None, never an exception)
     assert m["sustained"]["steps"] == 3 and m["sustained"]["ms_per_step"] > 0 and "sclk_mhz" in m["sustained"]
-    # the instrumented pass is normalised to the timed one: per-call times add up to no more than the timed step
+    # the instrumented pass reports what it measured (no rescale to the timed step): off-GPU there is no device-side blocker,
+    # the spans are host clocks; the dominant entry point is chosen over ALL its variants, call-weighted
     ip = m["extra"]["instrumented_pass"]
-    assert 0 < ip["scale"] <= 1.0 and ip["event_ms_per_step_sum"] > 0
-    # (the collective's span is this rank's wait for the slower rank as much as the transfer: it is reported, not part of the sum
-    # the normalisation holds to the timed step — bench.profile_summary leaves it out of event_ms_per_step_sum)
-    own = sum(v for k, v in m["extra"]["per_call_ms_per_step"].items() if not k.startswith("all_reduce"))
-    assert own <= m["ms_per_step"] * 1.02 + 1e-3, (m["extra"]["per_call_ms_per_step"], m["ms_per_step"], ip, m["per_rank"])
+    assert ip["event_ms_per_step_sum"] > 0 and ip["queue_ahead"]["on"] is False and "scale" not in ip
+    roof = m["extra"]["roofline"]
+    assert roof["kernel"].startswith("rg_mlp_") and len(roof["variants"]) >= 1
+    tot = sum(v["launches_per_step"] * v["avg_launch_us"] for v in roof["variants"])
+    assert abs(tot / roof["launches_per_step"] - roof["avg_launch_us"]) <= 1e-6 * roof["avg_launch_us"] + 1e-9
+    assert m["extra"]["fc_roofline"]["entry_points_us_per_step"]
+    # the digests main() repeats inside the objects the driver keeps verbatim
+    line = {"roofline": dict(roof), "config": {}, "fc_roofline": m["extra"]["fc_roofline"], "gather": m["extra"].get("gather"),
+            "instrumented_pass": ip, "parity": m["parity"], "sustained": m["sustained"],
+            "accurate": {"dtype": "bf16x3", "value": ma["value"], "ms_per_step": ma["ms_per_step"], "parity": ma["parity"],
+                         "fc_roofline": ma["extra"].get("fc_roofline", {}), "roofline": ma["extra"].get("roofline", {})}}
+    line = {k: v for k, v in line.items() if v is not None}
+    bench.digest_into_kept_objects(line)
+    assert line["roofline"]["whole_fc"]["frac"] > 0 and line["config"]["sustained"]["steps"] == 3
+    assert line["roofline"]["compliant_mode"]["dtype"] == "bf16x3" and "executed_frac" in line["roofline"]["compliant_mode"]["whole_fc"]
+    if rank == 0:
+        assert line["roofline"]["parity"]["gather_fields_bit_exact"] is True
     keep = dict(value=m["value"], ms=m["ms_per_step"], regions=m["region_ms"], per_rank=m["per_rank"], launch=m["launch"],
                 loss=m["final_loss"], parity=m["parity"], x3_value=ma["value"], x3_loss=ma["final_loss"],
                 x3_parity=ma["parity"], shard=float(m["cols"]["observation"].double().sum()))
