@@ -587,6 +587,15 @@ def kernel_profile(args, step, steps, device=None):
             step()
             host_ms.append((time.perf_counter() - t) * 1e3)
     rows = prof.summary()
+    # A span = the launch(es) of the entry point + the pair of marker packets that bracket it; what an EMPTY bracket costs
+    # behind a busy queue was calibrated above (QueueAhead.marker_us, ~4.7 us) and is taken off every span.  First
+    # measurement (profiles/r05_run1): raw spans 93.3 / 87.0 / 41.3 us for forward / backward / gather against rocprofv3's
+    # 88.6 / 82.3 / 37.2 us of the same box and binary — each high by exactly that pair.
+    marker_ms = (qa.marker_us or 0.0) * 1e-3
+    for r in rows:
+        r["span_ms"] = r["ms"]
+        r["ms"] = max(r["ms"] - r["calls"] * marker_ms, 0.05 * r["ms"])
+    rows.sort(key=lambda r: -r["ms"])
     for r in rows:
         m = r["meta"]
         if r["name"] not in FC_ENTRY_POINTS:
@@ -612,8 +621,9 @@ def kernel_profile(args, step, steps, device=None):
     if fc:
         by_name = {}
         for r in fc:  # merge an entry point's variants
-            g = by_name.setdefault(r["name"], {"name": r["name"], "ms": 0.0, "calls": 0, "flop": 0.0, "variants": []})
+            g = by_name.setdefault(r["name"], {"name": r["name"], "ms": 0.0, "span_ms": 0.0, "calls": 0, "flop": 0.0, "variants": []})
             g["ms"] += r["ms"]
+            g["span_ms"] += r["span_ms"]
             g["calls"] += r["calls"]
             g["flop"] += r["flop_per_launch"] * r["calls"]
             g["variants"].append({"label": r["label"], "launches_per_step": r["calls"] / steps,
@@ -624,9 +634,11 @@ def kernel_profile(args, step, steps, device=None):
         ach = dom["flop"] / dom["calls"] / sec
         out["roofline"] = {"bound": "mfma", "kernel": f"{dom['name']} ({KERNELS_OF.get(dom['name'], dom['name'])})",
                            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
-                           "avg_launch_us": sec * 1e6, "launches_per_step": dom["calls"] / steps,
+                           "avg_launch_us": sec * 1e6, "avg_span_us": dom["span_ms"] * 1e3 / dom["calls"],
+                           "marker_pair_us": qa.marker_us, "launches_per_step": dom["calls"] / steps,
                            "averaging": "call-weighted over every launch of the entry point in the instrumented steps "
-                                        "(all variants): algorithmic FLOP of those launches / their summed HIP-event time",
+                                        "(all variants): algorithmic FLOP of those launches / their summed HIP-event time; "
+                                        "launch time = event span - the calibrated cost of the marker pair that brackets it",
                            "variants": dom["variants"], "traffic": None}
         if mfma_per_product != 1:
             out["roofline"]["executed_frac"] = mfma_per_product * ach / peak
@@ -655,13 +667,12 @@ def kernel_profile(args, step, steps, device=None):
                         lab = v["label"]
                         key = lab.split(" ")[0] + (":save=%s" % lab.split("save=")[1] if "save=" in lab else "")
                         per[key] = (ks.get(f"{args.config}:{args.precision}:{key}"), v["launches_per_step"])
-                    if per and all(isinstance(tv, dict) for tv, _ in per.values()):
-                        n = sum(c for _, c in per.values())
-                        keys = set.intersection(*(set(k for k, x in tv.items() if isinstance(x, (int, float))) for tv, _ in per.values()))
-                        out["roofline"]["traffic"] = {k: sum(tv[k] * c for tv, c in per.values()) / n for k in sorted(keys)}
-                        out["roofline"]["traffic"]["per_variant"] = {k: tv for k, (tv, _) in per.items()}
+                    if per and all(isinstance(tv, (int, float)) for tv, _ in per.values()):
+                        out["roofline"]["traffic"] = sum(tv * c for tv, c in per.values()) / sum(c for _, c in per.values())
+                        out["roofline"]["traffic_per_variant"] = {k: tv for k, (tv, _) in per.items()}
+                        out["roofline"]["algorithmic_bytes_note"] = "HBM bytes per launch, PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), call-weighted like the time"
                     elif per and any(tv is not None for tv, _ in per.values()):
-                        out["roofline"]["traffic"] = {k: tv for k, (tv, _) in per.items()}
+                        out["roofline"]["traffic_per_variant"] = {k: tv for k, (tv, _) in per.items()}
                     out["roofline"]["traffic_source"] = t.get("from")
                 else:
                     out["roofline"]["traffic_source"] = "profiles/traffic.json is stamped for other kernel sources: not reported"
@@ -672,7 +683,7 @@ def kernel_profile(args, step, steps, device=None):
         sec = g[0]["ms"] * 1e-3 / g[0]["calls"]
         bytes_ = g[0]["meta"]["bytes_per_row"] * B
         out["gather"] = {"bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": bytes_ / sec / HBM_PEAK, "avg_launch_us": sec * 1e6,
+                         "frac": bytes_ / sec / HBM_PEAK, "avg_launch_us": sec * 1e6, "avg_span_us": g[0]["span_ms"] * 1e3 / g[0]["calls"],
                          "algorithmic_bytes_per_transition": g[0]["meta"]["bytes_per_row"], "kernel": g[0]["name"]}
     ar = [r for r in rows if r["name"] == "all_reduce"]
     if ar:
@@ -680,15 +691,16 @@ def kernel_profile(args, step, steps, device=None):
         out["all_reduce_bytes"] = ar[0]["meta"]["bytes"]
     out["per_call_ms_per_step"] = {f"{r['name']}{tuple(r['meta'].values())}": round(r["ms"] / steps, 4) for r in rows[:18]}
     out["event_ms_per_step_sum"] = sum(r["ms"] for r in rows if r["name"] != "all_reduce") / steps
+    out["event_span_ms_per_step_sum"] = sum(r["span_ms"] for r in rows if r["name"] != "all_reduce") / steps
     host = sorted(host_ms)[len(host_ms) // 2] if host_ms else None
     out["instrumented_pass"] = {
-        "steps": steps, "event_ms_per_step_sum": out["event_ms_per_step_sum"],
+        "steps": steps, "event_ms_per_step_sum": out["event_ms_per_step_sum"], "event_span_ms_per_step_sum": out["event_span_ms_per_step_sum"],
         "queue_ahead": {"on": qa.on, "blocker_ms": qa.ms if qa.on else None, "host_enqueue_ms_per_step": host,
                         "queued_behind_blocker": bool(qa.on and host is not None and host < qa.ms),
                         "marker_pair_us": qa.marker_us},
         "note": "HIP events on the launch stream around every C-ABI call; every step is enqueued behind a device-side blocker, "
-                "so a span is the launch's own duration (+ the marker pair), independent of the host's pace; figures are as "
-                "measured (no rescale to the timed step)"}
+                "so a span is the launch's own duration + the marker pair, independent of the host's pace; launch times = span - "
+                "marker_pair_us (calibrated in the same pass); nothing is rescaled to the timed step"}
     return out
 
 
