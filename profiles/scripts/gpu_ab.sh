@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of kernel variants: profiles/scripts/gpu_ab.sh "ENV1=a ENV2=b" "ENV1=c" ...   (each argument = one environment)
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 CFG=${AB_CONFIG:-c2}; PREC=${AB_PREC:-bf16}
 for rep in 1 2; do
 for envs in "$@"; do

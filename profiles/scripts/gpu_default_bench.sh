@@ -1,7 +1,7 @@
 #!/bin/bash
 # the driver's command (default flags) with its wall time: bash profiles/scripts/gpu_default_bench.sh [tag]
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT; TAG=${1:-def}
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 t0=$(date +%s.%N)
 timeout 900 python bench.py --gpus 1 --steps ${STEPS:-20} --warmup ${WARMUP:-5} > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "rc=$? wall=$(python -c "import time,sys; print(round(time.time()-float(sys.argv[1]),1))" $t0) s"
 python - <<PY

@@ -21,6 +21,7 @@
 
 #include "rg_mlp_frag.h"
 #include "rg_reduce.h"
+#include <cstdio>
 // workgroups per layer of the grouped weight-gradient launch (splits = this / tiles).
 // Round 3, same-box A/B in the C2 step (wgrad + reduce, us): this uniform 128 per layer 132-134; workgroups shared out in
 // proportion to the operand bytes a layer's tiles stream — 256 in all (one round on the chip, 52 MB of partials
@@ -40,6 +41,18 @@
 #define RG_FWD_SWAP 0  // non-saving forwards on transposed accumulator tiles (mlp_fwd_swap_kernel).  Round 4, same box: the two
 // non-saving forwards of a C2 step 169 -> 177 us, C4's 100 -> 106 — the 8-byte LDS writes collide two ways on the tile's row
 // pitch and the 16 bias values per tile are re-requested per row tile; bit-identical, slower: not the default.
+#endif
+#ifndef RG_WGRAD_BF16_PART
+#define RG_WGRAD_BF16_PART 1  // bf16 stack launch: split partials as bf16 tiles in accumulator order (WgradFragArgs.part_mode)
+#endif
+#ifndef RG_WGRAD_UNEVEN
+#define RG_WGRAD_UNEVEN 125  // stack launch: uneven splits of the multi-tile layers (rg_mlp_wgrad_fused); value = cost of a single-tile
+#endif                       // workgroup's block in percent of a multi-tile one's; 0 = every split of a layer the same length
+#ifndef RG_REDUCE_FLY
+#define RG_REDUCE_FLY 16      // split-reduce: fp32 partials requested per thread before the first add (multiple of 4; 4 = rounds 1-4)
+#endif
+#ifndef RG_REDUCE_FLY_BF16
+#define RG_REDUCE_FLY_BF16 8  // the same for the 32-byte bf16 tile records (even)
 #endif
 #ifndef RG_WGRAD_PIPE
 #define RG_WGRAD_PIPE 1  // weight gradient: LDS fragment reads one half ahead of the MFMAs (wgrad_shape_core)
@@ -428,7 +441,8 @@ struct WgradFragArgs {
   const bf16_t* a_frag;
   const bf16_t* b_frag;
   int NTa, NTb;       // tiles per 32-row block in each operand
-  int MB;             // 32-row blocks in total
+  int MB;             // 32-row blocks in total (= the END of this entry's block range)
+  int mb_base;        // first block of this entry's split 0 (0 but for the second class of an unevenly split layer)
   int mb_per_split;   // multiple of WG_MB_STAGE
   int splits;
   float* partial;     // [splits][N*K]
@@ -441,6 +455,11 @@ struct WgradFragArgs {
   int x3;
   long a_lo, b_lo;    // element offsets of the lo planes
   int shape;          // workgroup tile shape (WG_SHAPE_*, wgrad_shape_core / wgrad_x3_shape_core); 0 = 8 x 8 tiles
+  // How a split's partial tile leaves the workgroup.  0: fp32, row-major [N][K] (slab = N * K floats).  1 (round 5, the bf16
+  // stack launch): bf16, one 2 KB record per 32 x 32 MFMA tile in ACCUMULATOR order — record (tn * NTb + tk), lane's 16 values
+  // contiguous (32 bytes) — so a tile leaves as two 16-byte stores per lane instead of sixteen 4-byte ones and the launch
+  // writes (and its reduce reads) half the bytes; slab = NTa * NTb * 512 floats' worth.  The reduce launch undoes the order.
+  int part_mode;
 };
 
 
@@ -624,6 +643,25 @@ __device__ __forceinline__ void wgrad_shape_core(const WgradFragArgs& g, int ng,
     }
   }
 
+  if (g.part_mode == 1) {
+    typedef __attribute__((ext_vector_type(4))) unsigned pk4_t;
+    bf16_t* pb = (bf16_t*)part;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int tn = ta0 + wn * TA + i, tk = tb0 + wk * TB + j;
+        if (tn < nta && tk < ntb) {
+          pk4_t* dst = (pk4_t*)(pb + ((long)tn * ntb + tk) * 1024 + lane * 16);
+          const f32x16& c = acc[i][j];
+          dst[0] = pk4_t{pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7])};
+          dst[1] = pk4_t{pack_bf16x2(c[8], c[9]), pack_bf16x2(c[10], c[11]), pack_bf16x2(c[12], c[13]), pack_bf16x2(c[14], c[15])};
+        }
+      }
+    RG_PHASE(4);
+    RG_PHASE_FLUSH();
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -784,7 +822,8 @@ __device__ __forceinline__ void wgrad_frag_body(const WgradFragArgs& g, int bid,
   if (split >= g.splits) return;  // padding workgroups of a grouped launch (uniform for the workgroup)
   const int kg = tile % k_groups;
   const int ng = tile / k_groups;
-  const int mb_begin = split * g.mb_per_split;
+  const int mb_begin0 = g.mb_base + split * g.mb_per_split;
+  const int mb_begin = mb_begin0 < g.MB ? mb_begin0 : g.MB;
   const int mb_end = (mb_begin + g.mb_per_split < g.MB) ? mb_begin + g.mb_per_split : g.MB;
   wgrad_dispatch(g, ng, kg, mb_begin, mb_end, g.partial + (long)split * g.slab, smem);
 }
@@ -842,10 +881,12 @@ __global__ void reduce_grouped_kernel(const float* __restrict__ partial, long sl
 
 // all layers of a stack in ONE launch (workgroups of the small layers fill the CUs the big ones
 // leave idle; 4 launches + 4 reduces become 1 + 1)
+// (an ENTRY is a layer, or one of the two classes of splits of an unevenly split layer: rg_mlp_wgrad_fused)
+constexpr int WG_MAXV = FB_MAXL + 4;
 struct WgradGroupArgs {
   int n;
-  int wg_begin[FB_MAXL + 1];
-  WgradFragArgs layer[FB_MAXL];
+  int wg_begin[WG_MAXV + 1];
+  WgradFragArgs layer[WG_MAXV];
 };
 
 __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_group_kernel(WgradGroupArgs G) {
@@ -854,7 +895,7 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_group_kernel(WgradGroupArgs G) {
   WgradFragArgs g = G.layer[0];
   int base = 0;
 #pragma unroll
-  for (int i = 1; i < FB_MAXL; ++i)
+  for (int i = 1; i < WG_MAXV; ++i)
     if (i < G.n && bid >= G.wg_begin[i]) {
       g = G.layer[i];
       base = G.wg_begin[i];
@@ -864,12 +905,76 @@ __global__ void RG_LAUNCH_BOUNDS(512, 1) wgrad_group_kernel(WgradGroupArgs G) {
 
 struct ReduceGroupArgs {
   int n;
-  long elem_begin[FB_MAXL + 1];
+  long elem_begin[FB_MAXL + 1];  // in THREADS: one per element (row-major fp32 partials), 256 per 32 x 32 tile (part_mode 1)
   const float* partial[FB_MAXL];
   long slab[FB_MAXL];
   int splits[FB_MAXL];
   float* out[FB_MAXL];
+  // part_mode 1 layers (WgradFragArgs.part_mode): bf16 partial tiles in accumulator order; N x K = valid extents of dW
+  int mode[FB_MAXL], NTb[FB_MAXL], N[FB_MAXL], K[FB_MAXL];
 };
+
+// One 256-thread workgroup = one 32 x 32 tile: wave w sums the lane records (16 values, 32 contiguous bytes per split) of the
+// w-th quarter of the splits — all of a quarter's records requested before the first is added (RG_REDUCE_FLY_BF16 at a
+// time): the launch runs on loads in flight, 148 workgroups of one wave each were 16 dependent round trips — the four
+// quarter sums meet in LDS and are added in a fixed order.  Writes the row-major dW.
+__device__ __forceinline__ void reduce_tiles_bf16(const float* part, long slab, int splits, float* out, int NTb, int N, int K,
+                                                  long t, float (*red)[16][64]) {
+  typedef __attribute__((ext_vector_type(4))) unsigned pk4_t;
+  const int lane = (int)(t & 63), w = (int)((t >> 6) & 3);
+  const long tile = t >> 8;
+  const int tn = (int)(tile / NTb), tk = (int)(tile % NTb);
+  const int lr = lane & 31, lg = lane >> 5;
+  float s0[16], s1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+  const char* p = (const char*)part + (tile * 1024 + lane * 16) * 2;
+  const long stride = slab * 4;  // bytes between the splits' slabs
+  auto add = [&](float (&s)[16], const pk4_t a, const pk4_t b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s[2 * q] += __builtin_bit_cast(float, a[q] << 16);
+      s[2 * q + 1] += __builtin_bit_cast(float, a[q] & 0xffff0000u);
+      s[8 + 2 * q] += __builtin_bit_cast(float, b[q] << 16);
+      s[8 + 2 * q + 1] += __builtin_bit_cast(float, b[q] & 0xffff0000u);
+    }
+  };
+  const int per = (splits + 3) >> 2;
+  int k = w * per;
+  const int k_end = (k + per < splits) ? k + per : splits;
+  constexpr int U = RG_REDUCE_FLY_BF16;
+  for (; k + U <= k_end; k += U) {
+    pk4_t a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = stream_load((const pk4_t*)(p + (k + u) * stride));
+      b[u] = stream_load((const pk4_t*)(p + (k + u) * stride) + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+      add(s0, a[u], b[u]);
+      add(s1, a[u + 1], b[u + 1]);
+    }
+  }
+  for (; k + 1 < k_end; k += 2) {
+    const pk4_t a0 = stream_load((const pk4_t*)(p + k * stride)), b0 = stream_load((const pk4_t*)(p + k * stride) + 1);
+    const pk4_t a1 = stream_load((const pk4_t*)(p + (k + 1) * stride)), b1 = stream_load((const pk4_t*)(p + (k + 1) * stride) + 1);
+    add(s0, a0, b0);
+    add(s1, a1, b1);
+  }
+  if (k < k_end) add(s0, stream_load((const pk4_t*)(p + k * stride)), stream_load((const pk4_t*)(p + k * stride) + 1));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[w][r][lane] = s0[r] + s1[r];
+  __syncthreads();
+  const int col = tk * 32 + lr;
+  if (col >= K) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // this wave finishes the accumulator registers 4 w .. 4 w + 3: rows 8 w + q + 4 lg of the tile
+    const int r = 4 * w + q;
+    const int row = tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+    if (row < N) out[(long)row * K + col] = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+  }
+}
 
 __device__ __forceinline__ void reduce_group_body(const ReduceGroupArgs& R, long i) {
   if (i >= R.elem_begin[R.n]) return;
@@ -877,15 +982,36 @@ __device__ __forceinline__ void reduce_group_body(const ReduceGroupArgs& R, long
   long slab = R.slab[0], base = 0;
   int splits = R.splits[0];
   float* out = R.out[0];
+  int mode = R.mode[0], NTb = R.NTb[0], N = R.N[0], K = R.K[0];
 #pragma unroll
   for (int k = 1; k < FB_MAXL; ++k)
     if (k < R.n && i >= R.elem_begin[k]) {
       part = R.partial[k]; slab = R.slab[k]; splits = R.splits[k]; out = R.out[k]; base = R.elem_begin[k];
+      mode = R.mode[k]; NTb = R.NTb[k]; N = R.N[k]; K = R.K[k];
     }
+  if (mode == 1) {  // (whole workgroups: a layer's range is 256 threads per tile)
+    __shared__ float red[4][16][64];
+    reduce_tiles_bf16(part, slab, splits, out, NTb, N, K, i - base, red);
+    return;
+  }
   const long e = i - base;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = 0;
 #define RG_LDP(p) stream_load(p)  // the split partials are read exactly once
+  // RG_REDUCE_FLY loads in flight per thread (round 5; see reduce_tiles_bf16): 32 splits were 8 dependent round trips per wave.
+  // Same four chains, same order of additions: bit-identical to the 4-deep loop below.
+  for (; k + RG_REDUCE_FLY <= splits; k += RG_REDUCE_FLY) {
+    float v[RG_REDUCE_FLY];
+#pragma unroll
+    for (int u = 0; u < RG_REDUCE_FLY; ++u) v[u] = RG_LDP(part + (long)(k + u) * slab + e);
+#pragma unroll
+    for (int u = 0; u < RG_REDUCE_FLY; u += 4) {
+      s0 += v[u];
+      s1 += v[u + 1];
+      s2 += v[u + 2];
+      s3 += v[u + 3];
+    }
+  }
   for (; k + 3 < splits; k += 4) {
     s0 += RG_LDP(part + (long)k * slab + e);
     s1 += RG_LDP(part + (long)(k + 1) * slab + e);
@@ -918,6 +1044,15 @@ __device__ __forceinline__ void reduce_cols_body(const float* __restrict__ parti
   if (c < N) {
     // eight rows in flight per thread: the launch is a chain of dependent HBM round trips (S = 512 rows: 8 rounds)
     int r = g;
+    for (; r + 248 < S; r += 256) {  // 32 in flight (round 5), added in the order of four passes of the 8-deep loop below
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = partials[(long)(r + 8 * u) * N + c];
+#pragma unroll
+      for (int u = 0; u < 32; u += 8) {
+        s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; s4 += v[u + 4]; s5 += v[u + 5]; s6 += v[u + 6]; s7 += v[u + 7];
+      }
+    }
     for (; r + 56 < S; r += 64) {
       s0 += partials[(long)r * N + c];
       s1 += partials[(long)(r + 8) * N + c];
@@ -1523,9 +1658,9 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   if (!workspace || workspace_bytes < (size_t)p.splits * p.slab * sizeof(float)) return RG_EWORKSPACE;
   WgradFragArgs g;
   g.a_frag = (const bf16_t*)dz_frag; g.b_frag = (const bf16_t*)x_frag;
-  g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
+  g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_base = 0; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
-  g.x3 = 0; g.a_lo = g.b_lo = 0; g.shape = p.shape;
+  g.x3 = 0; g.a_lo = g.b_lo = 0; g.shape = p.shape; g.part_mode = 0;
   const int grid = p.tiles * ((p.splits + 7) / 8 * 8);
   const size_t lds = (size_t)WG_SHAPED_LDS;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
@@ -1555,13 +1690,13 @@ int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* 
     return RG_EWORKSPACE;
   WgradGroupedArgs G;
   G.g.a_frag = (const bf16_t*)dz_frag; G.g.b_frag = (const bf16_t*)h_frag;
-  G.g.NTa = (group_rows + 31) / 32; G.g.NTb = (in_features + 31) / 32; G.g.MB = 0; G.g.mb_per_split = 0; G.g.splits = splits;
+  G.g.NTa = (group_rows + 31) / 32; G.g.NTb = (in_features + 31) / 32; G.g.MB = 0; G.g.mb_base = 0; G.g.mb_per_split = 0; G.g.splits = splits;
   G.g.partial = (float*)workspace; G.g.slab = (long)group_rows * in_features; G.g.N = group_rows; G.g.K = in_features;
   // split-bf16: each operand is [hi plane | lo plane] over the `rows` rows of the grouped space (rg_frag_elems apart)
   G.g.x3 = x3 ? 1 : 0;
   G.g.a_lo = x3 ? (long)frag_elems(grouped_dz_rows(rows, n_groups), group_rows) : 0;
   G.g.b_lo = x3 ? (long)frag_elems(rows, in_features) : 0;
-  G.g.shape = WG_SHAPE_8x8;
+  G.g.shape = WG_SHAPE_8x8; G.g.part_mode = 0;
   G.row_begin = row_begin; G.n_groups = n_groups; G.splits = splits;
   const int k_groups = (G.g.NTb + 7) / 8;
   const size_t lds = (size_t)WgS8x8::LDS_BYTES;
@@ -1613,10 +1748,12 @@ int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t s
 // chosen so that ALL workgroups of the launch are one round of the chip (RG_WGRAD_TOTAL, default = the CU count) and
 // take the same time by the rates above: fewer partial bytes, no tail.  (Round 3's "256 in all" experiment lost because a
 // split count that is not a multiple of 8 fell off the XCD-grouped decode: every byte then came from HBM twice.)
-struct WgradTuning { int balanced, total; double shared, unshared; int thin, long_first; };
+struct WgradTuning { int balanced, total; double shared, unshared; int thin, long_first, bf16_part, uneven; };
 static const WgradTuning& wgrad_tuning() {
   static const WgradTuning t = [] {
-    WgradTuning v{0, 0, 46.0, 28.0, RG_WGRAD_TARGET_THIN, 1};
+    WgradTuning v{0, 0, 46.0, 28.0, RG_WGRAD_TARGET_THIN, 1, RG_WGRAD_BF16_PART, RG_WGRAD_UNEVEN};
+    if (const char* e = getenv("RG_WGRAD_BF16_PART")) v.bf16_part = atoi(e);
+    if (const char* e = getenv("RG_WGRAD_UNEVEN")) v.uneven = atoi(e);
     if (const char* e = getenv("RG_WGRAD_THIN")) v.thin = atoi(e);
     if (const char* e = getenv("RG_WGRAD_ORDER")) v.long_first = atoi(e);
     if (const char* e = getenv("RG_WGRAD_PLAN")) v.balanced = (e[0] == 'b');  // "balanced": one round by the cost model
@@ -1675,12 +1812,19 @@ static void wgrad_stack_plan(const rg_mlp_desc* d, int batch, WgradFragPlan* out
   }
 }
 
+// floats a split's slab takes in the stack launch: N * K row-major, or NTa * NTb bf16 tile records of 2 KB (a thin layer's
+// padded tiles can be the larger)
+static long wgrad_slab_floats(const WgradFragPlan& p) {
+  const long tiles = (long)p.NTa * p.NTb * 512;
+  return tiles > p.slab ? tiles : p.slab;
+}
+
 size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch) {
   if (!d || batch <= 0 || d->n_layers < 1 || d->n_layers > FB_MAXL) return 0;
   WgradFragPlan plan[FB_MAXL];
   wgrad_stack_plan(d, batch, plan);
-  size_t total = 0;
-  for (int l = 0; l < d->n_layers; ++l) total += (size_t)plan[l].splits * plan[l].slab;
+  size_t total = 0;  // in floats; a layer's slab is the larger of its two partial forms (WgradFragArgs.part_mode)
+  for (int l = 0; l < d->n_layers; ++l) total += (size_t)plan[l].splits * wgrad_slab_floats(plan[l]);
   return total * sizeof(float);
 }
 
@@ -1697,59 +1841,116 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   float* part = (float*)workspace;
   int wg = 0;
   long el = 0;
-  // Launch order: the layers whose workgroups run longest (most 32-row blocks per split) FIRST.  Workgroups are dispatched
-  // in id order, one per CU; in layer order dW0's short workgroups went first and the CUs that drew them started a
-  // hidden layer's long one late — the launch ended 3/2 of a balanced schedule in (profiles/microbench/out/r04a/
-  // wgrad_phases.txt: lifetimes 43 / 74 / 74 / 42 us, launch 117 us).  With the long ones first the short ones fill the tail.
-  int order[FB_MAXL];
-  for (int l = 0; l < FB_MAXL; ++l) order[l] = l;
-  if (wgrad_tuning().long_first)
-    for (int i = 1; i < d->n_layers; ++i)  // stable insertion sort by descending blocks per split
-      for (int j = i; j > 0 && plan[order[j]].mb_per_split > plan[order[j - 1]].mb_per_split; --j) {
-        const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+  // bf16 stacks: the splits' partial tiles as bf16 in accumulator order (half the bytes written here and read by the
+  // reduce; error 2^-9 of a PARTIAL sum, far inside what bf16 operands cost the gradient).  Split-bf16 stacks: fp32.
+  const int part_mode = (!d->x3 && wgrad_tuning().bf16_part) ? 1 : 0;
+  // ---- entries of the launch.  An entry is a layer, or one of the two CLASSES of splits of an unevenly split layer.
+  // Round 4: the layers whose workgroups run longest go first (workgroups are dispatched in id order, one per CU: with dW0's
+  // short ones first the launch ended at 3/2 of a balanced schedule).  Round 5: that order still leaves a staircase — at C2
+  // 256 hidden-layer workgroups of 64 blocks take every CU, then the 128 single-tile ones (dW0, the output layer: 32 blocks)
+  // run on half of the chip while the other half idles: 96 block times for 80 of work per CU.  The splits of the multi-tile
+  // layers are therefore cut UNEVENLY: a fraction f = (single-tile workgroups) / (multi-tile workgroups) of each layer's
+  // splits is shorter by what a single-tile workgroup costs (b blocks, weighted by RG_WGRAD_UNEVEN percent: its stage is a
+  // single-reader stream, dearer per block), L1 = L - (1 - f) b, the others longer, L2 = L + f b.  Launch order L2 | L1 |
+  // single-tile: the CUs that drew an L1 workgroup are the ones that free up for a single-tile one, and every CU ends at ~L2.
+  struct Entry { int layer, mb_base, mb_end, per, splits, split_base; };
+  Entry ent[WG_MAXV];
+  int n_ent = 0;
+  {
+    const WgradTuning& T = wgrad_tuning();
+    int n_multi = 0, n_single = 0;
+    double single_blocks = 0.0;
+    for (int l = 0; l < d->n_layers; ++l) {
+      if (plan[l].tiles > 1) n_multi += plan[l].tiles * plan[l].splits;
+      else { n_single += plan[l].splits; single_blocks += (double)plan[l].splits * plan[l].mb_per_split; }
+    }
+    const bool uneven = T.uneven > 0 && !T.balanced && n_multi == T.total && n_single > 0 && n_single <= n_multi &&
+                        d->n_layers + 2 <= WG_MAXV;
+    const double f = uneven ? (double)n_single / n_multi : 0.0;
+    const double b = uneven ? single_blocks / n_single * T.uneven / 100.0 : 0.0;
+    for (int l = 0; l < d->n_layers; ++l) {
+      const WgradFragPlan& p = plan[l];
+      int s_short = (uneven && p.tiles > 1) ? ((int)(f * p.splits + 0.5) + 4) / 8 * 8 : 0;  // whole XCD rows of splits (wgrad_frag_body)
+      if (s_short <= 0 || s_short >= p.splits || n_ent + 2 > WG_MAXV) s_short = 0;
+      if (!s_short) {
+        ent[n_ent++] = Entry{l, 0, p.MB, p.mb_per_split, p.splits, 0};
+        continue;
       }
-  int pos_of[FB_MAXL];
-  for (int j = 0; j < FB_MAXL; ++j) pos_of[order[j]] = j;
+      const int s_long = p.splits - s_short;
+      const double fl = (double)s_short / p.splits;
+      int L1 = (int)((double)p.MB / p.splits - (1.0 - fl) * b + 0.5);
+      if (L1 < 1) L1 = 1;
+      int L2 = (p.MB - s_short * L1 + s_long - 1) / s_long;
+      const int cut = s_long * L2 < p.MB ? s_long * L2 : p.MB;
+      L1 = (p.MB - cut + s_short - 1) / s_short;  // the short class covers exactly what is left
+      ent[n_ent++] = Entry{l, 0, cut, L2, s_long, 0};
+      ent[n_ent++] = Entry{l, cut, p.MB, L1 > 0 ? L1 : 1, s_short, s_long};
+    }
+    if (T.long_first)
+      for (int i = 1; i < n_ent; ++i)  // stable insertion sort by descending blocks per split
+        for (int j = i; j > 0 && ent[j].per > ent[j - 1].per; --j) { const Entry t = ent[j]; ent[j] = ent[j - 1]; ent[j - 1] = t; }
+  }
+  if (getenv("RG_WGRAD_DEBUG")) {  // the launch plan, once per distinct shape (diagnostics: profiles/scripts)
+    static int shown_batch = -1, shown_layers = -1;
+    if (shown_batch != batch || shown_layers != d->n_layers) {
+      shown_batch = batch; shown_layers = d->n_layers;
+      for (int j = 0; j < n_ent; ++j)
+        fprintf(stderr, "rg_mlp_wgrad_fused: entry %d layer %d (dW %d x %d, %d tile%s) blocks [%d, %d) in %d splits of %d\n", j, ent[j].layer,
+                d->dims[ent[j].layer + 1], d->dims[ent[j].layer], plan[ent[j].layer].tiles, plan[ent[j].layer].tiles > 1 ? "s" : "",
+                ent[j].mb_base, ent[j].mb_end, ent[j].splits, ent[j].per);
+    }
+  }
+  float* part_of[FB_MAXL];
+  long slab_of[FB_MAXL];
   for (int l = 0; l < FB_MAXL; ++l) {
     R.elem_begin[l] = el;
     if (l < d->n_layers) {
       if (!d->dz_frag[l] || !d->act_frag[l] || !d->dw[l]) return RG_EINVAL;
       const int out_f = d->dims[l + 1], in_f = d->dims[l];
-      WgradFragPlan p = plan[l];
+      const WgradFragPlan& p = plan[l];
+      const long slab = wgrad_slab_floats(p);
+      part_of[l] = part; slab_of[l] = slab;
+      R.partial[l] = part; R.slab[l] = slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
+      R.mode[l] = part_mode; R.NTb[l] = p.NTb; R.N[l] = out_f; R.K[l] = in_f;
 #ifdef RG_WGRAD_LAYER_MASK  // timing ablation only (profiles/scripts): layers outside the mask get no workgroups, dW = 0
-      if (!((RG_WGRAD_LAYER_MASK >> l) & 1)) p.splits = 0;
+      if (!((RG_WGRAD_LAYER_MASK >> l) & 1)) R.splits[l] = 0;
 #endif
-      WgradFragArgs& g = G.layer[pos_of[l]];
-      g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
-      g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
-      g.partial = part; g.slab = p.slab; g.N = out_f; g.K = in_f;
-      g.x3 = d->x3 ? 1 : 0;
-      g.shape = p.shape;
-      g.a_lo = d->x3 ? (long)frag_elems(batch, out_f) : 0;
-      g.b_lo = d->x3 ? (long)frag_elems(batch, in_f) : 0;
-      R.partial[l] = part; R.slab[l] = p.slab; R.splits[l] = p.splits; R.out[l] = d->dw[l];
-      part += (size_t)p.splits * p.slab;
-      el += p.slab;
+      part += (size_t)p.splits * slab;
+      el += part_mode == 1 ? (long)p.NTa * p.NTb * 256 : p.slab;  // threads of the reduce launch: a workgroup per tile, or one per element
     } else {
+      part_of[l] = nullptr; slab_of[l] = 0;
       R.partial[l] = nullptr; R.slab[l] = 0; R.splits[l] = 0; R.out[l] = nullptr;
+      R.mode[l] = 0; R.NTb[l] = 1; R.N[l] = 0; R.K[l] = 0;
     }
   }
-  for (int j = 0; j < FB_MAXL; ++j) {  // workgroup ranges in launch order
+  G.n = n_ent;
+  for (int j = 0; j < WG_MAXV; ++j) {  // workgroup ranges in launch order
     G.wg_begin[j] = wg;
-    if (j < d->n_layers) {
-      const WgradFragPlan& p = plan[order[j]];
-      int splits = p.splits;
-#ifdef RG_WGRAD_LAYER_MASK
-      if (!((RG_WGRAD_LAYER_MASK >> order[j]) & 1)) splits = 0;
-#endif
-      wg += p.tiles * ((splits + 7) / 8 * 8);  // the tiles of a split on ONE XCD (wgrad_frag_body), eight splits abreast
-    } else {
+    if (j >= n_ent) {
       G.layer[j] = G.layer[0];
+      continue;
     }
+    const Entry& e = ent[j];
+    const int l = e.layer;
+    const WgradFragPlan& p = plan[l];
+    WgradFragArgs& g = G.layer[j];
+    g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
+    g.NTa = p.NTa; g.NTb = p.NTb; g.MB = e.mb_end; g.mb_base = e.mb_base; g.mb_per_split = e.per; g.splits = e.splits;
+    g.partial = part_of[l] + (size_t)e.split_base * slab_of[l]; g.slab = slab_of[l]; g.N = d->dims[l + 1]; g.K = d->dims[l];
+    g.x3 = d->x3 ? 1 : 0;
+    g.shape = p.shape;
+    g.a_lo = d->x3 ? (long)frag_elems(batch, d->dims[l + 1]) : 0;
+    g.b_lo = d->x3 ? (long)frag_elems(batch, d->dims[l]) : 0;
+    g.part_mode = part_mode;
+    int splits = e.splits;
+#ifdef RG_WGRAD_LAYER_MASK
+    if (!((RG_WGRAD_LAYER_MASK >> l) & 1)) splits = g.splits = 0;
+#endif
+    wg += p.tiles * ((splits + 7) / 8 * 8);  // the tiles of a split on ONE XCD (wgrad_frag_body), eight splits abreast
   }
-  G.wg_begin[FB_MAXL] = wg;
+  G.wg_begin[WG_MAXV] = wg;
   R.elem_begin[FB_MAXL] = el;
-  for (int l = d->n_layers; l <= FB_MAXL; ++l) { G.wg_begin[l] = wg; R.elem_begin[l] = el; }
+  for (int l = d->n_layers; l <= FB_MAXL; ++l) R.elem_begin[l] = el;
   const size_t lds = (size_t)WG_SHAPED_LDS;
   RG_ALLOW_LDS(wgrad_group_kernel, lds);
   RG_LAUNCH_DYN(wgrad_group_kernel, dim3(wg), dim3(WG_THREADS), lds, (hipStream_t)stream, G);

@@ -49,6 +49,9 @@ struct GatherTable {
 // aligned unit (16 B when the row pitch allows, else the element size).  One workgroup moves
 // ROWS_PER_WG rows of one column; consecutive lanes take consecutive 16-B pieces of a row so a
 // 512-B observation row is one fully coalesced half-wave request.
+#ifndef RG_GATHER_REGCOLS
+#define RG_GATHER_REGCOLS 1  // replay_dqn_batch_kernel: column descriptors as a structure of arrays in LDS (16-byte, conflict-free reads)
+#endif
 constexpr int GATHER_ROWS_PER_WG = 64;
 constexpr int GATHER_MAX_LDS_COLS = 512;  // descriptors of one column staged in LDS (12 KB)
 
@@ -324,7 +327,7 @@ __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __rest
   __shared__ int s_steps[GATHER_ROWS_PER_WG];
   __shared__ unsigned char s_term[GATHER_ROWS_PER_WG];
   __shared__ int s_act[GATHER_ROWS_PER_WG], s_nact[GATHER_ROWS_PER_WG];
-  __shared__ rg_norm_col s_nc[GATHER_MAX_LDS_COLS];
+  __shared__ __attribute__((aligned(16))) rg_norm_col s_nc[GATHER_MAX_LDS_COLS];
   const rg_replay_view& v = a.v;
   const rg_dqn_batch_out& o = a.o;
   const int row0 = blockIdx.x * GATHER_ROWS_PER_WG;
@@ -358,12 +361,65 @@ __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __rest
       s_nact[threadIdx.x] = (a1 >= 0 && a1 < A) ? (int)a1 : -1;
     }
   }
+  // Round 5: the descriptors of the four columns of a 16-byte chunk come out of LDS as three 16-byte reads of a
+  // structure-of-arrays image (op | p0 | p1; p2 / p3 only for the two ops that have them) instead of twelve 4-byte reads of
+  // 24-byte records at a lane stride of 96 bytes — an 8-way bank conflict each: PMC (profiles/r04_pmc) showed the LDS pipe
+  // busy for half of the launch, 74 % of those cycles conflicts.  Same arithmetic, same bits.
+  const int cpr = F >> 2;  // F % 4 == 0 (checked by the host)
+#if RG_GATHER_REGCOLS
+  int* s_op = (int*)s_nc;                       // [GATHER_MAX_LDS_COLS] each, inside the same 12 KB
+  float* s_p0 = (float*)s_nc + GATHER_MAX_LDS_COLS;
+  float* s_p1 = s_p0 + GATHER_MAX_LDS_COLS;
+  float* s_p2 = s_p1 + GATHER_MAX_LDS_COLS;
+  float* s_p3 = s_p2 + GATHER_MAX_LDS_COLS;
+  if (piece < 2 && cols)
+    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+      const rg_norm_col c = cols[j];
+      s_op[j] = c.op; s_p0[j] = c.p0; s_p1[j] = c.p1; s_p2[j] = c.p2; s_p3[j] = c.p3;
+    }
+  __syncthreads();
+  if (piece < 2) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    void* dst = piece == 0 ? o.state : o.next_state;
+    const int total = nrows * cpr;
+    for (int it = threadIdx.x; it < total; it += blockDim.x) {
+      const int r = it / cpr, ch = it - r * cpr;
+      const f32x4 raw = stream_load((const f32x4*)(v.observation + s_src[r] * F + ch * 4));  // (read once: streaming, see below)
+      float w[4] = {raw[0], raw[1], raw[2], raw[3]};
+      if (cols) {
+        const i32x4 op = *(const i32x4*)(s_op + ch * 4);
+        const f32x4 p0 = *(const f32x4*)(s_p0 + ch * 4), p1 = *(const f32x4*)(s_p1 + ch * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rg_norm_col c;
+          c.op = op[e]; c.in_col = 0; c.p0 = p0[e]; c.p1 = p1[e]; c.p2 = 0.f; c.p3 = 0.f;
+          if (c.op == RG_NORM_BOXCOX || c.op == RG_NORM_CONTINUOUS_ACTION) {
+            c.p2 = s_p2[ch * 4 + e];
+            c.p3 = s_p3[ch * 4 + e];
+          }
+          w[e] = normalize_value(c, w[e], 1.f, quantiles);
+        }
+      }
+      const long at = (long)(row0 + r) * F + ch * 4;
+      if (o.state_dtype == RG_DT_BF16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(w[0], w[1]);
+        pk.y = pack_bf16x2(w[2], w[3]);
+        *(uint2*)((bf16_t*)dst + at) = pk;
+      } else {
+        *(f32x4*)((float*)dst + at) = f32x4{w[0], w[1], w[2], w[3]};
+      }
+    }
+    return;
+  }
+#else
   if (piece < 2 && cols)
     for (int j = threadIdx.x; j < F; j += blockDim.x) s_nc[j] = cols[j];
   __syncthreads();
+#endif
   if (piece < 2) {
     void* dst = piece == 0 ? o.state : o.next_state;
-    const int cpr = F >> 2, total = nrows * cpr;  // F % 4 == 0 (checked by the host)
+    const int total = nrows * cpr;
     for (int it = threadIdx.x; it < total; it += blockDim.x) {
       const int r = it / cpr, ch = it - r * cpr;
       // a sampled row is read once: streaming load, so that 67 MB of replay rows per batch do not push the networks'

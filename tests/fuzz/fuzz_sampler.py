@@ -9,8 +9,9 @@ from reagent_amd.replay_memory import ReplayBuffer
 
 random.seed(3)
 bad = 0
-for case in range(12):
-    F = 4 * random.randint(1, 40); A = random.randint(1, 20); H = random.randint(1, 5)
+for case in range(20):
+    # (widths whose 16-byte chunks divide the workgroup — 4 .. 128, 256, 512 — take the register-descriptor path of round 5)
+    F = random.choice([4 * random.randint(1, 40), 4 * random.randint(1, 40), 8, 32, 64, 128, 256]); A = random.randint(1, 20); H = random.randint(1, 5)
     cap = random.randint(H + 40, 300); n = random.randint(H + 5, cap + 50); B = random.choice([1, 5, 63, 64, 65, 130])
     with_mask = random.random() < 0.5; norm = random.random() < 0.6
     dt = torch.bfloat16 if (norm and random.random() < 0.5) else torch.float32
