@@ -205,6 +205,46 @@ def relaunch_under_torchrun(args):
     os.execv(sys.executable, cmd)
 
 
+def bind_rank_to_gpu_numa(local_rank, local_world):
+    """CPU affinity of this rank = its share of the cores of ITS GPU's NUMA node (sysfs: /sys/bus/pci/devices/<gpu>/numa_node,
+    local_cpulist).  Eight ranks of one node otherwise float over all sockets: an eager step costs the host ~0.3 ms of a
+    0.5 ms step, and a rank whose enqueue thread sits on the far socket (or shares cores with another rank's) goes host-bound
+    first.  The ranks whose GPUs hang off the same node split its cores evenly, in local-rank order.  Returns what was done
+    (reported per rank in the line) or a reason; never raises — an unreadable topology leaves the affinity alone."""
+    try:
+        def parse(cpulist):
+            out = []
+            for part in cpulist.strip().split(","):
+                if not part:
+                    continue
+                lo, _, hi = part.partition("-")
+                out.extend(range(int(lo), int(hi or lo) + 1))
+            return out
+
+        def gpu_node(i):
+            pr = torch.cuda.get_device_properties(i)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            base = f"/sys/bus/pci/devices/{pci}"
+            with open(base + "/numa_node") as fh:
+                node = int(fh.read())
+            with open(base + "/local_cpulist") as fh:
+                return node, parse(fh.read())
+
+        node, cpus = gpu_node(local_rank)
+        allowed = os.sched_getaffinity(0)
+        cpus = sorted(set(cpus) & allowed)
+        if node < 0 or not cpus:
+            return {"bound": False, "reason": f"numa_node {node}, {len(cpus)} usable local cpus"}
+        sharing = [r for r in range(local_world) if gpu_node(r)[0] == node]
+        pos, n = sharing.index(local_rank), len(sharing)
+        chunk = max(1, len(cpus) // n)
+        mine = cpus[pos * chunk:(pos + 1) * chunk] or cpus
+        os.sched_setaffinity(0, mine)
+        return {"bound": True, "numa_node": node, "cpus": len(mine), "first_cpu": mine[0], "ranks_on_node": n}
+    except Exception as e:  # containers without the sysfs entries, single-socket boxes, ...
+        return {"bound": False, "reason": repr(e)}
+
+
 def layer_dims(args):
     out = args.actions * (args.atoms or 1)
     return [args.state_dim] + [args.hidden] * args.layers + [out]
@@ -882,12 +922,16 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     if dist is not None:
         # every rank's own view, so a curve measured by the driver explains itself: the rank's wall time for the median
         # region and the HIP-event time of the gradient all-reduce (instrumented pass)
+        try:
+            ncpu = float(len(os.sched_getaffinity(0)))
+        except Exception:
+            ncpu = float("nan")
         mine = torch.tensor([own_regions[mid] / args.steps * 1e3, host_dt / args.steps * 1e3,
-                             extra.get("all_reduce_us", float("nan"))], device=device, dtype=torch.float64)
+                             extra.get("all_reduce_us", float("nan")), ncpu], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": i, "ms_per_step": t[0].item(), "host_enqueue_ms_per_step": t[1].item(),
-                     "all_reduce_us": t[2].item()} for i, t in enumerate(allr)]
+                     "all_reduce_us": t[2].item(), "cpus_in_affinity": t[3].item()} for i, t in enumerate(allr)]
     return {"value": world * args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
             "timing": f"median of {len(regions)} regions of {args.steps} steps each",
             "region_ms": [round(r * 1e3, 4) for r in regions], "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
@@ -974,6 +1018,7 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} has no GPU (device_count {torch.cuda.device_count()}, --gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    affinity = bind_rank_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -1002,6 +1047,8 @@ def main():
         }
         if world > 1:
             res["per_rank"] = m["per_rank"]
+            res["cpu_affinity_rank0"] = affinity
+            assert res["rccl_ranks"] == args.gpus == world, "the line must describe the group that ran"
         res["launch_calibration"] = m["launch_calibration"]
         if m["sustained"] is not None:
             res["sustained"] = m["sustained"]

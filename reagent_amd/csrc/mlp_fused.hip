@@ -690,10 +690,17 @@ __host__ __device__ __forceinline__ int wgrad_shape_gb(int shape) {
 // [a_hi (GA tiles) | a_lo (GA) | b_hi (GB) | b_lo (GB)] x 1 KB — the same bytes, ring and DMA count per thread as the bf16
 // core's stage of the same shape, twice the stages, three MFMAs per tile pair: per operand byte 1.5x the MFMA work of the
 // bf16 kernel.  DMA i of a stage moves the 1 KB planes 8 i .. 8 i + 7, one per wave.
-template <typename S>
+// TWO (x3 == 2, rg_mlp_frag.h: x3_dz_planes() == 1): the A operand (dZ) is ONE plane — a stage is [a_hi (GA) | b_hi (GB) | b_lo (GB)],
+// two MFMAs per tile pair (a_hi.b_lo + a_hi.b_hi).
+template <typename S, bool TWO = false>
 __device__ __forceinline__ void wgrad_x3_shape_core(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
                                                     char* smem) {
-  constexpr int GA = S::GA, GB = S::GB, TA = S::TA, TB = S::TB, DMA = S::DMA, SLOTS = S::SLOTS, FLY = S::SLOTS - 1;
+  constexpr int GA = S::GA, GB = S::GB, TA = S::TA, TB = S::TB;
+  constexpr int PA = TWO ? GA : 2 * GA;                     // A planes of a stage
+  constexpr int DMA = TWO ? (PA + 2 * GB + 7) / 8 : S::DMA; // 1 KB planes, eight (one per wave) per DMA
+  constexpr int STAGE_BYTES = TWO ? DMA * 8 * 1024 : S::STAGE_BYTES;
+  constexpr int SLOTS = TWO ? (STAGE_BYTES <= 32 * 1024 ? 4 : 3) : S::SLOTS, FLY = SLOTS - 1;
+  static_assert(SLOTS * STAGE_BYTES <= WG_SHAPED_LDS, "LDS of the two-product stage ring");
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int lr = lane & 31, lg = lane >> 5;
   const int wn = wave / S::WK, wk = wave % S::WK;
@@ -718,9 +725,9 @@ __device__ __forceinline__ void wgrad_x3_shape_core(const WgradFragArgs& g, int 
 #pragma unroll
   for (int i = 0; i < DMA; ++i) {
     const int q = i * 8 + wave;  // plane of this wave's DMA (wave-uniform)
-    const bool is_a = q < 2 * GA;
+    const bool is_a = q < PA;
     const int qa = q < GA ? q : q - GA;                  // tile within the A planes
-    int qb = q - 2 * GA;                                 // within the B planes (hi, lo, padding)
+    int qb = q - PA;                                     // within the B planes (hi, lo, padding)
     const bool b_is_lo = qb >= GB;
     qb = qb >= GB ? qb - GB : qb;
     qb = qb < 0 ? 0 : qb;
@@ -736,29 +743,29 @@ __device__ __forceinline__ void wgrad_x3_shape_core(const WgradFragArgs& g, int 
     const int h = sc & 1;
     static_for<0, DMA>([&](auto i_c) __attribute__((always_inline)) {
       constexpr int i = decltype(i_c)::value;
-      global_load_lds_b128(src0[i] + mb * blk_stride[i] + h * 512, smem + slot * S::STAGE_BYTES + (i * 8 + wave) * 1024);
+      global_load_lds_b128(src0[i] + mb * blk_stride[i] + h * 512, smem + slot * STAGE_BYTES + (i * 8 + wave) * 1024);
     });
   };
   const bool wave_has_tiles = wn * TA < na && wk * TB < nb;
   auto compute = [&](int slot) {
     if (!wave_has_tiles) return;
-    const char* base = smem + slot * S::STAGE_BYTES + lane * 16;
+    const char* base = smem + slot * STAGE_BYTES + lane * 16;
     u16x8 ah[TA], al[TA], bh[TB], bl[TB];
 #pragma unroll
     for (int i = 0; i < TA; ++i) {
       ah[i] = *(const u16x8*)(base + (wn * TA + i) * 1024);
-      al[i] = *(const u16x8*)(base + (GA + wn * TA + i) * 1024);
+      if (!TWO) al[i] = *(const u16x8*)(base + (GA + wn * TA + i) * 1024);
     }
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
-      bh[j] = *(const u16x8*)(base + (2 * GA + wk * TB + j) * 1024);
-      bl[j] = *(const u16x8*)(base + (2 * GA + GB + wk * TB + j) * 1024);
+      bh[j] = *(const u16x8*)(base + (PA + wk * TB + j) * 1024);
+      bl[j] = *(const u16x8*)(base + (PA + GB + wk * TB + j) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
       for (int j = 0; j < TB; ++j) {  // the small products first
-        acc[i][j] = mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
+        if (!TWO) acc[i][j] = mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
         acc[i][j] = mfma_32x32x16_bf16(ah[i], bl[j], acc[i][j]);
         acc[i][j] = mfma_32x32x16_bf16(ah[i], bh[j], acc[i][j]);
       }
@@ -789,6 +796,16 @@ __device__ __forceinline__ void wgrad_x3_shape_core(const WgradFragArgs& g, int 
 // the workgroup's core for its layer's operand format and tile shape (all arguments workgroup-uniform)
 __device__ __forceinline__ void wgrad_dispatch(const WgradFragArgs& g, int ng, int kg, int mb_begin, int mb_end, float* part,
                                                char* smem) {
+  if (g.x3 == 2) {  // dZ as one plane (two products)
+    switch (g.shape) {
+      case WG_SHAPE_16x4: wgrad_x3_shape_core<WgS16x4, true>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      case WG_SHAPE_4x16: wgrad_x3_shape_core<WgS4x16, true>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      case WG_SHAPE_2x16: wgrad_x3_shape_core<WgS2x16, true>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      case WG_SHAPE_1x16: wgrad_x3_shape_core<WgS1x16, true>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+      default: wgrad_x3_shape_core<WgS8x8, true>(g, ng, kg, mb_begin, mb_end, part, smem); break;
+    }
+    return;
+  }
   if (g.x3) {
     switch (g.shape) {
       case WG_SHAPE_16x4: wgrad_x3_shape_core<WgS16x4>(g, ng, kg, mb_begin, mb_end, part, smem); break;
@@ -1937,7 +1954,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     g.a_frag = (const bf16_t*)d->dz_frag[l]; g.b_frag = (const bf16_t*)d->act_frag[l];
     g.NTa = p.NTa; g.NTb = p.NTb; g.MB = e.mb_end; g.mb_base = e.mb_base; g.mb_per_split = e.per; g.splits = e.splits;
     g.partial = part_of[l] + (size_t)e.split_base * slab_of[l]; g.slab = slab_of[l]; g.N = d->dims[l + 1]; g.K = d->dims[l];
-    g.x3 = d->x3 ? 1 : 0;
+    g.x3 = d->x3 ? (x3_dz_planes() == 1 ? 2 : 1) : 0;
     g.shape = p.shape;
     g.a_lo = d->x3 ? (long)frag_elems(batch, d->dims[l + 1]) : 0;
     g.b_lo = d->x3 ? (long)frag_elems(batch, d->dims[l]) : 0;

@@ -458,7 +458,8 @@ __device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16
       for (int i = 0; i < 8; ++i) split_pack(v[2 * i], v[2 * i + 1], PH[tm][tn][i], PL[tm][tn][i]);
       if (STORE_DZ) {
         store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PH[tm][tn]);
-        store_packed_frags(dz_dst + dz_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
+        // dz_lo < 0: the weight gradient reads dZ as ONE bf16 plane (rg_mlp_frag.h: x3_dz_planes) — nobody reads a lo plane
+        if (dz_lo >= 0) store_packed_frags(dz_dst + dz_lo, mb_base + tm, nt, NT, lane, PL[tm][tn]);
       } else {
         pin_packed(PH[tm][tn]);
         pin_packed(PL[tm][tn]);
@@ -682,7 +683,7 @@ __device__ __forceinline__ void mlp_bwd_x3_body(const MlpArgs& a) {
   if (!GROUPED) {
     if (!DX_ONLY) {
       emit_frags_x3(act, pitch, nop / 32, a.dz_frag[L - 1], unit * X3_TM, wave, NW, lane);
-      emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], unit * X3_TM, wave, NW, lane);
+      if (a.dz_lo[L - 1] >= 0) emit_frags_x3(act + LO, pitch, nop / 32, a.dz_frag[L - 1] + a.dz_lo[L - 1], unit * X3_TM, wave, NW, lane);
     }
     if (a.db_part[L - 1] && tid < a.dims[L]) {
       float s = 0.f;

@@ -28,6 +28,25 @@ constexpr int WG_THREADS = 512;  // weight-gradient kernels
 constexpr int FB_NW = RG_FUSED_WAVES;  // waves per workgroup of the forward / backward kernels (4 or 8)
 constexpr int FB_MAXL = RG_MLP_MAX_LAYERS;
 
+// Split-bf16 stacks: how many bf16 planes of dZ the STACK'S weight gradient multiplies (RG_X3_DZ_PLANES, default below).
+// 2: dW = dZ_lo x_hi + dZ_hi x_lo + dZ_hi x_hi (three MFMAs per tile pair; gradients ~1e-6 of their largest entry from fp64).
+// 1 (round 5): dZ travels as ONE plane, dW = dZ_hi x_lo + dZ_hi x_hi — the backward launch writes no lo plane (205 MB per C2
+// step) and the weight gradient streams three planes instead of four; dZ's rounding (2^-9 per element, independent over the
+// batch rows a dW entry sums) leaves dW within ~1.4e-3 of its largest entry (profiles/microbench/two_product.py: the
+// first-Adam-step direction flips it adds stay under 0.05 %).  north_star's 1e-4 binds Q-values / logits — the forward and
+// dgrad stay three-product either way.
+#ifndef RG_X3_DZ_PLANES
+#define RG_X3_DZ_PLANES 2
+#endif
+inline int x3_dz_planes() {
+  static const int v = [] {
+    const char* e = getenv("RG_X3_DZ_PLANES");
+    const int n = e ? atoi(e) : RG_X3_DZ_PLANES;
+    return n == 1 ? 1 : 2;
+  }();
+  return v;
+}
+
 struct MlpArgs {
   int n_layers, batch;
   int dims[FB_MAXL + 1];
@@ -828,7 +847,11 @@ static inline int fill_args(const rg_mlp_desc* d, int batch, MlpArgs& a, int bac
     if (!a.wfrag[l] && !(backward && l == 0)) return RG_EINVAL;
     a.wfrag_lo[l] = d->x3 ? (long)(backward ? wfrag_elems(d->dims[l], d->dims[l + 1]) : wfrag_elems(d->dims[l + 1], d->dims[l])) : 0;
     // (a grouped output layer's dZ fragments: group g's 32-row blocks start g blocks late, grouped_dz_rows)
-    a.dz_lo[l] = d->x3 ? (long)frag_elems(d->tile_key && l == d->n_layers - 1 ? grouped_dz_rows(batch, d->n_groups) : batch, d->dims[l + 1]) : 0;
+    const bool grouped_out = d->tile_key && l == d->n_layers - 1;
+    a.dz_lo[l] = d->x3 ? (long)frag_elems(grouped_out ? grouped_dz_rows(batch, d->n_groups) : batch, d->dims[l + 1]) : 0;
+    // one-plane dZ for the stack's weight gradient (x3_dz_planes): the backward launch skips the lo-plane stores; a grouped
+    // output layer's dZ keeps both planes (rg_group_head_wgrad reads them)
+    if (d->x3 && !grouped_out && x3_dz_planes() == 1) a.dz_lo[l] = -1;
   }
   for (int l = 0; l <= d->n_layers; ++l) {
     a.act_frag[l] = (bf16_t*)(l < d->n_layers ? d->act_frag[l] : nullptr);

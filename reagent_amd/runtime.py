@@ -165,7 +165,7 @@ class _GraphedLoop:
 
         tr = self.trainer
         dev = torch.device(self.rb.device)
-        if dev.type != "cuda":
+        if not self._graphs_available(dev):
             raise RuntimeError("HIP graphs need the GPU")
         # every argument error BEFORE the trainer is switched to graph mode, warmed up or captured
         n_steps = max(1, int(steps_per_replay))
@@ -182,7 +182,8 @@ class _GraphedLoop:
         for _ in range(max(2, warmup)):  # eager: allocations, optimizer state, first-step staging; the step
             self.step()                  # after these is the steady-state launch sequence
         self.flush()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         # Indices: a persistent buffer the captured sampler reads.  Filled by the caller (static_indices) or, by default,
         # from the loop's index pool right before each replay (one 512 KB device copy) — the in-graph torch.randint was
         # THREE kernel nodes (Philox offset bookkeeping + the draw: ~23 us per step, what made the replayed C2 step
@@ -217,14 +218,10 @@ class _GraphedLoop:
                     out = self._eager_step(idx, **extra)
             graphs = (g,)
         else:
-            pool = torch.cuda.graph_pool_handle()
-            gs, gu, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs, pool=pool, capture_error_mode="thread_local"):  # captured in replay order (shared pool)
-                batch = self.make_batch(idx)
-            with torch.cuda.graph(gu, pool=pool, capture_error_mode="thread_local"):
-                tr.native_update()
-            with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
-                out = tr.native_forward_backward(batch)
+            pool = self._new_graph_pool()
+            gs, batch = self._record(lambda: self.make_batch(idx), pool)  # recorded in replay order (shared pool)
+            gu, _ = self._record(lambda: tr.native_update(), pool)
+            gc, out = self._record(lambda: tr.native_forward_backward(batch), pool)
             graphs = (gs, gu, gc)
             self._graph_batch = batch
         tr.all_batches_processed = done  # the capture call ran the host side of a step, not the step
@@ -238,6 +235,24 @@ class _GraphedLoop:
                            steps=n_steps)
         self.replay_steps = n_steps
         return self.replay
+
+    # ---- the three hooks through which capture() reaches the graph API (the world-2 gloo test of the data-parallel replay
+    # order substitutes re-executing stand-ins for them: tests/test_graph_replay.py) ----
+    @staticmethod
+    def _graphs_available(dev) -> bool:
+        return dev.type == "cuda"
+
+    @staticmethod
+    def _new_graph_pool():
+        return torch.cuda.graph_pool_handle()
+
+    @staticmethod
+    def _record(fn, pool=None):
+        """(graph, what fn returned): the launches fn enqueues, recorded as one HIP graph"""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            out = fn()
+        return g, out
 
     def _cursor_protocol(self, dev):
         """None, or what a capture with a device-side index cursor needs (the DQN-family loop on the one-launch sampler and

@@ -190,3 +190,35 @@ def test_parity_leg_of_the_other_configurations(emu_lib, monkeypatch, config, pr
         assert out["meets_north_star"] and out["rel_dloss"] <= 1e-4, out
     else:
         assert out["sane"], out
+
+
+def test_numa_binding_never_raises_and_reports_why(monkeypatch, tmp_path):
+    """bench.bind_rank_to_gpu_numa: a box without GPUs / sysfs topology is left alone with a reason; with a topology the ranks
+    whose GPUs share a NUMA node split its cores in local-rank order (fake sysfs + fake device properties)."""
+    import types
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    r = bench.bind_rank_to_gpu_numa(0, 8)
+    assert r["bound"] is False and "reason" in r
+    # fake topology: GPUs 0-3 on node 0 (cpus 0-7), GPUs 4-7 on node 1 (cpus 8-15)
+    props = lambda i: types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x10 + i, pci_device_id=0)  # noqa: E731
+    monkeypatch.setattr(bench.torch.cuda, "get_device_properties", props)
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/sys/bus/pci/devices/0000:"):
+            i = int(path.split(":")[1], 16) - 0x10
+            text = str(i // 4) if path.endswith("numa_node") else ("0-7" if i < 4 else "8-15")
+            f = tmp_path / f"f{i}_{path.split('/')[-1]}"
+            f.write_text(text + "\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr("builtins.open", fake_open)
+    monkeypatch.setattr(bench.os, "sched_getaffinity", lambda pid: set(range(16)))
+    bound = {}
+    monkeypatch.setattr(bench.os, "sched_setaffinity", lambda pid, cpus: bound.setdefault("cpus", list(cpus)))
+    r = bench.bind_rank_to_gpu_numa(5, 8)
+    assert r == {"bound": True, "numa_node": 1, "cpus": 2, "first_cpu": 10, "ranks_on_node": 4} and bound["cpus"] == [10, 11]

@@ -137,10 +137,11 @@ def _worker(rank, world, port, kind, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     B = 64
     full = _batches(kind, B)
-    half = {k: v[rank * B // 2 : (rank + 1) * B // 2].contiguous() for k, v in full.items()}
+    per = B // world  # equal shards: the mean over the batch is the mean of the ranks' means
+    half = {k: v[rank * per : (rank + 1) * per].contiguous() for k, v in full.items()}
     g = torch.Generator().manual_seed(9)
     noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
-    my_noise = tuple(n[rank * B // 2 : (rank + 1) * B // 2].contiguous() for n in noise)
+    my_noise = tuple(n[rank * per : (rank + 1) * per].contiguous() for n in noise)
     tr = _build(kind).enable_data_parallel()
     fused = kind in ("dqn_fused", "sac_fused", "dqn_x3", "qr_fused")
     calls = []
@@ -248,6 +249,29 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib,
     tr.apply_pending_update() if kind == "dqn_deferred" else None
     for a, p in zip(r0, tr.parameters()):
         assert (a.double() - p.detach().double()).abs().max() <= 2e-6, kind
+
+
+@pytest.mark.parametrize("world,kind", [(4, "dqn"), (4, "dqn_deferred"), (4, "sac"), (8, "dqn"), (8, "dqn_deferred")])
+def test_four_and_eight_ranks_equal_single_process_on_concatenated_batch(tmp_path, emu_lib, world, kind):
+    """BASELINE C5's equivalence at reduced size: `world` ranks on disjoint equal shards of one batch, gradient
+    slab all-reduced (sum) with 1/world folded into Adam — every replica bit-identical to every other, and equal to ONE
+    process stepping on the concatenated batch.  world = 8 is the node the scaling curve is measured on."""
+    port = free_port()
+    mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
+    reps = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    for r in range(1, world):
+        for a, b in zip(reps[0], reps[r]):
+            assert torch.equal(a, b), (r, kind)
+    B = 64
+    full = _batches(kind, B)
+    g = torch.Generator().manual_seed(9)
+    noise = (torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g))
+    tr = _build(kind)
+    for _ in range(2):
+        _step(kind, tr, full, noise)
+    tr.apply_pending_update() if kind == "dqn_deferred" else None
+    for a, p in zip(reps[0], tr.parameters()):
+        assert (a.double() - p.detach().double()).abs().max() <= 2e-6, (world, kind)
 
 
 @pytest.mark.gpu

@@ -189,6 +189,59 @@ def test_fused_x3_is_fp32_class(backend, dims, acts, batch):
     assert torch.equal(out2, out)
 
 
+_ONE_PLANE_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+if {emu}:
+    import emu_backend; emu_backend.install()
+import reagent_amd._lib as L
+import test_fused_mlp as T
+from reagent_amd.engine import FusedMLP, make_stack
+dev = "cpu" if {emu} else "cuda"
+dims, acts, batch = [128, 512, 512, 16], ["relu", "relu", "linear"], 192
+ws, bs = T._net(dims, acts, 1, dev)
+st = make_stack(ws, bs, [L.ACT[a] for a in acts], L.PREC_BF16X3)
+assert isinstance(st, FusedMLP) and st.x3
+st.set_need_input_grad(True); st.stage_weights(need_transposed=True)
+g = torch.Generator().manual_seed(2)
+x = torch.randn(batch, dims[0], generator=g).to(dev)
+dout = (torch.randn(batch, dims[-1], generator=g) / batch).to(dev)
+out = torch.zeros(batch, dims[-1], device=dev)
+xc, xt = st.stage_input(x, True)
+st.forward(xc, out, save=True)
+dw = [torch.zeros_like(w) for w in ws]; db = [torch.zeros_like(b) for b in bs]
+dx = torch.zeros(batch, dims[0], device=dev)
+st.backward(dout, xt, dw, db, dx32=dx)
+ref_out, ref_dw, ref_db, ref_dx = T._ref64(ws, bs, acts, x, dout)
+print("RESULT", T._rel(out, ref_out), max(T._rel(dw[l], ref_dw[l]) for l in range(3)), max(T._rel(db[l], ref_db[l]) for l in range(3)), T._rel(dx, ref_dx))
+"""
+
+
+def test_x3_one_plane_dz_option(backend):
+    """RG_X3_DZ_PLANES=1 (rg_mlp_frag.h: x3_dz_planes — opt-in, NOT the default): the stack's weight gradient multiplies dZ as ONE
+    bf16 plane (two MFMAs per tile pair, no dZ lo plane written or read: -6 % on the C2 split-bf16 step, profiles/r05_*).
+    What it keeps: the forward, dgrad (dx) and the bias gradients stay three-product / fp32-class.  What it gives up: dW is
+    bf16-rounded-dZ class, ~2e-3 relative — this test pins both (and that the default build is NOT that, test above)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for planes in ("1", "2"):
+        env = dict(os.environ, RG_X3_DZ_PLANES=planes)
+        p = subprocess.run([sys.executable, "-c", _ONE_PLANE_SNIPPET.format(root=root, emu=backend.name == "emu")],
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[planes] = [float(v) for v in [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0].split()[1:]]
+    print(f"\n[x3 dZ planes] (out, dW, db, dx) relative errors: two planes {res['2']}, one plane {res['1']}")
+    out1, dw1, db1, dx1 = res["1"]
+    out2, dw2, db2, dx2 = res["2"]
+    assert out1 == out2 and dx1 == dx2 and db1 == db2  # only the weight gradient changes
+    assert out1 < 2e-5 and dx1 < 3e-5 and db1 < 3e-5 and dw2 < 3e-5
+    assert 1e-4 < dw1 < 5e-3  # one plane of dZ: 2^-9 per element
+
+
 def test_x3_on_an_unserved_shape_runs_exact_fp32(backend):
     ws, bs = _net([16, 128, 64, 4], ["relu", "relu", "linear"], 0, backend.device)
     st = make_stack(ws, bs, [1, 1, 0], L.PREC_BF16X3)

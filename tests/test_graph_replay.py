@@ -393,3 +393,145 @@ def test_replayed_step_protocol_on_the_interpreter(emu_lib):
     for pa, pb in zip(te.q_network.parameters(), th.q_network.parameters()):
         assert torch.equal(oe.state[pa]["exp_avg"], oh.state[pb]["exp_avg"]) and torch.equal(oe.state[pa]["exp_avg_sq"], oh.state[pb]["exp_avg_sq"])
         assert float(oe.state[pa]["step"]) == float(oh.state[pb]["step"]) == 7.0
+
+
+# ---- the data-parallel three-graph replay ORDER on two real ranks (gloo), graphs replaced by re-executing stand-ins -------
+class _ReplayedLaunches:
+    """Stands for a HIP graph on a box without one: `replay()` re-issues the recorded launches (calls the recorded function
+    again) and leaves the results in the buffers of the first run — what a replayed graph does with its fixed addresses."""
+
+    def __init__(self, fn, trainer_ref, run_now):
+        # A capture RECORDS: nothing executes.  Only the sampler region is run here (it has no state, and the batch buffers it
+        # returns are what the third region reads); the update and forward/backward regions run at replay() only, their
+        # result landing in a placeholder the caller already holds.
+        self.fn, self.tr = fn, trainer_ref
+        self.out = fn() if run_now else torch.empty(0)
+
+    def _host_counters(self, restore=None):
+        """a real replay runs no python: what the re-executed function counted on the HOST (steps taken, Adam's pending device
+        steps) is put back — runtime.flush() counts the replays (note_graph_replays), as it does for real graphs"""
+        tr = self.tr["tr"]
+        scheds = [s for o in tr.native_optimizers() for s in getattr(o, "_scheds", {}).values()]
+        if restore is None:
+            return tr.all_batches_processed, [s.pending for s in scheds]
+        tr.all_batches_processed = restore[0]
+        for s, v in zip(scheds, restore[1]):
+            s.pending = v
+
+    @staticmethod
+    def _copy_into(dst, src):
+        import dataclasses
+
+        if isinstance(dst, torch.Tensor):
+            if dst.shape != src.shape:
+                dst.resize_(src.shape)
+            dst.copy_(src)
+        elif dataclasses.is_dataclass(dst):
+            for f in dataclasses.fields(dst):
+                a, b = getattr(dst, f.name), getattr(src, f.name)
+                if a is not None and b is not None:
+                    _ReplayedLaunches._copy_into(a, b)
+        elif isinstance(dst, (list, tuple)):
+            for a, b in zip(dst, src):
+                _ReplayedLaunches._copy_into(a, b)
+
+    def replay(self):
+        saved = self._host_counters()
+        res = self.fn()
+        if res is not None:
+            self._copy_into(self.out, res)
+        self._host_counters(saved)
+
+
+def _dp_graph_worker(rank, world, port, out_dir, mode):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import emu_backend
+
+    emu_backend.install()
+    import torch.distributed as dist
+
+    from reagent_amd.runtime import _GraphedLoop
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _GraphedLoop._graphs_available = staticmethod(lambda dev: True)
+    _GraphedLoop._new_graph_pool = staticmethod(lambda: None)
+
+    ref = {}
+
+    def record(fn, pool=None):
+        g = _ReplayedLaunches(fn, ref, run_now=not ref.setdefault("recorded", 0))
+        ref["recorded"] += 1
+        return g, g.out
+
+    _GraphedLoop._record = staticmethod(record)
+    loop, tr = _small_dp_loop(rank)
+    ref["tr"] = tr
+    tr.enable_data_parallel()
+    N = 5
+    idx = [torch.randint(512, (64,), generator=torch.Generator().manual_seed(60 + 10 * rank + k)) for k in range(N)]
+    losses = []
+    if mode == "eager":
+        for _ in range(2):
+            loop.step()
+        step = loop.step
+    else:
+        step = loop.capture(warmup=2, static_indices=True)
+        assert loop._graph["dp"] and len(loop._graph["graphs"]) == 3
+    for k in range(N):
+        losses.append(step(idx[k]).clone())
+    loop.flush()
+    assert tr.all_batches_processed == N + 2
+    torch.save(dict(losses=torch.stack(losses), params=[p.detach().clone() for p in tr.parameters()]),
+               os.path.join(out_dir, f"{mode}_rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _small_dp_loop(rank):
+    from reagent_amd.preprocessing import Preprocessor
+    from reagent_amd.replay_memory import ReplayBuffer
+    from reagent_amd.runtime import OfflineDqnLoop
+    from reagent_amd.training import DQNTrainer
+
+    S, A, C, B = 24, 4, 512, 64
+    set_default_precision(L.PREC_BF16)
+    try:
+        torch.manual_seed(3)  # identical initial weights on every rank
+        q = FullyConnectedDQN(S, A, [256, 256], ["relu", "relu"])
+    finally:
+        set_default_precision(L.PREC_F32)
+    tr = DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(A)],
+                    rl=RLParameters(gamma=0.9, target_update_rate=0.05, q_network_loss="huber"),
+                    optimizer=Optimizer__Union.default(lr=0.003), evaluation=EvaluationParameters(calc_cpe_in_training=False))
+    rb = ReplayBuffer(replay_capacity=C, batch_size=B, device="cpu")
+    rb.load_columns(synthetic.replay_contents(C, S, A, seed=9 + rank), mark_all_valid=True)  # this rank's shard
+    mean, std = synthetic.normalization_table(S, 7)
+    pre = Preprocessor({i: NormalizationParameters(feature_type="CONTINUOUS", mean=mean[i].item(), stddev=std[i].item())
+                        for i in range(S)}, device="cpu")
+    return OfflineDqnLoop(rb, tr, B, pre, state_dtype=torch.bfloat16), tr
+
+
+def test_data_parallel_three_graph_replay_order_on_two_gloo_ranks(tmp_path, emu_lib):
+    """the three-graph data-parallel replay (sample | update | forward + backward, the gradient all-reduce
+    launched eagerly between them, the update of step k joined at step k + 1) had only ever run on a ONE-rank RCCL group.
+    Here its host-side ORDER runs on two real ranks with a real collective (gloo), the graphs replaced by stand-ins that
+    re-issue the recorded launches: both ranks finish (no mismatched collective), stay bit-identical to each other, and
+    equal the eager data-parallel loop on the same indices step for step."""
+    import torch.multiprocessing as mp
+
+    from conftest import free_port
+
+    for mode in ("eager", "graph"):
+        mp.spawn(_dp_graph_worker, args=(2, free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    e0, e1 = torch.load(tmp_path / "eager_rank0.pt"), torch.load(tmp_path / "eager_rank1.pt")
+    g0, g1 = torch.load(tmp_path / "graph_rank0.pt"), torch.load(tmp_path / "graph_rank1.pt")
+    for a, b in zip(g0["params"], g1["params"]):
+        assert torch.equal(a, b)  # replicas in lockstep
+    for a, b in zip(e0["params"], g0["params"]):
+        assert torch.equal(a, b)  # the replayed order == the eager loop
+    assert torch.equal(e0["losses"], g0["losses"]) and torch.equal(e1["losses"], g1["losses"])
