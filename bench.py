@@ -619,13 +619,26 @@ def kernel_profile(args, step, steps, device=None):
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     qa = QueueAhead(device)
-    host_ms = []
+    # ONE blocker, long enough for the host to enqueue two warm steps and all `steps` instrumented ones behind it: the device
+    # then runs them back to back at the clock of a busy chip, as in the timed region (a blocker per step — the first form of
+    # this pass — let the chip idle 3 ms before every step: spans 1.6 % above the timed step, profiles/r05_run3).
+    with ops.profile():  # what the host needs per instrumented step (records dropped)
+        t = time.perf_counter()
+        step()
+        dry_ms = (time.perf_counter() - t) * 1e3
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    blocker_ms = 1.3 * dry_ms * (steps + 2) + 1.0
+    t0 = time.perf_counter()
+    qa.block(blocker_ms)
+    for _ in range(2):
+        step()
     with ops.profile() as prof:
         for _ in range(steps):
-            qa.block()
-            t = time.perf_counter()
             step()
-            host_ms.append((time.perf_counter() - t) * 1e3)
+    host_total_ms = (time.perf_counter() - t0) * 1e3
+    host_ms = [host_total_ms / (steps + 2)]
+    qa.ms = blocker_ms
     rows = prof.summary()
     # A span = the launch(es) of the entry point + the pair of marker packets that bracket it; what an EMPTY bracket costs
     # behind a busy queue was calibrated above (QueueAhead.marker_us, ~4.7 us) and is taken off every span.  First
@@ -736,9 +749,10 @@ def kernel_profile(args, step, steps, device=None):
     out["instrumented_pass"] = {
         "steps": steps, "event_ms_per_step_sum": out["event_ms_per_step_sum"], "event_span_ms_per_step_sum": out["event_span_ms_per_step_sum"],
         "queue_ahead": {"on": qa.on, "blocker_ms": qa.ms if qa.on else None, "host_enqueue_ms_per_step": host,
-                        "queued_behind_blocker": bool(qa.on and host is not None and host < qa.ms),
+                        "host_enqueue_ms_total": host_total_ms,
+                        "queued_behind_blocker": bool(qa.on and host_total_ms < qa.ms),
                         "marker_pair_us": qa.marker_us},
-        "note": "HIP events on the launch stream around every C-ABI call; every step is enqueued behind a device-side blocker, "
+        "note": "HIP events on the launch stream around every C-ABI call; two warm steps and all instrumented ones are enqueued behind ONE device-side blocker, "
                 "so a span is the launch's own duration + the marker pair, independent of the host's pace; launch times = span - "
                 "marker_pair_us (calibrated in the same pass); nothing is rescaled to the timed step"}
     return out

@@ -175,7 +175,10 @@ typedef struct {
   int32_t dx_col0;
   int32_t x2_dtype;                           /* element type of x2 (RG_DT_*): the panels may differ — network-ready bf16
                                                * state rows from the sampler next to fp32 actions */
-  int32_t reserved2;
+  int32_t wgrad_flags;                        /* ABI 10 (was reserved, 0).  rg_mlp_wgrad_fused: bit 0 = this launch shares the chip
+                                               * with another launch on a second stream (the QR-DQN trunk beside the grouped
+                                               * head's weight gradient): every split of a layer keeps the same length — the
+                                               * uneven plan leans on the launch's own dispatch order */
   /* forward only: row r of the batch the kernels work on reads input row rowmap[r] of x (-1: an all-zero row);
    * `batch` is then the length of rowmap.  Lets a stack run in "grouped space" (rows sorted by a key and padded to
    * whole 128-row tiles, qr_grouped.hip) without materialising the permuted input. */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RG_LIB: another build of the same library (same-box A/B of compile-time kernel variants); default = the in-tree build
 LIB_PATH = os.environ.get("RG_LIB") or os.path.join(_HERE, "lib", "libreagent_hip.so")
 
-ABI_VERSION = 9  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
+ABI_VERSION = 10  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5}
@@ -80,7 +80,7 @@ class MlpDesc(ctypes.Structure):
         ("x_split", ctypes.c_int32),
         ("dx_col0", ctypes.c_int32),
         ("x2_dtype", ctypes.c_int32),
-        ("reserved2", ctypes.c_int32),
+        ("wgrad_flags", ctypes.c_int32),  # ABI 10: bit 0 = the weight-gradient launch shares the chip (even splits)
         ("rowmap", c_void_p),
         ("tile_key", c_void_p),
         ("row_begin", c_void_p),

@@ -45,6 +45,9 @@
 #ifndef RG_WGRAD_BF16_PART
 #define RG_WGRAD_BF16_PART 1  // bf16 stack launch: split partials as bf16 tiles in accumulator order (WgradFragArgs.part_mode)
 #endif
+#ifndef RG_WGRAD_PART_NT
+#define RG_WGRAD_PART_NT 0   // (measured round 5: 0 / 1 / 2 / 3 all within 1 us; plain is the simplest) bf16 partial tiles: bit 0 = non-temporal stores (wgrad), bit 1 = non-temporal loads (reduce)
+#endif
 #ifndef RG_WGRAD_UNEVEN
 #define RG_WGRAD_UNEVEN 125  // stack launch: uneven splits of the multi-tile layers (rg_mlp_wgrad_fused); value = cost of a single-tile
 #endif                       // workgroup's block in percent of a multi-tile one's; 0 = every split of a layer the same length
@@ -460,6 +463,7 @@ struct WgradFragArgs {
   // contiguous (32 bytes) — so a tile leaves as two 16-byte stores per lane instead of sixteen 4-byte ones and the launch
   // writes (and its reduce reads) half the bytes; slab = NTa * NTb * 512 floats' worth.  The reduce launch undoes the order.
   int part_mode;
+  int part_nt;        // part_mode 1: bit 0 = the partial tiles leave as non-temporal stores (RG_WGRAD_PART_NT, A/B switch)
 };
 
 
@@ -654,8 +658,10 @@ __device__ __forceinline__ void wgrad_shape_core(const WgradFragArgs& g, int ng,
         if (tn < nta && tk < ntb) {
           pk4_t* dst = (pk4_t*)(pb + ((long)tn * ntb + tk) * 1024 + lane * 16);
           const f32x16& c = acc[i][j];
-          dst[0] = pk4_t{pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7])};
-          dst[1] = pk4_t{pack_bf16x2(c[8], c[9]), pack_bf16x2(c[10], c[11]), pack_bf16x2(c[12], c[13]), pack_bf16x2(c[14], c[15])};
+          const pk4_t v0 = pk4_t{pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]), pack_bf16x2(c[4], c[5]), pack_bf16x2(c[6], c[7])};
+          const pk4_t v1 = pk4_t{pack_bf16x2(c[8], c[9]), pack_bf16x2(c[10], c[11]), pack_bf16x2(c[12], c[13]), pack_bf16x2(c[14], c[15])};
+          if (g.part_nt & 1) { stream_store(v0, dst); stream_store(v1, dst + 1); }
+          else { dst[0] = v0; dst[1] = v1; }
         }
       }
     RG_PHASE(4);
@@ -929,15 +935,18 @@ struct ReduceGroupArgs {
   float* out[FB_MAXL];
   // part_mode 1 layers (WgradFragArgs.part_mode): bf16 partial tiles in accumulator order; N x K = valid extents of dW
   int mode[FB_MAXL], NTb[FB_MAXL], N[FB_MAXL], K[FB_MAXL];
+  int nt_loads;  // part_mode 1: the partial tiles are read with non-temporal loads (RG_WGRAD_PART_NT bit 1)
 };
 
 // One 256-thread workgroup = one 32 x 32 tile: wave w sums the lane records (16 values, 32 contiguous bytes per split) of the
 // w-th quarter of the splits — all of a quarter's records requested before the first is added (RG_REDUCE_FLY_BF16 at a
 // time): the launch runs on loads in flight, 148 workgroups of one wave each were 16 dependent round trips — the four
 // quarter sums meet in LDS and are added in a fixed order.  Writes the row-major dW.
+template <bool NT>
 __device__ __forceinline__ void reduce_tiles_bf16(const float* part, long slab, int splits, float* out, int NTb, int N, int K,
                                                   long t, float (*red)[16][64]) {
   typedef __attribute__((ext_vector_type(4))) unsigned pk4_t;
+  auto stream_load = [](const pk4_t* p) { return NT ? rg::stream_load(p) : *p; };  // (the partials are read exactly once)
   const int lane = (int)(t & 63), w = (int)((t >> 6) & 3);
   const long tile = t >> 8;
   const int tn = (int)(tile / NTb), tk = (int)(tile % NTb);
@@ -1008,7 +1017,8 @@ __device__ __forceinline__ void reduce_group_body(const ReduceGroupArgs& R, long
     }
   if (mode == 1) {  // (whole workgroups: a layer's range is 256 threads per tile)
     __shared__ float red[4][16][64];
-    reduce_tiles_bf16(part, slab, splits, out, NTb, N, K, i - base, red);
+    if (R.nt_loads) reduce_tiles_bf16<true>(part, slab, splits, out, NTb, N, K, i - base, red);
+    else reduce_tiles_bf16<false>(part, slab, splits, out, NTb, N, K, i - base, red);
     return;
   }
   const long e = i - base;
@@ -1677,7 +1687,7 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
   g.a_frag = (const bf16_t*)dz_frag; g.b_frag = (const bf16_t*)x_frag;
   g.NTa = p.NTa; g.NTb = p.NTb; g.MB = p.MB; g.mb_base = 0; g.mb_per_split = p.mb_per_split; g.splits = p.splits;
   g.partial = (float*)workspace; g.slab = p.slab; g.N = out_features; g.K = in_features;
-  g.x3 = 0; g.a_lo = g.b_lo = 0; g.shape = p.shape; g.part_mode = 0;
+  g.x3 = 0; g.a_lo = g.b_lo = 0; g.shape = p.shape; g.part_mode = 0; g.part_nt = 0;
   const int grid = p.tiles * ((p.splits + 7) / 8 * 8);
   const size_t lds = (size_t)WG_SHAPED_LDS;
   RG_ALLOW_LDS(wgrad_frag_kernel, lds);
@@ -1713,7 +1723,7 @@ int rg_group_head_wgrad(const void* dz_frag, const void* h_frag, const int32_t* 
   G.g.x3 = x3 ? 1 : 0;
   G.g.a_lo = x3 ? (long)frag_elems(grouped_dz_rows(rows, n_groups), group_rows) : 0;
   G.g.b_lo = x3 ? (long)frag_elems(rows, in_features) : 0;
-  G.g.shape = WG_SHAPE_8x8; G.g.part_mode = 0;
+  G.g.shape = WG_SHAPE_8x8; G.g.part_mode = 0; G.g.part_nt = 0;
   G.row_begin = row_begin; G.n_groups = n_groups; G.splits = splits;
   const int k_groups = (G.g.NTb + 7) / 8;
   const size_t lds = (size_t)WgS8x8::LDS_BYTES;
@@ -1765,10 +1775,11 @@ int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t s
 // chosen so that ALL workgroups of the launch are one round of the chip (RG_WGRAD_TOTAL, default = the CU count) and
 // take the same time by the rates above: fewer partial bytes, no tail.  (Round 3's "256 in all" experiment lost because a
 // split count that is not a multiple of 8 fell off the XCD-grouped decode: every byte then came from HBM twice.)
-struct WgradTuning { int balanced, total; double shared, unshared; int thin, long_first, bf16_part, uneven; };
+struct WgradTuning { int balanced, total; double shared, unshared; int thin, long_first, bf16_part, uneven, part_nt; };
 static const WgradTuning& wgrad_tuning() {
   static const WgradTuning t = [] {
-    WgradTuning v{0, 0, 46.0, 28.0, RG_WGRAD_TARGET_THIN, 1, RG_WGRAD_BF16_PART, RG_WGRAD_UNEVEN};
+    WgradTuning v{0, 0, 46.0, 28.0, RG_WGRAD_TARGET_THIN, 1, RG_WGRAD_BF16_PART, RG_WGRAD_UNEVEN, RG_WGRAD_PART_NT};
+    if (const char* e = getenv("RG_WGRAD_PART_NT")) v.part_nt = atoi(e);
     if (const char* e = getenv("RG_WGRAD_BF16_PART")) v.bf16_part = atoi(e);
     if (const char* e = getenv("RG_WGRAD_UNEVEN")) v.uneven = atoi(e);
     if (const char* e = getenv("RG_WGRAD_THIN")) v.thin = atoi(e);
@@ -1875,14 +1886,20 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
   int n_ent = 0;
   {
     const WgradTuning& T = wgrad_tuning();
+    // Applies to the launch it was measured on: every multi-tile layer's workgroups are ONE round of the chip and only
+    // single-tile layers follow (C2's stack, either precision: 101 -> 94.7 us, split-bf16 221 -> 203).  Measured and NOT
+    // extended (round 5, same box): counting a narrower multi-tile first layer among the followers (C4's critic, 512 x 288:
+    // 116 -> 119 us), and any launch that shares the chip with another one (C3's trunk beside the head's weight gradient on
+    // the second stream: 113.6 -> 122.6 us — the dispatch order this plan leans on is then not the launch's own; such
+    // callers set rg_mlp_desc.wgrad_flags & 1).
     int n_multi = 0, n_single = 0;
     double single_blocks = 0.0;
     for (int l = 0; l < d->n_layers; ++l) {
       if (plan[l].tiles > 1) n_multi += plan[l].tiles * plan[l].splits;
       else { n_single += plan[l].splits; single_blocks += (double)plan[l].splits * plan[l].mb_per_split; }
     }
-    const bool uneven = T.uneven > 0 && !T.balanced && n_multi == T.total && n_single > 0 && n_single <= n_multi &&
-                        d->n_layers + 2 <= WG_MAXV;
+    const bool uneven = T.uneven > 0 && !T.balanced && !(d->wgrad_flags & 1) && n_multi == T.total && n_single > 0 &&
+                        n_single <= n_multi && d->n_layers + 2 <= WG_MAXV;
     const double f = uneven ? (double)n_single / n_multi : 0.0;
     const double b = uneven ? single_blocks / n_single * T.uneven / 100.0 : 0.0;
     for (int l = 0; l < d->n_layers; ++l) {
@@ -1941,6 +1958,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     }
   }
   G.n = n_ent;
+  R.nt_loads = (wgrad_tuning().part_nt >> 1) & 1;
   for (int j = 0; j < WG_MAXV; ++j) {  // workgroup ranges in launch order
     G.wg_begin[j] = wg;
     if (j >= n_ent) {
@@ -1959,6 +1977,7 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     g.a_lo = d->x3 ? (long)frag_elems(batch, d->dims[l + 1]) : 0;
     g.b_lo = d->x3 ? (long)frag_elems(batch, d->dims[l]) : 0;
     g.part_mode = part_mode;
+    g.part_nt = wgrad_tuning().part_nt;
     int splits = e.splits;
 #ifdef RG_WGRAD_LAYER_MASK
     if (!((RG_WGRAD_LAYER_MASK >> l) & 1)) splits = g.splits = 0;

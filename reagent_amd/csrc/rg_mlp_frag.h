@@ -26,6 +26,9 @@ constexpr int WG_THREADS = 512;  // weight-gradient kernels
 #define RG_FUSED_WAVES 8
 #endif
 constexpr int FB_NW = RG_FUSED_WAVES;  // waves per workgroup of the forward / backward kernels (4 or 8)
+#ifndef RG_SAVE_NT
+#define RG_SAVE_NT 1  // saved fragments leave as non-temporal stores (store_packed_frags; same-box A/B switch)
+#endif
 constexpr int FB_MAXL = RG_MLP_MAX_LAYERS;
 
 // Split-bf16 stacks: how many bf16 planes of dZ the STACK'S weight gradient multiplies (RG_X3_DZ_PLANES, default below).
@@ -265,7 +268,11 @@ __device__ __forceinline__ void store_packed_frags(bf16_t* dst, int mb, int nt, 
     // streaming store: the fragments are read next by another launch (the weight gradient), never again by this one,
     // and should not push the weights out of L2 (same-box A/B: the consuming wgrad launch 137 -> 131 us)
     const u32x4 v = u32x4{P[4 * h], P[4 * h + 1], P[4 * h + 2], P[4 * h + 3]};
+#if RG_SAVE_NT
     stream_store(v, (u32x4*)(dst + frag_offset(mb, nt, NT, h, lane)));
+#else
+    *(u32x4*)(dst + frag_offset(mb, nt, NT, h, lane)) = v;
+#endif
   }
 }
 

@@ -659,6 +659,9 @@ def fused_backward_grouped(st: "FusedMLP", head: GroupedHead, space, dz32: torch
         else:
             ops.reduce_sum(part, part.numel(), scale, out)
     ws = st._ws
+    # (ABI 10) beside the head's weight gradient on the second stream the trunk's launch does not own the dispatch order its
+    # uneven split plan leans on: measured 113.6 -> 122.6 us with it, so it is told to keep its splits even
+    t.wgrad_flags = 1 if (dz32.is_cuda and two_streams) else 0
     # the trunk is its own launch plan (the splits of a launch are shared out over ITS layers): its own workspace size
     need = lib.rg_mlp_wgrad_fused_workspace_bytes(t, R)
     if ws["wgrad"].numel() * 4 < need:
