@@ -13,7 +13,7 @@ __device__ unsigned long long* g_stamps;
 namespace rg {
 int x3_forward_launch(const rg_mlp_desc*, MlpArgs&, hipStream_t) { return RG_EINVAL; }
 int x3_backward_launch(const rg_mlp_desc*, MlpArgs&, hipStream_t) { return RG_EINVAL; }
-void grouped_bias_reduce_launch(const float*, const int*, int, int, float*, hipStream_t) {}
+void grouped_bias_reduce_launch(const float*, const int*, int, int, float*, int, hipStream_t) {}
 }
 #include <cstdio>
 #include <vector>
