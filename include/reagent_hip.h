@@ -248,7 +248,12 @@ int rg_fc_wgrad_frag(const void* dz_frag, const void* x_frag, int out_features, 
 
 /* Whole-stack variants: every layer's weights staged by ONE launch (d->w -> d->wfrag_fwd, and
  * d->wfrag_bwd when need_bwd), every layer's weight gradient by ONE wgrad launch + ONE reduce
- * (d->dz_frag, d->act_frag -> d->dw). */
+ * (d->dz_frag, d->act_frag -> d->dw).  The weight gradient is a deterministic split over the batch (same inputs, same
+ * bits); the workspace holds the splits' partial tiles — fp32 for split-bf16 stacks, bf16 in accumulator-tile order for
+ * bf16 stacks (round 5: half the bytes; 2^-9 of a PARTIAL sum, far inside what bf16 operands cost the gradient) — and is
+ * sized by rg_mlp_wgrad_fused_workspace_bytes for either form.  Split-bf16 stacks multiply BOTH planes of dZ (three
+ * MFMAs per tile pair: fp32-class gradients) unless the library runs with RG_X3_DZ_PLANES=1 (dZ as one plane, two
+ * MFMAs, ~2e-3 relative on dW: an opt-in). */
 int rg_mlp_stage_weights_fused(const rg_mlp_desc* d, int need_bwd, rg_stream_t stream);
 size_t rg_mlp_wgrad_fused_workspace_bytes(const rg_mlp_desc* d, int batch);
 int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t workspace_bytes,
