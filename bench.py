@@ -691,7 +691,9 @@ def kernel_profile(args, step, steps, device=None):
                            "marker_pair_us": qa.marker_us, "launches_per_step": dom["calls"] / steps,
                            "averaging": "call-weighted over every launch of the entry point in the instrumented steps "
                                         "(all variants): algorithmic FLOP of those launches / their summed HIP-event time; "
-                                        "launch time = event span - the calibrated cost of the marker pair that brackets it",
+                                        "launch time = event span - the calibrated cost of the marker pair that brackets it; it still holds the "
+                                        "dispatch gap in front of the kernel (2-4 us: rocprofv3's kernel durations in profiles/ are that much "
+                                        "shorter, while the spans add up to the timed step within 1-2 %)",
                            "variants": dom["variants"], "traffic": None}
         if mfma_per_product != 1:
             out["roofline"]["executed_frac"] = mfma_per_product * ach / peak
