@@ -608,7 +608,7 @@ class QueueAhead:
             torch.cuda._sleep(int((ms or self.ms) * self.cycles_per_ms))
 
 
-def kernel_profile(args, step, steps, device=None):
+def kernel_profile(args, step, steps, device=None, gpu_ms=None):
     """Instrumented pass: HIP events around every C-ABI launch (on the launch stream), each step enqueued behind a
     device-side blocker (QueueAhead) so that the spans are kernel durations, not host gaps.  Rows of one entry point are
     MERGED over its variants (saving / non-saving forwards, the nets of a step): the dominant entry point is the one with
@@ -619,24 +619,41 @@ def kernel_profile(args, step, steps, device=None):
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     qa = QueueAhead(device)
-    # ONE blocker, long enough for the host to enqueue two warm steps and all `steps` instrumented ones behind it: the device
-    # then runs them back to back at the clock of a busy chip, as in the timed region (a blocker per step — the first form of
-    # this pass — let the chip idle 3 ms before every step: spans 1.6 % above the timed step, profiles/r05_run3).
-    with ops.profile():  # what the host needs per instrumented step (records dropped)
+    # The host has to be AHEAD of the device for the whole instrumented pass (two warm steps + `steps` instrumented ones), or
+    # the spans time host gaps.  The lead is built with the workload itself: plain steps enqueue faster than the device runs
+    # them (C2: 0.29 against 0.49 ms), so a burst of them leaves a backlog — and the chip at the clock and power of the
+    # timed region.  (The first forms of this pass used torch's spin kernel as the blocker: one wavefront busy, the chip
+    # otherwise idle, and its clock sagged under a 10 ms one — spans 7 % above the timed step on the pool's fastest box,
+    # profiles/r05_run4.)  Only a host that cannot outrun the device (a host-bound box) falls back to the spin kernel.
+    with ops.profile():  # what the host needs per INSTRUMENTED step (records dropped)
         t = time.perf_counter()
         step()
         dry_ms = (time.perf_counter() - t) * 1e3
     if device.type == "cuda":
         torch.cuda.synchronize()
-    blocker_ms = 1.3 * dry_ms * (steps + 2) + 1.0
+    t = time.perf_counter()
+    for _ in range(3):
+        step()
+    plain_ms = (time.perf_counter() - t) * 1e3 / 3
+    lead_needed = 1.3 * dry_ms * (steps + 2) + 0.5
+    gap = (gpu_ms - plain_ms) if gpu_ms else 0.0
     t0 = time.perf_counter()
-    qa.block(blocker_ms)
+    if qa.on and gap > 0.03:
+        backlog_steps = min(400, int(lead_needed / gap) + 1)
+        for _ in range(backlog_steps):
+            step()
+        lead_mode, blocker_ms = f"backlog of {backlog_steps} plain steps", backlog_steps * gap
+    else:
+        backlog_steps = 0
+        qa.block(lead_needed)
+        lead_mode, blocker_ms = "spin kernel (host-bound loop: the chip's clock may sag under it)", lead_needed
+    t1 = time.perf_counter()
     for _ in range(2):
         step()
     with ops.profile() as prof:
         for _ in range(steps):
             step()
-    host_total_ms = (time.perf_counter() - t0) * 1e3
+    host_total_ms = (time.perf_counter() - t1) * 1e3
     host_ms = [host_total_ms / (steps + 2)]
     qa.ms = blocker_ms
     rows = prof.summary()
@@ -750,11 +767,12 @@ def kernel_profile(args, step, steps, device=None):
     host = sorted(host_ms)[len(host_ms) // 2] if host_ms else None
     out["instrumented_pass"] = {
         "steps": steps, "event_ms_per_step_sum": out["event_ms_per_step_sum"], "event_span_ms_per_step_sum": out["event_span_ms_per_step_sum"],
-        "queue_ahead": {"on": qa.on, "blocker_ms": qa.ms if qa.on else None, "host_enqueue_ms_per_step": host,
+        "queue_ahead": {"on": qa.on, "lead": lead_mode if qa.on else None, "lead_ms": qa.ms if qa.on else None, "host_enqueue_ms_per_step": host,
+                        "plain_step_host_ms": plain_ms,
                         "host_enqueue_ms_total": host_total_ms,
                         "queued_behind_blocker": bool(qa.on and host_total_ms < qa.ms),
                         "marker_pair_us": qa.marker_us},
-        "note": "HIP events on the launch stream around every C-ABI call; two warm steps and all instrumented ones are enqueued behind ONE device-side blocker, "
+        "note": "HIP events on the launch stream around every C-ABI call; two warm steps and all instrumented ones are enqueued behind a backlog of plain steps, "
                 "so a span is the launch's own duration + the marker pair, independent of the host's pace; launch times = span - "
                 "marker_pair_us (calibrated in the same pass); nothing is rescaled to the timed step"}
     return out
@@ -928,7 +946,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         # every rank runs the instrumented steps (they contain the gradient all-reduce: a pass on rank 0
         # alone would never return); rank 0 reports.  Eager launches: events bracket each C-ABI call.
         n_prof = profile_steps or min(args.steps, 10)
-        extra = kernel_profile(args, loop.step, n_prof, device)
+        extra = kernel_profile(args, loop.step, n_prof, device, gpu_ms=dt / args.steps * 1e3)
         loop.flush()
         gq = trainer._grouped() if (args.algo == "qrdqn" and getattr(args, "grouped_head", False)) else None
         two_streams = gq is not None and (getattr(gq, "two_streams", False) or getattr(gq, "wgrad_streams", False))

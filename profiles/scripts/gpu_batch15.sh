@@ -2,7 +2,7 @@
 # round 4, batch 15: dense grouped spaces (no padding between the groups: B / 128 tiles) against the padded layout, same box:
 # GPU tests of the grouped engine, then C3 in bf16 and split-bf16 with RG_QR_DENSE = 1 / 0 (graph and eager)
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 timeout 900 python -m pytest tests/test_qrdqn_trainer.py tests/test_baseline_shapes.py tests/test_full_size.py -m gpu -q --no-header -p no:cacheprovider -k "qrdqn or c3 or grouped" > $OUT/pytest_b15.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^E  " $OUT/pytest_b15.log | tail -12
 for rep in 1 2; do
 for prec in bf16 bf16x3; do

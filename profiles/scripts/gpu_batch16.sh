@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, batch 16: with dense grouped spaces, do the two-stream halves of the C3 forward / backward still pay?  graph and eager
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 for rep in 1 2; do
 for prec in bf16 bf16x3; do
 for cfg in "RG_QR_STREAMS=1 RG_QR_WGRAD_STREAMS=1" "RG_QR_STREAMS=0 RG_QR_WGRAD_STREAMS=1" "RG_QR_STREAMS=1 RG_QR_WGRAD_STREAMS=0" "RG_QR_STREAMS=0 RG_QR_WGRAD_STREAMS=0"; do

@@ -2,7 +2,7 @@
 # round 4, batch 17: C3 after the grouped-space bookkeeping fix (scatter: sliced sums + ballots; count: loads eight at a time)
 # and the loss / trunk-bias tails folded into the trunk weight gradient's reduce launch: tests, timeline, bench bf16 / split-bf16
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 timeout 900 python -m pytest tests/test_qrdqn_trainer.py tests/test_baseline_shapes.py tests/test_full_size.py tests/test_graph_replay.py -m gpu -q --no-header -p no:cacheprovider > $OUT/pytest_b17.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^E  " $OUT/pytest_b17.log | tail -12
 bash profiles/scripts/gpu_timeline.sh c3 bf16 RG_X=1 > $OUT/tl_c3_b17.txt 2>&1; head -30 $OUT/tl_c3_b17.txt
 for rep in 1 2; do

@@ -2,7 +2,7 @@
 # round 4, batch 18: the grouped output layer (QR-DQN's 200 quantiles) through the hidden layers' main loop + staged whole-row stores
 # (ring 2 / 4 / 8) against the per-row-tile loop, same box, C3 bf16
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 timeout 600 python -m pytest tests/test_qrdqn_trainer.py tests/test_baseline_shapes.py -m gpu -q --no-header -p no:cacheprovider -k "qrdqn or c3 or grouped" 2>&1 | tail -2
 for rep in 1 2; do
 for lib in lib_out0 lib lib_out2 lib_out8; do

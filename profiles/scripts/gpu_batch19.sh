@@ -2,7 +2,7 @@
 # round 4, batch 19: the quantile head with byte-offset bisection counts (one VALU operation fewer per search step) and a DPP
 # fp64 prefix scan, against the previous build (reagent_amd/lib_prev), same box: head tests, then C3 bf16 eager, per-call times
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 timeout 600 python -m pytest tests/test_qrdqn_trainer.py tests/test_baseline_shapes.py -m gpu -q --no-header -p no:cacheprovider -k "qrdqn or c3 or grouped or compact" 2>&1 | tail -2
 for rep in 1 2 3; do
 for lib in lib_prev lib; do

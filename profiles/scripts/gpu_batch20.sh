@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, batch 20: the free-running next-batch sampler (--prefetch) on C3 / C2 / C4, eager launches, same box
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 for rep in 1 2; do
 for cfg in c3 c2; do
 for pf in "" "--prefetch"; do

@@ -2,7 +2,7 @@
 # round 4, batch 21: batch splits per action group in the grouped head's weight gradient (16 groups x 2 k-groups x splits workgroups
 # next to the trunk's weight gradient on the other stream): 8 (rounds 2-4) / 4 / 2 / 16, C3 bf16 and split-bf16, same box
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 for rep in 1 2; do
 for prec in bf16 bf16x3; do
 for sp in 8 4 2 16; do

@@ -3,7 +3,7 @@
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT; TAG=${1:-it}
 # preflight: a node whose first device touch faults (seen once: "Memory access fault by GPU" on tensor.to)
 # would otherwise burn the whole GPU budget in core dumps and timeouts
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 timeout 600 python -m pytest tests/test_fused_mlp.py tests/test_dqn_trainer.py -m gpu -q -x --no-header -p no:cacheprovider 2>&1 | tail -3
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "rc=$?"
 python - <<PY

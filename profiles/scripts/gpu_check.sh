@@ -5,7 +5,7 @@ set -u
 cd /root/repo
 # preflight: a node whose first device touch faults (seen once: "Memory access fault by GPU" on tensor.to)
 # would otherwise burn the whole GPU budget in core dumps and timeouts
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 OUT=/root/repo/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU check of the build: smoke, pytest -m gpu, bench c2 bf16 / bf16x3 / f32, c3, c4, rocprofv3 kernel stats (bf16 and bf16x3)
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT; TAG=${1:-r02}
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 export TMPDIR=/tmp
 { rocminfo 2>/dev/null | grep -E "Marketing|gfx|Compute Unit" | head -6; nproc; } > $OUT/env_$TAG.log 2>&1
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke_$TAG.log

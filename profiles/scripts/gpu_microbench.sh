@@ -2,7 +2,7 @@
 # The calibration microbenchmarks with their output KEPT: bash profiles/scripts/gpu_microbench.sh [tag]
 # (build the binaries first in the build container: bash profiles/microbench/build.sh)
 cd /root/repo; OUT=/root/repo/gpurun_out/microbench_${1:-r03}; mkdir -p $OUT
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 { rocminfo 2>/dev/null | grep -E "Marketing|gfx|Compute Unit|Uuid" | head -8; nproc; rocm-smi --showclocks --showpower 2>/dev/null | grep -vE "^=|^$" | head -20; } > $OUT/env.log 2>&1
 cd profiles/microbench
 # clocks sampled WHILE a microbenchmark runs (the chip clocks to its power budget under dense MFMA on random data)

@@ -3,7 +3,7 @@
 cd /root/repo; OUT=/root/repo/gpurun_out; TAG=${1:-pmc}; mkdir -p $OUT/pmc_$TAG
 # preflight: a node whose first device touch faults (seen once: "Memory access fault by GPU" on tensor.to)
 # would otherwise burn the whole GPU budget in core dumps and timeouts
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 export TMPDIR=/tmp
 CMD="python /root/repo/bench.py --config ${PMC_CONFIG:-c2} --precision ${PMC_PREC:-bf16} --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-parity --no-accurate --no-also --sustained-steps 0 --launch eager"
 i=0

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo; OUT=/root/repo/gpurun_out; mkdir -p $OUT; TAG=${1:-x3}
-timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
+eval "$(timeout 600 python -m reagent_amd.device_preflight | tee /dev/stderr | grep "^export ")"; timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum()) == 2 << 20" || { echo "preflight failed: faulty GPU node, aborting"; exit 97; }
 timeout 900 python -m pytest tests/test_fused_mlp.py tests/test_baseline_shapes.py tests/test_dueling.py -m gpu -q -s --no-header -p no:cacheprovider > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED" $OUT/pytest_$TAG.log | tail -5
 for spec in "c2 bf16x3" "c4 bf16x3" "c2 bf16"; do
   set -- $spec
