@@ -593,15 +593,25 @@ class QueueAhead:
         ev[1].record()
         torch.cuda.synchronize()
         self.cycles_per_ms = 20_000_000 / max(ev[0].elapsed_time(ev[1]), 1e-3)
-        # what two back-to-back records cost when nothing lies between them (behind a busy queue): the marker overhead a
-        # span carries; reported, not subtracted
+        # what two back-to-back records cost when nothing lies between them (an EMPTY bracket; reported as marker_empty_us)
         self.block()
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
         for a, b in pairs:
             a.record()
             b.record()
         torch.cuda.synchronize()
-        self.marker_us = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] * 1e3
+        self.marker_us = self.marker_empty_us = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] * 1e3
+        # A kernel of KNOWN length for the in-pass calibration (kernel_profile): a 20 us spin; its length = 64 of them back to
+        # back between ONE pair of events (the pair's cost spread over 64 launches), dispatch gap included
+        self.probe_cycles = max(1, int(0.02 * self.cycles_per_ms))
+        torch.cuda._sleep(self.probe_cycles)
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(64):
+            torch.cuda._sleep(self.probe_cycles)
+        ev[1].record()
+        torch.cuda.synchronize()
+        self.probe_us = ev[0].elapsed_time(ev[1]) * 1e3 / 64
 
     def block(self, ms=None):
         if self.on:
@@ -650,15 +660,31 @@ def kernel_profile(args, step, steps, device=None, gpu_ms=None):
     t1 = time.perf_counter()
     for _ in range(2):
         step()
+    pairs = []
     with ops.profile() as prof:
         for _ in range(steps):
             step()
+            if qa.on:
+                # What a bracket adds to the kernel inside it, measured IN this backed-up queue on a kernel of known length:
+                # span(bracketed 20 us spin) - its length.  (An empty bracket — two markers with nothing between them, 4.6-4.7
+                # us — overstates it: around a real kernel the second marker is processed while the kernel runs.  With the
+                # empty-bracket figure taken off, every launch came out 2-9 % BELOW rocprofv3 of the same box and the spans 5.5 %
+                # below the timed step; with nothing taken off 1-3.5 % above: profiles/r05_run5.)
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record()
+                torch.cuda._sleep(qa.probe_cycles)
+                b_.record()
+                pairs.append((a_, b_))
     host_total_ms = (time.perf_counter() - t1) * 1e3
+    if pairs:
+        torch.cuda.synchronize()
+        spans = sorted(x.elapsed_time(y) for x, y in pairs)
+        qa.marker_us = max(0.0, spans[len(spans) // 2] * 1e3 - qa.probe_us)
     host_ms = [host_total_ms / (steps + 2)]
     qa.ms = blocker_ms
     rows = prof.summary()
-    # A span = the launch(es) of the entry point + the pair of marker packets that bracket it; what an EMPTY bracket costs
-    # behind a busy queue was calibrated above (QueueAhead.marker_us, ~4.7 us) and is taken off every span.  First
+    # A span = the launch(es) of the entry point + what the pair of marker packets around it adds; that addition was measured
+    # once per instrumented step in the same backed-up queue, on a spin kernel of known length (QueueAhead.marker_us).  First
     # measurement (profiles/r05_run1): raw spans 93.3 / 87.0 / 41.3 us for forward / backward / gather against rocprofv3's
     # 88.6 / 82.3 / 37.2 us of the same box and binary — each high by exactly that pair.
     marker_ms = (qa.marker_us or 0.0) * 1e-3
@@ -708,9 +734,8 @@ def kernel_profile(args, step, steps, device=None, gpu_ms=None):
                            "marker_pair_us": qa.marker_us, "launches_per_step": dom["calls"] / steps,
                            "averaging": "call-weighted over every launch of the entry point in the instrumented steps "
                                         "(all variants): algorithmic FLOP of those launches / their summed HIP-event time; "
-                                        "launch time = event span - the calibrated cost of the marker pair that brackets it; it still holds the "
-                                        "dispatch gap in front of the kernel (2-4 us: rocprofv3's kernel durations in profiles/ are that much "
-                                        "shorter, while the spans add up to the timed step within 1-2 %)",
+                                        "launch time = event span - what a marker pair adds to a kernel of known length in the same queue "
+                                        "(marker_pair_us, measured in the pass)",
                            "variants": dom["variants"], "traffic": None}
         if mfma_per_product != 1:
             out["roofline"]["executed_frac"] = mfma_per_product * ach / peak
@@ -771,7 +796,8 @@ def kernel_profile(args, step, steps, device=None, gpu_ms=None):
                         "plain_step_host_ms": plain_ms,
                         "host_enqueue_ms_total": host_total_ms,
                         "queued_behind_blocker": bool(qa.on and host_total_ms < qa.ms),
-                        "marker_pair_us": qa.marker_us},
+                        "marker_pair_us": qa.marker_us, "marker_empty_bracket_us": getattr(qa, "marker_empty_us", None),
+                        "probe_kernel_us": getattr(qa, "probe_us", None)},
         "note": "HIP events on the launch stream around every C-ABI call; two warm steps and all instrumented ones are enqueued behind a backlog of plain steps, "
                 "so a span is the launch's own duration + the marker pair, independent of the host's pace; launch times = span - "
                 "marker_pair_us (calibrated in the same pass); nothing is rescaled to the timed step"}
