@@ -509,6 +509,9 @@ def parity_check(args, device, init, cols, norm):
                 out["max_abs_dq"] = (gq.qbar_next.cpu() - zrn_mean).abs().max().item()
                 out["dq_rows"] = int(live.sum())
                 out["path"] = "grouped engine, " + ("split-bf16" if gq.x3 else "bf16")
+                out["full_size"] = ("the reference cannot run this configuration at B = 65536 on a 62 GB host (its (N, B, N) tensor, "
+                                    "qrdqn_trainer.py:152): oracle parity of the full step is tested at B = 8192 and, at B = 65536, the "
+                                    "grouped engine against THIS library's dense exact-fp32 head — HIP against HIP (tests/test_full_size.py)")
             else:
                 rows = min(B, 512)  # the dense path: its [B, A * N] logits (a bounded slice of the saved forward)
                 z = trainer._q.view(B, args.actions, args.atoms)[:rows].cpu()
@@ -1014,7 +1017,7 @@ def digest_into_kept_objects(res):
         if not isinstance(pp, dict):
             return None
         return pick(pp, "ok", "meets_north_star", "sane", "batch", "max_abs_dq", "max_abs_dquantile", "max_abs_dlogits",
-                    "rel_dloss", "gather_fields_bit_exact", "path", "error")
+                    "rel_dloss", "gather_fields_bit_exact", "path", "full_size", "error")
 
     def mode_digest(o):
         d = pick(o, "dtype", "value", "ms_per_step", "error")

@@ -363,22 +363,89 @@ class Adam:
         return {"optimizer": optimizer, "lr_scheduler": self.lr_schedulers[0].make_from_optimizer(optimizer)}
 
 
+# ---- the other members of the reference's Optimizer__Union (optimizer/union.py:19-64: every torch.optim class is registered;
+# uninferrable_optimizers.py spells out the ones whose defaults cannot be inferred).  Adam is the hot path (FusedAdam, one
+# launch); these build torch's OWN optimizer over the same parameters — torch's device kernels, the reference's arithmetic — and
+# the native step then takes its separate-launch update path (optimizer.step(), rg_soft_update, re-staging on the version
+# counters).  No HIP graph capture with them (their step counts live on the host).
+class _TorchOptimizerConfig:
+    """a config whose class name is the torch.optim class it builds and whose fields are that class's arguments"""
+
+    lr_schedulers: List[LearningRateSchedulerConfig]
+
+    def make_optimizer_scheduler(self, params):
+        import dataclasses
+        import inspect
+
+        assert len(self.lr_schedulers) <= 1, "Multiple schedulers for one optimizer is no longer supported"
+        cls = getattr(torch.optim, type(self).__name__)
+        accepted = inspect.signature(cls).parameters
+        kwargs = {f.name: getattr(self, f.name) for f in dataclasses.fields(self)
+                  if f.name != "lr_schedulers" and f.name in accepted}
+        kwargs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in kwargs.items()}
+        optimizer = cls(params, **kwargs)
+        if len(self.lr_schedulers) == 0:
+            return {"optimizer": optimizer}
+        return {"optimizer": optimizer, "lr_scheduler": self.lr_schedulers[0].make_from_optimizer(optimizer)}
+
+
+def _torch_config(name, **defaults):
+    """dataclass `name` with the given fields / defaults (uninferrable_optimizers.py, torch.optim signatures) + lr_schedulers"""
+    import dataclasses
+
+    fields = [(k, type(v) if v is not None else Optional[float], dataclasses.field(default=v)) for k, v in defaults.items()]
+    fields.append(("lr_schedulers", List[LearningRateSchedulerConfig], dataclasses.field(default_factory=list)))
+    return dataclasses.make_dataclass(name, fields, bases=(_TorchOptimizerConfig,))
+
+
+SGD = _torch_config("SGD", lr=0.001, momentum=0.0, weight_decay=0.0, dampening=0.0, nesterov=False, maximize=False)
+AdamW = _torch_config("AdamW", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.01, amsgrad=False, maximize=False)
+NAdam = _torch_config("NAdam", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0, momentum_decay=4e-3)
+RAdam = _torch_config("RAdam", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0)
+Adamax = _torch_config("Adamax", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0)
+Rprop = _torch_config("Rprop", lr=0.01, etas=(0.5, 1.2), step_sizes=(1e-06, 50.0))
+RMSprop = _torch_config("RMSprop", lr=0.01, alpha=0.99, eps=1e-08, weight_decay=0.0, momentum=0.0, centered=False)
+Adagrad = _torch_config("Adagrad", lr=0.01, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10)
+Adadelta = _torch_config("Adadelta", lr=1.0, rho=0.9, eps=1e-06, weight_decay=0.0)
+ASGD = _torch_config("ASGD", lr=0.01, lambd=0.0001, alpha=0.75, t0=1000000.0, weight_decay=0.0)
+TORCH_OPTIMIZER_CONFIGS = {c.__name__: c for c in (SGD, AdamW, NAdam, RAdam, Adamax, Rprop, RMSprop, Adagrad, Adadelta, ASGD)}
+# members of the reference's union that cannot serve this path: LBFGS re-evaluates the loss through a closure (the training
+# step has no such re-entry), SparseAdam wants sparse gradients (the networks here are dense)
+_UNSERVED = {"LBFGS": "needs a closure that re-evaluates the loss", "SparseAdam": "needs sparse gradients"}
+
+
 class Optimizer__Union:
-    """``Optimizer__Union(Adam=Adam(lr=...))`` / ``Optimizer__Union.default()`` as in
-    reagent/optimizer/union.py:52-64.  Only Adam is on the hot path."""
+    """``Optimizer__Union(Adam=Adam(lr=...))`` / ``Optimizer__Union.default()`` / ``Optimizer__Union(SGD=SGD(lr=...))`` as in
+    reagent/optimizer/union.py:52-64: exactly one member set.  Adam is the hot path (FusedAdam, the one-launch update); the
+    other torch optimizers run as torch's own (TORCH_OPTIMIZER_CONFIGS) through the native step's separate-launch update."""
 
     def __init__(self, Adam: Optional["Adam"] = None, **others):
-        if others:
-            raise NotImplementedError(f"only Adam is implemented natively, got {list(others)}")
-        self.Adam = Adam if Adam is not None else globals()["Adam"]()
+        self._name, self._value = "Adam", None
+        for name, cfg in others.items():
+            if cfg is None:
+                continue
+            if name in _UNSERVED:
+                raise NotImplementedError(f"Optimizer__Union.{name}: {_UNSERVED[name]}")
+            if name not in TORCH_OPTIMIZER_CONFIGS:
+                raise ValueError(f"Optimizer__Union has no member {name!r} (members: Adam, {', '.join(sorted(TORCH_OPTIMIZER_CONFIGS))})")
+            if Adam is not None or self._value is not None:
+                raise ValueError("Optimizer__Union takes exactly one member")
+            self._name, self._value = name, cfg
+        if self._value is None:
+            self._value = Adam if Adam is not None else globals()["Adam"]()
+        self.Adam = self._value if self._name == "Adam" else None
 
     @classmethod
     def default(cls, **kwargs):
         return cls(Adam=globals()["Adam"](**kwargs))
 
     @property
+    def selected_field(self) -> str:
+        return self._name
+
+    @property
     def value(self):
-        return self.Adam
+        return self._value
 
     def make_optimizer_scheduler(self, params):
         return self.value.make_optimizer_scheduler(params)

@@ -316,6 +316,9 @@ class DiscreteCRRTrainer(DQNTrainerBaseLightning):
 
         self._dp_group = process_group if process_group is not None else dist.group.WORLD
         self._dp_world = dist.get_world_size(self._dp_group)
+        from .dqn_trainer import require_grad_scaling_optimizers
+
+        require_grad_scaling_optimizers(self)  # the 1/world of the summed gradients is folded into the Adam launches
         return self
 
     @torch.no_grad()

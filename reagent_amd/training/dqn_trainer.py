@@ -118,9 +118,23 @@ def enable_graph_mode(tr):
         # rg_dropout's Philox offset is a host-side launch argument: a replayed graph would repeat one mask forever
         raise NotImplementedError("networks with dropout layers are not captured into a HIP graph: run the native step eagerly")
     for o in tr.native_optimizers():
+        if type(o).__module__.startswith("torch.optim"):
+            # torch's own optimizers (Optimizer__Union's other members) count their steps on the host
+            raise NotImplementedError(f"{type(o).__name__}: only Adam steps are captured into a HIP graph; run the native step eagerly")
+    for o in tr.native_optimizers():
         if hasattr(o, "enable_device_schedule"):
             o.enable_device_schedule()
     tr._graph_mode = True
+
+
+def require_grad_scaling_optimizers(tr):
+    """data parallel on the trainers that fold 1/world into their Adam launches (SAC, TD3, discrete CRR): one of torch's own
+    optimizers (Optimizer__Union's other members) has no such argument — refuse rather than step on summed gradients"""
+    if getattr(tr, "_dp_world", 1) == 1:
+        return
+    for o in tr.native_optimizers():
+        if type(o).__module__.startswith("torch.optim"):  # (this package's own optimizer classes all scale in their launches)
+            raise NotImplementedError(f"{type(tr).__name__}: data parallel needs Adam optimizers (got torch.optim.{type(o).__name__})")
 
 
 def disable_graph_mode(tr):
@@ -566,7 +580,9 @@ class QStepCore(DQNTrainerBaseLightning):
                 self._fused_plan = False
         plan = self._fused_plan
         if plan is None:
-            ok = (isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and qs.x3 == ts.x3
+            from ..optimizer import FusedAdam
+
+            ok = (isinstance(adam, FusedAdam) and isinstance(qs, FusedMLP) and isinstance(ts, FusedMLP) and qs.x3 == ts.x3
                   and len(adam.param_groups) == 1
                   and len(soft.param_groups) == 1)
             if ok:
@@ -673,6 +689,20 @@ class QStepCore(DQNTrainerBaseLightning):
         with _NativeStep(self):
             self._apply_pending_update()
 
+    def _step_optimizer(self, opt):
+        """FusedAdam folds the data-parallel 1/world into its launch; one of torch's own optimizers (Optimizer__Union's other
+        members) gets the gradients scaled first — the all-reduce summed them"""
+        from ..optimizer import FusedAdam
+
+        if isinstance(opt, FusedAdam):
+            opt.grad_scale = 1.0 / self._dp_world
+        elif self._dp_world != 1:
+            for g in opt.param_groups:
+                for p in g["params"]:
+                    if p.grad is not None:
+                        p.grad.mul_(1.0 / self._dp_world)
+        opt.step()
+
     def _apply_pending_update(self):
         if self._pending_reduce is not None:
             self._pending_reduce.wait()  # the compute stream waits for the collective; the host does not
@@ -686,16 +716,14 @@ class QStepCore(DQNTrainerBaseLightning):
             return
         if self._graph_tick is not None:  # the sampler launch has already counted the step for the one-launch update
             raise RuntimeError("a step captured with a device-side index cursor needs the one-launch update")
-        adam.grad_scale = 1.0 / self._dp_world
-        adam.step()
+        self._step_optimizer(adam)
         if cpe is not None:  # reward network and CPE q-network, in the reference's optimizer order
             cpe.forward(self._pending_batch)
             for which, opt in (("reward", opts[1]), ("cpe", opts[2])):
                 for p in cpe.e[which]["params"]:
                     p.grad = None
                 cpe.backward(which)
-                opt.grad_scale = 1.0 / self._dp_world
-                opt.step()
+                self._step_optimizer(opt)
         elif self._pending_batch is not None:
             self._post_step_stats_forward(self._pending_batch)
         self._pending_batch = None

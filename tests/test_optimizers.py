@@ -173,3 +173,61 @@ def test_a_second_optimizer_over_the_same_parameters_starts_from_zero_moments(ba
         assert (p.detach().cpu() - r.detach()).abs().max() <= 1e-6
     assert float(first.state[ps[0]]["exp_avg"].abs().max()) > 0  # and the first one kept its own
     assert first.moments_for(0)[1].data_ptr() != second.moments_for(0)[1].data_ptr()
+
+
+# ---- the other members of Optimizer__Union (missing 5) -------------------------------------------------------------
+@pytest.mark.parametrize("name,kwargs", [
+    ("SGD", dict(lr=0.05, momentum=0.9, nesterov=True)),
+    ("RMSprop", dict(lr=0.01, momentum=0.5, centered=True)),
+    ("AdamW", dict(lr=0.003, weight_decay=0.05)),
+    ("Adagrad", dict(lr=0.05)),
+])
+def test_union_members_besides_adam_step_like_torch(backend, name, kwargs):
+    """Optimizer__Union(<member>=...) as in reagent/optimizer/union.py: the member's torch.optim class over the trainer's
+    parameters.  Three native DQN steps (exact-fp32 engine) against the same network stepped on the CPU by torch autograd and
+    the same torch optimizer: the gradients come from the HIP backward, the update is torch's own arithmetic."""
+    import reagent_amd.optimizer as O
+    from oracle import restated as R
+    from reagent_amd import synthetic
+    from reagent_amd.core.parameters import EvaluationParameters, RLParameters
+    from reagent_amd.models import FullyConnectedDQN
+    from reagent_amd.training import DQNTrainer
+
+    dev = backend.device
+    S, A, B = 12, 4, 64
+    torch.manual_seed(3)
+    q = FullyConnectedDQN(S, A, [32, 24], ["relu", "relu"])
+    init = [p.detach().clone() for p in q.parameters()]
+    q = q.to(dev)
+    union = O.Optimizer__Union(**{name: getattr(O, name)(**kwargs)})
+    assert union.selected_field == name and type(union.value).__name__ == name
+    tr = DQNTrainer(q, q.get_target_network(), None, actions=[str(i) for i in range(A)],
+                    rl=RLParameters(gamma=0.9, target_update_rate=0.1, q_network_loss="mse"), optimizer=union,
+                    evaluation=EvaluationParameters(calc_cpe_in_training=False)).to(dev)
+    assert isinstance(tr.native_optimizers()[0], getattr(torch.optim, name))
+    o = R.DQNOracle(init, init, ["relu", "relu", "linear"], gamma=0.9, tau=0.1, loss="mse")
+    o.opt = getattr(torch.optim, name)(o.params, **kwargs)  # the reference's arithmetic for this member IS torch's
+    for s in range(3):
+        b = synthetic.dqn_batch(B, S, A, seed=30 + s, p_impossible=0.2)
+        loss = tr.train_step_native(synthetic.to_dqn_input(b, dev))
+        ref = o.step(b)
+        assert abs(loss.item() - ref["loss"].item()) <= 1e-4 * max(1.0, abs(ref["loss"].item())), (name, s)
+    for p, r in zip(tr.q_network.parameters(), o.params):
+        assert (p.detach().cpu() - r.detach()).abs().max() <= 2e-5, name
+    for p, r in zip(tr.q_network_target.parameters(), o.target):
+        assert (p.detach().cpu() - r).abs().max() <= 2e-5, name
+
+
+def test_union_rejects_what_it_cannot_serve():
+    import reagent_amd.optimizer as O
+
+    with pytest.raises(ValueError, match="exactly one member"):
+        O.Optimizer__Union(Adam=O.Adam(), SGD=O.SGD())
+    with pytest.raises(ValueError, match="no member"):
+        O.Optimizer__Union(Lion=object())
+    with pytest.raises(NotImplementedError, match="closure"):
+        O.Optimizer__Union(LBFGS=object())
+    assert isinstance(O.Optimizer__Union.default(lr=0.01).value, O.Adam) and O.Optimizer__Union().selected_field == "Adam"
+    made = O.Optimizer__Union(SGD=O.SGD(lr=0.1, lr_schedulers=[O.StepLR(step_size=2)])).make_optimizer_scheduler(
+        [torch.nn.Parameter(torch.zeros(3))])
+    assert isinstance(made["optimizer"], torch.optim.SGD) and isinstance(made["lr_scheduler"], torch.optim.lr_scheduler.StepLR)
