@@ -46,8 +46,8 @@
 #define RG_WGRAD_BF16_PART 1  // bf16 stack launch: split partials as bf16 tiles in accumulator order (WgradFragArgs.part_mode)
 #endif
 #ifndef RG_WGRAD_PART_NT
-#define RG_WGRAD_PART_NT 0   // (measured round 5: 0 / 1 / 2 / 3 all within 1 us; plain is the simplest) bf16 partial tiles: bit 0 = non-temporal stores (wgrad), bit 1 = non-temporal loads (reduce)
-#endif
+#define RG_WGRAD_PART_NT 0   // bf16 partial tiles: bit 0 = non-temporal stores (wgrad), bit 1 = non-temporal loads (reduce).  Round 5,
+#endif                       // same box: 0 / 1 / 2 / 3 all within 1 us of each other; plain stores and loads are the default
 #ifndef RG_WGRAD_UNEVEN
 #define RG_WGRAD_UNEVEN 125  // stack launch: uneven splits of the multi-tile layers (rg_mlp_wgrad_fused); value = cost of a single-tile
 #endif                       // workgroup's block in percent of a multi-tile one's; 0 = every split of a layer the same length
@@ -1905,7 +1905,8 @@ int rg_mlp_wgrad_fused(const rg_mlp_desc* d, int batch, void* workspace, size_t 
     for (int l = 0; l < d->n_layers; ++l) {
       const WgradFragPlan& p = plan[l];
       int s_short = (uneven && p.tiles > 1) ? ((int)(f * p.splits + 0.5) + 4) / 8 * 8 : 0;  // whole XCD rows of splits (wgrad_frag_body)
-      if (s_short <= 0 || s_short >= p.splits || n_ent + 2 > WG_MAXV) s_short = 0;
+      // (an entry is kept in reserve for every layer still to come: the table has WG_MAXV slots)
+      if (s_short <= 0 || s_short >= p.splits || n_ent + 2 + (d->n_layers - 1 - l) > WG_MAXV) s_short = 0;
       if (!s_short) {
         ent[n_ent++] = Entry{l, 0, p.MB, p.mb_per_split, p.splits, 0};
         continue;
