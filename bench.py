@@ -574,14 +574,16 @@ KERNELS_OF = {"rg_mlp_forward_fused": "mlp_fwd_fused_kernel", "rg_mlp_backward_f
 
 
 class QueueAhead:
-    """Keeps the device busy for a few ms so that the host enqueues a whole instrumented step BEHIND it.
+    """Calibrations of the instrumented pass (kernel_profile) and its fallback blocker.
 
     HIP events around a launch that starts from an idle queue time the launch's dispatch latency and whatever the host
     did between its two records (round 4: the same binary summed to 0.57 ms one run and 0.78 ms the next, and a rescale
     hid it).  With the queue kept full, the start event of launch k completes when launch k-1 does and its end event when
-    launch k does: the span is the kernel's own duration plus the two marker packets, whatever the host's pace —
-    reproducible, and what `rocprofv3 --kernel-trace` reports for the same kernels (profiles/).  The blocker is torch's
-    spin kernel (torch.cuda._sleep), calibrated once with events; no blocker off-GPU (the interpreter tests)."""
+    launch k does: the span is the kernel's own duration plus what the two marker packets add, whatever the host's pace —
+    reproducible, and within a few percent of what `rocprofv3 --kernel-trace` reports for the same kernels (profiles/).
+    kernel_profile keeps the queue full with a backlog of plain steps; this class holds torch's spin kernel
+    (torch.cuda._sleep, calibrated with events) as the blocker of last resort for host-bound loops, and the kernel of known
+    length the marker pair's addition is measured on.  Nothing of it runs off-GPU (the interpreter tests)."""
 
     def __init__(self, device, ms=3.0):
         self.on = device.type == "cuda" and hasattr(torch.cuda, "_sleep")
@@ -622,8 +624,8 @@ class QueueAhead:
 
 
 def kernel_profile(args, step, steps, device=None, gpu_ms=None):
-    """Instrumented pass: HIP events around every C-ABI launch (on the launch stream), each step enqueued behind a
-    device-side blocker (QueueAhead) so that the spans are kernel durations, not host gaps.  Rows of one entry point are
+    """Instrumented pass: HIP events around every C-ABI launch (on the launch stream), all of it enqueued behind a backlog
+    of plain steps so that the spans are kernel durations, not host gaps.  Rows of one entry point are
     MERGED over its variants (saving / non-saving forwards, the nets of a step): the dominant entry point is the one with
     the largest total time and its figure the call-weighted average."""
     from reagent_amd import ops
