@@ -221,6 +221,15 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
           }
           __syncthreads();
           RG_STAMP(18);
+          // RG_OUT_ROWSTORE (round 5): the 128 x N outputs leave as whole rows, 16 bytes per lane, through a staging area in the
+          // (dead) activation tile — 8 wave stores of full 64-byte row segments for 16 Q-values instead of 64 four-byte ones
+          // that each touch 32 half-lines (fwd_phases: "sum + stores" was 4.6k of a workgroup's 83k ticks)
+          // (everything the row store needs is worked out HERE, from an opaque copy of the lane: hoisted above the hidden layers'
+          // main loops it cost the 512-wide kernel 5 spilled registers)
+          const int o_ln = opaque(lane), o_lr = o_ln & 31, o_lg = o_ln >> 5;
+          const bool rowstore = RG_OUT_ROWSTORE && (N & 3) == 0 && (a.ldo & 3) == 0 && !a.out_scatter &&
+                                ((reinterpret_cast<uintptr_t>(a.out32) & 15) == 0);
+          float* outs = (float*)act + 4 * 64 * 16;  // behind the hand-off records (16 KB)
           if (!half) {
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
@@ -228,7 +237,24 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
               acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
             }
             RG_STAMP(19);
-            store_tile(acc, tm, 0);
+            if (!rowstore) store_tile(acc, tm, 0);
+            else if (o_lr < N) {
+              const float b = b_tile0;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int rel = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lg;
+                outs[rel * N + o_lr] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+              }
+            }
+          }
+          if (rowstore) {  // (workgroup-uniform)
+            __syncthreads();
+            const int np = N >> 2;  // 16-byte pieces per row
+            for (int it = wave * 64 + o_ln; it < FB_BM * np; it += THREADS) {  // (tid, rebuilt from the live lane: tid itself is dead by now)
+              const int rel = it / np, c4 = it - rel * np;
+              const int row = row_base + rel;
+              if (row < a.batch) *(f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4) = *(const f32x4*)(outs + rel * N + c4 * 4);
+            }
           }
         } else if (GROUPED && RG_GROUPED_STAGE_OUT && NTo <= NW && a.stage_out) {
           // Grouped output layer, wide (QR-DQN: 200 quantiles per row).  Stored straight from the accumulators a wave

@@ -26,6 +26,11 @@ constexpr int WG_THREADS = 512;  // weight-gradient kernels
 #define RG_FUSED_WAVES 8
 #endif
 constexpr int FB_NW = RG_FUSED_WAVES;  // waves per workgroup of the forward / backward kernels (4 or 8)
+#ifndef RG_OUT_ROWSTORE
+#define RG_OUT_ROWSTORE 1  // bf16 forward: a thin output layer's [128, N] result leaves as whole rows through LDS, 16 bytes per lane
+// (round 5, same box: fwd_phases 84.6 -> 79.2 us per launch, C2 step 0.495-0.508 -> 0.482 ms.  The same change in the split-bf16
+// forward — 64-row tiles, four waves per tile — measured 377 -> 385 us per pair of launches and is not there.)
+#endif
 #ifndef RG_SAVE_NT
 #define RG_SAVE_NT 1  // saved fragments leave as non-temporal stores (store_packed_frags; same-box A/B switch)
 #endif
