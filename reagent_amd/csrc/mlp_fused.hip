@@ -214,46 +214,61 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
           RG_STAMP(16);
           __syncthreads();  // every wave is done reading the layer input
           RG_STAMP(17);
-          float* hand = (float*)act + (tm * 64 + lane) * 16;
-          if (half) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) *(f32x4*)(hand + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
-          }
-          __syncthreads();
-          RG_STAMP(18);
-          // RG_OUT_ROWSTORE (round 5): the 128 x N outputs leave as whole rows, 16 bytes per lane, through a staging area in the
-          // (dead) activation tile — 8 wave stores of full 64-byte row segments for 16 Q-values instead of 64 four-byte ones
-          // that each touch 32 half-lines (fwd_phases: "sum + stores" was 4.6k of a workgroup's 83k ticks)
+          // RG_OUT_ROWSTORE (round 5): the 128 x N outputs leave as whole rows, 16 bytes per lane, through the (dead) activation
+          // tile — 8 wave stores of 1 KB for 16 Q-values instead of 64 four-byte ones from the accumulators that each touch
+          // 32 half-lines (fwd_phases: "sum + stores" 4.6k of a workgroup's 83k ticks -> 3.1k, the launch 84.6 -> 79.2 us).
+          // Both halves of K put their partial sums into the staging area ([half][row][N] floats) and the row-store pass adds
+          // them — (lower + upper) + bias, the order of the accumulator hand-off below — one barrier instead of two.
           // (everything the row store needs is worked out HERE, from an opaque copy of the lane: hoisted above the hidden layers'
           // main loops it cost the 512-wide kernel 5 spilled registers)
           const int o_ln = opaque(lane), o_lr = o_ln & 31, o_lg = o_ln >> 5;
           const bool rowstore = RG_OUT_ROWSTORE && (N & 3) == 0 && (a.ldo & 3) == 0 && !a.out_scatter &&
                                 ((reinterpret_cast<uintptr_t>(a.out32) & 15) == 0);
-          float* outs = (float*)act + 4 * 64 * 16;  // behind the hand-off records (16 KB)
-          if (!half) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-              const f32x4 o = *(const f32x4*)(hand + r);
-              acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
-            }
-            RG_STAMP(19);
-            if (!rowstore) store_tile(acc, tm, 0);
-            else if (o_lr < N) {
-              const float b = b_tile0;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int rel = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lg;
-                outs[rel * N + o_lr] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
-              }
-            }
-          }
           if (rowstore) {  // (workgroup-uniform)
+            float* outs = (float*)act + half * (FB_BM * 32);
+            float* bias_s = (float*)act + 2 * (FB_BM * 32);  // the bias (requested before the K loop) travels through LDS too
+            if (o_lr < N) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) outs[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * o_lg) * N + o_lr] = acc[r];
+              if (wave == 0 && o_lg == 0) bias_s[o_lr] = b_tile0;
+            }
             __syncthreads();
+            RG_STAMP(18);
+            RG_STAMP(19);
+            const float* lo_ = (const float*)act;
+            const float* hi_ = lo_ + FB_BM * 32;
             const int np = N >> 2;  // 16-byte pieces per row
             for (int it = wave * 64 + o_ln; it < FB_BM * np; it += THREADS) {  // (tid, rebuilt from the live lane: tid itself is dead by now)
               const int rel = it / np, c4 = it - rel * np;
               const int row = row_base + rel;
-              if (row < a.batch) *(f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4) = *(const f32x4*)(outs + rel * N + c4 * 4);
+              if (row < a.batch) {
+                const f32x4 l4 = *(const f32x4*)(lo_ + rel * N + c4 * 4), h4 = *(const f32x4*)(hi_ + rel * N + c4 * 4);
+                const f32x4 b4 = *(const f32x4*)(bias_s + c4 * 4);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float v = (l4[e] + h4[e]) + b4[e];
+                  o[e] = out_act == ACT_LINEAR ? v : act_apply(v, out_act);
+                }
+                *(f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4) = o;
+              }
+            }
+          } else {
+            float* hand = (float*)act + (tm * 64 + lane) * 16;
+            if (half) {
+#pragma unroll
+              for (int r = 0; r < 16; r += 4) *(f32x4*)(hand + r) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+            }
+            __syncthreads();
+            RG_STAMP(18);
+            if (!half) {
+#pragma unroll
+              for (int r = 0; r < 16; r += 4) {
+                const f32x4 o = *(const f32x4*)(hand + r);
+                acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
+              }
+              RG_STAMP(19);
+              store_tile(acc, tm, 0);
             }
           }
         } else if (GROUPED && RG_GROUPED_STAGE_OUT && NTo <= NW && a.stage_out) {
