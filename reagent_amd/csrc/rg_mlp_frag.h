@@ -26,6 +26,9 @@ constexpr int WG_THREADS = 512;  // weight-gradient kernels
 #define RG_FUSED_WAVES 8
 #endif
 constexpr int FB_NW = RG_FUSED_WAVES;  // waves per workgroup of the forward / backward kernels (4 or 8)
+#ifndef RG_SIGN_STORE16
+#define RG_SIGN_STORE16 1  // saving forward, 512-wide stacks: a lane's sign words of both column tiles leave as one 16-byte store
+#endif
 #ifndef RG_OUT_ROWSTORE
 #define RG_OUT_ROWSTORE 1  // bf16 forward: a thin output layer's [128, N] result leaves as whole rows through LDS, 16 bytes per lane
 // (round 5, same box: fwd_phases 84.6 -> 79.2 us per launch, C2 step 0.495-0.508 -> 0.482 ms.  The same change in the split-bf16
@@ -652,6 +655,7 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
                                                 unsigned (&PK)[4][TN][8]) {
   lane = opaque(lane);
   const int lr = lane & 31;
+  unsigned sg_prev0 = 0u, sg_prev1 = 0u;  // (TN == 2: the first column tile's sign words wait for the second's — one 16-byte store)
   static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
     constexpr int tn = decltype(tn_c)::value;
     const int nt = wave * TN + tn, col = nt * 32 + lr;
@@ -671,8 +675,16 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
         else sg1 |= bits << ((tm & 1) * 16);
       }
     });
-    if (act_is_sign_based<ACT>() && sign_dst)
-      ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
+    if (act_is_sign_based<ACT>() && sign_dst) {
+      if constexpr (TN == 2 && RG_SIGN_STORE16) {
+        // a lane's four sign words (two per column tile) are contiguous: ONE 16-byte store per lane and layer — 1 KB per wave
+        // instruction — instead of two 8-byte ones at a lane stride of 16 bytes
+        if constexpr (tn == 0) { sg_prev0 = sg0; sg_prev1 = sg1; }
+        else *(u32x4*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)) = u32x4{sg_prev0, sg_prev1, sg0, sg1};
+      } else {
+        ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
+      }
+    }
   });
 }
 
