@@ -222,8 +222,11 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
           // (everything the row store needs is worked out HERE, from an opaque copy of the lane: hoisted above the hidden layers'
           // main loops it cost the 512-wide kernel 5 spilled registers)
           const int o_ln = opaque(lane), o_lr = o_ln & 31, o_lg = o_ln >> 5;
-          const bool rowstore = RG_OUT_ROWSTORE && (N & 3) == 0 && (a.ldo & 3) == 0 && !a.out_scatter &&
-                                ((reinterpret_cast<uintptr_t>(a.out32) & 15) == 0);
+          // two forms: rows of whole 16-byte pieces (N % 4 == 0), or — a dense output (ldo == N: e.g. a critic's single column)
+          // and a full tile — the tile's 128 x N block as ONE contiguous run, whatever N is
+          const bool aligned16 = (reinterpret_cast<uintptr_t>(a.out32) & 15) == 0;
+          const bool dense_run = a.ldo == N && row_base + FB_BM <= a.batch;
+          const bool rowstore = RG_OUT_ROWSTORE && !a.out_scatter && aligned16 && (dense_run || ((N & 3) == 0 && (a.ldo & 3) == 0));
           if (rowstore) {  // (workgroup-uniform)
             float* outs = (float*)act + half * (FB_BM * 32);
             float* bias_s = (float*)act + 2 * (FB_BM * 32);  // the bias (requested before the K loop) travels through LDS too
@@ -237,8 +240,21 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
             RG_STAMP(19);
             const float* lo_ = (const float*)act;
             const float* hi_ = lo_ + FB_BM * 32;
+            if (dense_run) {
+              float* dst = a.out32 + (long)row_base * N;
+              for (int it = wave * 64 + o_ln; it < (FB_BM * N) >> 2; it += THREADS) {
+                const f32x4 l4 = *(const f32x4*)(lo_ + it * 4), h4 = *(const f32x4*)(hi_ + it * 4);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float v = (l4[e] + h4[e]) + bias_s[(it * 4 + e) % N];
+                  o[e] = out_act == ACT_LINEAR ? v : act_apply(v, out_act);
+                }
+                *(f32x4*)(dst + it * 4) = o;
+              }
+            }
             const int np = N >> 2;  // 16-byte pieces per row
-            for (int it = wave * 64 + o_ln; it < FB_BM * np; it += THREADS) {  // (tid, rebuilt from the live lane: tid itself is dead by now)
+            for (int it = wave * 64 + o_ln; !dense_run && it < FB_BM * np; it += THREADS) {  // (tid, rebuilt from the live lane: tid itself is dead by now)
               const int rel = it / np, c4 = it - rel * np;
               const int row = row_base + rel;
               if (row < a.batch) {
