@@ -607,7 +607,50 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
       const int out_act = a.acts[l];
       constexpr int PARTS = NW / X3_TM;  // waves per tile when there is one column tile
       const bool split = NTo == 1 && KC >= 4 * PARTS;
-      for (int t = wave; t < (split ? NW : X3_TM * NTo); t += NW) {
+      // RG_OUT_ROWSTORE (round 5, as in mlp_fwd_fused_body): a thin output layer's [64, N] result leaves as whole 16-byte pieces
+      // — rows (N % 4 == 0) or, for a dense output and a full tile, the tile's block as one run (a critic's single column) —
+      // through a staging area in the dead activation planes: every part puts its partial sums there and the store pass adds
+      // them, ((p0 + p1) + p2) + p3 + bias as the accumulator hand-off below does; the bias is requested BEFORE the K loop.
+      const bool aligned16 = (reinterpret_cast<uintptr_t>(a.out32) & 15) == 0;
+      const bool dense_run = a.ldo == N && row_base + X3_BM <= a.batch;
+      const bool rowstore = RG_OUT_ROWSTORE && split && !a.out_scatter && aligned16 && (dense_run || ((N & 3) == 0 && (a.ldo & 3) == 0));
+      if (rowstore) {  // (workgroup-uniform; NW == PARTS * X3_TM waves, one (part, row tile) each)
+        const int tm = wave % X3_TM, part = wave / X3_TM, per = (KC / PARTS + 1) / 2 * 2;
+        const int lo = part * per, hi = part == PARTS - 1 ? KC : lo + per;
+        const float b0 = (a.bias[l] && lr < N) ? a.bias[l][lr] : 0.f;
+        const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, a.wfrag[l], a.wfrag_lo[l], tm, 0, lane, lo, hi);
+        __syncthreads();  // every wave is done reading the layer input
+        float* stage = (float*)act;
+        float* bias_s = stage + PARTS * (X3_BM * 32);
+        if (lr < N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) stage[part * (X3_BM * 32) + (tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * N + lr] = acc[r];
+          if (wave == 0 && lg == 0) bias_s[lr] = b0;
+        }
+        __syncthreads();
+        auto emit = [&](int i0, float* dst) {  // four consecutive staged floats i0 .. i0 + 3 -> dst
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = stage[i0 + e];
+#pragma unroll
+            for (int p = 1; p < PARTS; ++p) v += stage[p * (X3_BM * 32) + i0 + e];
+            v += bias_s[(i0 + e) % N];
+            o[e] = out_act == ACT_LINEAR ? v : act_apply(v, out_act);
+          }
+          *(f32x4*)dst = o;
+        };
+        if (dense_run) {
+          for (int it = tid; it < (X3_BM * N) >> 2; it += THREADS) emit(it * 4, a.out32 + (long)row_base * N + it * 4);
+        } else {
+          const int np = N >> 2;
+          for (int it = tid; it < X3_BM * np; it += THREADS) {
+            const int rel = it / np, c4 = it - rel * np;
+            if (row_base + rel < a.batch) emit(rel * N + c4 * 4, a.out32 + (long)(row_base + rel) * a.ldo + c4 * 4);
+          }
+        }
+      }
+      for (int t = wave; !rowstore && t < (split ? NW : X3_TM * NTo); t += NW) {
         const int tm = t % X3_TM, nt = split ? 0 : t / X3_TM;
         f32x16 acc;
         if (split) {

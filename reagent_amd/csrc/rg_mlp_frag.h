@@ -30,9 +30,10 @@ constexpr int FB_NW = RG_FUSED_WAVES;  // waves per workgroup of the forward / b
 #define RG_SIGN_STORE16 1  // saving forward, 512-wide stacks: a lane's sign words of both column tiles leave as one 16-byte store
 #endif
 #ifndef RG_OUT_ROWSTORE
-#define RG_OUT_ROWSTORE 1  // bf16 forward: a thin output layer's [128, N] result leaves as whole rows through LDS, 16 bytes per lane
-// (round 5, same box: fwd_phases 84.6 -> 79.2 us per launch, C2 step 0.495-0.508 -> 0.482 ms.  The same change in the split-bf16
-// forward — 64-row tiles, four waves per tile — measured 377 -> 385 us per pair of launches and is not there.)
+#define RG_OUT_ROWSTORE 1  // forwards: a thin output layer's [rows, N] result leaves as whole 16-byte pieces through LDS
+// (round 5, same box: fwd_phases 84.6 -> 79.2 us per launch, C2 step 0.495-0.508 -> 0.482 ms; a critic's single dense column as one
+// run per tile: C4 step 1.750 -> 1.708 ms.  Split-bf16 forward: a first form with an extra barrier lost 2 %; with every part's partial
+// sums staged — one barrier fewer — and the bias requested before the K loop: C2 step 1.136 -> 1.125 ms, C4 4.15 -> 4.115.)
 #endif
 #ifndef RG_SAVE_NT
 #define RG_SAVE_NT 1  // saved fragments leave as non-temporal stores (store_packed_frags; same-box A/B switch)
