@@ -332,3 +332,33 @@ def test_dx_only_backward_of_a_frozen_stack(backend, prec, acts):
         assert same or rewritten_ok, (k, i)
     with pytest.raises(AssertionError, match="SAVE_FOR_DX"):
         st.backward(dout, None, [torch.zeros_like(w) for w in ws], [torch.zeros_like(b) for b in bs])
+
+
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_BF16X3])
+@pytest.mark.parametrize("n_out,batch", [(16, 256), (16, 200), (1, 256), (1, 130), (3, 128), (8, 192)])
+def test_thin_output_layer_store_forms_agree_bit_for_bit(backend, prec, n_out, batch):
+    """RG_OUT_ROWSTORE (round 5): a thin output layer's result leaves as whole 16-byte pieces through LDS — the tile's block as one
+    run for a dense output and a full tile (a critic's single column), whole rows where N % 4 == 0 — and straight from the
+    accumulators otherwise (a misaligned base, a row pitch that is no multiple of 4 floats, the last partial tile of a dense
+    output).  Which form runs is decided per workgroup from the output's address and pitch; the VALUES must not depend on it:
+    the same forward into a dense aligned buffer, a buffer 4 bytes off 16-byte alignment and a wider-pitch buffer, bit for bit."""
+    dev = backend.device
+    dims, acts = [64, 256, 256, n_out], ["relu", "relu", "linear"]
+    ws, bs = _net(dims, acts, 1, dev)
+    st = make_stack(ws, bs, [L.ACT[a] for a in acts], prec)
+    assert isinstance(st, FusedMLP)
+    st.stage_weights(need_transposed=False)
+    x = torch.randn(batch, dims[0], generator=torch.Generator().manual_seed(4)).to(dev)
+    xc, _ = st.stage_input(x, False)
+    dense = torch.zeros(batch, n_out, device=dev)
+    st.forward(xc, dense, save=False)
+    off = torch.zeros(batch * n_out + 1, device=dev)[1:].view(batch, n_out)  # 4 bytes off: straight from the accumulators
+    st.forward(xc, off, save=False)
+    wide = torch.zeros(batch, n_out + 4, device=dev)  # pitch N + 4: rows of whole pieces (N % 4 == 0) or the accumulator path
+    st.forward(xc, wide[:, :n_out], save=False)
+    odd = torch.zeros(batch, n_out + 1, device=dev)  # pitch N + 1: never a multiple of 4 floats for these N
+    st.forward(xc, odd[:, :n_out], save=False)
+    assert torch.isfinite(dense).all() and dense.abs().max() > 0
+    assert torch.equal(off, dense) and torch.equal(wide[:, :n_out], dense) and torch.equal(odd[:, :n_out], dense)
+    assert torch.equal(wide[:, n_out:], torch.zeros(batch, 4, device=dev))  # nothing written past the row's N columns
+    assert torch.equal(odd[:, n_out:], torch.zeros(batch, 1, device=dev))
