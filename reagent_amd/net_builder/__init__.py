@@ -5,11 +5,14 @@ model class — an FC stack staged for the HIP kernels — sized from the normal
 it (`get_num_output_features`: an ENUM feature widens the input by its number of possible values).
 
 All builders live here, once: they differ only in their fields and in the model they construct.  The reference's module
-paths exist as thin namespaces (`reagent_amd.net_builder.discrete_dqn.FullyConnected`, `.quantile_dqn.Quantile`, ...).
+paths exist as namespaces made at the bottom of this file, not as files of their own
+(`reagent_amd.net_builder.discrete_dqn.FullyConnected`, `.quantile_dqn.Quantile`, ...; `import reagent_amd.net_builder.value` works).
 Sparse-feature embeddings (`embedding_dim`, `FullyConnectedWithEmbedding`) are not on the path and are
 rejected loudly.  `state_feature_config` is accepted where the reference takes it and only forwarded to the serving
 wrapper (dense features).
 """
+import sys
+import types
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -205,7 +208,7 @@ class ValueFullyConnected(_Stack):
                                           activations=self.activations, use_layer_norm=self.use_layer_norm)
 
 
-# the reference's module paths -> these classes (reagent_amd/net_builder/<namespace>.py re-export them under its names)
+# the reference's module paths -> these classes, under the reference's names
 BUILDERS = {
     "discrete_dqn": dict(FullyConnected=DiscreteDqnFullyConnected, Dueling=DiscreteDqnDueling),
     "quantile_dqn": dict(Quantile=Quantile, DuelingQuantile=DuelingQuantile),
@@ -215,3 +218,8 @@ BUILDERS = {
     "parametric_dqn": dict(FullyConnected=ParametricDqnFullyConnected),
     "value": dict(FullyConnected=ValueFullyConnected),
 }
+
+for _name, _classes in BUILDERS.items():  # reagent/net_builder/<family>/*: one importable namespace per family
+    _ns = types.ModuleType(f"{__name__}.{_name}", f"reagent/net_builder/{_name}/*: the builders of this family")
+    _ns.__dict__.update(_classes, __all__=sorted(_classes))
+    sys.modules[_ns.__name__] = globals()[_name] = _ns
