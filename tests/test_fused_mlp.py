@@ -362,3 +362,66 @@ def test_thin_output_layer_store_forms_agree_bit_for_bit(backend, prec, n_out, b
     assert torch.equal(off, dense) and torch.equal(wide[:, :n_out], dense) and torch.equal(odd[:, :n_out], dense)
     assert torch.equal(wide[:, n_out:], torch.zeros(batch, 4, device=dev))  # nothing written past the row's N columns
     assert torch.equal(odd[:, n_out:], torch.zeros(batch, 1, device=dev))
+
+
+_UNEVEN_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+if {emu}:
+    import emu_backend; emu_backend.install()
+import reagent_amd._lib as L
+import test_fused_mlp as T
+from reagent_amd.engine import FusedMLP, make_stack
+dev = "cpu" if {emu} else "cuda"
+dims, acts, batch = [64, 512, 512, 8], ["relu", "relu", "linear"], 2048
+ws, bs = T._net(dims, acts, 1, dev)
+st = make_stack(ws, bs, [L.ACT[a] for a in acts], {prec})
+assert isinstance(st, FusedMLP)
+st.stage_weights(need_transposed=True)
+g = torch.Generator().manual_seed(2)
+x = torch.randn(batch, dims[0], generator=g).to(dev)
+dout = (torch.randn(batch, dims[-1], generator=g) / batch).to(dev)
+out = torch.zeros(batch, dims[-1], device=dev)
+st.forward(x, out, save=True)
+dw = [torch.zeros_like(w) for w in ws]; db = [torch.zeros_like(b) for b in bs]
+st.backward(dout, None, dw, db)
+torch.save([t.cpu() for t in dw + db], {path!r})
+"""
+
+
+@pytest.mark.parametrize("prec", [L.PREC_BF16, L.PREC_BF16X3])
+def test_unevenly_split_weight_gradient_launch(backend, prec, tmp_path):
+    """rg_mlp_wgrad_fused's round-5 launch plan (mlp_fused.hip: "entries"): when the multi-tile layers' workgroups are exactly one
+    round of the chip and only single-tile layers follow, a part of each multi-tile layer's splits is made shorter and the
+    rest longer, as two ENTRIES of the launch (the second with mb_base > 0 and its partial slabs after the first's).  The plan
+    keys on the CU count, so only C2's full-size stack meets it on the GPU; here RG_WGRAD_TOTAL / RG_WGRAD_THIN make a small
+    stack meet it (128 workgroups of the 512 x 512 layer, 64 single-tile ones) on either backend.  Against the same launch
+    with even splits (RG_WGRAD_UNEVEN=0): the layers whose entries did not change are bit-identical, the unevenly split one
+    differs by the rounding of its partial sums only — bf16 partial tiles: 2^-9 of each of the 32 partials, which cut the batch
+    elsewhere (~2e-3 of max|dW| here; the bf16 operands themselves cost 4e-3); split-bf16 keeps fp32 partials: summation order."""
+    import os
+    import subprocess
+    import sys
+
+    if backend.name == "emu" and prec == L.PREC_BF16X3:
+        pytest.skip("a minute on the emulator for the same host-side plan; this case runs on the GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got, plans = {}, {}
+    for uneven in ("125", "0"):
+        path = str(tmp_path / f"dw_{uneven}.pt")
+        env = dict(os.environ, RG_WGRAD_UNEVEN=uneven, RG_WGRAD_TOTAL="128", RG_WGRAD_THIN="32", RG_WGRAD_DEBUG="1")
+        p = subprocess.run([sys.executable, "-c", _UNEVEN_SNIPPET.format(root=root, emu=backend.name == "emu", prec=prec, path=path)],
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        plans[uneven] = [ln for ln in p.stderr.splitlines() if ln.startswith("rg_mlp_wgrad_fused: entry")]
+        got[uneven] = torch.load(path)
+    print("\n" + "\n".join(plans["125"]))
+    assert len(plans["0"]) == 3 and len(plans["125"]) == 4  # the 512 x 512 layer as two entries ...
+    hidden = [ln for ln in plans["125"] if "layer 1 " in ln]
+    assert len(hidden) == 2 and "blocks [0, 48) in 16 splits of 3" in hidden[0] and "blocks [48, 64) in 16 splits of 1" in hidden[1]
+    assert plans["125"].index(hidden[0]) == 0 and plans["125"].index(hidden[1]) == 3  # ... the long class first, the short one last
+    (dw0, dw1, dw2, *db), (ew0, ew1, ew2, *eb) = got["125"], got["0"]
+    assert torch.equal(dw0, ew0) and torch.equal(dw2, ew2) and all(torch.equal(a, b) for a, b in zip(db, eb))
+    rel = float((dw1 - ew1).abs().max() / ew1.abs().max())
+    print(f"[uneven wgrad] hidden layer's dW, uneven vs even splits: {rel:.2e} of max|dW|")
+    assert 0 < rel < (6e-3 if prec == L.PREC_BF16 else 2e-6)
