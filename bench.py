@@ -1063,6 +1063,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    preflight = None
+    if world == 1 and os.path.exists("/dev/kfd") and not args.rendezvous_only and not os.environ.get("RG_SKIP_PREFLIGHT"):
+        # One GPU: the torch-only first device touch in a SUBPROCESS, before this process starts its HSA runtime (so before
+        # torch.cuda.is_available()).  A lease whose first touch faults (round 4's driver GPU record died that way) is tried
+        # under the runtime alternatives of reagent_amd.device_preflight and named if none works: the record then blames the
+        # node, not the benchmark.  (N > 1: every rank would spawn its own child on a shared host; the launcher's ranks go
+        # straight to their devices.)
+        from reagent_amd.device_preflight import NODE_FAULT, settle
+
+        ok, log, adopted = settle()
+        preflight = {"ok": bool(ok), "adopted": adopted, "attempts": len(log.splitlines())}
+        if not ok and not log.endswith("no GPU visible to torch"):
+            print(f"{NODE_FAULT}\n{log}", file=sys.stderr)
+            raise SystemExit(97)
     have_gpu = torch.cuda.is_available()
     if args.rendezvous_only:  # launcher self-test (CPU boxes use gloo)
         import torch.distributed as dist
@@ -1115,6 +1129,8 @@ def main():
             res["cpu_affinity_rank0"] = affinity
             assert res["rccl_ranks"] == args.gpus == world, "the line must describe the group that ran"
         res["launch_calibration"] = m["launch_calibration"]
+        if preflight is not None:
+            res["device_preflight"] = preflight
         if m["sustained"] is not None:
             res["sustained"] = m["sustained"]
         res.update(m["extra"])
