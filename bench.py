@@ -46,6 +46,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SIDE_UPDATE_DEFAULT = "off"
 MFMA_PEAK = {"bf16": 2.5e15, "bf16x3": 2.5e15, "f32": 157.3e12}  # /opt/skills/guides/MI355X_MICROARCH.md:40-42
 HBM_PEAK = 8.0e12
 
@@ -173,6 +174,9 @@ def parse():
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default=None,
                     help="auto: replay the captured HIP graph or enqueue eagerly, whichever a short calibration finds faster")
     ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
+    ap.add_argument("--side-update", choices=["on", "off"], default=os.environ.get("RG_SIDE_UPDATE", SIDE_UPDATE_DEFAULT),
+                    help="one GPU, eager launches: step k's Adam + soft update + re-staging on a second stream, beside step k+1's "
+                         "sampler (QStepCore.side_update; DQN / QR-DQN loops)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--parity-batch", type=int, default=4096)
     ap.add_argument("--graph-steps", type=int, default=1,
@@ -357,11 +361,12 @@ def build(args, device, rank, batch=None, cols=None):
 
         maker = PolicyNetworkInputMaker(np.full(A, R[0], dtype=np.float32), np.full(A, R[1], dtype=np.float32))
         loop = OfflinePolicyLoop(rb, trainer, batch, maker, pre,
-                                 state_dtype=torch.bfloat16 if args.precision == "bf16" else None)
+                                 state_dtype=torch.bfloat16 if args.precision == "bf16" else None,
+                                 side_update=getattr(args, "side_update", "off") == "on")
     else:
         loop = OfflineDqnLoop(rb, trainer, batch, pre,
                               state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32,
-                              prefetch=args.prefetch)
+                              prefetch=args.prefetch, side_update=getattr(args, "side_update", "off") == "on")
     return loop, trainer, init, cols, (mean, std)
 
 
@@ -832,6 +837,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         torch.cuda.synchronize()
 
     step = loop.step
+    replayed = False
     steps_per_call = 1  # steps one call of `step` makes (a replayed graph may hold several)
     graph_note = None
     calibration = None
@@ -920,6 +926,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
                            "rule": f"graph unless it is more than {round((margin - 1) * 100)} % slower than eager launches"}
             calibration["steps_per_graph"] = per
             step = replay if use_graph else loop.step
+            replayed = use_graph
             steps_per_call = per if use_graph else 1
             if not use_graph:
                 loop.release_graph()  # eager steps then pass Adam's coefficients per launch (no tick kernel)
@@ -983,6 +990,8 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         two_streams = gq is not None and (getattr(gq, "two_streams", False) or getattr(gq, "wgrad_streams", False))
         extra["instrumented_pass"]["timed_ms_per_step"] = dt / args.steps * 1e3
         extra["instrumented_pass"]["launch_streams"] = 2 if two_streams else 1
+    side_note = ("; Adam + soft update (+ re-staging) of step k on a second stream, beside step k+1's sampler"
+                 if (getattr(trainer, "side_update", False) and world == 1 and not replayed) else "")
     per_rank = None
     if dist is not None:
         # every rank's own view, so a curve measured by the driver explains itself: the rank's wall time for the median
@@ -1000,7 +1009,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     return {"value": world * args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
             "timing": f"median of {len(regions)} regions of {args.steps} steps each",
             "region_ms": [round(r * 1e3, 4) for r in regions], "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
-            "final_loss": loss_val, "launch": graph_note or "eager launches", "launch_calibration": calibration,
+            "final_loss": loss_val, "launch": (graph_note or "eager launches") + side_note, "launch_calibration": calibration,
             "sustained": sustained, "extra": extra, "parity": parity,
             "per_rank": per_rank, "init": init, "cols": cols, "cols_cpu": cols, "norm": norm}
 
