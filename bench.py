@@ -628,6 +628,20 @@ class QueueAhead:
             torch.cuda._sleep(int((ms or self.ms) * self.cycles_per_ms))
 
 
+def agree_over_ranks(n: int, device) -> int:
+    """The largest `n` any rank of the process group holds (n itself without a group).  Every step of a data-parallel loop
+    holds a gradient all-reduce, so a count of steps that a rank derives from its OWN host timing — the backlog the
+    instrumented pass queues ahead of itself — has to be made the same on every rank before it is used: ranks that enqueue
+    different numbers of collectives end in a hang."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return int(n)
+    t = torch.tensor([int(n)], dtype=torch.int64, device=device if device.type == "cuda" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def kernel_profile(args, step, steps, device=None, gpu_ms=None):
     """Instrumented pass: HIP events around every C-ABI launch (on the launch stream), all of it enqueued behind a backlog
     of plain steps so that the spans are kernel durations, not host gaps.  Rows of one entry point are
@@ -657,12 +671,12 @@ def kernel_profile(args, step, steps, device=None, gpu_ms=None):
     plain_ms = (time.perf_counter() - t) * 1e3 / 3
     lead_needed = 1.3 * dry_ms * (steps + 2) + 0.5
     gap = (gpu_ms - plain_ms) if gpu_ms else 0.0
+    backlog_steps = agree_over_ranks(min(400, int(lead_needed / gap) + 1) if (qa.on and gap > 0.03) else 0, device)
     t0 = time.perf_counter()
-    if qa.on and gap > 0.03:
-        backlog_steps = min(400, int(lead_needed / gap) + 1)
+    if backlog_steps > 0:
         for _ in range(backlog_steps):
             step()
-        lead_mode, blocker_ms = f"backlog of {backlog_steps} plain steps", backlog_steps * gap
+        lead_mode, blocker_ms = f"backlog of {backlog_steps} plain steps", backlog_steps * max(gap, 0.0)
     else:
         backlog_steps = 0
         qa.block(lead_needed)
@@ -880,6 +894,12 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         except Exception as e:
             replay = None
             graph_note = f"graph capture failed, eager launches: {e!r}"
+        if dist is not None and agree_over_ranks(0 if replay is not None else 1, device) and replay is not None:
+            # a capture that failed on ANOTHER rank: every rank goes on with eager launches (a rank calibrating a replay the
+            # others do not have would enqueue collectives they never join)
+            replay = None
+            loop.release_graph()
+            graph_note = "graph capture failed on another rank, eager launches"
         if replay is not None:
             per = int(getattr(loop, "replay_steps", 1))
             # Which launch path is faster depends on the workload: a replayed graph costs the host ~0.02 ms per

@@ -112,6 +112,9 @@ def _measure_worker(rank, world, port, out_dir):
     finally:
         sys.argv = argv
     dev = torch.device("cpu")
+    # a step count a rank derives from its own host timing (the instrumented pass's backlog) is agreed over the ranks before
+    # it is used: every step holds an all-reduce, different counts would hang a multi-GPU run
+    assert bench.agree_over_ranks(5 + 3 * rank, dev) == 5 + 3 * (world - 1)
     m = bench.measure(args, dev, rank, world, dist)
     # main()'s second pass: the same shard and initial weights in the split-bf16 mode
     import argparse
