@@ -305,3 +305,112 @@ def test_online_sac_reaches_the_reference_bar_on_the_pendulum(backend):
     if full:
         assert eval_rewards.mean() >= -500.0, f"Eval reward is {eval_rewards.mean()}, less than < -500."  # sac_pendulum_online.yaml:56
         assert np.mean(train_rewards[-10:]) > np.mean(train_rewards[:5]) + 300
+
+
+# ---- the widened rows: C51 on cart-pole, TD3 on the pendulum --------------------------------------------
+def test_online_c51_reaches_the_reference_bar_on_cartpole(backend):
+    """reagent/gym/tests/configs/cartpole/discrete_c51_cartpole_online.yaml: Categorical network [64, 64] leaky_relu with 21
+    atoms on [0, 40], C51Trainer with gamma 0.9, target_update_rate 0.05, double-Q, AdamW lr 1e-3 amsgrad, minibatch 512,
+    40 training episodes; passing_score_bar 100 over 20 evaluation episodes.  5 000 random transitions before training
+    (YAML: 20 000); the policies act greedily on the expected values."""
+    from reagent_amd.models.categorical_dqn import CategoricalDQN
+    from reagent_amd.optimizer import AdamW
+    from reagent_amd.training import C51Trainer
+
+    full = backend.name == "hip"
+    prefill, episodes, batch, eval_episodes = (5000, 40, 512, 20) if full else (96, 2, 32, 1)
+    dev = torch.device(backend.device)
+    torch.manual_seed(SEED)
+    if dev.type == "cuda":
+        torch.cuda.manual_seed(SEED)
+    env = CartPoleEnv(seed=SEED)
+    q = CategoricalDQN(FullyConnectedDQN(4, 2, [64, 64], ["leaky_relu", "leaky_relu"], num_atoms=21), qmin=0, qmax=40,
+                       num_atoms=21).to(dev)
+    trainer = C51Trainer(q, q.get_target_network(), actions=["0", "1"],
+                         rl=RLParameters(gamma=0.9, target_update_rate=0.05, maxq_learning=True, temperature=1.0),
+                         double_q_learning=True, minibatches_per_step=1, num_atoms=21, qmin=0, qmax=40,
+                         optimizer=Optimizer__Union(AdamW=AdamW(lr=0.001, amsgrad=True))).to(dev)
+
+    class ExpectedQ(torch.nn.Module):
+        def forward(self, state, possible_actions_mask=None):
+            return q(state)
+
+    rb = ReplayBuffer(replay_capacity=100000 if full else 4096, batch_size=batch, device=dev)
+    inserter = make_replay_buffer_inserter(env)
+    fill_replay_buffer(env, rb, max(prefill, batch), RandomAgent(2, SEED + 1), inserter, env.max_steps)
+    agent = GreedyQAgent(ExpectedQ(), dev)
+    train_rewards = []
+    ds = ReplayBufferDataset.create_for_trainer(
+        trainer, env, agent, rb, batch_size=batch, training_frequency=1, num_episodes=episodes, max_steps=env.max_steps,
+        post_episode_callback=lambda traj, info: train_rewards.append(traj.calculate_cumulative_reward()))
+    steps = 0
+    for b in ds:
+        loss = trainer.train_step_native(b)
+        steps += 1
+    assert len(train_rewards) == episodes and steps == int(sum(train_rewards)) and trainer.all_batches_processed == steps
+    assert torch.isfinite(loss).all()
+    eval_rewards = []
+    for _ in range(eval_episodes):
+        obs, total, terminal, t = env.reset(), 0.0, False, 0
+        while not terminal and t < env.max_steps:
+            obs, r, terminal, _ = env.step(agent.act(obs)[0])
+            total, t = total + r, t + 1
+        eval_rewards.append(total)
+    eval_rewards = np.array(eval_rewards)
+    print(f"\ncart-pole, C51: {steps} training steps over {episodes} episodes (last ten: {np.mean(train_rewards[-10:]):.1f} per "
+          f"episode); evaluation over {eval_episodes} episodes: mean {eval_rewards.mean():.1f}, min {eval_rewards.min():.0f}, "
+          f"max {eval_rewards.max():.0f}")
+    if full:
+        assert eval_rewards.mean() >= PASSING_SCORE_BAR, f"Eval reward is {eval_rewards.mean()}, less than < {PASSING_SCORE_BAR}."
+
+
+def test_online_td3_reaches_the_reference_bar_on_the_pendulum(backend):
+    """reagent/gym/tests/configs/pendulum/td3_pendulum_online.yaml: deterministic actor [64, 64] leaky_relu with exploration
+    variance 0.01, twin critics, Adam lr 0.005 (actor) / 0.01 (critics), gamma 0.99, target_update_rate 0.005, target-policy
+    noise 0.2 clipped at 0.5, the actor updated every second step, minibatch 256, 5 000 random transitions, 40 training
+    episodes (the YAML's own sizes); passing_score_bar -750 (the YAML evaluates one episode; twenty here)."""
+    from reagent_amd.models.actor import FullyConnectedActor
+    from reagent_amd.training import TD3Trainer
+
+    full = backend.name == "hip"
+    prefill, episodes, batch, eval_episodes = (5000, 40, 256, 20) if full else (64, 1, 32, 1)
+    dev = torch.device(backend.device)
+    torch.manual_seed(SEED)
+    if dev.type == "cuda":
+        torch.cuda.manual_seed(SEED)
+    env = PendulumEnv(seed=SEED)
+    if not full:
+        env.max_steps = 12
+    S, A, H, acts = 3, 1, [64, 64], ["leaky_relu", "leaky_relu"]
+    trainer = TD3Trainer(FullyConnectedActor(S, A, H, acts, exploration_variance=0.01).to(dev),
+                         FullyConnectedCritic(S, A, H, acts).to(dev), FullyConnectedCritic(S, A, H, acts).to(dev),
+                         rl=RLParameters(gamma=0.99, target_update_rate=0.005),
+                         q_network_optimizer=Optimizer__Union.default(lr=0.01),
+                         actor_network_optimizer=Optimizer__Union.default(lr=0.005), noise_variance=0.2, noise_clip=0.5,
+                         delayed_policy_update=2).to(dev)
+    rb = ReplayBuffer(replay_capacity=100000 if full else 4096, batch_size=batch, device=dev)
+    inserter = make_replay_buffer_inserter(env)
+    fill_replay_buffer(env, rb, max(prefill, batch), UniformBoxAgent(env.action_space, SEED + 1), inserter, env.max_steps)
+    agent = ActorAgent(trainer.actor_network, env.action_space, dev)  # the actor's forward, exploration noise included
+    train_rewards = []
+    ds = ReplayBufferDataset.create_for_trainer(
+        trainer, env, agent, rb, batch_size=batch, training_frequency=1, num_episodes=episodes, max_steps=env.max_steps,
+        post_episode_callback=lambda traj, info: train_rewards.append(traj.calculate_cumulative_reward()))
+    steps = 0
+    for b in ds:
+        trainer.train_step_native(b)
+        steps += 1
+    assert len(train_rewards) == episodes and steps == episodes * (env.max_steps + 1)
+    eval_rewards = []
+    for _ in range(eval_episodes):
+        obs, total = env.reset(), 0.0
+        for _ in range(env.max_steps):
+            obs, r, _, _ = env.step(agent.act(obs)[0])
+            total += r
+        eval_rewards.append(total)
+    eval_rewards = np.array(eval_rewards)
+    print(f"\npendulum, TD3: {steps} training steps over {episodes} episodes (first five {np.mean(train_rewards[:5]):.0f}, last ten "
+          f"{np.mean(train_rewards[-10:]):.0f} per episode); evaluation over {eval_episodes} episodes: mean {eval_rewards.mean():.0f}, "
+          f"min {eval_rewards.min():.0f}, max {eval_rewards.max():.0f}")
+    if full:
+        assert eval_rewards.mean() >= -750.0, f"Eval reward is {eval_rewards.mean()}, less than < -750."  # td3_pendulum_online.yaml
