@@ -15,7 +15,7 @@ that the agent LEARNS.  Sized down from the YAML where that only costs time (5 0
 the environment is tests/cartpole_env.py (gym is not installed).  The run is deterministic — seeded numpy environment and
 random policy, seeded device index draws, kernels with fixed summation orders — so its outcome does not depend on the box.
 It is the LAST test file on purpose: a `-x` run has judged every parity test before this one starts.
-On the SIMT interpreter the same flow runs for three short episodes (no bar: seconds, not learning).
+On the SIMT interpreter the DQN and SAC flows run for one or two short episodes (no bar: seconds, not learning).
 """
 import numpy as np
 import pytest
@@ -105,7 +105,7 @@ def evaluate(env, predictor, episodes, device):
 
 def test_online_dqn_reaches_the_reference_bar_on_cartpole(backend):
     full = backend.name == "hip"
-    prefill, episodes, batch, eval_episodes = (5000, 60, 512, 20) if full else (96, 3, 32, 2)
+    prefill, episodes, batch, eval_episodes = (5000, 60, 512, 20) if full else (48, 2, 16, 1)
     dev = torch.device(backend.device)
     torch.manual_seed(SEED)
     if dev.type == "cuda":
@@ -157,6 +157,8 @@ def test_online_qrdqn_reaches_the_reference_bar_on_cartpole(backend):
     from reagent_amd.optimizer import AdamW
     from reagent_amd.training import QRDQNTrainer
 
+    if backend.name == "emu":
+        pytest.skip("the interpreter runs this flow for DQN and SAC (time); the trainer itself has its own interpreter tests")
     full = backend.name == "hip"
     prefill, episodes, batch, eval_episodes = (5000, 40, 512, 20) if full else (96, 2, 32, 1)
     dev = torch.device(backend.device)
@@ -250,14 +252,14 @@ def test_online_sac_reaches_the_reference_bar_on_the_pendulum(backend):
     the YAML's own comment says its bar is low "to let tests finish in time"; this package at 5 000 / 40 on the GPU: -447
     (squashed mean -202), the same class.  The extra 20 episodes buy the margin for 10 s."""
     full = backend.name == "hip"
-    prefill, episodes, batch, eval_episodes = (10000, 60, 256, 20) if full else (64, 1, 32, 1)
+    prefill, episodes, batch, eval_episodes = (10000, 60, 256, 20) if full else (32, 1, 16, 1)
     dev = torch.device(backend.device)
     torch.manual_seed(SEED)
     if dev.type == "cuda":
         torch.cuda.manual_seed(SEED)
     env = PendulumEnv(seed=SEED)
     if not full:
-        env.max_steps = 12
+        env.max_steps = 8
     S, A, H, acts = 3, 1, [64, 64], ["leaky_relu", "leaky_relu"]
     adam = lambda: Optimizer__Union.default(lr=1e-3)  # noqa: E731
     trainer = SACTrainer(GaussianFullyConnectedActor(S, A, H, acts).to(dev), FullyConnectedCritic(S, A, H, acts).to(dev),
@@ -317,6 +319,8 @@ def test_online_c51_reaches_the_reference_bar_on_cartpole(backend):
     from reagent_amd.optimizer import AdamW
     from reagent_amd.training import C51Trainer
 
+    if backend.name == "emu":
+        pytest.skip("the interpreter runs this flow for DQN and SAC (time); the trainer itself has its own interpreter tests")
     full = backend.name == "hip"
     prefill, episodes, batch, eval_episodes = (5000, 40, 512, 20) if full else (96, 2, 32, 1)
     dev = torch.device(backend.device)
@@ -372,6 +376,8 @@ def test_online_td3_reaches_the_reference_bar_on_the_pendulum(backend):
     from reagent_amd.models.actor import FullyConnectedActor
     from reagent_amd.training import TD3Trainer
 
+    if backend.name == "emu":
+        pytest.skip("the interpreter runs this flow for DQN and SAC (time); the trainer itself has its own interpreter tests")
     full = backend.name == "hip"
     prefill, episodes, batch, eval_episodes = (5000, 40, 256, 20) if full else (64, 1, 32, 1)
     dev = torch.device(backend.device)
@@ -380,7 +386,7 @@ def test_online_td3_reaches_the_reference_bar_on_the_pendulum(backend):
         torch.cuda.manual_seed(SEED)
     env = PendulumEnv(seed=SEED)
     if not full:
-        env.max_steps = 12
+        env.max_steps = 8
     S, A, H, acts = 3, 1, [64, 64], ["leaky_relu", "leaky_relu"]
     trainer = TD3Trainer(FullyConnectedActor(S, A, H, acts, exploration_variance=0.01).to(dev),
                          FullyConnectedCritic(S, A, H, acts).to(dev), FullyConnectedCritic(S, A, H, acts).to(dev),
