@@ -49,6 +49,8 @@ sys.path.insert(0, ROOT)
 SIDE_UPDATE_DEFAULT = "off"
 MFMA_PEAK = {"bf16": 2.5e15, "bf16x3": 2.5e15, "f32": 157.3e12}  # /opt/skills/guides/MI355X_MICROARCH.md:40-42
 HBM_PEAK = 8.0e12
+LINE_LIMIT = 4096  # bytes of the ONE line rank 0 prints (round 5's 35.5 KB line was not parsed by the driver)
+REPORT_FILE = "bench_report.json"
 
 CONFIGS = {
     "c2": dict(algo="dqn", state_dim=128, actions=16, atoms=None,
@@ -183,6 +185,8 @@ def parse():
                     help="consecutive steps recorded per HIP graph where the loop supports it (must divide --steps); measured round 4 at 1 / 2 / 4 / 8: 0.5125 / 0.5134 / 0.5126 / 0.5159 ms per C2 step — no gain, default 1")
     ap.add_argument("--sustained-steps", type=int, default=4000,
                     help="steps of the one long region reported as `sustained` next to the K-step regions (0: skip)")
+    ap.add_argument("--report", default=None, help=f"where the full record goes (default {REPORT_FILE} beside bench.py); the printed "
+                                                   "line is a digest of it, at most LINE_LIMIT bytes")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launcher self-test: form the process group (gloo when there is no GPU), report its size, exit")
     args = ap.parse_args()
@@ -418,8 +422,11 @@ def cpu_baseline(args, init, cols, norm):
     kind "port": only when neither is present — oracle/restated.py (torch-CPU restatement) with an advanced-index gather."""
     B = args.batch if args.algo != "qrdqn" else min(args.batch, 8192)  # the (N, B, N) tensor: 62 GB hosts (SURVEY §6)
     steps = args.cpu_steps or 2
+    import logging
+
     from oracle import reference_bench as RB
 
+    logging.disable(logging.INFO)  # the reference logs every constructed module / replay buffer at INFO: not this run's output
     if RB.available():
         best, tried = RB.run(args.algo, args.state_dim, args.actions, args.hidden, args.layers, args.atoms, args.capacity, B,
                              init, cols, norm, steps=steps)
@@ -754,6 +761,7 @@ def kernel_profile(args, step, steps, device=None, gpu_ms=None):
         ach = dom["flop"] / dom["calls"] / sec
         out["roofline"] = {"bound": "mfma", "kernel": f"{dom['name']} ({KERNELS_OF.get(dom['name'], dom['name'])})",
                            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+                           "algorithmic_gflop_per_launch": dom["flop"] / dom["calls"] / 1e9,
                            "avg_launch_us": sec * 1e6, "avg_span_us": dom["span_ms"] * 1e3 / dom["calls"],
                            "marker_pair_us": qa.marker_us, "launches_per_step": dom["calls"] / steps,
                            "averaging": "call-weighted over every launch of the entry point in the instrumented steps "
@@ -1034,55 +1042,156 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
             "per_rank": per_rank, "init": init, "cols": cols, "cols_cpu": cols, "norm": norm}
 
 
-def digest_into_kept_objects(res):
-    """The driver's record keeps `roofline`, `config` and `cpu_baseline` of the line verbatim and only the NAMES of the other
-    objects: the figures a reader needs beside the headline — whole-FC fraction, the sustained region, the 1e-4-compliant
-    mode's throughput / executed fraction / parity, the other configurations — are therefore repeated inside the kept ones
-    (the full objects stay at the top level)."""
-    roof = res.get("roofline")
-    if roof is None:
-        return
-    pick = lambda o, *ks: {k: o[k] for k in ks if isinstance(o, dict) and k in o}  # noqa: E731
+def _sig(x, n=6):
+    """floats to n significant digits (the line is a digest; the report file keeps every digit)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{n}g}")
 
-    def parity_digest(pp):
-        if not isinstance(pp, dict):
-            return None
-        return pick(pp, "ok", "meets_north_star", "sane", "batch", "max_abs_dq", "max_abs_dquantile", "max_abs_dlogits",
-                    "rel_dloss", "gather_fields_bit_exact", "path", "full_size", "error")
 
-    def mode_digest(o):
-        d = pick(o, "dtype", "value", "ms_per_step", "error")
-        if isinstance(o.get("fc_roofline"), dict):
-            d["whole_fc"] = pick(o["fc_roofline"], "frac", "executed_frac", "fc_ms_per_step")
-        if isinstance(o.get("roofline"), dict):
-            d["dominant"] = pick(o["roofline"], "kernel", "frac", "executed_frac", "avg_launch_us")
-        if isinstance(o.get("sustained"), dict):
-            d["sustained_ms_per_step"] = o["sustained"].get("ms_per_step")
-        d["parity"] = parity_digest(o.get("parity"))
-        return d
+def _pick(o, *ks):
+    return {k: _sig(o[k]) for k in ks if isinstance(o, dict) and k in o and not isinstance(o[k], (dict, list))}
 
-    if "fc_roofline" in res:
-        roof["whole_fc"] = pick(res["fc_roofline"], "frac", "executed_frac", "fc_ms_per_step", "achieved", "algorithmic_gflop_per_step",
-                                "entry_points_us_per_step")
-    if "gather" in res:
-        roof["gather"] = pick(res["gather"], "bound", "frac", "achieved", "unit", "avg_launch_us", "kernel")
-    if "instrumented_pass" in res:
-        roof["instrumented_pass"] = pick(res["instrumented_pass"], "steps", "event_ms_per_step_sum", "timed_ms_per_step", "queue_ahead")
-    roof["parity"] = parity_digest(res.get("parity"))
-    if isinstance(res.get("accurate"), dict):
-        roof["compliant_mode"] = mode_digest(res["accurate"])
-    if isinstance(res.get("also_measured"), dict):
-        roof["other_configs"] = {}
-        for cfg, o in res["also_measured"].items():
-            d = mode_digest(o)
-            if isinstance(o.get("accurate"), dict):
-                d["compliant_mode"] = mode_digest(o["accurate"])
-            roof["other_configs"][cfg] = d
+
+def _parity_digest(pp):
+    """ok / meets_north_star / the largest Q (or quantile, or logit) difference from the CPU oracle / gather bit-exact;
+    `dw_flip_frac` = share of post-step weights further than 2e-5 from the oracle's (an Adam step of a weight whose
+    gradient's sign differs moves it by 2*lr)"""
+    if not isinstance(pp, dict):
+        return None
+    d = _pick(pp, "ok", "meets_north_star", "sane", "batch", "max_abs_dq", "max_abs_dquantile", "max_abs_dlogits",
+              "gather_fields_bit_exact")
+    if "frac_dw_beyond_2e-5" in pp:
+        d["dw_flip_frac"] = _sig(pp["frac_dw_beyond_2e-5"], 3)
+    if "error" in pp:
+        d["error"] = str(pp["error"])[:120]
+    return d
+
+
+def _mode_digest(o, with_parity=True):
+    """one measured region (a configuration in one precision) in six-odd fields"""
+    if not isinstance(o, dict):
+        return None
+    if "error" in o:
+        return {"dtype": o.get("dtype"), "error": str(o["error"])[:160]}
+    d = _pick(o, "dtype", "value", "ms_per_step")
+    fc = o.get("fc_roofline") if isinstance(o.get("fc_roofline"), dict) else {}
+    if "frac" in fc:
+        d["whole_fc_frac"] = _sig(fc["frac"], 4)
+    if "executed_frac" in fc:
+        d["executed_frac"] = _sig(fc["executed_frac"], 4)
+    if isinstance(o.get("sustained"), dict):
+        d["sustained_ms_per_step"] = _sig(o["sustained"].get("ms_per_step"))
+    if with_parity:
+        d["parity"] = _parity_digest(o.get("parity"))
+    return d
+
+
+def compact_line(res):
+    """The ONE line rank 0 prints: the contract's keys, `roofline`, `cpu_baseline`, and six-field digests of the 1e-4-compliant
+    mode (`compliant`, the co-headline: the mode north_star's tolerance binds) and of the other single-GPU configurations
+    (`c3`, `c4`).  Everything else bench.py measured is in the report file the line names.  Never longer than LINE_LIMIT bytes."""
+    line = {k: _sig(res[k], 10) for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in res}
+    cfg = res.get("config", {})
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:200], **_pick(cfg, "name", "global_batch", "parallelism"),
+                      "launch": str(cfg.get("launch", "")).split(":")[0].split(";")[0][:40]}
     if isinstance(res.get("sustained"), dict):
-        res["config"]["sustained"] = pick(res["sustained"], "steps", "seconds", "ms_per_step", "value", "sclk_mhz", "power_w")
+        line["sustained_ms_per_step"] = _sig(res["sustained"].get("ms_per_step"))
+        sc = res["sustained"].get("sclk_mhz")
+        if isinstance(sc, dict) and sc.get("mean") is not None:
+            line["sclk_mhz"] = _sig(sc["mean"], 4)
+    roof = res.get("roofline")
+    if isinstance(roof, dict):
+        r = _pick(roof, "bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "traffic",
+                  "algorithmic_bytes", "algorithmic_gflop_per_launch", "executed_frac")
+        r.setdefault("traffic", None)
+        fc = res.get("fc_roofline") if isinstance(res.get("fc_roofline"), dict) else {}
+        if "frac" in fc:
+            r["whole_fc_frac"] = _sig(fc["frac"], 4)
+            r["whole_fc_ms_per_step"] = _sig(fc.get("fc_ms_per_step"), 4)
+        g = res.get("gather") if isinstance(res.get("gather"), dict) else {}
+        if "frac" in g:
+            r["gather_hbm_frac"] = _sig(g["frac"], 4)
+            r["gather_us"] = _sig(g.get("avg_launch_us"), 4)
+        line["roofline"] = r
+    line["parity"] = _parity_digest(res.get("parity"))
+    if isinstance(res.get("accurate"), dict):
+        line["compliant"] = _mode_digest(res["accurate"])
+    for cfg_name, o in (res.get("also_measured") or {}).items():
+        d = _mode_digest(o)
+        if isinstance(o, dict) and isinstance(o.get("accurate"), dict):
+            d["compliant"] = _mode_digest(o["accurate"])
+        if cfg_name == "c3" and isinstance(d, dict) and "error" not in d:
+            d["full_size_check"] = "grouped vs dense fp32 (HIP vs HIP); oracle parity at B<=8192"
+        line[cfg_name] = d
+    if res.get("per_rank"):
+        line["per_rank_ms"] = [_sig(p.get("ms_per_step"), 5) for p in res["per_rank"]]
+        ar = [p.get("all_reduce_us") for p in res["per_rank"] if p.get("all_reduce_us") == p.get("all_reduce_us")]
+        if ar:
+            line["all_reduce_us_max"] = _sig(max(ar), 4)
+    pf = res.get("device_preflight")
+    if isinstance(pf, dict):
+        line["device_preflight"] = _pick(pf, "ok", "adopted")
+        if pf.get("adopted"):  # a runtime workaround was needed on this node: not comparable with a healthy node's number
+            line["value_valid"] = False
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, "value", "unit", "cores", "kind", "ms_per_step", "host_cpus")
+        if "sample" in cb:
+            c["sample"] = str(cb["sample"])[:150]
+        if "error" in cb:
+            c["error"] = str(cb["error"])[:160]
+        line["cpu_baseline"] = c
+    line["report"] = res.get("report_file", REPORT_FILE)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    # the line must stay parseable whatever a sub-measurement produced: shed the optional digests, largest first
+    keep = {"metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "report", "shed", "value_valid"}
+    while len(text.encode()) > LINE_LIMIT:
+        optional = sorted((k for k in line if k not in keep), key=lambda k: -len(json.dumps(line[k])))
+        if not optional:
+            break
+        line.pop(optional[0])
+        line["shed"] = line.get("shed", 0) + 1
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text.encode()) <= LINE_LIMIT, len(text)
+    return text
 
 
-def main():
+def write_report(res, path=None):
+    """the full record (every object of the run) beside bench.py, and under gpurun_out/ when that exists so a gpurun call brings
+    it back; returns the path written (None if the directory is read-only — the line must still be printed)"""
+    def clean(o):
+        if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+            return None
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        return o
+
+    text = json.dumps(clean(res), indent=1)
+    written = None
+    targets = [path or os.path.join(ROOT, REPORT_FILE)]
+    if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", REPORT_FILE))
+    for t in targets:
+        try:
+            with open(t, "w") as fh:
+                fh.write(text + "\n")
+            written = written or t
+        except OSError:
+            pass
+    return written
+
+
+def main(device=None, backend="nccl"):
+    """`device` / `backend` are None / "nccl" for every real run.  tests/bench_on_emu.py passes (cpu, "gloo") AFTER patching the
+    C ABI to the host-compiled kernel sources, to run this function's whole control flow — launcher, ranks, secondary regions,
+    report file, the one printed line — under torchrun on a box without GPUs; bench.py itself has no CPU path."""
     args = parse()
     under_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not under_torchrun:
@@ -1093,7 +1202,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     preflight = None
-    if world == 1 and os.path.exists("/dev/kfd") and not args.rendezvous_only and not os.environ.get("RG_SKIP_PREFLIGHT"):
+    if device is None and world == 1 and os.path.exists("/dev/kfd") and not args.rendezvous_only and not os.environ.get("RG_SKIP_PREFLIGHT"):
         # One GPU: the torch-only first device touch in a SUBPROCESS, before this process starts its HSA runtime (so before
         # torch.cuda.is_available()).  A lease whose first touch faults (round 4's driver GPU record died that way) is tried
         # under the runtime alternatives of reagent_amd.device_preflight and named if none works: the record then blames the
@@ -1119,20 +1228,24 @@ def main():
             print(json.dumps({"rendezvous": "ok", "ranks": int(t.item()), "backend": dist.get_backend(), "n_gpus": args.gpus}))
         dist.destroy_process_group()
         return
-    if not have_gpu:
+    if not have_gpu and device is None:
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback "
                          f"(rank {rank} of {world})")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} has no GPU (device_count {torch.cuda.device_count()}, --gpus {args.gpus})")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if device is None:
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} has no GPU (device_count {torch.cuda.device_count()}, --gpus {args.gpus})")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     affinity = bind_rank_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" IS RCCL on ROCm
+        if device.type == "cuda":
+            dist.init_process_group(backend, device_id=device)  # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
     m = measure(args, device, rank, world, dist)
     if dist is not None:
@@ -1229,13 +1342,15 @@ def main():
             del shared_cols
         res["also_measured"] = also
     if rank == 0:
-        digest_into_kept_objects(res)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, m["init"], m["cols_cpu"], m["norm"])
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res))
+        where = write_report(res, args.report)
+        res["report_file"] = os.path.relpath(where, ROOT) if where else None
+        sys.stderr.flush()
+        print(compact_line(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
