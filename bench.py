@@ -16,7 +16,10 @@ GPU over RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE and check
 Every rank owns a disjoint shard of the offline dataset (its own replay buffer), the per-rank batch
 stays 65536 (weak scaling) and the only collective is the gradient all-reduce.
 
-Prints ONE JSON line (rank 0).  Extra objects:
+Prints ONE JSON line (rank 0), at most LINE_LIMIT = 4096 bytes: the contract's keys + `roofline` + `cpu_baseline` + digests of
+`parity`, of the 1e-4-compliant bf16x3 mode (`compliant`, the co-headline) and of the other single-GPU configurations (`c3`,
+`c4`) — see compact_line().  The FULL record (every object below, every digit) goes to bench_report.json (--report).
+Objects of the full record:
   roofline     — dominant FC entry point (largest total time, all its variants merged, call-weighted):
                  algorithmic FLOP of its launches / HIP-event time of those launches (events on the launch
                  stream, in a second, instrumented pass so the timed region itself stays un-instrumented;
@@ -24,8 +27,6 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  spans are kernel durations, not host gaps, and agree with rocprofv3's kernel trace in
                  profiles/); `traffic` = HBM bytes per launch from the PMC pass stamped into
                  profiles/traffic.json for exactly this kernel source (null when the stamp does not match).
-                 Digests of `fc_roofline`, `gather`, `parity`, `accurate` (as `compliant_mode`) and
-                 `also_measured` are repeated inside it, `sustained` inside `config`
   fc_roofline  — all FC kernels together against the algorithmic FLOP of the step; in
                  bf16x3 mode `executed_frac` counts the three MFMAs per product that mode issues
   parity       — one extra step on a 4096-row slice of the same workload (fresh trainer, same initial
@@ -46,7 +47,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SIDE_UPDATE_DEFAULT = "off"
 MFMA_PEAK = {"bf16": 2.5e15, "bf16x3": 2.5e15, "f32": 157.3e12}  # /opt/skills/guides/MI355X_MICROARCH.md:40-42
 HBM_PEAK = 8.0e12
 LINE_LIMIT = 4096  # bytes of the ONE line rank 0 prints (round 5's 35.5 KB line was not parsed by the driver)
@@ -176,9 +176,6 @@ def parse():
     ap.add_argument("--launch", choices=["auto", "graph", "eager"], default=None,
                     help="auto: replay the captured HIP graph or enqueue eagerly, whichever a short calibration finds faster")
     ap.add_argument("--prefetch", action="store_true", help="gather the next batch on a second stream (slower, see runtime.py)")
-    ap.add_argument("--side-update", choices=["on", "off"], default=os.environ.get("RG_SIDE_UPDATE", SIDE_UPDATE_DEFAULT),
-                    help="one GPU, eager launches: step k's Adam + soft update + re-staging on a second stream, beside step k+1's "
-                         "sampler (QStepCore.side_update; DQN / QR-DQN loops)")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--parity-batch", type=int, default=4096)
     ap.add_argument("--graph-steps", type=int, default=1,
@@ -365,12 +362,11 @@ def build(args, device, rank, batch=None, cols=None):
 
         maker = PolicyNetworkInputMaker(np.full(A, R[0], dtype=np.float32), np.full(A, R[1], dtype=np.float32))
         loop = OfflinePolicyLoop(rb, trainer, batch, maker, pre,
-                                 state_dtype=torch.bfloat16 if args.precision == "bf16" else None,
-                                 side_update=getattr(args, "side_update", "off") == "on")
+                                 state_dtype=torch.bfloat16 if args.precision == "bf16" else None)
     else:
         loop = OfflineDqnLoop(rb, trainer, batch, pre,
                               state_dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32,
-                              prefetch=args.prefetch, side_update=getattr(args, "side_update", "off") == "on")
+                              prefetch=args.prefetch)
     return loop, trainer, init, cols, (mean, std)
 
 
@@ -1018,8 +1014,6 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
         two_streams = gq is not None and (getattr(gq, "two_streams", False) or getattr(gq, "wgrad_streams", False))
         extra["instrumented_pass"]["timed_ms_per_step"] = dt / args.steps * 1e3
         extra["instrumented_pass"]["launch_streams"] = 2 if two_streams else 1
-    side_note = ("; Adam + soft update (+ re-staging) of step k on a second stream, beside step k+1's sampler"
-                 if (getattr(trainer, "side_update", False) and world == 1 and not replayed) else "")
     per_rank = None
     if dist is not None:
         # every rank's own view, so a curve measured by the driver explains itself: the rank's wall time for the median
@@ -1037,7 +1031,7 @@ def measure(args, device, rank, world, dist, cols=None, profile_steps=None):
     return {"value": world * args.batch * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
             "timing": f"median of {len(regions)} regions of {args.steps} steps each",
             "region_ms": [round(r * 1e3, 4) for r in regions], "host_enqueue_ms_per_step": host_dt / args.steps * 1e3,
-            "final_loss": loss_val, "launch": (graph_note or "eager launches") + side_note, "launch_calibration": calibration,
+            "final_loss": loss_val, "launch": (graph_note or "eager launches"), "launch_calibration": calibration,
             "sustained": sustained, "extra": extra, "parity": parity,
             "per_rank": per_rank, "init": init, "cols": cols, "cols_cpu": cols, "norm": norm}
 

@@ -352,10 +352,20 @@ class Adam:
     eps: float = 1e-08
     weight_decay: float = 0
     amsgrad: bool = False
+    # accepted for configuration compatibility (uninferrable_optimizers.py:29-32).  foreach / capturable choose among torch's
+    # implementations of the same arithmetic (FusedAdam is one launch and capturable as it is); the other two change the
+    # arithmetic and are refused when set
+    maximize: bool = False
+    foreach: Optional[bool] = None
+    capturable: bool = False
+    differentiable: bool = False
     lr_schedulers: List[LearningRateSchedulerConfig] = field(default_factory=list)
 
     def make_optimizer_scheduler(self, params):
         assert len(self.lr_schedulers) <= 1, "Multiple schedulers for one optimizer is no longer supported"
+        if self.maximize or self.differentiable:
+            raise NotImplementedError("Adam(maximize=True / differentiable=True): the fused one-launch Adam minimises and is not "
+                                      "differentiable through")
         optimizer = FusedAdam(params, lr=self.lr, betas=tuple(self.betas), eps=self.eps,
                               weight_decay=self.weight_decay, amsgrad=self.amsgrad)
         if len(self.lr_schedulers) == 0:
@@ -380,8 +390,17 @@ class _TorchOptimizerConfig:
         assert len(self.lr_schedulers) <= 1, "Multiple schedulers for one optimizer is no longer supported"
         cls = getattr(torch.optim, type(self).__name__)
         accepted = inspect.signature(cls).parameters
-        kwargs = {f.name: getattr(self, f.name) for f in dataclasses.fields(self)
-                  if f.name != "lr_schedulers" and f.name in accepted}
+        kwargs = {}
+        for f in dataclasses.fields(self):
+            if f.name == "lr_schedulers":
+                continue
+            if f.name in accepted:
+                kwargs[f.name] = getattr(self, f.name)
+            elif getattr(self, f.name) != f.default:
+                # a field the installed torch.optim class does not take may only be dropped at its default: a dropped
+                # `maximize=True` would silently flip the direction of the optimisation
+                raise TypeError(f"{type(self).__name__}({f.name}={getattr(self, f.name)!r}): torch.optim.{type(self).__name__} of torch "
+                                f"{torch.__version__} has no such argument")
         kwargs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in kwargs.items()}
         optimizer = cls(params, **kwargs)
         if len(self.lr_schedulers) == 0:
@@ -393,17 +412,21 @@ def _torch_config(name, **defaults):
     """dataclass `name` with the given fields / defaults (uninferrable_optimizers.py, torch.optim signatures) + lr_schedulers"""
     import dataclasses
 
-    fields = [(k, type(v) if v is not None else Optional[float], dataclasses.field(default=v)) for k, v in defaults.items()]
+    fields = [(k, type(v) if v is not None else Optional[bool], dataclasses.field(default=v)) for k, v in defaults.items()]
     fields.append(("lr_schedulers", List[LearningRateSchedulerConfig], dataclasses.field(default_factory=list)))
     return dataclasses.make_dataclass(name, fields, bases=(_TorchOptimizerConfig,))
 
 
-SGD = _torch_config("SGD", lr=0.001, momentum=0.0, weight_decay=0.0, dampening=0.0, nesterov=False, maximize=False)
-AdamW = _torch_config("AdamW", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.01, amsgrad=False, maximize=False)
-NAdam = _torch_config("NAdam", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0, momentum_decay=4e-3)
-RAdam = _torch_config("RAdam", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0)
-Adamax = _torch_config("Adamax", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0)
-Rprop = _torch_config("Rprop", lr=0.01, etas=(0.5, 1.2), step_sizes=(1e-06, 50.0))
+# field lists = uninferrable_optimizers.py:36-114 (foreach: None = torch's own choice)
+SGD = _torch_config("SGD", lr=0.001, momentum=0.0, weight_decay=0.0, dampening=0.0, nesterov=False, maximize=False, foreach=None,
+                    differentiable=False)
+AdamW = _torch_config("AdamW", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.01, amsgrad=False, maximize=False, foreach=None,
+                      capturable=False)
+NAdam = _torch_config("NAdam", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0, momentum_decay=4e-3, maximize=False,
+                      foreach=None)
+RAdam = _torch_config("RAdam", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0, maximize=False, foreach=None)
+Adamax = _torch_config("Adamax", lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=0.0, maximize=False, foreach=None)
+Rprop = _torch_config("Rprop", lr=0.01, etas=(0.5, 1.2), step_sizes=(1e-06, 50.0), maximize=False, foreach=None)
 RMSprop = _torch_config("RMSprop", lr=0.01, alpha=0.99, eps=1e-08, weight_decay=0.0, momentum=0.0, centered=False)
 Adagrad = _torch_config("Adagrad", lr=0.01, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10)
 Adadelta = _torch_config("Adadelta", lr=1.0, rho=0.9, eps=1e-06, weight_decay=0.0)

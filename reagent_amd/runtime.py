@@ -267,9 +267,6 @@ class _GraphedLoop:
 
     def replay(self, indices=None):
         G = self._graph
-        join = getattr(self.trainer, "_join_side_update", None)
-        if join is not None:
-            join()  # an eager step before this replay left its update on the side stream (QStepCore.side_update)
         if G["cursor"] is not None:
             if indices is not None:
                 raise ValueError("this loop was captured with a device-side index cursor: replay() draws from the index pool")
@@ -331,20 +328,13 @@ class _GraphedLoop:
         self._join_update()
         note_graph_replays(self.trainer, self._replays)
         self._replays = 0
-        join = getattr(self.trainer, "_join_side_update", None)
-        if join is not None:
-            join()  # updates an eager step left on the side stream (side_update): the compute stream waits for them
 
 
 class OfflineDqnLoop(_GraphedLoop):
     def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int,
-                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None, prefetch: bool = False,
-                 side_update: bool = False):
+                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None, prefetch: bool = False):
         self.rb = replay_buffer
         self.trainer = trainer
-        # world 1, eager launches: step k's Adam + soft update + re-staging on the engine's side stream, beside step k + 1's
-        # sampler (QStepCore.side_update); `flush()` joins it — call it before reading parameters, as with any pending update
-        trainer.side_update = bool(side_update) and torch.device(replay_buffer.device).type == "cuda"
         self.batch_size = batch_size
         self.pre = state_preprocessor
         self.maker = DiscreteDqnInputMaker(trainer.num_actions)
@@ -480,13 +470,11 @@ class OfflinePolicyLoop(_GraphedLoop):
     actor's N(0,1) draws taken from the device RNG."""
 
     def __init__(self, replay_buffer: ReplayBuffer, trainer, batch_size: int, input_maker,
-                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None, side_update: bool = False):
+                 state_preprocessor: Optional[Preprocessor] = None, state_dtype=None):
         """state_dtype=torch.bfloat16 (with a state_preprocessor, bf16 engine): the gather writes the normalized state
         rows in the networks' operand type — half the bytes for the sampler to write and for each of the step's eight
         forwards to read, the same bf16 values the kernels would make of the fp32 rows"""
         self.rb, self.trainer, self.batch_size, self.maker = replay_buffer, trainer, batch_size, input_maker
-        # one GPU, eager launches: the networks' updates on the engine's side stream (SACTrainer.side_update); flush() joins
-        trainer.side_update = bool(side_update) and torch.device(replay_buffer.device).type == "cuda"
         self.pre = state_preprocessor
         self.state_dtype = state_dtype if state_preprocessor is not None else None
         if state_preprocessor is not None and not state_preprocessor.elementwise:

@@ -520,46 +520,8 @@ class QStepCore(DQNTrainerBaseLightning):
         self._pending_batch = (training_batch if getattr(self, "_cpe", None) is not None or self._q_has_batch_norm()
                                else None)
         if not deferred:
-            if self._side_update_ok():
-                self._update_on_side_stream()
-            else:
-                self.apply_pending_update()
-        return loss
-
-    # ---- world 1: the update of step k beside the sampler of step k + 1 --------------------------------
-    # Adam + soft update + re-staging (rg_mlp_update_fused; QR-DQN: + the per-action mean layer) are launch-bound tails
-    # (8-30 us) that nothing needs before the NEXT step's first forward, and the next batch's sampler — bound by random HBM
-    # rows — needs none of what they write.  With `side_update` (the runtime loops opt in) the update is enqueued on the
-    # engine's side stream behind the step's reduce launch, and the next train_step_native (or flush / any other caller of
-    # apply_pending_update) makes the compute stream wait for it before touching a weight: the sampler the loop enqueues
-    # in between runs beside it.  Same launches, same arithmetic, same order of every read and write of a weight.
-    # Off in data-parallel runs (there the deferred update already sits under the all-reduce), inside a graph capture and
-    # in bench.py's instrumented pass (whose spans are per-launch durations of a launch alone on the chip).
-    side_update = False
-    _side_update_event = None
-
-    def _side_update_ok(self) -> bool:
-        from ..optimizer import capturing
-
-        return bool(self.side_update and self._dp_group is None and self._graph_tick is None
-                    and isinstance(self._fused_plan, dict) and getattr(self, "_cpe", None) is None
-                    and self._pending_batch is None and self._slab.grad.is_cuda and not ops.profiling() and not capturing())
-
-    def _update_on_side_stream(self):
-        from ..engine import side_stream
-
-        side = side_stream(self._slab.grad.device)
-        side.wait_stream(torch.cuda.current_stream())  # behind the weight gradient's reduce launch
-        with torch.cuda.stream(side):
             self.apply_pending_update()
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self._side_update_event = ev
-
-    def _join_side_update(self):
-        ev, self._side_update_event = self._side_update_event, None
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        return loss
 
     # ---- the native step in two halves (data-parallel HIP-graph replay, runtime._GraphedLoop) -------------
     @torch.no_grad()
@@ -722,7 +684,6 @@ class QStepCore(DQNTrainerBaseLightning):
     @torch.no_grad()
     def apply_pending_update(self):
         """Adam + soft update of the last backward, after joining its gradient all-reduce."""
-        self._join_side_update()  # an update already enqueued on the side stream: the current stream waits for it
         if not self._update_pending:
             return
         with _NativeStep(self):

@@ -516,7 +516,6 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         self._noise_cur = noise_cur
         q1s = e["q1"]["stack"]
         has_q2 = "q2" in e
-        self._join_side_update()  # the critics' updates of this step, when they went to the side stream
         if self._panels:
             ops.gaussian_head_forward(self._ls, noise_cur, self._api, self._lp, None)
             # the critics are frozen in this segment: only d q / d action comes back (dx_save)
@@ -631,7 +630,6 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
 
     def train_step_gen(self, training_batch: rlt.PolicyNetworkInput, batch_idx: int):
         """IMPORTANT: the input action here is assumed to match the range of the output of the actor."""
-        self._join_side_update()
         assert hasattr(training_batch, "action") and hasattr(training_batch.action, "float_features")
         b = training_batch
         B, A = b.action.float_features.shape
@@ -743,46 +741,11 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         require_grad_scaling_optimizers(self)  # the 1/world of the summed gradients is folded into the Adam launches
         return self
 
-    # ---- one GPU: the networks' updates off the critical path (the policy loop opts in, bench.py --side-update) ----------
-    # Adam + soft update + re-staging of a network is a launch-bound tail of 10-15 us that nothing reads until that network's
-    # next forward.  With `side_update` they are enqueued on the engine's side stream: q1's beside q2's backward pass, q2's
-    # beside the actor's forward (both joined before the critics are evaluated on the actor's actions), the actor's and the
-    # temperature's beside the next step's sampler (joined by the next train_step_native, train_step_gen or the loop's
-    # flush()).  Same launches, same arithmetic; every read and write of a weight keeps its order.  Off under data
-    # parallelism, inside a graph capture, in bench.py's instrumented pass and with a logger attached.
-    side_update = False
-    _side_update_event = None
-
-    def _side_update_ok(self, fused, dev) -> bool:
-        from ..optimizer import capturing
-
-        return bool(self.side_update and fused is not None and self._dp_group is None and dev.type == "cuda"
-                    and not self.logger and not ops.profiling() and not capturing())
-
-    def _run_update(self, fn, side: bool):
-        if not side:
-            return fn()
-        from ..engine import side_stream
-
-        st = side_stream(next(self.actor_network.parameters()).device)
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            fn()
-            ev = torch.cuda.Event()
-            ev.record(st)
-        self._side_update_event = ev  # (the stream is in order: the latest event covers every earlier update)
-
-    def _join_side_update(self):
-        ev, self._side_update_event = self._side_update_event, None
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
     @torch.no_grad()
     @native_step
     def train_step_native(self, training_batch, noise_next=None, noise_cur=None):
         """All five segments with no autograd graph / generator / host sync.  Returns the dict of
         device-resident loss scalars."""
-        self._join_side_update()  # the previous step's actor / temperature updates (side_update)
         opts = self.native_optimizers()
         b = training_batch
         B, A = b.action.float_features.shape
@@ -802,7 +765,6 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         self._critic_forward(b, self._noise(B, A, dev, noise_next))
         fused = self._fused_updates(opts)  # Adam (+ soft update) + re-staging per network in one launch, or None
         dp = self._dp_group is not None
-        side = self._side_update_ok(fused, dev)
         bucket = self._dp_bucket() if dp else None
         critics = [k for k in ("q1", "q2") if k in self._e]
         if bucket is not None:
@@ -821,9 +783,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                 self._critic_backward(k)
             o = next(it)
             if fused is not None:
-                # side_update: beside the other critic's backward pass / the actor's forward; joined in _actor_forward before
-                # the critics are evaluated on the actor's actions
-                self._run_update(lambda k=k: fused[k].step(gs), side)
+                fused[k].step(gs)
             else:
                 o.grad_scale = gs
                 o.step()
@@ -861,9 +821,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                 self.log_alpha.grad = None
                 self.entropy_temperature = self._alpha(dev)
 
-        # side_update: the step's last launch-bound tails (actor update, temperature gradient and its Adam step) beside the
-        # NEXT step's sampler; the next train_step_native / flush() joins them (alpha_loss is final after that join)
-        self._run_update(actor_and_temperature, side)
+        actor_and_temperature()
         if self.value_network is not None:
             self._value_forward(b)
             for p in self._e["value"]["params"]:

@@ -233,114 +233,6 @@ def _qr_loop(dev, capacity=8192, batch=1024, precision=L.PREC_BF16, atoms=200):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("what", ["dqn_bf16", "dqn_bf16x3", "qrdqn_bf16"])
-def test_side_stream_update_equals_the_plain_step(what):
-    """QStepCore.side_update: step k's Adam + soft update + re-staging on the side stream, beside step k + 1's sampler, joined
-    before step k + 1's first forward — the same launches in the same order of every read and write of a weight, so losses,
-    weights, targets and Adam's state after N steps are those of the plain loop BIT FOR BIT; flush() joins the last one;
-    a checkpoint taken mid-run and a graph capture after side-stream steps see finished updates."""
-    dev = torch.device("cuda")
-    L.lib()
-    N = 7
-    make = dict(dqn_bf16=lambda: _c2_loop(dev), dqn_bf16x3=lambda: _c2_loop(dev, precision=L.PREC_BF16X3),
-                qrdqn_bf16=lambda: _qr_loop(dev))[what]
-    idx = [torch.randint(8192, (1024,), generator=torch.Generator().manual_seed(90 + k)).to(dev) for k in range(N)]
-    res = {}
-    for side in (False, True):
-        loop, tr = make()
-        tr.side_update = side
-        out = [loop.step(idx[k]).clone() for k in range(N)]
-        if side:
-            assert tr._side_update_event is not None, "the last update was not left on the side stream"
-        loop.flush()
-        assert tr._side_update_event is None and not tr._update_pending
-        torch.cuda.synchronize()
-        adam = tr.native_optimizers()[0]
-        assert {float(st["step"]) for st in adam.state_dict()["state"].values()} == {float(N)}
-        assert tr.all_batches_processed == N
-        res[side] = dict(loss=torch.stack(out).cpu(),
-                         params=[p.detach().cpu().clone() for p in list(tr.q_network.parameters()) + list(tr.q_network_target.parameters())],
-                         moments=[v.detach().cpu().clone() for st in adam.state_dict()["state"].values()
-                                  for v in (st["exp_avg"], st["exp_avg_sq"])])
-        if side and what == "dqn_bf16":  # a capture after side-stream steps: warm-up, flush, capture, replay, eager again
-            step = loop.capture(warmup=2)
-            l1 = step().clone()
-            l2 = loop.step(idx[0])
-            loop.flush()
-            assert torch.isfinite(l1).all() and torch.isfinite(l2).all() and tr.all_batches_processed == N + 4
-    assert torch.equal(res[False]["loss"], res[True]["loss"]), (res[False]["loss"], res[True]["loss"])
-    for a, b in zip(res[False]["params"] + res[False]["moments"], res[True]["params"] + res[True]["moments"]):
-        assert torch.equal(a, b)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
-def test_sac_side_stream_updates_equal_the_plain_step(precision):
-    """SACTrainer.side_update on the fused stacks (twin critics, one-launch updates): q1's update beside q2's backward, q2's
-    beside the actor's forward, the actor's and the temperature's beside the next step's sampler — losses, every network,
-    the targets and the temperature after N steps are the plain loop's bit for bit"""
-    import numpy as np
-
-    from reagent_amd.core.parameters import CONTINUOUS_TRAINING_ACTION_RANGE as R
-    from reagent_amd.engine import FusedMLP
-    from reagent_amd.preprocessing import PolicyNetworkInputMaker
-    from reagent_amd.replay_memory import ReplayBuffer
-    from reagent_amd.runtime import OfflinePolicyLoop
-    from reagent_amd.training import SACTrainer
-
-    dev = torch.device("cuda")
-    L.lib()
-    S, A, B, C, H, N = 64, 8, 512, 4096, [256, 256], 6
-    prec = dict(bf16=L.PREC_BF16, bf16x3=L.PREC_BF16X3)[precision]
-
-    def build(side):
-        torch.manual_seed(5)
-        adam = lambda: Optimizer__Union.default(lr=1e-3)  # noqa: E731
-        set_default_precision(prec)
-        try:
-            nets = [GaussianFullyConnectedActor(S, A, H, ["relu", "relu"]), FullyConnectedCritic(S, A, H, ["relu", "relu"]),
-                    FullyConnectedCritic(S, A, H, ["relu", "relu"])]
-        finally:
-            set_default_precision(L.PREC_F32)
-        tr = SACTrainer(*[n.to(dev) for n in nets], rl=RLParameters(gamma=0.99, target_update_rate=0.05),
-                        q_network_optimizer=adam(), actor_network_optimizer=adam(), alpha_optimizer=adam()).to(dev)
-        cols = synthetic.replay_contents(C, S, A, seed=3)
-        cols["action"] = torch.rand(C, A, generator=torch.Generator().manual_seed(4)) * 1.8 - 0.9
-        del cols["possible_actions_mask"]
-        rb = ReplayBuffer(replay_capacity=C, batch_size=B, device=dev)
-        rb.load_columns({k: v.to(dev) for k, v in cols.items()}, mark_all_valid=True)
-        maker = PolicyNetworkInputMaker(np.full(A, R[0], dtype=np.float32), np.full(A, R[1], dtype=np.float32))
-        return OfflinePolicyLoop(rb, tr, B, maker, side_update=side), tr
-
-    g = torch.Generator().manual_seed(17)
-    idx = [torch.randint(C, (B,), generator=g).to(dev) for _ in range(N)]
-    noise = [(torch.randn(B, A, generator=g).to(dev), torch.randn(B, A, generator=g).to(dev)) for _ in range(N)]
-    res = {}
-    for side in (False, True):
-        loop, tr = build(side)
-        assert tr.side_update == side
-        out = []
-        for k in range(N):
-            o = loop.step(idx[k], noise_next=noise[k][0], noise_cur=noise[k][1])
-            out.append(torch.stack([o[n].float().reshape(()) for n in ("q1_loss", "q2_loss", "actor_loss")]).clone())
-        assert all(isinstance(tr._e[k]["stack"], FusedMLP) for k in ("actor", "q1", "q2"))
-        if side:  # (from the second step on the one-launch updates are staged: the last step left its tail on the side stream)
-            assert tr._side_update_event is not None
-        loop.flush()
-        assert tr._side_update_event is None
-        torch.cuda.synchronize()
-        res[side] = dict(loss=torch.stack(out).cpu(), alpha_loss=o["alpha_loss"].cpu().clone(), log_alpha=tr.log_alpha.detach().cpu().clone(),
-                         params=[p.detach().cpu().clone() for n in (tr.actor_network, tr.q1_network, tr.q2_network,
-                                                                     tr.q1_network_target, tr.q2_network_target)
-                                 for p in n.parameters()])
-        assert tr.all_batches_processed == N
-    assert torch.equal(res[False]["loss"], res[True]["loss"]), (res[False]["loss"], res[True]["loss"])
-    assert torch.equal(res[False]["alpha_loss"], res[True]["alpha_loss"]) and torch.equal(res[False]["log_alpha"], res[True]["log_alpha"])
-    for a, b in zip(res[False]["params"], res[True]["params"]):
-        assert torch.equal(a, b)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("draw", ["device_rng", "pools"])
 def test_sac_loop_graph_replay_equals_eager(draw):
     import numpy as np

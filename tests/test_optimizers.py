@@ -231,3 +231,30 @@ def test_union_rejects_what_it_cannot_serve():
     made = O.Optimizer__Union(SGD=O.SGD(lr=0.1, lr_schedulers=[O.StepLR(step_size=2)])).make_optimizer_scheduler(
         [torch.nn.Parameter(torch.zeros(3))])
     assert isinstance(made["optimizer"], torch.optim.SGD) and isinstance(made["lr_scheduler"], torch.optim.lr_scheduler.StepLR)
+
+
+def test_union_members_take_the_reference_field_lists():
+    """uninferrable_optimizers.py:23-114: every field a reference config or YAML may pass is accepted; a field the installed
+    torch.optim class lacks is dropped only at its default (never a silent `maximize=True`); the fused Adam refuses the two
+    fields that would change its arithmetic"""
+    import dataclasses
+
+    import reagent_amd.optimizer as O
+
+    want = dict(Adam={"maximize", "foreach", "capturable", "differentiable"}, NAdam={"maximize", "foreach", "momentum_decay"},
+                RAdam={"maximize", "foreach"}, SGD={"maximize", "foreach", "differentiable", "nesterov", "dampening"},
+                AdamW={"maximize", "foreach", "capturable", "amsgrad"}, Adamax={"maximize", "foreach"},
+                Rprop={"maximize", "foreach", "etas", "step_sizes"})
+    for name, fields in want.items():
+        have = {f.name for f in dataclasses.fields(getattr(O, name))}
+        assert fields <= have, (name, fields - have)
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    opt = O.SGD(lr=0.1, maximize=True, foreach=False).make_optimizer_scheduler(p)["optimizer"]
+    assert opt.defaults["maximize"] is True and opt.defaults["foreach"] is False
+    assert isinstance(O.Adam(foreach=True, capturable=True).make_optimizer_scheduler(p)["optimizer"], O.FusedAdam)
+    with pytest.raises(NotImplementedError, match="maximize"):
+        O.Adam(maximize=True).make_optimizer_scheduler(p)
+    Odd = O._torch_config("SGD", lr=0.1, not_a_torch_argument=False)
+    assert isinstance(Odd().make_optimizer_scheduler(p)["optimizer"], torch.optim.SGD)  # at its default: dropped
+    with pytest.raises(TypeError, match="not_a_torch_argument"):
+        Odd(not_a_torch_argument=True).make_optimizer_scheduler(p)

@@ -425,12 +425,12 @@ def test_compact_head_against_the_pair_loop(backend):
 
 
 @pytest.mark.parametrize("name", ["qrdqn_double", "qrdqn_single_sarsa"])
-def test_reporter_fields_match_the_reference(emu_lib, name):
+def test_reporter_fields_match_the_reference(backend, name):
     """qrdqn_trainer.py:178-192: what the step hands its reporter — td_loss, logged action indices, propensities, boosted
     rewards, the mean-over-atoms Q-values and their masked arg-max — against what the reference's reporter received on the
     golden batches"""
     g = Golden(name)
-    tr = build(g, "cpu", L.PREC_F32)
+    tr = build(g, backend.device, L.PREC_F32)
     seen = {}
 
     class Reporter:
@@ -441,7 +441,7 @@ def test_reporter_fields_match_the_reference(emu_lib, name):
     opts = [o["optimizer"] for o in tr.configure_optimizers()]
     for s in range(g.cfg["steps"]):
         seen.clear()
-        lightning_like_step(tr, opts, synthetic.to_dqn_input(g.batch(s), "cpu"))
+        lightning_like_step(tr, opts, synthetic.to_dqn_input(g.batch(s), backend.device))
         want = {k[len(f"step{s}_report_"):]: g.t(k) for k in g.z.files if k.startswith(f"step{s}_report_")}
         assert set(seen) == set(want) and len(want) == 6
         for k, ref in want.items():

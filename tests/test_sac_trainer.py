@@ -310,13 +310,13 @@ def test_bf16_state_rows_from_the_sampler_equal_fp32_rows(backend):
 
 
 @pytest.mark.parametrize("name", ["sac_twin", "sac_value", "sac_crr", "sac_kld", "sac_kld_mean"])
-def test_per_step_metrics_match_the_reference(emu_lib, name):
+def test_per_step_metrics_match_the_reference(backend, name):
     """SURVEY §8 a19 — what SACTrainer hands `self.logger.log_metrics` each step (reagent/training/sac_trainer.py:343-380):
     every key and value the reference logged on the golden batches (recorded by the oracle's loop): td_loss, reward /
     Q-value / target means, entropy temperature, log-prob means, next-state value, min-Q of the actor's action, actor loss
     (before the KLD term), q2_value, target_state_value (value network), the KLD statistics."""
     g = Golden(name)
-    tr = build_variant(g, "cpu") if g.cfg.get("value") else build(g, "cpu")
+    tr = build_variant(g, backend.device) if g.cfg.get("value") else build(g, backend.device)
     logged = {}
 
     class Logger:
@@ -327,7 +327,7 @@ def test_per_step_metrics_match_the_reference(emu_lib, name):
     tr.logger = Logger()
     opts = [o["optimizer"] for o in tr.configure_optimizers()]
     for s in range(g.cfg["steps"]):
-        batch = synthetic.to_policy_input(g.batch(s), "cpu")
+        batch = synthetic.to_policy_input(g.batch(s), backend.device)
         tr.set_noise(g.t(f"step{s}_noise_next"), g.t(f"step{s}_noise_cur"))
         logged.clear()
         lightning_like_step(tr, opts, batch)

@@ -39,8 +39,14 @@ from reagent_amd.preprocessing.trainer_preprocessor import DiscreteDqnInputMaker
 from reagent_amd.replay_memory import ReplayBuffer
 from reagent_amd.training import DQNTrainer, SACTrainer
 
+import os
+
 SEED = 0
 PASSING_SCORE_BAR = 100.0  # discrete_dqn_cartpole_online.yaml:35
+# The driver's GPU run spends its time on parity: the DQN and SAC flows (the path's two trainers with a published bar) always
+# run; the QR-DQN, C51 and TD3 flows only with RG_ALL_LEARNING_CURVES=1 (they passed on the MI355X in round 5,
+# profiles/r05_run11/learning_curves.txt).
+all_flows = pytest.mark.skipif(not os.environ.get("RG_ALL_LEARNING_CURVES"), reason="set RG_ALL_LEARNING_CURVES=1 for the QR-DQN / C51 / TD3 flows")
 
 
 class RandomAgent:
@@ -146,6 +152,7 @@ def test_online_dqn_reaches_the_reference_bar_on_cartpole(backend):
 
 
 
+@all_flows
 def test_online_qrdqn_reaches_the_reference_bar_on_cartpole(backend):
     """reagent/gym/tests/configs/cartpole/discrete_qr_cartpole_online.yaml through the same flow: the DuelingQuantile network
     ([64, 64] leaky_relu: shared trunk, advantage and value streams, 11 quantiles per action), QRDQNTrainer with gamma 0.9,
@@ -310,6 +317,7 @@ def test_online_sac_reaches_the_reference_bar_on_the_pendulum(backend):
 
 
 # ---- the widened rows: C51 on cart-pole, TD3 on the pendulum --------------------------------------------
+@all_flows
 def test_online_c51_reaches_the_reference_bar_on_cartpole(backend):
     """reagent/gym/tests/configs/cartpole/discrete_c51_cartpole_online.yaml: Categorical network [64, 64] leaky_relu with 21
     atoms on [0, 40], C51Trainer with gamma 0.9, target_update_rate 0.05, double-Q, AdamW lr 1e-3 amsgrad, minibatch 512,
@@ -368,6 +376,7 @@ def test_online_c51_reaches_the_reference_bar_on_cartpole(backend):
         assert eval_rewards.mean() >= PASSING_SCORE_BAR, f"Eval reward is {eval_rewards.mean()}, less than < {PASSING_SCORE_BAR}."
 
 
+@all_flows
 def test_online_td3_reaches_the_reference_bar_on_the_pendulum(backend):
     """reagent/gym/tests/configs/pendulum/td3_pendulum_online.yaml: deterministic actor [64, 64] leaky_relu with exploration
     variance 0.01, twin critics, Adam lr 0.005 (actor) / 0.01 (critics), gamma 0.99, target_update_rate 0.005, target-policy
