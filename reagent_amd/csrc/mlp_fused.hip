@@ -34,6 +34,9 @@
 #ifndef RG_GROUPED_STAGE_OUT
 #define RG_GROUPED_STAGE_OUT 1  // a wide grouped output leaves through the (dead) activation tile as whole rows
 #endif
+#ifndef RG_GROUPED_RING
+#define RG_GROUPED_RING 8   // weight chunks in flight per wave in that path's K loop
+#endif
 #ifndef RG_WGRAD_TARGET
 #define RG_WGRAD_TARGET 128
 #endif
@@ -77,6 +80,54 @@ template <int NW> struct MlpCfg {
   static constexpr int RING = NW == 4 ? 8 : 2;
 #endif
 };
+
+// Grouped forward, the LAST segment of a tile (mlp_fwd_fused_body): wave w sums column tile w of the group's [N, K] layer for all four
+// row tiles in the software-pipelined main loop (one weight stream per wave, ring of 8 chunks), the 128 x N outputs are staged
+// in the activation tile — dead once every wave has left its K loop — as 128 x P floats and leave as whole rows, a wave per row.
+// (Its own function, with its own lane / wave derivations: written out inside the segment loop the 512-wide kernel spilled 45
+// registers; called through a non-inlined function 70.)
+template <int NW>
+__device__ __forceinline__ void grouped_whole_tile_out(bf16_t* act, int pitch, int KC, const bf16_t* wf_out, const float* b_out,
+                                                                 int N, int NTo, int out_act, int lo, int hi, int row_base,
+                                                                 const int* scatter, int batch, float* out32, long ldo) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 31, lg = lane >> 5;
+  const int P = NTo * 32 + 4, np = N >> 2;
+  f32x16 acc4[4][1];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc4[tm][0][r] = 0.f;
+  const int col = wave * 32 + lr;
+  float b = 0.f;
+  if (wave < NTo) {
+    if (b_out && col < N) b = b_out[col];  // (requested before the K loop)
+    wide_mainloop<1, RG_GROUPED_RING>(act, pitch, KC, wf_out + (long)wave * KC * 512, 0, acc4, lane, k_rotation(blockIdx.x, wave, KC));
+  }
+  RG_STAMP(16);
+  __syncthreads();  // every wave is done reading the layer input
+  RG_STAMP(17);
+  float* stage = (float*)act;
+  if (wave < NTo) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc4[tm][0][r] + b;
+      act_apply_n(v, out_act);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = v[r];
+    }
+  }
+  __syncthreads();
+  RG_STAMP(18);
+  for (int rel = lo + wave; rel < hi; rel += NW) {  // a wave per row: np <= 64 16-byte pieces
+    int row = row_base + rel;
+    if (scatter) row = scatter[row];  // back to batch order; padding rows (-1) are dropped
+    if (row >= 0 && (scatter || row < batch) && lane < np)
+      stream_store(*(const f32x4*)(stage + rel * P + lane * 4), (f32x4*)(out32 + (long)row * ldo + lane * 4));
+  }
+  RG_STAMP(19);
+}
 
 // PITCH (LDS row pitch in elements) is a template constant so that every LDS offset of the
 // epilogue stores folds into an instruction immediate instead of a vector add per store.
@@ -184,6 +235,10 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
           const int col = nt * 32 + lr;
           if (col < N) {
             const float b = nt == 0 ? b_tile0 : (b_out ? b_out[col] : 0.f);
+            float ov[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ov[r] = acc[r] + b;
+            act_apply_n(ov, out_act);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int rel = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
@@ -191,7 +246,7 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
               int row = row_base + rel;
               if (a.out_scatter) row = a.rowmap[row];  // back to batch order; padding rows (-1) are dropped
               if (row >= 0 && (a.out_scatter || row < a.batch)) {
-                const float o = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+                const float o = ov[r];
                 // a wide output (QR-DQN's 200 quantiles per row: 54 MB per launch, read once by the loss head) streams
                 // past the caches (same-box C3 step -1 %); a thin one is a few MB and its reader is next
                 if (stream_out) stream_store(o, a.out32 + (long)row * a.ldo + col);
@@ -244,13 +299,11 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
               float* dst = a.out32 + (long)row_base * N;
               for (int it = wave * 64 + o_ln; it < (FB_BM * N) >> 2; it += THREADS) {
                 const f32x4 l4 = *(const f32x4*)(lo_ + it * 4), h4 = *(const f32x4*)(hi_ + it * 4);
-                f32x4 o;
+                float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float v = (l4[e] + h4[e]) + bias_s[(it * 4 + e) % N];
-                  o[e] = out_act == ACT_LINEAR ? v : act_apply(v, out_act);
-                }
-                *(f32x4*)(dst + it * 4) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (l4[e] + h4[e]) + bias_s[(it * 4 + e) % N];
+                act_apply_n(o, out_act);
+                *(f32x4*)(dst + it * 4) = f32x4{o[0], o[1], o[2], o[3]};
               }
             }
             const int np = N >> 2;  // 16-byte pieces per row
@@ -260,13 +313,11 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
               if (row < a.batch) {
                 const f32x4 l4 = *(const f32x4*)(lo_ + rel * N + c4 * 4), h4 = *(const f32x4*)(hi_ + rel * N + c4 * 4);
                 const f32x4 b4 = *(const f32x4*)(bias_s + c4 * 4);
-                f32x4 o;
+                float o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float v = (l4[e] + h4[e]) + b4[e];
-                  o[e] = out_act == ACT_LINEAR ? v : act_apply(v, out_act);
-                }
-                *(f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (l4[e] + h4[e]) + b4[e];
+                act_apply_n(o, out_act);
+                *(f32x4*)(a.out32 + (long)row * a.ldo + c4 * 4) = f32x4{o[0], o[1], o[2], o[3]};
               }
             }
           } else {
@@ -293,17 +344,39 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
           // partial lines, 54 MB of them per launch (-20..-28 us with the stores removed).  Here the output leaves as
           // whole rows, 16 bytes per lane: one 32-row tile at a time (wave w computes its column tile w) through a staging
           // area BEHIND the activation tile (32 x (32 NTo + 4) floats, 29 KB of the 30 KB the tile leaves of the CU's LDS).
-          float* stage = (float*)(act + FB_BM * pitch);
           const int P = NTo * 32 + 4;  // floats per staged row
           const int np = N >> 2;       // 16-byte pieces per row
+#if RG_GROUPED_WHOLE
+          // Round 6.  The per-row-tile loop below is a chain of L2 round trips: each of its four passes runs tile_kloop (4 weight
+          // chunks in flight per wave, 8 dependent groups) and two barriers — ~45k of the workgroup's cycles for 8k of MFMAs.
+          // The LAST segment of a tile (the only one of a tile inside one group's range: all but <= n_groups - 1 tiles of a
+          // launch) leaves the activation tile dead after its K loop, so there: wave w sums column tile w for ALL FOUR row tiles
+          // in the software-pipelined main loop (one weight stream per wave, ring of 8 chunks), and the 128 x N outputs are staged
+          // in the dead activation tile (128 x P floats) and leave as whole rows — two barriers instead of eight.
+          bool last_segment = false;
+          if ((size_t)FB_BM * P * sizeof(float) <= (size_t)FB_BM * pitch * sizeof(bf16_t)) {
+            int g2 = seg_g;
+            RowSegment s2;
+            last_segment = !next_segment(a.row_begin, a.n_groups, row_base, FB_BM, g2, s2);  // (workgroup-uniform)
+          }
+          if (last_segment) {
+            grouped_whole_tile_out<NW>(act, pitch, KC, wf_out, b_out, N, NTo, out_act, seg.lo, seg.hi, row_base, a.out_scatter ? a.rowmap : nullptr,
+                                       a.batch, a.out32, a.ldo);
+            break;  // (the last segment)
+          }
+#endif
+          float* stage = (float*)(act + FB_BM * pitch);
           for (int tm = tm0; tm < tm1; ++tm) {
             if (wave < NTo) {
               const f32x16 acc = tile_kloop(act, pitch, KC, wf_out, tm, wave, lane);
               const int col = wave * 32 + lr;
               const float b = (b_out && col < N) ? b_out[col] : 0.f;
+              float v[16];
 #pragma unroll
-              for (int r = 0; r < 16; ++r)
-                stage[((r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+              for (int r = 0; r < 16; ++r) v[r] = acc[r] + b;
+              act_apply_n(v, out_act);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = v[r];
             }
             __syncthreads();
             for (int it = tid; it < 32 * np; it += THREADS) {

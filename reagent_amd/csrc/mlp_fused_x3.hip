@@ -470,6 +470,51 @@ __device__ __forceinline__ void x3_bwd_pack(f32x16 (&acc)[X3_TM][TN], const bf16
   });
 }
 
+// Grouped forward, the LAST segment of a 64-row unit (mlp_fwd_x3_body; the bf16 kernel's grouped_whole_tile_out on two planes):
+// wave w sums column tile w of the group's [N, K] layer for both row tiles in the pipelined main loop, the 64 x N outputs are
+// staged in the activation planes — dead once every wave has left its K loop — and leave as whole rows, a wave per row.
+#ifndef RG_X3_GROUPED_RING
+#define RG_X3_GROUPED_RING 4
+#endif
+template <int NW, int LO>
+__device__ __forceinline__ void x3_grouped_whole_unit_out(bf16_t* act, int pitch, int KC, const bf16_t* wf_out, long wlo, const float* b_out,
+                                                          int N, int NTo, int out_act, int lo, int hi, int row_base, const int* scatter,
+                                                          int batch, float* out32, long ldo) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 31, lg = lane >> 5;
+  const int P = NTo * 32 + 4, np = N >> 2;
+  f32x16 acc2[X3_TM][1];
+#pragma unroll
+  for (int tm = 0; tm < X3_TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[tm][0][r] = 0.f;
+  const int col = wave * 32 + lr;
+  float b = 0.f;
+  if (wave < NTo) {
+    if (b_out && col < N) b = b_out[col];  // (requested before the K loop)
+    x3_mainloop<1, RG_X3_GROUPED_RING, LO>(act, pitch, KC, wf_out + (long)wave * KC * 512, wlo, 0, acc2, lane, k_rotation(blockIdx.x, wave, KC));
+  }
+  __syncthreads();  // every wave is done reading the layer input
+  float* stage = (float*)act;
+  if (wave < NTo) {
+#pragma unroll
+    for (int tm = 0; tm < X3_TM; ++tm) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc2[tm][0][r] + b;
+      act_apply_n(v, out_act);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = v[r];
+    }
+  }
+  __syncthreads();
+  for (int rel = lo + wave; rel < hi; rel += NW) {  // a wave per row: np <= 64 16-byte pieces
+    int row = row_base + rel;
+    if (scatter) row = scatter[row];  // back to batch order; padding rows (-1) are dropped
+    if (row >= 0 && (scatter || row < batch) && lane < np)
+      stream_store(*(const f32x4*)(stage + rel * P + lane * 4), (f32x4*)(out32 + (long)row * ldo + lane * 4));
+  }
+}
+
 // GROUPED: the launch of a stack whose output layer takes per-tile weights (rg_mlp_desc.tile_key, qr_grouped.hip: QR-DQN's
 // wide layer, one action's [N, H] slice per 128-row tile of the grouped row space).  A 64-row workgroup is HALF such a tile:
 // unit u = rows [64 u, 64 u + 64), tile u / 2.  Units go to the XCDs in eighths of the (group-sorted) unit list, as the
@@ -556,17 +601,36 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
           // area behind the two activation planes — one 32-row tile at a time, wave w computing its column tile w (what
           // mlp_fwd_fused_body does for the bf16 stack: stored straight from the accumulators every wave instruction would
           // write partial cache lines)
-          float* stage = (float*)(act + 2 * LO);
           const int P = NTo * 32 + 4;  // floats per staged row
           const int np = N >> 2;       // 16-byte pieces per row
+#if RG_GROUPED_WHOLE
+          // Round 6 (as mlp_fwd_fused_body): the LAST segment of a unit leaves both activation planes dead after its K loop —
+          // wave w sums column tile w for both row tiles in the pipelined main loop (one weight stream per wave instead of a
+          // chain of x3_tile_kloop round trips per row tile), the 64 x N outputs are staged in the dead planes and leave as whole rows
+          bool last_segment = false;
+          if ((size_t)X3_BM * P * sizeof(float) <= (size_t)2 * LO * sizeof(bf16_t)) {
+            int g2 = seg_g;
+            RowSegment s2;
+            last_segment = !next_segment(a.row_begin, a.n_groups, row_base, X3_BM, g2, s2);  // (workgroup-uniform)
+          }
+          if (last_segment) {
+            x3_grouped_whole_unit_out<NW, LO>(act, pitch, KC, wf_out, a.wfrag_lo[l], b_out, N, NTo, out_act, seg.lo, seg.hi, row_base,
+                                              a.out_scatter ? a.rowmap : nullptr, a.batch, a.out32, a.ldo);
+            break;
+          }
+#endif
+          float* stage = (float*)(act + 2 * LO);
           for (int tm = tm0; tm < tm1; ++tm) {
             if (wave < NTo) {
               const f32x16 acc = x3_tile_kloop<LO>(act, pitch, KC, wf_out, a.wfrag_lo[l], tm, wave, lane);
               const int col = wave * 32 + lr;
               const float b = (b_out && col < N) ? b_out[col] : 0.f;
+              float v[16];
 #pragma unroll
-              for (int r = 0; r < 16; ++r)
-                stage[((r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+              for (int r = 0; r < 16; ++r) v[r] = acc[r] + b;
+              act_apply_n(v, out_act);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * lg) * P + col] = v[r];
             }
             __syncthreads();
             for (int it = tid; it < 32 * np; it += THREADS) {
@@ -588,14 +652,17 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
             const int col = nt * 32 + lr;
             if (col < N) {
               const float b = b_out ? b_out[col] : 0.f;
+              float ov[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) ov[r] = acc[r] + b;
+              act_apply_n(ov, out_act);
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int rel = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
                 if (rel < seg.lo || rel >= seg.hi) continue;  // another segment's row
                 int row = row_base + rel;
                 if (a.out_scatter) row = a.rowmap[row];
-                if (row >= 0 && (a.out_scatter || row < a.batch))
-                  a.out32[(long)row * a.ldo + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+                if (row >= 0 && (a.out_scatter || row < a.batch)) a.out32[(long)row * a.ldo + col] = ov[r];
               }
             }
           }
@@ -629,16 +696,16 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
         }
         __syncthreads();
         auto emit = [&](int i0, float* dst) {  // four consecutive staged floats i0 .. i0 + 3 -> dst
-          f32x4 o;
+          float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = stage[i0 + e];
 #pragma unroll
             for (int p = 1; p < PARTS; ++p) v += stage[p * (X3_BM * 32) + i0 + e];
-            v += bias_s[(i0 + e) % N];
-            o[e] = out_act == ACT_LINEAR ? v : act_apply(v, out_act);
+            o[e] = v + bias_s[(i0 + e) % N];
           }
-          *(f32x4*)dst = o;
+          act_apply_n(o, out_act);
+          *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
         };
         if (dense_run) {
           for (int it = tid; it < (X3_BM * N) >> 2; it += THREADS) emit(it * 4, a.out32 + (long)row_base * N + it * 4);
@@ -683,10 +750,14 @@ __device__ __forceinline__ void mlp_fwd_x3_body(const MlpArgs& a) {
         const int col = nt * 32 + lr;
         if (col < N) {
           const float b = a.bias[l] ? a.bias[l][col] : 0.f;
+          float ov[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ov[r] = acc[r] + b;
+          act_apply_n(ov, out_act);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-            if (row < a.batch) a.out32[(long)row * a.ldo + col] = out_act == ACT_LINEAR ? acc[r] + b : act_apply(acc[r] + b, out_act);
+            if (row < a.batch) a.out32[(long)row * a.ldo + col] = ov[r];
           }
         }
       }
