@@ -349,9 +349,41 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
     def _publish(self, e, held=(), reduce=True):
         slab = e["slab"]
         if self._dp_group is not None and reduce:
-            with ops.profile_span("all_reduce", dict(bytes=slab.grad.numel() * 4, world=self._dp_world)):
-                dp_reduce(self, slab)
+            rider = self._alpha_rider if e is self._e.get("actor") else None
+            if rider is not None:
+                # native data-parallel step: the temperature's gradient rides behind the actor's slab (_dp_actor_bucket) — ONE
+                # collective for both (the 1 / world is folded into the Adam launches)
+                with ops.profile_span("all_reduce", dict(bytes=rider.numel() * 4, world=self._dp_world)):
+                    torch.distributed.all_reduce(rider, group=self._dp_group)
+            else:
+                with ops.profile_span("all_reduce", dict(bytes=slab.grad.numel() * 4, world=self._dp_world)):
+                    dp_reduce(self, slab)
         publish_gradients(slab, e["params"], held)
+
+    _alpha_rider = None  # set by the native data-parallel step around the actor's backward pass
+
+    def _dp_actor_bucket(self):
+        """Data parallel: [the actor's gradient slab | one float] — the temperature's gradient (the mean of log_prob + target
+        entropy over the rank's rows, a float64 scalar) travels as the float behind the actor's gradients, so a native SAC step
+        is TWO collectives (critics, actor + temperature), not three (few, large collectives).  The fp32 sum over
+        the ranks rounds the temperature's gradient at 6e-8 relative; its Adam step is float64 as before."""
+        e = self._e["actor"]
+        slab = e["slab"]
+        b = getattr(self, "_dp_bucket_actor", None)
+        ok = (b is not None and b.device == slab.grad.device and b.numel() == slab.total + 1
+              and slab.grad.data_ptr() == b.data_ptr())
+        if not ok:
+            b = torch.zeros(slab.total + 1, dtype=torch.float32, device=slab.grad.device)
+            view = b[:slab.total]
+            view.copy_(slab.grad)
+            old = slab.grad.data_ptr()
+            for i, p in enumerate(slab.params):  # gradients published through the old slab follow it
+                if p.grad is not None and p.grad.data_ptr() == old + 4 * slab.offsets[i]:
+                    p.grad = slab.view(view, i)
+            slab.grad = view
+            e["dw"], e["db"] = grad_views(self.actor_network.fc, slab, e["params"])
+            self._dp_bucket_actor = b
+        return b
 
     def _dp_bucket(self):
         """Data parallel: the gradient slabs of the two critics become the two halves of ONE buffer, so that the native step
@@ -791,14 +823,19 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
         alpha_reduce = None
         if self.alpha_optimizer is not None and dp:
             # the temperature's gradient needs the actor FORWARD only (mean of log_prob + target entropy): under data
-            # parallelism it is taken here and its 8-byte all-reduce runs asynchronously under the actor's backward pass
-            # instead of standing, latency-bound, between two optimizer steps
+            # parallelism it is taken here and summed over the ranks by the actor's own all-reduce, as one more float behind
+            # the actor's gradient slab (round 6; rounds 4-5: an asynchronous 8-byte all-reduce of its own, a third collective)
             self.log_alpha.grad = None
             self._alpha_backward(alias=True)
-            alpha_reduce = torch.distributed.all_reduce(self.log_alpha.grad, group=self._dp_group, async_op=True)
+            alpha_reduce = self._dp_actor_bucket()
+            alpha_reduce[-1:].copy_(self.log_alpha.grad)
         for p in self._e["actor"]["params"]:
             p.grad = None
-        self._actor_backward()
+        self._alpha_rider = alpha_reduce
+        try:
+            self._actor_backward()
+        finally:
+            self._alpha_rider = None
         o = next(it)
         alpha_opt = next(it) if self.alpha_optimizer is not None else None
 
@@ -810,7 +847,7 @@ class SACTrainer(RLTrainerMixin, ReAgentLightningModule):
                 o.step()
             if alpha_opt is not None:
                 if alpha_reduce is not None:
-                    alpha_reduce.wait()  # (the compute stream waits; the host does not)
+                    self.log_alpha.grad.copy_(alpha_reduce[-1:])  # the sum over the ranks (float64 again for its Adam step)
                     self.log_alpha.grad.mul_(gs)
                 else:
                     self.log_alpha.grad = None

@@ -158,15 +158,17 @@ def _worker(rank, world, port, kind, out_dir):
     finally:
         dist.all_reduce = real_all_reduce
     if kind in ("sac", "sac_fused"):
-        # the twin critics' gradient slabs are ONE buffer and one collective, the temperature's 8-byte
-        # all-reduce is asynchronous (it runs under the actor's backward pass): three collectives per step, not four
+        # the twin critics' gradient slabs are ONE buffer and one collective, the temperature's gradient rides
+        # as one float behind the actor's slab: TWO collectives per step (rounds 4-5: three; the reference's DDP would take
+        # one per parameter bucket)
         n_steps = 3 if fused else 2
         s1, s2 = tr._e["q1"]["slab"], tr._e["q2"]["slab"]
         assert tr._dp_bucket_q.numel() == s1.total + s2.total and s1.grad.data_ptr() == tr._dp_bucket_q.data_ptr()
         assert s2.grad.data_ptr() == tr._dp_bucket_q.data_ptr() + 4 * s1.total
         per_step = calls[:len(calls) // n_steps]
-        assert len(calls) == 3 * n_steps and per_step[0] == (s1.total + s2.total, False), calls
-        assert per_step[1] == (1, True) and per_step[2] == (tr._e["actor"]["slab"].total, False), calls
+        sa = tr._e["actor"]["slab"]
+        assert len(calls) == 2 * n_steps and per_step[0] == (s1.total + s2.total, False), calls
+        assert per_step[1] == (sa.total + 1, False) and sa.grad.data_ptr() == tr._dp_bucket_actor.data_ptr(), calls
     if kind == "qr_fused":
         from reagent_amd.qr_engine import GroupedQR
 
