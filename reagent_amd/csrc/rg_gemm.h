@@ -49,6 +49,20 @@ __device__ __forceinline__ float act_apply(float z, int act) {
     default: return z;
   }
 }
+// v[i] = act(v[i]) for a register array, the run-time activation tested ONCE.  (Round 6: `act == ACT_LINEAR ? z : act_apply(z, act)`
+// per element of an unrolled loop puts a copy of every activation's code — tanhf, expf, log1pf — between two consecutive elements:
+// the grouped forward's 64 staged outputs per lane were 17k instructions, each copy skipped by a branch the instruction cache
+// pays for: 16.7k of a workgroup's cycles for 448 LDS writes.)
+template <int N> __device__ __forceinline__ void act_apply_n(float (&v)[N], int act) {
+  if (act == ACT_LINEAR) return;
+  if (act == ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = act_apply(v[i], act);
+}
 // d act(z) / dz expressed through the activation OUTPUT h = act(z) (all six are invertible enough)
 __device__ __forceinline__ float act_grad_from_output(float h, int act) {
   switch (act) {
@@ -349,7 +363,8 @@ struct EpiForward {  // y = act(acc + bias); row-major and/or transposed stores
     const float b = (bias && live) ? bias[col] : 0.f;
     float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] + b, act);
+    for (int e = 0; e < 4; ++e) o[e] = v[e] + b;
+    act_apply_n(o, act);
     if (y32 && live) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -365,7 +380,8 @@ struct EpiForward {  // y = act(acc + bias); row-major and/or transposed stores
     if (row >= M || col0 >= N) return;
     float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] + ((bias && col0 + e < N) ? bias[col0 + e] : 0.f), act);
+    for (int e = 0; e < 4; ++e) o[e] = v[e] + ((bias && col0 + e < N) ? bias[col0 + e] : 0.f);
+    act_apply_n(o, act);
     const bool full = col0 + 3 < N;
     if (y32) {
       float* p = y32 + (long)row * ldy + col0;

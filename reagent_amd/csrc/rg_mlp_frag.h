@@ -103,20 +103,7 @@ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m *
 // compile-time activation (a runtime `switch` per element would bloat the unrolled epilogues until
 // the unroller gives up and the accumulator arrays fall into scratch)
 template <int ACT> __device__ __forceinline__ float act_t(float z) { return act_apply(z, ACT); }
-// v[i] = act(v[i]) for a register array, the run-time activation tested ONCE.  (Round 6: `act == ACT_LINEAR ? z : act_apply(z, act)`
-// per element of an unrolled loop puts a copy of every activation's code — tanhf, expf, log1pf — between two consecutive elements:
-// the grouped forward's 64 staged outputs per lane were 17k instructions, each copy skipped by a branch the instruction cache
-// pays for: 16.7k of a workgroup's cycles for 448 LDS writes.)
-template <int N> __device__ __forceinline__ void act_apply_n(float (&v)[N], int act) {
-  if (act == ACT_LINEAR) return;
-  if (act == ACT_RELU) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = act_apply(v[i], act);
-}
+
 template <int ACT> __device__ __forceinline__ float act_grad_t(float h) { return act_grad_from_output(h, ACT); }
 #define RG_DISPATCH_ACT(act, ...)                                                   \
   switch (act) {                                                                    \
