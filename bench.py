@@ -578,7 +578,7 @@ FC_ENTRY_POINTS = ("rg_fc_forward", "rg_fc_dgrad", "rg_fc_wgrad", "rg_fc_wgrad_f
 # the __global__ functions an entry point launches (what `rocprofv3 --kernel-trace --stats` lists for it: profiles/)
 KERNELS_OF = {"rg_mlp_forward_fused": "mlp_fwd_fused_kernel", "rg_mlp_backward_fused": "mlp_bwd_fused_kernel",
               "rg_mlp_wgrad_fused": "wgrad_group_kernel + wgrad_reduce_tail_kernel",
-              "rg_replay_dqn_batch": "replay_dqn_batch_kernel"}
+              "rg_replay_dqn_batch": "replay_dqn_batch_kernel", "rg_replay_policy_batch": "replay_policy_batch_kernel"}
 
 
 class QueueAhead:
@@ -803,7 +803,7 @@ def kernel_profile(args, step, steps, device=None, gpu_ms=None):
                     out["roofline"]["traffic_source"] = "profiles/traffic.json is stamped for other kernel sources: not reported"
             except Exception as e:
                 out["roofline"]["traffic_source"] = f"profiles/traffic.json unreadable: {e!r}"
-    g = [r for r in rows if r["name"] in ("rg_replay_dqn_batch", "rg_replay_gather")]
+    g = [r for r in rows if r["name"] in ("rg_replay_dqn_batch", "rg_replay_policy_batch", "rg_replay_gather")]
     if g:
         sec = g[0]["ms"] * 1e-3 / g[0]["calls"]
         bytes_ = g[0]["meta"]["bytes_per_row"] * B

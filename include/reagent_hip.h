@@ -490,6 +490,42 @@ int rg_replay_dqn_batch_pooled(const rg_replay_view* view, const int64_t* index_
                                double* pre_tick_sched, int batch, const rg_norm_col* cols, const float* quantiles,
                                const rg_dqn_batch_out* out, rg_stream_t stream);
 
+/* ABI 11.  The continuous-action twin of rg_replay_dqn_batch: ReplayBuffer.sample_transition_batch
+ * (reagent/replay_memory/circular_replay_buffer.py:614-706, stack_size 1, dense fp32 observations and [capacity, action_dim]
+ * fp32 actions) + PolicyNetworkInputMaker (reagent/gym/preprocessors/trainer_preprocessor.py:175-227: rescale_actions of action
+ * and next_action into the training range, next_action rows of terminal transitions zero, not_terminal = 1 - terminal,
+ * action_probability = exp(log_prob)) in ONE launch, optionally with Preprocessor.forward on both state matrices.
+ * Bit-identical to rg_replay_nstep + rg_replay_gather + rg_make_policy_input (same operations, same roundings).
+ * ranges [4 * action_dim] (device) = prev_min | prev_max | new_min | new_max, as for rg_make_policy_input.
+ * RG_EUNSUPPORTED (n_features % 4, > 512 features, unaligned rows): use those three instead. */
+typedef struct {
+  const float* observation;  /* [capacity, n_features] */
+  const float* action;       /* [capacity, action_dim] */
+  const float* reward;       /* [capacity] */
+  const uint8_t* terminal;   /* [capacity] */
+  const float* log_prob;     /* [capacity], nullable (action_probability = 1) */
+  const float* decays;       /* [update_horizon] gamma**k, as for rg_replay_nstep */
+  const float* ranges;       /* [4 * action_dim] */
+  int64_t capacity;
+  int32_t n_features;
+  int32_t action_dim;
+  int32_t update_horizon;
+  int32_t reserved;
+} rg_policy_replay_view; /* host struct */
+typedef struct {
+  void* state;                /* [batch, n_features] fp32 or bf16 (state_dtype) */
+  void* next_state;
+  float* action;              /* [batch, action_dim] rescaled */
+  float* next_action;         /* [batch, action_dim] rescaled, zero rows for terminal transitions */
+  float* reward;              /* [batch] n-step discounted sum */
+  float* not_terminal;        /* [batch] */
+  float* action_probability;  /* [batch], nullable */
+  int32_t state_dtype;        /* RG_DT_F32 / RG_DT_BF16 */
+  int32_t reserved;
+} rg_policy_batch_out; /* host struct */
+int rg_replay_policy_batch(const rg_policy_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
+                           const float* quantiles, const rg_policy_batch_out* out, rg_stream_t stream);
+
 /* *bad_flag (device int, zeroed by the caller) becomes 1 if a sampled row holds an action outside
  * [0, n_actions) or a next_action outside [0, n_actions] (F.one_hot would raise), 2 if an index is
  * outside [0, n_rows). */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RG_LIB: another build of the same library (same-box A/B of compile-time kernel variants); default = the in-tree build
 LIB_PATH = os.environ.get("RG_LIB") or os.path.join(_HERE, "lib", "libreagent_hip.so")
 
-ABI_VERSION = 10  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
+ABI_VERSION = 11  # rg_abi_version() of include/reagent_hip.h this module's structs and signatures mirror
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 ACT = {"linear": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "softplus": 5}
@@ -145,6 +145,22 @@ class ReplayView(ctypes.Structure):
         ("update_horizon", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+POLICY_VIEW_COLUMNS = ("observation", "action", "reward", "terminal", "log_prob", "decays", "ranges")
+
+
+class PolicyReplayView(ctypes.Structure):  # rg_policy_replay_view (ABI 11)
+    _fields_ = [(n, c_void_p) for n in POLICY_VIEW_COLUMNS] + [
+        ("capacity", ctypes.c_int64), ("n_features", ctypes.c_int32), ("action_dim", ctypes.c_int32),
+        ("update_horizon", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+POLICY_OUT_FIELDS = ("state", "next_state", "action", "next_action", "reward", "not_terminal", "action_probability")
+
+
+class PolicyBatchOut(ctypes.Structure):  # rg_policy_batch_out (ABI 11)
+    _fields_ = [(n, c_void_p) for n in POLICY_OUT_FIELDS] + [("state_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 # every symbol include/reagent_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "rg_strerror": (ctypes.c_char_p, [c_int]),
@@ -209,6 +225,8 @@ SIGNATURES = {
                                     ctypes.POINTER(DqnBatchOut), c_void_p]),
     "rg_replay_dqn_batch": (c_int, [ctypes.POINTER(ReplayView), c_void_p, c_int, c_void_p, c_void_p,
                                      ctypes.POINTER(DqnBatchOut), c_void_p]),
+    "rg_replay_policy_batch": (c_int, [ctypes.POINTER(PolicyReplayView), c_void_p, c_int, c_void_p, c_void_p,
+                                        ctypes.POINTER(PolicyBatchOut), c_void_p]),
     "rg_replay_dqn_batch_pooled": (c_int, [ctypes.POINTER(ReplayView), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                             ctypes.POINTER(DqnBatchOut), c_void_p]),
     "rg_table_check_actions": (c_int, [ctypes.POINTER(DqnTable), c_void_p, c_int, c_void_p, c_void_p]),

@@ -84,7 +84,7 @@ int rg_soft_update(float* target, const float* source, int64_t n, double tau, rg
 /* 2: rg_mlp_desc grew (x3, panels, rowmap, grouped output layer), _sched and grouped-QR entry points
  * 3: rg_mlp_desc.dx_only (was reserved) and save = 2; layer norm, dueling, policy input, SAC KLD entry points
  * 4: rg_mlp_desc.x2_dtype (the two input panels may have different element types) */
-int rg_abi_version(void) { return 10; }
+int rg_abi_version(void) { return 11; }
 
 const char* rg_strerror(int code) {
   switch (code) {

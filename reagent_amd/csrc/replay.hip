@@ -472,6 +472,123 @@ __global__ void replay_dqn_batch_kernel(ReplayBatchArgs a, const int64_t* __rest
   }
 }
 
+// ---- sampled indices -> rlt.PolicyNetworkInput in one launch (ABI 11) -------------------------------
+// The continuous-action twin of replay_dqn_batch_kernel (BASELINE C4's sampler: rounds 1-5 took rg_replay_nstep +
+// rg_replay_gather + rg_make_policy_input, 72 us in three launches of which 17 us are launch-bound tails): workgroup
+// (block of 64 transitions, piece) with piece 0 = state rows, 1 = next_state rows (both normalized on the way, bf16 or fp32
+// out), 2 = the n-step reward, not_terminal, exp(log_prob) and the two rescaled action rows.  Every workgroup recomputes the
+// n-step bookkeeping of its 64 transitions (a handful of byte loads).  Same arithmetic, operation for operation, as
+// replay_nstep_kernel / replay_gather_kernel's normalize-on-gather branch / make_policy_input_kernel: tests compare bit for bit.
+struct PolicyBatchArgs {
+  rg_policy_replay_view v;
+  rg_policy_batch_out o;
+};
+
+__global__ void replay_policy_batch_kernel(PolicyBatchArgs a, const int64_t* __restrict__ indices, int batch,
+                                           const rg_norm_col* __restrict__ cols, const float* __restrict__ quantiles) {
+  __shared__ int64_t s_src[GATHER_ROWS_PER_WG];  // the row this piece reads: idx (state), next idx (next_state)
+  __shared__ int64_t s_nxt[GATHER_ROWS_PER_WG];
+  __shared__ int s_steps[GATHER_ROWS_PER_WG];
+  __shared__ unsigned char s_term[GATHER_ROWS_PER_WG];
+  __shared__ __attribute__((aligned(16))) rg_norm_col s_nc[GATHER_MAX_LDS_COLS];
+  const rg_policy_replay_view& v = a.v;
+  const rg_policy_batch_out& o = a.o;
+  const int row0 = blockIdx.x * GATHER_ROWS_PER_WG;
+  const int nrows = (batch - row0 < GATHER_ROWS_PER_WG) ? batch - row0 : GATHER_ROWS_PER_WG;
+  const int piece = blockIdx.y;  // 0 = state, 1 = next_state, 2 = everything else
+  const int F = v.n_features, A = v.action_dim, H = v.update_horizon;
+  const int64_t C = v.capacity;
+  auto wrap = [&](int64_t t) { return t >= C ? t - C : t; };  // (idx + k) % C: idx < C and k <= H <= C
+  if ((int)threadIdx.x < nrows) {
+    const int64_t idx = indices[row0 + threadIdx.x];
+    int st = H;  // _get_steps (:759-774); with H == 1 the window is one slot whatever it holds
+    if (H > 1)
+      for (int k = 0; k < H; ++k)
+        if (v.terminal[wrap(idx + k)]) {
+          st = k + 1;
+          break;
+        }
+    const int64_t nidx = wrap(idx + st);
+    s_src[threadIdx.x] = piece == 1 ? nidx : idx;
+    s_nxt[threadIdx.x] = nidx;
+    s_steps[threadIdx.x] = st;
+    if (piece == 2) s_term[threadIdx.x] = v.terminal[wrap(idx + st - 1)] ? 1 : 0;
+  }
+  const int cpr = F >> 2;  // F % 4 == 0 (checked by the host)
+  int* s_op = (int*)s_nc;  // the descriptors as a structure of arrays (replay_dqn_batch_kernel: conflict-free 16-byte reads)
+  float* s_p0 = (float*)s_nc + GATHER_MAX_LDS_COLS;
+  float* s_p1 = s_p0 + GATHER_MAX_LDS_COLS;
+  float* s_p2 = s_p1 + GATHER_MAX_LDS_COLS;
+  float* s_p3 = s_p2 + GATHER_MAX_LDS_COLS;
+  if (piece < 2 && cols)
+    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+      const rg_norm_col c = cols[j];
+      s_op[j] = c.op; s_p0[j] = c.p0; s_p1[j] = c.p1; s_p2[j] = c.p2; s_p3[j] = c.p3;
+    }
+  __syncthreads();
+  if (piece < 2) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    void* dst = piece == 0 ? o.state : o.next_state;
+    const int total = nrows * cpr;
+    for (int it = threadIdx.x; it < total; it += blockDim.x) {
+      const int r = it / cpr, ch = it - r * cpr;
+      const f32x4 raw = stream_load((const f32x4*)(v.observation + s_src[r] * F + ch * 4));  // a sampled row is read once
+      float w[4] = {raw[0], raw[1], raw[2], raw[3]};
+      if (cols) {
+        const i32x4 op = *(const i32x4*)(s_op + ch * 4);
+        const f32x4 p0 = *(const f32x4*)(s_p0 + ch * 4), p1 = *(const f32x4*)(s_p1 + ch * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rg_norm_col c;
+          c.op = op[e]; c.in_col = 0; c.p0 = p0[e]; c.p1 = p1[e]; c.p2 = 0.f; c.p3 = 0.f;
+          if (c.op == RG_NORM_BOXCOX || c.op == RG_NORM_CONTINUOUS_ACTION) {
+            c.p2 = s_p2[ch * 4 + e];
+            c.p3 = s_p3[ch * 4 + e];
+          }
+          w[e] = normalize_value(c, w[e], 1.f, quantiles);
+        }
+      }
+      const long at = (long)(row0 + r) * F + ch * 4;
+      if (o.state_dtype == RG_DT_BF16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(w[0], w[1]);
+        pk.y = pack_bf16x2(w[2], w[3]);
+        *(uint2*)((bf16_t*)dst + at) = pk;
+      } else {
+        *(f32x4*)((float*)dst + at) = f32x4{w[0], w[1], w[2], w[3]};
+      }
+    }
+    return;
+  }
+  if ((int)threadIdx.x < nrows) {
+    const int b = row0 + threadIdx.x, st = s_steps[threadIdx.x];
+    const int64_t idx = s_src[threadIdx.x];
+    // _reduce_multi_step_reward (:741-747): (reward * decays * masks).sum(dim=1), in that order
+    float acc = 0.f;
+    for (int k = 0; k < H; ++k) {
+      const float m = (k < st) ? 1.f : 0.f;
+      acc += (v.reward[wrap(idx + k)] * v.decays[k]) * m;
+    }
+    o.reward[b] = acc;
+    o.not_terminal[b] = 1.0f - (s_term[threadIdx.x] ? 1.f : 0.f);
+    if (o.action_probability) o.action_probability[b] = v.log_prob ? expf(v.log_prob[idx]) : 1.f;
+  }
+  // rescale_actions (training/utils.py:13-29) of the logged action and of the action stored at the next index; every product
+  // and sum rounded on its own, as in make_policy_input_kernel
+  const int total = nrows * A;
+  for (int it = threadIdx.x; it < total; it += blockDim.x) {
+    const int r = it / A, d = it - r * A;
+    const float lo = v.ranges[d], hi = v.ranges[A + d], tl = v.ranges[2 * A + d], th = v.ranges[3 * A + d];
+    const float prev_range = __fsub_rn(hi, lo), new_range = __fsub_rn(th, tl);
+    const float av = v.action[s_src[r] * A + d], nv = v.action[s_nxt[r] * A + d];
+    const float x = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(av, lo), prev_range), new_range), tl);
+    const float n = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(nv, lo), prev_range), new_range), tl);
+    const long at = (long)(row0 + r) * A + d;
+    o.action[at] = x;
+    o.next_action[at] = s_term[r] ? 0.f : n;
+  }
+}
+
 }  // namespace rg
 
 using namespace rg;
@@ -553,6 +670,27 @@ int rg_replay_dqn_batch_pooled(const rg_replay_view* view, const int64_t* index_
                                const rg_dqn_batch_out* out, rg_stream_t stream) {
   if (!cursor) return RG_EINVAL;
   return replay_dqn_batch_launch(view, index_pool, batch, cols, quantiles, out, cursor, pre_tick_sched, stream);
+}
+
+int rg_replay_policy_batch(const rg_policy_replay_view* view, const int64_t* indices, int batch, const rg_norm_col* cols,
+                           const float* quantiles, const rg_policy_batch_out* out, rg_stream_t stream) {
+  if (!view || !out || batch < 0) return RG_EINVAL;
+  if (batch == 0) return RG_OK;
+  const rg_policy_replay_view& v = *view;
+  const rg_policy_batch_out& o = *out;
+  if (!indices || !v.observation || !v.action || !v.reward || !v.terminal || !v.decays || !v.ranges || v.capacity <= 0 ||
+      v.n_features <= 0 || v.action_dim <= 0 || v.update_horizon <= 0)
+    return RG_EINVAL;
+  if (!o.state || !o.next_state || !o.action || !o.next_action || !o.reward || !o.not_terminal) return RG_EINVAL;
+  if (o.state_dtype != RG_DT_F32 && o.state_dtype != RG_DT_BF16) return RG_EINVAL;
+  if (!cols && o.state_dtype != RG_DT_F32) return RG_EINVAL;  // a raw copy stays fp32
+  if ((v.n_features & 3) || v.n_features > GATHER_MAX_LDS_COLS || (((uintptr_t)v.observation) & 15) ||
+      (((uintptr_t)o.state) & 15) || (((uintptr_t)o.next_state) & 15))
+    return RG_EUNSUPPORTED;  // callers fall back to rg_replay_nstep + rg_replay_gather + rg_make_policy_input
+  PolicyBatchArgs a{v, o};
+  RG_LAUNCH(replay_policy_batch_kernel, dim3((batch + GATHER_ROWS_PER_WG - 1) / GATHER_ROWS_PER_WG, 3), dim3(256),
+            (hipStream_t)stream, a, indices, batch, cols, quantiles);
+  return (int)hipGetLastError();
 }
 
 int rg_make_dqn_input(const int64_t* action, const int64_t* next_action, const uint8_t* terminal,

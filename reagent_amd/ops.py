@@ -428,6 +428,34 @@ def replay_dqn_batch(view: "L.ReplayView", indices, cols_dev, quantiles, out: di
     return rc[0] == 0
 
 
+def replay_policy_batch(view: "L.PolicyReplayView", indices, cols_dev, quantiles, out: dict) -> bool:
+    """one-launch sample + PolicyNetworkInputMaker (+ normalize) — rg_replay_policy_batch; False = shape not supported by the
+    fused kernel (the caller takes rg_replay_nstep + rg_replay_gather + rg_make_policy_input)"""
+    _chk_dev(indices, cols_dev, quantiles, *out.values())
+    assert indices.dtype == torch.int64 and indices.is_contiguous()
+    o = L.PolicyBatchOut()
+    for name in L.POLICY_OUT_FIELDS:
+        t = out.get(name)
+        assert t is None or t.is_contiguous()
+        setattr(o, name, t.data_ptr() if t is not None else None)
+    o.state_dtype = dt_code(out["state"].dtype)
+    B = indices.numel()
+    rc = [0]
+
+    def call():
+        rc[0] = L.lib().rg_replay_policy_batch(ctypes.byref(view), L.ptr(indices), B, L.ptr(cols_dev), L.ptr(quantiles),
+                                               ctypes.byref(o), L.stream_ptr())
+        return 0 if rc[0] == L.EUNSUPPORTED else rc[0]
+
+    F_, A_, H_ = view.n_features, view.action_dim, view.update_horizon
+    es = out["state"].element_size()
+    # algorithmic bytes per transition: state rows in (2 F fp32) and out (2 F), action rows in and out (4 A fp32), the n-step
+    # window (terminal byte + reward per slot), index, log_prob, three scalars out
+    nbytes = 2 * F_ * 4 + 2 * F_ * es + 4 * A_ * 4 + 5 * H_ + 8 + 4 + 3 * 4
+    _run("rg_replay_policy_batch", dict(B=B, bytes_per_row=nbytes), call)
+    return rc[0] == 0
+
+
 def table_check_actions(table, indices) -> int:
     _chk_dev(indices)
     flag = torch.zeros(1, dtype=torch.int32, device=indices.device)

@@ -534,6 +534,59 @@ class ReplayBuffer:
             extras=rlt.ExtraData(mdp_id=None, sequence_number=None, action_probability=out["action_probability"],
                                  max_num_actions=None, metrics=None))
 
+    def sample_policy_input(self, input_maker, batch_size=None, indices=None, state_preprocessor=None, state_dtype=None):
+        """sample_transition_batch + PolicyNetworkInputMaker (trainer_preprocessor.py:175-227) [+ the state Preprocessor] as
+        ONE launch (rg_replay_policy_batch, round 6): the n-step bookkeeping, both state gathers, the two rescaled action rows,
+        not_terminal and exp(log_prob) — bit-identical to rg_replay_nstep + rg_replay_gather + rg_make_policy_input.  Returns
+        None when the store is not of the shape the fused kernel serves (stacked frames, non-fp32 or non-vector
+        observations / actions, an ENUM-expanding preprocessor, ...): callers then use the generic path."""
+        from ..core import types as rlt
+
+        st = self._store
+        obs, act = st.get("observation"), st.get("action")
+        if (self._stack_size != 1 or self._return_everything_as_stack or self._return_as_timeline_format or obs is None
+                or obs.dtype != torch.float32 or obs.dim() != 2 or act is None or act.dtype != torch.float32
+                or act.dim() != 2 or "log_prob" not in st or st["log_prob"].dtype != torch.float32
+                or st["reward"].dtype != torch.float32 or not hasattr(input_maker, "_ranges")):
+            return None
+        if state_preprocessor is not None and not state_preprocessor.elementwise:
+            return None
+        if state_preprocessor is None and state_dtype not in (None, torch.float32):
+            return None
+        if batch_size is None:
+            batch_size = self._batch_size
+        if indices is None:
+            indices = self.sample_index_batch(batch_size)
+        else:
+            indices = indices.to(device=self.device, dtype=torch.int64)
+        assert len(indices) == batch_size
+        indices = indices.contiguous()
+        B, dev, F, A = batch_size, self.device, obs.shape[1], act.shape[1]
+        if self._decays_dev is None or self._decays_dev.device != dev:
+            self._decays_dev = self._decays.reshape(-1).to(device=dev, dtype=torch.float32)
+        ranges = input_maker._ranges(dev, A)
+        view = L.PolicyReplayView()
+        view.observation, view.action, view.reward = obs.data_ptr(), act.data_ptr(), st["reward"].data_ptr()
+        view.terminal, view.log_prob = st["terminal"].data_ptr(), st["log_prob"].data_ptr()
+        view.decays, view.ranges = self._decays_dev.data_ptr(), ranges.data_ptr()
+        view.capacity, view.n_features, view.action_dim = self._replay_capacity, F, A
+        view.update_horizon = self._update_horizon
+        f32 = dict(dtype=torch.float32, device=dev)
+        sdt = state_dtype or torch.float32
+        out = dict(state=torch.empty(B, F, dtype=sdt, device=dev), next_state=torch.empty(B, F, dtype=sdt, device=dev),
+                   action=torch.empty(B, A, **f32), next_action=torch.empty(B, A, **f32), reward=torch.empty(B, 1, **f32),
+                   not_terminal=torch.empty(B, 1, **f32), action_probability=torch.empty(B, 1, **f32))
+        pre = state_preprocessor
+        if not ops.replay_policy_batch(view, indices, pre._col_table if pre is not None else None,
+                                       pre._quantiles if pre is not None else None, out):
+            return None
+        return rlt.PolicyNetworkInput(
+            state=rlt.FeatureData(out["state"]), next_state=rlt.FeatureData(out["next_state"]),
+            action=rlt.FeatureData(out["action"]), next_action=rlt.FeatureData(out["next_action"]), reward=out["reward"],
+            not_terminal=out["not_terminal"], step=None, time_diff=None,
+            extras=rlt.ExtraData(mdp_id=None, sequence_number=None, action_probability=out["action_probability"],
+                                 max_num_actions=None, metrics=None))
+
     def get_transition_elements(self):
         extra_names = []
         for name in self._extra_keys:

@@ -480,7 +480,14 @@ class OfflinePolicyLoop(_GraphedLoop):
         if state_preprocessor is not None and not state_preprocessor.elementwise:
             raise NotImplementedError("normalize-on-gather needs a 1:1 column table")
 
+    fused_sampler = True  # rg_replay_policy_batch (one launch) where the store has the shape it serves
+
     def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.PolicyNetworkInput:
+        if self.fused_sampler and hasattr(self.rb, "sample_policy_input"):
+            batch = self.rb.sample_policy_input(self.maker, self.batch_size, indices=indices, state_preprocessor=self.pre,
+                                                state_dtype=self.state_dtype)
+            if batch is not None:
+                return batch
         tup = self.rb.sample_transition_batch(self.batch_size, indices=indices, state_preprocessor=self.pre,
                                               state_dtype=self.state_dtype)
         return self.maker(tup)

@@ -295,8 +295,9 @@ def test_two_ranks_under_torchrun_print_one_compact_line(tmp_path):
            "--warmup", "1", "--repeats", "2", "--sustained-steps", "2", "--report", str(report)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]  # (gloo's own connection banner)
-    assert len(out) == 1, out  # one line in all: rank 1 printed nothing
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    out = [l for l in lines if not l.startswith("[")]  # (library banners such as gloo's "[Gloo] Rank 0 is connected ..." aside)
+    assert len(out) == 1 and out[0].startswith("{") and lines[-1] == out[0], lines  # one line in all, the last: rank 1 printed nothing
     assert len(out[0].encode()) < 4096
     line = json.loads(out[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["parallelism"] == "dp2"

@@ -395,6 +395,65 @@ def test_fused_dqn_input_equals_sample_then_maker(backend, horizon, with_mask, n
     assert (fused.not_terminal == 0).any() and (fused.not_terminal == 1).any()
 
 
+def _policy_buffer(device, horizon, n=90, cap=96, F=8, A=3, seed=21):
+    rb = ReplayBuffer(device=device, stack_size=1, replay_capacity=cap, batch_size=16, update_horizon=horizon, gamma=0.9)
+    rng = np.random.RandomState(seed)
+    for i in range(n):
+        rb.add(observation=rng.randn(F).astype(np.float32), action=(rng.rand(A) * 4 - 2).astype(np.float32),
+               reward=np.float32(rng.rand()), terminal=bool(rng.rand() < 0.2), log_prob=np.float32(-rng.rand()))
+    return rb
+
+
+@pytest.mark.parametrize("horizon,normalize,dtype", [(1, False, torch.float32), (3, True, torch.float32), (3, True, torch.bfloat16),
+                                                      (2, False, torch.float32)])
+def test_fused_policy_input_equals_sample_then_maker(backend, horizon, normalize, dtype):
+    """rg_replay_policy_batch (ABI 11) == rg_replay_nstep + rg_replay_gather (+ normalize-on-gather) + rg_make_policy_input, bit
+    for bit, on every field of the PolicyNetworkInput (n-step windows crossing terminals, per-dimension action ranges)"""
+    from reagent_amd.core.parameters import NormalizationParameters as NP
+    from reagent_amd.preprocessing import PolicyNetworkInputMaker, Preprocessor
+
+    dev, F, A = backend.device, 8, 3
+    rb = _policy_buffer(dev, horizon, F=F, A=A)
+    pre = None
+    if normalize:
+        pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=0.1 * i, stddev=1.0 + 0.1 * i) for i in range(F)}, device=dev)
+    maker = PolicyNetworkInputMaker(np.array([-2.0, -1.5, -3.0], dtype=np.float32), np.array([2.0, 2.5, 1.0], dtype=np.float32))
+    idx = rb.sample_index_batch(70)
+    fused = rb.sample_policy_input(maker, 70, indices=idx, state_preprocessor=pre, state_dtype=dtype)
+    assert fused is not None
+    ref = maker(rb.sample_transition_batch(70, indices=idx, state_preprocessor=pre, state_dtype=dtype if pre is not None else None))
+    assert fused.state.float_features.dtype == dtype
+    for name in ("state", "next_state", "action", "next_action"):
+        assert torch.equal(getattr(fused, name).float_features, getattr(ref, name).float_features), name
+    for name in ("reward", "not_terminal"):
+        assert getattr(fused, name).shape == getattr(ref, name).shape and torch.equal(getattr(fused, name), getattr(ref, name)), name
+    assert torch.equal(fused.extras.action_probability, ref.extras.action_probability)
+    assert fused.step is None and fused.time_diff is None
+    assert (fused.not_terminal == 0).any() and (fused.not_terminal == 1).any()
+    assert (fused.next_action.float_features[fused.not_terminal.reshape(-1) == 0] == 0).all()
+
+
+def test_fused_policy_input_declines_other_stores(backend):
+    from reagent_amd.preprocessing import PolicyNetworkInputMaker
+    from reagent_amd.runtime import OfflinePolicyLoop
+
+    maker = PolicyNetworkInputMaker(np.full(2, -1.0, np.float32), np.full(2, 1.0, np.float32))
+    rb = ReplayBuffer(device=backend.device, stack_size=2, replay_capacity=20, batch_size=4)
+    for i in range(10):
+        rb.add(observation=np.zeros(8, np.float32), action=np.zeros(2, np.float32), reward=np.float32(0), terminal=False,
+               log_prob=np.float32(0))
+    assert rb.sample_policy_input(maker, 4) is None  # stacked frames
+    rb = ReplayBuffer(device=backend.device, stack_size=1, replay_capacity=20, batch_size=4)
+    for i in range(10):
+        rb.add(observation=np.zeros(6, np.float32), action=np.zeros(2, np.float32), reward=np.float32(i), terminal=False,
+               log_prob=np.float32(0))
+    assert rb.sample_policy_input(maker, 4) is None  # 6 features: not a multiple of 4
+    # the loop then takes the three-launch path, same batch type
+    loop = OfflinePolicyLoop(rb, trainer=None, batch_size=4, input_maker=maker)
+    b = loop.make_batch(rb.sample_index_batch(4))
+    assert b.state.float_features.shape == (4, 6) and b.action.float_features.shape == (4, 2)
+
+
 def test_fused_dqn_input_declines_other_stores(backend):
     rb = ReplayBuffer(device=backend.device, stack_size=2, replay_capacity=20, batch_size=4)
     for i in range(10):
