@@ -480,7 +480,8 @@ class OfflinePolicyLoop(_GraphedLoop):
         if state_preprocessor is not None and not state_preprocessor.elementwise:
             raise NotImplementedError("normalize-on-gather needs a 1:1 column table")
 
-    fused_sampler = True  # rg_replay_policy_batch (one launch) where the store has the shape it serves
+    # rg_replay_policy_batch (one launch) where the store has the shape it serves; RG_POLICY_SAMPLER=0: the three-launch path (A/B)
+    fused_sampler = os.environ.get("RG_POLICY_SAMPLER", "1") != "0"
 
     def make_batch(self, indices: Optional[torch.Tensor] = None) -> rlt.PolicyNetworkInput:
         if self.fused_sampler and hasattr(self.rb, "sample_policy_input"):
