@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) feed(const unsigned short* __r
   unsigned short* act = (unsigned short*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (blockIdx.x == 0 && tid == 0) g_clock[0] = __builtin_amdgcn_s_memtime();
-  for (int i = tid; i < TM * 32 * PITCH + ((MODE & 64) ? NWAVES * 3 * TN * 512 : 0); i += NWAVES * 64)
+  for (int i = tid; i < TM * 32 * PITCH + ((MODE & 64) ? NWAVES * TN * 512 : 0); i += NWAVES * 64)
     act[i] = (unsigned short)(0x3c00 + ((i * 2654435761u) >> 20));
   __syncthreads();
   const int lr = lane & 31, lg = lane >> 5;
@@ -48,11 +48,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) feed(const unsigned short* __r
   // MODE bit 6 (round 6): the B fragments come out of LDS (a per-wave region behind the activation tile, 3 chunk slots of
   // TN KB — what the 27 KB the product kernel's tile leaves free would hold) instead of L2: the UPPER bound of any scheme that
   // stages the weight stream through LDS (an LDS-DMA ring: VERDICT r5 item 5) — no global traffic at all here
-  const unsigned short* bl = act + TM * 32 * PITCH + wave * (3 * TN * 512);
+  const unsigned short* bl = act + TM * 32 * PITCH + wave * (TN * 512);
   auto loadB = [&](int s, int kc) {
     if (MODE & 64) {
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[s][tn] = *(const u16x8*)(bl + ((kc % 3) * TN + tn) * 512 + lane * 8);
+      for (int tn = 0; tn < TN; ++tn) b[s][tn] = *(const u16x8*)(bl + tn * 512 + lane * 8);
       return;
     }
     const unsigned short* chunk = wf_wave + (long)kx(kc) * 512;
@@ -171,7 +171,7 @@ int main() {
   run<3, 8, 4, 2, 2>("A from LDS + B from L2 ring 2", wf, out, 512, lds128);
   run<18, 8, 4, 2, 2>("B from L2 ring 2, tn-major", wf, out, 512, lds128);
   // round 6: the bound of an LDS-staged weight stream — both operands from LDS, no L2 traffic (6 fragment reads per 8 MFMAs)
-  const int ldsB = lds128 + 8 * 3 * 2 * 512 * 2;
+  const int ldsB = lds128 + 8 * 1 * 2 * 512 * 2;
   run<67, 8, 4, 2, 2>("A from LDS + B from LDS (bound of an LDS-DMA weight ring)", wf, out, 512, ldsB);
   run<66, 8, 4, 2, 2>("B from LDS only", wf, out, 512, ldsB);
   run<3, 8, 4, 2, 2>("A from LDS + B from L2 ring 2 (again, same clock state)", wf, out, 512, lds128);

@@ -693,6 +693,49 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
   });
 }
 
+// RG_ACC_AGPR form of the hidden layer's epilogue (round 6): the accumulators live in AccVGPRs, which nothing else wants, so they
+// may simply WAIT for the barrier that protects the in-place tile — PACK and the LDS store then run tile by tile AFTER it, a
+// tile's eight packed words alive for a few instructions instead of all 64 (x TN) across the barrier.  That is what lets the
+// 512-wide kernel live in the 128 arch registers AccVGPR accumulators leave it (round 3's attempt kept the two-phase epilogue
+// and spilled 20 values).  Same values, same stores as fwd_hidden_pack + store_packed_tiles.
+template <int TN, int ACT>
+__device__ __forceinline__ void fwd_hidden_pack_store(f32x16 (&acc)[4][TN], const float* bias, bf16_t* save_dst, unsigned* sign_dst,
+                                                      int NT, int mb_base, int wave, int lane, bf16_t* act, int pitch) {
+  lane = opaque(lane);
+  const int lr = lane & 31;
+  unsigned sg_prev0 = 0u, sg_prev1 = 0u;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    const int nt = wave * TN + tn, col = nt * 32 + lr;
+    const float b = bias ? bias[col] : 0.f;
+    unsigned sg0 = 0u, sg1 = 0u;
+    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      float v[16];
+      unsigned P[8];
+      RG_TILE_FENCE();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
+      pack_tile(v, P);
+      if (save_dst) store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, P);
+      if (act_is_sign_based<ACT>() && sign_dst) {
+        const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
+        if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
+        else sg1 |= bits << ((tm & 1) * 16);
+      }
+      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
+    });
+    if (act_is_sign_based<ACT>() && sign_dst) {
+      if constexpr (TN == 2 && RG_SIGN_STORE16) {
+        if constexpr (tn == 0) { sg_prev0 = sg0; sg_prev1 = sg1; }
+        else *(u32x4*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)) = u32x4{sg_prev0, sg_prev1, sg0, sg1};
+      } else {
+        ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
+      }
+    }
+  });
+}
+
 // Non-saving forward with transposed accumulator tiles (wide_mainloop<.., SWAP>): a lane holds ONE batch row and 16 features
 // of a tile in four runs of four consecutive ones, so the bf16 pairs are column neighbours already and the LDS tile takes
 // them as 8-byte writes — no neighbour swap (DPP + v_perm per pair) and half the LDS write instructions of the
@@ -780,6 +823,50 @@ __device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16
       if (STORE_DZ) store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
       else pin_packed(PK[tm][tn]);  // the stores force the bf16 packing here; without them the compiler keeps all
                                     // eight tiles in fp32 until the LDS pass after the barrier and spills 497 registers
+    });
+    colsum += shfl_xor(colsum, 32);
+    if (db_part && lane < 32) db_part[col] = colsum;
+  });
+}
+
+// RG_ACC_AGPR form of the backward epilogue (see fwd_hidden_pack_store): after the barrier, tile by tile, straight into the dZ tile
+template <int TN, int ACT, bool USE_SIGN, bool STORE_DZ = true>
+__device__ __forceinline__ void bwd_hidden_pack_store(f32x16 (&acc)[4][TN], const bf16_t* h_frag, const unsigned (&sg)[2 * TN],
+                                                      bf16_t* dz_dst, float* db_part, int NT, int mb_base, int wave, int lane,
+                                                      bf16_t* act, int pitch) {
+  lane = opaque(lane);
+  const int lr = lane & 31;
+  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
+    constexpr int tn = decltype(tn_c)::value;
+    const int nt = wave * TN + tn, col = nt * 32 + lr;
+    float colsum = 0.f;
+    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
+      constexpr int tm = decltype(tm_c)::value;
+      float v[16];
+      unsigned P[8];
+      RG_TILE_FENCE();
+      if (USE_SIGN && act_is_sign_based<ACT>()) {
+        const unsigned bits = sg[tn * 2 + (tm >> 1)] >> ((tm & 1) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float g = ((bits >> r) & 1u) ? 1.f : (ACT == ACT_RELU ? 0.f : 0.01f);
+          v[r] = acc[tm][tn][r] * g;
+          colsum += v[r];
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u16x8 hf = *(const u16x8*)(h_frag + frag_offset(mb_base + tm, nt, NT, h, lane));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_t<ACT>(bf16_to_f32(hf[e]));
+            colsum += v[8 * h + e];
+          }
+        }
+      }
+      pack_tile(v, P);
+      if (STORE_DZ) store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, P);
+      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
     });
     colsum += shfl_xor(colsum, 32);
     if (db_part && lane < 32) db_part[col] = colsum;
