@@ -97,6 +97,7 @@ def main():
         put("rg_mlp_forward_fused:all", fwd[:1])
         put("rg_mlp_wgrad_fused:all", ["wgrad_group_kernel", reduce_k])
         put("rg_replay_gather", first("replay_gather_kernel"))
+        put("rg_replay_policy_batch", first("replay_policy_batch_kernel"))  # round 6: the one-launch sampler
         put("rg_mlp_update_fused:all", first("mlp_update_tiles_kernel"))
     # every rg:: kernel of the run, averaged over its launches (evidence; the keys above are what bench.py looks up)
     per_kernel = {}
