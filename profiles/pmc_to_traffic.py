@@ -43,6 +43,8 @@ def main():
 
     def put(key, names, select=lambda i, n: True):
         total_f = total_w = 0.0
+        if not names:  # the kernel is not in this run (e.g. the three-launch sampler once the one-launch form serves the store)
+            return
         for nm in names:
             fs = [v for i, v in enumerate(fetch.get(nm, [])) if select(i, len(fetch[nm]))]
             wsz = [v for i, v in enumerate(write.get(nm, [])) if select(i, len(write[nm]))]
