@@ -795,6 +795,11 @@ int rg_adam_step_f64_sched(double* param, const double* grad, double* exp_avg, d
                            double beta1, double beta2, double eps, const double* sched,
                            double* exp_param_out, rg_stream_t stream);
 int rg_sched_tick(double* sched, rg_stream_t stream);
+/* ABI 11: the ticks of up to RG_MAX_TICKS DISTINCT schedules in one launch (a SAC step updates four optimizers — three networks and
+ * the temperature — each with its own schedule: one launch at the end of the step instead of four between its segments).
+ * `scheds` is a host array of n device pointers. */
+#define RG_MAX_TICKS 8
+int rg_sched_tick_many(double* const* scheds, int n, rg_stream_t stream);
 
 /* SoftUpdate.step, reagent/optimizer/soft_update.py:60-70: tgt = tau*src + (1-tau)*tgt */
 int rg_soft_update(float* target, const float* source, int64_t n, double tau, rg_stream_t stream);

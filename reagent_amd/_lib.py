@@ -282,6 +282,7 @@ SIGNATURES = {
     "rg_adam_step_f64_sched": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_d, c_d, c_d, c_void_p,
                                         c_void_p, c_void_p]),
     "rg_sched_tick": (c_int, [c_void_p, c_void_p]),
+    "rg_sched_tick_many": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p]),
 }
 
 _lib = None

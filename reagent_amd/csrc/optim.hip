@@ -19,6 +19,14 @@ __global__ void sched_tick_kernel(double* sched) {
   if (blockIdx.x == 0 && threadIdx.x == 0) sched[0] = sched[0] + 1.0;
 }
 
+struct TickMany {
+  double* s[RG_MAX_TICKS];
+};
+__global__ void sched_tick_many_kernel(TickMany t, int n) {
+  const int i = threadIdx.x;
+  if (blockIdx.x == 0 && i < n) t.s[i][0] = t.s[i][0] + 1.0;
+}
+
 __global__ void soft_update_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float tau,
                                    float one_minus_tau) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -70,6 +78,20 @@ int rg_adam_step_sched(float* param, const float* grad, float* exp_avg, float* e
 int rg_sched_tick(double* sched, rg_stream_t stream) {
   if (!sched) return RG_EINVAL;
   RG_LAUNCH(sched_tick_kernel, dim3(1), dim3(64), (hipStream_t)stream, sched);
+  return (int)hipGetLastError();
+}
+
+int rg_sched_tick_many(double* const* scheds, int n, rg_stream_t stream) {
+  if (!scheds || n < 0 || n > RG_MAX_TICKS) return RG_EINVAL;
+  if (n == 0) return RG_OK;
+  TickMany t;
+  for (int i = 0; i < RG_MAX_TICKS; ++i) {
+    t.s[i] = scheds[i < n ? i : 0];
+    if (i < n && !scheds[i]) return RG_EINVAL;
+    for (int j = 0; j < i && i < n; ++j)
+      if (scheds[j] == scheds[i]) return RG_EINVAL;  // one tick per schedule and launch
+  }
+  RG_LAUNCH(sched_tick_many_kernel, dim3(1), dim3(64), (hipStream_t)stream, t, n);
   return (int)hipGetLastError();
 }
 

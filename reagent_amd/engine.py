@@ -755,6 +755,7 @@ class FusedUpdate:
             if not capturing():
                 sched.set_lr(group["lr"])
                 sched.pending += 1
+            ops.tick_fence(sched.buf)
             ops._run("rg_mlp_update_fused", dict(P=slab.total),
                      lambda: L.lib().rg_mlp_update_fused_sched(d, beta1, beta2, group["eps"], group["weight_decay"],
                                                                grad_scale, tau, sched.buf.data_ptr(), L.stream_ptr()))

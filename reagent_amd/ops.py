@@ -600,6 +600,7 @@ def adam_step_sched(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weig
                     offset=0):
     """rg_adam_step with lr and the bias corrections read from the device schedule `sched` (graph-safe)."""
     _chk_dev(param, grad, exp_avg, exp_avg_sq, sched)
+    tick_fence(sched)
     o = offset * 4
     _run("rg_adam_step", dict(n=n),
          lambda: L.lib().rg_adam_step_sched(param.data_ptr() + o, grad.data_ptr() + o, exp_avg.data_ptr() + o,
@@ -607,8 +608,52 @@ def adam_step_sched(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weig
                                             grad_scale, sched.data_ptr(), L.stream_ptr()))
 
 
+# ---- schedule ticks of a native step in ONE launch ---------------------------------------------------------
+# A device-scheduled update is followed by the tick of ITS schedule (sched[0] += 1).  Nothing reads a schedule again before that
+# optimizer's next step, so inside `deferred_ticks()` (the trainers' native steps, dqn_trainer.native_step) the ticks are collected
+# and leave as one rg_sched_tick_many launch when the scope closes: SAC's four launch-bound ticks (15 us per step) become one.
+# `tick_fence(sched)` — called by every launch that READS a schedule — flushes first if that schedule has a tick waiting.
+MAX_TICKS = 8
+_tick_scopes = []
+
+
+def _flush_ticks(pending):
+    if not pending:
+        return
+    if len(pending) == 1:
+        s = pending[0]
+        _run("rg_sched_tick", {}, lambda: L.lib().rg_sched_tick(s.data_ptr(), L.stream_ptr()))
+    else:
+        arr = (ctypes.c_void_p * len(pending))(*[s.data_ptr() for s in pending])
+        _run("rg_sched_tick", dict(n=len(pending)), lambda: L.lib().rg_sched_tick_many(arr, len(pending), L.stream_ptr()))
+    del pending[:]
+
+
+class deferred_ticks:
+    def __enter__(self):
+        _tick_scopes.append([])
+        return self
+
+    def __exit__(self, *exc):
+        _flush_ticks(_tick_scopes.pop())
+        return False
+
+
+def tick_fence(sched):
+    """before a launch that reads `sched`: its waiting tick (if any) must have been enqueued"""
+    for pending in _tick_scopes:
+        if any(s.data_ptr() == sched.data_ptr() for s in pending):
+            _flush_ticks(pending)
+
+
 def sched_tick(sched):
     _chk_dev(sched)
+    if _tick_scopes:
+        pending = _tick_scopes[-1]
+        if any(s.data_ptr() == sched.data_ptr() for s in pending) or len(pending) == MAX_TICKS:
+            _flush_ticks(pending)
+        pending.append(sched)
+        return
     _run("rg_sched_tick", {}, lambda: L.lib().rg_sched_tick(sched.data_ptr(), L.stream_ptr()))
 
 
@@ -704,6 +749,7 @@ def adam_step_f64(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, bc1, 
 
 def adam_step_f64_sched(param, grad, exp_avg, exp_avg_sq, beta1, beta2, eps, sched, exp_out=None):
     _chk_dev(param, grad, exp_avg, exp_avg_sq, exp_out, sched)
+    tick_fence(sched)
     _run("rg_adam_step_f64", dict(n=param.numel()),
          lambda: L.lib().rg_adam_step_f64_sched(L.ptr(param), L.ptr(grad), L.ptr(exp_avg), L.ptr(exp_avg_sq),
                                                 param.numel(), beta1, beta2, eps, sched.data_ptr(), L.ptr(exp_out),

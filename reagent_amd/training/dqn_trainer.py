@@ -164,7 +164,8 @@ def native_step(fn):
 
     @functools.wraps(fn)
     def wrapper(self, *a, **k):
-        with _NativeStep(self):
+        # (ops.deferred_ticks: the schedule ticks of the step's device-scheduled updates leave as ONE launch at its end)
+        with _NativeStep(self), ops.deferred_ticks():
             return fn(self, *a, **k)
 
     return wrapper
@@ -656,6 +657,7 @@ class QStepCore(DQNTrainerBaseLightning):
             if gt is not None:  # the step's sampler launch has counted it; this launch advances the index cursor
                 assert gt["sched"] is sched.buf
                 d.sched_pre_ticked, d.post_tick_mod, d.post_tick = 1, int(gt["mod"]), gt["cursor"].data_ptr()
+            ops.tick_fence(sched.buf)
             ops._run("rg_mlp_update_fused", dict(P=slab.total),
                      lambda: L.lib().rg_mlp_update_fused_sched(d, beta1, beta2, group["eps"], group["weight_decay"],
                                                                1.0 / self._dp_world, tau, sched.buf.data_ptr(),

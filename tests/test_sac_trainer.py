@@ -340,3 +340,37 @@ def test_per_step_metrics_match_the_reference(backend, name):
     logged.clear()
     lightning_like_step(tr, opts, batch)
     assert not logged
+
+
+def test_device_scheduled_step_ticks_its_schedules_in_one_launch(backend, monkeypatch):
+    """The four optimizers of a SAC step (q1, q2, actor, temperature) each count their Adam steps in a device-resident schedule
+    (graph mode).  Their ticks leave as ONE rg_sched_tick_many launch at the end of the native step (ops.deferred_ticks) — and the
+    scheduled steps stay bit-identical to the scalar-coefficient steps."""
+    from reagent_amd import ops
+    from reagent_amd.training.dqn_trainer import enable_graph_mode
+
+    g = Golden("sac_twin")
+    res = {}
+    for sched in (False, True):
+        tr = build(g, backend.device)
+        if sched:
+            enable_graph_mode(tr)
+        launches = []
+        real_run = ops._run
+
+        def counting_run(name, meta, call):
+            launches.append((name, dict(meta)))
+            return real_run(name, meta, call)
+
+        monkeypatch.setattr(ops, "_run", counting_run)
+        for s in range(g.cfg["steps"]):
+            batch = synthetic.to_policy_input(g.batch(s), backend.device)
+            del launches[:]
+            tr.train_step_native(batch, g.t(f"step{s}_noise_next").to(backend.device), g.t(f"step{s}_noise_cur").to(backend.device))
+            ticks = [m for n, m in launches if n == "rg_sched_tick"]
+            assert ticks == ([{"n": 4}] if sched else []), ticks
+            assert launches[-1][0] == ("rg_sched_tick" if sched else launches[-1][0])  # the last launch of the step
+        monkeypatch.setattr(ops, "_run", real_run)
+        res[sched] = [p.detach().cpu().clone() for p in tr.parameters()] + [tr.log_alpha.detach().cpu().clone()]
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
