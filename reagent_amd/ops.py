@@ -6,6 +6,7 @@ the stream the kernels are enqueued on (bench.py's per-kernel roofline numbers c
 """
 import contextlib
 import ctypes
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -615,6 +616,7 @@ def adam_step_sched(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weig
 # `tick_fence(sched)` — called by every launch that READS a schedule — flushes first if that schedule has a tick waiting.
 MAX_TICKS = 8
 _tick_scopes = []
+_DEFER_TICKS = os.environ.get("RG_DEFER_TICKS", "1") != "0"  # 0: a tick launch per schedule, where it was (same-box A/B)
 
 
 def _flush_ticks(pending):
@@ -648,7 +650,7 @@ def tick_fence(sched):
 
 def sched_tick(sched):
     _chk_dev(sched)
-    if _tick_scopes:
+    if _tick_scopes and _DEFER_TICKS:
         pending = _tick_scopes[-1]
         if any(s.data_ptr() == sched.data_ptr() for s in pending) or len(pending) == MAX_TICKS:
             _flush_ticks(pending)
