@@ -258,3 +258,32 @@ def test_union_members_take_the_reference_field_lists():
     assert isinstance(Odd().make_optimizer_scheduler(p)["optimizer"], torch.optim.SGD)  # at its default: dropped
     with pytest.raises(TypeError, match="not_a_torch_argument"):
         Odd(not_a_torch_argument=True).make_optimizer_scheduler(p)
+
+
+def test_sched_tick_many_ticks_each_schedule_once(backend):
+    """rg_sched_tick_many (ABI 11): n distinct device schedules, [0] += 1 each, one launch; a repeated schedule or n > 8 is refused;
+    ops.deferred_ticks collects a scope's ticks, flushes before a second tick of the same schedule and at 8"""
+    import ctypes
+
+    import reagent_amd._lib as L
+    from reagent_amd import ops
+
+    dev = backend.device
+    sch = [torch.tensor([float(i), 1e-3, 0.0, 0.0], dtype=torch.float64, device=dev) for i in range(10)]
+    lib = L.lib()
+    arr = (ctypes.c_void_p * 3)(*[s.data_ptr() for s in sch[:3]])
+    assert lib.rg_sched_tick_many(arr, 3, L.stream_ptr()) == 0
+    assert [float(s[0]) for s in sch[:4]] == [1.0, 2.0, 3.0, 3.0]
+    dup = (ctypes.c_void_p * 2)(sch[0].data_ptr(), sch[0].data_ptr())
+    assert lib.rg_sched_tick_many(dup, 2, L.stream_ptr()) == -1  # RG_EINVAL
+    nine = (ctypes.c_void_p * 9)(*[s.data_ptr() for s in sch[:9]])
+    assert lib.rg_sched_tick_many(nine, 9, L.stream_ptr()) == -1 and lib.rg_sched_tick_many(nine, 0, L.stream_ptr()) == 0
+    with ops.deferred_ticks():
+        for s in sch:          # ten schedules: eight leave when the ninth arrives, two at the end of the scope
+            ops.sched_tick(s)
+        assert float(sch[9][0]) == 9.0 and float(sch[0][0]) == 2.0  # 0..7 already ticked, 8 and 9 still waiting
+        ops.sched_tick(sch[9])  # a second tick of a waiting schedule flushes first
+        ops.tick_fence(sch[9])  # ... and a reader of it sees both
+        assert float(sch[9][0]) == 11.0 and float(sch[8][0]) == 9.0
+    ops.sched_tick(sch[0])  # outside a scope: at once
+    assert float(sch[0][0]) == 3.0
