@@ -1,0 +1,40 @@
+import sys, random
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+import numpy as np, torch
+import emu_backend
+emu_backend.install()
+from reagent_amd.core.parameters import NormalizationParameters as NP
+from reagent_amd.preprocessing import PolicyNetworkInputMaker, Preprocessor
+from reagent_amd.replay_memory import ReplayBuffer
+
+# rg_replay_policy_batch (ABI 11) against rg_replay_nstep + rg_replay_gather + rg_make_policy_input on random stores: widths, action
+# dimensions, horizons, wrapped circular buffers, batch sizes around the 64-row workgroup, per-dimension action ranges, normalization
+random.seed(11)
+bad = 0
+for case in range(24):
+    F = random.choice([4 * random.randint(1, 40), 4 * random.randint(1, 40), 8, 32, 64, 128, 256]); A = random.randint(1, 40); H = random.randint(1, 5)
+    cap = random.randint(H + 40, 300); n = random.randint(H + 5, cap + 80); B = random.choice([1, 5, 63, 64, 65, 130])
+    norm = random.random() < 0.6
+    dt = torch.bfloat16 if (norm and random.random() < 0.5) else torch.float32
+    rb = ReplayBuffer(device="cpu", stack_size=1, replay_capacity=cap, batch_size=B, update_horizon=H, gamma=0.93)
+    rng = np.random.RandomState(case)
+    for i in range(n):
+        rb.add(observation=rng.randn(F).astype(np.float32), action=(rng.rand(A) * 6 - 3).astype(np.float32), reward=np.float32(rng.rand()),
+               terminal=bool(rng.rand() < 0.15), log_prob=np.float32(-rng.rand()))
+    if rb.size == 0: continue
+    pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=0.1 * (i % 5), stddev=1.0 + 0.1 * (i % 3)) for i in range(F)}, device="cpu") if norm else None
+    lo = (-3 + rng.rand(A)).astype(np.float32); hi = (2 + rng.rand(A)).astype(np.float32)
+    maker = PolicyNetworkInputMaker(lo, hi) if random.random() < 0.7 else PolicyNetworkInputMaker(np.float32(-3.0), np.float32(3.0))
+    idx = rb.sample_index_batch(B)
+    fused = rb.sample_policy_input(maker, B, indices=idx, state_preprocessor=pre, state_dtype=dt if norm else None)
+    ref = maker(rb.sample_transition_batch(B, indices=idx, state_preprocessor=pre, state_dtype=dt if norm else None))
+    ok = fused is not None
+    if ok:
+        for name in ("state", "next_state", "action", "next_action"):
+            ok = ok and torch.equal(getattr(fused, name).float_features, getattr(ref, name).float_features)
+        for name in ("reward", "not_terminal"):
+            ok = ok and getattr(fused, name).shape == getattr(ref, name).shape and torch.equal(getattr(fused, name), getattr(ref, name))
+        ok = ok and torch.equal(fused.extras.action_probability, ref.extras.action_probability)
+    bad += not ok
+    print("OK " if ok else "BAD", dict(F=F, A=A, H=H, cap=cap, n=n, B=B, norm=norm, dt=str(dt)))
+print("bad cases:", bad)
