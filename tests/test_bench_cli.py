@@ -296,8 +296,9 @@ def test_two_ranks_under_torchrun_print_one_compact_line(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
-    out = [l for l in lines if not l.startswith("[")]  # (library banners such as gloo's "[Gloo] Rank 0 is connected ..." aside)
-    assert len(out) == 1 and out[0].startswith("{") and lines[-1] == out[0], lines  # one line in all, the last: rank 1 printed nothing
+    out = [l for l in lines if l.startswith("{")]  # (library banners such as gloo's "[Gloo] Rank 0 is connected ..." aside)
+    assert len(out) == 1 and lines[-1] == out[0], lines  # ONE JSON line in all, the last line of the job: rank 1 printed none
+    assert sum('"metric"' in l for l in lines) == 1, lines
     assert len(out[0].encode()) < 4096
     line = json.loads(out[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["config"]["parallelism"] == "dp2"
