@@ -13,4 +13,5 @@ $HIPCC -DCH_KK=2 -DCH_NSLOT=9 chain_fwd.hip -o chain_fwd_k2s9
 $HIPCC -DCH_PF=4 chain_fwd.hip -o chain_fwd_k4s4p4
 
 $HIPCC x3_phases.hip -o x3_phases
+$HIPCC bwd_phases.hip -o bwd_phases
 ls -la mfma_peak mfma_feed fwd_phases wgrad_phases x3_phases chain_fwd*

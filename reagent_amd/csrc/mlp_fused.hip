@@ -451,8 +451,10 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
   constexpr int pitch = PITCH;
   const int L = a.n_layers;
   const int nop = round_up(a.dims[L], 32);
+  RG_BSTAMP(0);
   load_tile_to_lds<float, THREADS>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
+  RG_BSTAMP(1);
   if (!GROUPED) {
     if (!DX_ONLY) emit_frags_from_lds(act, pitch, nop / 32, a.dz_frag[L - 1], tile * 4, wave, NW, lane);
     if (a.db_part[L - 1] && tid < a.dims[L]) {
@@ -461,6 +463,7 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
       a.db_part[L - 1][(long)tile * a.dims[L] + tid] = s;
     }
   }
+  RG_BSTAMP(2);
 
   for (int l = L - 1; l >= 1; --l) {
     // dH = dZ_l (LDS, width dims[l+1]) . W_l -> [128, dims[l]] ; dZ_{l-1} = dH * act'(H_l)
@@ -532,6 +535,7 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
       }
     }
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)tile * N : nullptr;
+    RG_BSTAMP(3 + 4 * (L - 1 - l));
 #ifdef RG_ACC_AGPR
     __syncthreads();  // every wave is done reading dZ_l; the accumulators (AccVGPRs) waited for it
     if (use_sign) {
@@ -550,10 +554,13 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
       RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, false, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
                                                                               N / 32, tile * 4, wave, lane, PK)));
     }
+    RG_BSTAMP(4 + 4 * (L - 1 - l));
     __syncthreads();  // every wave is done reading dZ_l
+    RG_BSTAMP(5 + 4 * (L - 1 - l));
     store_packed_tiles<TN>(act, pitch, PK, wave, lane);
 #endif
     __syncthreads();
+    RG_BSTAMP(6 + 4 * (L - 1 - l));
   }
   if (a.dx32) {  // gradient w.r.t. the network input (e.g. the critic's action input in SAC)
     const int K = a.dims[1], N = a.dims[0];

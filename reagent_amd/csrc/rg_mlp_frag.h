@@ -12,6 +12,9 @@
 #ifndef RG_STAMP
 #define RG_STAMP(slot)
 #endif
+#ifndef RG_BSTAMP  // the backward kernel's hooks (profiles/microbench/bwd_phases.hip)
+#define RG_BSTAMP(slot)
+#endif
 #ifndef RG_PHASE_INIT  // accumulating variant for loops (profiles/microbench/wgrad_phases.hip)
 #define RG_PHASE_INIT()
 #define RG_PHASE(i)
