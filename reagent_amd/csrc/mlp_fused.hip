@@ -31,6 +31,9 @@
 #ifndef RG_OUT_LDS
 #define RG_OUT_LDS 1  // a thin output layer's weight fragments resident in LDS (tile_kloop_ldsb)
 #endif
+#ifndef RG_BWD_SIGNS_EARLY
+#define RG_BWD_SIGNS_EARLY 1  // backward: the first step's sign planes are requested before the dout tile (0 = before its main loop)
+#endif
 #ifndef RG_GROUPED_STAGE_OUT
 #define RG_GROUPED_STAGE_OUT 1  // a wide grouped output leaves through the (dead) activation tile as whole rows
 #endif
@@ -452,6 +455,34 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
   const int L = a.n_layers;
   const int nop = round_up(a.dims[L], 32);
   RG_BSTAMP(0);
+  // The sign bits of H_l are requested ahead of step l's main loop so that its epilogue finds them in registers.  The FIRST
+  // step's main loop is one or two K chunks long (K = the output width), too short to cover their HBM round trip
+  // (bwd_phases: its pack 7.9k cycles against 6.1-6.8k for the other steps), so its request leaves before the dout tile's.
+  auto request_signs = [&](int l, unsigned (&sg)[2 * TN]) {
+    if (a.act_sign[l] != nullptr) {
+      const u32x2* sp = (const u32x2*)(a.act_sign[l] + sign_offset(tile, wave, lane, TN, a.dims[l]));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const u32x2 t = sp[i];
+        sg[2 * i] = t[0];
+        sg[2 * i + 1] = t[1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2 * TN; ++i) sg[i] = 0u;
+    }
+  };
+  unsigned sg_first[2 * TN];
+  if (RG_BWD_SIGNS_EARLY && L >= 2) request_signs(L - 1, sg_first);
+  // ... and when that step's K is ONE chunk (<= 16 outputs: Q-values, a critic's scalar) so do its weight fragments: the step is
+  // then four LDS reads and 4 x TN MFMAs instead of an L2 round trip behind the tile's barrier (bwd_phases: 2.7k cycles).
+  const bool first_one_chunk = RG_BWD_SIGNS_EARLY && !GROUPED && L >= 2 && a.dims[L] <= 16;
+  u16x8 w_first[TN];
+  if (first_one_chunk) {
+    const bf16_t* wl = a.wfrag[L - 1] + (long)(wave * TN) * 512 + lane * 8;  // KC = 1: one 512-element record per n-tile
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) w_first[tn] = *(const u16x8*)(wl + tn * 512);
+  }
   load_tile_to_lds<float, THREADS>(act, pitch, a.dout32, a.lddo, row_base, a.batch, a.dims[L], nop, tid);
   __syncthreads();
   RG_BSTAMP(1);
@@ -480,17 +511,11 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
     // sign bits of H_l, requested before the main loop so they are in registers at the epilogue
     unsigned sg[2 * TN];
     const bool use_sign = a.act_sign[l] != nullptr;
-    if (use_sign) {
-      const u32x2* sp = (const u32x2*)(a.act_sign[l] + sign_offset(tile, wave, lane, TN, N));
+    if (RG_BWD_SIGNS_EARLY && l == L - 1) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const u32x2 t = sp[i];
-        sg[2 * i] = t[0];
-        sg[2 * i + 1] = t[1];
-      }
+      for (int i = 0; i < 2 * TN; ++i) sg[i] = sg_first[i];
     } else {
-#pragma unroll
-      for (int i = 0; i < 2 * TN; ++i) sg[i] = 0u;
+      request_signs(l, sg);
     }
     // The grouped layer's FIRST segment (the only one of a tile inside a group's range) goes through the main loop like a
     // plain layer's tile — one call site, no loop around it (the software-pipelined loop inside a loop over segments spilled
@@ -523,8 +548,20 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
       const bf16_t* src = act;
       if (grouped_layer) src = segment_side();
       const bf16_t* wl = a.wfrag[l] + (grouped_layer ? (long)seg.grp * a.group_stride : 0);  // the group's slice of W^T
-      wide_mainloop<TN, RING>(src, pitch, KC, wl + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
-                              k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+      if (first_one_chunk && l == L - 1) {
+        const bf16_t* arow = src + lr * pitch + lg * 8;
+        u16x8 af[4];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) af[tm] = *(const u16x8*)(arow + tm * 32 * pitch);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_main(af[tm], w_first[tn], acc[tm][tn]);
+        mfma_drain();
+      } else {
+        wide_mainloop<TN, RING>(src, pitch, KC, wl + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
+                                k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
+      }
     }
     if (grouped_layer) {
       while (more && next_segment(a.row_begin, a.n_groups, row_base, FB_BM, seg_g, seg)) {  // a boundary tile's other groups
