@@ -5,6 +5,7 @@ cd "$(dirname "$0")"
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../reagent_amd/csrc -I../../include -Wno-unused-value"
 $HIPCC mfma_peak.hip -o mfma_peak
 $HIPCC mfma_feed.hip -o mfma_feed
+$HIPCC mfma_feed_dma.hip -o mfma_feed_dma
 $HIPCC fwd_phases.hip -o fwd_phases
 $HIPCC wgrad_phases.hip -o wgrad_phases
 $HIPCC chain_fwd.hip -o chain_fwd

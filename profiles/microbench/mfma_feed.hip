@@ -97,6 +97,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) feed(const unsigned short* __r
       for (int s = 0; s < RING - 1; ++s) loadB(s, s);
     }
     if (MODE & 1) loadA(0, 0);
+    // NOT unrolled (round 6): KC is a compile-time constant here, and fully unrolled the compiler parked every chunk's weight
+    // address in VGPRs — modes 2 / 3 / 18 (B from L2, accumulators in arch VGPRs) compiled to 256 registers + 660-692 BYTES OF SCRATCH
+    // per lane, which is what rounds 2-6 quoted as "0.42-0.45 with B from L2" and as the AccVGPR variant's 19-22 % advantage (that
+    // variant fits without spills).  The product's K is a run-time value and its kernels have no scratch.
+#pragma unroll 1
     for (int kc = 0; kc < KC; kc += RING) {
 #pragma unroll
       for (int s = 0; s < RING; ++s) {
