@@ -197,17 +197,6 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
       wide_mainloop<TN, RING, SWAP>(act, pitch, KC, a.wfrag[l] + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
                                     k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
       RG_STAMP(2 + 4 * l);
-#ifdef RG_ACC_AGPR
-      // accumulators in AccVGPRs: they wait for the barrier, PACK + LDS store run after it tile by tile (fwd_hidden_pack_store)
-      RG_STAMP(3 + 4 * l);
-      __syncthreads();  // every wave is done reading the layer input
-      RG_STAMP(4 + 4 * l);
-      {
-        unsigned* sign_dst = a.save ? a.act_sign[l + 1] : nullptr;
-        RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack_store<TN, A_>(acc, a.bias[l], fwd_save_dst(a, l), sign_dst, N / 32, tile * 4,
-                                                                  wave, lane, act, pitch)));
-      }
-#else
       unsigned PK[4][TN][8];
       if constexpr (SWAP) {
         RG_DISPATCH_ACT(a.acts[l], (fwd_hidden_pack_swapped<TN, A_>(acc, a.bias[l], wave, lane, PK)));
@@ -221,7 +210,6 @@ __device__ __forceinline__ void mlp_fwd_fused_body(const MlpArgs& a) {
       RG_STAMP(4 + 4 * l);
       if constexpr (SWAP) store_packed_tiles_swapped<TN>(act, pitch, PK, wave, lane);
       else store_packed_tiles<TN>(act, pitch, PK, wave, lane);
-#endif
       if (out_lds) RG_WAIT_VMCNT(0);  // this wave's share of the output layer's weights has landed (long ago) ...
       __syncthreads();                // ... and after the barrier every wave's has
       RG_STAMP(5 + 4 * l);
@@ -557,7 +545,6 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_main(af[tm], w_first[tn], acc[tm][tn]);
-        mfma_drain();
       } else {
         wide_mainloop<TN, RING>(src, pitch, KC, wl + (long)(wave * TN) * nt_stride, nt_stride, acc, lane,
                                 k_rotation(blockIdx.x, wave, KC), wave / (NW / 2));
@@ -573,16 +560,6 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
     }
     float* dbp = a.db_part[l - 1] ? a.db_part[l - 1] + (long)tile * N : nullptr;
     RG_BSTAMP(3 + 4 * (L - 1 - l));
-#ifdef RG_ACC_AGPR
-    __syncthreads();  // every wave is done reading dZ_l; the accumulators (AccVGPRs) waited for it
-    if (use_sign) {
-      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack_store<TN, A_, true, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
-                                                                                   N / 32, tile * 4, wave, lane, act, pitch)));
-    } else {
-      RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack_store<TN, A_, false, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
-                                                                                    N / 32, tile * 4, wave, lane, act, pitch)));
-    }
-#else
     unsigned PK[4][TN][8];
     if (use_sign) {
       RG_DISPATCH_ACT(a.acts[l - 1], (bwd_hidden_pack<TN, A_, true, !DX_ONLY>(acc, a.act_frag[l], sg, a.dz_frag[l - 1], dbp,
@@ -595,7 +572,6 @@ __device__ __forceinline__ void mlp_bwd_fused_body(const MlpArgs& a) {
     __syncthreads();  // every wave is done reading dZ_l
     RG_BSTAMP(5 + 4 * (L - 1 - l));
     store_packed_tiles<TN>(act, pitch, PK, wave, lane);
-#endif
     __syncthreads();
     RG_BSTAMP(6 + 4 * (L - 1 - l));
   }

@@ -380,34 +380,13 @@ __device__ __forceinline__ int k_rotation(int wg, int wave, int KC) { return (wg
 // (Hoisting the ring fill of a layer ahead of the previous epilogue / the input-tile load was
 // measured with profiles/microbench/fwd_phases: the epilogues got 1.2k cycles slower each and the
 // main loops no faster, so the fill stays at the top of the main loop.)
-// RG_ACC_AGPR (experiment, off): the main loop's accumulators pinned to AccVGPRs.  profiles/microbench/mfma_feed measured
-// this loop ALONE at 0.51-0.52 of the nominal peak with them against 0.42-0.44 with the accumulators in arch VGPRs (where
-// the register allocator keeps them for kernels that fit 256 registers).  The MFMA is opaque inline asm then, so the
-// hazard recognizer does not see it: mfma_drain() supplies the wait states an MFMA result needs before a VALU /
-// v_accvgpr_read may read it (18 for the 16-pass 32x32 MFMA).
-// Round 3 in the product kernels (numerics tests green; profiles/microbench/out/r03e/fwd_phases*.txt, same box): the
-// 512-wide kernels are left 128 arch registers — 20 (forward) / 14 (backward) values spill to scratch, every
-// accumulator passes through a copy on its way to the VALU — and every phase got SLOWER, the main loop included
-// (K = 512 loop 18.4k -> 19.8k ticks, pack 3.6k -> 4.4k, LDS store 2.5k -> 3.5k, output layer 8.7k -> 13.0k; forward
-// 83.5 -> 100 us in the step).  The gain of the isolated loop does not survive the epilogues' register needs.
-// with the accumulators in AccVGPRs every value passes through an arch VGPR on its way to the VALU: the epilogues
-// then take one accumulator tile at a time (no overlap of a tile's copies with its neighbour's arithmetic), which
-// keeps the arch side under its 128 registers
-#ifdef RG_ACC_AGPR
-#define RG_TILE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define RG_TILE_FENCE() ((void)0)
-#endif
-#ifdef RG_ACC_AGPR
-__device__ __forceinline__ f32x16 mfma_main(u16x8 a, u16x8 b, f32x16 c) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  return c;
-}
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); }
-#else
+// Accumulators pinned to AccVGPRs (RG_ACC_AGPR, rounds 3 and 6) are gone from this file.  The experiment rested on
+// profiles/microbench/mfma_feed showing this loop ALONE 19-22 % faster with them; round 6 found that micro-benchmark's arch-VGPR
+// variant compiled to 660-692 bytes of scratch per lane (its K is a compile-time constant, the fully unrolled loop parked every
+// chunk's address in VGPRs) — spill-free both forms run at 0.50 of the nominal peak.  In these kernels (no scratch, run-time K)
+// the AccVGPR form measured slower both times: 20 / 14 cold spills out of the 128 arch registers it leaves, a copy per
+// accumulator on its way to the VALU, forward 78.9 -> 91.4 us (profiles/NOTES_r06.md §5, §9).
 __device__ __forceinline__ f32x16 mfma_main(u16x8 a, u16x8 b, f32x16 c) { return mfma_32x32x16_bf16(a, b, c); }
-__device__ __forceinline__ void mfma_drain() {}
-#endif
 
 // SWAP: the MFMA takes the WEIGHT fragment as its A operand and the activation fragment as B (the two fragment layouts are
 // the same registers: lane = row / column index, 8 consecutive k) — the accumulator tile is then the TRANSPOSE: lane =
@@ -441,12 +420,11 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
   if (KC % RING == 0) {
     // fast path: no conditionals around the loads in the steady state, so the compiler keeps exact
     // s_waitcnt vmcnt(N)/lgkmcnt(N) counts and (RING-1)*TN weight loads stay in flight.
-    // Round 2 (profiles/microbench/mfma_feed.hip, this loop without epilogues or barriers, random data, whole
-    // chip): MFMAs fed from registers only 0.62-0.66 of the nominal 2.5 PFLOP/s (0.84 per CU when only 64 CUs
-    // run: the chip clocks down under dense MFMA load on real data), + A fragments from LDS 0.54, + B
-    // fragments from L2 0.39 with RING = 4, 0.42-0.45 with RING = 2 (a deeper ring only lengthens the L2
-    // queues); in the step RING = 2 measured 168-171 us for the two non-saving forwards against 173-179 with
-    // RING = 4 (same box), so 2 is the default for the 8-wave kernels.
+    // profiles/microbench/mfma_feed.hip (this loop without epilogues or barriers, random data, whole chip; round 6's spill-free
+    // build — the L2-fed modes of rounds 2-5 carried 660-692 bytes of scratch per lane and read 0.39-0.45): MFMAs fed from
+    // registers only 0.65-0.71 of the nominal 2.5 PFLOP/s (the chip clocks down under dense MFMA load), + A fragments from LDS
+    // 0.60-0.65, + B fragments from L2 with RING = 2 0.50-0.51.  In the step RING = 2 measured 168-171 us for the two
+    // non-saving forwards against 173-179 with RING = 4 (same box), so 2 is the default for the 8-wave kernels.
     // Measured alternatives (profiles/microbench/fwd_phases, K=512 main loop, cycles of the early /
     // late wave of a SIMD): this loop 12.5k / 20.3k; RING=8 13.4k / 21.1k; rotation per block of 4
     // chunks with all addresses as immediates (a quarter of the scalar instructions) 16.4k / 22.9k;
@@ -485,7 +463,6 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
       mma(a[s & 1], b[s]);
       sched_fence();
     }
-    mfma_drain();
     return;
   }
   // generic K: same ring with guarded loads
@@ -505,7 +482,6 @@ __device__ __forceinline__ void wide_mainloop(const bf16_t* act, int pitch, int 
       }
     }
   }
-  mfma_drain();
 }
 
 // acc += A . B for one MORE segment of a boundary tile of a grouped layer (the first segment went through wide_mainloop):
@@ -528,7 +504,6 @@ __device__ __forceinline__ void segment_accumulate(const bf16_t* act, int pitch,
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_main(af[tm], bf[tn], acc[tm][tn]);
   }
-  mfma_drain();
 }
 
 // Thin output layer (<= 16 outputs: DQN's Q-values, a critic's scalar) with its weights resident in LDS.  Every workgroup
@@ -674,7 +649,6 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
     static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
       constexpr int tm = decltype(tm_c)::value;
       float v[16];
-      RG_TILE_FENCE();
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
       pack_tile(v, PK[tm][tn]);
@@ -689,49 +663,6 @@ __device__ __forceinline__ void fwd_hidden_pack(f32x16 (&acc)[4][TN], const floa
       if constexpr (TN == 2 && RG_SIGN_STORE16) {
         // a lane's four sign words (two per column tile) are contiguous: ONE 16-byte store per lane and layer — 1 KB per wave
         // instruction — instead of two 8-byte ones at a lane stride of 16 bytes
-        if constexpr (tn == 0) { sg_prev0 = sg0; sg_prev1 = sg1; }
-        else *(u32x4*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)) = u32x4{sg_prev0, sg_prev1, sg0, sg1};
-      } else {
-        ((u32x2*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)))[tn] = u32x2{sg0, sg1};
-      }
-    }
-  });
-}
-
-// RG_ACC_AGPR form of the hidden layer's epilogue (round 6): the accumulators live in AccVGPRs, which nothing else wants, so they
-// may simply WAIT for the barrier that protects the in-place tile — PACK and the LDS store then run tile by tile AFTER it, a
-// tile's eight packed words alive for a few instructions instead of all 64 (x TN) across the barrier.  That is what lets the
-// 512-wide kernel live in the 128 arch registers AccVGPR accumulators leave it (round 3's attempt kept the two-phase epilogue
-// and spilled 20 values).  Same values, same stores as fwd_hidden_pack + store_packed_tiles.
-template <int TN, int ACT>
-__device__ __forceinline__ void fwd_hidden_pack_store(f32x16 (&acc)[4][TN], const float* bias, bf16_t* save_dst, unsigned* sign_dst,
-                                                      int NT, int mb_base, int wave, int lane, bf16_t* act, int pitch) {
-  lane = opaque(lane);
-  const int lr = lane & 31;
-  unsigned sg_prev0 = 0u, sg_prev1 = 0u;
-  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
-    constexpr int tn = decltype(tn_c)::value;
-    const int nt = wave * TN + tn, col = nt * 32 + lr;
-    const float b = bias ? bias[col] : 0.f;
-    unsigned sg0 = 0u, sg1 = 0u;
-    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
-      constexpr int tm = decltype(tm_c)::value;
-      float v[16];
-      unsigned P[8];
-      RG_TILE_FENCE();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = act_t<ACT>(acc[tm][tn][r] + b);
-      pack_tile(v, P);
-      if (save_dst) store_packed_frags(save_dst, mb_base + tm, nt, NT, lane, P);
-      if (act_is_sign_based<ACT>() && sign_dst) {
-        const unsigned bits = positive_bits<ACT == ACT_RELU>(v);
-        if (tm < 2) sg0 |= bits << ((tm & 1) * 16);
-        else sg1 |= bits << ((tm & 1) * 16);
-      }
-      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
-    });
-    if (act_is_sign_based<ACT>() && sign_dst) {
-      if constexpr (TN == 2 && RG_SIGN_STORE16) {
         if constexpr (tn == 0) { sg_prev0 = sg0; sg_prev1 = sg1; }
         else *(u32x4*)(sign_dst + sign_offset(mb_base >> 2, wave, lane, TN, NT * 32)) = u32x4{sg_prev0, sg_prev1, sg0, sg1};
       } else {
@@ -804,7 +735,6 @@ __device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16
     static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
       constexpr int tm = decltype(tm_c)::value;
       float v[16];
-      RG_TILE_FENCE();
       if (USE_SIGN && act_is_sign_based<ACT>()) {
         const unsigned bits = sg[tn * 2 + (tm >> 1)] >> ((tm & 1) * 16);
 #pragma unroll
@@ -828,50 +758,6 @@ __device__ __forceinline__ void bwd_hidden_pack(f32x16 (&acc)[4][TN], const bf16
       if (STORE_DZ) store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, PK[tm][tn]);
       else pin_packed(PK[tm][tn]);  // the stores force the bf16 packing here; without them the compiler keeps all
                                     // eight tiles in fp32 until the LDS pass after the barrier and spills 497 registers
-    });
-    colsum += shfl_xor(colsum, 32);
-    if (db_part && lane < 32) db_part[col] = colsum;
-  });
-}
-
-// RG_ACC_AGPR form of the backward epilogue (see fwd_hidden_pack_store): after the barrier, tile by tile, straight into the dZ tile
-template <int TN, int ACT, bool USE_SIGN, bool STORE_DZ = true>
-__device__ __forceinline__ void bwd_hidden_pack_store(f32x16 (&acc)[4][TN], const bf16_t* h_frag, const unsigned (&sg)[2 * TN],
-                                                      bf16_t* dz_dst, float* db_part, int NT, int mb_base, int wave, int lane,
-                                                      bf16_t* act, int pitch) {
-  lane = opaque(lane);
-  const int lr = lane & 31;
-  static_for<0, TN>([&](auto tn_c) __attribute__((always_inline)) {
-    constexpr int tn = decltype(tn_c)::value;
-    const int nt = wave * TN + tn, col = nt * 32 + lr;
-    float colsum = 0.f;
-    static_for<0, 4>([&](auto tm_c) __attribute__((always_inline)) {
-      constexpr int tm = decltype(tm_c)::value;
-      float v[16];
-      unsigned P[8];
-      RG_TILE_FENCE();
-      if (USE_SIGN && act_is_sign_based<ACT>()) {
-        const unsigned bits = sg[tn * 2 + (tm >> 1)] >> ((tm & 1) * 16);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float g = ((bits >> r) & 1u) ? 1.f : (ACT == ACT_RELU ? 0.f : 0.01f);
-          v[r] = acc[tm][tn][r] * g;
-          colsum += v[r];
-        }
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const u16x8 hf = *(const u16x8*)(h_frag + frag_offset(mb_base + tm, nt, NT, h, lane));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[8 * h + e] = acc[tm][tn][8 * h + e] * act_grad_t<ACT>(bf16_to_f32(hf[e]));
-            colsum += v[8 * h + e];
-          }
-        }
-      }
-      pack_tile(v, P);
-      if (STORE_DZ) store_packed_frags(dz_dst, mb_base + tm, nt, NT, lane, P);
-      store_packed_to_lds(act, pitch, tm * 32, col, lane, P);
     });
     colsum += shfl_xor(colsum, 32);
     if (db_part && lane < 32) db_part[col] = colsum;
