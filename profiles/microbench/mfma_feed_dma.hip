@@ -90,6 +90,33 @@ __global__ void __launch_bounds__(NW * 64, 1) feed(const unsigned short* __restr
         }
       }
     }
+  } else if constexpr (VARIANT == 3) {
+    // variant 3: the register ring at depth NS (the product's RING): weight fragments NS - 1 chunks ahead, A one chunk ahead
+    u16x8 br[NS][TN];
+    auto loadBr = [&](u16x8 (&bf)[TN], int kc) {
+      const unsigned short* chunk = wf_wave + (long)kx(kc) * 512;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bf[tn] = *(const u16x8*)(chunk + tn * nt_stride + lane * 8);
+    };
+    for (int l = 0; l < layers; ++l) {
+#pragma unroll
+      for (int s = 0; s < NS - 1; ++s) loadBr(br[s], s);
+      loadA(a[0], 0);
+#pragma unroll 1
+      for (int kc = 0; kc < KC; kc += NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          if (kc + s + NS - 1 < KC) loadBr(br[(s + NS - 1) % NS], kc + s + NS - 1);
+          if (kc + s + 1 < KC) loadA(a[(s + 1) & 1], kc + s + 1);
+          sched_fence();
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(a[s & 1][tm], br[s][tn], acc[tm][tn]);
+          sched_fence();
+        }
+      }
+    }
   } else {
     // fragment f of the whole run: layer f / FRAGS, chunk (f % FRAGS) / TN, column tile f % TN
     char* ring = smem + (size_t)AROWS * PITCH * 2 + (size_t)wave * NS * 1024;
@@ -194,6 +221,9 @@ int main() {
   run<2, 16, 128>("  buffer loads, sc1 (L2-served, no L1 allocation)", wf, out, sums, 512);
   run<2, 17, 128>("  buffer loads, sc0 sc1", wf, out, sums, 512);
   run<2, 18, 128>("  buffer loads, sc1 nt", wf, out, sums, 512);
+  run<0, 1, 128>("A from LDS + B L2 -> VGPR ring 2 (again)", wf, out, sums, 512);
+  run<3, 2, 128>("  register ring, depth 2 (generic form)", wf, out, sums, 512);
+  run<3, 4, 128>("  register ring, depth 4", wf, out, sums, 512);
   run<0, 1, 128>("A from LDS + B L2 -> VGPR ring 2 (again)", wf, out, sums, 512);
   run<1, 3, 128>("A from LDS + B L2 -> LDS-DMA ring of 3 slots per wave (fits the product)", wf, out, sums, 512);
   run<0, 1, 128>("A from LDS + B L2 -> VGPR ring 2 (again)", wf, out, sums, 512);
