@@ -90,6 +90,30 @@ __global__ void __launch_bounds__(NW * 64, 1) feed(const unsigned short* __restr
         }
       }
     }
+  } else if constexpr (VARIANT == 4 || VARIANT == 5) {
+    // variant 4: A from LDS every chunk, the two B fragments loaded once; variant 5: nothing reloaded (MFMAs from registers)
+    {
+      const unsigned short* chunk = wf_wave + (long)kx(0) * 512;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[0][tn] = *(const u16x8*)(chunk + tn * nt_stride + lane * 8);
+    }
+    loadA(a[0], 0);
+    loadA(a[1], 1);
+    for (int l = 0; l < layers; ++l) {
+#pragma unroll 1
+      for (int kc = 0; kc < KC; kc += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (VARIANT == 4 && kc + s + 1 < KC) loadA(a[(s + 1) & 1], kc + s + 1);
+          sched_fence();
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma_32x32x16_bf16(a[s & 1][tm], b[0][tn], acc[tm][tn]);
+          sched_fence();
+        }
+      }
+    }
   } else if constexpr (VARIANT == 3) {
     // variant 3: the register ring at depth NS (the product's RING): weight fragments NS - 1 chunks ahead, A one chunk ahead
     u16x8 br[NS][TN];
@@ -168,6 +192,7 @@ __global__ void __launch_bounds__(NW * 64, 1) feed(const unsigned short* __restr
 }
 
 static std::vector<float> g_ref;
+static int g_long = 0;  // argv[2]: repetitions of the timed loop (default 40); telemetry runs use a few thousand
 
 template <int VARIANT, int NS, int AROWS>
 void run(const char* what, const unsigned short* wf, float* out, float* sums, int grid) {
@@ -184,7 +209,8 @@ void run(const char* what, const unsigned short* wf, float* out, float* sums, in
   if (AROWS == 128) {
     if (VARIANT == 0 && g_ref.empty()) g_ref = h;
     if (VARIANT == 0) check = "reference";
-    if (VARIANT != 0) check = (g_ref.size() == h.size() && memcmp(g_ref.data(), h.data(), h.size() * 4) == 0) ? "checksums == variant 0" : "CHECKSUMS DIFFER";
+    if (VARIANT != 0 && VARIANT < 4 && g_ref.empty()) check = "(no reference in this run)";
+    else if (VARIANT != 0 && VARIANT < 4) check = (g_ref.size() == h.size() && memcmp(g_ref.data(), h.data(), h.size() * 4) == 0) ? "checksums == variant 0" : "CHECKSUMS DIFFER";
   } else {
     check = "(64-row tile: no check)";
   }
@@ -193,7 +219,7 @@ void run(const char* what, const unsigned short* wf, float* out, float* sums, in
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   hipEventRecord(e0);
-  const int reps = 40;
+  const int reps = g_long > 0 ? g_long : 40;
   for (int r = 0; r < reps; ++r) k<<<grid, NW * 64, lds>>>(wf, out, sums, layers);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
@@ -205,7 +231,9 @@ void run(const char* what, const unsigned short* wf, float* out, float* sums, in
          check, (int)hipGetLastError());
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int only = argc > 1 ? atoi(argv[1]) : -1;  // -1 = every variant; 0..3 = one of the four below, for clock / power sampling
+  g_long = argc > 2 ? atoi(argv[2]) : 0;
   float *out, *sums;
   hipMalloc(&out, 4);
   hipMalloc(&sums, (size_t)512 * NW * 4);
@@ -215,6 +243,13 @@ int main() {
   unsigned short* wf;
   hipMalloc(&wf, n * 2);
   hipMemcpy(wf, h.data(), n * 2, hipMemcpyHostToDevice);
+  if (only >= 0) {
+    if (only == 0) run<0, 1, 128>("A from LDS + B L2 -> VGPR ring 2 (the product's loop)", wf, out, sums, 512);
+    if (only == 1) run<4, 1, 128>("A from LDS only (B fragments stay in registers)", wf, out, sums, 512);
+    if (only == 2) run<5, 1, 128>("registers only", wf, out, sums, 512);
+    if (only == 3) run<1, 3, 128>("A from LDS + B L2 -> LDS-DMA ring of 3 slots per wave", wf, out, sums, 512);
+    return 0;
+  }
   run<0, 1, 128>("A from LDS + B L2 -> VGPR ring 2 (the product's loop)", wf, out, sums, 512);
   run<2, 0, 128>("  the same by raw buffer loads, default policy", wf, out, sums, 512);
   run<2, 2, 128>("  buffer loads, nt", wf, out, sums, 512);
