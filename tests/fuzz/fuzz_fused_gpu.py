@@ -1,0 +1,120 @@
+"""TEST INFRASTRUCTURE — the fused stacks on the REAL library (MI355X), random shapes:  python tests/fuzz/fuzz_fused_gpu.py [seed] [cases]
+
+The interpreter fuzzers (fuzz_fused.py, fuzz_fused_x3.py) check index arithmetic; what only the hardware can show — a missing
+barrier, a miscounted s_waitcnt, an LDS-DMA landing late — would appear as run-to-run differences or as errors at sizes where
+every CU runs several workgroups back to back.  Per case: a bf16 or split-bf16 stack (hidden 256 / 512, random input and output
+widths, random activations), a batch that gives the launch 1 .. 5 rounds of workgroups on 256 CUs plus a ragged tail;
+forward (saving), backward with input gradient, weight gradient — run TWICE on the same inputs and compared BIT FOR BIT, then
+against the float64 statement of tests/test_fused_mlp.py (bf16: rounding at the kernels' points, 0.5 %; split-bf16: the exact
+float64 result — outputs fp32-class, gradients 1e-4 plus the allowance for derivative-branch flips fuzz_fused_x3.py explains)."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+
+import reagent_amd._lib as L
+from reagent_amd.engine import FusedMLP, make_stack
+import test_fused_mlp as T
+
+assert torch.cuda.is_available(), "this fuzzer needs the MI355X (the interpreter fuzzers are fuzz_fused.py / fuzz_fused_x3.py)"
+dev = torch.device("cuda", 0)
+random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+
+
+def exact64(ws, bs, acts, x, dout):
+    W = [w.detach().cpu().double() for w in ws]
+    Bv = [b.detach().cpu().double() for b in bs]
+    hs = [x.cpu().double()]
+    for w, b, a in zip(W, Bv, acts):
+        hs.append(T.ACTS[a](hs[-1] @ w.t() + b))
+    dz = dout.cpu().double()
+    dws, dbs = [None] * len(W), [None] * len(W)
+    for l in range(len(W) - 1, -1, -1):
+        dws[l], dbs[l] = dz.t() @ hs[l], dz.sum(0)
+        dh = dz @ W[l]
+        if l > 0:
+            dz = dh * T.DACT[acts[l - 1]](hs[l])
+    return hs[-1], dws, dbs, dh
+
+
+def run(st, x, dout, ws, bs, dims, batch):
+    out = torch.zeros(batch, dims[-1], device=dev)
+    xc, xt = st.stage_input(x, True)
+    st.forward(xc, out, save=True)
+    dw = [torch.zeros_like(w) for w in ws]
+    db = [torch.zeros_like(b) for b in bs]
+    dx = torch.zeros(batch, dims[0], device=dev)
+    st.backward(dout, xt, dw, db, dx32=dx)
+    torch.cuda.synchronize()
+    return out, dw, db, dx
+
+
+bad = 0
+for case in range(n_cases):
+    x3 = random.random() < 0.4
+    H = random.choice([256, 512])
+    nl = random.choice([2, 3, 4]) if H == 256 else random.choice([2, 3])
+    dims = [random.choice([random.randint(1, 512), 128, 256, 288])] + [H] * nl + [random.choice([1, 2, 16, random.randint(1, 200)])]
+    acts = [random.choice(["relu", "relu", "leaky_relu", "tanh"]) for _ in range(nl)] + ["linear"]
+    rows_per_wg = 64 if x3 else 128
+    batch = rows_per_wg * 256 * random.randint(0, 4) + random.choice([0, 1, rows_per_wg - 1, rows_per_wg * 100 + 17, rows_per_wg * 256 - 3])
+    batch = max(batch, 1)
+    ws, bs = T._net(dims, acts, 1000 + case, dev)
+    codes = [L.ACT[a] for a in acts]
+    prec = L.PREC_BF16X3 if x3 else L.PREC_BF16
+    if not FusedMLP.supported(ws, codes):
+        print("unsupported", dims)
+        continue
+    st = make_stack(ws, bs, codes, prec)
+    if not isinstance(st, FusedMLP):
+        print("not fused", dims, "x3" if x3 else "bf16")
+        continue
+    st.set_need_input_grad(True)
+    st.stage_weights(need_transposed=True)
+    g = torch.Generator().manual_seed(case)
+    x = torch.randn(batch, dims[0], generator=g).to(dev)
+    dout = (torch.randn(batch, dims[-1], generator=g) / batch).to(dev)
+    r1 = run(st, x, dout, ws, bs, dims, batch)
+    r2 = run(st, x, dout, ws, bs, dims, batch)
+    same = torch.equal(r1[0], r2[0]) and torch.equal(r1[3], r2[3]) and all(torch.equal(a, b) for a, b in zip(r1[1], r2[1])) and \
+        all(torch.equal(a, b) for a, b in zip(r1[2], r2[2]))
+    out, dw, db, dx = r1
+    if x3:
+        ro, rdw, rdb, rdx = exact64(ws, bs, acts, x, dout)
+        # the criterion of fuzz_fused_x3.py: the OUTPUT is fp32-class (3e-5); a ReLU / leaky-ReLU unit whose pre-activation lies
+        # inside the split-bf16 noise (~2e-5 of the mean magnitude) may take the other branch of the derivative than float64
+        # does, and each such unit moves its layer's dZ by ~sqrt(2 / (B H)) of its norm — counted and allowed for
+        hd, flips = x.cpu().double(), 0
+        for w, b, a in zip(ws[:-1], bs[:-1], acts[:-1]):
+            z = hd @ w.detach().cpu().double().t() + b.detach().cpu().double()
+            if a in ("relu", "leaky_relu"):
+                flips += int((z.abs() < 2e-5 * z.abs().mean()).sum())
+            hd = T.ACTS[a](z)
+        tol = 1e-4 + 3 * (2 * flips / (batch * H)) ** 0.5
+        # float32 torch on the same case is the yardstick of "fp32-class" (one output value of a deep ReLU stack can cancel)
+        h32 = x
+        for w, b, a in zip(ws, bs, acts):
+            h32 = T.ACTS[a](h32 @ w.detach().t() + b.detach())
+        out_tol = max(5e-5, 30 * T._rel(h32, ro))
+    else:
+        ro, rdw, rdb, rdx = T._ref(ws, bs, acts, x, dout)
+        tol, out_tol, flips = 5e-3, 5e-3, 0
+    errs = [T._rel(out, ro)] + [T._rel(a, b) for a, b in zip(dw, rdw)] + [T._rel(a, b) for a, b in zip(db, rdb)] + [T._rel(dx, rdx)]
+    abs_out = (out.double().cpu() - ro).abs().max().item()
+    # (split-bf16: north_star's clause is ABSOLUTE — outputs within 1e-4; a batch of one row is one number, and its relative error is that number's)
+    ok = same and (errs[0] < out_tol or (x3 and abs_out <= 1e-4)) and max(errs[1:]) < tol
+    # a ReLU mask flipped by a rounding tie moves a whole row of dZ: rare, small batches feel it most
+    if not ok and same and not x3 and max(errs) < 3e-2 and batch < 64:
+        ok = True
+    bad += 0 if ok else 1
+    print(("OK " if ok else "BAD"), "x3  " if x3 else "bf16", dims, acts, batch, "repeat " + ("identical" if same else "DIFFERS"),
+          "out %.1e (abs %.1e), max rel err %.1e (allowed %.1e%s)" % (errs[0], abs_out, max(errs), tol, ", %d borderline units" % flips if x3 else ""), flush=True)
+    del st, ws, bs, x, dout, r1, r2
+    torch.cuda.empty_cache()
+print("bad cases:", bad)
+sys.exit(1 if bad else 0)
