@@ -1,11 +1,10 @@
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT + "/tests/fuzz")
 import torch
 import torch.distributions as pyd
 import torch.nn.functional as F
-import emu_backend
-emu_backend.install()
-from reagent_amd import ops
+import gpu_ops  # FUZZ_ON_GPU=1: the real library on cuda:0 instead of the interpreter
+ops = gpu_ops.select()
 
 # the discrete-CRR heads on random (batch, actions): critic targets under softmax(actor(s')) with the twin minimum, both
 # critics' losses and gradients; the actor's clamped exp-advantage weight, the clipped importance-ratio entropy term and
@@ -40,9 +39,17 @@ for case in range(cases):
                         dq1, dq2 if twin else None, p1, p2 if twin else None)
     sc = max(1.0, target.abs().max().item())
     ok = bool((D(tgt) - target.squeeze(1)).abs().max() <= 3e-6 * sc) and abs(p1.sum().item() / B - l1.item()) <= 2e-5 * max(1.0, l1.item())
-    ok &= bool((D(dq1) - q1r.grad).abs().max() <= 3e-6 * sc / B + 1e-9)
+    # d loss / d q = 2 (q_sel - target) / B in fp32: the rounding scales with |q| + |target|, not with the target alone (seed 11's
+    # last case: |q| up to 20 against targets below 1 — 1.4e-8 where 3e-6 * sc / B allowed 1.3e-8)
+    scq = sc + max(q1.abs().max().item(), q2.abs().max().item())
+    ok &= bool((D(dq1) - q1r.grad).abs().max() <= 3e-6 * scq / B + 1e-9)
     if twin:
-        ok &= abs(p2.sum().item() / B - l2.item()) <= 2e-5 * max(1.0, l2.item()) and bool((D(dq2) - q2r.grad).abs().max() <= 3e-6 * sc / B + 1e-9)
+        ok &= abs(p2.sum().item() / B - l2.item()) <= 2e-5 * max(1.0, l2.item()) and bool((D(dq2) - q2r.grad).abs().max() <= 3e-6 * scq / B + 1e-9)
+    if not ok:  # which of the critic checks
+        print("   critic: tgt err %.2e (allowed %.2e) | loss1 %.8f vs %.8f | dq1 err %.2e (allowed %.2e)%s" % (
+            (D(tgt) - target.squeeze(1)).abs().max().item(), 3e-6 * sc, p1.sum().item() / B, l1.item(),
+            (D(dq1) - q1r.grad).abs().max().item(), 3e-6 * scq / B + 1e-9,
+            " | loss2 %.8f vs %.8f | dq2 err %.2e" % (p2.sum().item() / B, l2.item(), (D(dq2) - q2r.grad).abs().max().item()) if twin else ""))
     # ---- actor head
     beta, max_weight = random.choice([0.3, 0.6, 2.0]), random.choice([1.5, 2.5, 20.0])
     entropy_coeff, clip_limit = random.choice([0.0, 0.3]), random.choice([1.5, 10.0])

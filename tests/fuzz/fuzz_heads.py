@@ -1,11 +1,10 @@
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT + "/tests/fuzz")
 import torch
 import torch.nn.functional as F
-import emu_backend
-emu_backend.install()
+import gpu_ops  # FUZZ_ON_GPU=1: the real library on cuda:0 instead of the interpreter
+ops = gpu_ops.select()
 import reagent_amd._lib as L
-from reagent_amd import ops
 
 # rg_dqn_head on random shapes (batch sizes around the workgroup size, 1 .. 100 actions, masks with rows that allow a single
 # action, terminal rows, n-step discount exponents, reward boosts, both losses, double-Q on / off) against the reference's

@@ -2,8 +2,8 @@ import os, sys, random
 from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import torch
-import emu_backend
-emu_backend.install()
+import gpu_ops  # FUZZ_ON_GPU=1: the real library on cuda instead of the interpreter
+DEV = gpu_ops.device()
 from oracle import restated as R
 from reagent_amd.core.parameters import NormalizationParameters as NP
 from reagent_amd.preprocessing import Preprocessor
@@ -54,9 +54,9 @@ for case in range(cases):
             if random.random() < 0.3:
                 x[r, j] = random.choice(special[f])
     presence = (torch.rand(B, nf, generator=g) < 0.85).to(torch.uint8)
-    pre = Preprocessor(norm, device="cpu")
+    pre = Preprocessor(norm, device=DEV)
     assert pre.sorted_features == order
-    got = pre(x, presence)
+    got = pre(x.to(DEV), presence.to(DEV)).cpu()
     want = R.preprocess(norm, x, presence)
     both_nan = torch.isnan(got) & torch.isnan(want)
     diff = torch.where(both_nan, torch.zeros(()), (got - want).abs())

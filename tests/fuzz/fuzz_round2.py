@@ -1,11 +1,10 @@
 import sys, random
-ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT + "/tests/fuzz")
 import numpy as np
 import torch
-import emu_backend
-emu_backend.install()
+import gpu_ops  # FUZZ_ON_GPU=1: the real library on cuda:0 instead of the interpreter
+ops = gpu_ops.select()
 import reagent_amd._lib as L
-from reagent_amd import ops
 
 # random shapes through the round-2 kernels: layer norm (forward / backward), ragged gather, dueling combine / split,
 # the policy input maker, the SAC KLD term — each against torch on the same inputs

@@ -1,8 +1,8 @@
 import sys, random
 ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, torch
-import emu_backend
-emu_backend.install()
+import gpu_ops  # FUZZ_ON_GPU=1: the real library on cuda instead of the interpreter
+DEV = gpu_ops.device()
 from reagent_amd.core.parameters import NormalizationParameters as NP
 from reagent_amd.preprocessing import DiscreteDqnInputMaker, Preprocessor
 from reagent_amd.replay_memory import ReplayBuffer
@@ -15,7 +15,7 @@ for case in range(20):
     cap = random.randint(H + 40, 300); n = random.randint(H + 5, cap + 50); B = random.choice([1, 5, 63, 64, 65, 130])
     with_mask = random.random() < 0.5; norm = random.random() < 0.6
     dt = torch.bfloat16 if (norm and random.random() < 0.5) else torch.float32
-    rb = ReplayBuffer(device="cpu", stack_size=1, replay_capacity=cap, batch_size=B, update_horizon=H, gamma=0.93)
+    rb = ReplayBuffer(device=DEV, stack_size=1, replay_capacity=cap, batch_size=B, update_horizon=H, gamma=0.93)
     rng = np.random.RandomState(case)
     for i in range(n):
         kw = dict(observation=rng.randn(F).astype(np.float32), action=np.int64(rng.randint(A)), reward=np.float32(rng.rand()),
@@ -23,7 +23,7 @@ for case in range(20):
         if with_mask: kw["possible_actions_mask"] = (rng.rand(A) > 0.3).astype(np.float32)
         rb.add(**kw)
     if rb.size == 0: continue
-    pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=0.1 * (i % 5), stddev=1.0 + 0.1 * (i % 3)) for i in range(F)}, device="cpu") if norm else None
+    pre = Preprocessor({i: NP(feature_type="CONTINUOUS", mean=0.1 * (i % 5), stddev=1.0 + 0.1 * (i % 3)) for i in range(F)}, device=DEV) if norm else None
     idx = rb.sample_index_batch(B)
     fused = rb.sample_dqn_input(A, B, indices=idx, state_preprocessor=pre, state_dtype=dt if norm else None)
     tup = rb.sample_transition_batch(B, indices=idx, state_preprocessor=pre, state_dtype=dt if norm else None)
