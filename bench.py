@@ -1192,6 +1192,8 @@ def main(device=None, backend="nccl"):
         relaunch_under_torchrun(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world > 1:  # before this process's first device touch: dmabuf IPC, the only form this pool's host driver supports for RCCL
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
