@@ -7,7 +7,7 @@ python - $D <<'PY'
 import csv, sys, glob, re
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-first = "replay_dqn_batch" if any("replay_dqn_batch" in r["Kernel_Name"] for r in rows) else "replay_nstep"
+first = next((k for k in ("replay_dqn_batch", "replay_policy_batch", "replay_nstep") if any(k in r["Kernel_Name"] for r in rows)), "replay_nstep")
 idx = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])

@@ -120,6 +120,11 @@ class GroupedQR:
         self._B = -1
         self._side = None
         self.two_streams = os.environ.get("RG_QR_STREAMS", "1") != "0"  # the forward's two halves on two streams
+        # the native step's loss sum rides in the reduce launch of the trunk's weight gradient (round 6; 0 = on the weight gradients'
+        # side stream under the backward launch, rounds 4-5: one more fork of the main stream — a ~7 us marker gap — and a launch
+        # that waited 60 us for CUs in front of the side stream's weight gradient: same box C3 0.8095 / 0.8002 / 0.8094 ->
+        # 0.7752 / 0.7747 / 0.7756 ms, split-bf16 1.4777 / 1.4643 -> 1.4483 / 1.4481)
+        self.loss_in_reduce = os.environ.get("RG_QR_LOSS_IN_REDUCE", "1") != "0"
         self.wgrad_streams = os.environ.get("RG_QR_WGRAD_STREAMS", "1") != "0"  # the backward's two weight-gradient launches
         self.dense = os.environ.get("RG_QR_DENSE", "1") != "0"  # grouped spaces without per-group padding (GroupedSpace)
 
@@ -228,10 +233,10 @@ class GroupedQR:
                             tr._f32c(b.not_terminal).reshape(-1), tr.gamma, gamma_exp, tr.quantiles.reshape(-1), B, self.N,
                             self.dz, self.loss_partials)
         # the rows' loss terms (padding rows: 0) summed in fixed order.  Nothing on the device waits for the loss, so in the native
-        # step the sum leaves the critical path: on the weight gradients' side stream, under the backward launch (joined where
-        # fused_backward_grouped joins that stream) — or, without it, in the reduce launch of the trunk's weight gradient.
+        # step the sum leaves the critical path: in the reduce launch of the trunk's weight gradient (loss_in_reduce, the default)
+        # — or on the weight gradients' side stream, under the backward launch (joined where fused_backward_grouped joins it).
         # (Rounds 2-3: per-tile sums + their sum, two launch-bound launches = 13 us between the loss head and the backward.)
-        if getattr(tr, "_loss_tail_wanted", False) and state.is_cuda and self.wgrad_streams:
+        if getattr(tr, "_loss_tail_wanted", False) and state.is_cuda and self.wgrad_streams and not self.loss_in_reduce:
             from .engine import side_stream
 
             side = side_stream(dev)
