@@ -42,14 +42,32 @@ def exact64(ws, bs, acts, x, dout):
     return hs[-1], dws, dbs, dh
 
 
-def run(st, x, dout, ws, bs, dims, batch):
+def run(st, x, dout, ws, bs, dims, batch, mode="plain", split=0, state_bf16=False):
+    """mode "plain": one input matrix, full backward.  "critic": the input as two panels (state [batch, split] — fp32 or the
+    sampler's bf16 rows — and action fp32, FullyConnectedCritic's cat read in place), full backward, input gradient of the action
+    columns only.  "frozen": the same forward saved for a dx-only backward (SAC's actor step through the critics): no weight
+    gradient, no dZ fragments."""
+    from reagent_amd.engine import SAVE_FOR_DX
+
     out = torch.zeros(batch, dims[-1], device=dev)
-    xc, xt = st.stage_input(x, True)
-    st.forward(xc, out, save=True)
     dw = [torch.zeros_like(w) for w in ws]
     db = [torch.zeros_like(b) for b in bs]
-    dx = torch.zeros(batch, dims[0], device=dev)
-    st.backward(dout, xt, dw, db, dx32=dx)
+    if mode == "plain":
+        xc, xt = st.stage_input(x, True)
+        st.forward(xc, out, save=True)
+        dx = torch.zeros(batch, dims[0], device=dev)
+        st.backward(dout, xt, dw, db, dx32=dx)
+    else:
+        xs = x[:, :split].contiguous()
+        xs = xs.to(torch.bfloat16) if state_bf16 else xs
+        xa = x[:, split:].contiguous()
+        dx = torch.zeros(batch, dims[0] - split, device=dev)
+        if mode == "critic":
+            st.forward(xs, out, save=True, x2=xa)
+            st.backward(dout, None, dw, db, dx32=dx, dx_col0=split)
+        else:
+            st.forward(xs, out, save=SAVE_FOR_DX, x2=xa)
+            st.backward(dout, None, None, None, dx32=dx, skip_wgrad=True, dx_col0=split)
     torch.cuda.synchronize()
     return out, dw, db, dx
 
@@ -79,8 +97,16 @@ for case in range(n_cases):
     g = torch.Generator().manual_seed(case)
     x = torch.randn(batch, dims[0], generator=g).to(dev)
     dout = (torch.randn(batch, dims[-1], generator=g) / batch).to(dev)
-    r1 = run(st, x, dout, ws, bs, dims, batch)
-    r2 = run(st, x, dout, ws, bs, dims, batch)
+    # a third of the cases with more than 32 input columns run as a critic's two-panel input, half of those frozen
+    mode, split, state_bf16 = "plain", 0, False
+    if dims[0] > 32 and random.random() < 0.35:
+        split = 32 * random.randint(1, (dims[0] - 1) // 32)
+        mode = random.choice(["critic", "frozen"])
+        state_bf16 = (not x3) and random.random() < 0.5
+        if state_bf16:  # the reference sees the rows the kernel sees
+            x[:, :split] = x[:, :split].to(torch.bfloat16).float()
+    r1 = run(st, x, dout, ws, bs, dims, batch, mode, split, state_bf16)
+    r2 = run(st, x, dout, ws, bs, dims, batch, mode, split, state_bf16)
     same = torch.equal(r1[0], r2[0]) and torch.equal(r1[3], r2[3]) and all(torch.equal(a, b) for a, b in zip(r1[1], r2[1])) and \
         all(torch.equal(a, b) for a, b in zip(r1[2], r2[2]))
     out, dw, db, dx = r1
@@ -104,7 +130,10 @@ for case in range(n_cases):
     else:
         ro, rdw, rdb, rdx = T._ref(ws, bs, acts, x, dout)
         tol, out_tol, flips = 5e-3, 5e-3, 0
-    errs = [T._rel(out, ro)] + [T._rel(a, b) for a, b in zip(dw, rdw)] + [T._rel(a, b) for a, b in zip(db, rdb)] + [T._rel(dx, rdx)]
+    if mode == "frozen":  # no weight / bias gradients were asked for
+        errs = [T._rel(out, ro), T._rel(dx, rdx[:, split:])]
+    else:
+        errs = [T._rel(out, ro)] + [T._rel(a, b) for a, b in zip(dw, rdw)] + [T._rel(a, b) for a, b in zip(db, rdb)] + [T._rel(dx, rdx[:, split:])]
     abs_out = (out.double().cpu() - ro).abs().max().item()
     # (split-bf16: north_star's clause is ABSOLUTE — outputs within 1e-4; a batch of one row is one number, and its relative error is that number's)
     ok = same and (errs[0] < out_tol or (x3 and abs_out <= 1e-4)) and max(errs[1:]) < tol
@@ -112,7 +141,7 @@ for case in range(n_cases):
     if not ok and same and not x3 and max(errs) < 3e-2 and batch < 64:
         ok = True
     bad += 0 if ok else 1
-    print(("OK " if ok else "BAD"), "x3  " if x3 else "bf16", dims, acts, batch, "repeat " + ("identical" if same else "DIFFERS"),
+    print(("OK " if ok else "BAD"), "x3  " if x3 else "bf16", mode + (" %d+%d%s" % (split, dims[0] - split, " bf16 state" if state_bf16 else "") if split else ""), dims, acts, batch, "repeat " + ("identical" if same else "DIFFERS"),
           "out %.1e (abs %.1e), max rel err %.1e (allowed %.1e%s)" % (errs[0], abs_out, max(errs), tol, ", %d borderline units" % flips if x3 else ""), flush=True)
     del st, ws, bs, x, dout, r1, r2
     torch.cuda.empty_cache()
